@@ -1,0 +1,214 @@
+"""ctypes front-end of the CPU oracle (oracle/pre3_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under 3pre_amd/ imports this package.
+
+All wrappers take/return numpy fp64 arrays; landmark tables are (lm_type, lm_off) int32 arrays
+(type 0 = inverse depth (6 params), 1 = Cartesian (3 params); lm_off = 0-based offset into x).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libpre3_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "pre3_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+class Cam(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("f", "Cx", "Cy", "k1", "k2", "nRows", "nCols")]
+
+
+def make_cam(v):
+    """v = [f, Cx, Cy, k1, k2, nRows, nCols]"""
+    return Cam(*[float(t) for t in v])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        for name in ("orc_siftmatch_f64", "orc_siftmatch_f32", "orc_siftmatch_i8", "orc_siftmatch_u8", "orc_support"):
+            getattr(_lib, name).restype = C.c_int
+    return _lib
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def landmark_table(types):
+    types = _i(types)
+    dims = np.where(types == 0, 6, 3)
+    off = 13 + np.concatenate([[0], np.cumsum(dims)[:-1]]) if len(types) else np.zeros(0)
+    return types, _i(off), int(13 + dims.sum())
+
+
+def process_noise():
+    Pn = np.zeros((7, 7))
+    lib().orc_process_noise(_p(Pn))
+    return Pn
+
+
+def predict(x, P, u):
+    x, P, u = _d(x), _d(P), _d(u)
+    n = x.shape[0]
+    xo, Po = np.empty(n), np.empty((n, n))
+    rc = lib().orc_predict(n, _p(x), _p(P), _p(u), _p(xo), _p(Po))
+    assert rc == 0
+    return xo, Po
+
+
+def project(types, off, x, cam, h=None, has_h=None):
+    N = len(types)
+    h = np.zeros((N, 2)) if h is None else _d(h).copy()
+    has_h = np.zeros(N, np.int32) if has_h is None else _i(has_h).copy()
+    c = make_cam(cam)
+    lib().orc_project(N, _p(_i(types)), _p(_i(off)), _p(_d(x)), C.byref(c), _p(h), _p(has_h))
+    return h, has_h
+
+
+def jacobian(types, off, x, cam, h, has_h):
+    N = len(types)
+    Hc, Hl = np.zeros((N, 2, 7)), np.zeros((N, 2, 6))
+    c = make_cam(cam)
+    lib().orc_jacobian(N, _p(_i(types)), _p(_i(off)), _p(_d(x)), C.byref(c), _p(_d(h)), _p(_i(has_h)), _p(Hc), _p(Hl))
+    return Hc, Hl
+
+
+def innovation(types, off, P, Hc, Hl, has_h):
+    N = len(types)
+    n = P.shape[0]
+    S = np.zeros((N, 2, 2))
+    lib().orc_innovation(n, N, _p(_i(types)), _p(_i(off)), _p(_d(P)), _p(_d(Hc)), _p(_d(Hl)), _p(_i(has_h)), _p(S))
+    return S
+
+
+def window_gate(pred_idx, k1, zc, h, S, has_S, strict_reference=True):
+    M = len(k1)
+    acc = np.zeros(M, np.int32)
+    lib().orc_window_gate(M, _p(_i(pred_idx)), len(pred_idx), _p(_i(k1)), _p(_d(zc)), _p(_d(h)), _p(_d(S)), _p(_i(has_S)),
+                          int(strict_reference), _p(acc))
+    return acc
+
+
+def rescue(types, off, P, Hc, Hl, h, z, ic, li, chi2=5.9915):
+    N = len(types)
+    n = P.shape[0]
+    hi = np.zeros(N, np.int32)
+    d2 = np.full(N, np.nan)
+    lib().orc_rescue(n, N, _p(_i(types)), _p(_i(off)), _p(_d(P)), _p(_d(Hc)), _p(_d(Hl)), _p(_d(h)), _p(_d(np.nan_to_num(z))),
+                     _p(_i(ic)), _p(_i(li)), C.c_double(chi2), _p(hi), _p(d2))
+    return hi, d2
+
+
+def update(x, P, H, R, z, h, want_K=False):
+    x, P = _d(x), _d(P)
+    n = x.shape[0]
+    z, h = _d(z).ravel(), _d(h).ravel()
+    r = z.shape[0]
+    H = _d(H).reshape(r, n) if r else np.zeros((0, n))
+    Rm = None if R is None else _d(R)
+    xo, Po = np.empty(n), np.empty((n, n))
+    K = np.zeros((n, r)) if want_K else None
+    rc = lib().orc_update(n, r, _p(x), _p(P), _p(H), _p(Rm), _p(z), _p(h), _p(xo), _p(Po), _p(K))
+    assert rc == 0, rc
+    return (xo, Po, K) if want_K else (xo, Po)
+
+
+def update_landmarks(types, off, sel, x, P, Hc, Hl, z, h):
+    x, P = _d(x), _d(P)
+    n = x.shape[0]
+    sel = _i(sel)
+    xo, Po = np.empty(n), np.empty((n, n))
+    rc = lib().orc_update_landmarks(n, len(types), _p(_i(types)), _p(_i(off)), len(sel), _p(sel), _p(x), _p(P),
+                                    _p(_d(Hc)), _p(_d(Hl)), _p(_d(np.nan_to_num(z))), _p(_d(h)), _p(xo), _p(Po))
+    assert rc == 0, rc
+    return xo, Po
+
+
+def support(meas, types, off, xi, cam, z_meas, threshold):
+    m = len(meas)
+    mask = np.zeros(m, np.int32)
+    res = np.zeros(m)
+    c = make_cam(cam)
+    s = lib().orc_support(m, _p(_i(meas)), _p(_i(types)), _p(_i(off)), _p(_d(xi)), C.byref(c), _p(_d(z_meas)),
+                          C.c_double(threshold), _p(mask), _p(res))
+    return s, mask, res
+
+
+def hypothesis_state(sel, types, off, x, P, Hc, Hl, z, h):
+    x = _d(x)
+    n = x.shape[0]
+    xi = np.empty(n)
+    sel = _i(sel)
+    lib().orc_hypothesis_state(n, len(sel), _p(sel), _p(_i(types)), _p(_i(off)), _p(x), _p(_d(P)), _p(_d(Hc)), _p(_d(Hl)),
+                               _p(_d(np.nan_to_num(z))), _p(_d(h)), _p(xi))
+    return xi
+
+
+def ransac(types, off, x, P, Hc, Hl, z, h, ic_list, meas, cam, hyp, threshold, early_exit=True):
+    x = _d(x)
+    n = x.shape[0]
+    hyp = _i(hyp)
+    n_draw, k = hyp.shape
+    m = len(meas)
+    sup = np.zeros(n_draw, np.int32)
+    li = np.zeros(m, np.int32)
+    out = [C.c_int(0) for _ in range(4)]
+    c = make_cam(cam)
+    lib().orc_ransac(n, len(types), _p(_i(types)), _p(_i(off)), _p(x), _p(_d(P)), _p(_d(Hc)), _p(_d(Hl)),
+                     _p(_d(np.nan_to_num(z))), _p(_d(h)), len(ic_list), _p(_i(ic_list)), m, _p(_i(meas)), C.byref(c),
+                     n_draw, k, _p(hyp), C.c_double(threshold), int(early_exit), _p(sup), _p(li),
+                     C.byref(out[0]), C.byref(out[1]), C.byref(out[2]), C.byref(out[3]))
+    return dict(support=sup, li_mask=li, best=out[0].value, iters=out[1].value, n_hyp=out[2].value, max_support=out[3].value)
+
+
+_SIFT = {np.dtype(np.float64): "orc_siftmatch_f64", np.dtype(np.float32): "orc_siftmatch_f32",
+         np.dtype(np.int8): "orc_siftmatch_i8", np.dtype(np.uint8): "orc_siftmatch_u8"}
+
+
+def siftmatch(L1, L2, thresh=1.5):
+    """L1: ND x K1, L2: ND x K2 (MATLAB orientation: one descriptor per column).
+    Returns (matches 2 x M float64 1-based, scores M)."""
+    L1, L2 = np.asarray(L1), np.asarray(L2)
+    assert L1.dtype == L2.dtype and L1.shape[0] == L2.shape[0]
+    fn = getattr(lib(), _SIFT[L1.dtype])
+    ND, K1 = L1.shape
+    K2 = L2.shape[1]
+    a = np.asfortranarray(L1)
+    b = np.asfortranarray(L2)
+    pairs = np.zeros(2 * max(K1, 1))
+    score = np.zeros(max(K1, 1))
+    M = fn(ND, K1, a.ctypes.data_as(C.c_void_p), K2, b.ctypes.data_as(C.c_void_p), C.c_double(thresh), _p(pairs), _p(score))
+    return pairs[:2 * M].reshape(M, 2).T.copy(), score[:M].copy()
+
+
+def knn(data, query, k):
+    data, query = _d(data), _d(query)
+    N, D = data.shape
+    M = query.shape[0]
+    ids, dist = np.zeros((M, k)), np.zeros((M, k))
+    rc = lib().orc_knn(D, N, _p(data), M, _p(query), k, _p(ids), _p(dist))
+    assert rc == 0
+    return ids, dist
