@@ -1,0 +1,74 @@
+"""ctypes binding of lib/libpre3.so (the C ABI of include/pre3.h).
+
+There is no CPU fallback: if the shared library is missing this module raises at import, and
+every compute call raises Pre3Error when no HIP device is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+try:  # torch ships its own libamdhip64.so.7; load it first so both share ONE HIP runtime
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is plumbing, not a requirement of the library
+    torch = None
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpre3.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "3pre_amd: %s is missing -- build it with `make -C 3pre_amd/csrc` (or __graft_entry__.build()); "
+        "there is no CPU fallback for the HIP path" % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+lib.pre3_last_error.restype = C.c_char_p
+lib.pre3_version.restype = C.c_char_p
+lib.pre3_match_bench_create.restype = C.c_void_p
+
+F64, F32 = 0, 1
+INVDEPTH, CARTESIAN = 0, 1
+X_K_K, X_K_KM1 = 0, 1
+
+
+class Cam(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("f", "Cx", "Cy", "k1", "k2", "nRows", "nCols")]
+
+
+class Pre3Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libpre3 error %d: %s" % (code, msg))
+        self.code = code
+
+
+def check(rc):
+    if rc != 0:
+        raise Pre3Error(rc, lib.pre3_last_error().decode(errors="replace"))
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def device_count():
+    return int(lib.pre3_device_count())
+
+
+# every symbol include/pre3.h declares (checked by tests/test_abi.py against the header text)
+EXPORTS = [
+    "pre3_last_error", "pre3_device_count", "pre3_version", "pre3_create", "pre3_destroy", "pre3_sync", "pre3_set_cam",
+    "pre3_set_map", "pre3_state_size", "pre3_set_state", "pre3_get_state", "pre3_predict", "pre3_project", "pre3_innovation",
+    "pre3_get_landmark_fields", "pre3_window_gate", "pre3_set_measurements", "pre3_ransac", "pre3_ransac_score",
+    "pre3_ransac_select", "pre3_update_li", "pre3_rescue", "pre3_update_hi", "pre3_update_all", "pre3_get_flags",
+    "pre3_set_flags", "pre3_step", "pre3_update_ell", "pre3_siftmatch_f64", "pre3_siftmatch_f32", "pre3_siftmatch_u8",
+    "pre3_siftmatch_i8", "pre3_siftmatch_partial", "pre3_siftmatch_merge", "pre3_knn_f64", "pre3_timer_start",
+    "pre3_timer_stop", "pre3_kernel_timing", "pre3_kernel_timing_read", "pre3_bench_downdate",
+]

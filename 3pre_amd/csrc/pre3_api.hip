@@ -1,0 +1,714 @@
+// pre3_api.hip -- the C ABI of include/pre3.h: context management, host<->device marshalling, and the
+// stage order of one filter step (mono_slam.m:153-187).  No compute happens on the host.
+#include <cmath>
+#include <cstdarg>
+#include <new>
+
+#include "pre3_internal.h"
+
+namespace pre3 {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...)
+{
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+// launchers defined in the kernel files
+int launch_predict_impl(pre3_ctx *c, const double u[7]);
+int launch_window_gate(pre3_ctx *c, int M, const int32_t *pred_idx_dev, const int32_t *k1_dev, const double *zc_dev, int strict, int32_t *accept_dev);
+int launch_build_rows_impl(pre3_ctx *c, int nsel, const int32_t *sel_dev, int r_pad);
+int launch_ransac_score_impl(pre3_ctx *c, int k, double threshold, int hyp_begin, int hyp_end, int ldg, int32_t *support_dev, uint32_t *mask_dev, int mask_words);
+int launch_ransac_select_impl(pre3_ctx *c, int n_draw, int k, int early_exit, int32_t *support_dev, const uint32_t *mask_dev, int mask_words);
+int launch_fill_w(pre3_ctx *c, int r_pad);
+int match_partial(int device, int cls, int ND, int K1, const void *L1, int K2, const void *L2, int k2_offset, double *best, double *second, int32_t *arg);
+int knn_run(int device, int D, int N, const double *data, int M, const double *query, int k, double *ids, double *dist);
+void *match_bench_create(int ND, int K1, const uint8_t *L1, int K2, const uint8_t *L2);
+int match_bench_run(void *h, int reps, double *ms_per);
+int match_bench_fetch(void *h, double *best, double *second, int32_t *arg);
+void match_bench_destroy(void *h);
+
+template <typename T> static int dmalloc(T **p, size_t count)
+{
+    void *q = nullptr;
+    if (hipMalloc(&q, sizeof(T) * (count ? count : 1)) != hipSuccess) { set_error("hipMalloc of %zu bytes failed", sizeof(T) * count); return PRE3_E_NOMEM; }
+    *p = (T *)q;
+    return PRE3_OK;
+}
+static int dmalloc_bytes(void **p, size_t bytes)
+{
+    if (hipMalloc(p, bytes ? bytes : 16) != hipSuccess) { set_error("hipMalloc of %zu bytes failed", bytes); return PRE3_E_NOMEM; }
+    return PRE3_OK;
+}
+
+static int check_ctx(pre3_ctx *c)
+{
+    PRE3_CHECK(c != nullptr, PRE3_E_ARG, "null context");
+    PRE3_HIP(hipSetDevice(c->device));
+    return PRE3_OK;
+}
+
+static int fetch_stats(pre3_ctx *c)
+{
+    PRE3_HIP(hipMemcpyAsync(c->pinned_stats, c->stats, sizeof(int32_t) * 16, hipMemcpyDeviceToHost, c->stream));
+    PRE3_HIP(hipStreamSynchronize(c->stream));
+    PRE3_CHECK(c->pinned_stats[6] == 0, PRE3_E_NUMERIC, "innovation covariance S is not positive definite");
+    return PRE3_OK;
+}
+
+}  // namespace pre3
+
+using namespace pre3;
+
+extern "C" {
+
+const char *pre3_last_error(void) { return pre3::g_err; }
+const char *pre3_version(void) { return "pre3-mi355x 0.1 (gfx950)"; }
+
+int pre3_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int max_hyp)
+{
+    PRE3_CHECK(out != nullptr, PRE3_E_ARG, "pre3_create: null output pointer");
+    *out = nullptr;
+    PRE3_CHECK(dtype == PRE3_F64 || dtype == PRE3_F32, PRE3_E_ARG, "pre3_create: dtype must be PRE3_F64 or PRE3_F32");
+    PRE3_CHECK(max_landmarks >= 1 && max_hyp >= 1, PRE3_E_ARG, "pre3_create: capacities must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available (libpre3 has no CPU fallback)"); return PRE3_E_NODEVICE; }
+    PRE3_CHECK(device >= 0 && device < ndev, PRE3_E_NODEVICE, "pre3_create: device %d out of range (have %d)", device, ndev);
+    PRE3_HIP(hipSetDevice(device));
+    pre3_ctx *c = new (std::nothrow) pre3_ctx();
+    PRE3_CHECK(c != nullptr, PRE3_E_NOMEM, "out of host memory");
+    c->device = device; c->dtype = dtype; c->esz = dtype == PRE3_F64 ? 8 : 4;
+    c->capN = max_landmarks; c->capn = 13 + 6 * max_landmarks; c->capm = max_landmarks; c->caph = max_hyp;
+    c->ld = round_up(c->capn, TILE); c->ldw = c->ld + NB;
+    c->rcap = round_up(2 * c->capm, NB);
+    c->mask_words_cap = ceil_div(c->capm, 32);
+    int rc = PRE3_OK;
+    auto A = [&](int r) { if (rc == PRE3_OK) rc = r; };
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return PRE3_E_HIP; }
+    A(dmalloc(&c->x_kk, c->capn)); A(dmalloc(&c->x_km1, c->capn));
+    A(dmalloc_bytes(&c->P, (size_t)c->ld * c->ld * c->esz));
+    A(dmalloc(&c->lm.type, c->capN)); A(dmalloc(&c->lm.off, c->capN));
+    A(dmalloc(&c->lm.h, 2 * (size_t)c->capN)); A(dmalloc(&c->lm.has_h, c->capN));
+    A(dmalloc(&c->lm.Hc, 14 * (size_t)c->capN)); A(dmalloc(&c->lm.Hl, 12 * (size_t)c->capN));
+    A(dmalloc(&c->lm.S, 4 * (size_t)c->capN)); A(dmalloc(&c->lm.has_S, c->capN));
+    A(dmalloc(&c->lm.z, 2 * (size_t)c->capN));
+    A(dmalloc(&c->lm.ic, c->capN)); A(dmalloc(&c->lm.li, c->capN)); A(dmalloc(&c->lm.hi, c->capN));
+    A(dmalloc(&c->meas, c->capm));
+    A(dmalloc(&c->row_col, (size_t)c->rcap * ELLW)); A(dmalloc_bytes(&c->row_val, (size_t)c->rcap * ELLW * c->esz));
+    A(dmalloc(&c->row_nu, c->rcap));
+    A(dmalloc_bytes(&c->HP, (size_t)c->rcap * c->ldw * c->esz));
+    A(dmalloc_bytes(&c->W, (size_t)c->rcap * c->ldw * c->esz));
+    A(dmalloc_bytes(&c->G, (size_t)c->rcap * c->rcap * c->esz));
+    A(dmalloc_bytes(&c->Smat, (size_t)c->rcap * c->rcap * c->esz));
+    A(dmalloc(&c->sel_rows, c->rcap));
+    A(dmalloc(&c->hyp, (size_t)c->caph * MAXK)); A(dmalloc(&c->support, c->caph));
+    A(dmalloc(&c->masks, (size_t)c->caph * c->mask_words_cap));
+    A(dmalloc(&c->stats, 16)); A(dmalloc(&c->li_meas, c->capm)); A(dmalloc(&c->hi_meas, c->capm));
+    A(dmalloc(&c->pred_params, 128));
+    if (rc == PRE3_OK && hipHostMalloc((void **)&c->pinned_stats, sizeof(int32_t) * 16) != hipSuccess) { set_error("hipHostMalloc failed"); rc = PRE3_E_NOMEM; }
+    if (rc == PRE3_OK && (hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess)) { set_error("hipEventCreate failed"); rc = PRE3_E_HIP; }
+    if (rc != PRE3_OK) { pre3_destroy(c); return rc; }
+    (void)hipMemsetAsync(c->stats, 0, sizeof(int32_t) * 16, c->stream);
+    (void)hipMemsetAsync(c->P, 0, (size_t)c->ld * c->ld * c->esz, c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    *out = c;
+    return PRE3_OK;
+}
+
+int pre3_destroy(pre3_ctx *c)
+{
+    if (!c) return PRE3_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S, c->lm.z,
+                     c->lm.ic, c->lm.li, c->lm.hi, c->meas, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
+                     c->sel_rows, c->hyp, c->support, c->masks, c->stats, c->li_meas, c->hi_meas, c->pred_params };
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    if (c->pinned_stats) (void)hipHostFree(c->pinned_stats);
+    for (hipEvent_t e : c->kt.ev) (void)hipEventDestroy(e);
+    if (c->t0) (void)hipEventDestroy(c->t0);
+    if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return PRE3_OK;
+}
+
+int pre3_sync(pre3_ctx *c)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_HIP(hipStreamSynchronize(c->stream));
+    return PRE3_OK;
+}
+
+int pre3_set_cam(pre3_ctx *c, const pre3_cam *cam)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(cam != nullptr && cam->f > 0, PRE3_E_ARG, "pre3_set_cam: invalid camera");
+    c->cam = *cam; c->have_cam = true;
+    return PRE3_OK;
+}
+
+int pre3_set_map(pre3_ctx *c, int N, const int32_t *lm_type)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(N >= 0 && N <= c->capN, PRE3_E_ARG, "pre3_set_map: N=%d exceeds capacity %d", N, c->capN);
+    PRE3_CHECK(N == 0 || lm_type != nullptr, PRE3_E_ARG, "pre3_set_map: null type list");
+    std::vector<int32_t> off(N ? N : 1);
+    int n = 13;
+    for (int i = 0; i < N; ++i) {
+        PRE3_CHECK(lm_type[i] == PRE3_INVDEPTH || lm_type[i] == PRE3_CARTESIAN, PRE3_E_ARG, "pre3_set_map: landmark %d has unknown type %d", i, lm_type[i]);
+        off[i] = n; n += lm_type[i] == PRE3_INVDEPTH ? 6 : 3;
+    }
+    PRE3_CHECK(n <= c->capn, PRE3_E_ARG, "pre3_set_map: state size %d exceeds capacity %d", n, c->capn);
+    PRE3_HIP(hipStreamSynchronize(c->stream));
+    if (N) {
+        PRE3_HIP(hipMemcpy(c->lm.type, lm_type, sizeof(int32_t) * N, hipMemcpyHostToDevice));
+        PRE3_HIP(hipMemcpy(c->lm.off, off.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice));
+    }
+    c->N = N; c->n = n;
+    // the P buffer keeps its capacity-sized leading dimension; entries beyond n stay zero
+    PRE3_HIP(hipMemset(c->lm.has_h, 0, sizeof(int32_t) * c->capN)); PRE3_HIP(hipMemset(c->lm.has_S, 0, sizeof(int32_t) * c->capN));
+    PRE3_HIP(hipMemset(c->lm.ic, 0, sizeof(int32_t) * c->capN)); PRE3_HIP(hipMemset(c->lm.li, 0, sizeof(int32_t) * c->capN));
+    PRE3_HIP(hipMemset(c->lm.hi, 0, sizeof(int32_t) * c->capN));
+    c->m = 0; c->meas_host.clear(); c->measurements_set = false; c->projected = false; c->innovated = false;
+    c->x_valid[0] = c->x_valid[1] = false; c->p_which = -1;
+    return PRE3_OK;
+}
+
+int pre3_state_size(pre3_ctx *c) { return c ? c->n : PRE3_E_ARG; }
+
+int pre3_set_state(pre3_ctx *c, int which, int n, const double *x, const double *P)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(which == PRE3_X_K_K || which == PRE3_X_K_KM1, PRE3_E_ARG, "pre3_set_state: bad selector");
+    PRE3_CHECK(n == c->n, PRE3_E_ARG, "pre3_set_state: n=%d but the map defines n=%d", n, c->n);
+    PRE3_CHECK(x && P, PRE3_E_ARG, "pre3_set_state: null pointer");
+    PRE3_HIP(hipStreamSynchronize(c->stream));
+    PRE3_HIP(hipMemcpy(which == PRE3_X_K_K ? c->x_kk : c->x_km1, x, sizeof(double) * n, hipMemcpyHostToDevice));
+    const int ld = c->ld;
+    PRE3_HIP(hipMemset(c->P, 0, (size_t)ld * ld * c->esz));
+    if (c->dtype == PRE3_F64) {
+        PRE3_HIP(hipMemcpy2D(c->P, (size_t)ld * 8, P, (size_t)n * 8, (size_t)n * 8, n, hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> tmp((size_t)n * n);
+        for (size_t i = 0; i < (size_t)n * n; ++i) tmp[i] = (float)P[i];
+        PRE3_HIP(hipMemcpy2D(c->P, (size_t)ld * 4, tmp.data(), (size_t)n * 4, (size_t)n * 4, n, hipMemcpyHostToDevice));
+    }
+    c->x_valid[which] = true; c->p_which = which;
+    return PRE3_OK;
+}
+
+int pre3_get_state(pre3_ctx *c, int which, int n, double *x, double *P)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(which == PRE3_X_K_K || which == PRE3_X_K_KM1, PRE3_E_ARG, "pre3_get_state: bad selector");
+    PRE3_CHECK(n == c->n, PRE3_E_ARG, "pre3_get_state: n=%d but the map defines n=%d", n, c->n);
+    PRE3_CHECK(c->x_valid[which], PRE3_E_STATE, "pre3_get_state: that estimate has not been computed");
+    PRE3_TRY(fetch_stats(c));
+    if (x) PRE3_HIP(hipMemcpy(x, which == PRE3_X_K_K ? c->x_kk : c->x_km1, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (P) {
+        PRE3_CHECK(c->p_which == which, PRE3_E_STATE, "pre3_get_state: the covariance buffer currently holds the other estimate (it is updated in place)");
+        const int ld = c->ld;
+        if (c->dtype == PRE3_F64) {
+            PRE3_HIP(hipMemcpy2D(P, (size_t)n * 8, c->P, (size_t)ld * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost));
+        } else {
+            std::vector<float> tmp((size_t)n * n);
+            PRE3_HIP(hipMemcpy2D(tmp.data(), (size_t)n * 4, c->P, (size_t)ld * 4, (size_t)n * 4, n, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < (size_t)n * n; ++i) P[i] = (double)tmp[i];
+        }
+    }
+    return PRE3_OK;
+}
+
+int pre3_predict(pre3_ctx *c, const double u[7])
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(u != nullptr, PRE3_E_ARG, "pre3_predict: null u");
+    PRE3_CHECK(c->x_valid[PRE3_X_K_K] && c->p_which == PRE3_X_K_K, PRE3_E_STATE, "pre3_predict: needs (x_k_k, p_k_k) on the device");
+    PRE3_TRY(launch_predict_impl(c, u));
+    c->x_valid[PRE3_X_K_KM1] = true; c->p_which = PRE3_X_K_KM1;
+    return PRE3_OK;
+}
+
+int pre3_project(pre3_ctx *c, int which, int clear_first)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(which == PRE3_X_K_K || which == PRE3_X_K_KM1, PRE3_E_ARG, "pre3_project: bad selector");
+    PRE3_CHECK(c->have_cam, PRE3_E_STATE, "pre3_project: camera not set");
+    PRE3_CHECK(c->x_valid[which], PRE3_E_STATE, "pre3_project: that estimate is not on the device");
+    if (c->N == 0) return PRE3_OK;
+    PRE3_TRY(launch_project(c, which, clear_first));
+    c->projected = true;
+    return PRE3_OK;
+}
+
+int pre3_innovation(pre3_ctx *c)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(c->projected, PRE3_E_STATE, "pre3_innovation: call pre3_project first");
+    if (c->N == 0) return PRE3_OK;
+    PRE3_TRY(launch_innovation(c, 0, 0.0));
+    c->innovated = true;
+    return PRE3_OK;
+}
+
+int pre3_get_landmark_fields(pre3_ctx *c, double *h, int32_t *has_h, double *Hc, double *Hl, double *S)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_HIP(hipStreamSynchronize(c->stream));
+    int N = c->N;
+    if (N == 0) return PRE3_OK;
+    if (h) PRE3_HIP(hipMemcpy(h, c->lm.h, sizeof(double) * 2 * N, hipMemcpyDeviceToHost));
+    if (has_h) PRE3_HIP(hipMemcpy(has_h, c->lm.has_h, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+    if (Hc) PRE3_HIP(hipMemcpy(Hc, c->lm.Hc, sizeof(double) * 14 * N, hipMemcpyDeviceToHost));
+    if (Hl) PRE3_HIP(hipMemcpy(Hl, c->lm.Hl, sizeof(double) * 12 * N, hipMemcpyDeviceToHost));
+    if (S) PRE3_HIP(hipMemcpy(S, c->lm.S, sizeof(double) * 4 * N, hipMemcpyDeviceToHost));
+    return PRE3_OK;
+}
+
+static int install_measurements(pre3_ctx *c, int m, const int32_t *meas_idx, const double *z /* 2m, may be null if z already on device */)
+{
+    PRE3_CHECK(m >= 0 && m <= c->capm, PRE3_E_ARG, "measurements: m=%d exceeds capacity %d", m, c->capm);
+    for (int j = 0; j < m; ++j) {
+        PRE3_CHECK(meas_idx[j] >= 0 && meas_idx[j] < c->N, PRE3_E_ARG, "measurements: landmark index %d out of range", meas_idx[j]);
+        PRE3_CHECK(j == 0 || meas_idx[j] > meas_idx[j - 1], PRE3_E_ARG, "measurements: landmark indices must be strictly ascending");
+    }
+    c->m = m; c->meas_host.assign(meas_idx, meas_idx + m);
+    PRE3_HIP(hipMemsetAsync(c->lm.ic, 0, sizeof(int32_t) * c->N, c->stream));
+    PRE3_HIP(hipMemsetAsync(c->lm.li, 0, sizeof(int32_t) * c->N, c->stream));
+    PRE3_HIP(hipMemsetAsync(c->lm.hi, 0, sizeof(int32_t) * c->N, c->stream));
+    PRE3_HIP(hipMemsetAsync(c->li_meas, 0, sizeof(int32_t) * c->capm, c->stream));
+    PRE3_HIP(hipMemsetAsync(c->hi_meas, 0, sizeof(int32_t) * c->capm, c->stream));
+    if (m) {
+        std::vector<int32_t> ones(c->N, 0);
+        std::vector<double> zl;
+        for (int j = 0; j < m; ++j) ones[meas_idx[j]] = 1;
+        PRE3_HIP(hipMemcpyAsync(c->meas, meas_idx, sizeof(int32_t) * m, hipMemcpyHostToDevice, c->stream));
+        PRE3_HIP(hipMemcpyAsync(c->lm.ic, ones.data(), sizeof(int32_t) * c->N, hipMemcpyHostToDevice, c->stream));
+        if (z) {
+            zl.assign(2 * (size_t)c->N, 0.0);
+            for (int j = 0; j < m; ++j) { zl[2 * meas_idx[j]] = z[2 * j]; zl[2 * meas_idx[j] + 1] = z[2 * j + 1]; }
+            PRE3_HIP(hipMemcpyAsync(c->lm.z, zl.data(), sizeof(double) * 2 * c->N, hipMemcpyHostToDevice, c->stream));
+        }
+        PRE3_HIP(hipStreamSynchronize(c->stream));      // host staging vectors go out of scope
+    }
+    c->measurements_set = true;
+    return PRE3_OK;
+}
+
+int pre3_set_measurements(pre3_ctx *c, int m, const int32_t *meas_idx, const double *z)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(m == 0 || (meas_idx && z), PRE3_E_ARG, "pre3_set_measurements: null pointer");
+    return install_measurements(c, m, meas_idx, z);
+}
+
+int pre3_window_gate(pre3_ctx *c, int M, const int32_t *k1, const double *zc, int strict_reference, int32_t *accept_out)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(c->projected, PRE3_E_STATE, "pre3_window_gate: call pre3_project / pre3_innovation first");
+    PRE3_CHECK(M >= 0 && (M == 0 || (k1 && zc)), PRE3_E_ARG, "pre3_window_gate: bad arguments");
+    int N = c->N;
+    std::vector<int32_t> has_h(N ? N : 1), pred;
+    PRE3_HIP(hipStreamSynchronize(c->stream));
+    if (N) PRE3_HIP(hipMemcpy(has_h.data(), c->lm.has_h, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+    for (int i = 0; i < N; ++i) if (has_h[i]) pred.push_back(i);
+    PRE3_CHECK(M <= (int)pred.size(), PRE3_E_ARG, "pre3_window_gate: %d candidates but only %zu predicted landmarks", M, pred.size());
+    for (int q = 0; q < M; ++q) PRE3_CHECK(k1[q] >= 0 && k1[q] < (int)pred.size(), PRE3_E_ARG, "pre3_window_gate: k1[%d]=%d out of range", q, k1[q]);
+    std::vector<int32_t> acc(M ? M : 1, 0);
+    if (M) {
+        int32_t *d_pred = nullptr, *d_k1 = nullptr, *d_acc = nullptr; double *d_zc = nullptr;
+        PRE3_TRY(dmalloc(&d_pred, pred.size())); PRE3_TRY(dmalloc(&d_k1, M)); PRE3_TRY(dmalloc(&d_acc, M)); PRE3_TRY(dmalloc(&d_zc, 2 * (size_t)M));
+        PRE3_HIP(hipMemcpy(d_pred, pred.data(), sizeof(int32_t) * pred.size(), hipMemcpyHostToDevice));
+        PRE3_HIP(hipMemcpy(d_k1, k1, sizeof(int32_t) * M, hipMemcpyHostToDevice));
+        PRE3_HIP(hipMemcpy(d_zc, zc, sizeof(double) * 2 * M, hipMemcpyHostToDevice));
+        PRE3_HIP(hipMemsetAsync(c->lm.ic, 0, sizeof(int32_t) * N, c->stream));
+        int rc = launch_window_gate(c, M, d_pred, d_k1, d_zc, strict_reference, d_acc);
+        if (rc == PRE3_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = PRE3_E_HIP;
+        if (rc == PRE3_OK && hipMemcpy(acc.data(), d_acc, sizeof(int32_t) * M, hipMemcpyDeviceToHost) != hipSuccess) rc = PRE3_E_HIP;
+        (void)hipFree(d_pred); (void)hipFree(d_k1); (void)hipFree(d_acc); (void)hipFree(d_zc);
+        PRE3_TRY(rc);
+    }
+    // accepted candidates become the measurement list (ascending landmark order; one match per landmark)
+    std::vector<int32_t> flag(N ? N : 1, 0);
+    for (int q = 0; q < M; ++q) if (acc[q]) flag[pred[k1[q]]] = 1;
+    std::vector<int32_t> meas;
+    for (int i = 0; i < N; ++i) if (flag[i]) meas.push_back(i);
+    if (accept_out) for (int q = 0; q < M; ++q) accept_out[q] = acc[q];
+    // z was written on the device by the gate kernel; keep it (z == nullptr)
+    return install_measurements(c, (int)meas.size(), meas.data(), nullptr);
+}
+
+// ---- RANSAC ---------------------------------------------------------------------------------------
+static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp)
+{
+    PRE3_CHECK(c->measurements_set && c->projected, PRE3_E_STATE, "ransac: needs pre3_project and measurements");
+    PRE3_CHECK(c->p_which == PRE3_X_K_KM1, PRE3_E_STATE, "ransac: needs the predicted estimate (call pre3_predict or set x_k_km1)");
+    PRE3_CHECK(n_draw >= 1 && n_draw <= c->caph, PRE3_E_ARG, "ransac: n_draw=%d exceeds capacity %d", n_draw, c->caph);
+    PRE3_CHECK(k >= 1 && k <= MAXK, PRE3_E_ARG, "ransac: k=%d unsupported (1..%d)", k, MAXK);
+    PRE3_CHECK(hyp != nullptr, PRE3_E_ARG, "ransac: null hypothesis table");
+    PRE3_CHECK(c->m >= k, PRE3_E_ARG, "ransac: %d measurements but k=%d", c->m, k);
+    for (int i = 0; i < n_draw * k; ++i) PRE3_CHECK(hyp[i] >= 0 && hyp[i] < c->m, PRE3_E_ARG, "ransac: hyp[%d]=%d not a position in the IC list (m=%d)", i, hyp[i], c->m);
+    PRE3_HIP(hipMemcpyAsync(c->hyp, hyp, sizeof(int32_t) * n_draw * k, hipMemcpyHostToDevice, c->stream));
+    int r = 2 * c->m, r_pad = round_up(r, NB);
+    PRE3_TRY(launch_build_rows_impl(c, c->m, nullptr, r_pad));
+    PRE3_TRY(launch_ell_HP(c, r, c->HP, true));
+    PRE3_TRY(launch_ell_G(c, r, c->HP, c->G, r_pad, 0, nullptr));
+    return PRE3_OK;
+}
+
+int pre3_ransac_score(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, double threshold, int hyp_begin, int hyp_end,
+                      void **support_dev, void **mask_dev, int *mask_words)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(hyp_begin >= 0 && hyp_begin <= hyp_end && hyp_end <= n_draw, PRE3_E_ARG, "ransac: bad hypothesis range [%d,%d) of %d", hyp_begin, hyp_end, n_draw);
+    PRE3_TRY(ransac_prepare(c, n_draw, k, hyp));
+    int words = ceil_div(c->m, 32);
+    PRE3_HIP(hipMemsetAsync(c->support, 0, sizeof(int32_t) * n_draw, c->stream));
+    PRE3_HIP(hipMemsetAsync(c->masks, 0, sizeof(uint32_t) * (size_t)n_draw * words, c->stream));
+    PRE3_TRY(launch_ransac_score_impl(c, k, threshold, hyp_begin, hyp_end, round_up(2 * c->m, NB), c->support, c->masks, words));
+    if (support_dev) *support_dev = c->support;
+    if (mask_dev) *mask_dev = c->masks;
+    if (mask_words) *mask_words = words;
+    PRE3_HIP(hipStreamSynchronize(c->stream));     // the caller's collective runs on another stream
+    return PRE3_OK;
+}
+
+int pre3_ransac_select(pre3_ctx *c, int n_draw, int k, int early_exit, int32_t *support, int32_t *li_mask, int32_t stats[4])
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(n_draw >= 1 && n_draw <= c->caph, PRE3_E_ARG, "ransac: n_draw out of range");
+    int words = ceil_div(c->m, 32);
+    PRE3_TRY(launch_ransac_select_impl(c, n_draw, k, early_exit, c->support, c->masks, words));
+    PRE3_TRY(fetch_stats(c));
+    if (support) PRE3_HIP(hipMemcpy(support, c->support, sizeof(int32_t) * n_draw, hipMemcpyDeviceToHost));
+    if (li_mask && c->m) PRE3_HIP(hipMemcpy(li_mask, c->li_meas, sizeof(int32_t) * c->m, hipMemcpyDeviceToHost));
+    if (stats) for (int i = 0; i < 4; ++i) stats[i] = c->pinned_stats[i];
+    return PRE3_OK;
+}
+
+int pre3_ransac(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, double threshold, int early_exit, int32_t *support, int32_t *li_mask,
+                int32_t stats[4])
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_TRY(ransac_prepare(c, n_draw, k, hyp));
+    int words = ceil_div(c->m, 32);
+    PRE3_TRY(launch_ransac_score_impl(c, k, threshold, 0, n_draw, round_up(2 * c->m, NB), c->support, c->masks, words));
+    return pre3_ransac_select(c, n_draw, k, early_exit, support, li_mask, stats);
+}
+
+// ---- updates --------------------------------------------------------------------------------------
+static int update_selected(pre3_ctx *c, int which_prior, int nsel, const int32_t *sel_dev)
+{
+    PRE3_CHECK(c->p_which == which_prior, PRE3_E_STATE, "update: the covariance buffer does not hold the required prior");
+    int r = 2 * nsel;
+    if (r > 0) PRE3_TRY(launch_build_rows_impl(c, nsel, sel_dev, round_up(r, NB)));
+    PRE3_TRY(run_update(c, which_prior, r, false, nullptr));
+    c->x_valid[PRE3_X_K_K] = true; c->p_which = PRE3_X_K_K;
+    return PRE3_OK;
+}
+
+int pre3_update_li(pre3_ctx *c)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(c->measurements_set && c->projected, PRE3_E_STATE, "pre3_update_li: needs projection and measurements");
+    PRE3_TRY(fetch_stats(c));
+    return update_selected(c, PRE3_X_K_KM1, c->pinned_stats[4], c->sel_rows);
+}
+
+int pre3_rescue(pre3_ctx *c, double chi2, int32_t *hi_mask)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(c->p_which == PRE3_X_K_K && c->x_valid[PRE3_X_K_K], PRE3_E_STATE, "pre3_rescue: needs (x_k_k, p_k_k), i.e. after the LI update");
+    PRE3_TRY(launch_project(c, PRE3_X_K_K, 0));
+    PRE3_TRY(launch_innovation(c, 1, chi2));
+    if (hi_mask) {
+        PRE3_TRY(fetch_stats(c));
+        if (c->m) PRE3_HIP(hipMemcpy(hi_mask, c->hi_meas, sizeof(int32_t) * c->m, hipMemcpyDeviceToHost));
+    }
+    return PRE3_OK;
+}
+
+int pre3_update_hi(pre3_ctx *c)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_TRY(fetch_stats(c));
+    return update_selected(c, PRE3_X_K_K, c->pinned_stats[5], c->sel_rows);
+}
+
+int pre3_update_all(pre3_ctx *c)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(c->measurements_set && c->projected, PRE3_E_STATE, "pre3_update_all: needs projection and measurements");
+    return update_selected(c, PRE3_X_K_KM1, c->m, nullptr);
+}
+
+int pre3_get_flags(pre3_ctx *c, int32_t *li, int32_t *hi)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_HIP(hipStreamSynchronize(c->stream));
+    if (c->m == 0) return PRE3_OK;
+    if (li) PRE3_HIP(hipMemcpy(li, c->li_meas, sizeof(int32_t) * c->m, hipMemcpyDeviceToHost));
+    if (hi) PRE3_HIP(hipMemcpy(hi, c->hi_meas, sizeof(int32_t) * c->m, hipMemcpyDeviceToHost));
+    return PRE3_OK;
+}
+
+int pre3_set_flags(pre3_ctx *c, const int32_t *li, const int32_t *hi)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(c->measurements_set, PRE3_E_STATE, "pre3_set_flags: no measurements");
+    PRE3_HIP(hipStreamSynchronize(c->stream));
+    int m = c->m, N = c->N;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int32_t *src = pass == 0 ? li : hi;
+        if (!src) continue;
+        std::vector<int32_t> lmflag(N ? N : 1, 0), sel;
+        for (int j = 0; j < m; ++j) { lmflag[c->meas_host[j]] = src[j] ? 1 : 0; if (src[j]) sel.push_back(j); }
+        PRE3_HIP(hipMemcpy(pass == 0 ? c->lm.li : c->lm.hi, lmflag.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice));
+        if (m) PRE3_HIP(hipMemcpy(pass == 0 ? c->li_meas : c->hi_meas, src, sizeof(int32_t) * m, hipMemcpyHostToDevice));
+        if (!sel.empty()) PRE3_HIP(hipMemcpy(c->sel_rows, sel.data(), sizeof(int32_t) * sel.size(), hipMemcpyHostToDevice));
+        int32_t cnt = (int32_t)sel.size();
+        PRE3_HIP(hipMemcpy(c->stats + (pass == 0 ? 4 : 5), &cnt, sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    return PRE3_OK;
+}
+
+int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, const double *z, int n_draw, int k, const int32_t *hyp,
+              double threshold, int early_exit, double chi2, int32_t stats[8])
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_TRY(pre3_predict(c, u));                                   // mono_slam.m:153
+    PRE3_TRY(pre3_project(c, PRE3_X_K_KM1, 1));                     // search_IC_matches.m:31-32
+    PRE3_TRY(pre3_innovation(c));                                   // search_IC_matches.m:33-44
+    PRE3_TRY(pre3_set_measurements(c, m, meas_idx, z));             // matching_sift_based.m:131-134 outcome
+    int32_t st[8] = { -1, 0, 0, 0, 0, 0, 0, 0 };
+    if (m >= k && m > 0) {
+        PRE3_TRY(pre3_ransac(c, n_draw, k, hyp, threshold, early_exit, nullptr, nullptr, st));   // mono_slam.m:178
+        st[4] = c->pinned_stats[4];
+    } else {
+        int32_t zero = 0;
+        PRE3_HIP(hipMemcpyAsync(c->stats + 4, &zero, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        PRE3_HIP(hipStreamSynchronize(c->stream));
+    }
+    PRE3_TRY(pre3_update_li(c));                                    // mono_slam.m:181
+    PRE3_TRY(pre3_rescue(c, chi2, nullptr));                        // mono_slam.m:184
+    PRE3_TRY(pre3_update_hi(c));                                    // mono_slam.m:187
+    st[5] = c->pinned_stats[5];
+    if (stats) for (int i = 0; i < 8; ++i) stats[i] = st[i];
+    return PRE3_OK;
+}
+
+// ---- stateless update.m drop-in ---------------------------------------------------------------------
+int pre3_update_ell(int device, int dtype, int n, int r, const double *x, const double *P, int width, const int32_t *nnz, const int32_t *col,
+                    const double *val, const double *R, const double *z, const double *h, double *x_out, double *P_out, double *K_out)
+{
+    PRE3_CHECK(n >= 13 && r >= 0 && x && P && x_out && P_out, PRE3_E_ARG, "pre3_update_ell: bad arguments");
+    PRE3_CHECK(r == 0 || (nnz && col && val && z && h && width >= 1), PRE3_E_ARG, "pre3_update_ell: null row data");
+    if (r == 0) {            // update.m:50-55
+        if (x_out != x) memcpy(x_out, x, sizeof(double) * n);
+        if (P_out != P) memcpy(P_out, P, sizeof(double) * (size_t)n * n);
+        int nd = 0;
+        if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) { set_error("no HIP device available (libpre3 has no CPU fallback)"); return PRE3_E_NODEVICE; }
+        return PRE3_OK;
+    }
+    for (int a = 0; a < r; ++a) {
+        PRE3_CHECK(nnz[a] >= 0 && nnz[a] <= width && nnz[a] <= ELLW, PRE3_E_ARG, "pre3_update_ell: row %d has %d non-zeros (max %d)", a, nnz[a], ELLW);
+        for (int t = 0; t < nnz[a]; ++t) PRE3_CHECK(col[a * width + t] >= 0 && col[a * width + t] < n, PRE3_E_ARG, "pre3_update_ell: column index out of range in row %d", a);
+    }
+    // a throw-away context sized for this call: capacity in "landmarks" such that 13+6*cap >= n and 2*cap >= r
+    int capL = std::max((n - 13 + 5) / 6, (r + 1) / 2);
+    if (capL < 1) capL = 1;
+    pre3_ctx *c = nullptr;
+    PRE3_TRY(pre3_create(&c, device, dtype, capL, 1));
+    int rc = PRE3_OK;
+    do {
+        c->n = n; c->N = 0;
+        c->x_valid[PRE3_X_K_KM1] = true;
+        if ((rc = pre3_set_state(c, PRE3_X_K_KM1, n, x, P)) != PRE3_OK) break;
+        int r_pad = round_up(r, NB);
+        std::vector<int32_t> hc((size_t)r_pad * ELLW, 0);
+        std::vector<double> hv((size_t)r_pad * ELLW, 0.0), nu(r_pad, 0.0);
+        for (int a = 0; a < r; ++a) {
+            for (int t = 0; t < nnz[a]; ++t) { hc[(size_t)a * ELLW + t] = col[a * width + t]; hv[(size_t)a * ELLW + t] = val[a * width + t]; }
+            nu[a] = z[a] - h[a];
+        }
+        if (hipMemcpy(c->row_col, hc.data(), sizeof(int32_t) * hc.size(), hipMemcpyHostToDevice) != hipSuccess) { rc = PRE3_E_HIP; set_error("copy failed"); break; }
+        if (dtype == PRE3_F64) {
+            if (hipMemcpy(c->row_val, hv.data(), sizeof(double) * hv.size(), hipMemcpyHostToDevice) != hipSuccess) { rc = PRE3_E_HIP; break; }
+        } else {
+            std::vector<float> hf(hv.begin(), hv.end());
+            if (hipMemcpy(c->row_val, hf.data(), sizeof(float) * hf.size(), hipMemcpyHostToDevice) != hipSuccess) { rc = PRE3_E_HIP; break; }
+        }
+        if (hipMemcpy(c->row_nu, nu.data(), sizeof(double) * r_pad, hipMemcpyHostToDevice) != hipSuccess) { rc = PRE3_E_HIP; break; }
+        if (R) {
+            if ((rc = dmalloc_bytes(&c->Rdense, (size_t)r * r * c->esz)) != PRE3_OK) break;
+            if (dtype == PRE3_F64) { if (hipMemcpy(c->Rdense, R, sizeof(double) * r * r, hipMemcpyHostToDevice) != hipSuccess) { rc = PRE3_E_HIP; break; } }
+            else { std::vector<float> rf(R, R + (size_t)r * r); if (hipMemcpy(c->Rdense, rf.data(), sizeof(float) * rf.size(), hipMemcpyHostToDevice) != hipSuccess) { rc = PRE3_E_HIP; break; } }
+        }
+        void *Kt = nullptr;
+        if (K_out) { if ((rc = dmalloc_bytes(&Kt, (size_t)r_pad * c->ldw * c->esz)) != PRE3_OK) break; }
+        rc = run_update(c, PRE3_X_K_KM1, r, R != nullptr, Kt);
+        if (rc == PRE3_OK) { c->x_valid[PRE3_X_K_K] = true; c->p_which = PRE3_X_K_K; rc = pre3_get_state(c, PRE3_X_K_K, n, x_out, P_out); }
+        if (rc == PRE3_OK && K_out) {
+            // Kt (r x ldw, T) -> K_out (n x r column-major) : K(i,a) = Kt[a][i]
+            if (dtype == PRE3_F64) {
+                if (hipMemcpy2D(K_out, sizeof(double) * n, Kt, sizeof(double) * c->ldw, sizeof(double) * n, r, hipMemcpyDeviceToHost) != hipSuccess) rc = PRE3_E_HIP;
+            } else {
+                std::vector<float> kf((size_t)r * n);
+                if (hipMemcpy2D(kf.data(), sizeof(float) * n, Kt, sizeof(float) * c->ldw, sizeof(float) * n, r, hipMemcpyDeviceToHost) != hipSuccess) rc = PRE3_E_HIP;
+                else for (size_t i = 0; i < kf.size(); ++i) K_out[i] = kf[i];
+            }
+        }
+        if (Kt) (void)hipFree(Kt);
+    } while (0);
+    pre3_destroy(c);
+    return rc;
+}
+
+// ---- matcher ------------------------------------------------------------------------------------------
+int pre3_siftmatch_merge(int cls, int G, int K1, const double *best, const double *second, const int32_t *arg, double thresh_d,
+                         double *pairs_out, double *score_out, int *M_out)
+{
+    PRE3_CHECK(G >= 1 && K1 >= 0 && M_out, PRE3_E_ARG, "pre3_siftmatch_merge: bad arguments");
+    PRE3_CHECK(K1 == 0 || (best && second && arg && pairs_out), PRE3_E_ARG, "pre3_siftmatch_merge: null pointer");
+    const float thresh = (float)thresh_d;      // the gateway passes its double into a float parameter (siftmatch.c:208-216)
+    int M = 0;
+    for (int k1 = 0; k1 < K1; ++k1) {
+        double B = 0, S2 = 0; int K = -1;
+        for (int g = 0; g < G; ++g) {
+            double ob = best[(size_t)g * K1 + k1], os = second[(size_t)g * K1 + k1]; int ok = arg[(size_t)g * K1 + k1];
+            if (ok < 0) continue;
+            if (K < 0) { B = ob; S2 = os; K = ok; continue; }
+            if (ob < B || (ob == B && ok < K)) { S2 = os < B ? os : B; B = ob; K = ok; }
+            else { S2 = ob < S2 ? ob : S2; }
+        }
+        if (K < 0) continue;
+        // Lowe's ratio test in float (siftmatch.c:122); integer classes convert int -> float
+        float fb, fs;
+        if (cls == 1) { fb = (float)B; fs = (float)S2; }
+        else if (cls >= 2) { fb = (float)(int)B; fs = (float)(int)S2; }
+        else { fb = (float)B; fs = (float)S2; }
+        if (thresh * fb <= fs) {
+            pairs_out[2 * M] = k1 + 1; pairs_out[2 * M + 1] = K + 1;
+            if (score_out) score_out[M] = B;
+            ++M;
+        }
+    }
+    *M_out = M;
+    return PRE3_OK;
+}
+
+int pre3_siftmatch_partial(int device, int cls, int ND, int K1, const void *L1, int K2_local, const void *L2_local, int k2_offset,
+                           double *best, double *second, int32_t *arg)
+{
+    return match_partial(device, cls, ND, K1, L1, K2_local, L2_local, k2_offset, best, second, arg);
+}
+
+static int siftmatch_any(int device, int cls, int ND, int K1, const void *L1, int K2, const void *L2, double thresh, double *pairs_out,
+                         double *score_out, int *M_out)
+{
+    PRE3_CHECK(M_out != nullptr, PRE3_E_ARG, "siftmatch: null M_out");
+    *M_out = 0;
+    PRE3_CHECK(ND > 0 && K1 >= 0 && K2 >= 0, PRE3_E_ARG, "siftmatch: bad sizes");
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) { set_error("no HIP device available (libpre3 has no CPU fallback)"); return PRE3_E_NODEVICE; }
+    if (K1 == 0) return PRE3_OK;
+    std::vector<double> b(K1), s(K1); std::vector<int32_t> a(K1);
+    PRE3_TRY(match_partial(device, cls, ND, K1, L1, K2, L2, 0, b.data(), s.data(), a.data()));
+    return pre3_siftmatch_merge(cls, 1, K1, b.data(), s.data(), a.data(), thresh, pairs_out, score_out, M_out);
+}
+
+int pre3_siftmatch_f64(int device, int ND, int K1, const double *L1, int K2, const double *L2, double thresh, double *pairs_out, double *score_out, int *M_out)
+{ return siftmatch_any(device, 0, ND, K1, L1, K2, L2, thresh, pairs_out, score_out, M_out); }
+int pre3_siftmatch_f32(int device, int ND, int K1, const float *L1, int K2, const float *L2, double thresh, double *pairs_out, double *score_out, int *M_out)
+{ return siftmatch_any(device, 1, ND, K1, L1, K2, L2, thresh, pairs_out, score_out, M_out); }
+int pre3_siftmatch_u8(int device, int ND, int K1, const uint8_t *L1, int K2, const uint8_t *L2, double thresh, double *pairs_out, double *score_out, int *M_out)
+{ return siftmatch_any(device, 2, ND, K1, L1, K2, L2, thresh, pairs_out, score_out, M_out); }
+int pre3_siftmatch_i8(int device, int ND, int K1, const int8_t *L1, int K2, const int8_t *L2, double thresh, double *pairs_out, double *score_out, int *M_out)
+{ return siftmatch_any(device, 3, ND, K1, L1, K2, L2, thresh, pairs_out, score_out, M_out); }
+
+int pre3_knn_f64(int device, int D, int N, const double *data, int M, const double *query, int k, double *ids_out, double *dist_out)
+{
+    PRE3_CHECK(data && (M == 0 || (query && ids_out && dist_out)), PRE3_E_ARG, "pre3_knn_f64: null pointer");
+    return knn_run(device, D, N, data, M, query, k, ids_out, dist_out);
+}
+
+// ---- measurement hooks ---------------------------------------------------------------------------------
+int pre3_timer_start(pre3_ctx *c)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_HIP(hipEventRecord(c->t0, c->stream));
+    return PRE3_OK;
+}
+
+int pre3_timer_stop(pre3_ctx *c, double *ms_out)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_HIP(hipEventRecord(c->t1, c->stream));
+    PRE3_HIP(hipEventSynchronize(c->t1));
+    float ms = 0;
+    PRE3_HIP(hipEventElapsedTime(&ms, c->t0, c->t1));
+    if (ms_out) *ms_out = ms;
+    return PRE3_OK;
+}
+
+int pre3_kernel_timing(pre3_ctx *c, int enable)
+{
+    PRE3_TRY(check_ctx(c));
+    c->kt.enabled = enable != 0; c->kt.used = 0; c->kt.flops = 0; c->kt.bytes = 0;
+    return PRE3_OK;
+}
+
+int pre3_kernel_timing_read(pre3_ctx *c, int *launches_out, double *total_ms_out, double *flops_out, double *bytes_out)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_HIP(hipStreamSynchronize(c->stream));
+    double tot = 0;
+    for (int i = 0; i + 1 < c->kt.used; i += 2) { float ms = 0; PRE3_HIP(hipEventElapsedTime(&ms, c->kt.ev[i], c->kt.ev[i + 1])); tot += ms; }
+    if (launches_out) *launches_out = c->kt.used / 2;
+    if (total_ms_out) *total_ms_out = tot;
+    if (flops_out) *flops_out = c->kt.flops;
+    if (bytes_out) *bytes_out = c->kt.bytes;
+    c->kt.used = 0; c->kt.flops = 0; c->kt.bytes = 0;
+    return PRE3_OK;
+}
+
+int pre3_bench_downdate(pre3_ctx *c, int r, int reps, double *ms_per_launch_out)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(r >= 1 && round_up(r, NB) <= c->rcap && reps >= 1, PRE3_E_ARG, "pre3_bench_downdate: bad r/reps");
+    PRE3_CHECK(c->n > 0, PRE3_E_STATE, "pre3_bench_downdate: no map/state set");
+    int r_pad = round_up(r, NB);
+    PRE3_TRY(launch_fill_w(c, r_pad));
+    bool was = c->kt.enabled; c->kt.enabled = false;
+    PRE3_TRY(launch_downdate(c, r, c->W));
+    PRE3_HIP(hipEventRecord(c->t0, c->stream));
+    for (int i = 0; i < reps; ++i) PRE3_TRY(launch_downdate(c, r, c->W));
+    PRE3_HIP(hipEventRecord(c->t1, c->stream));
+    PRE3_HIP(hipEventSynchronize(c->t1));
+    float ms = 0; PRE3_HIP(hipEventElapsedTime(&ms, c->t0, c->t1));
+    if (ms_per_launch_out) *ms_per_launch_out = ms / reps;
+    c->kt.enabled = was;
+    return PRE3_OK;
+}
+
+// matcher roofline/bench probe (inputs resident in HBM); not part of the reference-shaped API
+PRE3_API void *pre3_match_bench_create(int device, int ND, int K1, const uint8_t *L1, int K2, const uint8_t *L2)
+{
+    if (hipSetDevice(device) != hipSuccess) { set_error("no HIP device %d", device); return nullptr; }
+    return match_bench_create(ND, K1, L1, K2, L2);
+}
+PRE3_API int pre3_match_bench_run(void *h, int reps, double *ms_per) { return h ? match_bench_run(h, reps, ms_per) : PRE3_E_ARG; }
+PRE3_API int pre3_match_bench_fetch(void *h, double *best, double *second, int32_t *arg) { return h ? match_bench_fetch(h, best, second, arg) : PRE3_E_ARG; }
+PRE3_API void pre3_match_bench_destroy(void *h) { if (h) match_bench_destroy(h); }
+
+}  // extern "C"

@@ -1,0 +1,705 @@
+// pre3_geom.hip -- per-landmark / per-hypothesis kernels of the 1-point-RANSAC EKF step (gfx950).
+//
+// These stages are gather- and latency-bound (a few hundred KB per launch), not GEMMs: one lane per
+// landmark (K2/K3), one workgroup per hypothesis with a wavefront-shuffle min/count reduction (K4/K5),
+// one wavefront for the sequential termination replay (K6).  All camera geometry is fp64 regardless of
+// the covariance dtype; only reads of P / H*P are typed.
+//
+// Reference statements reproduced (paths under matlab_code/):
+//   predict        predict_state_and_covariance.m:59-143, aux_code/odometry_model.m:44-68
+//   project        predict_camera_measurements.m:27-68, hi_inverse_depth.m:33-85, hi_cartesian.m:33-81
+//   jacobian       calculate_Hi_inverse_depth_my_version.m:46-183, calculate_Hi_cartesian_my_version.m
+//   innovation     search_IC_matches.m:33-44; rescue gate @ekf_filter/rescue_hi_inliers.m:35-46
+//   window gate    matching_sift_based.m:119-134
+//   ransac         ransac_hypotheses.m:40-80, compute_hypothesis_support_fast.m:33-110
+#include "pre3_internal.h"
+
+namespace pre3 {
+
+struct CamD { double f, Cx, Cy, k1, k2, nRows, nCols; };
+struct U7 { double v[7]; };
+
+// ------------------------------------------------------------------------------------------------
+// device math (fp64)
+// ------------------------------------------------------------------------------------------------
+
+// q2r.m:29-36
+__device__ inline void d_q2r(const double *q, double *R)
+{
+    double r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = r * r + x * x - y * y - z * z; R[1] = 2 * (x * y - r * z);           R[2] = 2 * (z * x + r * y);
+    R[3] = 2 * (x * y + r * z);           R[4] = r * r - x * x + y * y - z * z; R[5] = 2 * (y * z - r * x);
+    R[6] = 2 * (z * x - r * y);           R[7] = 2 * (y * z + r * x);           R[8] = r * r - x * x - y * y + z * z;
+}
+
+// slamToolbox .../Rotations/q2R.m:18-34
+__device__ inline void d_q2R_sola(const double *q, double *R)
+{
+    double a = q[0], b = q[1], c = q[2], d = q[3];
+    double aa = a * a, ab = 2 * a * b, ac = 2 * a * c, ad = 2 * a * d;
+    double bb = b * b, bc = 2 * b * c, bd = 2 * b * d, cc = c * c, cd = 2 * c * d, dd = d * d;
+    R[0] = aa + bb - cc - dd; R[1] = bc - ad;           R[2] = bd + ac;
+    R[3] = bc + ad;           R[4] = aa - bb + cc - dd; R[5] = cd - ab;
+    R[6] = bd - ac;           R[7] = cd + ab;           R[8] = aa - bb - cc + dd;
+}
+
+// normJac.m:27-38
+__device__ inline void d_normjac(const double *q, double *J)
+{
+    double r = q[0], x = q[1], y = q[2], z = q[3];
+    double s = pow(r * r + x * x + y * y + z * z, -1.5);
+    J[0] = s * (x * x + y * y + z * z); J[1] = s * (-r * x); J[2] = s * (-r * y); J[3] = s * (-r * z);
+    J[4] = s * (-x * r); J[5] = s * (r * r + y * y + z * z); J[6] = s * (-x * y); J[7] = s * (-x * z);
+    J[8] = s * (-y * r); J[9] = s * (-y * x); J[10] = s * (r * r + x * x + z * z); J[11] = s * (-y * z);
+    J[12] = s * (-z * r); J[13] = s * (-z * x); J[14] = s * (-z * y); J[15] = s * (r * r + x * x + y * y);
+}
+
+// hu_my_version.m:41-42 + distort_fm_my_version.m:52-61
+__device__ inline void d_pinhole_distort(const double *hrl, const CamD &cam, double *uvd)
+{
+    double uu = cam.Cx + (hrl[0] / hrl[2]) * cam.f;
+    double vu = cam.Cy + (hrl[1] / hrl[2]) * cam.f;
+    double xu = (uu - cam.Cx) / cam.f, yu = (vu - cam.Cy) / cam.f;
+    double ru = sqrt(xu * xu + yu * yu);
+    double r2 = ru * ru;
+    double D = 1 + cam.k1 * r2 + cam.k2 * (r2 * r2);
+    uvd[0] = xu * D * cam.f + cam.Cx;
+    uvd[1] = yu * D * cam.f + cam.Cy;
+}
+
+// direction vector of a landmark in the world frame before rotation: (y-r)*rho + m(theta,phi)  or  y-r
+__device__ inline void d_ray(int type, const double *y, const double *t, double *v)
+{
+    if (type == PRE3_INVDEPTH) {
+        double cphi = cos(y[4]);
+        double mi0 = cphi * sin(y[3]), mi1 = -sin(y[4]), mi2 = cphi * cos(y[3]);   // m.m:38-40
+        v[0] = (y[0] - t[0]) * y[5] + mi0;
+        v[1] = (y[1] - t[1]) * y[5] + mi1;
+        v[2] = (y[2] - t[2]) * y[5] + mi2;
+    } else {
+        v[0] = y[0] - t[0]; v[1] = y[1] - t[1]; v[2] = y[2] - t[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 predict: x_k_km1 from x_k_k and u; P rows/cols 3..6 and the 7x7 pose block in place.
+// F = blkdiag(I3, Qq1, I6) and Jnorm = blkdiag(I3, Jn, I..) only touch rows/cols 3..6, so the
+// reference's full 13 x n products reduce to a 4 x n strip (multiplications by 1/0 are exact).
+// ------------------------------------------------------------------------------------------------
+
+// process noise Pn (7x7), predict_state_and_covariance.m:98-102 (constant)
+__device__ inline void d_process_noise(double *Pn)
+{
+    for (int i = 0; i < 49; ++i) Pn[i] = 0;
+    double sx = 0.01 / 3; sx = sx * sx;
+    Pn[0] = Pn[8] = Pn[16] = sx;
+    const double PI = 3.141592653589793238462643383279502884;
+    double a = 0.24 / 2 * PI / 180;
+    double e[3] = { a * 1, a * 0.1, a * 1 };
+    double sr = sin(e[0] / 2), sp = sin(e[1] / 2), sy = sin(e[2] / 2);
+    double cr = cos(e[0] / 2), cp = cos(e[1] / 2), cy = cos(e[2] / 2);
+    double Qe[12] = {   // e2q.m:25-30
+        0.5 * (-cy * cp * sr + sy * sp * cr), 0.5 * (-cy * sp * cr + sy * cp * sr), 0.5 * (-sy * cp * cr + cy * sp * sr),
+        0.5 * ( cy * cp * cr + sy * sp * sr), 0.5 * (-cy * sp * sr - sy * cp * cr), 0.5 * (-sy * cp * sr - cy * sp * cr),
+        0.5 * (-cy * sp * sr + sy * cp * cr), 0.5 * ( cy * cp * cr - sy * sp * sr), 0.5 * (-sy * sp * cr + cy * cp * sr),
+        0.5 * (-sy * cp * sr - cy * sp * cr), 0.5 * (-cy * cp * sr - sy * sp * cr), 0.5 * ( cy * cp * cr + sy * sp * sr) };
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double s = 0;
+            for (int t = 0; t < 3; ++t) s += (Qe[i * 3 + t] * (e[t] * e[t])) * Qe[j * 3 + t];
+            Pn[(3 + i) * 7 + 3 + j] = s;
+        }
+}
+
+// pred_params layout: [0..15] A4 = Qq1, [16..31] Jn, [32..80] Q7 = G Pn G' (7x7)
+__global__ void k_predict_x(const double *__restrict__ x_in, double *__restrict__ x_out, int n, U7 u, double *__restrict__ params)
+{
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    // landmarks copied (predict_state_and_covariance.m:79)
+    for (int i = 13 + tid; i < n; i += gridDim.x * blockDim.x) x_out[i] = x_in[i];
+    if (tid != 0) return;
+    const double *q = x_in + 3;
+    double R[9];
+    d_q2R_sola(q, R);
+    double xo[7];
+    for (int i = 0; i < 3; ++i) xo[i] = x_in[i] + (R[i * 3] * u.v[0] + R[i * 3 + 1] * u.v[1] + R[i * 3 + 2] * u.v[2]);
+    // qProd.m:16-33
+    double a = q[0], b = q[1], c = q[2], d = q[3];
+    double w = u.v[3], x = u.v[4], y = u.v[5], z = u.v[6];
+    xo[3] = a * w - b * x - c * y - d * z;
+    xo[4] = a * x + b * w + c * z - d * y;
+    xo[5] = a * y - b * z + c * w + d * x;
+    xo[6] = a * z + b * y - c * x + d * w;
+    double Qq1[16] = { w, -x, -y, -z,  x, w, z, -y,  y, -z, w, x,  z, y, -x, w };
+    double Qq2[16] = { a, -b, -c, -d,  b, a, -d, c,  c, d, a, -b,  d, -c, b, a };
+    // G = [R 0; 0 Qq2] (7x7 non-zero part), Q7 = G Pn G'
+    double G[49], Pn[49], GP[49];
+    for (int i = 0; i < 49; ++i) G[i] = 0;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) G[i * 7 + j] = R[i * 3 + j];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) G[(3 + i) * 7 + 3 + j] = Qq2[i * 4 + j];
+    d_process_noise(Pn);
+    for (int i = 0; i < 7; ++i)
+        for (int j = 0; j < 7; ++j) {
+            double s = 0;
+            for (int t = 0; t < 7; ++t) s += G[i * 7 + t] * Pn[t * 7 + j];
+            GP[i * 7 + j] = s;
+        }
+    for (int i = 0; i < 7; ++i)
+        for (int j = 0; j < 7; ++j) {
+            double s = 0;
+            for (int t = 0; t < 7; ++t) s += GP[i * 7 + t] * G[j * 7 + t];
+            params[32 + i * 7 + j] = s;
+        }
+    double Jn[16];
+    d_normjac(xo + 3, Jn);     // at the un-normalised q (predict_state_and_covariance.m:137)
+    for (int i = 0; i < 16; ++i) { params[i] = Qq1[i]; params[16 + i] = Jn[i]; }
+    double nq = sqrt(xo[3] * xo[3] + xo[4] * xo[4] + xo[5] * xo[5] + xo[6] * xo[6]);
+    for (int i = 0; i < 3; ++i) x_out[i] = xo[i];
+    for (int i = 0; i < 4; ++i) x_out[3 + i] = xo[3 + i] / nq;
+    for (int i = 7; i < 13; ++i) x_out[i] = 0;
+}
+
+// One lane per column j: v = P[3:7, j]  ->  Jn*(Qq1*v [+ Q[3:7,j]]) written to P[3:7,j] and P[j,3:7].
+// Block 0 also owns the 7x7 pose block.
+template <typename T>
+__global__ void k_predict_P(T *__restrict__ P, int n, int ld, const double *__restrict__ params)
+{
+    __shared__ double sQq1[16], sJn[16], sQ[49];
+    __shared__ double corner[49];      // old P[0:7,0:7]
+    if (threadIdx.x < 16) { sQq1[threadIdx.x] = params[threadIdx.x]; sJn[threadIdx.x] = params[16 + threadIdx.x]; }
+    if (threadIdx.x < 49) sQ[threadIdx.x] = params[32 + threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x < 49) corner[threadIdx.x] = (double)P[(threadIdx.x / 7) * ld + (threadIdx.x % 7)];
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[4] = { 0, 0, 0, 0 };
+    if (j >= 7 && j < n) for (int t = 0; t < 4; ++t) v[t] = (double)P[(3 + t) * ld + j];
+    __syncthreads();
+    if (j >= 7 && j < n) {
+        double a[4], b[4];
+        for (int i = 0; i < 4; ++i) a[i] = sQq1[i * 4] * v[0] + sQq1[i * 4 + 1] * v[1] + sQq1[i * 4 + 2] * v[2] + sQq1[i * 4 + 3] * v[3];
+        for (int i = 0; i < 4; ++i) b[i] = sJn[i * 4] * a[0] + sJn[i * 4 + 1] * a[1] + sJn[i * 4 + 2] * a[2] + sJn[i * 4 + 3] * a[3];
+        for (int i = 0; i < 4; ++i) { P[(3 + i) * ld + j] = (T)b[i]; P[j * ld + 3 + i] = (T)b[i]; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // pose block: C = F7 * P7 * F7' + Q7 with F7 = blkdiag(I3, Qq1); then J7 C J7', J7 = blkdiag(I3, Jn)
+        double F7[49], J7[49], T1[49], C[49];
+        for (int i = 0; i < 49; ++i) { F7[i] = 0; J7[i] = 0; }
+        for (int i = 0; i < 3; ++i) { F7[i * 7 + i] = 1; J7[i * 7 + i] = 1; }
+        for (int i = 0; i < 4; ++i) for (int k = 0; k < 4; ++k) { F7[(3 + i) * 7 + 3 + k] = sQq1[i * 4 + k]; J7[(3 + i) * 7 + 3 + k] = sJn[i * 4 + k]; }
+        for (int i = 0; i < 7; ++i) for (int k = 0; k < 7; ++k) { double s = 0; for (int t = 0; t < 7; ++t) s += F7[i * 7 + t] * corner[t * 7 + k]; T1[i * 7 + k] = s; }
+        for (int i = 0; i < 7; ++i) for (int k = 0; k < 7; ++k) { double s = 0; for (int t = 0; t < 7; ++t) s += T1[i * 7 + t] * F7[k * 7 + t]; C[i * 7 + k] = s + sQ[i * 7 + k]; }
+        for (int i = 0; i < 7; ++i) for (int k = 0; k < 7; ++k) { double s = 0; for (int t = 0; t < 7; ++t) s += J7[i * 7 + t] * C[t * 7 + k]; T1[i * 7 + k] = s; }
+        for (int i = 0; i < 7; ++i) for (int k = 0; k < 7; ++k) { double s = 0; for (int t = 0; t < 7; ++t) s += T1[i * 7 + t] * J7[k * 7 + t]; P[i * ld + k] = (T)s; }
+    }
+}
+
+// rows/cols 3..6 <- Jn (update.m:42-46).  params[16..31] = Jn.
+template <typename T>
+__global__ void k_jnorm_P(T *__restrict__ P, int n, int ld, const double *__restrict__ params)
+{
+    __shared__ double sJn[16];
+    __shared__ double corner[16];
+    if (threadIdx.x < 16) sJn[threadIdx.x] = params[16 + threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x < 16) corner[threadIdx.x] = (double)P[(3 + threadIdx.x / 4) * ld + 3 + (threadIdx.x % 4)];
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    bool strip = j < n && (j < 3 || j >= 7);
+    double v[4] = { 0, 0, 0, 0 };
+    if (strip) for (int t = 0; t < 4; ++t) v[t] = (double)P[(3 + t) * ld + j];
+    __syncthreads();
+    if (strip) {
+        for (int i = 0; i < 4; ++i) {
+            double b = sJn[i * 4] * v[0] + sJn[i * 4 + 1] * v[1] + sJn[i * 4 + 2] * v[2] + sJn[i * 4 + 3] * v[3];
+            P[(3 + i) * ld + j] = (T)b; P[j * ld + 3 + i] = (T)b;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double T1[16];
+        for (int i = 0; i < 4; ++i) for (int k = 0; k < 4; ++k) { double s = 0; for (int t = 0; t < 4; ++t) s += sJn[i * 4 + t] * corner[t * 4 + k]; T1[i * 4 + k] = s; }
+        for (int i = 0; i < 4; ++i) for (int k = 0; k < 4; ++k) { double s = 0; for (int t = 0; t < 4; ++t) s += T1[i * 4 + t] * sJn[k * 4 + t]; P[(3 + i) * ld + 3 + k] = (T)s; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 project + Jacobian: one lane per landmark
+// ------------------------------------------------------------------------------------------------
+__global__ void k_project(int N, const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
+                          const double *__restrict__ x, CamD cam, int clear_first,
+                          double *__restrict__ h, int32_t *__restrict__ has_h, double *__restrict__ Hc, double *__restrict__ Hl)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    int type = lm_type[i];
+    const double *y = x + lm_off[i];
+    double Rwc[9];
+    d_q2r(x + 3, Rwc);
+    double v[3], hrl[3];
+    d_ray(type, y, x, v);
+    // r_cw = r_wc' (hi_inverse_depth.m:33); hi_cartesian.m:33 uses inv(r_wc) = r_wc' to rounding
+    for (int c = 0; c < 3; ++c) hrl[c] = Rwc[0 * 3 + c] * v[0] + Rwc[1 * 3 + c] * v[1] + Rwc[2 * 3 + c] * v[2];
+    const double PI = 3.141592653589793238462643383279502884;
+    double ax = atan2(hrl[0], hrl[2]) * 180 / PI, ay = atan2(hrl[1], hrl[2]) * 180 / PI;
+    bool ok = !(ax < -60 || ax > 60 || ay < -60 || ay > 60);
+    double uvd[2] = { 0, 0 };
+    if (ok) {
+        d_pinhole_distort(hrl, cam, uvd);
+        ok = (uvd[0] > 0) && (uvd[0] < cam.nCols) && (uvd[1] > 0) && (uvd[1] < cam.nRows);
+    }
+    int had = clear_first ? 0 : has_h[i];
+    double zi[2];
+    if (ok) { zi[0] = uvd[0]; zi[1] = uvd[1]; h[2 * i] = zi[0]; h[2 * i + 1] = zi[1]; }
+    else if (had) { zi[0] = h[2 * i]; zi[1] = h[2 * i + 1]; }      // stale h kept (quirk Q7)
+    int now = ok || had;
+    has_h[i] = now;
+    if (!now) return;
+    // ---- Jacobian (calculate_Hi_*_my_version.m); distortion Jacobian at the stored h (quirk Q8)
+    double u_ = zi[0], v_ = zi[1];
+    double xx = u_ - cam.Cx, yy = v_ - cam.Cy, f2 = cam.f * cam.f;
+    double r2 = (xx * xx + yy * yy) / f2, r4 = r2 * r2;
+    double g = cam.k1 + 2 * cam.k2 * r2, D0 = 1 + cam.k1 * r2 + cam.k2 * r4;
+    double Jd[4] = { D0 + xx * g * (2 * xx / f2), xx * g * (2 * yy / f2), yy * g * (2 * xx / f2), D0 + yy * g * (2 * yy / f2) };
+    // hc = Rrw * a  with Rrw = inv(q2r(q)) = q2r(q)' to rounding
+    double hc[3] = { hrl[0], hrl[1], hrl[2] };
+    double f = cam.f;
+    double dhu[6] = { f / hc[2], 0, -hc[0] * f / (hc[2] * hc[2]),  0, f / hc[2], -hc[1] * f / (hc[2] * hc[2]) };
+    double A[6];   // dh_dhrl = dhd_dhu * dhu_dhrl (2x3)
+    for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) A[r * 3 + c] = Jd[r * 2] * dhu[c] + Jd[r * 2 + 1] * dhu[3 + c];
+    double Rrw[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rrw[r * 3 + c] = Rwc[c * 3 + r];
+    double sc = (type == PRE3_INVDEPTH) ? y[5] : 1.0;
+    double *hc_out = Hc + 14 * i, *hl_out = Hl + 12 * i;
+    // dh_drw = A * (-Rrw*rho)
+    for (int r = 0; r < 2; ++r)
+        for (int c = 0; c < 3; ++c)
+            hc_out[r * 7 + c] = A[r * 3] * (-Rrw[c] * sc) + A[r * 3 + 1] * (-Rrw[3 + c] * sc) + A[r * 3 + 2] * (-Rrw[6 + c] * sc);
+    // dhrl_dqwr = dRq_times_a_by_dq(qconj(q), a) * diag(1,-1,-1,-1)   (dRq_times_a_by_dq.m:29-101)
+    double q0 = x[3], qx = -x[4], qy = -x[5], qz = -x[6];
+    double a0 = v[0], a1 = v[1], a2 = v[2];
+    double dq[12];
+    dq[0] = 2 * q0 * a0 - 2 * qz * a1 + 2 * qy * a2;  dq[4] = 2 * qz * a0 + 2 * q0 * a1 - 2 * qx * a2;  dq[8]  = -2 * qy * a0 + 2 * qx * a1 + 2 * q0 * a2;
+    dq[1] = 2 * qx * a0 + 2 * qy * a1 + 2 * qz * a2;  dq[5] = 2 * qy * a0 - 2 * qx * a1 - 2 * q0 * a2;  dq[9]  = 2 * qz * a0 + 2 * q0 * a1 - 2 * qx * a2;
+    dq[2] = -2 * qy * a0 + 2 * qx * a1 + 2 * q0 * a2; dq[6] = 2 * qx * a0 + 2 * qy * a1 + 2 * qz * a2;  dq[10] = -2 * q0 * a0 + 2 * qz * a1 - 2 * qy * a2;
+    dq[3] = -2 * qz * a0 - 2 * q0 * a1 + 2 * qx * a2; dq[7] = 2 * q0 * a0 - 2 * qz * a1 + 2 * qy * a2;  dq[11] = 2 * qx * a0 + 2 * qy * a1 + 2 * qz * a2;
+    for (int r = 0; r < 3; ++r) { dq[r * 4 + 1] = -dq[r * 4 + 1]; dq[r * 4 + 2] = -dq[r * 4 + 2]; dq[r * 4 + 3] = -dq[r * 4 + 3]; }
+    for (int r = 0; r < 2; ++r)
+        for (int c = 0; c < 4; ++c)
+            hc_out[r * 7 + 3 + c] = A[r * 3] * dq[c] + A[r * 3 + 1] * dq[4 + c] + A[r * 3 + 2] * dq[8 + c];
+    for (int t = 0; t < 12; ++t) hl_out[t] = 0;
+    if (type == PRE3_INVDEPTH) {
+        double theta = y[3], phi = y[4], lambda = y[5];
+        double dth[3] = { cos(phi) * cos(theta), 0, -cos(phi) * sin(theta) };
+        double dph[3] = { -sin(phi) * sin(theta), -cos(phi), -sin(phi) * cos(theta) };
+        double d3[3] = { y[0] - x[0], y[1] - x[1], y[2] - x[2] };
+        double B[18];
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) B[r * 6 + c] = lambda * Rrw[r * 3 + c];
+            B[r * 6 + 3] = Rrw[r * 3] * dth[0] + Rrw[r * 3 + 1] * dth[1] + Rrw[r * 3 + 2] * dth[2];
+            B[r * 6 + 4] = Rrw[r * 3] * dph[0] + Rrw[r * 3 + 1] * dph[1] + Rrw[r * 3 + 2] * dph[2];
+            B[r * 6 + 5] = Rrw[r * 3] * d3[0] + Rrw[r * 3 + 1] * d3[1] + Rrw[r * 3 + 2] * d3[2];
+        }
+        for (int r = 0; r < 2; ++r) for (int c = 0; c < 6; ++c) hl_out[r * 6 + c] = A[r * 3] * B[c] + A[r * 3 + 1] * B[6 + c] + A[r * 3 + 2] * B[12 + c];
+    } else {
+        for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) hl_out[r * 6 + c] = A[r * 3] * Rrw[c] + A[r * 3 + 1] * Rrw[3 + c] + A[r * 3 + 2] * Rrw[6 + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 innovation covariance / rescue gate: one lane per landmark gathers the 13x13 (10x10) block of P
+// that H_i's non-zeros select.  mode 0: S_i = H P H' + I for predicted landmarks.
+// mode 1 (rescue_hi_inliers.m:35-46): for ic && !li: d2 = nu' inv(H P H') nu < chi2 -> hi flag.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_innovation(int N, const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
+                             const T *__restrict__ P, int ld, const double *__restrict__ Hc, const double *__restrict__ Hl,
+                             const int32_t *__restrict__ has_h, int mode, double chi2,
+                             const double *__restrict__ h, const double *__restrict__ z,
+                             const int32_t *__restrict__ ic, const int32_t *__restrict__ li, int32_t *__restrict__ hi,
+                             double *__restrict__ S, int32_t *__restrict__ has_S)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    if (mode == 0) { if (!has_h[i]) { has_S[i] = 0; return; } }
+    else { if (!(ic[i] == 1 && li[i] == 0)) return; }
+    int d = lm_type[i] == PRE3_INVDEPTH ? 6 : 3;
+    int off = lm_off[i];
+    int nn = 7 + d;
+    double Hr[2][13];
+    for (int r = 0; r < 2; ++r) {
+        for (int c = 0; c < 7; ++c) Hr[r][c] = Hc[14 * i + r * 7 + c];
+        for (int c = 0; c < d; ++c) Hr[r][7 + c] = Hl[12 * i + r * 6 + c];
+    }
+    // HP[r][b] = sum_a H[r][a] P[ia][ib]
+    double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+    for (int b = 0; b < nn; ++b) {
+        int ib = b < 7 ? b : off + b - 7;
+        double hp0 = 0, hp1 = 0;
+        for (int a = 0; a < nn; ++a) {
+            int ia = a < 7 ? a : off + a - 7;
+            double p = (double)P[(size_t)ia * ld + ib];
+            hp0 += Hr[0][a] * p; hp1 += Hr[1][a] * p;
+        }
+        s00 += hp0 * Hr[0][b]; s01 += hp0 * Hr[1][b];
+        s10 += hp1 * Hr[0][b]; s11 += hp1 * Hr[1][b];
+    }
+    if (mode == 0) {
+        S[4 * i + 0] = s00 + 1; S[4 * i + 1] = s01; S[4 * i + 2] = s10; S[4 * i + 3] = s11 + 1;
+        has_S[i] = 1;
+    } else {
+        double det = s00 * s11 - s01 * s10;
+        double i00 = s11 / det, i01 = -s01 / det, i10 = -s10 / det, i11 = s00 / det;
+        double n0 = z[2 * i] - h[2 * i], n1 = z[2 * i + 1] - h[2 * i + 1];
+        double t0 = n0 * i00 + n1 * i10, t1 = n0 * i01 + n1 * i11;
+        double d2 = t0 * n0 + t1 * n1;
+        hi[i] = d2 < chi2 ? 1 : 0;
+    }
+}
+
+// matching_sift_based.m:119-134
+__global__ void k_window_gate(int M, const int32_t *__restrict__ pred_idx, const int32_t *__restrict__ k1,
+                              const double *__restrict__ zc, const double *__restrict__ h, const double *__restrict__ S,
+                              const int32_t *__restrict__ has_S, int strict, double *__restrict__ z, int32_t *__restrict__ ic,
+                              int32_t *__restrict__ accept)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= M) return;
+    int lm = pred_idx[k1[c]];
+    int slm = strict ? pred_idx[c] : lm;
+    double half = has_S[slm] ? ceil(3 * sqrt(S[4 * slm])) : 40.0;
+    double dx = zc[2 * c] - h[2 * lm], dy = zc[2 * c + 1] - h[2 * lm + 1];
+    int ok = sqrt(dx * dx + dy * dy) <= half;
+    if (ok) { ic[lm] = 1; z[2 * lm] = zc[2 * c]; z[2 * lm + 1] = zc[2 * c + 1]; }
+    if (accept) accept[c] = ok;
+}
+
+// ------------------------------------------------------------------------------------------------
+// measurement rows in ELL form: row 2s+c of the selected measurement sel[s] (index into meas[])
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_build_rows(int nsel, const int32_t *__restrict__ sel, const int32_t *__restrict__ meas,
+                             const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
+                             const double *__restrict__ Hc, const double *__restrict__ Hl,
+                             const double *__restrict__ z, const double *__restrict__ h,
+                             int32_t *__restrict__ row_col, T *__restrict__ row_val, double *__restrict__ row_nu, int r_pad)
+{
+    int a = blockIdx.x * blockDim.x + threadIdx.x;     // row
+    if (a >= r_pad) return;
+    int32_t *cc = row_col + a * ELLW;
+    T *vv = row_val + a * ELLW;
+    if (a >= 2 * nsel) {
+        for (int t = 0; t < ELLW; ++t) { cc[t] = 0; vv[t] = (T)0; }
+        row_nu[a] = 0;
+        return;
+    }
+    int s = a >> 1, c = a & 1;
+    int i = meas[sel ? sel[s] : s];
+    int d = lm_type[i] == PRE3_INVDEPTH ? 6 : 3;
+    int off = lm_off[i];
+    for (int t = 0; t < 7; ++t) { cc[t] = t; vv[t] = (T)Hc[14 * i + c * 7 + t]; }
+    for (int t = 0; t < 6; ++t) { cc[7 + t] = t < d ? off + t : 0; vv[7 + t] = t < d ? (T)Hl[12 * i + c * 6 + t] : (T)0; }
+    for (int t = 13; t < ELLW; ++t) { cc[t] = 0; vv[t] = (T)0; }
+    row_nu[a] = z[2 * i + c] - h[2 * i + c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4+K5 RANSAC hypothesis state + support: one workgroup per hypothesis.
+//   S_h = G[sel,sel] + I (2k x 2k), w = S_h^-1 nu_h, x_i = x + (H P)[sel,:]' w   (ransac_hypotheses.m:61-63)
+//   support per compute_hypothesis_support_fast.m:33-110 on the rows of x_i the scorer reads.
+// ------------------------------------------------------------------------------------------------
+__device__ inline double wave_min(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ inline int wave_sum(int v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_ransac_score(int hyp_begin, int k, const int32_t *__restrict__ hyp, int m,
+                                                      const int32_t *__restrict__ meas, const int32_t *__restrict__ lm_type,
+                                                      const int32_t *__restrict__ lm_off, const double *__restrict__ x,
+                                                      const T *__restrict__ HP, int ldw, const T *__restrict__ G, int ldg,
+                                                      const double *__restrict__ row_nu, const double *__restrict__ z,
+                                                      CamD cam, double threshold, int32_t *__restrict__ support,
+                                                      uint32_t *__restrict__ masks, int mask_words)
+{
+    extern __shared__ double s_res[];       // [m] residuals, then mask words
+    __shared__ double s_w[2 * MAXK];
+    __shared__ int s_rows[2 * MAXK];
+    __shared__ double s_red[4];
+    __shared__ int s_cnt[4];
+    int hidx = hyp_begin + blockIdx.x;
+    int r = 2 * k;
+    int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) {
+        double A[2 * MAXK][2 * MAXK + 1];
+        int rows[2 * MAXK];
+        for (int s = 0; s < k; ++s) { int j = hyp[hidx * k + s]; rows[2 * s] = 2 * j; rows[2 * s + 1] = 2 * j + 1; }
+        for (int a = 0; a < r; ++a) {
+            for (int b = 0; b < r; ++b) A[a][b] = (double)G[(size_t)rows[a] * ldg + rows[b]] + (a == b ? 1.0 : 0.0);
+            A[a][r] = row_nu[rows[a]];
+        }
+        // Gaussian elimination with partial pivoting (MATLAB inv(S)*nu up to rounding)
+        for (int c = 0; c < r; ++c) {
+            int p = c; double best = fabs(A[c][c]);
+            for (int a = c + 1; a < r; ++a) if (fabs(A[a][c]) > best) { best = fabs(A[a][c]); p = a; }
+            if (p != c) for (int b = c; b <= r; ++b) { double t = A[c][b]; A[c][b] = A[p][b]; A[p][b] = t; }
+            double dinv = 1.0 / A[c][c];
+            for (int a = c + 1; a < r; ++a) {
+                double l = A[a][c] * dinv;
+                for (int b = c; b <= r; ++b) A[a][b] -= l * A[c][b];
+            }
+        }
+        for (int a = r - 1; a >= 0; --a) {
+            double s = A[a][r];
+            for (int b = a + 1; b < r; ++b) s -= A[a][b] * s_w[b];
+            s_w[a] = s / A[a][a];
+        }
+        for (int a = 0; a < r; ++a) s_rows[a] = rows[a];
+    }
+    __syncthreads();
+    // pose part of x_i (every lane redundantly: 7 x 2k broadcast loads)
+    double xc[7];
+    for (int c = 0; c < 7; ++c) {
+        double s = 0;
+        for (int b = 0; b < r; ++b) s += s_w[b] * (double)HP[(size_t)s_rows[b] * ldw + c];
+        xc[c] = x[c] + s;
+    }
+    double rot[9];
+    d_q2r(xc + 3, rot);                   // un-normalised quaternion (quirk Q4)
+    double lmin = INFINITY;
+    for (int j = tid; j < m; j += blockDim.x) {
+        int i = meas[j];
+        int type = lm_type[i], off = lm_off[i];
+        int d = type == PRE3_INVDEPTH ? 6 : 3;
+        double y[6];
+        for (int c = 0; c < d; ++c) {
+            double s = 0;
+            for (int b = 0; b < r; ++b) s += s_w[b] * (double)HP[(size_t)s_rows[b] * ldw + off + c];
+            y[c] = x[off + c] + s;
+        }
+        double v[3], hc[3];
+        d_ray(type, y, xc, v);
+        for (int c = 0; c < 3; ++c) hc[c] = rot[0 * 3 + c] * v[0] + rot[1 * 3 + c] * v[1] + rot[2 * 3 + c] * v[2];
+        double uvd[2];
+        d_pinhole_distort(hc, cam, uvd);
+        double n0 = z[2 * i] - uvd[0], n1 = z[2 * i + 1] - uvd[1];
+        double res = sqrt(n0 * n0 + n1 * n1);
+        s_res[j] = res;
+        if (type == PRE3_INVDEPTH) lmin = fmin(lmin, res);
+    }
+    lmin = wave_min(lmin);
+    if (lane == 0) s_red[wv] = lmin;
+    uint32_t *s_mask = (uint32_t *)(s_res + m);
+    for (int w = tid; w < mask_words; w += blockDim.x) s_mask[w] = 0;
+    __syncthreads();
+    double minres = fmin(fmin(s_red[0], s_red[1]), fmin(s_red[2], s_red[3]));
+    int cnt = 0;
+    for (int j = tid; j < m; j += blockDim.x) {
+        int type = lm_type[meas[j]];
+        double res = s_res[j];
+        // NaN residuals compare false, as in MATLAB
+        int in = (type == PRE3_INVDEPTH) ? (res < (minres + threshold)) : (res < threshold);
+        if (in) { atomicOr(&s_mask[j >> 5], 1u << (j & 31)); ++cnt; }
+    }
+    cnt = wave_sum(cnt);
+    if (lane == 0) s_cnt[wv] = cnt;
+    __syncthreads();
+    if (tid == 0) support[hidx] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    for (int w = tid; w < mask_words; w += blockDim.x) masks[(size_t)hidx * mask_words + w] = s_mask[w];
+}
+
+// K6: sequential replay of ransac_hypotheses.m:40-80 over the supports (quirk Q1), winner's mask ->
+// low_innovation_inlier flags (set_as_most_supported_hypothesis.m:32-52) + compacted row list.
+// stats: [0] best [1] iterations [2] n_hyp [3] max_support [4] n_li
+__global__ void k_ransac_select(int n_draw, int k, int early_exit, int m, const int32_t *__restrict__ meas,
+                                int32_t *__restrict__ support, const uint32_t *__restrict__ masks, int mask_words,
+                                int32_t *__restrict__ li_meas, int32_t *__restrict__ lm_li, int32_t *__restrict__ sel_rows,
+                                int32_t *__restrict__ stats)
+{
+    __shared__ int s_best, s_iters;
+    if (threadIdx.x == 0) {
+        int n_hyp = 1000, max_support = 0, best = -1, iters = 0;
+        int limit = early_exit ? (n_draw < 1000 ? n_draw : 1000) : n_draw;
+        for (int it = 0; it < limit; ++it) {
+            if (early_exit && n_hyp == 0) break;
+            int sup = support[it];
+            ++iters;
+            if (sup > max_support) {
+                max_support = sup; best = it;
+                double epsilon = 1 - ((double)sup / (double)m);
+                n_hyp = (int)ceil(log(1 - 0.99) / log(1 - (1 - epsilon)));
+            }
+            if (early_exit && n_hyp <= k) break;
+        }
+        s_best = best; s_iters = iters;
+        stats[0] = best; stats[1] = iters; stats[2] = n_hyp; stats[3] = max_support;
+    }
+    __syncthreads();
+    int best = s_best, iters = s_iters;
+    for (int it = iters + threadIdx.x; it < n_draw; it += blockDim.x) support[it] = -1;   // never evaluated by the reference
+    __shared__ int s_count;
+    if (threadIdx.x == 0) {
+        int cnt = 0;
+        for (int j = 0; j < m; ++j) {
+            int in = best >= 0 ? (masks[(size_t)best * mask_words + (j >> 5)] >> (j & 31)) & 1 : 0;
+            li_meas[j] = in; lm_li[meas[j]] = in;
+            if (in) sel_rows[cnt++] = j;
+        }
+        s_count = cnt; stats[4] = cnt;
+    }
+}
+
+// hi flags (landmark order, written by k_innovation mode 1) -> measurement order + compacted list
+__global__ void k_collect_hi(int m, const int32_t *__restrict__ meas, const int32_t *__restrict__ lm_ic,
+                             const int32_t *__restrict__ lm_li, const int32_t *__restrict__ lm_hi,
+                             int32_t *__restrict__ hi_meas, int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int cnt = 0;
+    for (int j = 0; j < m; ++j) {
+        int i = meas[j];
+        int in = (lm_ic[i] == 1 && lm_li[i] == 0) ? lm_hi[i] : 0;
+        hi_meas[j] = in;
+        if (in) sel_rows[cnt++] = j;
+    }
+    stats[5] = cnt;
+}
+
+// x_out = x_prior + W' y  (update.m:36), then Jn at the un-normalised quaternion (update.m:42) -> params,
+// then normalise (update.m:48).  W: r_pad x ldw, y = column `ld` of W.
+template <typename T>
+__global__ __launch_bounds__(256) void k_update_x(int n, int r, const T *__restrict__ W, int ldw, int ld,
+                                                  const double *__restrict__ x_prior, double *__restrict__ x_out,
+                                                  double *__restrict__ params)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double s = 0;
+    if (i < n) {
+        for (int a = 0; a < r; ++a) s += (double)W[(size_t)a * ldw + i] * (double)W[(size_t)a * ldw + ld];
+        s += x_prior[i];
+    }
+    __shared__ double q[4];
+    if (blockIdx.x == 0) {
+        if (i >= 3 && i < 7) q[i - 3] = s;
+        __syncthreads();
+        if (i == 0) { double Jn[16]; d_normjac(q, Jn); for (int t = 0; t < 16; ++t) params[16 + t] = Jn[t]; }
+        if (i >= 3 && i < 7) s = s / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    }
+    if (i < n) x_out[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+static CamD to_camd(const pre3_cam &c) { return CamD{ c.f, c.Cx, c.Cy, c.k1, c.k2, c.nRows, c.nCols }; }
+
+#define DISPATCH_T(c, expr_f64, expr_f32) do { if ((c)->dtype == PRE3_F64) { expr_f64; } else { expr_f32; } } while (0)
+
+int launch_predict_impl(pre3_ctx *c, const double u[7])
+{
+    U7 uu; for (int i = 0; i < 7; ++i) uu.v[i] = u[i];
+    hipLaunchKernelGGL(k_predict_x, dim3(ceil_div(c->n, 256)), dim3(256), 0, c->stream, c->x_kk, c->x_km1, c->n, uu, c->pred_params);
+    int blocks = ceil_div(c->n, 256);
+    DISPATCH_T(c,
+        hipLaunchKernelGGL(k_predict_P<double>, dim3(blocks), dim3(256), 0, c->stream, (double *)c->P, c->n, c->ld, c->pred_params),
+        hipLaunchKernelGGL(k_predict_P<float>, dim3(blocks), dim3(256), 0, c->stream, (float *)c->P, c->n, c->ld, c->pred_params));
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
+int launch_jnorm(pre3_ctx *c, int)
+{
+    int blocks = ceil_div(c->n, 256);
+    DISPATCH_T(c,
+        hipLaunchKernelGGL(k_jnorm_P<double>, dim3(blocks), dim3(256), 0, c->stream, (double *)c->P, c->n, c->ld, c->pred_params),
+        hipLaunchKernelGGL(k_jnorm_P<float>, dim3(blocks), dim3(256), 0, c->stream, (float *)c->P, c->n, c->ld, c->pred_params));
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
+int launch_project(pre3_ctx *c, int which, int clear_first)
+{
+    const double *x = which == PRE3_X_K_K ? c->x_kk : c->x_km1;
+    hipLaunchKernelGGL(k_project, dim3(ceil_div(c->N, 64)), dim3(64), 0, c->stream, c->N, c->lm.type, c->lm.off, x, to_camd(c->cam),
+                       clear_first, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl);
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
+int launch_innovation(pre3_ctx *c, int mode, double chi2)
+{
+    dim3 g(ceil_div(c->N, 64)), b(64);
+    DISPATCH_T(c,
+        hipLaunchKernelGGL(k_innovation<double>, g, b, 0, c->stream, c->N, c->lm.type, c->lm.off, (const double *)c->P, c->ld, c->lm.Hc,
+                           c->lm.Hl, c->lm.has_h, mode, chi2, c->lm.h, c->lm.z, c->lm.ic, c->lm.li, c->lm.hi, c->lm.S, c->lm.has_S),
+        hipLaunchKernelGGL(k_innovation<float>, g, b, 0, c->stream, c->N, c->lm.type, c->lm.off, (const float *)c->P, c->ld, c->lm.Hc,
+                           c->lm.Hl, c->lm.has_h, mode, chi2, c->lm.h, c->lm.z, c->lm.ic, c->lm.li, c->lm.hi, c->lm.S, c->lm.has_S));
+    PRE3_HIP(hipGetLastError());
+    if (mode == 1) {
+        hipLaunchKernelGGL(k_collect_hi, dim3(1), dim3(64), 0, c->stream, c->m, c->meas, c->lm.ic, c->lm.li, c->lm.hi, c->hi_meas,
+                           c->sel_rows, c->stats);
+        PRE3_HIP(hipGetLastError());
+    }
+    return PRE3_OK;
+}
+
+int launch_window_gate(pre3_ctx *c, int M, const int32_t *pred_idx_dev, const int32_t *k1_dev, const double *zc_dev, int strict,
+                       int32_t *accept_dev)
+{
+    hipLaunchKernelGGL(k_window_gate, dim3(ceil_div(M, 64)), dim3(64), 0, c->stream, M, pred_idx_dev, k1_dev, zc_dev, c->lm.h, c->lm.S,
+                       c->lm.has_S, strict, c->lm.z, c->lm.ic, accept_dev);
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
+// sel_dev == nullptr: all measured rows
+int launch_build_rows_impl(pre3_ctx *c, int nsel, const int32_t *sel_dev, int r_pad)
+{
+    dim3 g(ceil_div(r_pad, 64)), b(64);
+    DISPATCH_T(c,
+        hipLaunchKernelGGL(k_build_rows<double>, g, b, 0, c->stream, nsel, sel_dev, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl,
+                           c->lm.z, c->lm.h, c->row_col, (double *)c->row_val, c->row_nu, r_pad),
+        hipLaunchKernelGGL(k_build_rows<float>, g, b, 0, c->stream, nsel, sel_dev, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl,
+                           c->lm.z, c->lm.h, c->row_col, (float *)c->row_val, c->row_nu, r_pad));
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
+int launch_ransac_score_impl(pre3_ctx *c, int k, double threshold, int hyp_begin, int hyp_end, int ldg, int32_t *support_dev,
+                             uint32_t *mask_dev, int mask_words)
+{
+    int nb = hyp_end - hyp_begin;
+    if (nb <= 0) return PRE3_OK;
+    size_t shm = sizeof(double) * c->m + sizeof(uint32_t) * mask_words + 16;
+    DISPATCH_T(c,
+        hipLaunchKernelGGL(k_ransac_score<double>, dim3(nb), dim3(256), shm, c->stream, hyp_begin, k, c->hyp, c->m, c->meas, c->lm.type,
+                           c->lm.off, c->x_km1, (const double *)c->HP, c->ldw, (const double *)c->G, ldg, c->row_nu, c->lm.z,
+                           to_camd(c->cam), threshold, support_dev, mask_dev, mask_words),
+        hipLaunchKernelGGL(k_ransac_score<float>, dim3(nb), dim3(256), shm, c->stream, hyp_begin, k, c->hyp, c->m, c->meas, c->lm.type,
+                           c->lm.off, c->x_km1, (const float *)c->HP, c->ldw, (const float *)c->G, ldg, c->row_nu, c->lm.z,
+                           to_camd(c->cam), threshold, support_dev, mask_dev, mask_words));
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
+int launch_ransac_select_impl(pre3_ctx *c, int n_draw, int k, int early_exit, int32_t *support_dev, const uint32_t *mask_dev, int mask_words)
+{
+    hipLaunchKernelGGL(k_ransac_select, dim3(1), dim3(256), 0, c->stream, n_draw, k, early_exit, c->m, c->meas, support_dev, mask_dev,
+                       mask_words, c->li_meas, c->lm.li, c->sel_rows, c->stats);
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
+int launch_update_x(pre3_ctx *c, int which_prior, int r)
+{
+    const double *xp = which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1;
+    dim3 g(ceil_div(c->n, 256)), b(256);
+    DISPATCH_T(c,
+        hipLaunchKernelGGL(k_update_x<double>, g, b, 0, c->stream, c->n, r, (const double *)c->W, c->ldw, c->ld, xp, c->x_kk, c->pred_params),
+        hipLaunchKernelGGL(k_update_x<float>, g, b, 0, c->stream, c->n, r, (const float *)c->W, c->ldw, c->ld, xp, c->x_kk, c->pred_params));
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
+}  // namespace pre3

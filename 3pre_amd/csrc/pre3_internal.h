@@ -1,0 +1,124 @@
+// pre3_internal.h -- shared host-side declarations of libpre3.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pre3.h"
+
+namespace pre3 {
+
+void set_error(const char *fmt, ...);
+
+#define PRE3_HIP(call)                                                                         \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            pre3::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return PRE3_E_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+#define PRE3_CHECK(cond, status, ...)                                                          \
+    do {                                                                                       \
+        if (!(cond)) { pre3::set_error(__VA_ARGS__); return (status); }                        \
+    } while (0)
+
+#define PRE3_TRY(expr)                                                                         \
+    do { int rc_ = (expr); if (rc_ != PRE3_OK) return rc_; } while (0)
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+constexpr int TILE = 128;       // K9 output tile; P's leading dimension is a multiple of this
+constexpr int NB = 64;          // Cholesky / triangular-solve panel width
+constexpr int ELLW = 16;        // ELL width of measurement rows (7 pose + 6 landmark = 13 used)
+constexpr int MAXK = 4;         // landmarks per RANSAC hypothesis (reference uses 3 or 1)
+
+// flags of the per-landmark table
+struct LmBuffers {
+    int32_t *type = nullptr, *off = nullptr;          // [N]
+    double *h = nullptr;                              // [2N]
+    int32_t *has_h = nullptr;                         // [N]
+    double *Hc = nullptr, *Hl = nullptr;              // [14N], [12N]
+    double *S = nullptr;                              // [4N]
+    int32_t *has_S = nullptr;                         // [N]
+    double *z = nullptr;                              // [2N]
+    int32_t *ic = nullptr, *li = nullptr, *hi = nullptr;   // [N]
+};
+
+struct KernelTiming {
+    bool enabled = false;
+    std::vector<hipEvent_t> ev;     // pairs
+    int used = 0;
+    double flops = 0, bytes = 0;
+};
+
+}  // namespace pre3
+
+struct pre3_ctx {
+    int device = 0, dtype = PRE3_F32;
+    size_t esz = 4;
+    hipStream_t stream = nullptr;
+    int capN = 0, capn = 0, capm = 0, caph = 0;
+    int N = 0, n = 0;
+    int ld = 0;                 // leading dimension of P (multiple of TILE), rows/cols >= n are zero
+    int ldw = 0;                // leading dimension of the row workspace W/HP: ld + NB (column `ld` carries nu)
+    int rcap = 0;               // max update rows (2*capm rounded to NB)
+    pre3_cam cam{};
+    bool have_cam = false;
+    // device state
+    double *x_kk = nullptr, *x_km1 = nullptr;     // [capn]
+    void *P = nullptr;                            // [ld*ld] T
+    int p_which = -1;                             // which estimate P currently holds (-1: none)
+    bool x_valid[2] = {false, false};
+    pre3::LmBuffers lm;
+    // measurements (host mirrors kept: m and the index list are host-known)
+    int m = 0;
+    std::vector<int32_t> meas_host;
+    int32_t *meas = nullptr;                      // [capm] landmark index per measurement
+    // measurement-row workspace
+    int32_t *row_col = nullptr;                   // [rcap*ELLW]
+    void *row_val = nullptr;                      // [rcap*ELLW] T
+    double *row_nu = nullptr;                     // [rcap]  z-h per row
+    void *HP = nullptr;                           // [rcap*ldw] T   H*P for all measured rows (RANSAC)
+    void *G = nullptr;                            // [rcap*rcap] T  H*P*H' (no +R)
+    void *W = nullptr;                            // [rcap*ldw] T   update workspace: HP rows -> W = L^-1 HP
+    void *Smat = nullptr;                         // [rcap*rcap] T  S -> L
+    void *Rdense = nullptr;                       // [rcap*rcap] T  optional dense R (stateless update)
+    int32_t *sel_rows = nullptr;                  // [rcap] compacted row list (indices into the measured rows)
+    // RANSAC
+    int32_t *hyp = nullptr;                       // [caph*MAXK]
+    int32_t *support = nullptr;                   // [caph]
+    uint32_t *masks = nullptr;                    // [caph*mask_words_cap]
+    int mask_words_cap = 0;
+    int32_t *stats = nullptr;                     // [16] device: best, iters, n_hyp, max_support, n_li, n_hi, status
+    int32_t *li_meas = nullptr, *hi_meas = nullptr;   // [capm] flags in measurement order
+    double *pred_params = nullptr;                // [64] predict: Qq1(16) Jn(16) Q(49->7x7) etc.
+    int32_t *pinned_stats = nullptr;              // host pinned [16]
+    // timing
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    pre3::KernelTiming kt;
+    bool measurements_set = false, projected = false, innovated = false;
+};
+
+namespace pre3 {
+
+// ---- geometry / RANSAC kernels (pre3_geom.hip)
+int launch_project(pre3_ctx *c, int which, int clear_first);
+int launch_innovation(pre3_ctx *c, int mode /*0: S=HPH'+I for predicted; 1: rescue gate + HI list*/, double chi2);
+int launch_update_x(pre3_ctx *c, int which_prior, int r);
+int launch_jnorm(pre3_ctx *c, int which);
+
+// ---- dense update kernels (pre3_update.hip)
+// rows: ELL rows [r] in c->row_col/row_val with nu in c->row_nu; computes W = H*P (+ nu column),
+// S = H*P*H' + R, Cholesky, W = L^-1 [HP | nu], x += W' y, P -= W'W, Jnorm + normalise.
+int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_dev /*nullable, r_pad x ldw T*/);
+int launch_ell_HP(pre3_ctx *c, int r, void *dst /*r_pad x ldw*/, bool with_nu);
+int launch_ell_G(pre3_ctx *c, int r, const void *HPsrc, void *dst, int ldg, int add_identity, const void *Rdense);
+int launch_downdate(pre3_ctx *c, int r, const void *W);
+
+}  // namespace pre3

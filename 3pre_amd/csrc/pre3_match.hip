@@ -1,0 +1,385 @@
+// pre3_match.hip -- descriptor matching (sift/siftmatch.c:83-132) and kNearestNeighbors.m:29-39 on gfx950.
+//
+// Exactness contract: the reference accumulates (a-b)^2 bin by bin in the promoted class (double, float,
+// int, int) with a separate multiply and add, keeps the first index on ties, and applies Lowe's ratio test
+// in float.  (best, second best, first arg-best) of a sequential scan is order independent as a multiset
+// statistic, so it can be reduced in parallel and merged across database shards.
+//
+//   * float / double classes: one lane per (query, database) pair walks the 128 bins in the reference's
+//     order with contraction off -> bit-identical distances.
+//   * uint8 / int8 classes: distances are integers; d2 = |a|^2 + |b|^2 - 2 a.b is evaluated exactly in
+//     int32 on the matrix cores (v_mfma_i32_32x32x32_i8; uint8 is re-centred by -128, which leaves a-b
+//     unchanged) with the best/second-best scan fused into the epilogue.
+#include "pre3_internal.h"
+
+namespace pre3 {
+
+template <typename ACC> struct Best3 { ACC best, second; int k; };
+
+template <typename ACC> __device__ inline ACC acc_max();
+template <> __device__ inline double acc_max<double>() { return INFINITY; }
+template <> __device__ inline float acc_max<float>() { return INFINITY; }
+template <> __device__ inline int acc_max<int>() { return 0x7fffffff; }
+
+// merge two scan states (order independent; ties -> lowest index)
+template <typename ACC>
+__device__ inline void merge3(ACC &best, ACC &second, int &k, ACC ob, ACC os, int ok)
+{
+    if (ok < 0) return;
+    if (k < 0) { best = ob; second = os; k = ok; return; }
+    if (ob < best || (ob == best && ok < k)) {
+        ACC ns = os < best ? os : best;
+        best = ob; k = ok; second = ns;
+    } else {
+        ACC ns = ob < second ? ob : second;
+        second = ns;
+    }
+}
+
+template <typename ACC>
+__device__ inline void push3(ACC &best, ACC &second, int &k, ACC v, int idx)
+{
+    // siftmatch.c:110-116 for increasing idx
+    if (v < best) { second = best; best = v; k = idx; }
+    else if (v < second) { second = v; }
+}
+
+// generic exact kernel: block = one query column; lanes stride over database columns.
+// L1: ND x K1, L2: ND x K2 column-major.  Outputs per query: best, second (as double), arg (global index).
+template <typename T, typename ACC>
+__global__ __launch_bounds__(256) void k_match_exact(int ND, int K2, const T *__restrict__ L1, const T *__restrict__ L2, int k2_offset,
+                                                     double *__restrict__ obest, double *__restrict__ osecond, int32_t *__restrict__ oarg)
+{
+#pragma clang fp contract(off)
+    extern __shared__ unsigned char smem_raw[];
+    ACC *q = reinterpret_cast<ACC *>(smem_raw);
+    const int k1 = blockIdx.x, tid = threadIdx.x;
+    for (int b = tid; b < ND; b += blockDim.x) q[b] = (ACC)L1[(size_t)k1 * ND + b];
+    __syncthreads();
+    ACC best = acc_max<ACC>(), second = acc_max<ACC>();
+    int bk = -1;
+    for (int k2 = tid; k2 < K2; k2 += blockDim.x) {
+        const T *b = L2 + (size_t)k2 * ND;
+        ACC acc = 0;
+        for (int bin = 0; bin < ND; ++bin) {
+            ACC delta = q[bin] - (ACC)b[bin];
+            ACC sq = delta * delta;
+            acc = acc + sq;
+        }
+        push3(best, second, bk, acc, k2);
+    }
+    // wave reduction then block reduction
+    for (int o = 32; o > 0; o >>= 1) {
+        ACC ob = __shfl_xor(best, o, 64), os = __shfl_xor(second, o, 64);
+        int ok = __shfl_xor(bk, o, 64);
+        merge3(best, second, bk, ob, os, ok);
+    }
+    __shared__ int sk[4];
+    __shared__ ACC sbb[4], sss[4];
+    int wv = tid >> 6;
+    if ((tid & 63) == 0) { sbb[wv] = best; sss[wv] = second; sk[wv] = bk; }
+    __syncthreads();
+    if (tid == 0) {
+        ACC B = sbb[0], S2 = sss[0]; int K = sk[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) merge3(B, S2, K, sbb[w], sss[w], sk[w]);
+        obest[k1] = (double)B; osecond[k1] = (double)S2; oarg[k1] = K < 0 ? -1 : K + k2_offset;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// int8 MFMA distance kernel.  A (queries) and B (database) are int8, ND padded to a multiple of 32 with
+// zeros; norms precomputed.  Tile: 128 queries x 128 database columns per workgroup (4 waves, 2x2 of 64x64,
+// each 2x2 MFMA 32x32 blocks); K loop over ND in steps of 32 (one v_mfma_i32_32x32x32_i8 per block per step).
+// Epilogue: d2 = na + nb - 2*dot, per-row scan over this tile's 128 columns, merged across column tiles by
+// a second pass (k_match_reduce) over the per-tile partials.
+// Operand layout for v_mfma_i32_32x32x32_i8: lane l holds 16 consecutive k (int8x16 = 4 VGPRs) of
+// row/col (l&31), k-group (l>>5): k = 16*(l>>5) + j.
+// ------------------------------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void k_match_i8_mfma(int NDp, int K1, int K2, const int8_t *__restrict__ A, const int8_t *__restrict__ B,
+                                                       const int *__restrict__ na, const int *__restrict__ nb, int ntile_n,
+                                                       int *__restrict__ pbest, int *__restrict__ psecond, int *__restrict__ parg)
+{
+    // A: K1p x NDp row-major (one descriptor per row), B: K2p x NDp row-major; both padded to 128 rows.
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int I0 = blockIdx.y * 128, J0 = blockIdx.x * 128;
+    v16i acc[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[p][q][e] = 0;
+    const int r = lane & 31, kg = lane >> 5;
+    for (int k0 = 0; k0 < NDp; k0 += 32) {
+        v4i av[2], bv[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            av[p] = *reinterpret_cast<const v4i *>(A + (size_t)(I0 + wi * 64 + p * 32 + r) * NDp + k0 + 16 * kg);
+            bv[p] = *reinterpret_cast<const v4i *>(B + (size_t)(J0 + wj * 64 + p * 32 + r) * NDp + k0 + 16 * kg);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[p][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[p], bv[q], acc[p][q], 0, 0, 0);
+    }
+    // epilogue: each lane holds, per block, column (lane&31) and 16 rows.  Stage d2 through LDS so that one
+    // lane scans one query row over the tile's 128 columns in increasing column order.
+    __shared__ int sd[64][129];
+    for (int half = 0; half < 2; ++half) {
+        if (wi == half) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        int row = p * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        int col = wj * 64 + q * 32 + (lane & 31);
+                        sd[row][col] = na[I0 + half * 64 + row] + nb[J0 + col] - 2 * acc[p][q][e];
+                    }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            int row = tid;
+            int best = 0x7fffffff, second = 0x7fffffff, bk = -1;
+            int ncol = K2 - J0 < 128 ? K2 - J0 : 128;
+            for (int cidx = 0; cidx < ncol; ++cidx) push3(best, second, bk, sd[row][cidx], J0 + cidx);
+            size_t o = (size_t)(I0 + half * 64 + row) * ntile_n + blockIdx.x;
+            pbest[o] = best; psecond[o] = second; parg[o] = bk;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_match_reduce_i32(int K1, int ntile_n, const int *__restrict__ pbest, const int *__restrict__ psecond,
+                                   const int *__restrict__ parg, int k2_offset, double *__restrict__ obest, double *__restrict__ osecond,
+                                   int32_t *__restrict__ oarg)
+{
+    int k1 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k1 >= K1) return;
+    int best = 0x7fffffff, second = 0x7fffffff, bk = -1;
+    for (int t = 0; t < ntile_n; ++t) {
+        size_t o = (size_t)k1 * ntile_n + t;
+        merge3(best, second, bk, pbest[o], psecond[o], parg[o]);
+    }
+    obest[k1] = (double)best; osecond[k1] = (double)second; oarg[k1] = bk < 0 ? -1 : bk + k2_offset;
+}
+
+// pack ND x K (column-major, one descriptor per column) uint8/int8 into K_pad x NDp int8 rows (+ norms)
+template <typename T>
+__global__ void k_pack_i8(int ND, int NDp, int K, int Kp, const T *__restrict__ L, int center, int8_t *__restrict__ out, int *__restrict__ norm)
+{
+    int kcol = blockIdx.x * blockDim.x + threadIdx.x;
+    if (kcol >= Kp) return;
+    int s = 0;
+    for (int b = 0; b < NDp; ++b) {
+        int v = (kcol < K && b < ND) ? (int)L[(size_t)kcol * ND + b] - center : 0;
+        out[(size_t)kcol * NDp + b] = (int8_t)v;
+        s += v * v;
+    }
+    norm[kcol] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kNearestNeighbors.m:29-39: block per query; distances in the reference's accumulation order, then k
+// selection rounds (stable: lowest index first on ties).  data N x D, query M x D column-major.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_knn(int D, int N, int M, const double *__restrict__ data, const double *__restrict__ query, int k,
+                                             double *__restrict__ scratch, double *__restrict__ ids, double *__restrict__ dist)
+{
+#pragma clang fp contract(off)
+    const int qi = blockIdx.x, tid = threadIdx.x;
+    double *dsq = scratch + (size_t)qi * N;
+    for (int j = tid; j < N; j += blockDim.x) {
+        double s = 0;
+        for (int d = 0; d < D; ++d) {
+            double t = query[(size_t)d * M + qi] - data[(size_t)d * N + j];
+            double sq = t * t;
+            s = s + sq;
+        }
+        dsq[j] = s;
+    }
+    __syncthreads();
+    __shared__ double sv[4];
+    __shared__ int si[4];
+    __shared__ double lastv;
+    __shared__ int lasti;
+    if (tid == 0) { lastv = -INFINITY; lasti = -1; }
+    __syncthreads();
+    for (int c = 0; c < k; ++c) {
+        double bv = INFINITY; int bi = 0x7fffffff;
+        double lv = lastv; int li = lasti;
+        for (int j = tid; j < N; j += blockDim.x) {
+            double v = dsq[j];
+            // strictly after (lv, li) in (value, index) order
+            bool after = (v > lv) || (v == lv && j > li);
+            if (after && (v < bv || (v == bv && j < bi))) { bv = v; bi = j; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            double ov = __shfl_xor(bv, o, 64); int oi = __shfl_xor(bi, o, 64);
+            if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if ((tid & 63) == 0) { sv[tid >> 6] = bv; si[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w) if (sv[w] < sv[0] || (sv[w] == sv[0] && si[w] < si[0])) { sv[0] = sv[w]; si[0] = si[w]; }
+            lastv = sv[0]; lasti = si[0];
+            ids[(size_t)c * M + qi] = (double)(si[0] + 1);
+            dist[(size_t)c * M + qi] = sqrt(sv[0]);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { p = nullptr; set_error("hipMalloc of %zu bytes failed", bytes); return PRE3_E_NOMEM; } return PRE3_OK; }
+};
+
+template <typename T, typename ACC>
+static int partial_exact(int ND, int K1, const T *L1, int K2, const T *L2, int k2_offset, double *best, double *second, int32_t *arg)
+{
+    DevBuf d1, d2, db, ds, da;
+    PRE3_TRY(d1.alloc(sizeof(T) * (size_t)ND * K1));
+    PRE3_TRY(d2.alloc(sizeof(T) * (size_t)ND * K2));
+    PRE3_TRY(db.alloc(sizeof(double) * K1)); PRE3_TRY(ds.alloc(sizeof(double) * K1)); PRE3_TRY(da.alloc(sizeof(int32_t) * K1));
+    PRE3_HIP(hipMemcpy(d1.p, L1, sizeof(T) * (size_t)ND * K1, hipMemcpyHostToDevice));
+    if (K2) PRE3_HIP(hipMemcpy(d2.p, L2, sizeof(T) * (size_t)ND * K2, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL((k_match_exact<T, ACC>), dim3(K1), dim3(256), sizeof(ACC) * ND, 0, ND, K2, (const T *)d1.p, (const T *)d2.p, k2_offset,
+                       (double *)db.p, (double *)ds.p, (int32_t *)da.p);
+    PRE3_HIP(hipGetLastError());
+    PRE3_HIP(hipMemcpy(best, db.p, sizeof(double) * K1, hipMemcpyDeviceToHost));
+    PRE3_HIP(hipMemcpy(second, ds.p, sizeof(double) * K1, hipMemcpyDeviceToHost));
+    PRE3_HIP(hipMemcpy(arg, da.p, sizeof(int32_t) * K1, hipMemcpyDeviceToHost));
+    return PRE3_OK;
+}
+
+// device-resident int8 MFMA matcher state, reusable across calls (bench: inputs resident in HBM)
+struct I8Match {
+    int ND = 0, NDp = 0, K1 = 0, K2 = 0, K1p = 0, K2p = 0, ntn = 0;
+    DevBuf A, B, na, nb, pb, ps, pa, ob, os, oa;
+};
+
+template <typename T>
+static int i8_prepare(I8Match &m, int ND, int K1, const T *L1, int K2, const T *L2, int center)
+{
+    m.ND = ND; m.NDp = round_up(ND, 32); m.K1 = K1; m.K2 = K2; m.K1p = round_up(K1, 128); m.K2p = round_up(K2 ? K2 : 1, 128);
+    m.ntn = m.K2p / 128;
+    DevBuf r1, r2;
+    PRE3_TRY(r1.alloc((size_t)ND * K1)); PRE3_TRY(r2.alloc((size_t)ND * (K2 ? K2 : 1)));
+    PRE3_HIP(hipMemcpy(r1.p, L1, (size_t)ND * K1, hipMemcpyHostToDevice));
+    if (K2) PRE3_HIP(hipMemcpy(r2.p, L2, (size_t)ND * K2, hipMemcpyHostToDevice));
+    PRE3_TRY(m.A.alloc((size_t)m.K1p * m.NDp)); PRE3_TRY(m.B.alloc((size_t)m.K2p * m.NDp));
+    PRE3_TRY(m.na.alloc(sizeof(int) * m.K1p)); PRE3_TRY(m.nb.alloc(sizeof(int) * m.K2p));
+    size_t np = (size_t)m.K1p * m.ntn;
+    PRE3_TRY(m.pb.alloc(sizeof(int) * np)); PRE3_TRY(m.ps.alloc(sizeof(int) * np)); PRE3_TRY(m.pa.alloc(sizeof(int) * np));
+    PRE3_TRY(m.ob.alloc(sizeof(double) * K1)); PRE3_TRY(m.os.alloc(sizeof(double) * K1)); PRE3_TRY(m.oa.alloc(sizeof(int32_t) * K1));
+    hipLaunchKernelGGL(k_pack_i8<T>, dim3(ceil_div(m.K1p, 64)), dim3(64), 0, 0, ND, m.NDp, K1, m.K1p, (const T *)r1.p, center, (int8_t *)m.A.p, (int *)m.na.p);
+    hipLaunchKernelGGL(k_pack_i8<T>, dim3(ceil_div(m.K2p, 64)), dim3(64), 0, 0, ND, m.NDp, K2, m.K2p, (const T *)r2.p, center, (int8_t *)m.B.p, (int *)m.nb.p);
+    PRE3_HIP(hipGetLastError());
+    PRE3_HIP(hipDeviceSynchronize());
+    return PRE3_OK;
+}
+
+static int i8_run(I8Match &m, int k2_offset, hipStream_t st)
+{
+    dim3 g(m.ntn, m.K1p / 128), b(256);
+    hipLaunchKernelGGL(k_match_i8_mfma, g, b, 0, st, m.NDp, m.K1, m.K2, (const int8_t *)m.A.p, (const int8_t *)m.B.p, (const int *)m.na.p,
+                       (const int *)m.nb.p, m.ntn, (int *)m.pb.p, (int *)m.ps.p, (int *)m.pa.p);
+    hipLaunchKernelGGL(k_match_reduce_i32, dim3(ceil_div(m.K1, 256)), dim3(256), 0, st, m.K1, m.ntn, (const int *)m.pb.p, (const int *)m.ps.p,
+                       (const int *)m.pa.p, k2_offset, (double *)m.ob.p, (double *)m.os.p, (int32_t *)m.oa.p);
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
+template <typename T>
+static int partial_i8(int ND, int K1, const T *L1, int K2, const T *L2, int center, int k2_offset, double *best, double *second, int32_t *arg)
+{
+    I8Match m;
+    PRE3_TRY(i8_prepare(m, ND, K1, L1, K2, L2, center));
+    PRE3_TRY(i8_run(m, k2_offset, 0));
+    PRE3_HIP(hipMemcpy(best, m.ob.p, sizeof(double) * K1, hipMemcpyDeviceToHost));
+    PRE3_HIP(hipMemcpy(second, m.os.p, sizeof(double) * K1, hipMemcpyDeviceToHost));
+    PRE3_HIP(hipMemcpy(arg, m.oa.p, sizeof(int32_t) * K1, hipMemcpyDeviceToHost));
+    return PRE3_OK;
+}
+
+int match_partial(int device, int cls, int ND, int K1, const void *L1, int K2, const void *L2, int k2_offset, double *best, double *second,
+                  int32_t *arg)
+{
+    PRE3_CHECK(ND > 0 && K1 >= 0 && K2 >= 0, PRE3_E_ARG, "siftmatch: bad sizes ND=%d K1=%d K2=%d", ND, K1, K2);
+    PRE3_CHECK(K1 == 0 || (L1 && best && second && arg), PRE3_E_ARG, "siftmatch: null pointer");
+    if (K1 == 0) return PRE3_OK;
+    if (hipSetDevice(device) != hipSuccess) { set_error("no HIP device %d", device); return PRE3_E_NODEVICE; }
+    if (K2 == 0) {
+        for (int i = 0; i < K1; ++i) { best[i] = (cls >= 2) ? 2147483647.0 : INFINITY; second[i] = best[i]; arg[i] = -1; }
+        return PRE3_OK;
+    }
+    switch (cls) {
+    case 0: return partial_exact<double, double>(ND, K1, (const double *)L1, K2, (const double *)L2, k2_offset, best, second, arg);
+    case 1: return partial_exact<float, float>(ND, K1, (const float *)L1, K2, (const float *)L2, k2_offset, best, second, arg);
+    case 2: return partial_i8<uint8_t>(ND, K1, (const uint8_t *)L1, K2, (const uint8_t *)L2, 128, k2_offset, best, second, arg);
+    case 3: return partial_i8<int8_t>(ND, K1, (const int8_t *)L1, K2, (const int8_t *)L2, 0, k2_offset, best, second, arg);
+    default: set_error("siftmatch: unsupported class %d", cls); return PRE3_E_ARG;
+    }
+}
+
+int knn_run(int device, int D, int N, const double *data, int M, const double *query, int k, double *ids, double *dist)
+{
+    PRE3_CHECK(D > 0 && N > 0 && M >= 0 && k >= 1 && k <= N, PRE3_E_ARG, "kNearestNeighbors: bad sizes D=%d N=%d M=%d k=%d", D, N, M, k);
+    if (M == 0) return PRE3_OK;
+    if (hipSetDevice(device) != hipSuccess) { set_error("no HIP device %d", device); return PRE3_E_NODEVICE; }
+    DevBuf dd, dq, sc, di, ds;
+    PRE3_TRY(dd.alloc(sizeof(double) * (size_t)N * D)); PRE3_TRY(dq.alloc(sizeof(double) * (size_t)M * D));
+    PRE3_TRY(sc.alloc(sizeof(double) * (size_t)M * N)); PRE3_TRY(di.alloc(sizeof(double) * (size_t)M * k)); PRE3_TRY(ds.alloc(sizeof(double) * (size_t)M * k));
+    PRE3_HIP(hipMemcpy(dd.p, data, sizeof(double) * (size_t)N * D, hipMemcpyHostToDevice));
+    PRE3_HIP(hipMemcpy(dq.p, query, sizeof(double) * (size_t)M * D, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_knn, dim3(M), dim3(256), 0, 0, D, N, M, (const double *)dd.p, (const double *)dq.p, k, (double *)sc.p, (double *)di.p, (double *)ds.p);
+    PRE3_HIP(hipGetLastError());
+    PRE3_HIP(hipMemcpy(ids, di.p, sizeof(double) * (size_t)M * k, hipMemcpyDeviceToHost));
+    PRE3_HIP(hipMemcpy(dist, ds.p, sizeof(double) * (size_t)M * k, hipMemcpyDeviceToHost));
+    return PRE3_OK;
+}
+
+// matcher bench handle (inputs resident in HBM): uint8 descriptors, MFMA path
+struct MatchBench { I8Match m; };
+void *match_bench_create(int ND, int K1, const uint8_t *L1, int K2, const uint8_t *L2)
+{
+    MatchBench *b = new MatchBench();
+    if (i8_prepare(b->m, ND, K1, L1, K2, L2, 128) != PRE3_OK) { delete b; return nullptr; }
+    return b;
+}
+int match_bench_run(void *h, int reps, double *ms_per)
+{
+    MatchBench *b = (MatchBench *)h;
+    hipEvent_t e0, e1;
+    PRE3_HIP(hipEventCreate(&e0)); PRE3_HIP(hipEventCreate(&e1));
+    PRE3_TRY(i8_run(b->m, 0, 0));
+    PRE3_HIP(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) PRE3_TRY(i8_run(b->m, 0, 0));
+    PRE3_HIP(hipEventRecord(e1, 0));
+    PRE3_HIP(hipEventSynchronize(e1));
+    float ms = 0; PRE3_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per = ms / reps;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return PRE3_OK;
+}
+int match_bench_fetch(void *h, double *best, double *second, int32_t *arg)
+{
+    MatchBench *b = (MatchBench *)h;
+    PRE3_HIP(hipMemcpy(best, b->m.ob.p, sizeof(double) * b->m.K1, hipMemcpyDeviceToHost));
+    PRE3_HIP(hipMemcpy(second, b->m.os.p, sizeof(double) * b->m.K1, hipMemcpyDeviceToHost));
+    PRE3_HIP(hipMemcpy(arg, b->m.oa.p, sizeof(int32_t) * b->m.K1, hipMemcpyDeviceToHost));
+    return PRE3_OK;
+}
+void match_bench_destroy(void *h) { delete (MatchBench *)h; }
+
+}  // namespace pre3

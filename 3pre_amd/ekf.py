@@ -1,0 +1,285 @@
+"""Host-side mirror of the reference's EKF interface for the hot path, over the C ABI (include/pre3.h).
+
+Names, argument meaning and error behaviour follow the MATLAB functions they replace (paths under
+matlab_code/ of the reference):
+
+    EkfFilter                     <-> @ekf_filter/ekf_filter.m:27-89 (x_k_k, p_k_k, x_k_km1, p_k_km1, std_z ...)
+      .ekf_prediction(u)          <-> @ekf_filter/ekf_prediction.m:29 -> predict_state_and_covariance.m:27
+      .search_IC_matches()        <-> search_IC_matches.m:31-44 (projection, Jacobians, S_i)
+      .matching(k1, zc)           <-> matching_sift_based.m:119-134 (window gate on siftmatch's output)
+      .ransac_hypotheses(hyp)     <-> ransac_hypotheses.m:27-85 (draws are an input: MATLAB's RNG is not reproducible)
+      .ekf_update_li_inliers()    <-> @ekf_filter/ekf_update_li_inliers.m:45-58
+      .rescue_hi_inliers()        <-> @ekf_filter/rescue_hi_inliers.m:29-47
+      .ekf_update_hi_inliers()    <-> @ekf_filter/ekf_update_hi_inliers.m:45-58
+      .ekf_update_all()           <-> @ekf_filter/ekf_update_all.m:46-62
+    update(x, P, H, R, z, h)      <-> update.m:27   (stateless drop-in: host arrays in, host arrays out)
+    predict_state_and_covariance  <-> predict_state_and_covariance.m:27 (u passed explicitly instead of fv.m's disk read)
+
+All compute runs in libpre3.so on the GPU; this module only marshals numpy arrays.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Cam, Pre3Error, check, dptr, f64, i32, lib
+
+CHI2INV_2_95 = 5.9915          # rescue_hi_inliers.m:29
+
+
+def _cam(cam):
+    if isinstance(cam, dict):
+        cam = [cam[k] for k in ("f", "Cx", "Cy", "k1", "k2", "nRows", "nCols")]
+    return Cam(*[float(v) for v in cam])
+
+
+class EkfFilter:
+    """Device-resident filter state.  dtype: 'f64' or 'f32' (covariance path); geometry is always fp64."""
+
+    def __init__(self, cam, lm_type, dtype="f32", device=0, max_hyp=1000, max_landmarks=None, std_z=1.0):
+        lm_type = i32(lm_type)
+        self.N = int(lm_type.shape[0])
+        self.dtype = {"f64": _lib.F64, "f32": _lib.F32}[dtype]
+        self.std_z = float(std_z)
+        self._ctx = C.c_void_p()
+        check(lib.pre3_create(C.byref(self._ctx), int(device), self.dtype, int(max_landmarks or max(self.N, 1)), int(max_hyp)))
+        c = _cam(cam)
+        check(lib.pre3_set_cam(self._ctx, C.byref(c)))
+        check(lib.pre3_set_map(self._ctx, self.N, dptr(lm_type)))
+        self.n = int(lib.pre3_state_size(self._ctx))
+        self.lm_type = lm_type
+        self.m = 0
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            lib.pre3_destroy(self._ctx)
+            self._ctx = None
+
+    __del__ = close
+
+    # ---- state (set_x_k_k.m / get_x_k_k.m ...)
+    def set_x_p_k_k(self, x, P):
+        x, P = f64(x), f64(P)
+        check(lib.pre3_set_state(self._ctx, _lib.X_K_K, x.shape[0], dptr(x), dptr(P)))
+
+    def set_x_p_k_km1(self, x, P):
+        x, P = f64(x), f64(P)
+        check(lib.pre3_set_state(self._ctx, _lib.X_K_KM1, x.shape[0], dptr(x), dptr(P)))
+
+    def _get(self, which, want_P=True):
+        x = np.empty(self.n)
+        P = np.empty((self.n, self.n)) if want_P else None
+        check(lib.pre3_get_state(self._ctx, which, self.n, dptr(x), dptr(P)))
+        return x, P
+
+    def get_x_k_k(self):
+        return self._get(_lib.X_K_K, False)[0]
+
+    def get_p_k_k(self):
+        return self._get(_lib.X_K_K)[1]
+
+    def get_x_k_km1(self):
+        return self._get(_lib.X_K_KM1, False)[0]
+
+    def get_p_k_km1(self):
+        return self._get(_lib.X_K_KM1)[1]
+
+    def sync(self):
+        check(lib.pre3_sync(self._ctx))
+
+    # ---- step stages
+    def ekf_prediction(self, u):
+        u = f64(u)
+        assert u.shape == (7,), "u = [dX(3); dq(4)]"
+        check(lib.pre3_predict(self._ctx, dptr(u)))
+
+    def predict_camera_measurements(self, which=_lib.X_K_KM1, clear_first=True):
+        """Also computes the Jacobians (calculate_derivatives.m) -- the reference always calls them as a pair."""
+        check(lib.pre3_project(self._ctx, int(which), int(bool(clear_first))))
+
+    def search_IC_matches(self):
+        check(lib.pre3_project(self._ctx, _lib.X_K_KM1, 1))
+        check(lib.pre3_innovation(self._ctx))
+
+    def landmark_fields(self):
+        N = self.N
+        h, has_h = np.zeros((N, 2)), np.zeros(N, np.int32)
+        Hc, Hl, S = np.zeros((N, 2, 7)), np.zeros((N, 2, 6)), np.zeros((N, 2, 2))
+        check(lib.pre3_get_landmark_fields(self._ctx, dptr(h), dptr(has_h), dptr(Hc), dptr(Hl), dptr(S)))
+        return dict(h=h, has_h=has_h, Hc=Hc, Hl=Hl, S=S)
+
+    def matching(self, k1, zc, strict_reference=True):
+        """Window gate on siftmatch's pairs: k1[c] = 0-based column of L1 (= c-th predicted landmark list entry
+        matched), zc[c] = matched pixel.  Returns the accept flags; accepted candidates become measurements."""
+        k1, zc = i32(k1), f64(zc)
+        M = int(k1.shape[0])
+        acc = np.zeros(M, np.int32)
+        check(lib.pre3_window_gate(self._ctx, M, dptr(k1), dptr(zc), int(bool(strict_reference)), dptr(acc)))
+        return acc
+
+    def set_measurements(self, meas_idx, z):
+        meas_idx, z = i32(meas_idx), f64(z)
+        self.m = int(meas_idx.shape[0])
+        check(lib.pre3_set_measurements(self._ctx, self.m, dptr(meas_idx), dptr(z)))
+
+    def ransac_hypotheses(self, hyp, threshold=None, early_exit=True):
+        hyp = i32(hyp)
+        n_draw, k = hyp.shape
+        sup = np.zeros(n_draw, np.int32)
+        li = np.zeros(max(self.m, 1), np.int32)
+        st = np.zeros(4, np.int32)
+        thr = self.std_z if threshold is None else float(threshold)     # ransac_hypotheses.m:33
+        check(lib.pre3_ransac(self._ctx, n_draw, k, dptr(hyp), C.c_double(thr), int(bool(early_exit)), dptr(sup), dptr(li), dptr(st)))
+        return dict(support=sup, li_mask=li[:self.m], best=int(st[0]), iters=int(st[1]), n_hyp=int(st[2]), max_support=int(st[3]))
+
+    def ransac_score_shard(self, hyp, threshold, hyp_begin, hyp_end):
+        """Score hypotheses [hyp_begin, hyp_end) only; returns (support_dev_ptr, mask_dev_ptr, mask_words)."""
+        hyp = i32(hyp)
+        n_draw, k = hyp.shape
+        sp, mp, mw = C.c_void_p(), C.c_void_p(), C.c_int(0)
+        check(lib.pre3_ransac_score(self._ctx, n_draw, k, dptr(hyp), C.c_double(float(threshold)), int(hyp_begin), int(hyp_end),
+                                    C.byref(sp), C.byref(mp), C.byref(mw)))
+        return sp.value, mp.value, mw.value
+
+    def ransac_select(self, n_draw, k, early_exit=True):
+        sup = np.zeros(n_draw, np.int32)
+        li = np.zeros(max(self.m, 1), np.int32)
+        st = np.zeros(4, np.int32)
+        check(lib.pre3_ransac_select(self._ctx, int(n_draw), int(k), int(bool(early_exit)), dptr(sup), dptr(li), dptr(st)))
+        return dict(support=sup, li_mask=li[:self.m], best=int(st[0]), iters=int(st[1]), n_hyp=int(st[2]), max_support=int(st[3]))
+
+    def ekf_update_li_inliers(self):
+        check(lib.pre3_update_li(self._ctx))
+
+    def rescue_hi_inliers(self, chi2=CHI2INV_2_95):
+        hi = np.zeros(max(self.m, 1), np.int32)
+        check(lib.pre3_rescue(self._ctx, C.c_double(chi2), dptr(hi)))
+        return hi[:self.m]
+
+    def ekf_update_hi_inliers(self):
+        check(lib.pre3_update_hi(self._ctx))
+
+    def ekf_update_all(self):
+        check(lib.pre3_update_all(self._ctx))
+
+    def set_flags(self, li=None, hi=None):
+        li = None if li is None else i32(li)
+        hi = None if hi is None else i32(hi)
+        check(lib.pre3_set_flags(self._ctx, dptr(li), dptr(hi)))
+
+    def get_flags(self):
+        li, hi = np.zeros(max(self.m, 1), np.int32), np.zeros(max(self.m, 1), np.int32)
+        check(lib.pre3_get_flags(self._ctx, dptr(li), dptr(hi)))
+        return li[:self.m], hi[:self.m]
+
+    def step(self, u, meas_idx, z, hyp, threshold=None, early_exit=True, chi2=CHI2INV_2_95):
+        """One '1PRE' filter step (mono_slam.m:153-187)."""
+        u, meas_idx, z, hyp = f64(u), i32(meas_idx), f64(z), i32(hyp)
+        self.m = int(meas_idx.shape[0])
+        n_draw, k = hyp.shape
+        st = np.zeros(8, np.int32)
+        thr = self.std_z if threshold is None else float(threshold)
+        check(lib.pre3_step(self._ctx, dptr(u), self.m, dptr(meas_idx), dptr(z), n_draw, k, dptr(hyp), C.c_double(thr),
+                            int(bool(early_exit)), C.c_double(chi2), dptr(st)))
+        return dict(best=int(st[0]), iters=int(st[1]), n_hyp=int(st[2]), max_support=int(st[3]), n_li=int(st[4]), n_hi=int(st[5]))
+
+    # ---- measurement hooks
+    def timer_start(self):
+        check(lib.pre3_timer_start(self._ctx))
+
+    def timer_stop(self):
+        ms = C.c_double(0)
+        check(lib.pre3_timer_stop(self._ctx, C.byref(ms)))
+        return ms.value
+
+    def kernel_timing(self, enable):
+        check(lib.pre3_kernel_timing(self._ctx, int(bool(enable))))
+
+    def kernel_timing_read(self):
+        n, ms, fl, by = C.c_int(0), C.c_double(0), C.c_double(0), C.c_double(0)
+        check(lib.pre3_kernel_timing_read(self._ctx, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
+        return dict(launches=n.value, total_ms=ms.value, flops=fl.value, bytes=by.value)
+
+    def bench_downdate(self, r, reps):
+        ms = C.c_double(0)
+        check(lib.pre3_bench_downdate(self._ctx, int(r), int(reps), C.byref(ms)))
+        return ms.value
+
+
+# ---------------------------------------------------------------------------------------------------
+# stateless drop-ins
+# ---------------------------------------------------------------------------------------------------
+def _to_ell(H, n):
+    """rows of H (dense r x n ndarray or scipy.sparse) -> (width, nnz[r], col[r*width], val[r*width])"""
+    try:
+        import scipy.sparse as sp
+        if sp.issparse(H):
+            H = H.tocsr()
+            r = H.shape[0]
+            nnz = np.diff(H.indptr).astype(np.int32)
+            width = max(int(nnz.max()) if r else 1, 1)
+            col = np.zeros((r, width), np.int32)
+            val = np.zeros((r, width))
+            for a in range(r):
+                s, e = H.indptr[a], H.indptr[a + 1]
+                col[a, :e - s] = H.indices[s:e]
+                val[a, :e - s] = H.data[s:e]
+            return width, nnz, col, val
+    except ImportError:  # pragma: no cover
+        pass
+    H = np.asarray(H, dtype=np.float64)
+    r = H.shape[0]
+    nz = H != 0
+    nnz = nz.sum(axis=1).astype(np.int32)
+    width = max(int(nnz.max()) if r else 1, 1)
+    col = np.zeros((r, width), np.int32)
+    val = np.zeros((r, width))
+    for a in range(r):
+        idx = np.nonzero(nz[a])[0]
+        col[a, :len(idx)] = idx
+        val[a, :len(idx)] = H[a, idx]
+    return width, nnz, col, val
+
+
+def update(x_km1_k, p_km1_k, H, R, z, h, dtype="f64", device=0, want_K=True):
+    """[x_k_k, p_k_k, K] = update(x_km1_k, p_km1_k, H, R, z, h)   (update.m:27).
+
+    H: r x n (dense or scipy sparse, at most 16 non-zeros per row -- the reference's rows have 13);
+    R: r x r or None for eye(r).  An empty z returns the inputs and K = 0 (update.m:50-55)."""
+    x, P = f64(x_km1_k).ravel(), f64(p_km1_k)
+    n = x.shape[0]
+    z, h = f64(z).ravel(), f64(h).ravel()
+    r = z.shape[0]
+    xo, Po = np.empty(n), np.empty((n, n))
+    if r == 0:
+        check(lib.pre3_update_ell(int(device), {"f64": 0, "f32": 1}[dtype], n, 0, dptr(x), dptr(P), 1, None, None, None, None, None, None,
+                                  dptr(xo), dptr(Po), None))
+        return xo, Po, 0
+    width, nnz, col, val = _to_ell(H, n)
+    if width > 16:
+        raise Pre3Error(-1, "update: H has a row with %d non-zeros; the measurement rows of this filter have 13 (max 16)" % width)
+    col, val = i32(col), f64(val)
+    Rm = None if R is None else f64(R)
+    K = np.zeros((r, n)) if want_K else None
+    check(lib.pre3_update_ell(int(device), {"f64": 0, "f32": 1}[dtype], n, r, dptr(x), dptr(P), width, dptr(nnz), dptr(col), dptr(val),
+                              dptr(Rm), dptr(z), dptr(h), dptr(xo), dptr(Po), dptr(K)))
+    return xo, Po, (K.T.copy() if want_K else None)       # K_out is n x r column-major == (r x n row-major)'
+
+
+def predict_state_and_covariance(X_k, P_k, u, cam=None, dtype="f64", device=0):
+    """[X_km1_k, P_km1_k] = predict_state_and_covariance(X_k, P_k, ...) with u = [dX; dq] explicit."""
+    X_k, P_k = f64(X_k).ravel(), f64(P_k)
+    n = X_k.shape[0]
+    if (n - 13) % 6 == 0:
+        types = np.zeros((n - 13) // 6, np.int32)
+    elif (n - 13) % 3 == 0:
+        types = np.ones((n - 13) // 3, np.int32)
+    else:
+        raise Pre3Error(-1, "predict: state size %d is not 13 + 6a + 3b" % n)
+    f = EkfFilter(cam if cam is not None else [1, 0, 0, 0, 0, 1, 1], types, dtype=dtype, device=device, max_hyp=1)
+    try:
+        f.set_x_p_k_k(X_k, P_k)
+        f.ekf_prediction(u)
+        return f.get_x_k_km1(), f.get_p_k_km1()
+    finally:
+        f.close()

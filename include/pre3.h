@@ -1,0 +1,201 @@
+/*
+ * pre3.h -- C ABI of libpre3.so: the MI355X (gfx950) implementation of the per-step hot path of
+ * the MATLAB 1-point-RANSAC EKF-SLAM reference ahtamjidi/3PRE.
+ *
+ * The reference's only native plug-in boundary is the MATLAB MEX interface
+ * (matlab_code/sift/siftmatch.c:139-141 `mexFunction`; Coder variant
+ * matlab_code/mex_files/CorePar_Ver1/codegen/mex/corrcoef_partitioned/corrcoef_partitioned_mex.c:50-57).
+ * A MEX file named like an .m function shadows it, so each entry point below states the .m (or .c)
+ * function it replaces; mex/ holds the gateways and INTEGRATION.md the binding recipe.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 on success or a negative pre3_status;
+ *     pre3_last_error() gives the message of the calling thread's last failure.  Nothing exits or throws.
+ *   - host arrays are caller-owned `double`, MATLAB (column-major) order unless stated; the covariance is
+ *     symmetric so its orientation does not matter.  Indices crossing the ABI are 0-based int32
+ *     (the MEX gateways convert from MATLAB's 1-based doubles).
+ *   - a pre3_ctx owns device-resident filter state (x, P, landmark table, per-landmark h/H/S/z/flags) on
+ *     ONE GPU and one HIP stream; calls on one ctx must be serialised by the caller (MATLAB's
+ *     interpreter thread does); different contexts are independent.
+ *   - dtype selects the storage/compute type of the dense covariance path (P, H*P, S, Cholesky, the
+ *     MFMA down-date): PRE3_F64 or PRE3_F32.  The state vector, camera geometry, Jacobians, innovations
+ *     and gates are always evaluated in fp64.
+ *   - there is no CPU fallback: without a HIP device every call fails with PRE3_E_NODEVICE.
+ */
+#ifndef PRE3_H
+#define PRE3_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRE3_API __attribute__((visibility("default")))
+
+typedef struct pre3_ctx pre3_ctx;
+
+typedef enum {
+    PRE3_OK = 0,
+    PRE3_E_ARG = -1,        /* bad argument / shape mismatch (the MEX gateways map this to mexErrMsgTxt) */
+    PRE3_E_NODEVICE = -2,   /* no HIP device / HIP runtime failure at init */
+    PRE3_E_HIP = -3,        /* a HIP call or kernel failed */
+    PRE3_E_STATE = -4,      /* call order violated (e.g. update before predict/project) */
+    PRE3_E_NUMERIC = -5,    /* S not positive definite */
+    PRE3_E_NOMEM = -6
+} pre3_status;
+
+enum { PRE3_F64 = 0, PRE3_F32 = 1 };
+enum { PRE3_INVDEPTH = 0, PRE3_CARTESIAN = 1 };   /* features_info(i).type */
+enum { PRE3_X_K_K = 0, PRE3_X_K_KM1 = 1 };        /* which estimate (ekf_filter.m:63-87 fields) */
+
+/* cam struct fields used by the path (initialize_cam.m:69-78) */
+typedef struct { double f, Cx, Cy, k1, k2, nRows, nCols; } pre3_cam;
+
+PRE3_API const char *pre3_last_error(void);
+PRE3_API int pre3_device_count(void);
+PRE3_API const char *pre3_version(void);
+
+/* ---- context ----------------------------------------------------------------------------------- */
+
+/* device = HIP ordinal; max_landmarks / max_hyp size the device buffers once (no allocation afterwards). */
+PRE3_API int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int max_hyp);
+PRE3_API int pre3_destroy(pre3_ctx *ctx);
+PRE3_API int pre3_sync(pre3_ctx *ctx);                       /* wait for the ctx stream */
+PRE3_API int pre3_set_cam(pre3_ctx *ctx, const pre3_cam *cam);
+
+/* Landmark table = [features_info.type] in state order (add_feature_to_info_vector_my_version_sift.m:37-60).
+ * Resets all per-landmark fields (h, H, S, z, flags), as update_features_info.m:30-44 does each step. */
+PRE3_API int pre3_set_map(pre3_ctx *ctx, int N, const int32_t *lm_type);
+PRE3_API int pre3_state_size(pre3_ctx *ctx);                 /* n = 13 + 6*N_id + 3*N_euc */
+
+/* x(n), P(n x n) -> device as x_k_k / p_k_k (set_x_k_k.m / set_p_k_k.m), or as x_k_km1 / p_k_km1. */
+PRE3_API int pre3_set_state(pre3_ctx *ctx, int which, int n, const double *x, const double *P);
+PRE3_API int pre3_get_state(pre3_ctx *ctx, int which, int n, double *x, double *P);   /* P may be NULL */
+
+/* ---- a2: predict_state_and_covariance.m:27-143 (called by @ekf_filter/ekf_prediction.m:29) ------ */
+/* u = [dX(3); dq(4)], the visual-odometry increment the reference reads through fv.m:47.
+ * (x_k_k, p_k_k) -> (x_k_km1, p_k_km1); the covariance is transformed IN PLACE (only rows/cols 4:7
+ * and the 7x7 pose block change), so p_k_k is no longer available afterwards. */
+PRE3_API int pre3_predict(pre3_ctx *ctx, const double u[7]);
+
+/* ---- a3/a4: predict_camera_measurements.m:27-68 + calculate_derivatives.m:27-60 ------------------ */
+/* Projects every landmark at the chosen estimate and linearises it (compact H_i = 2x7 pose block +
+ * 2x6 landmark block; columns 8:13 of the reference's H are zero).  clear_first=1 empties h/H first
+ * (the state search_IC_matches.m:31 sees after update_features_info.m:40); clear_first=0 keeps the
+ * previous h of landmarks that are not predicted now (rescue_hi_inliers.m:32-33, quirk Q7). */
+PRE3_API int pre3_project(pre3_ctx *ctx, int which, int clear_first);
+
+/* ---- a5: search_IC_matches.m:33-44: S_i = H_i P H_i' + R_i (R_i = eye(2)) for predicted landmarks */
+PRE3_API int pre3_innovation(pre3_ctx *ctx);
+
+/* read back per-landmark fields (any pointer may be NULL): h[2N], has_h[N], Hc[14N] (2x7 row-major),
+ * Hl[12N] (2x6 row-major), S[4N] */
+PRE3_API int pre3_get_landmark_fields(pre3_ctx *ctx, double *h, int32_t *has_h, double *Hc, double *Hl, double *S);
+
+/* matching_sift_based.m:119-134 window gate.  Candidate c pairs the k1[c]-th PREDICTED landmark (the
+ * L1 column siftmatch matched) with pixel zc[2c..2c+1]; accepted candidates become individually
+ * compatible and get z.  strict_reference=1 reproduces quirk Q5 (S of the c-th predicted landmark).
+ * accept_out[M] may be NULL. */
+PRE3_API int pre3_window_gate(pre3_ctx *ctx, int M, const int32_t *k1, const double *zc, int strict_reference,
+                              int32_t *accept_out);
+
+/* Direct form: landmarks meas_idx[m] (ascending) are individually compatible with pixels z[2m]
+ * (what matching_sift_based.m:131-134 leaves in features_info). */
+PRE3_API int pre3_set_measurements(pre3_ctx *ctx, int m, const int32_t *meas_idx, const double *z);
+
+/* ---- a6-a8: ransac_hypotheses.m:27-85 ----------------------------------------------------------- */
+/* hyp[n_draw*k]: per hypothesis k positions in the individually-compatible list (what
+ * select_random_match.m:40-51 draws with randperm; MATLAB's legacy RNG stream is not reproducible,
+ * so the draws are an input).  early_exit=1 replays the reference's adaptive termination (quirk Q1)
+ * over the supports; 0 uses all n_draw.  [hyp_begin, hyp_end) restricts the hypotheses THIS context
+ * scores (multi-GPU sharding, see pre3_ransac_score / pre3_ransac_select).
+ * Outputs (may be NULL): support[n_draw] (int32; -1 for hypotheses after the exit point),
+ * li_mask[m] (int32 0/1 in measurement order), stats[4] = {best, iterations, n_hyp, max_support}. */
+PRE3_API int pre3_ransac(pre3_ctx *ctx, int n_draw, int k, const int32_t *hyp, double threshold, int early_exit,
+                         int32_t *support, int32_t *li_mask, int32_t stats[4]);
+
+/* Sharded form: score hypotheses [hyp_begin,hyp_end) only, leaving their supports (int32, others 0)
+ * and inlier bitmasks in device buffers; *support_dev / *mask_dev receive DEVICE pointers to
+ * int32[n_draw] and uint32[n_draw * mask_words] so the caller can all-reduce them (RCCL) in place;
+ * pre3_ransac_select then replays the termination rule on the (reduced) buffers. */
+PRE3_API int pre3_ransac_score(pre3_ctx *ctx, int n_draw, int k, const int32_t *hyp, double threshold,
+                               int hyp_begin, int hyp_end, void **support_dev, void **mask_dev, int *mask_words);
+PRE3_API int pre3_ransac_select(pre3_ctx *ctx, int n_draw, int k, int early_exit,
+                                int32_t *support, int32_t *li_mask, int32_t stats[4]);
+
+/* ---- a9: update.m:27-56 via the @ekf_filter wrappers --------------------------------------------- */
+/* ekf_update_li_inliers.m:45-58: prior (x_k_km1,p_k_km1), rows = low-innovation inliers */
+PRE3_API int pre3_update_li(pre3_ctx *ctx);
+/* rescue_hi_inliers.m:29-47: re-project + re-linearise at x_k_k, chi-square gate (no +R, quirk Q6).
+ * hi_mask[m] (may be NULL) in measurement order. */
+PRE3_API int pre3_rescue(pre3_ctx *ctx, double chi2, int32_t *hi_mask);
+/* ekf_update_hi_inliers.m:45-58: prior (x_k_k,p_k_k), rows = high-innovation inliers */
+PRE3_API int pre3_update_hi(pre3_ctx *ctx);
+/* ekf_update_all.m:46-62 ('PURE_EKF'): prior km1, rows = all individually compatible landmarks */
+PRE3_API int pre3_update_all(pre3_ctx *ctx);
+/* read/force the per-measurement flags: li/hi[m] int32 in measurement order (NULL = leave) */
+PRE3_API int pre3_get_flags(pre3_ctx *ctx, int32_t *li, int32_t *hi);
+PRE3_API int pre3_set_flags(pre3_ctx *ctx, const int32_t *li, const int32_t *hi);
+
+/* One whole filter step of mono_slam.m:153-187 ('1PRE'): predict, project+linearise, S_i,
+ * [measurements given], RANSAC, LI update, rescue, HI update -- enqueued back to back on the ctx
+ * stream.  stats[8] = {best, iterations, n_hyp, max_support, n_li, n_hi, 0, 0} (may be NULL). */
+PRE3_API int pre3_step(pre3_ctx *ctx, const double u[7], int m, const int32_t *meas_idx, const double *z,
+                       int n_draw, int k, const int32_t *hyp, double threshold, int early_exit, double chi2,
+                       int32_t stats[8]);
+
+/* Stateless drop-in for `[x,P,K] = update(x,P,H,R,z,h)` (update.m:27): host in, host out.
+ * H is r x n given by rows in ELL form: row a has nnz[a] <= width entries (col[a*width+t], val[...]);
+ * R is r x r dense or NULL for eye(r) (every caller in the reference passes eye).  K_out (n x r,
+ * column-major) may be NULL.  r == 0 returns the inputs (update.m:50-55). */
+PRE3_API int pre3_update_ell(int device, int dtype, int n, int r, const double *x, const double *P, int width,
+                             const int32_t *nnz, const int32_t *col, const double *val, const double *R,
+                             const double *z, const double *h, double *x_out, double *P_out, double *K_out);
+
+/* ---- a10: sift/siftmatch.c:83-132,139-250 ------------------------------------------------------- */
+/* L1: ND x K1, L2: ND x K2, one descriptor per column (column-major, as mxGetData returns them).
+ * pairs_out[2*K1] receives 1-based (k1,k2) doubles in increasing k1 exactly as the MEX writes them
+ * (:241-242); score_out[K1] (may be NULL) the best squared distance; *M_out the number of matches.
+ * Accumulation follows the class promotion of :61-64 (double, float, int, int); the ratio test is in
+ * float (:122).  Ties keep the first index (:110-116). */
+PRE3_API int pre3_siftmatch_f64(int device, int ND, int K1, const double *L1, int K2, const double *L2, double thresh,
+                                double *pairs_out, double *score_out, int *M_out);
+PRE3_API int pre3_siftmatch_f32(int device, int ND, int K1, const float *L1, int K2, const float *L2, double thresh,
+                                double *pairs_out, double *score_out, int *M_out);
+PRE3_API int pre3_siftmatch_u8(int device, int ND, int K1, const uint8_t *L1, int K2, const uint8_t *L2, double thresh,
+                               double *pairs_out, double *score_out, int *M_out);
+PRE3_API int pre3_siftmatch_i8(int device, int ND, int K1, const int8_t *L1, int K2, const int8_t *L2, double thresh,
+                               double *pairs_out, double *score_out, int *M_out);
+
+/* Sharded matcher (database columns [k2_begin,k2_end) of L2 on this GPU): per query the local best,
+ * second best (as double) and the GLOBAL 0-based index of the best, for the all-gather + merge of
+ * DESIGN.md section "multi-GPU".  cls: 0 f64, 1 f32, 2 u8, 3 i8.  best/second/arg: host arrays [K1]. */
+PRE3_API int pre3_siftmatch_partial(int device, int cls, int ND, int K1, const void *L1, int K2_local, const void *L2_local,
+                                    int k2_offset, double *best, double *second, int32_t *arg);
+/* merge G shards' partials (best[g*K1+k1] ...) and apply the ratio test; same outputs as pre3_siftmatch_* */
+PRE3_API int pre3_siftmatch_merge(int cls, int G, int K1, const double *best, const double *second, const int32_t *arg,
+                                  double thresh, double *pairs_out, double *score_out, int *M_out);
+
+/* ---- a11: kNearestNeighbors.m:29-39 ------------------------------------------------------------- */
+/* data: N x D, query: M x D, MATLAB column-major.  ids_out (M x k, column-major, 1-based doubles),
+ * dist_out (M x k, Euclidean).  Ties: lowest index first (MATLAB's stable sort). */
+PRE3_API int pre3_knn_f64(int device, int D, int N, const double *data, int M, const double *query, int k,
+                          double *ids_out, double *dist_out);
+
+/* ---- measurement hooks (bench.py) ---------------------------------------------------------------- */
+/* HIP-event timing on the ctx stream: the timed region of bench.py and the per-launch duration of
+ * the covariance down-date kernel (K9) are measured with these, not with torch events. */
+PRE3_API int pre3_timer_start(pre3_ctx *ctx);
+PRE3_API int pre3_timer_stop(pre3_ctx *ctx, double *ms_out);             /* synchronises */
+PRE3_API int pre3_kernel_timing(pre3_ctx *ctx, int enable);             /* bracket every K9 launch with events */
+PRE3_API int pre3_kernel_timing_read(pre3_ctx *ctx, int *launches_out, double *total_ms_out, double *flops_out,
+                                     double *bytes_out);                /* synchronises, then resets */
+/* run only the K9 down-date P <- P - W'W with a synthetic W of r rows `reps` times (roofline probe) */
+PRE3_API int pre3_bench_downdate(pre3_ctx *ctx, int r, int reps, double *ms_per_launch_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRE3_H */
