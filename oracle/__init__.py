@@ -212,3 +212,32 @@ def knn(data, query, k):
     rc = lib().orc_knn(D, N, _p(data), M, _p(query), k, _p(ids), _p(dist))
     assert rc == 0
     return ids, dist
+
+
+def step(types, off, cam, x_kk, P_kk, u, meas_idx, z_meas, hyp, threshold, early_exit=True, chi2=5.9915):
+    """One '1PRE' filter step in the reference's order (mono_slam.m:153-187) built from the oracle pieces.
+    meas_idx: measured (= individually compatible) landmarks, ascending; z_meas: their pixels (m x 2);
+    hyp: (n_draw x k) positions in the IC list."""
+    N = len(types)
+    meas_idx = np.asarray(meas_idx, np.int32)
+    x1, P1 = predict(x_kk, P_kk, u)                                   # ekf_prediction
+    h, has_h = project(types, off, x1, cam)                           # search_IC_matches.m:31
+    Hc, Hl = jacobian(types, off, x1, cam, h, has_h)                  # :32
+    S = innovation(types, off, P1, Hc, Hl, has_h)                     # :33-44
+    z = np.zeros((N, 2))
+    z[meas_idx] = z_meas
+    ic = np.zeros(N, np.int32)
+    ic[meas_idx] = 1
+    li = np.zeros(N, np.int32)
+    out = dict(x_km1=x1, P_km1=P1, S=S, h_km1=h.copy())
+    if len(meas_idx) >= hyp.shape[1] and len(meas_idx) > 0:
+        r = ransac(types, off, x1, P1, Hc, Hl, z, h, meas_idx, meas_idx, cam, hyp, threshold, early_exit)
+        li[meas_idx] = r["li_mask"]
+        out["ransac"] = r
+    x2, P2 = update_landmarks(types, off, np.nonzero(li)[0], x1, P1, Hc, Hl, z, h)      # ekf_update_li_inliers
+    h2, has2 = project(types, off, x2, cam, h, has_h)                                     # rescue_hi_inliers.m:32
+    Hc2, Hl2 = jacobian(types, off, x2, cam, h2, has2)
+    hi, d2 = rescue(types, off, P2, Hc2, Hl2, h2, z, ic, li, chi2)
+    x3, P3 = update_landmarks(types, off, np.nonzero(hi)[0], x2, P2, Hc2, Hl2, z, h2)   # ekf_update_hi_inliers
+    out.update(x_kk=x3, P_kk=P3, li=li[meas_idx], hi=hi[meas_idx], x_li=x2, P_li=P2, d2=d2)
+    return out
