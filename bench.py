@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""bench.py -- EKF steps/s (predict + project/Jacobian + S_i + RANSAC + LI update + rescue + HI update) at
+N=500 inverse-depth landmarks (n=3013), 200 RANSAC hypotheses, fp32 covariance path: BASELINE.json configs[2],
+the configuration the headline metric is quoted on.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one whole filter step on one synthetic frame (3pre_amd/synth.py, deterministic seeds).  State
+and covariance are resident in HBM before the timed region; per step only the frame's measurements (<= 400
+pixels), the odometry increment and the hypothesis draws cross PCIe, as they would from the matcher.
+N > 1: the EKF state does not shard (DESIGN.md "multi-GPU"), so each rank filters its own independent
+sequence (weak scaling, no data-path collective); value = steps of all ranks / max-over-ranks time.
+The sharded RANSAC scorer with its RCCL all-reduce is measured as a separate leg ("ransac_shard").
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK = {"f32": 157.3, "f64": 78.6}       # dense MFMA TFLOP/s, MI355X_MICROARCH.md "Chip-level parameters" / "Matrix cores"
+
+
+def cpu_baseline(seq, n_steps, threshold):
+    """The oracle's numpy twin (interpreter + multithreaded BLAS: the MATLAB-equivalent restatement) timed on
+    the host cores over a bounded sample of the SAME sequence.  Checker code, used here only as a baseline."""
+    twin = importlib.import_module("oracle.np_twin")
+    import oracle as orc
+    N = seq["N"]
+    types, off, _ = orc.landmark_table(np.zeros(N, int))
+    x, P = seq["x0"], seq["P0"]
+    t_tot, done = 0.0, 0
+    for s in seq["steps"][:n_steps]:
+        t0 = time.perf_counter()
+        o = twin.step(types, off, seq["cam"], x, P, s["u"], s["meas_idx"], s["z"], s["hyp"], threshold, early_exit=False)
+        t_tot += time.perf_counter() - t0
+        done += 1
+        x, P = o["x_kk"], o["P_kk"]
+        if t_tot > 30.0:
+            break
+    try:
+        import threadpoolctl
+        cores = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {"value": done / t_tot, "unit": "steps/s", "cores": int(cores), "kind": "port",
+            "sample": "%d steps of the same N=%d, %d-hypothesis sequence; numpy twin of the oracle (Python loops + OpenBLAS, "
+                      "fp64, all hypotheses evaluated)" % (done, N, seq["steps"][0]["hyp"].shape[0])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--landmarks", type=int, default=500)
+    ap.add_argument("--hyp", type=int, default=200)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=8)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    pre3 = importlib.import_module("3pre_amd")
+    synth = importlib.import_module("3pre_amd.synth")
+    if pre3.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+
+    N, K, W = args.landmarks, args.steps, args.warmup
+    thr = 1.0
+    seq = synth.make_sequence(N, K + W, args.hyp, seed=None if rank == 0 else 10_000 * rank + N)
+    f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype=args.dtype, device=local_rank, max_hyp=args.hyp, std_z=thr)
+    f.set_x_p_k_k(seq["x0"], seq["P0"])
+    stats = []
+    for s in seq["steps"][:W]:
+        f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=thr, early_exit=False)
+    f.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    f.kernel_timing(True)
+    f.timer_start()
+    t0 = time.perf_counter()
+    for s in seq["steps"][W:W + K]:
+        stats.append(f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=thr, early_exit=False))
+    ev_ms = f.timer_stop()                       # HIP events on the stream the kernels run on (synchronises)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kt = f.kernel_timing_read()
+    f.kernel_timing(False)
+
+    out = None
+    if rank == 0:
+        n = seq["n"]
+        n_li = float(np.mean([s["n_li"] for s in stats]))
+        n_hi = float(np.mean([s["n_hi"] for s in stats]))
+        achieved = kt["flops"] / (kt["total_ms"] * 1e-3) / 1e12 if kt["total_ms"] > 0 else 0.0
+        out = {
+            "metric": "EKF steps/sec (predict+RANSAC+update) at N=500 landmarks; P-update %MFMA peak",
+            "value": world * K / elapsed, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "configs[2]: N=%d inverse-depth landmarks (n=%d), %d RANSAC hypotheses (k=3, all evaluated), "
+                                   "%s covariance path, full 1PRE step" % (N, n, args.hyp, args.dtype),
+                       "measured_per_step": int(np.mean([len(s["meas_idx"]) for s in seq["steps"][W:W + K]])),
+                       "mean_li_rows": 2 * n_li, "mean_hi_rows": 2 * n_hi, "parallelism": "replicas x%d" % world,
+                       "hip_event_ms_per_step": ev_ms / K},
+            "roofline": {"kernel": "k_downdate (K9: P <- P - W'W)", "bound": "mfma", "achieved": achieved, "peak": PEAK[args.dtype],
+                         "unit": "TFLOP/s", "frac": achieved / PEAK[args.dtype], "traffic": None,
+                         "launches": kt["launches"], "avg_launch_us": 1e3 * kt["total_ms"] / max(kt["launches"], 1),
+                         "algorithmic": "2*n^2*r flop per launch (SURVEY 8d), r = rows of that update"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(seq, args.cpu_steps, thr)
+    f.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

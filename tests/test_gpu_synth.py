@@ -1,0 +1,178 @@
+"""GPU parity on seeded synthetic sequences (sizes the oracle finishes in seconds) and size-independent
+properties at BASELINE.json's full sizes.  Everything goes through the C ABI."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+synth = importlib.import_module("3pre_amd.synth")
+
+
+def _run_sequence(pre3, orc, N, steps, n_hyp, dtype, tol_x, tol_P, chain_on_oracle=True, seed=None):
+    seq = synth.make_sequence(N, steps, n_hyp, seed=seed)
+    types, off, n = orc.landmark_table(np.zeros(N, int))
+    f = pre3.EkfFilter(seq["cam"], types, dtype=dtype, max_hyp=n_hyp, std_z=1.0)
+    x, P = seq["x0"], seq["P0"]
+    f.set_x_p_k_k(x, P)
+    for s in seq["steps"]:
+        st = f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=1.0, early_exit=True)
+        ref = orc.step(types, off, seq["cam"], x, P, s["u"], s["meas_idx"], s["z"], s["hyp"], 1.0, early_exit=True)
+        li, hi = f.get_flags()
+        assert np.array_equal(li, ref["li"]), "LI set differs"
+        assert np.array_equal(hi, ref["hi"]), "HI set differs"
+        r = ref["ransac"]
+        assert (st["best"], st["iters"], st["n_hyp"], st["max_support"]) == (r["best"], r["iters"], r["n_hyp"], r["max_support"])
+        xg, Pg = f.get_x_k_k(), f.get_p_k_k()
+        assert np.abs(xg - ref["x_kk"]).max() < tol_x
+        assert np.abs(Pg - ref["P_kk"]).max() < tol_P * np.abs(ref["P_kk"]).max()
+        assert np.abs(Pg - Pg.T).max() == 0.0 or np.abs(Pg - Pg.T).max() < 1e-3 * tol_P * np.abs(Pg).max()
+        # chain on the oracle's state so that tolerances do not compound (fp32) / on the GPU's own state (fp64)
+        x, P = ref["x_kk"], ref["P_kk"]
+        if chain_on_oracle:
+            f.set_x_p_k_k(x, P)
+    f.close()
+
+
+def test_sequence_fp64_n50(pre3, orc):
+    _run_sequence(pre3, orc, 50, 4, 40, "f64", 1e-10, 1e-11, chain_on_oracle=False)
+
+
+def test_sequence_fp64_n120(pre3, orc):
+    _run_sequence(pre3, orc, 120, 2, 60, "f64", 1e-10, 1e-11)
+
+
+def test_sequence_fp32_n50(pre3, orc):
+    # fp32 covariance path: inlier index sets must still be identical on this data; P to 5e-4 of its scale
+    _run_sequence(pre3, orc, 50, 4, 40, "f32", 2e-5, 5e-4)
+
+
+def test_predict_parity(pre3, orc):
+    seq = synth.make_sequence(30, 1, 4, seed=9)
+    x, P = seq["x0"].copy(), seq["P0"]
+    x[3:7] = np.array([0.98, 0.1, -0.12, 0.05]) / np.linalg.norm([0.98, 0.1, -0.12, 0.05])
+    x[7:13] = 0.3
+    u = seq["steps"][0]["u"]
+    xr, Pr = orc.predict(x, P, u)
+    for dtype, tol in (("f64", 1e-13), ("f32", 2e-6)):
+        xg, Pg = pre3.predict_state_and_covariance(x, P, u, dtype=dtype)
+        assert np.abs(xg - xr).max() < 1e-14
+        assert np.abs(Pg - Pr).max() < tol * np.abs(Pr).max()
+
+
+def test_mixed_landmark_types(pre3, orc):
+    """Cartesian + inverse-depth landmarks through projection, S_i, RANSAC, updates (unpinned branch: GPU vs oracle)."""
+    from test_oracle import _mixed_problem
+    types, x, P, cam = _mixed_problem(seed=4, N=30)
+    t, off, n = orc.landmark_table(types)
+    f = pre3.EkfFilter(cam, types, dtype="f64", max_hyp=32, std_z=1.0)
+    f.set_x_p_k_km1(x, P)
+    f.search_IC_matches()
+    fld = f.landmark_fields()
+    h, has = orc.project(t, off, x, cam)
+    Hc, Hl = orc.jacobian(t, off, x, cam, h, has)
+    S = orc.innovation(t, off, P, Hc, Hl, has)
+    assert np.array_equal(fld["has_h"], has)
+    v = has.astype(bool)
+    assert np.abs(fld["h"][v] - h[v]).max() < 1e-10
+    assert np.abs(fld["Hc"][v] - Hc[v]).max() < 1e-8 and np.abs(fld["Hl"][v] - Hl[v]).max() < 1e-8
+    assert np.abs(fld["S"][v] - S[v]).max() < 1e-9
+    vis = np.nonzero(has)[0].astype(np.int32)
+    rng = np.random.default_rng(1)
+    z = np.zeros((len(types), 2))
+    z[vis] = h[vis] + rng.normal(0, 0.4, (len(vis), 2))
+    z[vis[3]] += 25
+    f.set_measurements(vis, z[vis])
+    hyp = np.stack([rng.permutation(len(vis))[:3] for _ in range(20)]).astype(np.int32)
+    out = f.ransac_hypotheses(hyp, threshold=1.0, early_exit=False)
+    ref = orc.ransac(t, off, x, P, Hc, Hl, z, h, vis, vis, cam, hyp, 1.0, early_exit=False)
+    assert np.array_equal(out["support"], ref["support"]) and np.array_equal(out["li_mask"], ref["li_mask"])
+    f.ekf_update_li_inliers()
+    sel = vis[ref["li_mask"].astype(bool)]
+    xr, Pr = orc.update_landmarks(t, off, sel, x, P, Hc, Hl, z, h)
+    # this prior is rank-12 + 1e-6 I, so cond(S) ~ 1e4 and P shrinks 100x: tolerance relative to the PRIOR scale
+    assert np.abs(f.get_x_k_k() - xr).max() < 1e-10 and np.abs(f.get_p_k_k() - Pr).max() < 1e-11 * np.abs(P).max()
+    f.close()
+
+
+def test_update_all_and_empty_measurements(pre3, orc):
+    seq = synth.make_sequence(20, 1, 4, seed=21)
+    types, off, n = orc.landmark_table(np.zeros(20, int))
+    s = seq["steps"][0]
+    f = pre3.EkfFilter(seq["cam"], types, dtype="f64", max_hyp=4)
+    f.set_x_p_k_km1(seq["x0"], seq["P0"])
+    f.search_IC_matches()
+    # 'PURE_EKF' branch: ekf_update_all with all IC landmarks
+    f.set_measurements(s["meas_idx"], s["z"])
+    f.ekf_update_all()
+    h, has = orc.project(types, off, seq["x0"], seq["cam"])
+    Hc, Hl = orc.jacobian(types, off, seq["x0"], seq["cam"], h, has)
+    z = np.zeros((20, 2))
+    z[s["meas_idx"]] = s["z"]
+    xr, Pr = orc.update_landmarks(types, off, s["meas_idx"], seq["x0"], seq["P0"], Hc, Hl, z, h)
+    assert np.abs(f.get_p_k_k() - Pr).max() < 1e-11 * np.abs(Pr).max()
+    assert np.abs(f.get_x_k_k() - xr).max() < 1e-10
+    # no measurements at all: the step degenerates to predict; updates are the identity (update.m:50-55)
+    f.set_x_p_k_k(seq["x0"], seq["P0"])
+    st = f.step(s["u"], np.zeros(0, np.int32), np.zeros((0, 2)), np.zeros((1, 3), np.int32))
+    xr, Pr = orc.predict(seq["x0"], seq["P0"], s["u"])
+    assert st["n_li"] == 0 and st["n_hi"] == 0
+    assert np.abs(f.get_x_k_k() - xr).max() < 1e-14 and np.abs(f.get_p_k_k() - Pr).max() < 1e-13 * np.abs(Pr).max()
+    f.close()
+
+
+def test_window_gate(pre3, orc):
+    seq = synth.make_sequence(40, 1, 4, seed=33)
+    types, off, n = orc.landmark_table(np.zeros(40, int))
+    f = pre3.EkfFilter(seq["cam"], types, dtype="f64", max_hyp=4)
+    f.set_x_p_k_km1(seq["x0"], seq["P0"])
+    f.search_IC_matches()
+    fld = f.landmark_fields()
+    pred = np.nonzero(fld["has_h"])[0]
+    rng = np.random.default_rng(2)
+    k1 = np.sort(rng.choice(len(pred), 25, replace=False)).astype(np.int32)
+    zc = fld["h"][pred[k1]] + rng.normal(0, 6, (25, 2))
+    for strict in (True, False):
+        f.search_IC_matches()
+        acc = f.matching(k1, zc, strict_reference=strict)
+        ref = orc.window_gate(pred, k1, zc, fld["h"], fld["S"], fld["has_h"], strict_reference=strict)
+        assert np.array_equal(acc, ref)
+        assert 0 < acc.sum() < 25
+    f.close()
+
+
+def test_full_size_properties_config3(pre3):
+    """N=500 (n=3013), 200 hypotheses, fp32: no oracle at this size in seconds -> properties:
+    exact symmetry, positive diagonal, covariance never grows in the update, unit quaternion, stable inlier
+    counts, and fp32 vs fp64 agreement of the inlier sets on the first step."""
+    N, n_hyp = 500, 200
+    seq = synth.make_sequence(N, 3, n_hyp)
+    types = np.zeros(N, np.int32)
+    res = {}
+    for dtype in ("f64", "f32"):
+        f = pre3.EkfFilter(seq["cam"], types, dtype=dtype, max_hyp=n_hyp)
+        f.set_x_p_k_k(seq["x0"], seq["P0"])
+        flags = []
+        for s in seq["steps"]:
+            st = f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=1.0, early_exit=True)
+            li, hi = f.get_flags()
+            flags.append((li.copy(), hi.copy()))
+            inl = (li | hi).astype(bool)
+            assert inl[s["outliers"]].sum() <= 2                       # gross outliers rejected
+            assert inl.sum() >= 0.9 * (len(li) - len(s["outliers"]))   # true matches kept
+        P = f.get_p_k_k()
+        x = f.get_x_k_k()
+        # exactly symmetric except the 4 quaternion rows/cols the Jnorm rebuild touches (as in the reference: 6.6e-24 there)
+        A = np.abs(P - P.T)
+        assert A.max() < 1e-12 * np.abs(P).max()
+        A[3:7, :] = 0
+        A[:, 3:7] = 0
+        A[:7, :7] = 0
+        assert A.max() == 0.0
+        assert P.diagonal().min() > 0
+        assert abs(np.linalg.norm(x[3:7]) - 1) < 1e-12
+        assert np.trace(P) < np.trace(seq["P0"])
+        res[dtype] = (flags, x, P)
+        f.close()
+    assert np.array_equal(res["f64"][0][0][0], res["f32"][0][0][0])     # first-step LI sets identical
+    assert np.abs(res["f64"][2] - res["f32"][2]).max() < 2e-3 * np.abs(res["f64"][2]).max()
