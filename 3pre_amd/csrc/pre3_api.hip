@@ -1,5 +1,6 @@
 // pre3_api.hip -- the C ABI of include/pre3.h: context management, host<->device marshalling, and the
 // stage order of one filter step (mono_slam.m:153-187).  No compute happens on the host.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <new>
@@ -23,6 +24,7 @@ int launch_build_rows_impl(pre3_ctx *c, int nsel, const int32_t *sel_dev, int r_
 int launch_ransac_score_impl(pre3_ctx *c, int k, double threshold, int hyp_begin, int hyp_end, int ldg, int32_t *support_dev, uint32_t *mask_dev, int mask_words);
 int launch_ransac_select_impl(pre3_ctx *c, int n_draw, int k, int early_exit, int32_t *support_dev, const uint32_t *mask_dev, int mask_words);
 int launch_fill_w(pre3_ctx *c, int r_pad);
+int launch_clear_flags(pre3_ctx *c);
 int match_partial(int device, int cls, int ND, int K1, const void *L1, int K2, const void *L2, int k2_offset, double *best, double *second, int32_t *arg);
 int knn_run(int device, int D, int N, const double *data, int M, const double *query, int k, double *ids, double *dist);
 void *match_bench_create(int ND, int K1, const uint8_t *L1, int K2, const uint8_t *L2);
@@ -100,9 +102,22 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
     A(dmalloc(&c->lm.h, 2 * (size_t)c->capN)); A(dmalloc(&c->lm.has_h, c->capN));
     A(dmalloc(&c->lm.Hc, 14 * (size_t)c->capN)); A(dmalloc(&c->lm.Hl, 12 * (size_t)c->capN));
     A(dmalloc(&c->lm.S, 4 * (size_t)c->capN)); A(dmalloc(&c->lm.has_S, c->capN));
-    A(dmalloc(&c->lm.z, 2 * (size_t)c->capN));
-    A(dmalloc(&c->lm.ic, c->capN)); A(dmalloc(&c->lm.li, c->capN)); A(dmalloc(&c->lm.hi, c->capN));
-    A(dmalloc(&c->meas, c->capm));
+    A(dmalloc(&c->lm.li, c->capN)); A(dmalloc(&c->lm.hi, c->capN));
+    {
+        c->off_meas = 0;
+        c->off_ic = c->off_meas + sizeof(int32_t) * c->capm;
+        c->off_hyp = c->off_ic + sizeof(int32_t) * c->capN;
+        c->off_z = (c->off_hyp + sizeof(int32_t) * (size_t)c->caph * MAXK + 15) / 16 * 16;
+        c->inbox_bytes = c->off_z + sizeof(double) * 2 * c->capN;
+        A(dmalloc_bytes(&c->inbox_dev, c->inbox_bytes));
+        if (rc == PRE3_OK && hipHostMalloc((void **)&c->inbox_host, c->inbox_bytes) != hipSuccess) { set_error("hipHostMalloc failed"); rc = PRE3_E_NOMEM; }
+        if (rc == PRE3_OK) {
+            memset(c->inbox_host, 0, c->inbox_bytes);
+            unsigned char *d = (unsigned char *)c->inbox_dev;
+            c->meas = (int32_t *)(d + c->off_meas); c->lm.ic = (int32_t *)(d + c->off_ic);
+            c->hyp = (int32_t *)(d + c->off_hyp); c->lm.z = (double *)(d + c->off_z);
+        }
+    }
     A(dmalloc(&c->row_col, (size_t)c->rcap * ELLW)); A(dmalloc_bytes(&c->row_val, (size_t)c->rcap * ELLW * c->esz));
     A(dmalloc(&c->row_nu, c->rcap));
     A(dmalloc_bytes(&c->HP, (size_t)c->rcap * c->ldw * c->esz));
@@ -110,10 +125,30 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
     A(dmalloc_bytes(&c->G, (size_t)c->rcap * c->rcap * c->esz));
     A(dmalloc_bytes(&c->Smat, (size_t)c->rcap * c->rcap * c->esz));
     A(dmalloc(&c->sel_rows, c->rcap));
-    A(dmalloc(&c->hyp, (size_t)c->caph * MAXK)); A(dmalloc(&c->support, c->caph));
+    A(dmalloc(&c->support, c->caph));
     A(dmalloc(&c->masks, (size_t)c->caph * c->mask_words_cap));
     A(dmalloc(&c->stats, 16)); A(dmalloc(&c->li_meas, c->capm)); A(dmalloc(&c->hi_meas, c->capm));
     A(dmalloc(&c->pred_params, 128));
+    {
+        // K9 tile schedule: upper-triangle 64x64 tiles grouped in 4x4 super-tiles (8 W panels = 1.3 MB at r=640,
+        // inside one XCD's 4 MiB L2); super-tile s goes to blocks b with b % 8 == s % 8 (blocks are dealt
+        // round-robin over the 8 XCDs -- speed only, never correctness), padded with (-1,-1).
+        const int nt = c->ld / 64, ns = ceil_div(nt, 4);
+        std::vector<std::vector<int2>> per_xcd(8);
+        int sidx = 0;
+        for (int SI = 0; SI < ns; ++SI)
+            for (int SJ = SI; SJ < ns; ++SJ, ++sidx)
+                for (int i = SI * 4; i < std::min(nt, SI * 4 + 4); ++i)
+                    for (int j = SJ * 4; j < std::min(nt, SJ * 4 + 4); ++j)
+                        if (j >= i) per_xcd[sidx % 8].push_back(make_int2(i, j));
+        size_t mx = 0;
+        for (auto &v : per_xcd) mx = std::max(mx, v.size());
+        std::vector<int2> flat(mx * 8, make_int2(-1, -1));
+        for (int x = 0; x < 8; ++x) for (size_t k = 0; k < per_xcd[x].size(); ++k) flat[k * 8 + x] = per_xcd[x][k];
+        c->n_tiles = (int)flat.size();
+        A(dmalloc_bytes(&c->tiles, sizeof(int2) * flat.size()));
+        if (rc == PRE3_OK && hipMemcpy(c->tiles, flat.data(), sizeof(int2) * flat.size(), hipMemcpyHostToDevice) != hipSuccess) { set_error("tile table upload failed"); rc = PRE3_E_HIP; }
+    }
     if (rc == PRE3_OK && hipHostMalloc((void **)&c->pinned_stats, sizeof(int32_t) * 16) != hipSuccess) { set_error("hipHostMalloc failed"); rc = PRE3_E_NOMEM; }
     if (rc == PRE3_OK && (hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess)) { set_error("hipEventCreate failed"); rc = PRE3_E_HIP; }
     if (rc != PRE3_OK) { pre3_destroy(c); return rc; }
@@ -129,11 +164,12 @@ int pre3_destroy(pre3_ctx *c)
     if (!c) return PRE3_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S, c->lm.z,
-                     c->lm.ic, c->lm.li, c->lm.hi, c->meas, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
-                     c->sel_rows, c->hyp, c->support, c->masks, c->stats, c->li_meas, c->hi_meas, c->pred_params };
+    void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
+                     c->lm.li, c->lm.hi, c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
+                     c->sel_rows, c->support, c->masks, c->stats, c->li_meas, c->hi_meas, c->pred_params, c->tiles };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->pinned_stats) (void)hipHostFree(c->pinned_stats);
+    if (c->inbox_host) (void)hipHostFree(c->inbox_host);
     for (hipEvent_t e : c->kt.ev) (void)hipEventDestroy(e);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
@@ -177,7 +213,7 @@ int pre3_set_map(pre3_ctx *c, int N, const int32_t *lm_type)
     c->N = N; c->n = n;
     // the P buffer keeps its capacity-sized leading dimension; entries beyond n stay zero
     PRE3_HIP(hipMemset(c->lm.has_h, 0, sizeof(int32_t) * c->capN)); PRE3_HIP(hipMemset(c->lm.has_S, 0, sizeof(int32_t) * c->capN));
-    PRE3_HIP(hipMemset(c->lm.ic, 0, sizeof(int32_t) * c->capN)); PRE3_HIP(hipMemset(c->lm.li, 0, sizeof(int32_t) * c->capN));
+    PRE3_HIP(hipMemset(c->inbox_dev, 0, c->inbox_bytes)); PRE3_HIP(hipMemset(c->lm.li, 0, sizeof(int32_t) * c->capN));
     PRE3_HIP(hipMemset(c->lm.hi, 0, sizeof(int32_t) * c->capN));
     c->m = 0; c->meas_host.clear(); c->measurements_set = false; c->projected = false; c->innovated = false;
     c->x_valid[0] = c->x_valid[1] = false; c->p_which = -1;
@@ -275,32 +311,33 @@ int pre3_get_landmark_fields(pre3_ctx *c, double *h, int32_t *has_h, double *Hc,
     return PRE3_OK;
 }
 
-static int install_measurements(pre3_ctx *c, int m, const int32_t *meas_idx, const double *z /* 2m, may be null if z already on device */)
+// Fill the pinned inbox and ship it with ONE async copy: [meas | ic | (hyp) | z].  hyp (n_hyp_ints ints) optional.
+static int install_measurements(pre3_ctx *c, int m, const int32_t *meas_idx, const double *z /* 2m, null: z already on device */,
+                                const int32_t *hyp, int n_hyp_ints)
 {
     PRE3_CHECK(m >= 0 && m <= c->capm, PRE3_E_ARG, "measurements: m=%d exceeds capacity %d", m, c->capm);
     for (int j = 0; j < m; ++j) {
         PRE3_CHECK(meas_idx[j] >= 0 && meas_idx[j] < c->N, PRE3_E_ARG, "measurements: landmark index %d out of range", meas_idx[j]);
         PRE3_CHECK(j == 0 || meas_idx[j] > meas_idx[j - 1], PRE3_E_ARG, "measurements: landmark indices must be strictly ascending");
     }
+    PRE3_HIP(hipStreamSynchronize(c->stream));          // the previous copy out of the pinned inbox must have completed
     c->m = m; c->meas_host.assign(meas_idx, meas_idx + m);
-    PRE3_HIP(hipMemsetAsync(c->lm.ic, 0, sizeof(int32_t) * c->N, c->stream));
-    PRE3_HIP(hipMemsetAsync(c->lm.li, 0, sizeof(int32_t) * c->N, c->stream));
-    PRE3_HIP(hipMemsetAsync(c->lm.hi, 0, sizeof(int32_t) * c->N, c->stream));
-    PRE3_HIP(hipMemsetAsync(c->li_meas, 0, sizeof(int32_t) * c->capm, c->stream));
-    PRE3_HIP(hipMemsetAsync(c->hi_meas, 0, sizeof(int32_t) * c->capm, c->stream));
-    if (m) {
-        std::vector<int32_t> ones(c->N, 0);
-        std::vector<double> zl;
-        for (int j = 0; j < m; ++j) ones[meas_idx[j]] = 1;
-        PRE3_HIP(hipMemcpyAsync(c->meas, meas_idx, sizeof(int32_t) * m, hipMemcpyHostToDevice, c->stream));
-        PRE3_HIP(hipMemcpyAsync(c->lm.ic, ones.data(), sizeof(int32_t) * c->N, hipMemcpyHostToDevice, c->stream));
-        if (z) {
-            zl.assign(2 * (size_t)c->N, 0.0);
-            for (int j = 0; j < m; ++j) { zl[2 * meas_idx[j]] = z[2 * j]; zl[2 * meas_idx[j] + 1] = z[2 * j + 1]; }
-            PRE3_HIP(hipMemcpyAsync(c->lm.z, zl.data(), sizeof(double) * 2 * c->N, hipMemcpyHostToDevice, c->stream));
-        }
-        PRE3_HIP(hipStreamSynchronize(c->stream));      // host staging vectors go out of scope
+    int32_t *hm = (int32_t *)(c->inbox_host + c->off_meas), *hic = (int32_t *)(c->inbox_host + c->off_ic);
+    double *hz = (double *)(c->inbox_host + c->off_z);
+    memset(hic, 0, sizeof(int32_t) * c->N);
+    for (int j = 0; j < m; ++j) { hm[j] = meas_idx[j]; hic[meas_idx[j]] = 1; }
+    if (z) {
+        memset(hz, 0, sizeof(double) * 2 * c->N);
+        for (int j = 0; j < m; ++j) { hz[2 * meas_idx[j]] = z[2 * j]; hz[2 * meas_idx[j] + 1] = z[2 * j + 1]; }
     }
+    if (hyp) memcpy(c->inbox_host + c->off_hyp, hyp, sizeof(int32_t) * n_hyp_ints);
+    unsigned char *d = (unsigned char *)c->inbox_dev;
+    if (z) {
+        PRE3_HIP(hipMemcpyAsync(d, c->inbox_host, c->off_z + sizeof(double) * 2 * c->N, hipMemcpyHostToDevice, c->stream));
+    } else {
+        PRE3_HIP(hipMemcpyAsync(d, c->inbox_host, c->off_hyp + (hyp ? sizeof(int32_t) * n_hyp_ints : 0), hipMemcpyHostToDevice, c->stream));
+    }
+    PRE3_TRY(launch_clear_flags(c));
     c->measurements_set = true;
     return PRE3_OK;
 }
@@ -309,7 +346,7 @@ int pre3_set_measurements(pre3_ctx *c, int m, const int32_t *meas_idx, const dou
 {
     PRE3_TRY(check_ctx(c));
     PRE3_CHECK(m == 0 || (meas_idx && z), PRE3_E_ARG, "pre3_set_measurements: null pointer");
-    return install_measurements(c, m, meas_idx, z);
+    return install_measurements(c, m, meas_idx, z, nullptr, 0);
 }
 
 int pre3_window_gate(pre3_ctx *c, int M, const int32_t *k1, const double *zc, int strict_reference, int32_t *accept_out)
@@ -345,7 +382,7 @@ int pre3_window_gate(pre3_ctx *c, int M, const int32_t *k1, const double *zc, in
     for (int i = 0; i < N; ++i) if (flag[i]) meas.push_back(i);
     if (accept_out) for (int q = 0; q < M; ++q) accept_out[q] = acc[q];
     // z was written on the device by the gate kernel; keep it (z == nullptr)
-    return install_measurements(c, (int)meas.size(), meas.data(), nullptr);
+    return install_measurements(c, (int)meas.size(), meas.data(), nullptr, nullptr, 0);
 }
 
 // ---- RANSAC ---------------------------------------------------------------------------------------
@@ -358,7 +395,11 @@ static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp)
     PRE3_CHECK(hyp != nullptr, PRE3_E_ARG, "ransac: null hypothesis table");
     PRE3_CHECK(c->m >= k, PRE3_E_ARG, "ransac: %d measurements but k=%d", c->m, k);
     for (int i = 0; i < n_draw * k; ++i) PRE3_CHECK(hyp[i] >= 0 && hyp[i] < c->m, PRE3_E_ARG, "ransac: hyp[%d]=%d not a position in the IC list (m=%d)", i, hyp[i], c->m);
-    PRE3_HIP(hipMemcpyAsync(c->hyp, hyp, sizeof(int32_t) * n_draw * k, hipMemcpyHostToDevice, c->stream));
+    if (hyp != (const int32_t *)(c->inbox_host + c->off_hyp)) {       // not already shipped with the measurements
+        PRE3_HIP(hipStreamSynchronize(c->stream));
+        memcpy(c->inbox_host + c->off_hyp, hyp, sizeof(int32_t) * n_draw * k);
+        PRE3_HIP(hipMemcpyAsync(c->hyp, c->inbox_host + c->off_hyp, sizeof(int32_t) * n_draw * k, hipMemcpyHostToDevice, c->stream));
+    }
     int r = 2 * c->m, r_pad = round_up(r, NB);
     PRE3_TRY(launch_build_rows_impl(c, c->m, nullptr, r_pad));
     PRE3_TRY(launch_ell_HP(c, r, c->HP, true));
@@ -489,10 +530,12 @@ int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, co
     PRE3_TRY(pre3_predict(c, u));                                   // mono_slam.m:153
     PRE3_TRY(pre3_project(c, PRE3_X_K_KM1, 1));                     // search_IC_matches.m:31-32
     PRE3_TRY(pre3_innovation(c));                                   // search_IC_matches.m:33-44
-    PRE3_TRY(pre3_set_measurements(c, m, meas_idx, z));             // matching_sift_based.m:131-134 outcome
+    PRE3_CHECK(m == 0 || (meas_idx && z), PRE3_E_ARG, "pre3_step: null measurement pointers");
+    PRE3_CHECK(n_draw >= 1 && n_draw <= c->caph && k >= 1 && k <= MAXK && hyp, PRE3_E_ARG, "pre3_step: bad hypothesis table");
+    PRE3_TRY(install_measurements(c, m, meas_idx, z, hyp, n_draw * k));   // matching_sift_based.m:131-134 outcome (+ the draws)
     int32_t st[8] = { -1, 0, 0, 0, 0, 0, 0, 0 };
     if (m >= k && m > 0) {
-        PRE3_TRY(pre3_ransac(c, n_draw, k, hyp, threshold, early_exit, nullptr, nullptr, st));   // mono_slam.m:178
+        PRE3_TRY(pre3_ransac(c, n_draw, k, (const int32_t *)(c->inbox_host + c->off_hyp), threshold, early_exit, nullptr, nullptr, st));   // mono_slam.m:178
         st[4] = c->pinned_stats[4];
     } else {
         int32_t zero = 0;

@@ -512,18 +512,31 @@ __global__ __launch_bounds__(256) void k_ransac_score(int hyp_begin, int k, cons
 // K6: sequential replay of ransac_hypotheses.m:40-80 over the supports (quirk Q1), winner's mask ->
 // low_innovation_inlier flags (set_as_most_supported_hypothesis.m:32-52) + compacted row list.
 // stats: [0] best [1] iterations [2] n_hyp [3] max_support [4] n_li
-__global__ void k_ransac_select(int n_draw, int k, int early_exit, int m, const int32_t *__restrict__ meas,
-                                int32_t *__restrict__ support, const uint32_t *__restrict__ masks, int mask_words,
-                                int32_t *__restrict__ li_meas, int32_t *__restrict__ lm_li, int32_t *__restrict__ sel_rows,
-                                int32_t *__restrict__ stats)
+__device__ inline int wave_compact(int flag, int lane, int base_cnt, int32_t *__restrict__ dst, int value)
 {
+    unsigned long long mask = __ballot(flag);
+    int pos = __popcll(mask & ((1ull << lane) - 1ull));
+    if (flag) dst[base_cnt + pos] = value;
+    return base_cnt + __popcll(mask);
+}
+
+__global__ __launch_bounds__(256) void k_ransac_select(int n_draw, int k, int early_exit, int m, const int32_t *__restrict__ meas,
+                                                       int32_t *__restrict__ support, const uint32_t *__restrict__ masks, int mask_words,
+                                                       int32_t *__restrict__ li_meas, int32_t *__restrict__ lm_li,
+                                                       int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats)
+{
+    constexpr int CAP = 4096;
+    __shared__ int s_sup[CAP];
     __shared__ int s_best, s_iters;
-    if (threadIdx.x == 0) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n_draw && i < CAP; i += blockDim.x) s_sup[i] = support[i];
+    __syncthreads();
+    if (tid == 0) {
         int n_hyp = 1000, max_support = 0, best = -1, iters = 0;
         int limit = early_exit ? (n_draw < 1000 ? n_draw : 1000) : n_draw;
         for (int it = 0; it < limit; ++it) {
             if (early_exit && n_hyp == 0) break;
-            int sup = support[it];
+            int sup = it < CAP ? s_sup[it] : support[it];
             ++iters;
             if (sup > max_support) {
                 max_support = sup; best = it;
@@ -536,57 +549,71 @@ __global__ void k_ransac_select(int n_draw, int k, int early_exit, int m, const 
         stats[0] = best; stats[1] = iters; stats[2] = n_hyp; stats[3] = max_support;
     }
     __syncthreads();
-    int best = s_best, iters = s_iters;
-    for (int it = iters + threadIdx.x; it < n_draw; it += blockDim.x) support[it] = -1;   // never evaluated by the reference
-    __shared__ int s_count;
-    if (threadIdx.x == 0) {
+    const int best = s_best, iters = s_iters;
+    for (int it = iters + tid; it < n_draw; it += blockDim.x) support[it] = -1;   // never evaluated by the reference
+    if (tid < 64) {
         int cnt = 0;
-        for (int j = 0; j < m; ++j) {
-            int in = best >= 0 ? (masks[(size_t)best * mask_words + (j >> 5)] >> (j & 31)) & 1 : 0;
-            li_meas[j] = in; lm_li[meas[j]] = in;
-            if (in) sel_rows[cnt++] = j;
+        for (int base = 0; base < m; base += 64) {
+            int j = base + tid;
+            int in = 0;
+            if (j < m) {
+                in = best >= 0 ? (masks[(size_t)best * mask_words + (j >> 5)] >> (j & 31)) & 1 : 0;
+                li_meas[j] = in; lm_li[meas[j]] = in;
+            }
+            cnt = wave_compact(in, tid, cnt, sel_rows, j);
         }
-        s_count = cnt; stats[4] = cnt;
+        if (tid == 0) stats[4] = cnt;
     }
 }
 
 // hi flags (landmark order, written by k_innovation mode 1) -> measurement order + compacted list
-__global__ void k_collect_hi(int m, const int32_t *__restrict__ meas, const int32_t *__restrict__ lm_ic,
-                             const int32_t *__restrict__ lm_li, const int32_t *__restrict__ lm_hi,
-                             int32_t *__restrict__ hi_meas, int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats)
+__global__ __launch_bounds__(64) void k_collect_hi(int m, const int32_t *__restrict__ meas, const int32_t *__restrict__ lm_ic,
+                                                   const int32_t *__restrict__ lm_li, const int32_t *__restrict__ lm_hi,
+                                                   int32_t *__restrict__ hi_meas, int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int tid = threadIdx.x;
     int cnt = 0;
-    for (int j = 0; j < m; ++j) {
-        int i = meas[j];
-        int in = (lm_ic[i] == 1 && lm_li[i] == 0) ? lm_hi[i] : 0;
-        hi_meas[j] = in;
-        if (in) sel_rows[cnt++] = j;
+    for (int base = 0; base < m; base += 64) {
+        int j = base + tid;
+        int in = 0;
+        if (j < m) {
+            int i = meas[j];
+            in = (lm_ic[i] == 1 && lm_li[i] == 0) ? lm_hi[i] : 0;
+            hi_meas[j] = in;
+        }
+        cnt = wave_compact(in, tid, cnt, sel_rows, j);
     }
-    stats[5] = cnt;
+    if (tid == 0) stats[5] = cnt;
 }
 
 // x_out = x_prior + W' y  (update.m:36), then Jn at the un-normalised quaternion (update.m:42) -> params,
 // then normalise (update.m:48).  W: r_pad x ldw, y = column `ld` of W.
 template <typename T>
-__global__ __launch_bounds__(256) void k_update_x(int n, int r, const T *__restrict__ W, int ldw, int ld,
-                                                  const double *__restrict__ x_prior, double *__restrict__ x_out,
-                                                  double *__restrict__ params)
+__global__ __launch_bounds__(1024) void k_update_x(int n, int r, const T *__restrict__ W, int ldw, int ld,
+                                                   const double *__restrict__ x_prior, double *__restrict__ x_out,
+                                                   double *__restrict__ params)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    double s = 0;
-    if (i < n) {
-        for (int a = 0; a < r; ++a) s += (double)W[(size_t)a * ldw + i] * (double)W[(size_t)a * ldw + ld];
-        s += x_prior[i];
-    }
+    __shared__ double red[16][64];
     __shared__ double q[4];
-    if (blockIdx.x == 0) {
-        if (i >= 3 && i < 7) q[i - 3] = s;
-        __syncthreads();
-        if (i == 0) { double Jn[16]; d_normjac(q, Jn); for (int t = 0; t < 16; ++t) params[16 + t] = Jn[t]; }
-        if (i >= 3 && i < 7) s = s / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const int ci = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + ci;            // i < ldw always (ldw >= ld + 64 > n rounded up)
+    double s = 0;
+    for (int a = rg; a < r; a += 16) s += (double)W[(size_t)a * ldw + i] * (double)W[(size_t)a * ldw + ld];
+    red[rg][ci] = s;
+    __syncthreads();
+    if (rg == 0) {
+        s = 0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s += red[g][ci];
+        if (i < n) s += x_prior[i];
     }
-    if (i < n) x_out[i] = s;
+    if (blockIdx.x == 0) {          // block-uniform branch: every thread of block 0 reaches the barrier
+        if (rg == 0 && i >= 3 && i < 7) q[i - 3] = s;
+        __syncthreads();
+        if (rg == 0 && i == 0) { double Jn[16]; d_normjac(q, Jn); for (int t = 0; t < 16; ++t) params[16 + t] = Jn[t]; }
+        if (rg == 0 && i >= 3 && i < 7) s = s / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    }
+    if (rg == 0 && i < n) x_out[i] = s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -691,10 +718,27 @@ int launch_ransac_select_impl(pre3_ctx *c, int n_draw, int k, int early_exit, in
     return PRE3_OK;
 }
 
+__global__ void k_clear_flags(int N, int m, int32_t *__restrict__ li, int32_t *__restrict__ hi, int32_t *__restrict__ li_meas,
+                              int32_t *__restrict__ hi_meas, int32_t *__restrict__ stats)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) { li[i] = 0; hi[i] = 0; }
+    if (i < m) { li_meas[i] = 0; hi_meas[i] = 0; }
+    if (i == 0) { stats[4] = 0; stats[5] = 0; }
+}
+
+int launch_clear_flags(pre3_ctx *c)
+{
+    int cnt = c->N > c->capm ? c->N : c->capm;
+    hipLaunchKernelGGL(k_clear_flags, dim3(ceil_div(cnt, 256)), dim3(256), 0, c->stream, c->N, c->capm, c->lm.li, c->lm.hi, c->li_meas, c->hi_meas, c->stats);
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
 int launch_update_x(pre3_ctx *c, int which_prior, int r)
 {
     const double *xp = which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1;
-    dim3 g(ceil_div(c->n, 256)), b(256);
+    dim3 g(ceil_div(c->n, 64)), b(1024);
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_update_x<double>, g, b, 0, c->stream, c->n, r, (const double *)c->W, c->ldw, c->ld, xp, c->x_kk, c->pred_params),
         hipLaunchKernelGGL(k_update_x<float>, g, b, 0, c->stream, c->n, r, (const float *)c->W, c->ldw, c->ld, xp, c->x_kk, c->pred_params));

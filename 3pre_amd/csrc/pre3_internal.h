@@ -73,6 +73,8 @@ struct pre3_ctx {
     // device state
     double *x_kk = nullptr, *x_km1 = nullptr;     // [capn]
     void *P = nullptr;                            // [ld*ld] T
+    void *tiles = nullptr;                        // int2[n_tiles]: (I,J) of every 64x64 upper-triangle tile, XCD-aware order
+    int n_tiles = 0;
     int p_which = -1;                             // which estimate P currently holds (-1: none)
     bool x_valid[2] = {false, false};
     pre3::LmBuffers lm;
@@ -99,6 +101,9 @@ struct pre3_ctx {
     int32_t *li_meas = nullptr, *hi_meas = nullptr;   // [capm] flags in measurement order
     double *pred_params = nullptr;                // [64] predict: Qq1(16) Jn(16) Q(49->7x7) etc.
     int32_t *pinned_stats = nullptr;              // host pinned [16]
+    // per-step inbox: [meas | ic | hyp | z] contiguous on the device, mirrored in pinned host memory -> ONE H2D copy
+    void *inbox_dev = nullptr; unsigned char *inbox_host = nullptr;
+    size_t inbox_bytes = 0, off_meas = 0, off_ic = 0, off_hyp = 0, off_z = 0;
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;
     pre3::KernelTiming kt;

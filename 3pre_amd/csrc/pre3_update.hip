@@ -80,103 +80,275 @@ __global__ __launch_bounds__(64) void k_ell_G(int r, int r_pad, const int32_t *_
 //   k_chol_trail : M_bK -= M_bJ M_KJ'  for K > J                         (S lower tiles and all W strips)
 // W strip c holds M(i,a) = W[a][c*64+i] (transposed storage), so its loads/stores are coalesced in i.
 // ------------------------------------------------------------------------------------------------
+template <typename T> struct Mfma;
+template <> struct Mfma<float> {
+    static constexpr int BLK = 32, KS = 2, NREG = 16;
+    typedef float acc_t __attribute__((ext_vector_type(16)));
+    static __device__ inline void mma(float a, float b, acc_t &c) { c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+    static __device__ inline int row(int lane, int reg) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+    static __device__ inline int col(int lane) { return lane & 31; }
+    static __device__ inline int kk(int lane) { return lane >> 5; }
+};
+template <> struct Mfma<double> {
+    static constexpr int BLK = 16, KS = 4, NREG = 4;
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static __device__ inline void mma(double a, double b, acc_t &c) { c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ inline int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+    static __device__ inline int col(int lane) { return lane & 15; }
+    static __device__ inline int kk(int lane) { return lane >> 4; }
+};
+
+// 1/sqrt(x): hardware estimate + one Newton step (fp32: v_rsq_f32, fp64: v_rsq_f64) -- keeps the dependent
+// chain of the 8x8 factorisation short; error <= 2 ulp, far inside the tolerances of DESIGN.md
+__device__ inline float fast_rsqrt(float x) { float y = __builtin_amdgcn_rsqf(x); return y * (1.5f - 0.5f * x * y * y); }
+__device__ inline double fast_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y * (1.5 - 0.5 * x * y * y);
+}
+
+#ifdef PRE3_PROBE
+__device__ unsigned long long g_probe[16];
+#define PROBE_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_probe[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PROBE_ACC(k, t0) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_probe[k] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
+#else
+#define PROBE_STAMP(k)
+#define PROBE_ACC(k, t0)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_chol_panel(T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb,
                                                     int32_t *__restrict__ status)
 {
+    PROBE_STAMP(0);
     __shared__ T Ls[NB][NB + 1];
     __shared__ T Xs[NB][NB + 1];      // Xs[a][i]
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     const int nS = nrb - J - 1;
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        int i = idx / NB, a = idx % NB;
-        Ls[i][a] = S[(size_t)(J * NB + i) * lds + J * NB + a];
-    }
-    // load X early (independent of the factorisation)
     const bool isW = b > nS;
     const int c0 = isW ? (b - nS - 1) * NB : 0;
-    if (b >= 1) {
-        if (!isW) {
-            int rb = J + b;
-            for (int idx = tid; idx < NB * NB; idx += 256) {
-                int i = idx / NB, a = idx % NB;
-                Xs[a][i] = S[(size_t)(rb * NB + i) * lds + J * NB + a];
+    {
+        // all 32 global loads of the two blocks are issued before the first LDS store
+        T ga[16], gx[16];
+        const int lr = tid >> 6, lc = tid & 63;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) ga[t] = S[(size_t)(J * NB + lr + 4 * t) * lds + J * NB + lc];
+        if (b >= 1) {
+            if (!isW) {
+                const int rb = J + b;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) gx[t] = S[(size_t)(rb * NB + lr + 4 * t) * lds + J * NB + lc];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) gx[t] = W[(size_t)(J * NB + lr + 4 * t) * ldw + c0 + lc];
             }
-        } else {
-            for (int idx = tid; idx < NB * NB; idx += 256) {
-                int a = idx / NB, i = idx % NB;
-                Xs[a][i] = W[(size_t)(J * NB + a) * ldw + c0 + i];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) Ls[lr + 4 * t][lc] = ga[t];
+        if (b >= 1) {
+            if (!isW) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) Xs[lc][lr + 4 * t] = gx[t];        // S block: (i = lr+4t, a = lc) -> Xs[a][i]
+            } else {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) Xs[lr + 4 * t][lc] = gx[t];        // W strip: (a = lr+4t, i = lc)
             }
         }
     }
     __syncthreads();
-    // --- potrf (lower) with deferred column scaling: after step c, column c holds l_ic * sqrt(piv_c)
+    // Right-looking sweep in 8-column micro-panels, two barriers per micro-panel (16 per 64 columns instead of
+    // one per column): the dependent chain of the factorisation is what bounds this kernel, not its flops.
+    //   publish : owners copy the micro-panel's 8 columns of L (rows >= C0) and 8 rows of X into LDS
+    //   phase 1 : wave 0, lane = row i: factor the 8x8 diagonal block in registers (redundantly), solve the
+    //             lane's row  y <- y L8^-T  -> final L[i][C0..C0+7];  wave 1, lane = column of X: z <- L8^-1 x
+    //   phase 2 : all lanes apply the rank-8 update to their register-resident 4x4 patches of L and X
+    __shared__ __attribute__((aligned(16))) T Pn[NB][8];     // micro-panel columns, Pn[i][t] = A[i][C0+t]
+    __shared__ __attribute__((aligned(16))) T Yb[NB][8];     // final L[i][C0+t]
+    __shared__ __attribute__((aligned(16))) T Zt[NB][8];     // final X[C0+t][i]  (transposed: Zt[i][t])
+    __shared__ T Xr[8][NB];                                  // published rows of X
+    const int tr = tid >> 4, tc = tid & 15;
+    T lv[4][4], xs[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            lv[p][q] = Ls[tr + 16 * p][tc + 16 * q];
+            xs[p][q] = b >= 1 ? Xs[tr + 16 * p][tc + 16 * q] : (T)0;      // xs: row = panel column index a, col = i
+        }
     bool bad = false;
-    for (int c = 0; c < NB; ++c) {
-        T piv = Ls[c][c];
-        if (!(piv > (T)0)) { bad = true; piv = (T)1; }
-        T inv = (T)1 / piv;
-        int mrem = NB - 1 - c;
-        for (int idx = tid; idx < mrem * mrem; idx += 256) {
-            int i = c + 1 + idx / mrem, j = c + 1 + idx % mrem;
-            if (j <= i) Ls[i][j] -= Ls[i][c] * Ls[j][c] * inv;
+    PROBE_STAMP(1);
+#ifdef PRE3_PROBE
+    if (threadIdx.x == 0 && blockIdx.x == 0) { g_probe[4] = g_probe[5] = g_probe[6] = 0; }
+#endif
+    for (int s8 = 0; s8 < NB / 8; ++s8) {
+#ifdef PRE3_PROBE
+        unsigned long long tA = __builtin_amdgcn_s_memtime();
+#endif
+        const int C0 = 8 * s8, hq = C0 >> 4, half = (C0 >> 3) & 1;
+        if ((tc >> 3) == half) {
+            const int t = tc & 7;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) Pn[tr + 16 * p][t] = hq == 0 ? lv[p][0] : hq == 1 ? lv[p][1] : hq == 2 ? lv[p][2] : lv[p][3];
+        }
+        if (b >= 1 && (tr >> 3) == half) {
+            const int t = tr & 7;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Xr[t][tc + 16 * q] = hq == 0 ? xs[0][q] : hq == 1 ? xs[1][q] : hq == 2 ? xs[2][q] : xs[3][q];
         }
         __syncthreads();
+        PROBE_ACC(4, tA);
+#ifdef PRE3_PROBE
+        unsigned long long tB = __builtin_amdgcn_s_memtime();
+#endif
+        if (tid < 128 && (tid < 64 || b >= 1)) {
+            // 8x8 diagonal block (lower) -> L8, inverse diagonal
+            T d[8][8], invd[8];
+            typedef T vrow_t __attribute__((ext_vector_type(8)));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const vrow_t rowv = *reinterpret_cast<const vrow_t *>(&Pn[C0 + u][0]);
+#pragma unroll
+                for (int v = 0; v <= u; ++v) d[u][v] = rowv[v];
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                T piv = d[c][c];
+                if (!(piv > (T)0)) { bad = true; piv = (T)1; }
+                invd[c] = fast_rsqrt(piv);
+                d[c][c] = piv * invd[c];
+#pragma unroll
+                for (int u = c + 1; u < 8; ++u) d[u][c] *= invd[c];
+#pragma unroll
+                for (int u = c + 1; u < 8; ++u)
+#pragma unroll
+                    for (int v = c + 1; v <= u; ++v) d[u][v] -= d[u][c] * d[v][c];
+            }
+            if (tid < 64) {
+                const int i = tid;
+                if (i >= C0) {
+                    T y[8];
+                    {
+                        const vrow_t rowv = *reinterpret_cast<const vrow_t *>(&Pn[i][0]);
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) y[t] = rowv[t];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        T acc = y[t];
+#pragma unroll
+                        for (int u = 0; u < t; ++u) acc -= y[u] * d[t][u];
+                        y[t] = acc * invd[t];
+                    }
+                    if (i < C0 + 8) {        // rows of the diagonal block: exact factor entries, zeros above
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) y[t] = (t <= i - C0) ? y[t] : (T)0;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) { Yb[i][t] = y[t]; Ls[i][C0 + t] = y[t]; }
+                }
+            } else {
+                const int ii = tid - 64;
+                T z[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) z[t] = Xr[t][ii];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    T acc = z[t];
+#pragma unroll
+                    for (int u = 0; u < t; ++u) acc -= d[t][u] * z[u];
+                    z[t] = acc * invd[t];
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) { Zt[ii][t] = z[t]; Xs[C0 + t][ii] = z[t]; }
+            }
+        }
+        __syncthreads();
+        PROBE_ACC(5, tB);
+#ifdef PRE3_PROBE
+        unsigned long long tC = __builtin_amdgcn_s_memtime();
+#endif
+        {
+            T Yi[4][8], Yj[4][8];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) { Yi[p][t] = Yb[tr + 16 * p][t]; Yj[p][t] = Yb[tc + 16 * p][t]; }
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = tr + 16 * p, j = tc + 16 * q;
+                    if (j >= C0 + 8 && j <= i) {
+                        T acc = lv[p][q];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) acc -= Yi[p][t] * Yj[q][t];
+                        lv[p][q] = acc;
+                    }
+                }
+            if (b >= 1) {
+                T Zc[4][8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) Zc[q][t] = Zt[tc + 16 * q][t];
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (tr + 16 * p >= C0 + 8) {
+                            T acc = xs[p][q];
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) acc -= Yi[p][t] * Zc[q][t];
+                            xs[p][q] = acc;
+                        }
+            }
+        }
+        PROBE_ACC(6, tC);
     }
+    __syncthreads();
+    PROBE_STAMP(2);
     if (bad && tid == 0 && b == 0) atomicExch(status, 1);
-    // scale: L[i][c] = A[i][c] / sqrt(piv_c), L[c][c] = sqrt(piv_c)
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        int i = idx / NB, c = idx % NB;
-        if (i > c) { T p = Ls[c][c]; if (!(p > (T)0)) p = (T)1; Ls[i][c] = Ls[i][c] / sqrt(p); }
-    }
-    __syncthreads();
-    if (tid < NB) { T p = Ls[tid][tid]; if (!(p > (T)0)) p = (T)1; Ls[tid][tid] = sqrt(p); }
-    __syncthreads();
     if (b == 0) {
         for (int idx = tid; idx < NB * NB; idx += 256) {
-            int i = idx / NB, a = idx % NB;
-            S[(size_t)(J * NB + i) * lds + J * NB + a] = (a <= i) ? Ls[i][a] : (T)0;
+            int i = idx >> 6, a2 = idx & 63;
+            S[(size_t)(J * NB + i) * lds + J * NB + a2] = a2 <= i ? Ls[i][a2] : (T)0;
         }
         return;
-    }
-    // --- X <- X L^-T, right-looking with deferred scaling: after step c row Xs[c][:] holds x_c * L[c][c]
-    for (int c = 0; c < NB; ++c) {
-        T invd = (T)1 / Ls[c][c];
-        int mrem = NB - 1 - c;
-        for (int idx = tid; idx < mrem * NB; idx += 256) {
-            int j = c + 1 + idx / NB, i = idx % NB;
-            Xs[j][i] -= (Xs[c][i] * invd) * Ls[j][c];
-        }
-        __syncthreads();
     }
     if (!isW) {
         int rb = J + b;
         for (int idx = tid; idx < NB * NB; idx += 256) {
-            int i = idx / NB, a = idx % NB;
-            S[(size_t)(rb * NB + i) * lds + J * NB + a] = Xs[a][i] / Ls[a][a];
+            int i = idx >> 6, a2 = idx & 63;
+            S[(size_t)(rb * NB + i) * lds + J * NB + a2] = Xs[a2][i];
         }
     } else {
         for (int idx = tid; idx < NB * NB; idx += 256) {
-            int a = idx / NB, i = idx % NB;
-            W[(size_t)(J * NB + a) * ldw + c0 + i] = Xs[a][i] / Ls[a][a];
+            int a2 = idx >> 6, i = idx & 63;
+            W[(size_t)(J * NB + a2) * ldw + c0 + i] = Xs[a2][i];
         }
     }
 }
 
+// Trailing update on the matrix cores: one 64 x 64 tile  C -= A B'  (K = 64) per workgroup, 4 waves, each a
+// 32 x 32 sub-tile.  S-type tiles keep (row, a) order in LDS and are read with a 65-float stride (conflict
+// free); W-type tiles are stored k-major.  For W strips the operands are swapped so that the accumulator's
+// lane index runs along i, the contiguous direction of W.
 template <typename T>
 __global__ __launch_bounds__(256) void k_chol_trail(T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb, int nW)
 {
-    __shared__ T As[NB][NB + 4];   // As[a][i]
-    __shared__ T Bs[NB][NB + 4];   // Bs[a][j]
-    const int tid = threadIdx.x;
+    using M = Mfma<T>;
+    constexpr int NBLK = 32 / M::BLK;
+    __shared__ T As[NB][NB + 1];
+    __shared__ T Bs[NB][NB + 1];   // Bs[j][a]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nK = nrb - J - 1;
     const int nSt = nK * (nK + 1) / 2;
     int idx = blockIdx.x;
     bool isW;
     int rb = 0, K, c0 = 0;
     if (idx < nSt) {
-        // triangular decode: rows bb = 0..nK-1 (block J+1+bb), cols kk <= bb
         int bb = 0;
         while ((bb + 1) * (bb + 2) / 2 <= idx) ++bb;
         int kk = idx - bb * (bb + 1) / 2;
@@ -186,47 +358,73 @@ __global__ __launch_bounds__(256) void k_chol_trail(T *__restrict__ S, int lds, 
         c0 = (t % nW) * NB; K = J + 1 + t / nW; isW = true;
     }
     for (int e = tid; e < NB * NB; e += 256) {
-        int j = e / NB, a = e % NB;
-        Bs[a][j] = S[(size_t)(K * NB + j) * lds + J * NB + a];
+        int j = e >> 6, a = e & 63;
+        Bs[j][a] = S[(size_t)(K * NB + j) * lds + J * NB + a];
     }
     if (!isW) {
         for (int e = tid; e < NB * NB; e += 256) {
-            int i = e / NB, a = e % NB;
-            As[a][i] = S[(size_t)(rb * NB + i) * lds + J * NB + a];
+            int i = e >> 6, a = e & 63;
+            As[i][a] = S[(size_t)(rb * NB + i) * lds + J * NB + a];        // [i][a]
         }
     } else {
         for (int e = tid; e < NB * NB; e += 256) {
-            int a = e / NB, i = e % NB;
-            As[a][i] = W[(size_t)(J * NB + a) * ldw + c0 + i];
+            int a = e >> 6, i = e & 63;
+            As[a][i] = W[(size_t)(J * NB + a) * ldw + c0 + i];              // [a][i]
         }
     }
     __syncthreads();
-    const int ti = (tid & 15) * 4, tj = (tid >> 4) * 4;
-    T acc[4][4];
+    const int w0 = (wave >> 1) * 32, w1 = (wave & 1) * 32;
+    typename M::acc_t acc[NBLK][NBLK];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < NBLK; ++p)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[p][q] = (T)0;
-#pragma unroll 8
-    for (int a = 0; a < NB; ++a) {
-        T av[4], bv[4];
+        for (int q = 0; q < NBLK; ++q)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) { av[p] = As[a][ti + p]; bv[p] = Bs[a][tj + p]; }
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[p][q] += av[p] * bv[q];
-    }
+            for (int e = 0; e < M::NREG; ++e) acc[p][q][e] = (T)0;
     if (!isW) {
+        // acc rows -> i (A tile rows, offset w0), acc cols (lanes) -> j (B tile rows, offset w1)
+#pragma unroll 4
+        for (int k0 = 0; k0 < NB; k0 += M::KS) {
+            const int k = k0 + M::kk(lane);
+            T av[NBLK], bv[NBLK];
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+            for (int p = 0; p < NBLK; ++p) { av[p] = As[w0 + p * M::BLK + M::col(lane)][k]; bv[p] = Bs[w1 + p * M::BLK + M::col(lane)][k]; }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) S[(size_t)(rb * NB + ti + p) * lds + K * NB + tj + q] -= acc[p][q];
+            for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+                for (int q = 0; q < NBLK; ++q) M::mma(av[p], bv[q], acc[p][q]);
+        }
+#pragma unroll
+        for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+            for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+                for (int e = 0; e < M::NREG; ++e) {
+                    int i = w0 + p * M::BLK + M::row(lane, e), j = w1 + q * M::BLK + M::col(lane);
+                    S[(size_t)(rb * NB + i) * lds + K * NB + j] -= acc[p][q][e];
+                }
     } else {
+        // acc rows -> j (B tile rows, offset w0), acc cols (lanes) -> i (W columns, offset w1)
+#pragma unroll 4
+        for (int k0 = 0; k0 < NB; k0 += M::KS) {
+            const int k = k0 + M::kk(lane);
+            T av[NBLK], bv[NBLK];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+            for (int p = 0; p < NBLK; ++p) { av[p] = Bs[w0 + p * M::BLK + M::col(lane)][k]; bv[p] = As[k][w1 + p * M::BLK + M::col(lane)]; }
 #pragma unroll
-            for (int p = 0; p < 4; ++p) W[(size_t)(K * NB + tj + q) * ldw + c0 + ti + p] -= acc[p][q];
+            for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+                for (int q = 0; q < NBLK; ++q) M::mma(av[p], bv[q], acc[p][q]);
+        }
+#pragma unroll
+        for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+            for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+                for (int e = 0; e < M::NREG; ++e) {
+                    int j = w0 + p * M::BLK + M::row(lane, e), i = w1 + q * M::BLK + M::col(lane);
+                    W[(size_t)(K * NB + j) * ldw + c0 + i] -= acc[p][q][e];
+                }
     }
 }
 
@@ -251,41 +449,34 @@ __global__ __launch_bounds__(256) void k_gain(int n, int r, const T *__restrict_
 // Workgroup = 4 waves in 2x2, each wave owns a 64x64 sub-tile of a 128x128 tile of P; W is staged
 // k-major through LDS (BK rows x 128 contiguous columns per operand), double-buffered.
 // ------------------------------------------------------------------------------------------------
-template <typename T> struct Mfma;
-template <> struct Mfma<float> {
-    static constexpr int BLK = 32, KS = 2, NREG = 16;
-    typedef float acc_t __attribute__((ext_vector_type(16)));
-    static __device__ inline void mma(float a, float b, acc_t &c) { c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
-    static __device__ inline int row(int lane, int reg) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
-    static __device__ inline int col(int lane) { return lane & 31; }
-    static __device__ inline int kk(int lane) { return lane >> 5; }
-};
-template <> struct Mfma<double> {
-    static constexpr int BLK = 16, KS = 4, NREG = 4;
-    typedef double acc_t __attribute__((ext_vector_type(4)));
-    static __device__ inline void mma(double a, double b, acc_t &c) { c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-    static __device__ inline int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
-    static __device__ inline int col(int lane) { return lane & 15; }
-    static __device__ inline int kk(int lane) { return lane >> 4; }
-};
-
+// K9 v2: symmetric.  One workgroup per 64x64 tile (I <= J) of the upper triangle; 4 waves, each a 32x32
+// sub-tile (fp32: one v_mfma_f32_32x32x2 accumulator; fp64: 2x2 v_mfma_f64_16x16x4 accumulators).  W is
+// staged k-major through LDS (BK rows x 64 contiguous columns per operand), double-buffered with register
+// prefetch.  Epilogue: new = P_IJ - acc is written to P_IJ and, transposed through a wave-private LDS patch,
+// to P_JI, so the lower triangle is never read and P comes out exactly symmetric.
+// tiles[] lists (I, J) per block (an XCD-aware order built on the host); I < 0 marks a padding block.
 template <typename T, int BK>
-__global__ __launch_bounds__(256) void k_downdate(T *__restrict__ P, int ld, const T *__restrict__ W, int ldw, int r_pad)
+__global__ __launch_bounds__(256) void k_downdate(T *__restrict__ P, int ld, const T *__restrict__ W, int ldw, int r_pad,
+                                                  const int2 *__restrict__ tiles)
 {
     using M = Mfma<T>;
-    constexpr int NBLK = 64 / M::BLK;                 // MFMA blocks per wave-tile dimension
-    constexpr int VEC = 16 / sizeof(T);               // elements per 16-byte access
-    constexpr int ROWV = TILE / VEC;                  // 16-byte vectors per staged row
-    constexpr int NLD = (BK * ROWV) / 256;            // 16-byte loads per thread per operand per stage
-    static_assert((BK * ROWV) % 256 == 0, "stage must divide over the workgroup");
+    constexpr int TS = 64;                            // workgroup tile
+    constexpr int NBLK = 32 / M::BLK;                 // MFMA blocks per wave sub-tile dimension (1 or 2)
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int ROWV = TS / VEC;
+    constexpr int NLD = (BK * ROWV) / 256;
+    static_assert((BK * ROWV) % 256 == 0 && NLD >= 1, "stage must divide over the workgroup");
     typedef T vec_t __attribute__((ext_vector_type(VEC)));
 
-    __shared__ __attribute__((aligned(16))) T sA[2][BK][TILE];
-    __shared__ __attribute__((aligned(16))) T sB[2][BK][TILE];
+    __shared__ __attribute__((aligned(16))) T smem[4 * BK * TS];
+    T (*sA)[BK][TS] = reinterpret_cast<T (*)[BK][TS]>(smem);                     // sA[2][BK][TS]
+    T (*sB)[BK][TS] = reinterpret_cast<T (*)[BK][TS]>(smem + 2 * BK * TS);       // sB[2][BK][TS]
 
+    const int2 ij = tiles[blockIdx.x];
+    if (ij.x < 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
-    const int I0 = blockIdx.y * TILE, J0 = blockIdx.x * TILE;
+    const int I0 = ij.x * TS, J0 = ij.y * TS;
 
     typename M::acc_t acc[NBLK][NBLK];
 #pragma unroll
@@ -328,8 +519,8 @@ __global__ __launch_bounds__(256) void k_downdate(T *__restrict__ P, int ld, con
             T av[NBLK], bv[NBLK];
 #pragma unroll
             for (int p = 0; p < NBLK; ++p) {
-                av[p] = sA[buf][krow][wi * 64 + p * M::BLK + M::col(lane)];
-                bv[p] = sB[buf][krow][wj * 64 + p * M::BLK + M::col(lane)];
+                av[p] = sA[buf][krow][wi * 32 + p * M::BLK + M::col(lane)];
+                bv[p] = sB[buf][krow][wj * 32 + p * M::BLK + M::col(lane)];
             }
 #pragma unroll
             for (int p = 0; p < NBLK; ++p)
@@ -339,18 +530,33 @@ __global__ __launch_bounds__(256) void k_downdate(T *__restrict__ P, int ld, con
         if (s + 1 < nstage) sstore(buf ^ 1);
         __syncthreads();
     }
-    // epilogue: P <- P - acc
+    // ---- epilogue.  The staging buffers are dead now: each wave takes a private [32][33] patch of sA.
+    T (*patch)[33] = reinterpret_cast<T (*)[33]>(smem + wave * (32 * 33));
+    static_assert(4 * 32 * 33 <= 4 * BK * TS, "patches must fit in the staging buffers");
+    const bool mirror = ij.x != ij.y;
 #pragma unroll
     for (int p = 0; p < NBLK; ++p)
 #pragma unroll
         for (int q = 0; q < NBLK; ++q)
 #pragma unroll
             for (int e = 0; e < M::NREG; ++e) {
-                int row = I0 + wi * 64 + p * M::BLK + M::row(lane, e);
-                int col = J0 + wj * 64 + q * M::BLK + M::col(lane);
-                size_t o = (size_t)row * ld + col;
-                P[o] = P[o] - acc[p][q][e];
+                const int lr = p * M::BLK + M::row(lane, e), lc = q * M::BLK + M::col(lane);
+                const size_t o = (size_t)(I0 + wi * 32 + lr) * ld + J0 + wj * 32 + lc;
+                const T v = P[o] - acc[p][q][e];
+                P[o] = v;
+                if (mirror) patch[lr][lc] = v;
             }
+    if (mirror) {
+        // wave-private patch: LDS ops of one wave complete in order, no workgroup barrier needed
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const int rr = lane & 31, half = lane >> 5;
+#pragma unroll
+        for (int cc = 0; cc < 32; cc += 2) {
+            const int c = cc + half;                                   // column of the patch = row of P_JI
+            P[(size_t)(J0 + wj * 32 + c) * ld + I0 + wi * 32 + rr] = patch[rr][c];
+        }
+    }
 }
 
 // synthetic W for the roofline probe
@@ -418,7 +624,7 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad)
 int launch_downdate(pre3_ctx *c, int r, const void *W)
 {
     int r_pad = round_up(r, NB);
-    dim3 g(c->ld / TILE, c->ld / TILE), b(256);
+    dim3 g(c->n_tiles), b(256);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->kt.enabled) {
         if ((size_t)c->kt.used + 2 > c->kt.ev.size()) {
@@ -429,12 +635,12 @@ int launch_downdate(pre3_ctx *c, int r, const void *W)
         PRE3_HIP(hipEventRecord(e0, c->stream));
     }
     DISPATCH_T(c,
-        hipLaunchKernelGGL((k_downdate<double, 8>), g, b, 0, c->stream, (double *)c->P, c->ld, (const double *)W, c->ldw, r_pad),
-        hipLaunchKernelGGL((k_downdate<float, 16>), g, b, 0, c->stream, (float *)c->P, c->ld, (const float *)W, c->ldw, r_pad));
+        hipLaunchKernelGGL((k_downdate<double, 32>), g, b, 0, c->stream, (double *)c->P, c->ld, (const double *)W, c->ldw, r_pad, (const int2 *)c->tiles),
+        hipLaunchKernelGGL((k_downdate<float, 32>), g, b, 0, c->stream, (float *)c->P, c->ld, (const float *)W, c->ldw, r_pad, (const int2 *)c->tiles));
     if (c->kt.enabled) {
         PRE3_HIP(hipEventRecord(e1, c->stream));
-        c->kt.flops += 2.0 * c->n * (double)c->n * r;                    // F_K9 = 2 n^2 r
-        c->kt.bytes += 2.0 * c->n * (double)c->n * c->esz + 2.0 * c->n * (double)r * c->esz;
+        c->kt.flops += (double)c->n * ((double)c->n + 1.0) * r;          // SYRK count n(n+1)r; the survey's un-halved figure is 2 n^2 r
+        c->kt.bytes += 1.5 * c->n * (double)c->n * c->esz + (double)c->n * (double)r * c->esz;
     }
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
