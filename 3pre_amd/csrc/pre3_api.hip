@@ -52,6 +52,20 @@ static int check_ctx(pre3_ctx *c)
     return PRE3_OK;
 }
 
+// Poll the pinned mailbox until the kernel that was launched with sequence number `seq` has published.
+// slot 8: k_ransac_select, slot 9: k_collect_hi.  Falls back to a stream sync if the word does not arrive.
+static int wait_mail(pre3_ctx *c, int slot, int32_t seq)
+{
+    volatile int32_t *w = c->mail_host + slot;
+    for (long spin = 0; spin < 20000000L; ++spin) {
+        if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == seq) return PRE3_OK;
+        if ((spin & 1023) == 1023 && hipStreamQuery(c->stream) == hipSuccess) break;
+    }
+    PRE3_HIP(hipStreamSynchronize(c->stream));
+    PRE3_CHECK(__atomic_load_n(w, __ATOMIC_ACQUIRE) == seq, PRE3_E_STATE, "mailbox: the producing kernel has not been launched");
+    return PRE3_OK;
+}
+
 static int fetch_stats(pre3_ctx *c)
 {
     PRE3_HIP(hipMemcpyAsync(c->pinned_stats, c->stats, sizeof(int32_t) * 16, hipMemcpyDeviceToHost, c->stream));
@@ -150,6 +164,11 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
         if (rc == PRE3_OK && hipMemcpy(c->tiles, flat.data(), sizeof(int2) * flat.size(), hipMemcpyHostToDevice) != hipSuccess) { set_error("tile table upload failed"); rc = PRE3_E_HIP; }
     }
     if (rc == PRE3_OK && hipHostMalloc((void **)&c->pinned_stats, sizeof(int32_t) * 16) != hipSuccess) { set_error("hipHostMalloc failed"); rc = PRE3_E_NOMEM; }
+    if (rc == PRE3_OK && hipHostMalloc((void **)&c->mail_host, sizeof(int32_t) * 16, hipHostMallocMapped) != hipSuccess) { set_error("hipHostMalloc failed"); rc = PRE3_E_NOMEM; }
+    if (rc == PRE3_OK) {
+        memset(c->mail_host, 0, sizeof(int32_t) * 16);
+        if (hipHostGetDevicePointer((void **)&c->mail_dev, c->mail_host, 0) != hipSuccess) { set_error("hipHostGetDevicePointer failed"); rc = PRE3_E_HIP; }
+    }
     if (rc == PRE3_OK && (hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess)) { set_error("hipEventCreate failed"); rc = PRE3_E_HIP; }
     if (rc != PRE3_OK) { pre3_destroy(c); return rc; }
     (void)hipMemsetAsync(c->stats, 0, sizeof(int32_t) * 16, c->stream);
@@ -170,6 +189,7 @@ int pre3_destroy(pre3_ctx *c)
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->pinned_stats) (void)hipHostFree(c->pinned_stats);
     if (c->inbox_host) (void)hipHostFree(c->inbox_host);
+    if (c->mail_host) (void)hipHostFree(c->mail_host);
     for (hipEvent_t e : c->kt.ev) (void)hipEventDestroy(e);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
@@ -338,6 +358,7 @@ static int install_measurements(pre3_ctx *c, int m, const int32_t *meas_idx, con
         PRE3_HIP(hipMemcpyAsync(d, c->inbox_host, c->off_hyp + (hyp ? sizeof(int32_t) * n_hyp_ints : 0), hipMemcpyHostToDevice, c->stream));
     }
     PRE3_TRY(launch_clear_flags(c));
+    c->li_from_host = c->hi_from_host = -1; c->li_kernel = c->hi_kernel = false;
     c->measurements_set = true;
     return PRE3_OK;
 }
@@ -430,10 +451,13 @@ int pre3_ransac_select(pre3_ctx *c, int n_draw, int k, int early_exit, int32_t *
     PRE3_CHECK(n_draw >= 1 && n_draw <= c->caph, PRE3_E_ARG, "ransac: n_draw out of range");
     int words = ceil_div(c->m, 32);
     PRE3_TRY(launch_ransac_select_impl(c, n_draw, k, early_exit, c->support, c->masks, words));
-    PRE3_TRY(fetch_stats(c));
-    if (support) PRE3_HIP(hipMemcpy(support, c->support, sizeof(int32_t) * n_draw, hipMemcpyDeviceToHost));
-    if (li_mask && c->m) PRE3_HIP(hipMemcpy(li_mask, c->li_meas, sizeof(int32_t) * c->m, hipMemcpyDeviceToHost));
-    if (stats) for (int i = 0; i < 4; ++i) stats[i] = c->pinned_stats[i];
+    c->li_from_host = -1; c->li_kernel = true;
+    if (support || li_mask) {
+        PRE3_HIP(hipStreamSynchronize(c->stream));
+        if (support) PRE3_HIP(hipMemcpy(support, c->support, sizeof(int32_t) * n_draw, hipMemcpyDeviceToHost));
+        if (li_mask && c->m) PRE3_HIP(hipMemcpy(li_mask, c->li_meas, sizeof(int32_t) * c->m, hipMemcpyDeviceToHost));
+    }
+    if (stats) { PRE3_TRY(wait_mail(c, 8, c->seq_select)); for (int i = 0; i < 4; ++i) stats[i] = c->mail_host[i]; }
     return PRE3_OK;
 }
 
@@ -462,8 +486,10 @@ int pre3_update_li(pre3_ctx *c)
 {
     PRE3_TRY(check_ctx(c));
     PRE3_CHECK(c->measurements_set && c->projected, PRE3_E_STATE, "pre3_update_li: needs projection and measurements");
-    PRE3_TRY(fetch_stats(c));
-    return update_selected(c, PRE3_X_K_KM1, c->pinned_stats[4], c->sel_rows);
+    int n_li = 0;       // no RANSAC / flags for this measurement set: no low-innovation inliers, update is the identity
+    if (c->li_from_host >= 0) n_li = c->li_from_host;
+    else if (c->li_kernel) { PRE3_TRY(wait_mail(c, 8, c->seq_select)); n_li = c->mail_host[4]; }
+    return update_selected(c, PRE3_X_K_KM1, n_li, c->sel_rows);
 }
 
 int pre3_rescue(pre3_ctx *c, double chi2, int32_t *hi_mask)
@@ -472,8 +498,9 @@ int pre3_rescue(pre3_ctx *c, double chi2, int32_t *hi_mask)
     PRE3_CHECK(c->p_which == PRE3_X_K_K && c->x_valid[PRE3_X_K_K], PRE3_E_STATE, "pre3_rescue: needs (x_k_k, p_k_k), i.e. after the LI update");
     PRE3_TRY(launch_project(c, PRE3_X_K_K, 0));
     PRE3_TRY(launch_innovation(c, 1, chi2));
+    c->hi_from_host = -1; c->hi_kernel = true;
     if (hi_mask) {
-        PRE3_TRY(fetch_stats(c));
+        PRE3_HIP(hipStreamSynchronize(c->stream));
         if (c->m) PRE3_HIP(hipMemcpy(hi_mask, c->hi_meas, sizeof(int32_t) * c->m, hipMemcpyDeviceToHost));
     }
     return PRE3_OK;
@@ -482,8 +509,10 @@ int pre3_rescue(pre3_ctx *c, double chi2, int32_t *hi_mask)
 int pre3_update_hi(pre3_ctx *c)
 {
     PRE3_TRY(check_ctx(c));
-    PRE3_TRY(fetch_stats(c));
-    return update_selected(c, PRE3_X_K_K, c->pinned_stats[5], c->sel_rows);
+    int n_hi = 0;
+    if (c->hi_from_host >= 0) n_hi = c->hi_from_host;
+    else if (c->hi_kernel) { PRE3_TRY(wait_mail(c, 9, c->seq_collect)); n_hi = c->mail_host[5]; }
+    return update_selected(c, PRE3_X_K_K, n_hi, c->sel_rows);
 }
 
 int pre3_update_all(pre3_ctx *c)
@@ -519,6 +548,7 @@ int pre3_set_flags(pre3_ctx *c, const int32_t *li, const int32_t *hi)
         if (!sel.empty()) PRE3_HIP(hipMemcpy(c->sel_rows, sel.data(), sizeof(int32_t) * sel.size(), hipMemcpyHostToDevice));
         int32_t cnt = (int32_t)sel.size();
         PRE3_HIP(hipMemcpy(c->stats + (pass == 0 ? 4 : 5), &cnt, sizeof(int32_t), hipMemcpyHostToDevice));
+        if (pass == 0) c->li_from_host = cnt; else c->hi_from_host = cnt;
     }
     return PRE3_OK;
 }
@@ -536,16 +566,13 @@ int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, co
     int32_t st[8] = { -1, 0, 0, 0, 0, 0, 0, 0 };
     if (m >= k && m > 0) {
         PRE3_TRY(pre3_ransac(c, n_draw, k, (const int32_t *)(c->inbox_host + c->off_hyp), threshold, early_exit, nullptr, nullptr, st));   // mono_slam.m:178
-        st[4] = c->pinned_stats[4];
-    } else {
-        int32_t zero = 0;
-        PRE3_HIP(hipMemcpyAsync(c->stats + 4, &zero, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        PRE3_HIP(hipStreamSynchronize(c->stream));
+        st[4] = 0;
     }
     PRE3_TRY(pre3_update_li(c));                                    // mono_slam.m:181
     PRE3_TRY(pre3_rescue(c, chi2, nullptr));                        // mono_slam.m:184
     PRE3_TRY(pre3_update_hi(c));                                    // mono_slam.m:187
-    st[5] = c->pinned_stats[5];
+    st[4] = c->li_from_host >= 0 ? c->li_from_host : (c->li_kernel ? c->mail_host[4] : 0);
+    st[5] = c->hi_from_host >= 0 ? c->hi_from_host : (c->hi_kernel ? c->mail_host[5] : 0);
     if (stats) for (int i = 0; i < 8; ++i) stats[i] = st[i];
     return PRE3_OK;
 }

@@ -179,16 +179,24 @@ __global__ void k_predict_P(T *__restrict__ P, int n, int ld, const double *__re
         for (int i = 0; i < 4; ++i) b[i] = sJn[i * 4] * a[0] + sJn[i * 4 + 1] * a[1] + sJn[i * 4 + 2] * a[2] + sJn[i * 4 + 3] * a[3];
         for (int i = 0; i < 4; ++i) { P[(3 + i) * ld + j] = (T)b[i]; P[j * ld + 3 + i] = (T)b[i]; }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // pose block: C = F7 * P7 * F7' + Q7 with F7 = blkdiag(I3, Qq1); then J7 C J7', J7 = blkdiag(I3, Jn)
-        double F7[49], J7[49], T1[49], C[49];
-        for (int i = 0; i < 49; ++i) { F7[i] = 0; J7[i] = 0; }
-        for (int i = 0; i < 3; ++i) { F7[i * 7 + i] = 1; J7[i * 7 + i] = 1; }
-        for (int i = 0; i < 4; ++i) for (int k = 0; k < 4; ++k) { F7[(3 + i) * 7 + 3 + k] = sQq1[i * 4 + k]; J7[(3 + i) * 7 + 3 + k] = sJn[i * 4 + k]; }
-        for (int i = 0; i < 7; ++i) for (int k = 0; k < 7; ++k) { double s = 0; for (int t = 0; t < 7; ++t) s += F7[i * 7 + t] * corner[t * 7 + k]; T1[i * 7 + k] = s; }
-        for (int i = 0; i < 7; ++i) for (int k = 0; k < 7; ++k) { double s = 0; for (int t = 0; t < 7; ++t) s += T1[i * 7 + t] * F7[k * 7 + t]; C[i * 7 + k] = s + sQ[i * 7 + k]; }
-        for (int i = 0; i < 7; ++i) for (int k = 0; k < 7; ++k) { double s = 0; for (int t = 0; t < 7; ++t) s += J7[i * 7 + t] * C[t * 7 + k]; T1[i * 7 + k] = s; }
-        for (int i = 0; i < 7; ++i) for (int k = 0; k < 7; ++k) { double s = 0; for (int t = 0; t < 7; ++t) s += T1[i * 7 + t] * J7[k * 7 + t]; P[i * ld + k] = (T)s; }
+    if (blockIdx.x == 0) {
+        // pose block: C = F7 * P7 * F7' + Q7 with F7 = blkdiag(I3, Qq1); then J7 C J7', J7 = blkdiag(I3, Jn).
+        // 49 lanes, one per entry, four product phases through LDS (block-uniform branch: barriers are safe).
+        __shared__ double F7[49], J7[49], T1[49], C7[49];
+        const int t = threadIdx.x, i = t / 7, k = t % 7;
+        if (t < 49) {
+            double f = (i == k && i < 3) ? 1.0 : 0.0, jn = f;
+            if (i >= 3 && k >= 3) { f = sQq1[(i - 3) * 4 + (k - 3)]; jn = sJn[(i - 3) * 4 + (k - 3)]; }
+            F7[t] = f; J7[t] = jn;
+        }
+        __syncthreads();
+        if (t < 49) { double s = 0; for (int u = 0; u < 7; ++u) s += F7[i * 7 + u] * corner[u * 7 + k]; T1[t] = s; }
+        __syncthreads();
+        if (t < 49) { double s = 0; for (int u = 0; u < 7; ++u) s += T1[i * 7 + u] * F7[k * 7 + u]; C7[t] = s + sQ[t]; }
+        __syncthreads();
+        if (t < 49) { double s = 0; for (int u = 0; u < 7; ++u) s += J7[i * 7 + u] * C7[u * 7 + k]; T1[t] = s; }
+        __syncthreads();
+        if (t < 49) { double s = 0; for (int u = 0; u < 7; ++u) s += T1[i * 7 + u] * J7[k * 7 + u]; P[i * ld + k] = (T)s; }
     }
 }
 
@@ -307,42 +315,51 @@ __global__ void k_project(int N, const int32_t *__restrict__ lm_type, const int3
 // mode 1 (rescue_hi_inliers.m:35-46): for ic && !li: d2 = nu' inv(H P H') nu < chi2 -> hi flag.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void k_innovation(int N, const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
-                             const T *__restrict__ P, int ld, const double *__restrict__ Hc, const double *__restrict__ Hl,
-                             const int32_t *__restrict__ has_h, int mode, double chi2,
-                             const double *__restrict__ h, const double *__restrict__ z,
-                             const int32_t *__restrict__ ic, const int32_t *__restrict__ li, int32_t *__restrict__ hi,
-                             double *__restrict__ S, int32_t *__restrict__ has_S)
+__global__ __launch_bounds__(256) void k_innovation(int N, const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
+                                                    const T *__restrict__ P, int ld, const double *__restrict__ Hc, const double *__restrict__ Hl,
+                                                    const int32_t *__restrict__ has_h, int mode, double chi2,
+                                                    const double *__restrict__ h, const double *__restrict__ z,
+                                                    const int32_t *__restrict__ ic, const int32_t *__restrict__ li, int32_t *__restrict__ hi,
+                                                    double *__restrict__ S, int32_t *__restrict__ has_S)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    if (mode == 0) { if (!has_h[i]) { has_S[i] = 0; return; } }
-    else { if (!(ic[i] == 1 && li[i] == 0)) return; }
-    int d = lm_type[i] == PRE3_INVDEPTH ? 6 : 3;
-    int off = lm_off[i];
-    int nn = 7 + d;
-    double Hr[2][13];
-    for (int r = 0; r < 2; ++r) {
-        for (int c = 0; c < 7; ++c) Hr[r][c] = Hc[14 * i + r * 7 + c];
-        for (int c = 0; c < d; ++c) Hr[r][7 + c] = Hl[12 * i + r * 6 + c];
-    }
-    // HP[r][b] = sum_a H[r][a] P[ia][ib]
+    // 16 lanes per landmark: lane b < 13 owns column b of the gathered 13x13 block of P (7 pose + 6 landmark
+    // entries; P is symmetric, so the column is read as a row: two contiguous runs), then a 16-lane shuffle sum.
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = gt >> 4, b = gt & 15;
+    const bool valid = i < N;
+    const int ii = valid ? i : 0;
+    bool active = valid;
+    if (mode == 0) active = active && has_h[ii];
+    else active = active && (ic[ii] == 1 && li[ii] == 0);
+    const int d = lm_type[ii] == PRE3_INVDEPTH ? 6 : 3;
+    const int off = lm_off[ii];
+    const int nn = 7 + d;
     double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
-    for (int b = 0; b < nn; ++b) {
-        int ib = b < 7 ? b : off + b - 7;
+    if (active && b < nn) {
+        const int ib = b < 7 ? b : off + b - 7;
+        const T *prow = P + (size_t)ib * ld;
         double hp0 = 0, hp1 = 0;
-        for (int a = 0; a < nn; ++a) {
-            int ia = a < 7 ? a : off + a - 7;
-            double p = (double)P[(size_t)ia * ld + ib];
-            hp0 += Hr[0][a] * p; hp1 += Hr[1][a] * p;
-        }
-        s00 += hp0 * Hr[0][b]; s01 += hp0 * Hr[1][b];
-        s10 += hp1 * Hr[0][b]; s11 += hp1 * Hr[1][b];
+#pragma unroll
+        for (int a = 0; a < 7; ++a) { double p = (double)prow[a]; hp0 += Hc[14 * ii + a] * p; hp1 += Hc[14 * ii + 7 + a] * p; }
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+            if (a < d) { double p = (double)prow[off + a]; hp0 += Hl[12 * ii + a] * p; hp1 += Hl[12 * ii + 6 + a] * p; }
+        const double h0b = b < 7 ? Hc[14 * ii + b] : Hl[12 * ii + b - 7];
+        const double h1b = b < 7 ? Hc[14 * ii + 7 + b] : Hl[12 * ii + 6 + b - 7];
+        s00 = hp0 * h0b; s01 = hp0 * h1b; s10 = hp1 * h0b; s11 = hp1 * h1b;
     }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        s00 += __shfl_xor(s00, o, 16); s01 += __shfl_xor(s01, o, 16);
+        s10 += __shfl_xor(s10, o, 16); s11 += __shfl_xor(s11, o, 16);
+    }
+    if (!valid || b != 0) return;
     if (mode == 0) {
+        if (!active) { has_S[i] = 0; return; }
         S[4 * i + 0] = s00 + 1; S[4 * i + 1] = s01; S[4 * i + 2] = s10; S[4 * i + 3] = s11 + 1;
         has_S[i] = 1;
     } else {
+        if (!active) return;
         double det = s00 * s11 - s01 * s10;
         double i00 = s11 / det, i01 = -s01 / det, i10 = -s10 / det, i11 = s00 / det;
         double n0 = z[2 * i] - h[2 * i], n1 = z[2 * i + 1] - h[2 * i + 1];
@@ -414,8 +431,8 @@ __device__ inline int wave_sum(int v)
     return v;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_ransac_score(int hyp_begin, int k, const int32_t *__restrict__ hyp, int m,
+template <typename T, int K>
+__global__ __launch_bounds__(256) void k_ransac_score(int hyp_begin, const int32_t *__restrict__ hyp, int m,
                                                       const int32_t *__restrict__ meas, const int32_t *__restrict__ lm_type,
                                                       const int32_t *__restrict__ lm_off, const double *__restrict__ x,
                                                       const T *__restrict__ HP, int ldw, const T *__restrict__ G, int ldg,
@@ -423,90 +440,120 @@ __global__ __launch_bounds__(256) void k_ransac_score(int hyp_begin, int k, cons
                                                       CamD cam, double threshold, int32_t *__restrict__ support,
                                                       uint32_t *__restrict__ masks, int mask_words)
 {
+    constexpr int R = 2 * K;                // compile-time so that every small array stays in registers
     extern __shared__ double s_res[];       // [m] residuals, then mask words
-    __shared__ double s_w[2 * MAXK];
-    __shared__ int s_rows[2 * MAXK];
+    __shared__ double s_w[R];
+    __shared__ int s_rows[R];
     __shared__ double s_red[4];
     __shared__ int s_cnt[4];
-    int hidx = hyp_begin + blockIdx.x;
-    int r = 2 * k;
-    int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) {
-        double A[2 * MAXK][2 * MAXK + 1];
-        int rows[2 * MAXK];
-        for (int s = 0; s < k; ++s) { int j = hyp[hidx * k + s]; rows[2 * s] = 2 * j; rows[2 * s + 1] = 2 * j + 1; }
-        for (int a = 0; a < r; ++a) {
-            for (int b = 0; b < r; ++b) A[a][b] = (double)G[(size_t)rows[a] * ldg + rows[b]] + (a == b ? 1.0 : 0.0);
-            A[a][r] = row_nu[rows[a]];
+    const int hidx = hyp_begin + blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 64) {
+        // wave 0: lane (a, b) gathers one entry of the augmented system [S_h | nu_h]; lane 0 then eliminates
+        int rows[R];
+#pragma unroll
+        for (int s = 0; s < K; ++s) { int j = hyp[hidx * K + s]; rows[2 * s] = 2 * j; rows[2 * s + 1] = 2 * j + 1; }
+        double A[R][R + 1];
+#pragma unroll
+        for (int a = 0; a < R; ++a) {
+#pragma unroll
+            for (int b = 0; b < R; ++b) A[a][b] = (double)G[(size_t)rows[a] * ldg + rows[b]] + (a == b ? 1.0 : 0.0);
+            A[a][R] = row_nu[rows[a]];
         }
-        // Gaussian elimination with partial pivoting (MATLAB inv(S)*nu up to rounding)
-        for (int c = 0; c < r; ++c) {
-            int p = c; double best = fabs(A[c][c]);
-            for (int a = c + 1; a < r; ++a) if (fabs(A[a][c]) > best) { best = fabs(A[a][c]); p = a; }
-            if (p != c) for (int b = c; b <= r; ++b) { double t = A[c][b]; A[c][b] = A[p][b]; A[p][b] = t; }
-            double dinv = 1.0 / A[c][c];
-            for (int a = c + 1; a < r; ++a) {
-                double l = A[a][c] * dinv;
-                for (int b = c; b <= r; ++b) A[a][b] -= l * A[c][b];
+        if (tid == 0) {
+            // Gaussian elimination with partial pivoting (MATLAB's inv(S)*nu up to rounding), fully unrolled
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                int p = c; double best = fabs(A[c][c]);
+#pragma unroll
+                for (int a = c + 1; a < R; ++a) { double v = fabs(A[a][c]); if (v > best) { best = v; p = a; } }
+#pragma unroll
+                for (int a = c + 1; a < R; ++a)
+                    if (a == p) {
+#pragma unroll
+                        for (int b = 0; b <= R; ++b) { double t = A[c][b]; A[c][b] = A[a][b]; A[a][b] = t; }
+                    }
+                const double dinv = 1.0 / A[c][c];
+#pragma unroll
+                for (int a = c + 1; a < R; ++a) {
+                    const double l = A[a][c] * dinv;
+#pragma unroll
+                    for (int b = c + 1; b <= R; ++b) A[a][b] -= l * A[c][b];
+                }
             }
+            double w[R];
+#pragma unroll
+            for (int a = R - 1; a >= 0; --a) {
+                double s = A[a][R];
+#pragma unroll
+                for (int b = a + 1; b < R; ++b) s -= A[a][b] * w[b];
+                w[a] = s / A[a][a];
+            }
+#pragma unroll
+            for (int a = 0; a < R; ++a) { s_w[a] = w[a]; s_rows[a] = rows[a]; }
         }
-        for (int a = r - 1; a >= 0; --a) {
-            double s = A[a][r];
-            for (int b = a + 1; b < r; ++b) s -= A[a][b] * s_w[b];
-            s_w[a] = s / A[a][a];
-        }
-        for (int a = 0; a < r; ++a) s_rows[a] = rows[a];
     }
     __syncthreads();
+    double w[R];
+    const T *hp[R];
+#pragma unroll
+    for (int b = 0; b < R; ++b) { w[b] = s_w[b]; hp[b] = HP + (size_t)s_rows[b] * ldw; }
     // pose part of x_i (every lane redundantly: 7 x 2k broadcast loads)
     double xc[7];
+#pragma unroll
     for (int c = 0; c < 7; ++c) {
         double s = 0;
-        for (int b = 0; b < r; ++b) s += s_w[b] * (double)HP[(size_t)s_rows[b] * ldw + c];
+#pragma unroll
+        for (int b = 0; b < R; ++b) s += w[b] * (double)hp[b][c];
         xc[c] = x[c] + s;
     }
     double rot[9];
     d_q2r(xc + 3, rot);                   // un-normalised quaternion (quirk Q4)
     double lmin = INFINITY;
     for (int j = tid; j < m; j += blockDim.x) {
-        int i = meas[j];
-        int type = lm_type[i], off = lm_off[i];
-        int d = type == PRE3_INVDEPTH ? 6 : 3;
+        const int i = meas[j];
+        const int type = lm_type[i], off = lm_off[i];
         double y[6];
-        for (int c = 0; c < d; ++c) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
             double s = 0;
-            for (int b = 0; b < r; ++b) s += s_w[b] * (double)HP[(size_t)s_rows[b] * ldw + off + c];
-            y[c] = x[off + c] + s;
+            if (c < 3 || type == PRE3_INVDEPTH) {
+#pragma unroll
+                for (int b = 0; b < R; ++b) s += w[b] * (double)hp[b][off + c];
+                s += x[off + c];
+            }
+            y[c] = s;
         }
         double v[3], hc[3];
         d_ray(type, y, xc, v);
+#pragma unroll
         for (int c = 0; c < 3; ++c) hc[c] = rot[0 * 3 + c] * v[0] + rot[1 * 3 + c] * v[1] + rot[2 * 3 + c] * v[2];
         double uvd[2];
         d_pinhole_distort(hc, cam, uvd);
-        double n0 = z[2 * i] - uvd[0], n1 = z[2 * i + 1] - uvd[1];
-        double res = sqrt(n0 * n0 + n1 * n1);
+        const double n0 = z[2 * i] - uvd[0], n1 = z[2 * i + 1] - uvd[1];
+        const double res = sqrt(n0 * n0 + n1 * n1);
         s_res[j] = res;
         if (type == PRE3_INVDEPTH) lmin = fmin(lmin, res);
     }
     lmin = wave_min(lmin);
     if (lane == 0) s_red[wv] = lmin;
     uint32_t *s_mask = (uint32_t *)(s_res + m);
-    for (int w = tid; w < mask_words; w += blockDim.x) s_mask[w] = 0;
+    for (int wd = tid; wd < mask_words; wd += blockDim.x) s_mask[wd] = 0;
     __syncthreads();
-    double minres = fmin(fmin(s_red[0], s_red[1]), fmin(s_red[2], s_red[3]));
+    const double minres = fmin(fmin(s_red[0], s_red[1]), fmin(s_red[2], s_red[3]));
     int cnt = 0;
     for (int j = tid; j < m; j += blockDim.x) {
-        int type = lm_type[meas[j]];
-        double res = s_res[j];
+        const int type = lm_type[meas[j]];
+        const double res = s_res[j];
         // NaN residuals compare false, as in MATLAB
-        int in = (type == PRE3_INVDEPTH) ? (res < (minres + threshold)) : (res < threshold);
+        const int in = (type == PRE3_INVDEPTH) ? (res < (minres + threshold)) : (res < threshold);
         if (in) { atomicOr(&s_mask[j >> 5], 1u << (j & 31)); ++cnt; }
     }
     cnt = wave_sum(cnt);
     if (lane == 0) s_cnt[wv] = cnt;
     __syncthreads();
     if (tid == 0) support[hidx] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    for (int w = tid; w < mask_words; w += blockDim.x) masks[(size_t)hidx * mask_words + w] = s_mask[w];
+    for (int wd = tid; wd < mask_words; wd += blockDim.x) masks[(size_t)hidx * mask_words + wd] = s_mask[wd];
 }
 
 // K6: sequential replay of ransac_hypotheses.m:40-80 over the supports (quirk Q1), winner's mask ->
@@ -520,56 +567,92 @@ __device__ inline int wave_compact(int flag, int lane, int base_cnt, int32_t *__
     return base_cnt + __popcll(mask);
 }
 
+__device__ inline int ransac_n_hyp(int sup, int m)
+{
+    // ransac_hypotheses.m:77-78: epsilon = 1 - support/num_IC; n_hyp = ceil(log(1-p)/log(1-(1-epsilon)))
+    double epsilon = 1 - ((double)sup / (double)m);
+    return (int)ceil(log(1 - 0.99) / log(1 - (1 - epsilon)));
+}
+
+// The reference's loop only changes state at "improvements" (support > running max), and its exit test
+// n_hyp <= k can only become true at an improvement, so the replay walks the improvements in order:
+// wave 0 finds them 64 supports at a time (prefix max by shuffles + ballot) and evaluates the few hits.
+// out[0..5]: written twice -- device stats (for later kernels) and the pinned host mirror (polled by the host).
 __global__ __launch_bounds__(256) void k_ransac_select(int n_draw, int k, int early_exit, int m, const int32_t *__restrict__ meas,
                                                        int32_t *__restrict__ support, const uint32_t *__restrict__ masks, int mask_words,
                                                        int32_t *__restrict__ li_meas, int32_t *__restrict__ lm_li,
-                                                       int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats)
+                                                       int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats,
+                                                       int32_t *mail, int seq)
 {
-    constexpr int CAP = 4096;
-    __shared__ int s_sup[CAP];
-    __shared__ int s_best, s_iters;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < n_draw && i < CAP; i += blockDim.x) s_sup[i] = support[i];
-    __syncthreads();
-    if (tid == 0) {
-        int n_hyp = 1000, max_support = 0, best = -1, iters = 0;
-        int limit = early_exit ? (n_draw < 1000 ? n_draw : 1000) : n_draw;
-        for (int it = 0; it < limit; ++it) {
-            if (early_exit && n_hyp == 0) break;
-            int sup = it < CAP ? s_sup[it] : support[it];
-            ++iters;
-            if (sup > max_support) {
-                max_support = sup; best = it;
-                double epsilon = 1 - ((double)sup / (double)m);
-                n_hyp = (int)ceil(log(1 - 0.99) / log(1 - (1 - epsilon)));
+    __shared__ int s_best, s_iters, s_wcnt[4], s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_base = 0;
+    if (wv == 0) {
+        const int limit = early_exit ? (n_draw < 1000 ? n_draw : 1000) : n_draw;
+        int n_hyp = 1000, max_support = 0, best = -1, iters = limit;
+        bool done = false;
+        for (int base = 0; base < limit && !done; base += 64) {
+            const int it = base + lane;
+            const int v = it < limit ? support[it] : -1;
+            int pm = v;                                          // inclusive prefix max over the chunk
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(pm, o, 64); if (lane >= o) pm = max(pm, t); }
+            int excl = __shfl_up(pm, 1, 64);
+            if (lane == 0) excl = -1;
+            excl = max(excl, max_support);
+            unsigned long long hits = __ballot(v > excl);        // improvements, in index order
+            while (hits) {
+                const int l = __ffsll((long long)hits) - 1;
+                hits &= hits - 1;
+                const int sup = __shfl(v, l, 64);
+                max_support = sup; best = base + l;
+                if (early_exit) {
+                    n_hyp = ransac_n_hyp(sup, m);
+                    if (n_hyp <= k) { iters = base + l + 1; done = true; break; }
+                }
             }
-            if (early_exit && n_hyp <= k) break;
         }
-        s_best = best; s_iters = iters;
-        stats[0] = best; stats[1] = iters; stats[2] = n_hyp; stats[3] = max_support;
+        if (!early_exit && best >= 0) n_hyp = ransac_n_hyp(max_support, m);
+        if (lane == 0) {
+            s_best = best; s_iters = iters;
+            stats[0] = best; stats[1] = iters; stats[2] = n_hyp; stats[3] = max_support;
+        }
     }
     __syncthreads();
     const int best = s_best, iters = s_iters;
     for (int it = iters + tid; it < n_draw; it += blockDim.x) support[it] = -1;   // never evaluated by the reference
-    if (tid < 64) {
-        int cnt = 0;
-        for (int base = 0; base < m; base += 64) {
-            int j = base + tid;
-            int in = 0;
-            if (j < m) {
-                in = best >= 0 ? (masks[(size_t)best * mask_words + (j >> 5)] >> (j & 31)) & 1 : 0;
-                li_meas[j] = in; lm_li[meas[j]] = in;
-            }
-            cnt = wave_compact(in, tid, cnt, sel_rows, j);
+    // winner's mask -> flags (set_as_most_supported_hypothesis.m:32-52) + ordered compaction of the LI rows
+    for (int base = 0; base < m; base += 256) {
+        const int j = base + tid;
+        int in = 0;
+        if (j < m) {
+            in = best >= 0 ? (masks[(size_t)best * mask_words + (j >> 5)] >> (j & 31)) & 1 : 0;
+            li_meas[j] = in; lm_li[meas[j]] = in;
         }
-        if (tid == 0) stats[4] = cnt;
+        const unsigned long long bal = __ballot(in);
+        if (lane == 0) s_wcnt[wv] = __popcll(bal);
+        __syncthreads();
+        int pre = s_base;
+        for (int w2 = 0; w2 < wv; ++w2) pre += s_wcnt[w2];
+        if (in) sel_rows[pre + __popcll(bal & ((1ull << lane) - 1ull))] = j;
+        __syncthreads();
+        if (tid == 0) s_base += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        stats[4] = s_base;
+        // host mailbox: payload, system-scope fence, then the sequence word the host polls
+        mail[0] = stats[0]; mail[1] = stats[1]; mail[2] = stats[2]; mail[3] = stats[3]; mail[4] = s_base;
+        __threadfence_system();
+        __hip_atomic_store(&mail[8], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
 // hi flags (landmark order, written by k_innovation mode 1) -> measurement order + compacted list
 __global__ __launch_bounds__(64) void k_collect_hi(int m, const int32_t *__restrict__ meas, const int32_t *__restrict__ lm_ic,
                                                    const int32_t *__restrict__ lm_li, const int32_t *__restrict__ lm_hi,
-                                                   int32_t *__restrict__ hi_meas, int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats)
+                                                   int32_t *__restrict__ hi_meas, int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats,
+                                                   int32_t *mail, int seq)
 {
     const int tid = threadIdx.x;
     int cnt = 0;
@@ -583,7 +666,12 @@ __global__ __launch_bounds__(64) void k_collect_hi(int m, const int32_t *__restr
         }
         cnt = wave_compact(in, tid, cnt, sel_rows, j);
     }
-    if (tid == 0) stats[5] = cnt;
+    if (tid == 0) {
+        stats[5] = cnt;
+        mail[5] = cnt;
+        __threadfence_system();
+        __hip_atomic_store(&mail[9], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // x_out = x_prior + W' y  (update.m:36), then Jn at the un-normalised quaternion (update.m:42) -> params,
@@ -656,7 +744,7 @@ int launch_project(pre3_ctx *c, int which, int clear_first)
 
 int launch_innovation(pre3_ctx *c, int mode, double chi2)
 {
-    dim3 g(ceil_div(c->N, 64)), b(64);
+    dim3 g(ceil_div(c->N * 16, 256)), b(256);
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_innovation<double>, g, b, 0, c->stream, c->N, c->lm.type, c->lm.off, (const double *)c->P, c->ld, c->lm.Hc,
                            c->lm.Hl, c->lm.has_h, mode, chi2, c->lm.h, c->lm.z, c->lm.ic, c->lm.li, c->lm.hi, c->lm.S, c->lm.has_S),
@@ -665,7 +753,7 @@ int launch_innovation(pre3_ctx *c, int mode, double chi2)
     PRE3_HIP(hipGetLastError());
     if (mode == 1) {
         hipLaunchKernelGGL(k_collect_hi, dim3(1), dim3(64), 0, c->stream, c->m, c->meas, c->lm.ic, c->lm.li, c->lm.hi, c->hi_meas,
-                           c->sel_rows, c->stats);
+                           c->sel_rows, c->stats, c->mail_dev, ++c->seq_collect);
         PRE3_HIP(hipGetLastError());
     }
     return PRE3_OK;
@@ -693,6 +781,21 @@ int launch_build_rows_impl(pre3_ctx *c, int nsel, const int32_t *sel_dev, int r_
     return PRE3_OK;
 }
 
+template <typename T>
+static void launch_score_k(pre3_ctx *c, int k, int nb, size_t shm, int hyp_begin, double threshold, int ldg, int32_t *support_dev,
+                           uint32_t *mask_dev, int mask_words)
+{
+#define SCORE_ARGS hyp_begin, c->hyp, c->m, c->meas, c->lm.type, c->lm.off, c->x_km1, (const T *)c->HP, c->ldw, (const T *)c->G, ldg, \
+                   c->row_nu, c->lm.z, to_camd(c->cam), threshold, support_dev, mask_dev, mask_words
+    switch (k) {
+    case 1: hipLaunchKernelGGL((k_ransac_score<T, 1>), dim3(nb), dim3(256), shm, c->stream, SCORE_ARGS); break;
+    case 2: hipLaunchKernelGGL((k_ransac_score<T, 2>), dim3(nb), dim3(256), shm, c->stream, SCORE_ARGS); break;
+    case 3: hipLaunchKernelGGL((k_ransac_score<T, 3>), dim3(nb), dim3(256), shm, c->stream, SCORE_ARGS); break;
+    default: hipLaunchKernelGGL((k_ransac_score<T, 4>), dim3(nb), dim3(256), shm, c->stream, SCORE_ARGS); break;
+    }
+#undef SCORE_ARGS
+}
+
 int launch_ransac_score_impl(pre3_ctx *c, int k, double threshold, int hyp_begin, int hyp_end, int ldg, int32_t *support_dev,
                              uint32_t *mask_dev, int mask_words)
 {
@@ -700,12 +803,8 @@ int launch_ransac_score_impl(pre3_ctx *c, int k, double threshold, int hyp_begin
     if (nb <= 0) return PRE3_OK;
     size_t shm = sizeof(double) * c->m + sizeof(uint32_t) * mask_words + 16;
     DISPATCH_T(c,
-        hipLaunchKernelGGL(k_ransac_score<double>, dim3(nb), dim3(256), shm, c->stream, hyp_begin, k, c->hyp, c->m, c->meas, c->lm.type,
-                           c->lm.off, c->x_km1, (const double *)c->HP, c->ldw, (const double *)c->G, ldg, c->row_nu, c->lm.z,
-                           to_camd(c->cam), threshold, support_dev, mask_dev, mask_words),
-        hipLaunchKernelGGL(k_ransac_score<float>, dim3(nb), dim3(256), shm, c->stream, hyp_begin, k, c->hyp, c->m, c->meas, c->lm.type,
-                           c->lm.off, c->x_km1, (const float *)c->HP, c->ldw, (const float *)c->G, ldg, c->row_nu, c->lm.z,
-                           to_camd(c->cam), threshold, support_dev, mask_dev, mask_words));
+        launch_score_k<double>(c, k, nb, shm, hyp_begin, threshold, ldg, support_dev, mask_dev, mask_words),
+        launch_score_k<float>(c, k, nb, shm, hyp_begin, threshold, ldg, support_dev, mask_dev, mask_words));
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }
@@ -713,7 +812,7 @@ int launch_ransac_score_impl(pre3_ctx *c, int k, double threshold, int hyp_begin
 int launch_ransac_select_impl(pre3_ctx *c, int n_draw, int k, int early_exit, int32_t *support_dev, const uint32_t *mask_dev, int mask_words)
 {
     hipLaunchKernelGGL(k_ransac_select, dim3(1), dim3(256), 0, c->stream, n_draw, k, early_exit, c->m, c->meas, support_dev, mask_dev,
-                       mask_words, c->li_meas, c->lm.li, c->sel_rows, c->stats);
+                       mask_words, c->li_meas, c->lm.li, c->sel_rows, c->stats, c->mail_dev, ++c->seq_select);
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }

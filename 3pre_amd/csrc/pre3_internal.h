@@ -101,6 +101,12 @@ struct pre3_ctx {
     int32_t *li_meas = nullptr, *hi_meas = nullptr;   // [capm] flags in measurement order
     double *pred_params = nullptr;                // [64] predict: Qq1(16) Jn(16) Q(49->7x7) etc.
     int32_t *pinned_stats = nullptr;              // host pinned [16]
+    // mailbox: pinned, host-coherent; k_ransac_select / k_collect_hi store their counts here and bump a
+    // sequence word, so the host learns r for the next launches by polling instead of a copy + stream sync
+    int32_t *mail_host = nullptr, *mail_dev = nullptr;
+    int32_t seq_select = 0, seq_collect = 0;
+    int li_from_host = -1, hi_from_host = -1;     // row counts forced through pre3_set_flags (-1: use the kernels' counts)
+    bool li_kernel = false, hi_kernel = false;    // a select / collect kernel has run for the current measurement set
     // per-step inbox: [meas | ic | hyp | z] contiguous on the device, mirrored in pinned host memory -> ONE H2D copy
     void *inbox_dev = nullptr; unsigned char *inbox_host = nullptr;
     size_t inbox_bytes = 0, off_meas = 0, off_ic = 0, off_hyp = 0, off_z = 0;

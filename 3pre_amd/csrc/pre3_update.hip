@@ -357,23 +357,35 @@ __global__ __launch_bounds__(256) void k_chol_trail(T *__restrict__ S, int lds, 
         int t = idx - nSt;
         c0 = (t % nW) * NB; K = J + 1 + t / nW; isW = true;
     }
-    for (int e = tid; e < NB * NB; e += 256) {
-        int j = e >> 6, a = e & 63;
-        Bs[j][a] = S[(size_t)(K * NB + j) * lds + J * NB + a];
-    }
-    if (!isW) {
-        for (int e = tid; e < NB * NB; e += 256) {
-            int i = e >> 6, a = e & 63;
-            As[i][a] = S[(size_t)(rb * NB + i) * lds + J * NB + a];        // [i][a]
-        }
-    } else {
-        for (int e = tid; e < NB * NB; e += 256) {
-            int a = e >> 6, i = e & 63;
-            As[a][i] = W[(size_t)(J * NB + a) * ldw + c0 + i];              // [a][i]
-        }
-    }
-    __syncthreads();
     const int w0 = (wave >> 1) * 32, w1 = (wave & 1) * 32;
+    {
+        // all global loads (both operand tiles and the 16 output elements this lane will update) are issued
+        // before the first LDS store, so their latencies overlap
+        T ga[16], gb[16];
+        const int lr = tid >> 6, lc = tid & 63;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) gb[t] = S[(size_t)(K * NB + lr + 4 * t) * lds + J * NB + lc];
+        if (!isW) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) ga[t] = S[(size_t)(rb * NB + lr + 4 * t) * lds + J * NB + lc];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) ga[t] = W[(size_t)(J * NB + lr + 4 * t) * ldw + c0 + lc];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { Bs[lr + 4 * t][lc] = gb[t]; As[lr + 4 * t][lc] = ga[t]; }   // As: [i][a] (S) or [a][i] (W)
+    }
+    T cv[NBLK][NBLK][M::NREG];
+#pragma unroll
+    for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+        for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+            for (int e = 0; e < M::NREG; ++e) {
+                const int r_ = w0 + p * M::BLK + M::row(lane, e), c_ = w1 + q * M::BLK + M::col(lane);
+                cv[p][q][e] = !isW ? S[(size_t)(rb * NB + r_) * lds + K * NB + c_] : W[(size_t)(K * NB + r_) * ldw + c0 + c_];
+            }
+    __syncthreads();
     typename M::acc_t acc[NBLK][NBLK];
 #pragma unroll
     for (int p = 0; p < NBLK; ++p)
@@ -401,7 +413,7 @@ __global__ __launch_bounds__(256) void k_chol_trail(T *__restrict__ S, int lds, 
 #pragma unroll
                 for (int e = 0; e < M::NREG; ++e) {
                     int i = w0 + p * M::BLK + M::row(lane, e), j = w1 + q * M::BLK + M::col(lane);
-                    S[(size_t)(rb * NB + i) * lds + K * NB + j] -= acc[p][q][e];
+                    S[(size_t)(rb * NB + i) * lds + K * NB + j] = cv[p][q][e] - acc[p][q][e];
                 }
     } else {
         // acc rows -> j (B tile rows, offset w0), acc cols (lanes) -> i (W columns, offset w1)
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(256) void k_chol_trail(T *__restrict__ S, int lds, 
 #pragma unroll
                 for (int e = 0; e < M::NREG; ++e) {
                     int j = w0 + p * M::BLK + M::row(lane, e), i = w1 + q * M::BLK + M::col(lane);
-                    W[(size_t)(K * NB + j) * ldw + c0 + i] -= acc[p][q][e];
+                    W[(size_t)(K * NB + j) * ldw + c0 + i] = cv[p][q][e] - acc[p][q][e];
                 }
     }
 }
