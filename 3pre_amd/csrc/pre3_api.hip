@@ -144,22 +144,39 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
     A(dmalloc(&c->stats, 16)); A(dmalloc(&c->li_meas, c->capm)); A(dmalloc(&c->hi_meas, c->capm));
     A(dmalloc(&c->pred_params, 128));
     {
-        // K9 tile schedule: upper-triangle 64x64 tiles grouped in 4x4 super-tiles (8 W panels = 1.3 MB at r=640,
-        // inside one XCD's 4 MiB L2); super-tile s goes to blocks b with b % 8 == s % 8 (blocks are dealt
-        // round-robin over the 8 XCDs -- speed only, never correctness), padded with (-1,-1).
+        // K9 tile schedule: upper-triangle 64x64 tiles in 4x4 super-tile order, so that the tiles in flight at
+        // any moment (tickets are handed out in this order) share W panels in L2 / Infinity Cache.
         const int nt = c->ld / 64, ns = ceil_div(nt, 4);
-        std::vector<std::vector<int2>> per_xcd(8);
+        std::vector<std::vector<int2>> lists(8);
         int sidx = 0;
         for (int SI = 0; SI < ns; ++SI)
-            for (int SJ = SI; SJ < ns; ++SJ, ++sidx)
+            for (int SJ = SI; SJ < ns; ++SJ) {
+                // whole super-tiles go to the currently shortest list (balanced to within one super-tile)
+                int best = 0;
+                for (int x = 1; x < 8; ++x) if (lists[x].size() < lists[best].size()) best = x;
+                (void)sidx;
                 for (int i = SI * 4; i < std::min(nt, SI * 4 + 4); ++i)
                     for (int j = SJ * 4; j < std::min(nt, SJ * 4 + 4); ++j)
-                        if (j >= i) per_xcd[sidx % 8].push_back(make_int2(i, j));
-        size_t mx = 0;
-        for (auto &v : per_xcd) mx = std::max(mx, v.size());
-        std::vector<int2> flat(mx * 8, make_int2(-1, -1));
-        for (int x = 0; x < 8; ++x) for (size_t k = 0; k < per_xcd[x].size(); ++k) flat[k * 8 + x] = per_xcd[x][k];
-        c->n_tiles = (int)flat.size();
+                        if (j >= i) lists[best].push_back(make_int2(i, j));
+            }
+        for (;;) {       // even the lists out to within one tile (moves come from the tail: the last, partial super-tiles)
+            int lo = 0, hi = 0;
+            for (int x = 1; x < 8; ++x) { if (lists[x].size() < lists[lo].size()) lo = x; if (lists[x].size() > lists[hi].size()) hi = x; }
+            if (lists[hi].size() <= lists[lo].size() + 1) break;
+            lists[lo].push_back(lists[hi].back());
+            lists[hi].pop_back();
+        }
+        size_t mx = 1;
+        int cnts[8];
+        for (int x = 0; x < 8; ++x) { mx = std::max(mx, lists[x].size()); cnts[x] = (int)lists[x].size(); }
+        std::vector<int2> flat(mx * 8, make_int2(0, 0));
+        int total = 0;
+        for (int x = 0; x < 8; ++x) { for (size_t k2 = 0; k2 < lists[x].size(); ++k2) flat[x * mx + k2] = lists[x][k2]; total += cnts[x]; }
+        c->tiles_stride = (int)mx;
+        c->n_tiles = total;
+        A(dmalloc(&c->tile_ctr, 8)); A(dmalloc(&c->tile_cnt, 8));
+        if (rc == PRE3_OK) { (void)hipMemset(c->tile_ctr, 0, sizeof(unsigned int) * 8); (void)hipMemcpy(c->tile_cnt, cnts, sizeof(cnts), hipMemcpyHostToDevice); }
+        { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) c->num_cus = pr.multiProcessorCount; }
         A(dmalloc_bytes(&c->tiles, sizeof(int2) * flat.size()));
         if (rc == PRE3_OK && hipMemcpy(c->tiles, flat.data(), sizeof(int2) * flat.size(), hipMemcpyHostToDevice) != hipSuccess) { set_error("tile table upload failed"); rc = PRE3_E_HIP; }
     }
@@ -185,7 +202,7 @@ int pre3_destroy(pre3_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
                      c->lm.li, c->lm.hi, c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
-                     c->sel_rows, c->support, c->masks, c->stats, c->li_meas, c->hi_meas, c->pred_params, c->tiles };
+                     c->sel_rows, c->support, c->masks, c->stats, c->li_meas, c->hi_meas, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->pinned_stats) (void)hipHostFree(c->pinned_stats);
     if (c->inbox_host) (void)hipHostFree(c->inbox_host);

@@ -679,8 +679,9 @@ __global__ __launch_bounds__(64) void k_collect_hi(int m, const int32_t *__restr
 template <typename T>
 __global__ __launch_bounds__(1024) void k_update_x(int n, int r, const T *__restrict__ W, int ldw, int ld,
                                                    const double *__restrict__ x_prior, double *__restrict__ x_out,
-                                                   double *__restrict__ params)
+                                                   double *__restrict__ params, unsigned int *__restrict__ tile_ctr)
 {
+    if (blockIdx.x == 0 && threadIdx.x < 8) tile_ctr[threadIdx.x] = 0;       // tickets of the K9 launch that follows
     __shared__ double red[16][64];
     __shared__ double q[4];
     const int ci = threadIdx.x & 63, rg = threadIdx.x >> 6;
@@ -839,8 +840,9 @@ int launch_update_x(pre3_ctx *c, int which_prior, int r)
     const double *xp = which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1;
     dim3 g(ceil_div(c->n, 64)), b(1024);
     DISPATCH_T(c,
-        hipLaunchKernelGGL(k_update_x<double>, g, b, 0, c->stream, c->n, r, (const double *)c->W, c->ldw, c->ld, xp, c->x_kk, c->pred_params),
-        hipLaunchKernelGGL(k_update_x<float>, g, b, 0, c->stream, c->n, r, (const float *)c->W, c->ldw, c->ld, xp, c->x_kk, c->pred_params));
+        hipLaunchKernelGGL(k_update_x<double>, g, b, 0, c->stream, c->n, r, (const double *)c->W, c->ldw, c->ld, xp, c->x_kk, c->pred_params, c->tile_ctr),
+        hipLaunchKernelGGL(k_update_x<float>, g, b, 0, c->stream, c->n, r, (const float *)c->W, c->ldw, c->ld, xp, c->x_kk, c->pred_params, c->tile_ctr));
+    c->tile_ctr_clean = true;
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }

@@ -14,6 +14,9 @@
 //
 // Layout: P is ld x ld (ld multiple of 128, zero beyond n); W/HP are r_pad x ldw row-major, i.e. one
 // length-n vector per measurement row, so both MFMA operands of W'W are read k-major/contiguous.
+#include <algorithm>
+#include <cstdlib>
+
 #include "pre3_internal.h"
 
 namespace pre3 {
@@ -461,19 +464,21 @@ __global__ __launch_bounds__(256) void k_gain(int n, int r, const T *__restrict_
 // Workgroup = 4 waves in 2x2, each wave owns a 64x64 sub-tile of a 128x128 tile of P; W is staged
 // k-major through LDS (BK rows x 128 contiguous columns per operand), double-buffered.
 // ------------------------------------------------------------------------------------------------
-// K9 v2: symmetric.  One workgroup per 64x64 tile (I <= J) of the upper triangle; 4 waves, each a 32x32
-// sub-tile (fp32: one v_mfma_f32_32x32x2 accumulator; fp64: 2x2 v_mfma_f64_16x16x4 accumulators).  W is
-// staged k-major through LDS (BK rows x 64 contiguous columns per operand), double-buffered with register
-// prefetch.  Epilogue: new = P_IJ - acc is written to P_IJ and, transposed through a wave-private LDS patch,
-// to P_JI, so the lower triangle is never read and P comes out exactly symmetric.
-// tiles[] lists (I, J) per block (an XCD-aware order built on the host); I < 0 marks a padding block.
+// K9 v3: symmetric, persistent.  Workgroups (2 per CU) pull 64x64 upper-triangle tiles (I <= J) from a
+// monotonic global counter, so a workgroup in its load/store phase overlaps one in its MFMA phase on the
+// same SIMDs and the tail is balanced at tile granularity.  4 waves per tile, each a 32x32 sub-tile (fp32: one
+// v_mfma_f32_32x32x2 accumulator; fp64: 2x2 v_mfma_f64_16x16x4 accumulators).  W is staged k-major through
+// LDS (BK rows x 64 contiguous columns per operand), double-buffered with register prefetch; the P tile is
+// prefetched into registers before the k-loop.  Epilogue: new = P_IJ - acc goes to P_IJ and, transposed
+// through a wave-private LDS patch, to P_JI: the lower triangle is never read and P is exactly symmetric.
 template <typename T, int BK>
 __global__ __launch_bounds__(256) void k_downdate(T *__restrict__ P, int ld, const T *__restrict__ W, int ldw, int r_pad,
-                                                  const int2 *__restrict__ tiles)
+                                                  const int2 *__restrict__ tiles, int tiles_stride, const int *__restrict__ tile_cnt,
+                                                  unsigned int *__restrict__ ctr)
 {
     using M = Mfma<T>;
-    constexpr int TS = 64;                            // workgroup tile
-    constexpr int NBLK = 32 / M::BLK;                 // MFMA blocks per wave sub-tile dimension (1 or 2)
+    constexpr int TS = 64;
+    constexpr int NBLK = 32 / M::BLK;
     constexpr int VEC = 16 / sizeof(T);
     constexpr int ROWV = TS / VEC;
     constexpr int NLD = (BK * ROWV) / 256;
@@ -481,92 +486,119 @@ __global__ __launch_bounds__(256) void k_downdate(T *__restrict__ P, int ld, con
     typedef T vec_t __attribute__((ext_vector_type(VEC)));
 
     __shared__ __attribute__((aligned(16))) T smem[4 * BK * TS];
-    T (*sA)[BK][TS] = reinterpret_cast<T (*)[BK][TS]>(smem);                     // sA[2][BK][TS]
-    T (*sB)[BK][TS] = reinterpret_cast<T (*)[BK][TS]>(smem + 2 * BK * TS);       // sB[2][BK][TS]
+    __shared__ unsigned int s_tile;
+    T (*sA)[BK][TS] = reinterpret_cast<T (*)[BK][TS]>(smem);
+    T (*sB)[BK][TS] = reinterpret_cast<T (*)[BK][TS]>(smem + 2 * BK * TS);
+    T (*patch)[33] = reinterpret_cast<T (*)[33]>(smem + (threadIdx.x >> 6) * (32 * 33));
+    static_assert(4 * 32 * 33 <= 4 * BK * TS, "patches must fit in the staging buffers");
 
-    const int2 ij = tiles[blockIdx.x];
-    if (ij.x < 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
-    const int I0 = ij.x * TS, J0 = ij.y * TS;
-
-    typename M::acc_t acc[NBLK][NBLK];
-#pragma unroll
-    for (int p = 0; p < NBLK; ++p)
-#pragma unroll
-        for (int q = 0; q < NBLK; ++q)
-#pragma unroll
-            for (int e = 0; e < M::NREG; ++e) acc[p][q][e] = (T)0;
-
-    vec_t ra[NLD], rb[NLD];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int l = 0; l < NLD; ++l) {
-            int v = tid + l * 256;
-            int kr = v / ROWV, cv = (v % ROWV) * VEC;
-            ra[l] = *reinterpret_cast<const vec_t *>(W + (size_t)(k0 + kr) * ldw + I0 + cv);
-            rb[l] = *reinterpret_cast<const vec_t *>(W + (size_t)(k0 + kr) * ldw + J0 + cv);
-        }
-    };
-    auto sstore = [&](int buf) {
-#pragma unroll
-        for (int l = 0; l < NLD; ++l) {
-            int v = tid + l * 256;
-            int kr = v / ROWV, cv = (v % ROWV) * VEC;
-            *reinterpret_cast<vec_t *>(&sA[buf][kr][cv]) = ra[l];
-            *reinterpret_cast<vec_t *>(&sB[buf][kr][cv]) = rb[l];
-        }
-    };
-
     const int nstage = r_pad / BK;
-    gload(0);
-    sstore(0);
-    __syncthreads();
-    for (int s = 0; s < nstage; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nstage) gload((s + 1) * BK);
+
+    // Tickets: 8 lists / 8 counters (one per XCD label blockIdx % 8: blocks are dealt round-robin over the XCDs,
+    // so a list's tiles -- whole 4x4 super-tiles -- stay in one L2; speed only).  A workgroup drains its own
+    // list only (the lists are balanced to within one tile); one contended word would serialise at ~88 tickets/us.
+    auto next_ticket = [&]() -> unsigned int {
+        const int x = blockIdx.x & 7;          // lists are balanced to within one tile: no stealing, one failing ticket per workgroup
+        const unsigned int t = atomicAdd(&ctr[x], 1u);
+        return t < (unsigned int)tile_cnt[x] ? (unsigned int)(x * tiles_stride) + t : 0xffffffffu;
+    };
+    if (tid == 0) s_tile = next_ticket();
+    for (;;) {
+        __syncthreads();                       // ticket visible; previous tile's patch reads fenced against new staging
+        const unsigned int t = s_tile;
+        if (t == 0xffffffffu) return;          // uniform exit: every wave of the workgroup leaves together
+        const int2 ij = tiles[t];
+        const int I0 = ij.x * TS, J0 = ij.y * TS;
+
+        vec_t ra[NLD], rb[NLD];
+        auto gload = [&](int k0) {
 #pragma unroll
-        for (int ks = 0; ks < BK / M::KS; ++ks) {
-            const int krow = ks * M::KS + M::kk(lane);
-            T av[NBLK], bv[NBLK];
-#pragma unroll
-            for (int p = 0; p < NBLK; ++p) {
-                av[p] = sA[buf][krow][wi * 32 + p * M::BLK + M::col(lane)];
-                bv[p] = sB[buf][krow][wj * 32 + p * M::BLK + M::col(lane)];
+            for (int l = 0; l < NLD; ++l) {
+                int v = tid + l * 256;
+                int kr = v / ROWV, cv = (v % ROWV) * VEC;
+                ra[l] = *reinterpret_cast<const vec_t *>(W + (size_t)(k0 + kr) * ldw + I0 + cv);
+                rb[l] = *reinterpret_cast<const vec_t *>(W + (size_t)(k0 + kr) * ldw + J0 + cv);
             }
+        };
+        auto sstore = [&](int buf) {
 #pragma unroll
-            for (int p = 0; p < NBLK; ++p)
+            for (int l = 0; l < NLD; ++l) {
+                int v = tid + l * 256;
+                int kr = v / ROWV, cv = (v % ROWV) * VEC;
+                *reinterpret_cast<vec_t *>(&sA[buf][kr][cv]) = ra[l];
+                *reinterpret_cast<vec_t *>(&sB[buf][kr][cv]) = rb[l];
+            }
+        };
+        gload(0);
+        // prefetch this lane's 16 entries of the P tile
+        T pv[NBLK][NBLK][M::NREG];
 #pragma unroll
-                for (int q = 0; q < NBLK; ++q) M::mma(av[p], bv[q], acc[p][q]);
-        }
-        if (s + 1 < nstage) sstore(buf ^ 1);
+        for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+            for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+                for (int e = 0; e < M::NREG; ++e)
+                    pv[p][q][e] = P[(size_t)(I0 + wi * 32 + p * M::BLK + M::row(lane, e)) * ld + J0 + wj * 32 + q * M::BLK + M::col(lane)];
+
+        typename M::acc_t acc[NBLK][NBLK];
+#pragma unroll
+        for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+            for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+                for (int e = 0; e < M::NREG; ++e) acc[p][q][e] = (T)0;
+
+        sstore(0);
         __syncthreads();
-    }
-    // ---- epilogue.  The staging buffers are dead now: each wave takes a private [32][33] patch of sA.
-    T (*patch)[33] = reinterpret_cast<T (*)[33]>(smem + wave * (32 * 33));
-    static_assert(4 * 32 * 33 <= 4 * BK * TS, "patches must fit in the staging buffers");
-    const bool mirror = ij.x != ij.y;
+        for (int s = 0; s < nstage; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < nstage) gload((s + 1) * BK);
+            else if (tid == 0) s_tile = next_ticket();     // no loads behind it: its latency hides under the last stage
+            // all operand fragments of the stage are read from LDS up front (registers are plentiful), so the
+            // MFMAs issue back to back behind counted lgkmcnt waits instead of one LDS round trip per pair
+            T av[BK / M::KS][NBLK], bv[BK / M::KS][NBLK];
 #pragma unroll
-    for (int p = 0; p < NBLK; ++p)
+            for (int ks = 0; ks < BK / M::KS; ++ks) {
+                const int krow = ks * M::KS + M::kk(lane);
 #pragma unroll
-        for (int q = 0; q < NBLK; ++q)
-#pragma unroll
-            for (int e = 0; e < M::NREG; ++e) {
-                const int lr = p * M::BLK + M::row(lane, e), lc = q * M::BLK + M::col(lane);
-                const size_t o = (size_t)(I0 + wi * 32 + lr) * ld + J0 + wj * 32 + lc;
-                const T v = P[o] - acc[p][q][e];
-                P[o] = v;
-                if (mirror) patch[lr][lc] = v;
+                for (int p = 0; p < NBLK; ++p) {
+                    av[ks][p] = sA[buf][krow][wi * 32 + p * M::BLK + M::col(lane)];
+                    bv[ks][p] = sB[buf][krow][wj * 32 + p * M::BLK + M::col(lane)];
+                }
             }
-    if (mirror) {
-        // wave-private patch: LDS ops of one wave complete in order, no workgroup barrier needed
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        const int rr = lane & 31, half = lane >> 5;
 #pragma unroll
-        for (int cc = 0; cc < 32; cc += 2) {
-            const int c = cc + half;                                   // column of the patch = row of P_JI
-            P[(size_t)(J0 + wj * 32 + c) * ld + I0 + wi * 32 + rr] = patch[rr][c];
+            for (int ks = 0; ks < BK / M::KS; ++ks)
+#pragma unroll
+                for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+                    for (int q = 0; q < NBLK; ++q) M::mma(av[ks][p], bv[ks][q], acc[p][q]);
+            if (s + 1 < nstage) sstore(buf ^ 1);
+            __syncthreads();
+        }
+        // ---- epilogue (the staging buffers are dead: each wave owns a private [32][33] patch of them)
+        const bool mirror = ij.x != ij.y;
+#pragma unroll
+        for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+            for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+                for (int e = 0; e < M::NREG; ++e) {
+                    const int lr = p * M::BLK + M::row(lane, e), lc = q * M::BLK + M::col(lane);
+                    const T v = pv[p][q][e] - acc[p][q][e];
+                    P[(size_t)(I0 + wi * 32 + lr) * ld + J0 + wj * 32 + lc] = v;
+                    if (mirror) patch[lr][lc] = v;
+                }
+        if (mirror) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);      // wave-private patch: this wave's LDS writes have landed
+            __builtin_amdgcn_wave_barrier();
+            const int rr = lane & 31, half = lane >> 5;
+#pragma unroll
+            for (int cc = 0; cc < 32; cc += 2) {
+                const int c = cc + half;
+                P[(size_t)(J0 + wj * 32 + c) * ld + I0 + wi * 32 + rr] = patch[rr][c];
+            }
         }
     }
 }
@@ -636,7 +668,13 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad)
 int launch_downdate(pre3_ctx *c, int r, const void *W)
 {
     int r_pad = round_up(r, NB);
-    dim3 g(c->n_tiles), b(256);
+    // persistent grid: 2 workgroups per CU (or one per tile when there are fewer tiles); the tile counter is
+    // monotonic across launches (each launch consumes grid + n_tiles tickets), reset long before it could wrap
+    static const int wgs_per_cu = getenv("PRE3_K9_WGS") ? atoi(getenv("PRE3_K9_WGS")) : 3;
+    const int gsz = std::min(c->n_tiles, wgs_per_cu * c->num_cus);
+    if (!c->tile_ctr_clean) PRE3_HIP(hipMemsetAsync(c->tile_ctr, 0, sizeof(unsigned int) * 8, c->stream));   // normally done by k_update_x
+    c->tile_ctr_clean = false;
+    dim3 g(gsz), b(256);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->kt.enabled) {
         if ((size_t)c->kt.used + 2 > c->kt.ev.size()) {
@@ -647,8 +685,8 @@ int launch_downdate(pre3_ctx *c, int r, const void *W)
         PRE3_HIP(hipEventRecord(e0, c->stream));
     }
     DISPATCH_T(c,
-        hipLaunchKernelGGL((k_downdate<double, 32>), g, b, 0, c->stream, (double *)c->P, c->ld, (const double *)W, c->ldw, r_pad, (const int2 *)c->tiles),
-        hipLaunchKernelGGL((k_downdate<float, 32>), g, b, 0, c->stream, (float *)c->P, c->ld, (const float *)W, c->ldw, r_pad, (const int2 *)c->tiles));
+        hipLaunchKernelGGL((k_downdate<double, 32>), g, b, 0, c->stream, (double *)c->P, c->ld, (const double *)W, c->ldw, r_pad, (const int2 *)c->tiles, c->tiles_stride, c->tile_cnt, c->tile_ctr),
+        hipLaunchKernelGGL((k_downdate<float, 32>), g, b, 0, c->stream, (float *)c->P, c->ld, (const float *)W, c->ldw, r_pad, (const int2 *)c->tiles, c->tiles_stride, c->tile_cnt, c->tile_ctr));
     if (c->kt.enabled) {
         PRE3_HIP(hipEventRecord(e1, c->stream));
         c->kt.flops += (double)c->n * ((double)c->n + 1.0) * r;          // SYRK count n(n+1)r; the survey's un-halved figure is 2 n^2 r
