@@ -120,22 +120,53 @@ __device__ unsigned long long g_probe[16];
 #define PROBE_ACC(k, t0)
 #endif
 
+// wave-uniform lane read (v_readlane_b32): a few cycles, no LDS round trip
+__device__ inline float rdlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ inline double rdlane(double v, int l)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// hardware 1/sqrt: fp32 takes v_rsq_f32 as is (1 ulp), fp64 refines v_rsq_f64 twice
+__device__ inline float chain_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ inline double chain_rsqrt(double x) { return fast_rsqrt(x); }
+
+// Panel kernel.  What bounds it is the dependent chain of the 64 columns, not flops, so the chain runs on a
+// dedicated wave with one-step lookahead and everything else is kept off it:
+//   wave 0  (factor wave; lane = row i of the L block and column i of the X block): per 4-column micro-panel it
+//           takes the micro-panel as published by the workers (updated through micro-panel s-1), applies the
+//           update of micro-panel s itself, factors the 4x4 diagonal block in registers, finishes its row of L
+//           (y <- y L4^-T) and its column of X (z <- L4^-1 x) and publishes both;
+//   waves 1-4 (workers; 16x16 lanes, a register-resident 4x4 patch of each 64x64 block per lane) apply the
+//           rank-4 update of micro-panel s to all patches and publish micro-panel s+2 -- concurrently with the
+//           factor wave working on s+1.  ONE workgroup barrier per micro-panel (16 per 64 columns).
+// Every workgroup factors the diagonal block redundantly; workgroup b then owns X = its 64-row block of
+// [S ; HP'] (b = 0: the diagonal block itself).
 template <typename T>
-__global__ __launch_bounds__(256) void k_chol_panel(T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb,
+__global__ __launch_bounds__(320) void k_chol_panel(T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb,
                                                     int32_t *__restrict__ status)
 {
     PROBE_STAMP(0);
+    constexpr int MB = 4, NMP = NB / MB;
+    typedef T v4_t __attribute__((ext_vector_type(4)));
     __shared__ T Ls[NB][NB + 1];
-    __shared__ T Xs[NB][NB + 1];      // Xs[a][i]
+    __shared__ T Xs[NB][NB + 1];                              // Xs[a][i]
+    __shared__ __attribute__((aligned(16))) T Pn[2][NB][MB];  // published micro-panel columns: Pn[par][i][t] = A[i][C+t]
+    __shared__ __attribute__((aligned(16))) T Yb[2][NB][MB];  // final L[i][C+t]
+    __shared__ __attribute__((aligned(16))) T Zt[2][NB][MB];  // final X[C+t][i]
+    __shared__ __attribute__((aligned(16))) T Xr[2][MB][NB];  // published rows of X
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     const int nS = nrb - J - 1;
     const bool isW = b > nS;
     const int c0 = isW ? (b - nS - 1) * NB : 0;
-    {
+    const bool worker = tid >= 64;
+    const int wt = tid - 64;                                  // worker lane id 0..255
+    if (worker) {
         // all 32 global loads of the two blocks are issued before the first LDS store
         T ga[16], gx[16];
-        const int lr = tid >> 6, lc = tid & 63;
+        const int lr = wt >> 6, lc = wt & 63;
 #pragma unroll
         for (int t = 0; t < 16; ++t) ga[t] = S[(size_t)(J * NB + lr + 4 * t) * lds + J * NB + lc];
         if (b >= 1) {
@@ -161,160 +192,152 @@ __global__ __launch_bounds__(256) void k_chol_panel(T *__restrict__ S, int lds, 
         }
     }
     __syncthreads();
-    // Right-looking sweep in 8-column micro-panels, two barriers per micro-panel (16 per 64 columns instead of
-    // one per column): the dependent chain of the factorisation is what bounds this kernel, not its flops.
-    //   publish : owners copy the micro-panel's 8 columns of L (rows >= C0) and 8 rows of X into LDS
-    //   phase 1 : wave 0, lane = row i: factor the 8x8 diagonal block in registers (redundantly), solve the
-    //             lane's row  y <- y L8^-T  -> final L[i][C0..C0+7];  wave 1, lane = column of X: z <- L8^-1 x
-    //   phase 2 : all lanes apply the rank-8 update to their register-resident 4x4 patches of L and X
-    __shared__ __attribute__((aligned(16))) T Pn[NB][8];     // micro-panel columns, Pn[i][t] = A[i][C0+t]
-    __shared__ __attribute__((aligned(16))) T Yb[NB][8];     // final L[i][C0+t]
-    __shared__ __attribute__((aligned(16))) T Zt[NB][8];     // final X[C0+t][i]  (transposed: Zt[i][t])
-    __shared__ T Xr[8][NB];                                  // published rows of X
-    const int tr = tid >> 4, tc = tid & 15;
-    T lv[4][4], xs[4][4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            lv[p][q] = Ls[tr + 16 * p][tc + 16 * q];
-            xs[p][q] = b >= 1 ? Xs[tr + 16 * p][tc + 16 * q] : (T)0;      // xs: row = panel column index a, col = i
-        }
-    bool bad = false;
     PROBE_STAMP(1);
-#ifdef PRE3_PROBE
-    if (threadIdx.x == 0 && blockIdx.x == 0) { g_probe[4] = g_probe[5] = g_probe[6] = 0; }
-#endif
-    for (int s8 = 0; s8 < NB / 8; ++s8) {
-#ifdef PRE3_PROBE
-        unsigned long long tA = __builtin_amdgcn_s_memtime();
-#endif
-        const int C0 = 8 * s8, hq = C0 >> 4, half = (C0 >> 3) & 1;
-        if ((tc >> 3) == half) {
-            const int t = tc & 7;
+    const int tr = (wt >> 4) & 15, tc = wt & 15;
+    T lv[4][4], xs[4][4];
+    if (worker) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) Pn[tr + 16 * p][t] = hq == 0 ? lv[p][0] : hq == 1 ? lv[p][1] : hq == 2 ? lv[p][2] : lv[p][3];
-        }
-        if (b >= 1 && (tr >> 3) == half) {
-            const int t = tr & 7;
+        for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) Xr[t][tc + 16 * q] = hq == 0 ? xs[0][q] : hq == 1 ? xs[1][q] : hq == 2 ? xs[2][q] : xs[3][q];
-        }
-        __syncthreads();
-        PROBE_ACC(4, tA);
-#ifdef PRE3_PROBE
-        unsigned long long tB = __builtin_amdgcn_s_memtime();
-#endif
-        if (tid < 128 && (tid < 64 || b >= 1)) {
-            // 8x8 diagonal block (lower) -> L8, inverse diagonal
-            T d[8][8], invd[8];
-            typedef T vrow_t __attribute__((ext_vector_type(8)));
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const vrow_t rowv = *reinterpret_cast<const vrow_t *>(&Pn[C0 + u][0]);
-#pragma unroll
-                for (int v = 0; v <= u; ++v) d[u][v] = rowv[v];
+            for (int q = 0; q < 4; ++q) {
+                lv[p][q] = Ls[tr + 16 * p][tc + 16 * q];
+                xs[p][q] = b >= 1 ? Xs[tr + 16 * p][tc + 16 * q] : (T)0;      // xs: row = panel column index a, col = i
             }
+    }
+    bool bad = false;
+    T yprev[MB] = { 0, 0, 0, 0 }, zprev[MB] = { 0, 0, 0, 0 };     // factor wave: its row of Y(s) / column of Z(s)
+    // Software pipeline over micro-panels; iteration mp: workers apply micro-panel mp and publish mp+2, the factor
+    // wave works on mp+1.  The two lead-in iterations (mp = -2, -1) only publish / factor.  (Written as one
+    // straight-line body -- no lambdas -- so that the register patches stay in VGPRs.)
+    for (int mp = -2; mp < NMP; ++mp) {
+        if (worker) {
+            if (mp >= 0) {
+                const int C = MB * mp, par = mp & 1;
+                T Yi[4][MB], Yj[4][MB];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                T piv = d[c][c];
-                if (!(piv > (T)0)) { bad = true; piv = (T)1; }
-                invd[c] = fast_rsqrt(piv);
-                d[c][c] = piv * invd[c];
+                for (int p = 0; p < 4; ++p) {
+                    const v4_t a4 = *reinterpret_cast<const v4_t *>(&Yb[par][tr + 16 * p][0]);
+                    const v4_t b4 = *reinterpret_cast<const v4_t *>(&Yb[par][tc + 16 * p][0]);
 #pragma unroll
-                for (int u = c + 1; u < 8; ++u) d[u][c] *= invd[c];
-#pragma unroll
-                for (int u = c + 1; u < 8; ++u)
-#pragma unroll
-                    for (int v = c + 1; v <= u; ++v) d[u][v] -= d[u][c] * d[v][c];
-            }
-            if (tid < 64) {
-                const int i = tid;
-                if (i >= C0) {
-                    T y[8];
-                    {
-                        const vrow_t rowv = *reinterpret_cast<const vrow_t *>(&Pn[i][0]);
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) y[t] = rowv[t];
-                    }
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        T acc = y[t];
-#pragma unroll
-                        for (int u = 0; u < t; ++u) acc -= y[u] * d[t][u];
-                        y[t] = acc * invd[t];
-                    }
-                    if (i < C0 + 8) {        // rows of the diagonal block: exact factor entries, zeros above
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) y[t] = (t <= i - C0) ? y[t] : (T)0;
-                    }
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) { Yb[i][t] = y[t]; Ls[i][C0 + t] = y[t]; }
+                    for (int t = 0; t < MB; ++t) { Yi[p][t] = a4[t]; Yj[p][t] = b4[t]; }
                 }
-            } else {
-                const int ii = tid - 64;
-                T z[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) z[t] = Xr[t][ii];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    T acc = z[t];
-#pragma unroll
-                    for (int u = 0; u < t; ++u) acc -= d[t][u] * z[u];
-                    z[t] = acc * invd[t];
-                }
-#pragma unroll
-                for (int t = 0; t < 8; ++t) { Zt[ii][t] = z[t]; Xs[C0 + t][ii] = z[t]; }
-            }
-        }
-        __syncthreads();
-        PROBE_ACC(5, tB);
-#ifdef PRE3_PROBE
-        unsigned long long tC = __builtin_amdgcn_s_memtime();
-#endif
-        {
-            T Yi[4][8], Yj[4][8];
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-#pragma unroll
-                for (int t = 0; t < 8; ++t) { Yi[p][t] = Yb[tr + 16 * p][t]; Yj[p][t] = Yb[tc + 16 * p][t]; }
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int i = tr + 16 * p, j = tc + 16 * q;
-                    if (j >= C0 + 8 && j <= i) {
-                        T acc = lv[p][q];
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) acc -= Yi[p][t] * Yj[q][t];
-                        lv[p][q] = acc;
-                    }
-                }
-            if (b >= 1) {
-                T Zc[4][8];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) Zc[q][t] = Zt[tc + 16 * q][t];
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (tr + 16 * p >= C0 + 8) {
-                            T acc = xs[p][q];
+                    for (int q = 0; q < 4; ++q) {
+                        const int i = tr + 16 * p, j = tc + 16 * q;
+                        if (j >= C + MB && j <= i) {
+                            T acc = lv[p][q];
 #pragma unroll
-                            for (int t = 0; t < 8; ++t) acc -= Yi[p][t] * Zc[q][t];
-                            xs[p][q] = acc;
+                            for (int t = 0; t < MB; ++t) acc -= Yi[p][t] * Yj[q][t];
+                            lv[p][q] = acc;
                         }
+                    }
+                if (b >= 1) {
+                    T Zc[4][MB];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const v4_t z4 = *reinterpret_cast<const v4_t *>(&Zt[par][tc + 16 * q][0]);
+#pragma unroll
+                        for (int t = 0; t < MB; ++t) Zc[q][t] = z4[t];
+                    }
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (tr + 16 * p >= C + MB) {
+                                T acc = xs[p][q];
+#pragma unroll
+                                for (int t = 0; t < MB; ++t) acc -= Yi[p][t] * Zc[q][t];
+                                xs[p][q] = acc;
+                            }
+                }
+            }
+            if (mp + 2 < NMP) {
+                // publish micro-panel mp+2: columns C..C+3 of L (all rows) and rows C..C+3 of X, from the patches
+                const int C = MB * (mp + 2), par = (mp + 2) & 1, hq = C >> 4, grp = (C >> 2) & 3;
+                if ((tc >> 2) == grp) {
+                    const int t = tc & 3;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) Pn[par][tr + 16 * p][t] = hq == 0 ? lv[p][0] : hq == 1 ? lv[p][1] : hq == 2 ? lv[p][2] : lv[p][3];
+                }
+                if (b >= 1 && (tr >> 2) == grp) {
+                    const int t = tr & 3;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Xr[par][t][tc + 16 * q] = hq == 0 ? xs[0][q] : hq == 1 ? xs[1][q] : hq == 2 ? xs[2][q] : xs[3][q];
+                }
+            }
+        } else if (mp + 1 >= 0 && mp + 1 < NMP) {
+            // factor wave, micro-panel mp+1
+            const int fm = mp + 1, C = MB * fm, par = fm & 1, i = tid;
+            T pr[MB], xr[MB];
+            {
+                const v4_t v = *reinterpret_cast<const v4_t *>(&Pn[par][i][0]);
+#pragma unroll
+                for (int t = 0; t < MB; ++t) pr[t] = v[t];
+            }
+#pragma unroll
+            for (int t = 0; t < MB; ++t) xr[t] = b >= 1 ? Xr[par][t][i] : (T)0;
+            if (fm > 0) {
+                // lookahead: the published values carry the updates of micro-panels < fm-1; apply micro-panel fm-1
+                // here.  L[C+t][C-4+u] is lane C+t's own yprev[u]: wave-uniform lane reads, no LDS.
+#pragma unroll
+                for (int t = 0; t < MB; ++t)
+#pragma unroll
+                    for (int u = 0; u < MB; ++u) {
+                        const T l = rdlane(yprev[u], C + t);
+                        pr[t] -= yprev[u] * l; xr[t] -= l * zprev[u];
+                    }
+            }
+            // the 4x4 diagonal block = rows C..C+3 of the updated micro-panel, i.e. lanes C..C+3
+            T d[MB][MB], rs[MB];
+#pragma unroll
+            for (int u = 0; u < MB; ++u)
+#pragma unroll
+                for (int w2 = 0; w2 <= u; ++w2) d[u][w2] = rdlane(pr[w2], C + u);
+#pragma unroll
+            for (int c = 0; c < MB; ++c) {
+                T piv = d[c][c];
+                if (!(piv > (T)0)) { bad = true; piv = (T)1; }
+                rs[c] = chain_rsqrt(piv);
+#pragma unroll
+                for (int u = c + 1; u < MB; ++u) d[u][c] *= rs[c];
+#pragma unroll
+                for (int u = c + 1; u < MB; ++u)
+#pragma unroll
+                    for (int w2 = c + 1; w2 <= u; ++w2) d[u][w2] -= d[u][c] * d[w2][c];
+            }
+            // row of L: y <- y L4^-T ; column of X: z <- L4^-1 x   (entries u < t are already this micro-panel's)
+#pragma unroll
+            for (int t = 0; t < MB; ++t) {
+                T ay = pr[t], az = xr[t];
+#pragma unroll
+                for (int u = 0; u < t; ++u) { ay -= yprev[u] * d[t][u]; az -= d[t][u] * zprev[u]; }
+                yprev[t] = ay * rs[t];
+                zprev[t] = az * rs[t];
+            }
+            if (i < C + MB) {          // rows of the diagonal block: entries right of the diagonal are zero
+#pragma unroll
+                for (int t = 0; t < MB; ++t) if (t > i - C) yprev[t] = (T)0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            *reinterpret_cast<v4_t *>(&Yb[par][i][0]) = v4_t{ yprev[0], yprev[1], yprev[2], yprev[3] };
+            if (i >= C) {
+#pragma unroll
+                for (int t = 0; t < MB; ++t) Ls[i][C + t] = yprev[t];
+            }
+            if (b >= 1) {
+                *reinterpret_cast<v4_t *>(&Zt[par][i][0]) = v4_t{ zprev[0], zprev[1], zprev[2], zprev[3] };
+#pragma unroll
+                for (int t = 0; t < MB; ++t) Xs[C + t][i] = zprev[t];
             }
         }
-        PROBE_ACC(6, tC);
+        __syncthreads();
     }
-    __syncthreads();
     PROBE_STAMP(2);
     if (bad && tid == 0 && b == 0) atomicExch(status, 1);
     if (b == 0) {
-        for (int idx = tid; idx < NB * NB; idx += 256) {
+        for (int idx = tid; idx < NB * NB; idx += 320) {
             int i = idx >> 6, a2 = idx & 63;
             S[(size_t)(J * NB + i) * lds + J * NB + a2] = a2 <= i ? Ls[i][a2] : (T)0;
         }
@@ -322,12 +345,12 @@ __global__ __launch_bounds__(256) void k_chol_panel(T *__restrict__ S, int lds, 
     }
     if (!isW) {
         int rb = J + b;
-        for (int idx = tid; idx < NB * NB; idx += 256) {
+        for (int idx = tid; idx < NB * NB; idx += 320) {
             int i = idx >> 6, a2 = idx & 63;
             S[(size_t)(rb * NB + i) * lds + J * NB + a2] = Xs[a2][i];
         }
     } else {
-        for (int idx = tid; idx < NB * NB; idx += 256) {
+        for (int idx = tid; idx < NB * NB; idx += 320) {
             int a2 = idx >> 6, i = idx & 63;
             W[(size_t)(J * NB + a2) * ldw + c0 + i] = Xs[a2][i];
         }
@@ -650,10 +673,10 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad)
     int nrb = r_pad / NB, nW = c->ldw / NB;
     for (int J = 0; J < nrb; ++J) {
         int nS = nrb - J - 1;
-        dim3 gA(1 + nS + nW), b(256);
+        dim3 gA(1 + nS + nW), b(256), bP(320);
         DISPATCH_T(c,
-            hipLaunchKernelGGL(k_chol_panel<double>, gA, b, 0, c->stream, (double *)c->Smat, r_pad, (double *)c->W, c->ldw, J, nrb, c->stats + 6),
-            hipLaunchKernelGGL(k_chol_panel<float>, gA, b, 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J, nrb, c->stats + 6));
+            hipLaunchKernelGGL(k_chol_panel<double>, gA, bP, 0, c->stream, (double *)c->Smat, r_pad, (double *)c->W, c->ldw, J, nrb, c->stats + 6),
+            hipLaunchKernelGGL(k_chol_panel<float>, gA, bP, 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J, nrb, c->stats + 6));
         if (nS > 0) {
             dim3 gB(nS * (nS + 1) / 2 + nS * nW);
             DISPATCH_T(c,

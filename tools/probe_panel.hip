@@ -52,18 +52,18 @@ int main()
     float ms;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(k_chol_panel<float>, dim3(1 + (nrb - 1) + nW), dim3(256), 0, 0, S, r_pad, W, ldw, 0, nrb, status);
+        hipLaunchKernelGGL(k_chol_panel<float>, dim3(1 + (nrb - 1) + nW), dim3(320), 0, 0, S, r_pad, W, ldw, 0, nrb, status);
         hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
         printf("k_chol_panel J=0 (59 WGs): %.1f us\n", ms * 1e3);
         hipMemcpy(S, hS.data(), hS.size() * 4, hipMemcpyHostToDevice);
     }
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(k_chol_panel<float>, dim3(1), dim3(256), 0, 0, S, r_pad, W, ldw, 0, nrb, status);
+        hipLaunchKernelGGL(k_chol_panel<float>, dim3(1), dim3(320), 0, 0, S, r_pad, W, ldw, 0, nrb, status);
         hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
         printf("k_chol_panel diag only (1 WG): %.1f us\n", ms * 1e3);
         { unsigned long long g[16]; hipMemcpyFromSymbol(g, HIP_SYMBOL(pre3::g_probe), sizeof g);
-          printf("   cycles: load %llu, loop %llu (publish+barrier %llu, phase1+barrier %llu, phase2 %llu)\n", g[1]-g[0], g[2]-g[1], g[4], g[5], g[6]); }
+          printf("   cycles: load %llu, loop %llu\n", g[1]-g[0], g[2]-g[1]); }
         hipMemcpy(S, hS.data(), hS.size() * 4, hipMemcpyHostToDevice);
     }
     for (int spin : {1000, 100000}) {
