@@ -478,6 +478,28 @@ int pre3_ransac_select(pre3_ctx *c, int n_draw, int k, int early_exit, int32_t *
     return PRE3_OK;
 }
 
+int pre3_ransac_export(pre3_ctx *c, int n_draw, void *support_dst_dev, void *mask_dst_dev)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(n_draw >= 1 && n_draw <= c->caph, PRE3_E_ARG, "ransac: n_draw out of range");
+    int words = ceil_div(c->m, 32);
+    if (support_dst_dev) PRE3_HIP(hipMemcpyAsync(support_dst_dev, c->support, sizeof(int32_t) * n_draw, hipMemcpyDeviceToDevice, c->stream));
+    if (mask_dst_dev) PRE3_HIP(hipMemcpyAsync(mask_dst_dev, c->masks, sizeof(uint32_t) * (size_t)n_draw * words, hipMemcpyDeviceToDevice, c->stream));
+    PRE3_HIP(hipStreamSynchronize(c->stream));
+    return PRE3_OK;
+}
+
+int pre3_ransac_import(pre3_ctx *c, int n_draw, const void *support_src_dev, const void *mask_src_dev)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(n_draw >= 1 && n_draw <= c->caph, PRE3_E_ARG, "ransac: n_draw out of range");
+    int words = ceil_div(c->m, 32);
+    if (support_src_dev) PRE3_HIP(hipMemcpyAsync(c->support, support_src_dev, sizeof(int32_t) * n_draw, hipMemcpyDeviceToDevice, c->stream));
+    if (mask_src_dev) PRE3_HIP(hipMemcpyAsync(c->masks, mask_src_dev, sizeof(uint32_t) * (size_t)n_draw * words, hipMemcpyDeviceToDevice, c->stream));
+    PRE3_HIP(hipStreamSynchronize(c->stream));
+    return PRE3_OK;
+}
+
 int pre3_ransac(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, double threshold, int early_exit, int32_t *support, int32_t *li_mask,
                 int32_t stats[4])
 {

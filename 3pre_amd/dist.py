@@ -1,0 +1,112 @@
+"""Multi-GPU sharding of the two stages of the path that shard (DESIGN.md "multi-GPU"); one process per GPU,
+torch.distributed ("nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+  * RANSAC (C1): every rank holds the same filter state, scores hypotheses [lo, hi) of the shared draw table
+    on its GPU, and the int32 supports + inlier bitmasks (zero outside a rank's slice) are summed with ONE
+    all-reduce each (<= 8 KB + n_draw*ceil(m/32)*4 B); every rank then replays the reference's termination
+    rule on the reduced buffers and reaches the same winner.  The EKF update is not sharded.
+  * matcher (C2): the database L2 is split by columns; every rank computes (best, second, arg) of all
+    queries against its slice, one all-gather of 3*K1 numbers per rank, then the order-independent merge +
+    ratio test (pre3_siftmatch_merge) -- bit-identical to the unsharded match for any number of ranks.
+
+The compute callables are injected, so that the CPU test-suite can drive the SAME sharding / collective /
+merge code with the oracle standing in for the GPU kernels (tests/test_dist_cpu.py).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n, rank, world):
+    """contiguous slice [lo, hi) of n items for `rank` (sizes differ by at most one)"""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+# ---------------------------------------------------------------------------------------------------
+# C1: sharded RANSAC scoring
+# ---------------------------------------------------------------------------------------------------
+def ransac_sharded(f, hyp, threshold, early_exit=True, device=None):
+    """f: EkfFilter with projection + measurements installed (identical on every rank).
+    Scores this rank's slice on the GPU, all-reduces supports and masks, selects.  Returns the same dict as
+    EkfFilter.ransac_hypotheses on every rank."""
+    rank, world = _world()
+    hyp = np.ascontiguousarray(hyp, np.int32)
+    n_draw, k = hyp.shape
+    lo, hi = shard_range(n_draw, rank, world)
+    _, _, words = f.ransac_score_shard(hyp, threshold, lo, hi)
+    if world > 1:
+        backend = dist.get_backend()
+        if backend == "nccl":
+            dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+            sup = torch.empty(n_draw, dtype=torch.int32, device=dev)
+            msk = torch.empty(n_draw * max(words, 1), dtype=torch.int32, device=dev)
+            f.ransac_export(n_draw, sup.data_ptr(), msk.data_ptr())
+            dist.all_reduce(sup, op=dist.ReduceOp.SUM)
+            dist.all_reduce(msk, op=dist.ReduceOp.SUM)      # slices are disjoint: integer sum == bitwise or
+            torch.cuda.synchronize()
+            f.ransac_import(n_draw, sup.data_ptr(), msk.data_ptr())
+        else:                                               # gloo rehearsal: stage through the host
+            sup = torch.empty(n_draw, dtype=torch.int32, device="cuda")
+            msk = torch.empty(n_draw * max(words, 1), dtype=torch.int32, device="cuda")
+            f.ransac_export(n_draw, sup.data_ptr(), msk.data_ptr())
+            sup_h, msk_h = sup.cpu(), msk.cpu()
+            dist.all_reduce(sup_h, op=dist.ReduceOp.SUM)
+            dist.all_reduce(msk_h, op=dist.ReduceOp.SUM)
+            sup.copy_(sup_h); msk.copy_(msk_h)
+            torch.cuda.synchronize()
+            f.ransac_import(n_draw, sup.data_ptr(), msk.data_ptr())
+    return f.ransac_select(n_draw, k, early_exit)
+
+
+def ransac_sharded_generic(score_slice, select, n_draw, words):
+    """The collective skeleton of ransac_sharded with injected compute (CPU tests):
+    score_slice(lo, hi) -> (support int32[n_draw] zero outside the slice, masks int32[n_draw*words]);
+    select(support, masks) -> result."""
+    rank, world = _world()
+    lo, hi = shard_range(n_draw, rank, world)
+    sup, msk = score_slice(lo, hi)
+    sup = torch.from_numpy(np.ascontiguousarray(sup, np.int32))
+    msk = torch.from_numpy(np.ascontiguousarray(msk, np.int32))
+    if world > 1:
+        dist.all_reduce(sup, op=dist.ReduceOp.SUM)
+        dist.all_reduce(msk, op=dist.ReduceOp.SUM)
+    return select(sup.numpy(), msk.numpy())
+
+
+# ---------------------------------------------------------------------------------------------------
+# C2: sharded matcher
+# ---------------------------------------------------------------------------------------------------
+def siftmatch_sharded(L1, L2, thresh=1.5, partial=None, merge=None, return_scores=False):
+    """L1 (ND x K1) replicated, L2 (ND x K2) known to every rank; rank g matches against columns
+    shard_range(K2, g, G).  partial(L1, L2_slice, offset) -> (best, second, arg); merge(dtype, B, S, A, thresh).
+    Defaults are the GPU kernels of this package."""
+    if partial is None or merge is None:
+        from . import matcher
+        partial = partial or matcher.siftmatch_partial
+        merge = merge or (lambda dt, B, S, A, th: matcher.siftmatch_merge(dt, B, S, A, th, return_scores=True))
+    rank, world = _world()
+    L1, L2 = np.asarray(L1), np.asarray(L2)
+    K1 = L1.shape[1]
+    lo, hi = shard_range(L2.shape[1], rank, world)
+    b, s, a = partial(L1, L2[:, lo:hi], lo)
+    pack = torch.from_numpy(np.concatenate([np.asarray(b, np.float64), np.asarray(s, np.float64), np.asarray(a, np.float64)]))
+    if world > 1:
+        use_cuda = dist.get_backend() == "nccl"
+        if use_cuda:
+            pack = pack.cuda()
+        out = [torch.empty_like(pack) for _ in range(world)]
+        dist.all_gather(out, pack)
+        allp = torch.stack(out).cpu().numpy()
+    else:
+        allp = pack.numpy()[None, :]
+    B, S, A = allp[:, :K1], allp[:, K1:2 * K1], allp[:, 2 * K1:].astype(np.int32)
+    m, d = merge(L1.dtype, B, S, A, thresh)
+    return (m, d) if return_scores else m

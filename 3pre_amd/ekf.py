@@ -148,6 +148,12 @@ class EkfFilter:
         check(lib.pre3_ransac_select(self._ctx, int(n_draw), int(k), int(bool(early_exit)), dptr(sup), dptr(li), dptr(st)))
         return dict(support=sup, li_mask=li[:self.m], best=int(st[0]), iters=int(st[1]), n_hyp=int(st[2]), max_support=int(st[3]))
 
+    def ransac_export(self, n_draw, support_ptr, mask_ptr):
+        check(lib.pre3_ransac_export(self._ctx, int(n_draw), C.c_void_p(support_ptr), C.c_void_p(mask_ptr)))
+
+    def ransac_import(self, n_draw, support_ptr, mask_ptr):
+        check(lib.pre3_ransac_import(self._ctx, int(n_draw), C.c_void_p(support_ptr), C.c_void_p(mask_ptr)))
+
     def ekf_update_li_inliers(self):
         check(lib.pre3_update_li(self._ctx))
 

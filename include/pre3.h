@@ -124,6 +124,11 @@ PRE3_API int pre3_ransac_score(pre3_ctx *ctx, int n_draw, int k, const int32_t *
                                int hyp_begin, int hyp_end, void **support_dev, void **mask_dev, int *mask_words);
 PRE3_API int pre3_ransac_select(pre3_ctx *ctx, int n_draw, int k, int early_exit,
                                 int32_t *support, int32_t *li_mask, int32_t stats[4]);
+/* Copy the context's support / mask buffers to (export) or from (import) caller-owned DEVICE buffers of
+ * int32[n_draw] and uint32[n_draw*mask_words] -- e.g. torch tensors handed to an RCCL all-reduce.  Either
+ * pointer may be NULL.  Synchronous on return. */
+PRE3_API int pre3_ransac_export(pre3_ctx *ctx, int n_draw, void *support_dst_dev, void *mask_dst_dev);
+PRE3_API int pre3_ransac_import(pre3_ctx *ctx, int n_draw, const void *support_src_dev, const void *mask_src_dev);
 
 /* ---- a9: update.m:27-56 via the @ekf_filter wrappers --------------------------------------------- */
 /* ekf_update_li_inliers.m:45-58: prior (x_k_km1,p_k_km1), rows = low-innovation inliers */
