@@ -58,6 +58,66 @@ def cpu_baseline(seq, n_steps, threshold):
                       "fp64, all hypotheses evaluated)" % (done, N, seq["steps"][0]["hyp"].shape[0])}
 
 
+def ransac_shard_leg(pre3, synth, dist, rank, world, local_rank, N=2000, n_hyp=1000, reps=10):
+    """BASELINE.json configs[4]: N=2000 landmarks (n=12013), 1000 hypotheses sharded over the ranks with an RCCL
+    all-reduce of supports + inlier masks (3pre_amd/dist.ransac_sharded); state replicated.  Whole-job
+    hypotheses/s at this number of GPUs (the all-reduce and the replay are inside the timed region)."""
+    import torch
+    pd = importlib.import_module("3pre_amd.dist")
+    seq = synth.make_sequence(N, 1, n_hyp)              # same seed on every rank: identical replicas
+    s = seq["steps"][0]
+    f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", device=local_rank, max_hyp=n_hyp)
+    try:
+        f.set_x_p_k_k(seq["x0"], seq["P0"])
+        f.ekf_prediction(s["u"])
+        f.search_IC_matches()
+        f.set_measurements(s["meas_idx"], s["z"])
+        for _ in range(2):
+            out = pd.ransac_sharded(f, s["hyp"], 1.0, early_exit=False)
+        f.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = pd.ransac_sharded(f, s["hyp"], 1.0, early_exit=False)
+        f.sync()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+            t = torch.tensor([el], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return {"workload": "configs[4]: N=%d (n=%d), %d hypotheses (k=3), m=%d measured, f32; per round: H*P and H*P*H' gathers, "
+                            "sharded scoring, all-reduce, replay" % (N, seq["n"], n_hyp, len(s["meas_idx"])),
+                "value": reps * n_hyp / el, "unit": "hypotheses/s", "n_gpus": world, "ms_per_round": 1e3 * el / reps,
+                "max_support": int(out["max_support"]), "scaling": "strong"}
+    finally:
+        f.close()
+
+
+def matcher_leg(pre3, reps=20):
+    """BASELINE.json configs[3]: 4096 x 4096 x 128 uint8 descriptors, int8-MFMA distance kernel + fused
+    best/second-best scan, inputs resident in HBM (kernel time, HIP events)."""
+    import ctypes as C
+    rng = np.random.default_rng(5000)
+    K = 4096
+    L1 = np.minimum(np.round(np.abs(rng.standard_normal((K, 128))) * 40), 255).astype(np.uint8)
+    L2 = np.clip(L1[rng.permutation(K)].astype(int) + rng.integers(-2, 3, (K, 128)), 0, 255).astype(np.uint8)
+    lib = pre3._lib.lib
+    h = lib.pre3_match_bench_create(0, 128, K, L1.ctypes.data_as(C.c_void_p), K, L2.ctypes.data_as(C.c_void_p))
+    if not h:
+        return None
+    ms = C.c_double(0)
+    rc = lib.pre3_match_bench_run(C.c_void_p(h), reps, C.byref(ms))
+    lib.pre3_match_bench_destroy(C.c_void_p(h))
+    if rc != 0:
+        return None
+    return {"workload": "configs[3]: 4096x4096x128 uint8, 1 GPU", "ms_per_match": ms.value, "pairs_per_s": K * K / (ms.value * 1e-3),
+            "int8_mfma_TOPS": 2.0 * K * K * 128 / (ms.value * 1e-3) / 1e12}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,6 +128,7 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the sharded-RANSAC and matcher legs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,6 +181,14 @@ def main():
         n_li = float(np.mean([s["n_li"] for s in stats]))
         n_hi = float(np.mean([s["n_hi"] for s in stats]))
         achieved = kt["flops"] / (kt["total_ms"] * 1e-3) / 1e12 if kt["total_ms"] > 0 else 0.0
+        traffic, traffic_src = None, None
+        try:    # HBM bytes per LI launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
+            with open(os.path.join(ROOT, "profiles", "r1_pmc_k9.json")) as fh:
+                pj = json.load(fh)
+            traffic = pj["hbm_bytes_per_li_launch"]["raw"]
+            traffic_src = "profiles/r1_pmc_k9.json (raw FETCH_SIZE+WRITE_SIZE of the r=640 launches; FETCH_SIZE under-reports 16 B/lane reads by up to 2x on gfx950)"
+        except Exception:
+            pass
         out = {
             "metric": "EKF steps/sec (predict+RANSAC+update) at N=500 landmarks; P-update %MFMA peak",
             "value": world * K / elapsed, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -131,13 +200,30 @@ def main():
                        "mean_li_rows": 2 * n_li, "mean_hi_rows": 2 * n_hi, "parallelism": "replicas x%d" % world,
                        "hip_event_ms_per_step": ev_ms / K},
             "roofline": {"kernel": "k_downdate (K9: P <- P - W'W)", "bound": "mfma", "achieved": achieved, "peak": PEAK[args.dtype],
-                         "unit": "TFLOP/s", "frac": achieved / PEAK[args.dtype], "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK[args.dtype], "traffic": traffic, "traffic_source": traffic_src,
                          "launches": kt["launches"], "avg_launch_us": 1e3 * kt["total_ms"] / max(kt["launches"], 1),
-                         "algorithmic": "2*n^2*r flop per launch (SURVEY 8d), r = rows of that update"},
+                         "algorithmic": "symmetric rank-r down-date (SYRK): n(n+1)r flop per launch, r = rows of that update, averaged over "
+                                        "ALL K9 launches of the timed region (LI updates with r~640 and HI updates with r<=64); "
+                                        "SURVEY 8(d)'s un-halved convention 2n^2r gives twice this figure",
+                         "survey_2n2r_equivalent": 2.0 * achieved * n / (n + 1.0)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(seq, args.cpu_steps, thr)
     f.close()
+    # secondary legs (never allowed to break the headline line): sharded RANSAC at every N, matcher at N=1
+    if not args.no_extra_legs:
+        try:
+            leg = ransac_shard_leg(pre3, synth, dist, rank, world, local_rank)
+            if rank == 0:
+                out["ransac_shard"] = leg
+        except Exception as e:                                  # pragma: no cover
+            if rank == 0:
+                out["ransac_shard"] = {"error": repr(e)[:300]}
+        if world == 1:
+            try:
+                out["matcher"] = matcher_leg(pre3)
+            except Exception as e:                              # pragma: no cover
+                out["matcher"] = {"error": repr(e)[:300]}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
