@@ -174,6 +174,15 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
         for (int x = 0; x < 8; ++x) { for (size_t k2 = 0; k2 < lists[x].size(); ++k2) flat[x * mx + k2] = lists[x][k2]; total += cnts[x]; }
         c->tiles_stride = (int)mx;
         c->n_tiles = total;
+        {
+            std::vector<int2> inter;                  // interleave: block b takes the next tile of list b % 8
+            size_t pos[8] = { 0 };
+            while ((int)inter.size() < total)
+                for (int x = 0; x < 8 && (int)inter.size() < total; ++x)
+                    if (pos[x] < lists[x].size()) inter.push_back(lists[x][pos[x]++]);
+            A(dmalloc_bytes(&c->tiles_flat, sizeof(int2) * (inter.size() ? inter.size() : 1)));
+            if (rc == PRE3_OK && hipMemcpy(c->tiles_flat, inter.data(), sizeof(int2) * inter.size(), hipMemcpyHostToDevice) != hipSuccess) { set_error("tile table upload failed"); rc = PRE3_E_HIP; }
+        }
         A(dmalloc(&c->tile_ctr, 8)); A(dmalloc(&c->tile_cnt, 8));
         if (rc == PRE3_OK) { (void)hipMemset(c->tile_ctr, 0, sizeof(unsigned int) * 8); (void)hipMemcpy(c->tile_cnt, cnts, sizeof(cnts), hipMemcpyHostToDevice); }
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) c->num_cus = pr.multiProcessorCount; }
@@ -202,7 +211,7 @@ int pre3_destroy(pre3_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
                      c->lm.li, c->lm.hi, c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
-                     c->sel_rows, c->support, c->masks, c->stats, c->li_meas, c->hi_meas, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt };
+                     c->sel_rows, c->support, c->masks, c->stats, c->li_meas, c->hi_meas, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->pinned_stats) (void)hipHostFree(c->pinned_stats);
     if (c->inbox_host) (void)hipHostFree(c->inbox_host);

@@ -75,6 +75,7 @@ struct pre3_ctx {
     void *P = nullptr;                            // [ld*ld] T
     void *tiles = nullptr;                        // int2[n_tiles]: (I,J) of every 64x64 upper-triangle tile, XCD-aware order
     int n_tiles = 0;
+    void *tiles_flat = nullptr;                   // int2[n_tiles]: the 8 lists interleaved (block b -> list b % 8) for the one-tile kernel
     unsigned int *tile_ctr = nullptr;             // device ticket counter of the persistent K9 grid
     int *tile_cnt = nullptr; int tiles_stride = 0;  // per-list lengths [8] and list stride
     bool tile_ctr_clean = false;                  // the 8 counters are zero (k_update_x resets them ahead of K9)

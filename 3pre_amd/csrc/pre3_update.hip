@@ -113,6 +113,8 @@ __device__ inline double fast_rsqrt(double x)
 
 #ifdef PRE3_PROBE
 __device__ unsigned long long g_probe[16];
+__device__ unsigned long long g_k9[64 * 8 * 4];
+__device__ unsigned long long g_k9rt[2048 * 4];     // s_memrealtime (100 MHz, chip-wide) per workgroup of the one-tile kernel
 #define PROBE_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_probe[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #define PROBE_ACC(k, t0) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_probe[k] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
 #else
@@ -527,44 +529,56 @@ __global__ __launch_bounds__(256) void k_downdate(T *__restrict__ P, int ld, con
         const unsigned int t = atomicAdd(&ctr[x], 1u);
         return t < (unsigned int)tile_cnt[x] ? (unsigned int)(x * tiles_stride) + t : 0xffffffffu;
     };
-    if (tid == 0) s_tile = next_ticket();
-    for (;;) {
-        __syncthreads();                       // ticket visible; previous tile's patch reads fenced against new staging
-        const unsigned int t = s_tile;
-        if (t == 0xffffffffu) return;          // uniform exit: every wave of the workgroup leaves together
-        const int2 ij = tiles[t];
-        const int I0 = ij.x * TS, J0 = ij.y * TS;
-
-        vec_t ra[NLD], rb[NLD];
-        auto gload = [&](int k0) {
+    vec_t ra[NLD], rb[NLD];
+    auto gload = [&](int I0_, int J0_, int k0) __attribute__((always_inline)) {
 #pragma unroll
-            for (int l = 0; l < NLD; ++l) {
-                int v = tid + l * 256;
-                int kr = v / ROWV, cv = (v % ROWV) * VEC;
-                ra[l] = *reinterpret_cast<const vec_t *>(W + (size_t)(k0 + kr) * ldw + I0 + cv);
-                rb[l] = *reinterpret_cast<const vec_t *>(W + (size_t)(k0 + kr) * ldw + J0 + cv);
-            }
-        };
-        auto sstore = [&](int buf) {
+        for (int l = 0; l < NLD; ++l) {
+            int v = tid + l * 256;
+            int kr = v / ROWV, cv = (v % ROWV) * VEC;
+            ra[l] = *reinterpret_cast<const vec_t *>(W + (size_t)(k0 + kr) * ldw + I0_ + cv);
+            rb[l] = *reinterpret_cast<const vec_t *>(W + (size_t)(k0 + kr) * ldw + J0_ + cv);
+        }
+    };
+    auto sstore = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-            for (int l = 0; l < NLD; ++l) {
-                int v = tid + l * 256;
-                int kr = v / ROWV, cv = (v % ROWV) * VEC;
-                *reinterpret_cast<vec_t *>(&sA[buf][kr][cv]) = ra[l];
-                *reinterpret_cast<vec_t *>(&sB[buf][kr][cv]) = rb[l];
-            }
-        };
-        gload(0);
-        // prefetch this lane's 16 entries of the P tile
-        T pv[NBLK][NBLK][M::NREG];
+        for (int l = 0; l < NLD; ++l) {
+            int v = tid + l * 256;
+            int kr = v / ROWV, cv = (v % ROWV) * VEC;
+            *reinterpret_cast<vec_t *>(&sA[buf][kr][cv]) = ra[l];
+            *reinterpret_cast<vec_t *>(&sB[buf][kr][cv]) = rb[l];
+        }
+    };
+    // this lane's 16 entries of a P tile (accumulator layout)
+    auto pload = [&](T (&dst)[NBLK][NBLK][M::NREG], int I0_, int J0_) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < NBLK; ++p)
 #pragma unroll
             for (int q = 0; q < NBLK; ++q)
 #pragma unroll
                 for (int e = 0; e < M::NREG; ++e)
-                    pv[p][q][e] = P[(size_t)(I0 + wi * 32 + p * M::BLK + M::row(lane, e)) * ld + J0 + wj * 32 + q * M::BLK + M::col(lane)];
+                    dst[p][q][e] = P[(size_t)(I0_ + wi * 32 + p * M::BLK + M::row(lane, e)) * ld + J0_ + wj * 32 + q * M::BLK + M::col(lane)];
+    };
 
+#ifdef PRE3_PROBE
+    if (tid == 0 && blockIdx.x == 0) { g_probe[8] = __builtin_amdgcn_s_memtime(); g_probe[9] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    if (tid == 0) s_tile = next_ticket();
+    __syncthreads();
+    unsigned int t = s_tile;
+    if (t == 0xffffffffu) return;              // uniform: every wave of the workgroup leaves together
+    int2 ij = tiles[t];
+    T pv[NBLK][NBLK][M::NREG];
+    gload(ij.x * TS, ij.y * TS, 0);
+    pload(pv, ij.x * TS, ij.y * TS);
+#ifdef PRE3_PROBE
+    int probe_tile = 0;
+#define K9_STAMP(k) do { if (tid == 0 && blockIdx.x < 64 && probe_tile < 8) g_k9[(blockIdx.x * 8 + probe_tile) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define K9_STAMP(k)
+#endif
+    for (;;) {
+        K9_STAMP(0);
+        const int I0 = ij.x * TS, J0 = ij.y * TS;
         typename M::acc_t acc[NBLK][NBLK];
 #pragma unroll
         for (int p = 0; p < NBLK; ++p)
@@ -575,9 +589,10 @@ __global__ __launch_bounds__(256) void k_downdate(T *__restrict__ P, int ld, con
 
         sstore(0);
         __syncthreads();
+        K9_STAMP(1);
         for (int s = 0; s < nstage; ++s) {
             const int buf = s & 1;
-            if (s + 1 < nstage) gload((s + 1) * BK);
+            if (s + 1 < nstage) gload(I0, J0, (s + 1) * BK);
             else if (tid == 0) s_tile = next_ticket();     // no loads behind it: its latency hides under the last stage
             // all operand fragments of the stage are read from LDS up front (registers are plentiful), so the
             // MFMAs issue back to back behind counted lgkmcnt waits instead of one LDS round trip per pair
@@ -599,6 +614,18 @@ __global__ __launch_bounds__(256) void k_downdate(T *__restrict__ P, int ld, con
                     for (int q = 0; q < NBLK; ++q) M::mma(av[ks][p], bv[ks][q], acc[p][q]);
             if (s + 1 < nstage) sstore(buf ^ 1);
             __syncthreads();
+        }
+        K9_STAMP(2);
+        // ---- cross-tile prefetch: the next ticket is visible (barrier above); start its first stage and its P tile
+        //      now, so their HBM/L2 latency overlaps this tile's epilogue instead of leaving the matrix cores idle
+        const unsigned int tn = s_tile;
+        const bool has_next = tn != 0xffffffffu;
+        int2 ijn = ij;
+        T pvn[NBLK][NBLK][M::NREG];
+        if (has_next) {
+            ijn = tiles[tn];
+            gload(ijn.x * TS, ijn.y * TS, 0);
+            pload(pvn, ijn.x * TS, ijn.y * TS);
         }
         // ---- epilogue (the staging buffers are dead: each wave owns a private [32][33] patch of them)
         const bool mirror = ij.x != ij.y;
@@ -623,7 +650,165 @@ __global__ __launch_bounds__(256) void k_downdate(T *__restrict__ P, int ld, con
                 P[(size_t)(J0 + wj * 32 + c) * ld + I0 + wi * 32 + rr] = patch[rr][c];
             }
         }
+        K9_STAMP(3);
+#ifdef PRE3_PROBE
+        ++probe_tile;
+        if (tid == 0 && blockIdx.x == 0) { g_probe[10] = __builtin_amdgcn_s_memtime(); g_probe[11] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+        if (!has_next) return;
+        ij = ijn;
+#pragma unroll
+        for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+            for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+                for (int e = 0; e < M::NREG; ++e) pv[p][q][e] = pvn[p][q][e];
+        __syncthreads();                       // every wave's patch reads are done before the buffers are restaged
     }
+}
+
+// K9, one-tile-per-workgroup form for launches whose whole tile list fits on the chip at once (n_tiles <= 5 per
+// CU, e.g. n = 3013: 1176 tiles = 4.6 per CU).  Five 4-wave workgroups per CU (exactly 160 KiB of LDS, <= 96
+// VGPRs) make the launch ONE round: a CU's matrix cores are shared by all of its tiles from start to end, so there
+// is no second, half-empty round and load/epilogue phases of one workgroup hide behind the others' MFMAs.
+// Same tile math, staging and mirrored epilogue as k_downdate.
+template <typename T, int BK>
+__global__ __launch_bounds__(256) void k_downdate_1t(T *__restrict__ P, int ld, const T *__restrict__ W, int ldw, int r_pad,
+                                                     const int2 *__restrict__ tiles, int gen_size)
+{
+    // Workgroups are dispatched in generations of one per CU; give each generation its own wave priority so the
+    // tiles sharing a SIMD finish one after another (their epilogue/HBM phases then hide behind the next tile's
+    // MFMAs) instead of all together at the end.  Priority is a speed hint only.
+    {
+        const int gen = blockIdx.x / gen_size;
+        if (gen == 0) __builtin_amdgcn_s_setprio(3);
+        else if (gen == 1) __builtin_amdgcn_s_setprio(2);
+        else if (gen == 2) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    }
+    using M = Mfma<T>;
+    constexpr int TS = 64;
+    constexpr int NBLK = 32 / M::BLK;
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int ROWV = TS / VEC;
+    constexpr int NLD = (BK * ROWV) / 256;
+    constexpr int HS = BK / M::KS / 2;                // k-steps per half stage
+    static_assert((BK * ROWV) % 256 == 0 && NLD >= 1, "stage must divide over the workgroup");
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    constexpr int SMEM = 4 * BK * TS > 4 * 32 * 33 ? 4 * BK * TS : 4 * 32 * 33;     // staging buffers, reused by the 4 epilogue patches
+    __shared__ __attribute__((aligned(16))) T smem[SMEM];
+    T (*sA)[BK][TS] = reinterpret_cast<T (*)[BK][TS]>(smem);
+    T (*sB)[BK][TS] = reinterpret_cast<T (*)[BK][TS]>(smem + 2 * BK * TS);
+    T (*patch)[33] = reinterpret_cast<T (*)[33]>(smem + (threadIdx.x >> 6) * (32 * 33));
+    const int2 ij = tiles[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef PRE3_PROBE
+#define RT_STAMP(k) do { if (tid == 0 && blockIdx.x < 2048) g_k9rt[blockIdx.x * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RT_STAMP(k)
+#endif
+    RT_STAMP(0);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int I0 = ij.x * TS, J0 = ij.y * TS;
+    const int nstage = r_pad / BK;
+    typename M::acc_t acc[NBLK][NBLK];
+#pragma unroll
+    for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+        for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+            for (int e = 0; e < M::NREG; ++e) acc[p][q][e] = (T)0;
+    vec_t ra[NLD], rb[NLD];
+#pragma unroll
+    for (int l = 0; l < NLD; ++l) {
+        int v = tid + l * 256, kr = v / ROWV, cv = (v % ROWV) * VEC;
+        ra[l] = *reinterpret_cast<const vec_t *>(W + (size_t)kr * ldw + I0 + cv);
+        rb[l] = *reinterpret_cast<const vec_t *>(W + (size_t)kr * ldw + J0 + cv);
+    }
+#pragma unroll
+    for (int l = 0; l < NLD; ++l) {
+        int v = tid + l * 256, kr = v / ROWV, cv = (v % ROWV) * VEC;
+        *reinterpret_cast<vec_t *>(&sA[0][kr][cv]) = ra[l];
+        *reinterpret_cast<vec_t *>(&sB[0][kr][cv]) = rb[l];
+    }
+    __syncthreads();
+    RT_STAMP(1);
+    // this lane's 16 entries of the P tile: requested now, consumed in the epilogue (latency hidden by the k-loop)
+    T pv[NBLK][NBLK][M::NREG];
+#pragma unroll
+    for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+        for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+            for (int e = 0; e < M::NREG; ++e)
+                pv[p][q][e] = P[(size_t)(I0 + wi * 32 + p * M::BLK + M::row(lane, e)) * ld + J0 + wj * 32 + q * M::BLK + M::col(lane)];
+
+    for (int s = 0; s < nstage; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nstage) {
+#pragma unroll
+            for (int l = 0; l < NLD; ++l) {
+                int v = tid + l * 256, kr = v / ROWV, cv = (v % ROWV) * VEC;
+                ra[l] = *reinterpret_cast<const vec_t *>(W + (size_t)((s + 1) * BK + kr) * ldw + I0 + cv);
+                rb[l] = *reinterpret_cast<const vec_t *>(W + (size_t)((s + 1) * BK + kr) * ldw + J0 + cv);
+            }
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            T av[HS][NBLK], bv[HS][NBLK];
+#pragma unroll
+            for (int ks = 0; ks < HS; ++ks) {
+                const int krow = (hf * HS + ks) * M::KS + M::kk(lane);
+#pragma unroll
+                for (int p = 0; p < NBLK; ++p) {
+                    av[ks][p] = sA[buf][krow][wi * 32 + p * M::BLK + M::col(lane)];
+                    bv[ks][p] = sB[buf][krow][wj * 32 + p * M::BLK + M::col(lane)];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);       // keep the half-stage's LDS reads ahead of its MFMAs (hipcc otherwise re-serialises them pairwise)
+#pragma unroll
+            for (int ks = 0; ks < HS; ++ks)
+#pragma unroll
+                for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+                    for (int q = 0; q < NBLK; ++q) M::mma(av[ks][p], bv[ks][q], acc[p][q]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (s + 1 < nstage) {
+#pragma unroll
+            for (int l = 0; l < NLD; ++l) {
+                int v = tid + l * 256, kr = v / ROWV, cv = (v % ROWV) * VEC;
+                *reinterpret_cast<vec_t *>(&sA[buf ^ 1][kr][cv]) = ra[l];
+                *reinterpret_cast<vec_t *>(&sB[buf ^ 1][kr][cv]) = rb[l];
+            }
+        }
+        __syncthreads();
+    }
+    RT_STAMP(2);
+    const bool mirror = ij.x != ij.y;
+#pragma unroll
+    for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+        for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+            for (int e = 0; e < M::NREG; ++e) {
+                const int lr = p * M::BLK + M::row(lane, e), lc = q * M::BLK + M::col(lane);
+                const size_t o = (size_t)(I0 + wi * 32 + lr) * ld + J0 + wj * 32 + lc;
+                const T v = pv[p][q][e] - acc[p][q][e];
+                P[o] = v;
+                if (mirror) patch[lr][lc] = v;
+            }
+    if (mirror) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const int rr = lane & 31, half = lane >> 5;
+#pragma unroll
+        for (int cc = 0; cc < 32; cc += 2) {
+            const int c = cc + half;
+            P[(size_t)(J0 + wj * 32 + c) * ld + I0 + wi * 32 + rr] = patch[rr][c];
+        }
+    }
+    RT_STAMP(3);
 }
 
 // synthetic W for the roofline probe
@@ -707,6 +892,14 @@ int launch_downdate(pre3_ctx *c, int r, const void *W)
         c->kt.used += 2;
         PRE3_HIP(hipEventRecord(e0, c->stream));
     }
+    static const int force = getenv("PRE3_K9_FORM") ? atoi(getenv("PRE3_K9_FORM")) : 0;     // 1: one-tile, 2: persistent (experiments)
+    const bool one_tile = force == 1 || (force == 0 && c->dtype == PRE3_F32 && c->n_tiles <= 5 * c->num_cus);
+    if (one_tile) {
+        dim3 g1(c->n_tiles);
+        DISPATCH_T(c,
+            hipLaunchKernelGGL((k_downdate_1t<double, 16>), g1, b, 0, c->stream, (double *)c->P, c->ld, (const double *)W, c->ldw, r_pad, (const int2 *)c->tiles_flat, c->num_cus),
+            hipLaunchKernelGGL((k_downdate_1t<float, 16>), g1, b, 0, c->stream, (float *)c->P, c->ld, (const float *)W, c->ldw, r_pad, (const int2 *)c->tiles_flat, c->num_cus));
+    } else
     DISPATCH_T(c,
         hipLaunchKernelGGL((k_downdate<double, 32>), g, b, 0, c->stream, (double *)c->P, c->ld, (const double *)W, c->ldw, r_pad, (const int2 *)c->tiles, c->tiles_stride, c->tile_cnt, c->tile_ctr),
         hipLaunchKernelGGL((k_downdate<float, 32>), g, b, 0, c->stream, (float *)c->P, c->ld, (const float *)W, c->ldw, r_pad, (const int2 *)c->tiles, c->tiles_stride, c->tile_cnt, c->tile_ctr));
@@ -756,5 +949,25 @@ int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_d
     }
     return PRE3_OK;
 }
+
+#ifdef PRE3_PROBE
+extern "C" __attribute__((visibility("default"))) int pre3_debug_k9_stamps(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k9), sizeof(unsigned long long) * 64 * 8 * 4) == hipSuccess ? 0 : -3;
+}
+extern "C" __attribute__((visibility("default"))) int pre3_debug_k9rt(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k9rt), sizeof(unsigned long long) * 2048 * 4) == hipSuccess ? 0 : -3;
+}
+extern "C" __attribute__((visibility("default"))) int pre3_debug_probe(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -3;
+}
+extern "C" __attribute__((visibility("default"))) int pre3_debug_k9_clear(void)
+{
+    static unsigned long long z[64 * 8 * 4];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_k9), z, sizeof z) == hipSuccess ? 0 : -3;
+}
+#endif
 
 }  // namespace pre3
