@@ -667,11 +667,32 @@ __global__ __launch_bounds__(256) void k_downdate(T *__restrict__ P, int ld, con
     }
 }
 
+// LDS-DMA of one [BK][64] operand stage (both operands): granule v = tid + l*256 covers row kr = v / ROWV, columns
+// (v % ROWV)*VEC ..; its LDS address is v*16 bytes into the stage image = wave-uniform base + lane*16, as the
+// instruction requires (global_load_lds_dwordx4).
+template <typename T, int BK>
+__device__ __forceinline__ void lds_dma_stage(const T *__restrict__ W, int ldw, int k0, int I0, int J0, T *sA, T *sB, int tid, int wave)
+{
+    constexpr int VEC = 16 / sizeof(T), ROWV = 64 / VEC, NLD = (BK * ROWV) / 256;
+#pragma unroll
+    for (int l = 0; l < NLD; ++l) {
+        const int v = tid + l * 256, kr = v / ROWV, cv = (v % ROWV) * VEC;
+        const T *ga = W + (size_t)(k0 + kr) * ldw + I0 + cv;
+        const T *gb = W + (size_t)(k0 + kr) * ldw + J0 + cv;
+        T *la = sA + (size_t)(wave * 64 + l * 256) * VEC;            // lane 0's granule
+        T *lb = sB + (size_t)(wave * 64 + l * 256) * VEC;
+        __builtin_amdgcn_global_load_lds(ga, (__attribute__((address_space(3))) void *)la, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(gb, (__attribute__((address_space(3))) void *)lb, 16, 0, 0);
+    }
+}
+
 // K9, one-tile-per-workgroup form for launches whose whole tile list fits on the chip at once (n_tiles <= 5 per
-// CU, e.g. n = 3013: 1176 tiles = 4.6 per CU).  Five 4-wave workgroups per CU (exactly 160 KiB of LDS, <= 96
-// VGPRs) make the launch ONE round: a CU's matrix cores are shared by all of its tiles from start to end, so there
-// is no second, half-empty round and load/epilogue phases of one workgroup hide behind the others' MFMAs.
-// Same tile math, staging and mirrored epilogue as k_downdate.
+// CU, e.g. n = 3013: 1176 tiles = 4.6 per CU).  Five 4-wave workgroups per CU (<= 160 KiB of LDS, <= 96 VGPRs)
+// make the launch ONE round: a CU's matrix cores are shared by all of its tiles from start to end, so there is
+// no second, half-empty round and load/epilogue phases of one workgroup hide behind the others' MFMAs.
+// W is staged by LDS-DMA (global_load_lds_dwordx4: the [BK][64] image is lane-linear, 16 B per lane, so no
+// VGPR round trip and no ds_write), double-buffered: stage s+1 is requested when stage s starts and waited for
+// (vmcnt(0) + barrier) when it ends.  Same tile math and mirrored epilogue as k_downdate.
 template <typename T, int BK>
 __global__ __launch_bounds__(256) void k_downdate_1t(T *__restrict__ P, int ld, const T *__restrict__ W, int ldw, int r_pad,
                                                      const int2 *__restrict__ tiles, int gen_size)
@@ -689,16 +710,14 @@ __global__ __launch_bounds__(256) void k_downdate_1t(T *__restrict__ P, int ld, 
     using M = Mfma<T>;
     constexpr int TS = 64;
     constexpr int NBLK = 32 / M::BLK;
-    constexpr int VEC = 16 / sizeof(T);
-    constexpr int ROWV = TS / VEC;
-    constexpr int NLD = (BK * ROWV) / 256;
+    constexpr int VEC = 16 / sizeof(T);               // elements per 16-byte LDS-DMA granule
+    constexpr int ROWV = TS / VEC;                    // granules per staged row
+    constexpr int NLD = (BK * ROWV) / 256;            // granules per lane per operand per stage
     constexpr int HS = BK / M::KS / 2;                // k-steps per half stage
     static_assert((BK * ROWV) % 256 == 0 && NLD >= 1, "stage must divide over the workgroup");
-    typedef T vec_t __attribute__((ext_vector_type(VEC)));
-    constexpr int SMEM = 4 * BK * TS > 4 * 32 * 33 ? 4 * BK * TS : 4 * 32 * 33;     // staging buffers, reused by the 4 epilogue patches
-    __shared__ __attribute__((aligned(16))) T smem[SMEM];
-    T (*sA)[BK][TS] = reinterpret_cast<T (*)[BK][TS]>(smem);
-    T (*sB)[BK][TS] = reinterpret_cast<T (*)[BK][TS]>(smem + 2 * BK * TS);
+    constexpr int STG = BK * TS;                      // elements of one operand stage
+    constexpr int SMEM = 4 * STG > 4 * 32 * 33 ? 4 * STG : 4 * 32 * 33;     // staging buffers, reused by the 4 epilogue patches
+    __shared__ __attribute__((aligned(16))) T smem[SMEM];                   // [A0 | A1 | B0 | B1], each [BK][64]
     T (*patch)[33] = reinterpret_cast<T (*)[33]>(smem + (threadIdx.x >> 6) * (32 * 33));
     const int2 ij = tiles[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -718,21 +737,7 @@ __global__ __launch_bounds__(256) void k_downdate_1t(T *__restrict__ P, int ld, 
         for (int q = 0; q < NBLK; ++q)
 #pragma unroll
             for (int e = 0; e < M::NREG; ++e) acc[p][q][e] = (T)0;
-    vec_t ra[NLD], rb[NLD];
-#pragma unroll
-    for (int l = 0; l < NLD; ++l) {
-        int v = tid + l * 256, kr = v / ROWV, cv = (v % ROWV) * VEC;
-        ra[l] = *reinterpret_cast<const vec_t *>(W + (size_t)kr * ldw + I0 + cv);
-        rb[l] = *reinterpret_cast<const vec_t *>(W + (size_t)kr * ldw + J0 + cv);
-    }
-#pragma unroll
-    for (int l = 0; l < NLD; ++l) {
-        int v = tid + l * 256, kr = v / ROWV, cv = (v % ROWV) * VEC;
-        *reinterpret_cast<vec_t *>(&sA[0][kr][cv]) = ra[l];
-        *reinterpret_cast<vec_t *>(&sB[0][kr][cv]) = rb[l];
-    }
-    __syncthreads();
-    RT_STAMP(1);
+    lds_dma_stage<T, BK>(W, ldw, 0, I0, J0, smem, smem + 2 * STG, tid, wave);
     // this lane's 16 entries of the P tile: requested now, consumed in the epilogue (latency hidden by the k-loop)
     T pv[NBLK][NBLK][M::NREG];
 #pragma unroll
@@ -742,17 +747,14 @@ __global__ __launch_bounds__(256) void k_downdate_1t(T *__restrict__ P, int ld, 
 #pragma unroll
             for (int e = 0; e < M::NREG; ++e)
                 pv[p][q][e] = P[(size_t)(I0 + wi * 32 + p * M::BLK + M::row(lane, e)) * ld + J0 + wj * 32 + q * M::BLK + M::col(lane)];
-
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    RT_STAMP(1);
     for (int s = 0; s < nstage; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nstage) {
-#pragma unroll
-            for (int l = 0; l < NLD; ++l) {
-                int v = tid + l * 256, kr = v / ROWV, cv = (v % ROWV) * VEC;
-                ra[l] = *reinterpret_cast<const vec_t *>(W + (size_t)((s + 1) * BK + kr) * ldw + I0 + cv);
-                rb[l] = *reinterpret_cast<const vec_t *>(W + (size_t)((s + 1) * BK + kr) * ldw + J0 + cv);
-            }
-        }
+        if (s + 1 < nstage)       // buf^1 was last read in stage s-1: every wave is past that barrier
+            lds_dma_stage<T, BK>(W, ldw, (s + 1) * BK, I0, J0, smem + (buf ^ 1) * STG, smem + (2 + (buf ^ 1)) * STG, tid, wave);
+        const T *sA = smem + buf * STG, *sB = smem + (2 + buf) * STG;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             T av[HS][NBLK], bv[HS][NBLK];
@@ -761,27 +763,18 @@ __global__ __launch_bounds__(256) void k_downdate_1t(T *__restrict__ P, int ld, 
                 const int krow = (hf * HS + ks) * M::KS + M::kk(lane);
 #pragma unroll
                 for (int p = 0; p < NBLK; ++p) {
-                    av[ks][p] = sA[buf][krow][wi * 32 + p * M::BLK + M::col(lane)];
-                    bv[ks][p] = sB[buf][krow][wj * 32 + p * M::BLK + M::col(lane)];
+                    av[ks][p] = sA[krow * TS + wi * 32 + p * M::BLK + M::col(lane)];
+                    bv[ks][p] = sB[krow * TS + wj * 32 + p * M::BLK + M::col(lane)];
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);       // keep the half-stage's LDS reads ahead of its MFMAs (hipcc otherwise re-serialises them pairwise)
 #pragma unroll
             for (int ks = 0; ks < HS; ++ks)
 #pragma unroll
                 for (int p = 0; p < NBLK; ++p)
 #pragma unroll
                     for (int q = 0; q < NBLK; ++q) M::mma(av[ks][p], bv[ks][q], acc[p][q]);
-            __builtin_amdgcn_sched_barrier(0);
         }
-        if (s + 1 < nstage) {
-#pragma unroll
-            for (int l = 0; l < NLD; ++l) {
-                int v = tid + l * 256, kr = v / ROWV, cv = (v % ROWV) * VEC;
-                *reinterpret_cast<vec_t *>(&sA[buf ^ 1][kr][cv]) = ra[l];
-                *reinterpret_cast<vec_t *>(&sB[buf ^ 1][kr][cv]) = rb[l];
-            }
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's LDS-DMA granules of stage s+1 have landed
         __syncthreads();
     }
     RT_STAMP(2);
