@@ -285,7 +285,7 @@ int pre3_set_state(pre3_ctx *c, int which, int n, const double *x, const double 
         for (size_t i = 0; i < (size_t)n * n; ++i) tmp[i] = (float)P[i];
         PRE3_HIP(hipMemcpy2D(c->P, (size_t)ld * 4, tmp.data(), (size_t)n * 4, (size_t)n * 4, n, hipMemcpyHostToDevice));
     }
-    c->x_valid[which] = true; c->p_which = which;
+    c->x_valid[which] = true; c->p_which = which; c->hp_all_valid = false;
     return PRE3_OK;
 }
 
@@ -317,7 +317,7 @@ int pre3_predict(pre3_ctx *c, const double u[7])
     PRE3_CHECK(u != nullptr, PRE3_E_ARG, "pre3_predict: null u");
     PRE3_CHECK(c->x_valid[PRE3_X_K_K] && c->p_which == PRE3_X_K_K, PRE3_E_STATE, "pre3_predict: needs (x_k_k, p_k_k) on the device");
     PRE3_TRY(launch_predict_impl(c, u));
-    c->x_valid[PRE3_X_K_KM1] = true; c->p_which = PRE3_X_K_KM1;
+    c->x_valid[PRE3_X_K_KM1] = true; c->p_which = PRE3_X_K_KM1; c->hp_all_valid = false;
     return PRE3_OK;
 }
 
@@ -385,6 +385,7 @@ static int install_measurements(pre3_ctx *c, int m, const int32_t *meas_idx, con
     }
     PRE3_TRY(launch_clear_flags(c));
     c->li_from_host = c->hi_from_host = -1; c->li_kernel = c->hi_kernel = false;
+    c->hp_all_valid = false;
     c->measurements_set = true;
     return PRE3_OK;
 }
@@ -451,6 +452,7 @@ static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp)
     PRE3_TRY(launch_build_rows_impl(c, c->m, nullptr, r_pad));
     PRE3_TRY(launch_ell_HP(c, r, c->HP, true));
     PRE3_TRY(launch_ell_G(c, r, c->HP, c->G, r_pad, 0, nullptr));
+    c->hp_all_valid = true;
     return PRE3_OK;
 }
 
@@ -524,8 +526,12 @@ static int update_selected(pre3_ctx *c, int which_prior, int nsel, const int32_t
 {
     PRE3_CHECK(c->p_which == which_prior, PRE3_E_STATE, "update: the covariance buffer does not hold the required prior");
     int r = 2 * nsel;
-    if (r > 0) PRE3_TRY(launch_build_rows_impl(c, nsel, sel_dev, round_up(r, NB)));
-    PRE3_TRY(run_update(c, which_prior, r, false, nullptr));
+    // rows of the predicted-state update that RANSAC already multiplied out: gather instead of recomputing
+    const bool reuse = r > 0 && which_prior == PRE3_X_K_KM1 && c->hp_all_valid && sel_dev != nullptr;
+    if (reuse) PRE3_TRY(launch_gather_li(c, nsel, sel_dev, round_up(2 * c->m, NB)));
+    else if (r > 0) PRE3_TRY(launch_build_rows_impl(c, nsel, sel_dev, round_up(r, NB)));
+    PRE3_TRY(run_update(c, which_prior, r, false, nullptr, reuse));
+    c->hp_all_valid = false;                 // P changed
     c->x_valid[PRE3_X_K_K] = true; c->p_which = PRE3_X_K_K;
     return PRE3_OK;
 }

@@ -687,6 +687,7 @@ __global__ __launch_bounds__(1024) void k_update_x(int n, int r, const T *__rest
     const int ci = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + ci;            // i < ldw always (ldw >= ld + 64 > n rounded up)
     double s = 0;
+#pragma unroll 8
     for (int a = rg; a < r; a += 16) s += (double)W[(size_t)a * ldw + i] * (double)W[(size_t)a * ldw + ld];
     red[rg][ci] = s;
     __syncthreads();

@@ -74,6 +74,33 @@ __global__ __launch_bounds__(64) void k_ell_G(int r, int r_pad, const int32_t *_
     dst[(size_t)a * ldg + b] = out;
 }
 
+// LI rows are a subset of the measured rows whose H*P and H*P*H' already exist (computed once per step for RANSAC):
+// gather them instead of recomputing.  sel[s] = measurement index of selected landmark s; row a = 2*sel[a/2] + (a&1).
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_rows(int r, int r_pad, const int32_t *__restrict__ sel, const T *__restrict__ HP,
+                                                     T *__restrict__ W, int ldw)
+{
+    const int a = blockIdx.y;
+    const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (j >= ldw || a >= r_pad) return;
+    typedef T v4_t __attribute__((ext_vector_type(4)));
+    v4_t v = { (T)0, (T)0, (T)0, (T)0 };
+    if (a < r) v = *reinterpret_cast<const v4_t *>(HP + (size_t)(2 * sel[a >> 1] + (a & 1)) * ldw + j);
+    *reinterpret_cast<v4_t *>(W + (size_t)a * ldw + j) = v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_gather_S(int r, int r_pad, const int32_t *__restrict__ sel, const T *__restrict__ G, int ldg,
+                                                 T *__restrict__ S)
+{
+    const int a = blockIdx.y;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= r_pad || a >= r_pad) return;
+    T out = (a == b) ? (T)1 : (T)0;
+    if (a < r && b < r) out += G[(size_t)(2 * sel[a >> 1] + (a & 1)) * ldg + 2 * sel[b >> 1] + (b & 1)];
+    S[(size_t)a * r_pad + b] = out;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Blocked Cholesky of S fused with the forward solve W = L^-1 [HP | nu].
 // The stacked matrix M = [S ; HP'] (rows: r_pad rows of S, then the ldw columns of HP as rows) is swept
@@ -919,7 +946,22 @@ int launch_fill_w(pre3_ctx *c, int r_pad)
 int launch_update_x(pre3_ctx *c, int which_prior, int r);   // pre3_geom.hip
 
 // rows already in c->row_* (r rows).  which_prior selects x prior; P currently holds the prior covariance.
-int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_dev)
+int launch_gather_li(pre3_ctx *c, int nsel, const int32_t *sel_dev, int ldg)
+{
+    const int r = 2 * nsel, r_pad = round_up(r, NB);
+    dim3 g1(ceil_div(c->ldw / 4, 256), r_pad), b1(256), g2(ceil_div(r_pad, 64), r_pad), b2(64);
+    DISPATCH_T(c,
+        hipLaunchKernelGGL(k_gather_rows<double>, g1, b1, 0, c->stream, r, r_pad, sel_dev, (const double *)c->HP, (double *)c->W, c->ldw),
+        hipLaunchKernelGGL(k_gather_rows<float>, g1, b1, 0, c->stream, r, r_pad, sel_dev, (const float *)c->HP, (float *)c->W, c->ldw));
+    DISPATCH_T(c,
+        hipLaunchKernelGGL(k_gather_S<double>, g2, b2, 0, c->stream, r, r_pad, sel_dev, (const double *)c->G, ldg, (double *)c->Smat),
+        hipLaunchKernelGGL(k_gather_S<float>, g2, b2, 0, c->stream, r, r_pad, sel_dev, (const float *)c->G, ldg, (float *)c->Smat));
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
+// prebuilt: W (H*P with the nu column) and Smat (S) are already in place (launch_gather_li)
+int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_dev, bool prebuilt)
 {
     if (r == 0) {   // update.m:50-55: x_k_k = x_km1_k, p_k_k = p_km1_k
         if (which_prior == PRE3_X_K_KM1) PRE3_HIP(hipMemcpyAsync(c->x_kk, c->x_km1, sizeof(double) * c->n, hipMemcpyDeviceToDevice, c->stream));
@@ -927,8 +969,10 @@ int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_d
     }
     int r_pad = round_up(r, NB);
     PRE3_CHECK(r_pad <= c->rcap, PRE3_E_ARG, "update with %d rows exceeds the context capacity %d", r, c->rcap);
-    PRE3_TRY(launch_ell_HP(c, r, c->W, true));
-    PRE3_TRY(launch_ell_G(c, r, c->W, c->Smat, r_pad, 1, dense_R ? c->Rdense : nullptr));
+    if (!prebuilt) {
+        PRE3_TRY(launch_ell_HP(c, r, c->W, true));
+        PRE3_TRY(launch_ell_G(c, r, c->W, c->Smat, r_pad, 1, dense_R ? c->Rdense : nullptr));
+    }
     PRE3_TRY(launch_chol_solve(c, r_pad));
     PRE3_TRY(launch_update_x(c, which_prior, r));
     PRE3_TRY(launch_downdate(c, r, c->W));

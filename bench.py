@@ -136,7 +136,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):     # launched by torch.distributed.run (any N)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
