@@ -195,7 +195,8 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
         memset(c->mail_host, 0, sizeof(int32_t) * 16);
         if (hipHostGetDevicePointer((void **)&c->mail_dev, c->mail_host, 0) != hipSuccess) { set_error("hipHostGetDevicePointer failed"); rc = PRE3_E_HIP; }
     }
-    if (rc == PRE3_OK && (hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess)) { set_error("hipEventCreate failed"); rc = PRE3_E_HIP; }
+    if (rc == PRE3_OK && (hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess ||
+                          hipEventCreateWithFlags(&c->inbox_copied, hipEventDisableTiming) != hipSuccess)) { set_error("hipEventCreate failed"); rc = PRE3_E_HIP; }
     if (rc != PRE3_OK) { pre3_destroy(c); return rc; }
     (void)hipMemsetAsync(c->stats, 0, sizeof(int32_t) * 16, c->stream);
     (void)hipMemsetAsync(c->P, 0, (size_t)c->ld * c->ld * c->esz, c->stream);
@@ -219,6 +220,7 @@ int pre3_destroy(pre3_ctx *c)
     for (hipEvent_t e : c->kt.ev) (void)hipEventDestroy(e);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->inbox_copied) (void)hipEventDestroy(c->inbox_copied);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PRE3_OK;
@@ -366,7 +368,9 @@ static int install_measurements(pre3_ctx *c, int m, const int32_t *meas_idx, con
         PRE3_CHECK(meas_idx[j] >= 0 && meas_idx[j] < c->N, PRE3_E_ARG, "measurements: landmark index %d out of range", meas_idx[j]);
         PRE3_CHECK(j == 0 || meas_idx[j] > meas_idx[j - 1], PRE3_E_ARG, "measurements: landmark indices must be strictly ascending");
     }
-    PRE3_HIP(hipStreamSynchronize(c->stream));          // the previous copy out of the pinned inbox must have completed
+    // the previous copy out of the pinned inbox must have completed before the host overwrites it (it has, a whole
+    // step ago: this returns immediately and -- unlike a stream sync -- does not wait for the kernels queued since)
+    if (c->inbox_pending) { PRE3_HIP(hipEventSynchronize(c->inbox_copied)); c->inbox_pending = false; }
     c->m = m; c->meas_host.assign(meas_idx, meas_idx + m);
     int32_t *hm = (int32_t *)(c->inbox_host + c->off_meas), *hic = (int32_t *)(c->inbox_host + c->off_ic);
     double *hz = (double *)(c->inbox_host + c->off_z);
@@ -383,6 +387,7 @@ static int install_measurements(pre3_ctx *c, int m, const int32_t *meas_idx, con
     } else {
         PRE3_HIP(hipMemcpyAsync(d, c->inbox_host, c->off_hyp + (hyp ? sizeof(int32_t) * n_hyp_ints : 0), hipMemcpyHostToDevice, c->stream));
     }
+    PRE3_HIP(hipEventRecord(c->inbox_copied, c->stream)); c->inbox_pending = true;
     PRE3_TRY(launch_clear_flags(c));
     c->li_from_host = c->hi_from_host = -1; c->li_kernel = c->hi_kernel = false;
     c->hp_all_valid = false;
@@ -444,9 +449,10 @@ static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp)
     PRE3_CHECK(c->m >= k, PRE3_E_ARG, "ransac: %d measurements but k=%d", c->m, k);
     for (int i = 0; i < n_draw * k; ++i) PRE3_CHECK(hyp[i] >= 0 && hyp[i] < c->m, PRE3_E_ARG, "ransac: hyp[%d]=%d not a position in the IC list (m=%d)", i, hyp[i], c->m);
     if (hyp != (const int32_t *)(c->inbox_host + c->off_hyp)) {       // not already shipped with the measurements
-        PRE3_HIP(hipStreamSynchronize(c->stream));
+        if (c->inbox_pending) { PRE3_HIP(hipEventSynchronize(c->inbox_copied)); c->inbox_pending = false; }
         memcpy(c->inbox_host + c->off_hyp, hyp, sizeof(int32_t) * n_draw * k);
         PRE3_HIP(hipMemcpyAsync(c->hyp, c->inbox_host + c->off_hyp, sizeof(int32_t) * n_draw * k, hipMemcpyHostToDevice, c->stream));
+        PRE3_HIP(hipEventRecord(c->inbox_copied, c->stream)); c->inbox_pending = true;
     }
     int r = 2 * c->m, r_pad = round_up(r, NB);
     PRE3_TRY(launch_build_rows_impl(c, c->m, nullptr, r_pad));

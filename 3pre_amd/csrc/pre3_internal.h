@@ -115,6 +115,8 @@ struct pre3_ctx {
     // per-step inbox: [meas | ic | hyp | z] contiguous on the device, mirrored in pinned host memory -> ONE H2D copy
     void *inbox_dev = nullptr; unsigned char *inbox_host = nullptr;
     size_t inbox_bytes = 0, off_meas = 0, off_ic = 0, off_hyp = 0, off_z = 0;
+    hipEvent_t inbox_copied = nullptr;            // recorded behind every copy out of the pinned inbox
+    bool inbox_pending = false;
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;
     pre3::KernelTiming kt;
