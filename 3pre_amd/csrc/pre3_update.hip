@@ -913,7 +913,8 @@ int launch_downdate(pre3_ctx *c, int r, const void *W)
         PRE3_HIP(hipEventRecord(e0, c->stream));
     }
     static const int force = getenv("PRE3_K9_FORM") ? atoi(getenv("PRE3_K9_FORM")) : 0;     // 1: one-tile, 2: persistent (experiments)
-    const bool one_tile = force == 1 || (force == 0 && c->dtype == PRE3_F32 && c->n_tiles <= 5 * c->num_cus);
+    // all tiles resident at once: 5 workgroups/CU in fp32 (16.9 KB of LDS each), 4 in fp64 (33.8 KB)
+    const bool one_tile = force == 1 || (force == 0 && c->n_tiles <= (c->dtype == PRE3_F32 ? 5 : 4) * c->num_cus);
     if (one_tile) {
         dim3 g1(c->n_tiles);
         DISPATCH_T(c,
