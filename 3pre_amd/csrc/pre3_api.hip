@@ -212,7 +212,7 @@ int pre3_destroy(pre3_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
                      c->lm.li, c->lm.hi, c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
-                     c->sel_rows, c->support, c->masks, c->stats, c->li_meas, c->hi_meas, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat };
+                     c->sel_rows, c->support, c->masks, c->stats, c->li_meas, c->hi_meas, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->pinned_stats) (void)hipHostFree(c->pinned_stats);
     if (c->inbox_host) (void)hipHostFree(c->inbox_host);
@@ -259,6 +259,7 @@ int pre3_set_map(pre3_ctx *c, int N, const int32_t *lm_type)
         PRE3_HIP(hipMemcpy(c->lm.off, off.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice));
     }
     c->N = N; c->n = n;
+    c->lm_type_host.assign(lm_type, lm_type + N);
     // the P buffer keeps its capacity-sized leading dimension; entries beyond n stay zero
     PRE3_HIP(hipMemset(c->lm.has_h, 0, sizeof(int32_t) * c->capN)); PRE3_HIP(hipMemset(c->lm.has_S, 0, sizeof(int32_t) * c->capN));
     PRE3_HIP(hipMemset(c->inbox_dev, 0, c->inbox_bytes)); PRE3_HIP(hipMemset(c->lm.li, 0, sizeof(int32_t) * c->capN));

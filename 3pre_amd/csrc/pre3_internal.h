@@ -117,6 +117,10 @@ struct pre3_ctx {
     size_t inbox_bytes = 0, off_meas = 0, off_ic = 0, off_hyp = 0, off_z = 0;
     hipEvent_t inbox_copied = nullptr;            // recorded behind every copy out of the pinned inbox
     bool inbox_pending = false;
+    // map management (allocated on first use)
+    void *P_alt = nullptr; double *x_alt = nullptr; int32_t *map_col = nullptr; void *map_val = nullptr; int32_t *map_desc = nullptr;
+    double *map_feat = nullptr; int32_t *map_flags = nullptr;
+    std::vector<int32_t> lm_type_host;
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;
     pre3::KernelTiming kt;

@@ -87,6 +87,36 @@ class EkfFilter:
     def sync(self):
         check(lib.pre3_sync(self._ctx))
 
+    # ---- map management between steps (map_management.m:27-79); the policy stays with the caller
+    def _refresh_map(self):
+        self.N = int(lib.pre3_get_map(self._ctx, None))
+        t = np.zeros(max(self.N, 1), np.int32)
+        lib.pre3_get_map(self._ctx, dptr(t))
+        self.lm_type = t[:self.N].copy()
+        self.n = int(lib.pre3_state_size(self._ctx))
+        self.m = 0
+
+    def delete_features(self, del_idx):
+        """delete_features.m:54-74 -> delete_a_feature.m:47-51 (0-based landmark indices)."""
+        d = i32(sorted(int(v) for v in del_idx))
+        check(lib.pre3_map_delete(self._ctx, int(d.shape[0]), dptr(d)))
+        self._refresh_map()
+
+    def add_features_inverse_depth(self, uvd, std_pxl, initial_rho):
+        """add_features_inverse_depth.m:27-47; uvd is (k, 2) distorted pixels, initial_rho scalar or (k,)."""
+        uvd = f64(uvd).reshape(-1, 2)
+        rho = f64(np.broadcast_to(initial_rho, (uvd.shape[0],)))
+        check(lib.pre3_map_add_inverse_depth(self._ctx, int(uvd.shape[0]), dptr(uvd), C.c_double(std_pxl), dptr(rho)))
+        self._refresh_map()
+
+    def inversedepth_2_cartesian(self, linearity_index_threshold=0.1):
+        """inversedepth_2_cartesian.m:27-76; returns the per-landmark converted flags."""
+        conv = np.zeros(max(self.N, 1), np.int32)
+        check(lib.pre3_map_inversedepth_2_cartesian(self._ctx, C.c_double(linearity_index_threshold), dptr(conv)))
+        conv = conv[:self.N].copy()
+        self._refresh_map()
+        return conv
+
     # ---- step stages
     def ekf_prediction(self, u):
         u = f64(u)

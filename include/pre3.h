@@ -159,6 +159,24 @@ PRE3_API int pre3_update_ell(int device, int dtype, int n, int r, const double *
                              const int32_t *nnz, const int32_t *col, const double *val, const double *R,
                              const double *z, const double *h, double *x_out, double *P_out, double *K_out);
 
+/* ---- map management on the device (map_management.m:27-79) ----------------------------- */
+/* These act on (x_k_k, p_k_k) between steps, as map_management.m:140 does, and keep P resident: P <- A P A' (+D) with
+ * a sparse A (selection rows / the 6x13 and 3x6 Jacobians of the reference), evaluated by two gather passes through a
+ * second ld x ld buffer (allocated on first use).  Per-landmark fields (h, H, S, z, flags) are cleared afterwards,
+ * as update_features_info.m:30-44 does.  The POLICY (which landmarks to delete, which pixels to initialise) stays on
+ * the host, as in delete_features.m:31-52 / initialize_features.m. */
+/* delete_features.m:54-74 -> delete_a_feature.m:47-51: remove landmarks del_idx[n_del] (ascending, 0-based). */
+PRE3_API int pre3_map_delete(pre3_ctx *ctx, int n_del, const int32_t *del_idx);
+/* add_features_inverse_depth.m:27-47 (hinv_my_version.m:26-53 + add_a_feature_covariance_inverse_depth.m:27-90):
+ * append n_new inverse-depth landmarks observed at distorted pixels uvd[2*n_new] with initial inverse depths
+ * initial_rho[n_new]; std_rho = initial_rho^2 * 0.01 as the reference hard-codes (:41). */
+PRE3_API int pre3_map_add_inverse_depth(pre3_ctx *ctx, int n_new, const double *uvd, double std_pxl, const double *initial_rho);
+/* inversedepth_2_cartesian.m:27-76: convert every inverse-depth landmark whose linearity index is below the threshold
+ * (0.1 in the reference) to a Cartesian point; converted_out[N] (may be NULL) receives the flags. */
+PRE3_API int pre3_map_inversedepth_2_cartesian(pre3_ctx *ctx, double linearity_threshold, int32_t *converted_out);
+/* current landmark table: returns N, writes lm_type_out[N] if not NULL */
+PRE3_API int pre3_get_map(pre3_ctx *ctx, int32_t *lm_type_out);
+
 /* ---- a10: sift/siftmatch.c:83-132,139-250 ------------------------------------------------------- */
 /* L1: ND x K1, L2: ND x K2, one descriptor per column (column-major, as mxGetData returns them).
  * pairs_out[2*K1] receives 1-based (k1,k2) doubles in increasing k1 exactly as the MEX writes them

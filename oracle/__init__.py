@@ -241,3 +241,38 @@ def step(types, off, cam, x_kk, P_kk, u, meas_idx, z_meas, hyp, threshold, early
     x3, P3 = update_landmarks(types, off, np.nonzero(hi)[0], x2, P2, Hc2, Hl2, z, h2)   # ekf_update_hi_inliers
     out.update(x_kk=x3, P_kk=P3, li=li[meas_idx], hi=hi[meas_idx], x_li=x2, P_li=P2, d2=d2)
     return out
+
+
+# ---- map management (unpinned; see pre3_oracle.c)
+def map_delete(types, off, x, P, del_idx):
+    x, P = _d(x), _d(P)
+    n = x.shape[0]
+    del_idx = _i(sorted(del_idx))
+    xo, Po = np.empty(n), np.empty(n * n)
+    nn = lib().orc_map_delete(n, len(types), _p(_i(types)), _p(_i(off)), len(del_idx), _p(del_idx), _p(x), _p(P), _p(xo), _p(Po))
+    keep = np.ones(len(types), bool)
+    keep[del_idx] = False
+    return xo[:nn].copy(), Po[:nn * nn].reshape(nn, nn).copy(), np.asarray(types)[keep]
+
+
+def map_add(x, P, cam, uvd, std_pxl, initial_rho):
+    x, P = _d(x), _d(P)
+    n = x.shape[0]
+    uvd = _d(uvd).reshape(-1, 2)
+    k = uvd.shape[0]
+    rho = _d(np.broadcast_to(initial_rho, (k,)))
+    nm = n + 6 * k
+    xo, Po = np.empty(nm), np.empty(nm * nm)
+    c = make_cam(cam)
+    nn = lib().orc_map_add(n, k, _p(uvd), C.c_double(std_pxl), _p(rho), C.byref(c), _p(x), _p(P), _p(xo), _p(Po))
+    return xo[:nn].copy(), Po[:nn * nn].reshape(nn, nn).copy()
+
+
+def map_convert(types, x, P, threshold=0.1):
+    x, P = _d(x), _d(P)
+    n = x.shape[0]
+    N = len(types)
+    xo, Po = np.empty(n), np.empty(n * n)
+    to, conv = np.zeros(N, np.int32), np.zeros(N, np.int32)
+    nn = lib().orc_map_convert(n, N, _p(_i(types)), C.c_double(threshold), _p(x), _p(P), _p(xo), _p(Po), _p(to), _p(conv))
+    return xo[:nn].copy(), Po[:nn * nn].reshape(nn, nn).copy(), to, conv

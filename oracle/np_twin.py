@@ -392,3 +392,92 @@ def knn(data, query, k):              # kNearestNeighbors.m:29-39
         ids[i] = order[:k] + 1
         dist[i] = np.sqrt(d[order[:k]])
     return ids, dist
+
+
+# ---- map management (independent restatement; unpinned)
+def undistort(uvd, cam):                      # undistort_fm_my_version.m:27-48
+    f, Cx, Cy, k1, k2 = cam[:5]
+    xd, yd = (uvd[0] - Cx) / f, (uvd[1] - Cy) / f
+    rd = np.sqrt(xd * xd + yd * yd)
+    ru = rd / (1 + k1 * rd ** 2 + k2 * rd ** 4)
+    for _ in range(10):
+        ru = ru - (ru + k1 * ru ** 3 + k2 * ru ** 5 - rd) / (1 + 3 * k1 * ru ** 2 + 5 * k2 * ru ** 4)
+    D = 1 + k1 * ru ** 2 + k2 * ru ** 4
+    return np.array([f * xd / D + Cx, f * yd / D + Cy])
+
+
+def map_delete(types, off, x, P, del_idx):    # delete_features.m:54-74 / delete_a_feature.m:47-51, from the back
+    x, P, types = x.copy(), P.copy(), list(types)
+    offs = list(off)
+    for i in sorted(del_idx, reverse=True):
+        d = 6 if types[i] == INVDEPTH else 3
+        o = offs[i]
+        x = np.concatenate([x[:o], x[o + d:]])
+        P = np.hstack([P[:, :o], P[:, o + d:]])
+        P = np.vstack([P[:o, :], P[o + d:, :]])
+        del types[i]
+        offs = [13 + sum(6 if t == INVDEPTH else 3 for t in types[:k]) for k in range(len(types))]
+    return x, P, np.array(types, np.int32)
+
+
+def map_add(x, P, cam, uvd, std_pxl, initial_rho):   # add_features_inverse_depth.m / add_a_feature_covariance_inverse_depth.m
+    f, Cx, Cy = cam[0], cam[1], cam[2]
+    X, PR = x.copy(), P.copy()
+    Xv = x[:13]
+    uvd = np.asarray(uvd, float).reshape(-1, 2)
+    rho0 = np.broadcast_to(initial_rho, (len(uvd),))
+    for k in range(len(uvd)):
+        uv = undistort(uvd[k], cam)
+        R = q2r(Xv[3:7])
+        hc = np.array([-(Cx - uv[0]) / f, -(Cy - uv[1]) / f, 1.0])
+        nw = R @ hc
+        X = np.concatenate([X, Xv[:3], [np.arctan2(nw[0], nw[2]), np.arctan2(-nw[1], np.hypot(nw[0], nw[2])), rho0[k]]])
+        std_rho = rho0[k] ** 2 * 0.01
+        Xw, Yw, Zw = nw
+        dth = np.array([Zw / (Xw ** 2 + Zw ** 2), 0, -Xw / (Xw ** 2 + Zw ** 2)])
+        s2, sxz = Xw ** 2 + Yw ** 2 + Zw ** 2, np.sqrt(Xw ** 2 + Zw ** 2)
+        dph = np.array([Xw * Yw / (s2 * sxz), -sxz / s2, Zw * Yw / (s2 * sxz)])
+        dg_dq = dRq_times_a_by_dq(Xv[3:7], hc)
+        dy_dxv = np.zeros((6, 13))
+        dy_dxv[:3, :3] = np.eye(3)
+        dy_dxv[3, 3:7] = dth @ dg_dq
+        dy_dxv[4, 3:7] = dph @ dg_dq
+        dyp_dgw = np.vstack([np.zeros((3, 3)), dth, dph])
+        dgc_dhu = np.array([[1 / f, 0], [0, 1 / f], [0, 0]])
+        dhu_dhd = np.linalg.inv(jacob_distor(cam, uvd[k]))
+        dy_dhd = np.zeros((6, 3))
+        dy_dhd[:5, :2] = dyp_dgw @ R @ dgc_dhu @ dhu_dhd
+        dy_dhd[5, 2] = 1
+        Padd = np.diag([std_pxl ** 2, std_pxl ** 2, std_rho ** 2])
+        P_xv, P_yxv, P_y, P_xvy = PR[:13, :13], PR[13:, :13], PR[13:, 13:], PR[:13, 13:]
+        PR = np.block([[P_xv, P_xvy, P_xv @ dy_dxv.T], [P_yxv, P_y, P_yxv @ dy_dxv.T],
+                       [dy_dxv @ P_xv, dy_dxv @ P_xvy, dy_dxv @ P_xv @ dy_dxv.T + dy_dhd @ Padd @ dy_dhd.T]])
+    return X, PR
+
+
+def map_convert(types, x, P, threshold=0.1):  # inversedepth_2_cartesian.m:27-76
+    X, PR, types = x.copy(), P.copy(), np.array(types, np.int32).copy()
+    conv = np.zeros(len(types), np.int32)
+    for i in range(len(types)):
+        if types[i] != INVDEPTH:
+            continue
+        o = 13 + sum(6 if t == INVDEPTH else 3 for t in types[:i])
+        rho, theta, phi = X[o + 5], X[o + 3], X[o + 4]
+        std_d = np.sqrt(PR[o + 5, o + 5]) / rho ** 2
+        mi = m_dir(theta, phi)
+        p = X[o:o + 3] + mi / rho
+        a, c2 = p - X[o:o + 3], p - X[0:3]
+        li = 4 * std_d * (a @ c2) / (np.linalg.norm(a) * np.linalg.norm(c2)) / np.linalg.norm(c2)
+        if li < threshold:
+            n0 = X.shape[0]
+            J = np.hstack([np.eye(3), (np.array([np.cos(phi) * np.cos(theta), 0, -np.cos(phi) * np.sin(theta)]) / rho)[:, None],
+                           (np.array([-np.sin(phi) * np.sin(theta), -np.cos(phi), -np.sin(phi) * np.cos(theta)]) / rho)[:, None], (-mi / rho ** 2)[:, None]])
+            Jall = np.zeros((n0 - 3, n0))
+            Jall[:o, :o] = np.eye(o)
+            Jall[o:o + 3, o:o + 6] = J
+            Jall[o + 3:, o + 6:] = np.eye(n0 - o - 6)
+            X = np.concatenate([X[:o], p, X[o + 6:]])
+            PR = Jall @ PR @ Jall.T
+            types[i] = CARTESIAN
+            conv[i] = 1
+    return X, PR, types, conv

@@ -808,3 +808,184 @@ ORC_API int orc_knn(int D, int N, const double *data, int M, const double *query
     free(kv);
     return 0;
 }
+
+/* ------------------------------------------------------------------ map management
+ * (map_management.m:27-79).  UNPINNED: no reference artefact holds a before/after pair of these
+ * operations; checked against the numpy twin and by round-trip / symmetry properties only. */
+
+/* undistort_fm_my_version.m:27-48 (10 Newton steps) */
+static void undistort_fm(const orc_cam *cam, const double uvd[2], double uv[2])
+{
+    double xd = (uvd[0] - cam->Cx) / cam->f, yd = (uvd[1] - cam->Cy) / cam->f;
+    double rd = sqrt(xd * xd + yd * yd);
+    double ru = rd / (1 + cam->k1 * rd * rd + cam->k2 * pow(rd, 4));
+    for (int k = 0; k < 10; ++k) {
+        double f1 = ru + cam->k1 * pow(ru, 3) + cam->k2 * pow(ru, 5) - rd;
+        double f1p = 1 + 3 * cam->k1 * ru * ru + 5 * cam->k2 * pow(ru, 4);
+        ru = ru - f1 / f1p;
+    }
+    double D = 1 + cam->k1 * ru * ru + cam->k2 * pow(ru, 4);
+    uv[0] = cam->f * xd / D + cam->Cx;
+    uv[1] = cam->f * yd / D + cam->Cy;
+}
+
+/* delete_a_feature.m:47-51 applied to the landmarks del[n_del] (ascending; delete_features.m:54-74 deletes
+ * from the back so that indices stay valid).  Returns the new state size. */
+ORC_API int orc_map_delete(int n, int N, const int *lm_type, const int *lm_off, int n_del, const int *del,
+                           const double *x, const double *P, double *x_out, double *P_out)
+{
+    int *keep = (int *)malloc(sizeof(int) * n);
+    int nn = 0;
+    for (int i = 0; i < 13; ++i) keep[nn++] = i;
+    int d = 0;
+    for (int i = 0; i < N; ++i) {
+        int dim = lm_type[i] == ORC_INVDEPTH ? 6 : 3;
+        if (d < n_del && del[d] == i) { ++d; continue; }
+        for (int c = 0; c < dim; ++c) keep[nn++] = lm_off[i] + c;
+    }
+    for (int a = 0; a < nn; ++a) {
+        x_out[a] = x[keep[a]];
+        for (int b = 0; b < nn; ++b) P_out[(size_t)a * nn + b] = P[(size_t)keep[a] * n + keep[b]];
+    }
+    free(keep);
+    return nn;
+}
+
+/* add_features_inverse_depth.m:27-47 -> hinv_my_version.m:26-53 + add_a_feature_covariance_inverse_depth.m:27-90,
+ * one feature appended after the other.  x_out/P_out hold n + 6*n_new entries per dimension. */
+ORC_API int orc_map_add(int n, int n_new, const double *uvd, double std_pxl, const double *initial_rho, const orc_cam *cam,
+                        const double *x, const double *P, double *x_out, double *P_out)
+{
+    int cur = n;
+    int nmax = n + 6 * n_new;
+    double *Pc = (double *)calloc((size_t)nmax * nmax, sizeof(double));
+    for (int i = 0; i < n; ++i) { x_out[i] = x[i]; for (int j = 0; j < n; ++j) Pc[(size_t)i * nmax + j] = P[(size_t)i * n + j]; }
+    double fku = cam->f, fkv = cam->f, U0 = cam->Cx, V0 = cam->Cy;      /* cam.K = [f 0 Cx; 0 f Cy; 0 0 1] */
+    for (int f = 0; f < n_new; ++f) {
+        const double *pix = uvd + 2 * f;
+        double uvu[2];
+        undistort_fm(cam, pix, uvu);
+        double Rwc[9];
+        q2r(x + 3, Rwc);
+        double hc[3] = { -(U0 - uvu[0]) / fku, -(V0 - uvu[1]) / fkv, 1.0 };
+        double nw[3];
+        for (int i = 0; i < 3; ++i) nw[i] = Rwc[i * 3] * hc[0] + Rwc[i * 3 + 1] * hc[1] + Rwc[i * 3 + 2] * hc[2];
+        /* hinv_my_version.m:51 */
+        double ynew[6] = { x[0], x[1], x[2], atan2(nw[0], nw[2]), atan2(-nw[1], sqrt(nw[0] * nw[0] + nw[2] * nw[2])), initial_rho[f] };
+        for (int i = 0; i < 6; ++i) x_out[cur + i] = ynew[i];
+        double std_rho = initial_rho[f] * initial_rho[f] * 0.01;            /* add_features_inverse_depth.m:41 overrides its argument */
+        double Xw = nw[0], Yw = nw[1], Zw = nw[2];
+        double dth[3] = { Zw / (Xw * Xw + Zw * Zw), 0, -Xw / (Xw * Xw + Zw * Zw) };
+        double s2 = Xw * Xw + Yw * Yw + Zw * Zw, sxz = sqrt(Xw * Xw + Zw * Zw);
+        double dph[3] = { (Xw * Yw) / (s2 * sxz), -sxz / s2, (Zw * Yw) / (s2 * sxz) };
+        double dg_dq[12];
+        dRq_times_a_by_dq(x + 3, hc, dg_dq);
+        double dth_dq[4], dph_dq[4];
+        for (int c = 0; c < 4; ++c) {
+            dth_dq[c] = dth[0] * dg_dq[0 * 4 + c] + dth[1] * dg_dq[1 * 4 + c] + dth[2] * dg_dq[2 * 4 + c];
+            dph_dq[c] = dph[0] * dg_dq[0 * 4 + c] + dph[1] * dg_dq[1 * 4 + c] + dph[2] * dg_dq[2 * 4 + c];
+        }
+        double J[6 * 13] = { 0 };                                          /* dy_dxv */
+        J[0 * 13 + 0] = J[1 * 13 + 1] = J[2 * 13 + 2] = 1;
+        for (int c = 0; c < 4; ++c) { J[3 * 13 + 3 + c] = dth_dq[c]; J[4 * 13 + 3 + c] = dph_dq[c]; }
+        /* dy_dhd (6x3) = [dyprima_dgw*dgw_dgc*dgc_dhu*dhu_dhd  0; 0 0 1] */
+        double Jd[4], dhu_dhd[4];
+        jacob_distor(cam, pix, Jd);
+        inv2(Jd, dhu_dhd);                                                  /* jacob_undistor_fm_my_version.m:38 */
+        double dgc_dhu[6] = { 1 / fku, 0,  0, 1 / fkv,  0, 0 };             /* 3x2 */
+        double dyp_dgw[15] = { 0 };                                         /* 5x3: rows 3,4 = dtheta_dgw, dphi_dgw */
+        for (int c = 0; c < 3; ++c) { dyp_dgw[3 * 3 + c] = dth[c]; dyp_dgw[4 * 3 + c] = dph[c]; }
+        double T1[15], T2[10], T3[10];
+        mm(dyp_dgw, Rwc, T1, 5, 3, 3);
+        mm(T1, dgc_dhu, T2, 5, 3, 2);
+        mm(T2, dhu_dhd, T3, 5, 2, 2);
+        double dy_dhd[18] = { 0 };
+        for (int r_ = 0; r_ < 5; ++r_) { dy_dhd[r_ * 3] = T3[r_ * 2]; dy_dhd[r_ * 3 + 1] = T3[r_ * 2 + 1]; }
+        dy_dhd[5 * 3 + 2] = 1;
+        double Padd[9] = { std_pxl * std_pxl, 0, 0,  0, std_pxl * std_pxl, 0,  0, 0, std_rho * std_rho };
+        double T4[18], Nn[36];
+        mm(dy_dhd, Padd, T4, 6, 3, 3);
+        for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) { double s = 0; for (int t = 0; t < 3; ++t) s += T4[i * 3 + t] * dy_dhd[j * 3 + t]; Nn[i * 6 + j] = s; }
+        /* new rows: dy_dxv*[P_xv P_xvy] ; new cols: [P_xv; P_yxv]*dy_dxv' ; corner: dy_dxv*P_xv*dy_dxv' + Nn */
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < cur; ++j) {
+                double s = 0, c2 = 0;
+                for (int t = 0; t < 13; ++t) { s += J[i * 13 + t] * Pc[(size_t)t * nmax + j]; c2 += Pc[(size_t)j * nmax + t] * J[i * 13 + t]; }
+                Pc[(size_t)(cur + i) * nmax + j] = s;
+                Pc[(size_t)j * nmax + cur + i] = c2;
+            }
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 6; ++j) {
+                double s = 0;
+                for (int t = 0; t < 13; ++t) s += Pc[(size_t)(cur + i) * nmax + t] * J[j * 13 + t];       /* (dy_dxv*P_xv)*dy_dxv' */
+                Pc[(size_t)(cur + i) * nmax + cur + j] = s + Nn[i * 6 + j];
+            }
+        cur += 6;
+    }
+    for (int i = 0; i < cur; ++i) for (int j = 0; j < cur; ++j) P_out[(size_t)i * cur + j] = Pc[(size_t)i * nmax + j];
+    free(Pc);
+    return cur;
+}
+
+/* inversedepth_2_cartesian.m:27-76.  converted[N] receives the flags; lm_type_out the new types.  Landmarks are
+ * processed in order on the evolving (X, P) exactly as the reference does.  Returns the new state size. */
+ORC_API int orc_map_convert(int n, int N, const int *lm_type, double threshold, const double *x, const double *P,
+                            double *x_out, double *P_out, int *lm_type_out, int *converted)
+{
+    int cur = n;
+    double *X = (double *)malloc(sizeof(double) * n), *Pc = (double *)malloc(sizeof(double) * (size_t)n * n);
+    double *Pn = (double *)malloc(sizeof(double) * (size_t)n * n), *T = (double *)malloc(sizeof(double) * (size_t)n * n);
+    memcpy(X, x, sizeof(double) * n);
+    memcpy(Pc, P, sizeof(double) * (size_t)n * n);
+    for (int i = 0; i < N; ++i) { lm_type_out[i] = lm_type[i]; converted[i] = 0; }
+    for (int i = 0; i < N; ++i) {
+        if (lm_type_out[i] != ORC_INVDEPTH) continue;
+        int o = 13;
+        for (int j = 0; j < i; ++j) o += lm_type_out[j] == ORC_INVDEPTH ? 6 : 3;
+        double std_rho = sqrt(Pc[(size_t)(o + 5) * cur + o + 5]);
+        double rho = X[o + 5], std_d = std_rho / (rho * rho), theta = X[o + 3], phi = X[o + 4];
+        double mi[3];
+        m_dir(theta, phi, mi);
+        double p[3] = { X[o] + (1 / rho) * mi[0], X[o + 1] + (1 / rho) * mi[1], X[o + 2] + (1 / rho) * mi[2] };   /* inversedepth2cartesian.m */
+        double a[3] = { p[0] - X[o], p[1] - X[o + 1], p[2] - X[o + 2] }, c2[3] = { p[0] - X[0], p[1] - X[1], p[2] - X[2] };
+        double d_c2p = sqrt(c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2]);
+        double cos_alpha = (a[0] * c2[0] + a[1] * c2[1] + a[2] * c2[2]) / (sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) * d_c2p);
+        double li = 4 * std_d * cos_alpha / d_c2p;
+        if (!(li < threshold)) continue;
+        double dmt[3] = { cos(phi) * cos(theta), 0, -cos(phi) * sin(theta) };
+        double dmp[3] = { -sin(phi) * sin(theta), -cos(phi), -sin(phi) * cos(theta) };
+        double J[18];
+        for (int r_ = 0; r_ < 3; ++r_) {
+            for (int c = 0; c < 3; ++c) J[r_ * 6 + c] = r_ == c ? 1 : 0;
+            J[r_ * 6 + 3] = (1 / rho) * dmt[r_]; J[r_ * 6 + 4] = (1 / rho) * dmp[r_]; J[r_ * 6 + 5] = -mi[r_] / (rho * rho);
+        }
+        int nn = cur - 3;
+        /* T = J_all * P (nn x cur), Pn = T * J_all' (nn x nn) */
+        for (int a2 = 0; a2 < nn; ++a2)
+            for (int j = 0; j < cur; ++j) {
+                double s;
+                if (a2 < o) s = Pc[(size_t)a2 * cur + j];
+                else if (a2 < o + 3) { s = 0; for (int t = 0; t < 6; ++t) s += J[(a2 - o) * 6 + t] * Pc[(size_t)(o + t) * cur + j]; }
+                else s = Pc[(size_t)(a2 + 3) * cur + j];
+                T[(size_t)a2 * cur + j] = s;
+            }
+        for (int a2 = 0; a2 < nn; ++a2)
+            for (int b2 = 0; b2 < nn; ++b2) {
+                double s;
+                if (b2 < o) s = T[(size_t)a2 * cur + b2];
+                else if (b2 < o + 3) { s = 0; for (int t = 0; t < 6; ++t) s += T[(size_t)a2 * cur + o + t] * J[(b2 - o) * 6 + t]; }
+                else s = T[(size_t)a2 * cur + b2 + 3];
+                Pn[(size_t)a2 * nn + b2] = s;
+            }
+        for (int t = 0; t < 3; ++t) X[o + t] = p[t];
+        memmove(X + o + 3, X + o + 6, sizeof(double) * (cur - o - 6));
+        memcpy(Pc, Pn, sizeof(double) * (size_t)nn * nn);
+        cur = nn;
+        lm_type_out[i] = ORC_CARTESIAN;
+        converted[i] = 1;
+    }
+    memcpy(x_out, X, sizeof(double) * cur);
+    memcpy(P_out, Pc, sizeof(double) * (size_t)cur * cur);
+    free(X); free(Pc); free(Pn); free(T);
+    return cur;
+}
