@@ -106,6 +106,21 @@ void mexFunction(int nout, mxArray *out[], int nin, const mxArray *in[])
         for (i = 0; i < m; ++i) mxGetPr(out[0])[i] = hi[i];
         mxFree(hi); check(rc);
     }
+    else if (!strcmp(cmd, "map_delete")) {        /* pre3_mex('map_delete', idx (0-based, ascending))   delete_features.m:54-74 */
+        int k = (int)mxGetNumberOfElements(in[1]), i, rc; int32_t *d = (int32_t *)mxMalloc(sizeof(int32_t) * (k ? k : 1));
+        for (i = 0; i < k; ++i) d[i] = (int32_t)mxGetPr(in[1])[i];
+        rc = pre3_map_delete(g_ctx, k, d); mxFree(d); check(rc);
+    }
+    else if (!strcmp(cmd, "map_add")) {           /* pre3_mex('map_add', uvd (2xk), std_pxl, initial_rho (1xk))   add_features_inverse_depth.m:27-47 */
+        check(pre3_map_add_inverse_depth(g_ctx, (int)mxGetN(in[1]), mxGetPr(in[1]), mxGetScalar(in[2]), mxGetPr(in[3])));
+    }
+    else if (!strcmp(cmd, "map_convert")) {       /* converted = pre3_mex('map_convert', 0.1)   inversedepth_2_cartesian.m:27-76 */
+        int N = pre3_get_map(g_ctx, NULL), i, rc; int32_t *f = (int32_t *)mxCalloc(N ? N : 1, sizeof(int32_t));
+        rc = pre3_map_inversedepth_2_cartesian(g_ctx, mxGetScalar(in[1]), f);
+        out[0] = mxCreateDoubleMatrix(1, N, mxREAL);
+        for (i = 0; i < N; ++i) mxGetPr(out[0])[i] = f[i];
+        mxFree(f); check(rc);
+    }
     else if (!strcmp(cmd, "destroy")) { at_exit(); if (mexIsLocked()) mexUnlock(); }
     else mexErrMsgTxt("pre3_mex: unknown command");
 }

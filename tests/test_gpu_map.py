@@ -49,7 +49,7 @@ def test_add_inverse_depth(pre3, orc, dtype):
     assert np.abs(P - Po).max() < TOL[dtype] * np.abs(Po).max()
     n = seq["x0"].shape[0]
     assert np.array_equal(P[:n, :n], P0)                    # the old block is copied, not recomputed
-    assert np.abs(P - P.T).max() <= 1e-7 * TOL[dtype] * np.abs(Po).max() + 1e-22
+    assert np.abs(P - P.T).max() <= {"f64": 1e-15, "f32": 2e-7}[dtype] * np.abs(Po).max()    # rounding only, as in the reference's own J P J'
     # add -> delete round trip restores the state bit for bit
     f.delete_features(range(30, 37))
     assert np.array_equal(f.get_x_k_k(), seq["x0"]) and np.array_equal(f.get_p_k_k(), P0)
