@@ -212,7 +212,7 @@ int pre3_destroy(pre3_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
                      c->lm.li, c->lm.hi, c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
-                     c->sel_rows, c->support, c->masks, c->stats, c->li_meas, c->hi_meas, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags };
+                     c->sel_rows, c->support, c->masks, c->stats, c->li_meas, c->hi_meas, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_pairs, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->pinned_stats) (void)hipHostFree(c->pinned_stats);
     if (c->inbox_host) (void)hipHostFree(c->inbox_host);
@@ -436,6 +436,93 @@ int pre3_window_gate(pre3_ctx *c, int M, const int32_t *k1, const double *zc, in
     for (int i = 0; i < N; ++i) if (flag[i]) meas.push_back(i);
     if (accept_out) for (int q = 0; q < M; ++q) accept_out[q] = acc[q];
     // z was written on the device by the gate kernel; keep it (z == nullptr)
+    return install_measurements(c, (int)meas.size(), meas.data(), nullptr, nullptr, 0);
+}
+
+// ---- IC search on the device ---------------------------------------------------------
+static int ensure_ic_buffers(pre3_ctx *c)
+{
+    if (c->bank) return PRE3_OK;
+    const size_t N = (size_t)c->capN;
+    PRE3_TRY(dmalloc(&c->bank, N * DESC_DIM)); PRE3_TRY(dmalloc(&c->bank_alt, N * DESC_DIM));
+    PRE3_TRY(dmalloc(&c->ic_pred, N)); PRE3_TRY(dmalloc(&c->ic_counts, 4)); PRE3_TRY(dmalloc(&c->ic_arg, N)); PRE3_TRY(dmalloc(&c->ic_pairs, 3 * N));
+    PRE3_TRY(dmalloc(&c->ic_newk2, N)); PRE3_TRY(dmalloc(&c->ic_best, N)); PRE3_TRY(dmalloc(&c->ic_second, N)); PRE3_TRY(dmalloc(&c->bank_src, N));
+    PRE3_HIP(hipMemset(c->bank, 0, sizeof(double) * N * DESC_DIM));
+    return PRE3_OK;
+}
+
+int pre3_set_descriptors(pre3_ctx *c, int first, int count, const double *desc)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(first >= 0 && count >= 0 && first + count <= c->N && (count == 0 || desc), PRE3_E_ARG, "pre3_set_descriptors: range [%d, %d) outside the map (N=%d)", first, first + count, c->N);
+    PRE3_TRY(ensure_ic_buffers(c));
+    PRE3_HIP(hipStreamSynchronize(c->stream));
+    if (count) PRE3_HIP(hipMemcpy(c->bank + (size_t)first * DESC_DIM, desc, sizeof(double) * (size_t)count * DESC_DIM, hipMemcpyHostToDevice));
+    c->bank_set = true;
+    return PRE3_OK;
+}
+
+int pre3_get_descriptors(pre3_ctx *c, int first, int count, double *desc)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(first >= 0 && count >= 0 && first + count <= c->N && (count == 0 || desc), PRE3_E_ARG, "pre3_get_descriptors: range outside the map");
+    PRE3_CHECK(c->bank_set, PRE3_E_STATE, "pre3_get_descriptors: no descriptors have been set");
+    PRE3_HIP(hipStreamSynchronize(c->stream));
+    if (count) PRE3_HIP(hipMemcpy(desc, c->bank + (size_t)first * DESC_DIM, sizeof(double) * (size_t)count * DESC_DIM, hipMemcpyDeviceToHost));
+    return PRE3_OK;
+}
+
+int pre3_set_scan(pre3_ctx *c, int K2, const double *descriptor_raw, const double *scale_orient_pos_raw)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(K2 >= 0 && (K2 == 0 || (descriptor_raw && scale_orient_pos_raw)), PRE3_E_ARG, "pre3_set_scan: bad arguments");
+    PRE3_HIP(hipStreamSynchronize(c->stream));
+    if (K2 > c->scan_cap) {
+        if (c->scan_desc) (void)hipFree(c->scan_desc);
+        if (c->scan_pos) (void)hipFree(c->scan_pos);
+        c->scan_desc = c->scan_pos = nullptr; c->scan_cap = 0;
+        const int cap = round_up(K2, 256);
+        PRE3_TRY(dmalloc(&c->scan_desc, (size_t)cap * DESC_DIM)); PRE3_TRY(dmalloc(&c->scan_pos, (size_t)cap * 4));
+        c->scan_cap = cap;
+    }
+    if (K2) {
+        PRE3_HIP(hipMemcpy(c->scan_desc, descriptor_raw, sizeof(double) * (size_t)K2 * DESC_DIM, hipMemcpyHostToDevice));
+        PRE3_HIP(hipMemcpy(c->scan_pos, scale_orient_pos_raw, sizeof(double) * (size_t)K2 * 4, hipMemcpyHostToDevice));
+    }
+    c->scan_K2 = K2;
+    return PRE3_OK;
+}
+
+int pre3_ic_search(pre3_ctx *c, double thresh, int strict_reference, int32_t *n_matches_out, int32_t *m_out, int32_t *meas_idx_out,
+                   double *z_out, int32_t *pairs_out)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(c->bank_set, PRE3_E_STATE, "pre3_ic_search: call pre3_set_descriptors first");
+    PRE3_CHECK(c->scan_K2 >= 0 && (c->scan_K2 == 0 || c->scan_desc), PRE3_E_STATE, "pre3_ic_search: call pre3_set_scan first");
+    PRE3_CHECK(c->x_valid[PRE3_X_K_KM1] && c->p_which == PRE3_X_K_KM1, PRE3_E_STATE, "pre3_ic_search: needs the predicted estimate (call pre3_predict first)");
+    PRE3_CHECK(m_out != nullptr, PRE3_E_ARG, "pre3_ic_search: null m_out");
+    const int N = c->N;
+    // search_IC_matches.m:31-44: h, H and S for every landmark at the prediction
+    PRE3_TRY(pre3_project(c, PRE3_X_K_KM1, 1));
+    PRE3_TRY(pre3_innovation(c));
+    PRE3_HIP(hipMemsetAsync(c->lm.ic, 0, sizeof(int32_t) * (N ? N : 1), c->stream));
+    PRE3_TRY(launch_ic_search(c, thresh, strict_reference));
+    PRE3_HIP(hipStreamSynchronize(c->stream));
+    int32_t counts[4] = { 0, 0, 0, 0 };
+    PRE3_HIP(hipMemcpy(counts, c->ic_counts, sizeof(counts), hipMemcpyDeviceToHost));
+    std::vector<int32_t> ic(N ? N : 1, 0), meas;
+    if (N) PRE3_HIP(hipMemcpy(ic.data(), c->lm.ic, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+    for (int i = 0; i < N; ++i) if (ic[i]) meas.push_back(i);
+    PRE3_CHECK((int)meas.size() == counts[2], PRE3_E_STATE, "pre3_ic_search: accepted-count mismatch (%zu vs %d)", meas.size(), counts[2]);
+    if (n_matches_out) *n_matches_out = counts[1];
+    if (pairs_out && counts[1]) PRE3_HIP(hipMemcpy(pairs_out, c->ic_pairs, sizeof(int32_t) * 3 * counts[1], hipMemcpyDeviceToHost));
+    *m_out = (int)meas.size();
+    if (meas_idx_out) for (size_t j = 0; j < meas.size(); ++j) meas_idx_out[j] = meas[j];
+    if (z_out && !meas.empty()) {
+        std::vector<double> z(2 * (size_t)N);
+        PRE3_HIP(hipMemcpy(z.data(), c->lm.z, sizeof(double) * 2 * N, hipMemcpyDeviceToHost));
+        for (size_t j = 0; j < meas.size(); ++j) { z_out[2 * j] = z[2 * meas[j]]; z_out[2 * j + 1] = z[2 * meas[j] + 1]; }
+    }
     return install_measurements(c, (int)meas.size(), meas.data(), nullptr, nullptr, 0);
 }
 

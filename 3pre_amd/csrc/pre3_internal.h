@@ -121,6 +121,11 @@ struct pre3_ctx {
     void *P_alt = nullptr; double *x_alt = nullptr; int32_t *map_col = nullptr; void *map_val = nullptr; int32_t *map_desc = nullptr;
     double *map_feat = nullptr; int32_t *map_flags = nullptr;
     std::vector<int32_t> lm_type_host;
+    // IC search (matching_sift_based.m): landmark descriptor bank [capN][128], the current scan's SIFT set, match scratch
+    double *bank = nullptr, *bank_alt = nullptr; bool bank_set = false;
+    double *scan_desc = nullptr, *scan_pos = nullptr; int scan_K2 = 0, scan_cap = 0;
+    int32_t *ic_pred = nullptr, *ic_counts = nullptr, *ic_arg = nullptr, *ic_pairs = nullptr, *ic_newk2 = nullptr; double *ic_best = nullptr, *ic_second = nullptr;
+    int32_t *bank_src = nullptr;
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;
     pre3::KernelTiming kt;
@@ -129,6 +134,11 @@ struct pre3_ctx {
 };
 
 namespace pre3 {
+
+// ---- IC search (pre3_match.hip)
+int launch_ic_search(pre3_ctx *c, double thresh, int strict);
+int launch_bank_gather(pre3_ctx *c, int N_new, const int32_t *src_host);
+constexpr int DESC_DIM = 128;
 
 // ---- geometry / RANSAC kernels (pre3_geom.hip)
 int launch_project(pre3_ctx *c, int which, int clear_first);

@@ -213,7 +213,7 @@ static int ensure_map_buffers(pre3_ctx *c)
 
 // apply the state map described by desc (3 ints per new row), then install the new landmark table
 static int apply_map(pre3_ctx *c, const std::vector<int32_t> &desc, int n_new, const std::vector<int32_t> &new_types,
-                     int n_feat, int first_new_off)
+                     int n_feat, int first_new_off, const std::vector<int32_t> &lm_src)
 {
     PRE3_CHECK(n_new <= c->capn && (int)new_types.size() <= c->capN, PRE3_E_ARG, "map management: the new map (N=%zu, n=%d) exceeds the context capacity (N=%d, n=%d)",
                new_types.size(), n_new, c->capN, c->capn);
@@ -250,6 +250,7 @@ static int apply_map(pre3_ctx *c, const std::vector<int32_t> &desc, int n_new, c
     PRE3_HIP(hipMemset(c->lm.has_h, 0, sizeof(int32_t) * c->capN)); PRE3_HIP(hipMemset(c->lm.has_S, 0, sizeof(int32_t) * c->capN));
     PRE3_HIP(hipMemset(c->inbox_dev, 0, c->inbox_bytes)); PRE3_HIP(hipMemset(c->lm.li, 0, sizeof(int32_t) * c->capN));
     PRE3_HIP(hipMemset(c->lm.hi, 0, sizeof(int32_t) * c->capN));
+    PRE3_TRY(launch_bank_gather(c, N, lm_src.data()));
     c->N = N; c->n = n; c->lm_type_host = new_types;
     c->m = 0; c->meas_host.clear(); c->measurements_set = false; c->projected = false; c->innovated = false; c->hp_all_valid = false;
     c->li_from_host = c->hi_from_host = -1; c->li_kernel = c->hi_kernel = false;
@@ -285,17 +286,17 @@ int pre3_map_delete(pre3_ctx *c, int n_del, const int32_t *del_idx)
     for (int d = 0; d < n_del; ++d)
         PRE3_CHECK(del_idx[d] >= 0 && del_idx[d] < c->N && (d == 0 || del_idx[d] > del_idx[d - 1]), PRE3_E_ARG, "pre3_map_delete: indices must be ascending and in range");
     if (n_del == 0) return PRE3_OK;
-    std::vector<int32_t> desc, types;
+    std::vector<int32_t> desc, types, src;
     for (int i = 0; i < 13; ++i) { desc.push_back(0); desc.push_back(i); desc.push_back(0); }
     int d = 0, off = 13;
     for (int i = 0; i < c->N; ++i) {
         const int dim = c->lm_type_host[i] == PRE3_INVDEPTH ? 6 : 3;
         if (d < n_del && del_idx[d] == i) { ++d; off += dim; continue; }
         for (int q = 0; q < dim; ++q) { desc.push_back(0); desc.push_back(off + q); desc.push_back(0); }
-        types.push_back(c->lm_type_host[i]);
+        types.push_back(c->lm_type_host[i]); src.push_back(i);
         off += dim;
     }
-    return apply_map(c, desc, (int)desc.size() / 3, types, 0, 0);
+    return apply_map(c, desc, (int)desc.size() / 3, types, 0, 0, src);
 }
 
 int pre3_map_add_inverse_depth(pre3_ctx *c, int n_new, const double *uvd, double std_pxl, const double *initial_rho)
@@ -313,13 +314,14 @@ int pre3_map_add_inverse_depth(pre3_ctx *c, int n_new, const double *uvd, double
     CamM cam{ c->cam.f, c->cam.Cx, c->cam.Cy, c->cam.k1, c->cam.k2 };
     hipLaunchKernelGGL(k_map_new_features, dim3(ceil_div(n_new, 64)), dim3(64), 0, c->stream, n_new, d_uvd, d_uvd + 2 * n_new, std_pxl, c->x_kk, cam, c->map_feat);
     PRE3_HIP(hipGetLastError());
-    std::vector<int32_t> desc, types(c->lm_type_host);
+    std::vector<int32_t> desc, types(c->lm_type_host), src;
+    for (int i = 0; i < c->N; ++i) src.push_back(i);
     for (int i = 0; i < c->n; ++i) { desc.push_back(0); desc.push_back(i); desc.push_back(0); }
     for (int f = 0; f < n_new; ++f) {
         for (int q = 0; q < 6; ++q) { desc.push_back(1); desc.push_back(f); desc.push_back(q); }
-        types.push_back(PRE3_INVDEPTH);
+        types.push_back(PRE3_INVDEPTH); src.push_back(-1);
     }
-    return apply_map(c, desc, c->n + 6 * n_new, types, n_new, c->n);
+    return apply_map(c, desc, c->n + 6 * n_new, types, n_new, c->n, src);
 }
 
 int pre3_map_inversedepth_2_cartesian(pre3_ctx *c, double thr, int32_t *converted_out)
@@ -338,7 +340,8 @@ int pre3_map_inversedepth_2_cartesian(pre3_ctx *c, double thr, int32_t *converte
     bool any = false;
     for (int i = 0; i < N; ++i) any |= flags[i] != 0;
     if (!any) return PRE3_OK;
-    std::vector<int32_t> desc, types;
+    std::vector<int32_t> desc, types, src;
+    for (int i = 0; i < N; ++i) src.push_back(i);
     for (int i = 0; i < 13; ++i) { desc.push_back(0); desc.push_back(i); desc.push_back(0); }
     int off = 13;
     for (int i = 0; i < N; ++i) {
@@ -352,7 +355,7 @@ int pre3_map_inversedepth_2_cartesian(pre3_ctx *c, double thr, int32_t *converte
         }
         off += dim;
     }
-    return apply_map(c, desc, (int)desc.size() / 3, types, 0, 0);
+    return apply_map(c, desc, (int)desc.size() / 3, types, 0, 0, src);
 }
 
 }  // extern "C"

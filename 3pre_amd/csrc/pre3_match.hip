@@ -48,13 +48,16 @@ __device__ inline void push3(ACC &best, ACC &second, int &k, ACC v, int idx)
 // L1: ND x K1, L2: ND x K2 column-major.  Outputs per query: best, second (as double), arg (global index).
 template <typename T, typename ACC>
 __global__ __launch_bounds__(256) void k_match_exact(int ND, int K2, const T *__restrict__ L1, const T *__restrict__ L2, int k2_offset,
-                                                     double *__restrict__ obest, double *__restrict__ osecond, int32_t *__restrict__ oarg)
+                                                     double *__restrict__ obest, double *__restrict__ osecond, int32_t *__restrict__ oarg,
+                                                     const int32_t *__restrict__ qidx = nullptr, const int32_t *__restrict__ nq = nullptr)
 {
 #pragma clang fp contract(off)
     extern __shared__ unsigned char smem_raw[];
     ACC *q = reinterpret_cast<ACC *>(smem_raw);
     const int k1 = blockIdx.x, tid = threadIdx.x;
-    for (int b = tid; b < ND; b += blockDim.x) q[b] = (ACC)L1[(size_t)k1 * ND + b];
+    if (nq && k1 >= *nq) return;                       // IC search: the query count is only known on the device
+    const size_t qcol = qidx ? (size_t)qidx[k1] : (size_t)k1;
+    for (int b = tid; b < ND; b += blockDim.x) q[b] = (ACC)L1[qcol * ND + b];
     __syncthreads();
     ACC best = acc_max<ACC>(), second = acc_max<ACC>();
     int bk = -1;
@@ -330,6 +333,103 @@ int match_partial(int device, int cls, int ND, int K1, const void *L1, int K2, c
     case 3: return partial_i8<int8_t>(ND, K1, (const int8_t *)L1, K2, (const int8_t *)L2, 0, k2_offset, best, second, arg);
     default: set_error("siftmatch: unsupported class %d", cls); return PRE3_E_ARG;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// IC search on the device: matching_sift_based.m:104-149 without leaving HBM.
+// ------------------------------------------------------------------------------------------------
+// index_in_info (matching_sift_based.m:108-114): the predicted landmarks in map order.  One wave.
+__global__ void k_ic_stack(int N, const int32_t *__restrict__ has_h, int32_t *__restrict__ pred, int32_t *__restrict__ counts,
+                           int32_t *__restrict__ newk2)
+{
+    const int lane = threadIdx.x;
+    int base = 0;
+    for (int i0 = 0; i0 < N; i0 += 64) {
+        const int i = i0 + lane;
+        const int f = i < N && has_h[i] != 0;
+        if (i < N) newk2[i] = -1;
+        const unsigned long long b = __ballot(f);
+        if (f) pred[base + __popcll(b & ((1ull << lane) - 1))] = i;
+        base += __popcll(b);
+    }
+    if (lane == 0) { counts[0] = base; counts[1] = 0; counts[2] = 0; }
+}
+
+// Lowe's test (siftmatch.c:122, in float), then the window gate of matching_sift_based.m:119-133 on the i-th match
+// (quirk Q5 needs the RANK of the match: S is read from index_in_info(i)).  One wave, ordered.
+__global__ void k_ic_gate(const int32_t *__restrict__ pred, const double *__restrict__ best,
+                          const double *__restrict__ second, const int32_t *__restrict__ arg, float thresh, int strict,
+                          const double *__restrict__ pos, const double *__restrict__ h, const double *__restrict__ S,
+                          const int32_t *__restrict__ has_S, double *__restrict__ z, int32_t *__restrict__ ic,
+                          int32_t *__restrict__ pairs, int32_t *__restrict__ newk2, int32_t *counts)
+{
+    const int lane = threadIdx.x, npred = counts[0];
+    int base = 0, m = 0;
+    for (int k0 = 0; k0 < npred; k0 += 64) {
+        const int k1 = k0 + lane;
+        int ok = 0, k2 = -1;
+        if (k1 < npred) {
+            k2 = arg[k1];
+            ok = k2 >= 0 && thresh * (float)best[k1] <= (float)second[k1];
+        }
+        const unsigned long long b = __ballot(ok);
+        int acc = 0;
+        if (ok) {
+            const int c = base + __popcll(b & ((1ull << lane) - 1));
+            const int lm = pred[k1], slm = strict ? pred[c] : lm;
+            const double half = has_S[slm] ? ceil(3 * sqrt(S[4 * slm])) : 40.0;
+            const double dx = pos[4 * (size_t)k2] - h[2 * lm], dy = pos[4 * (size_t)k2 + 1] - h[2 * lm + 1];
+            acc = sqrt(dx * dx + dy * dy) <= half;
+            pairs[3 * c] = k1; pairs[3 * c + 1] = k2; pairs[3 * c + 2] = acc;
+            if (acc) { ic[lm] = 1; z[2 * lm] = pos[4 * (size_t)k2]; z[2 * lm + 1] = pos[4 * (size_t)k2 + 1]; newk2[lm] = k2; }
+        }
+        base += __popcll(b);
+        m += __popcll(__ballot(acc));
+    }
+    if (lane == 0) { counts[1] = base; counts[2] = m; }
+}
+
+// matching_sift_based.m:135: the accepted landmark takes the scan's descriptor
+__global__ void k_ic_refresh(const int32_t *__restrict__ newk2, const double *__restrict__ scan_desc, double *__restrict__ bank)
+{
+    const int lm = blockIdx.x, k2 = newk2[lm];
+    if (k2 < 0) return;
+    bank[(size_t)lm * DESC_DIM + threadIdx.x] = scan_desc[(size_t)k2 * DESC_DIM + threadIdx.x];
+}
+
+__global__ void k_bank_gather(const int32_t *__restrict__ src, const double *__restrict__ bank, double *__restrict__ out)
+{
+    const int s = src[blockIdx.x];
+    out[(size_t)blockIdx.x * DESC_DIM + threadIdx.x] = s >= 0 ? bank[(size_t)s * DESC_DIM + threadIdx.x] : 0.0;
+}
+
+int launch_ic_search(pre3_ctx *c, double thresh, int strict)
+{
+    const int N = c->N;
+    hipLaunchKernelGGL(k_ic_stack, dim3(1), dim3(64), 0, c->stream, N, c->lm.has_h, c->ic_pred, c->ic_counts, c->ic_newk2);
+    if (c->scan_K2 > 0) {
+        hipLaunchKernelGGL((k_match_exact<double, double>), dim3(N), dim3(256), sizeof(double) * DESC_DIM, c->stream, DESC_DIM, c->scan_K2,
+                           (const double *)c->bank, (const double *)c->scan_desc, 0, c->ic_best, c->ic_second, c->ic_arg,
+                           (const int32_t *)c->ic_pred, (const int32_t *)c->ic_counts);
+        hipLaunchKernelGGL(k_ic_gate, dim3(1), dim3(64), 0, c->stream, c->ic_pred, c->ic_best, c->ic_second, c->ic_arg,
+                           (float)thresh, strict, c->scan_pos, c->lm.h, c->lm.S, c->lm.has_S, c->lm.z, c->lm.ic, c->ic_pairs, c->ic_newk2,
+                           c->ic_counts);
+        hipLaunchKernelGGL(k_ic_refresh, dim3(N), dim3(DESC_DIM), 0, c->stream, c->ic_newk2, c->scan_desc, c->bank);
+    }
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
+// re-lay the descriptor bank after map management: new landmark i takes the descriptor of old landmark src[i] (-1: zeros)
+int launch_bank_gather(pre3_ctx *c, int N_new, const int32_t *src_host)
+{
+    if (!c->bank || N_new == 0) return PRE3_OK;
+    PRE3_HIP(hipMemcpyAsync(c->bank_src, src_host, sizeof(int32_t) * N_new, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_bank_gather, dim3(N_new), dim3(DESC_DIM), 0, c->stream, c->bank_src, c->bank, c->bank_alt);
+    PRE3_HIP(hipGetLastError());
+    PRE3_HIP(hipStreamSynchronize(c->stream));       // src_host is the caller's stack vector
+    std::swap(c->bank, c->bank_alt);
+    return PRE3_OK;
 }
 
 int knn_run(int device, int D, int N, const double *data, int M, const double *query, int k, double *ids, double *dist)

@@ -117,6 +117,36 @@ class EkfFilter:
         self._refresh_map()
         return conv
 
+    # ---- IC search on the device (search_IC_matches.m:31-44 + matching_sift_based.m:104-149)
+    def set_descriptors(self, desc, first=0):
+        """features_info(first+i).Descriptor; desc is (128, count) as MATLAB stores it (or (count, 128) C-order rows)."""
+        desc = np.asarray(desc, dtype=np.float64)
+        cols = np.ascontiguousarray(desc.T) if desc.shape[0] == 128 and desc.ndim == 2 else f64(desc)
+        assert cols.ndim == 2 and cols.shape[1] == 128, "descriptors are 128-vectors"
+        check(lib.pre3_set_descriptors(self._ctx, int(first), int(cols.shape[0]), dptr(cols)))
+
+    def get_descriptors(self):
+        out = np.zeros((max(self.N, 1), 128))
+        check(lib.pre3_get_descriptors(self._ctx, 0, self.N, dptr(out)))
+        return out[:self.N].T.copy()                     # (128, N) like [features_info.Descriptor]
+
+    def load_scan(self, Descriptor_RAW, SCALE_ORIENT_POS_RAW):
+        """SCAN_SIFT.Descriptor_RAW (128 x K2) and SCAN_SIFT.SCALE_ORIENT_POS_RAW (4 x K2) of SIFT_result%04d.mat."""
+        d = np.ascontiguousarray(np.asarray(Descriptor_RAW, dtype=np.float64).reshape(128, -1).T)
+        p = np.ascontiguousarray(np.asarray(SCALE_ORIENT_POS_RAW, dtype=np.float64).reshape(4, -1).T)
+        assert d.shape[0] == p.shape[0], "Descriptor_RAW and SCALE_ORIENT_POS_RAW disagree on K2"
+        check(lib.pre3_set_scan(self._ctx, int(d.shape[0]), dptr(d), dptr(p)))
+
+    def matching_sift_based(self, thresh=1.5, strict_reference=True):
+        """The whole IC-search stage in one call; the accepted matches become the measurement list."""
+        N = max(self.N, 1)
+        nm, m = C.c_int32(0), C.c_int32(0)
+        meas, z, pairs = np.zeros(N, np.int32), np.zeros((N, 2)), np.zeros((N, 3), np.int32)
+        check(lib.pre3_ic_search(self._ctx, C.c_double(thresh), int(bool(strict_reference)), C.byref(nm), C.byref(m), dptr(meas), dptr(z), dptr(pairs)))
+        self.m = int(m.value)
+        return dict(meas_idx=meas[:self.m].copy(), z=z[:self.m].copy(), match_idx=pairs[:nm.value, :2].T.copy(),
+                    accepted=pairs[:nm.value, 2].copy())
+
     # ---- step stages
     def ekf_prediction(self, u):
         u = f64(u)

@@ -177,6 +177,23 @@ PRE3_API int pre3_map_inversedepth_2_cartesian(pre3_ctx *ctx, double linearity_t
 /* current landmark table: returns N, writes lm_type_out[N] if not NULL */
 PRE3_API int pre3_get_map(pre3_ctx *ctx, int32_t *lm_type_out);
 
+/* ---- the IC-search stage on the device (search_IC_matches.m:31-44 + matching_sift_based.m:104-149) ---- */
+/* features_info(i).Descriptor (128 x 1 double each, add_feature_to_info_vector_my_version_sift.m): desc is 128 x count
+ * column-major for landmarks first .. first+count-1.  The bank follows the map through pre3_map_* (deleted landmarks
+ * drop out, new ones start at zero until set). */
+PRE3_API int pre3_set_descriptors(pre3_ctx *ctx, int first, int count, const double *desc);
+PRE3_API int pre3_get_descriptors(pre3_ctx *ctx, int first, int count, double *desc);
+/* the frame's SIFT set as stored in SIFT_result%04d.mat (SIFT_extract_save.m:68-69): SCAN_SIFT.Descriptor_RAW (128 x K2)
+ * and SCAN_SIFT.SCALE_ORIENT_POS_RAW (4 x K2; rows 1:2 = pixel u,v), both column-major doubles. */
+PRE3_API int pre3_set_scan(pre3_ctx *ctx, int K2, const double *descriptor_raw, const double *scale_orient_pos_raw);
+/* One call = search_IC_matches.m:31-44 (h, H, S at the prediction) + matching_sift_based.m:104-149: stack the descriptors
+ * of the predicted landmarks, siftmatch(des1', Descriptor_RAW) (double class, thresh 1.5 in the reference), window
+ * gate (strict_reference = 1 reproduces quirk Q5), z / individually_compatible / descriptor refresh for the accepted.
+ * Outputs: *n_matches = size(match_idx, 2); *m = number of accepted (= measurements installed, ascending landmark order);
+ * meas_idx_out[m], z_out[2m] (optional); pairs_out[3*n_matches] (optional) = (k1, k2, accepted) per match, 0-based. */
+PRE3_API int pre3_ic_search(pre3_ctx *ctx, double thresh, int strict_reference, int32_t *n_matches_out, int32_t *m_out,
+                            int32_t *meas_idx_out, double *z_out, int32_t *pairs_out);
+
 /* ---- a10: sift/siftmatch.c:83-132,139-250 ------------------------------------------------------- */
 /* L1: ND x K1, L2: ND x K2, one descriptor per column (column-major, as mxGetData returns them).
  * pairs_out[2*K1] receives 1-based (k1,k2) doubles in increasing k1 exactly as the MEX writes them

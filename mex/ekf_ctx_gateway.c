@@ -121,6 +121,26 @@ void mexFunction(int nout, mxArray *out[], int nin, const mxArray *in[])
         for (i = 0; i < N; ++i) mxGetPr(out[0])[i] = f[i];
         mxFree(f); check(rc);
     }
+    else if (!strcmp(cmd, "set_descriptors")) {   /* pre3_mex('set_descriptors', [features_info.Descriptor] (128xN), first (0-based)) */
+        check(pre3_set_descriptors(g_ctx, nin > 2 ? (int)mxGetScalar(in[2]) : 0, (int)mxGetN(in[1]), mxGetPr(in[1])));
+    }
+    else if (!strcmp(cmd, "set_scan")) {          /* pre3_mex('set_scan', SCAN_SIFT.Descriptor_RAW, SCAN_SIFT.SCALE_ORIENT_POS_RAW) */
+        check(pre3_set_scan(g_ctx, (int)mxGetN(in[1]), mxGetPr(in[1]), mxGetPr(in[2])));
+    }
+    else if (!strcmp(cmd, "ic_search")) {         /* [meas_idx, z, match_idx] = pre3_mex('ic_search', 1.5, strict)   matching_sift_based.m:104-149 */
+        int N = pre3_get_map(g_ctx, NULL), i, rc; int32_t nm = 0, m = 0;
+        int32_t *meas = (int32_t *)mxCalloc(N ? N : 1, sizeof(int32_t)), *pairs = (int32_t *)mxCalloc(3 * (N ? N : 1), sizeof(int32_t));
+        double *z = (double *)mxCalloc(2 * (N ? N : 1), sizeof(double));
+        rc = pre3_ic_search(g_ctx, mxGetScalar(in[1]), nin > 2 ? (int)mxGetScalar(in[2]) : 1, &nm, &m, meas, z, pairs);
+        if (rc == PRE3_OK) {
+            out[0] = mxCreateDoubleMatrix(1, m, mxREAL);
+            for (i = 0; i < m; ++i) mxGetPr(out[0])[i] = meas[i] + 1;                       /* 1-based landmark numbers */
+            if (nout > 1) { out[1] = mxCreateDoubleMatrix(2, m, mxREAL); memcpy(mxGetPr(out[1]), z, sizeof(double) * 2 * m); }
+            if (nout > 2) { out[2] = mxCreateDoubleMatrix(2, nm, mxREAL);
+                for (i = 0; i < nm; ++i) { mxGetPr(out[2])[2 * i] = pairs[3 * i] + 1; mxGetPr(out[2])[2 * i + 1] = pairs[3 * i + 1] + 1; } }
+        }
+        mxFree(meas); mxFree(pairs); mxFree(z); check(rc);
+    }
     else if (!strcmp(cmd, "destroy")) { at_exit(); if (mexIsLocked()) mexUnlock(); }
     else mexErrMsgTxt("pre3_mex: unknown command");
 }

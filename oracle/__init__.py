@@ -276,3 +276,33 @@ def map_convert(types, x, P, threshold=0.1):
     to, conv = np.zeros(N, np.int32), np.zeros(N, np.int32)
     nn = lib().orc_map_convert(n, N, _p(_i(types)), C.c_double(threshold), _p(x), _p(P), _p(xo), _p(Po), _p(to), _p(conv))
     return xo[:nn].copy(), Po[:nn * nn].reshape(nn, nn).copy(), to, conv
+
+
+def ic_search(types, off, x_km1, P_km1, cam, bank, scan_desc, scan_pos, thresh=1.5, strict=True):
+    """search_IC_matches.m:31-44 + matching_sift_based.m:104-149 composed from the restated pieces.
+    bank (128, N) landmark descriptors, scan_desc (128, K2), scan_pos (4, K2).  Returns the new bank too."""
+    N = len(types)
+    h, has_h = project(types, off, x_km1, cam)
+    Hc, Hl = jacobian(types, off, x_km1, cam, h, has_h)
+    S = innovation(types, off, P_km1, Hc, Hl, has_h)
+    has_S = has_h                                        # search_IC_matches.m:36-43: S exists exactly where h does
+    pred = np.nonzero(has_h)[0].astype(np.int32)
+    out = dict(h=h, has_h=has_h, S=S, pred=pred, match_idx=np.zeros((2, 0), np.int32), accepted=np.zeros(0, np.int32),
+               meas_idx=np.zeros(0, np.int32), z=np.zeros((0, 2)), bank=np.array(bank, dtype=np.float64, copy=True))
+    if pred.size == 0:                                   # matching_sift_based.m:115-117
+        return out
+    des1 = np.ascontiguousarray(np.asarray(bank, dtype=np.float64)[:, pred])
+    pairs, _ = siftmatch(des1, np.asarray(scan_desc, dtype=np.float64), thresh)       # 1-based (2, M)
+    k1 = (pairs[0] - 1).astype(np.int32)
+    k2 = (pairs[1] - 1).astype(np.int32)
+    zc = np.asarray(scan_pos, dtype=np.float64)[0:2, k2].T.copy()
+    acc = window_gate(pred, k1, zc, h, S, has_S, strict)
+    z_all, ic = np.zeros((N, 2)), np.zeros(N, np.int32)
+    for c in range(len(k1)):
+        if acc[c]:
+            lm = pred[k1[c]]
+            ic[lm] = 1; z_all[lm] = zc[c]                                              # matching_sift_based.m:131-132
+            out["bank"][:, lm] = np.asarray(scan_desc)[:, k2[c]]                       # matching_sift_based.m:135
+    meas = np.nonzero(ic)[0].astype(np.int32)
+    out.update(match_idx=np.stack([k1, k2]), accepted=np.asarray(acc, np.int32), meas_idx=meas, z=z_all[meas])
+    return out
