@@ -37,6 +37,29 @@ def triu_pack(P):
     return P[iu]
 
 
+def make_snapshot_sub(K=24):
+    """snapshot3 of the reference's RANSAC_SR4000_result.mat cut down to its first K landmarks, re-saved as a MATLAB v5 file
+    with scipy's writer directly (NOT through 3pre_amd/snapshot.py, so the reader test is independent of our writer)."""
+    m = sio.loadmat(os.path.join(REF, "RANSAC_SR4000_result.mat"), struct_as_record=True, squeeze_me=False)
+    snap = m["snapshot3"][0, 0]
+    fi = snap["features_info"][:, :K].copy()
+    n = 13 + 6 * K
+    for i in range(K):
+        fi[0, i]["H"] = fi[0, i]["H"][:, :n]
+    flt = snap["filter"][0, 0]
+    out = {}
+    for k in flt.dtype.names:
+        v = flt[k]
+        if k in ("x_k_k", "x_k_km1"):
+            v = v[:n]
+        elif k in ("p_k_k", "p_k_km1"):
+            v = v[:n, :n]
+        out[k] = v
+    sio.savemat(os.path.join(OUT, "snapshot3_sub.mat"), {"snapshot3": {"features_info": fi, "filter": out, "step": snap["step"]}},
+                format="5", do_compression=True, long_field_names=True)
+    print("snapshot3_sub.mat", os.path.getsize(os.path.join(OUT, "snapshot3_sub.mat")), "bytes")
+
+
 def make_sr4000():
     m = sio.loadmat(os.path.join(REF, "RANSAC_SR4000_result.mat"), struct_as_record=False, squeeze_me=True)
     cam = m["cam"]
@@ -147,6 +170,7 @@ def make_siftmatch_kat():
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; fixtures can only be regenerated where /root/reference exists")
+    make_snapshot_sub()
     make_sr4000()
     make_sift()
     make_siftmatch_kat()
