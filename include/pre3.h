@@ -194,6 +194,38 @@ PRE3_API int pre3_set_scan(pre3_ctx *ctx, int K2, const double *descriptor_raw, 
 PRE3_API int pre3_ic_search(pre3_ctx *ctx, double thresh, int strict_reference, int32_t *n_matches_out, int32_t *m_out,
                             int32_t *meas_idx_out, double *z_out, int32_t *pairs_out);
 
+/* ---- the VO front end's 4-point 3D-3D RANSAC (code_from_dr_ye/) ------------------------------------ */
+typedef struct pre3_vo_result {
+    double rot[9];          /* final rotation, row-major (find_transform_matrix_dr_ye.m on the winner's inliers, vodometry_dr_ye.m:221) */
+    double trans[3];
+    double euler[3];        /* R2e(rot): phi, theta, psi (vodometry_dr_ye.m:245-248); zeros when sta < 1 */
+    double u[7];            /* Calculate_V_Omega_RANSAC_dr_ye.m:40-50: [T; R2q(R)] -- what pre3_predict takes; identity unless sta == 1 */
+    double error_mean, error_std;   /* RANSAC_STAT.ErrorMean / ErrorStd (vodometry_dr_ye.m:222-225) */
+    double dist;            /* inlier radius scale of ransac_dr_ye.m:20-23 (threshold = 0.001*dist on squared distances) */
+    int32_t sta;            /* state of the final fit: 1 ok, 2 co-planar, -1 / 0 failed; 4 = no consensus (op_num < 3, :198-205) */
+    int32_t n_support;      /* op_num */
+    int32_t n_iterations;   /* RANSAC_STAT.nIterationRansac = min(rst, nIterations) (:226) */
+    int32_t best;           /* rs_ind (0-based): the first hypothesis with the largest consensus */
+} pre3_vo_result;
+/* vodometry_dr_ye.m:162-236 over ransac_dr_ye.m:48-72.  pset1/pset2: 3 x pnum column-major matched 3-D points (frame 1 / 2).
+ * draws[n_hyp][4]: 0-based positions in the match list -- the caller draws them with the reference's own rejection rule
+ * (ransac_dr_ye.m:28-46; MATLAB's rand stream is not reproducible) and passes rst = min(700, nchoosek(pnum,4)) of them:
+ * the reference evaluates all rst (its for-range is fixed at loop entry).  cnum_out[n_hyp], state_out[n_hyp],
+ * inlier_out[pnum] optional. */
+PRE3_API int pre3_vo_ransac(int device, int pnum, const double *pset1, const double *pset2, int n_hyp, const int32_t *draws,
+                            int32_t *cnum_out, int32_t *state_out, int32_t *inlier_out, pre3_vo_result *res);
+/* The same with ransac_dr_ye's own inputs: range images x,y,z (rows x cols column-major) of both frames, SIFT frames
+ * frm1 (ldf x K1), frm2 (ldf x K2) (rows 1:2 = pixel column,row; 1-based), match (2 x pnum doubles, 1-based, as
+ * siftmatch returns).  The point sets of ransac_dr_ye.m:13-19 are gathered on the device (and returned if asked). */
+PRE3_API int pre3_vo_ransac_frames(int device, int rows, int cols, const double *x1, const double *y1, const double *z1,
+                                   const double *x2, const double *y2, const double *z2, int ldf, int K1, const double *frm1,
+                                   int K2, const double *frm2, int pnum, const double *match, int n_hyp, const int32_t *draws,
+                                   double *pset1_out, double *pset2_out, int32_t *cnum_out, int32_t *state_out,
+                                   int32_t *inlier_out, pre3_vo_result *res);
+/* measurement only: average device time of one RANSAC (inputs resident) */
+PRE3_API int pre3_vo_bench(int device, int pnum, const double *pset1, const double *pset2, int n_hyp, const int32_t *draws, int reps,
+                           double *ms_per_call);
+
 /* ---- a10: sift/siftmatch.c:83-132,139-250 ------------------------------------------------------- */
 /* L1: ND x K1, L2: ND x K2, one descriptor per column (column-major, as mxGetData returns them).
  * pairs_out[2*K1] receives 1-based (k1,k2) doubles in increasing k1 exactly as the MEX writes them

@@ -306,3 +306,44 @@ def ic_search(types, off, x_km1, P_km1, cam, bank, scan_desc, scan_pos, thresh=1
     meas = np.nonzero(ic)[0].astype(np.int32)
     out.update(match_idx=np.stack([k1, k2]), accepted=np.asarray(acc, np.int32), meas_idx=meas, z=z_all[meas])
     return out
+
+
+# ---- VO front end -----------------------------------------------------------------------------------
+def vo_find_transform(pset1, pset2):
+    """pset: (3, pnum).  -> rot (3,3), trans (3,), state"""
+    p1, p2 = np.ascontiguousarray(_d(pset1).T), np.ascontiguousarray(_d(pset2).T)
+    rot, tr = np.zeros(9), np.zeros(3)
+    st = lib().orc_vo_find_transform(p1.shape[0], None, _p(p1), _p(p2), _p(rot), _p(tr))
+    return rot.reshape(3, 3), tr, int(st)
+
+
+def vo_gather(x, y, z, frm, sel):
+    """x, y, z: (rows, cols) range images; frm (>=2, K) SIFT frames; sel: 1-based keypoint numbers -> (3, pnum)"""
+    x, y, z = (np.asfortranarray(_d(a)) for a in (x, y, z))
+    frm = np.asfortranarray(_d(frm))
+    sel = _d(sel)
+    out = np.zeros((len(sel), 3))
+    rc = lib().orc_vo_gather(x.shape[0], x.shape[1], x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p),
+                             frm.shape[0], frm.ctypes.data_as(C.c_void_p), len(sel), _p(sel), _p(out))
+    if rc:
+        raise IndexError("vo_gather: a keypoint rounds to a pixel outside the range image")
+    return out.T.copy()
+
+
+def vo_ransac(pset1, pset2, draws):
+    p1, p2 = np.ascontiguousarray(_d(pset1).T), np.ascontiguousarray(_d(pset2).T)
+    draws = _i(draws).reshape(-1, 4)
+    pnum = p1.shape[0]
+    cn, inl = np.zeros(len(draws), np.int32), np.zeros(pnum, np.int32)
+    out, out2, iout = np.zeros(16), np.zeros(2), np.zeros(6, np.int32)
+    rc = lib().orc_vo_ransac(pnum, _p(p1), _p(p2), len(draws), _p(draws), _p(cn), _p(inl), _p(out), _p(out2), _p(iout))
+    if rc:
+        raise ValueError("vo_ransac: %s" % {-1: "no point farther than 0.4 m (dist undefined)", -2: "fewer than 4 matches"}[rc])
+    return dict(cnum=cn, inliers=inl, rot=out[:9].reshape(3, 3).copy(), trans=out[9:12].copy(), euler=out[12:15].copy(), error_mean=out[15],
+                error_std=out2[0], dist=out2[1], sta=int(iout[0]), n_support=int(iout[1]), n_iterations=int(iout[2]), best=int(iout[3]))
+
+
+def R2q(R):
+    q = np.zeros(4)
+    lib().orc_R2q(_p(_d(R)), _p(q))
+    return q

@@ -481,3 +481,64 @@ def map_convert(types, x, P, threshold=0.1):  # inversedepth_2_cartesian.m:27-76
             types[i] = CARTESIAN
             conv[i] = 1
     return X, PR, types, conv
+
+
+# ---- VO front end (code_from_dr_ye/), LAPACK svd like MATLAB's ----------------------------------------
+def vo_find_transform(pset1, pset2):              # find_transform_matrix_dr_ye.m:8-41 (3 x pnum arrays)
+    pnum = pset2.shape[1]
+    ct1, ct2 = pset1.sum(1) / pnum, pset2.sum(1) / pnum
+    H = np.zeros((3, 3))
+    for i in range(pnum):
+        H = H + np.outer(pset2[:, i] - ct2, pset1[:, i] - ct1)
+    U, S, Vt = np.linalg.svd(H)
+    V = Vt.T
+    Xq = V @ U.T
+    mdet = np.linalg.det(Xq)
+    if np.round(mdet) == 1:
+        return Xq, ct1 - Xq @ ct2, 1
+    if np.round(mdet) == -1:
+        zn = np.nonzero(np.abs(S) < 0.00000000000001)[0]
+        if zn.size == 1:
+            V[:, zn] = -V[:, zn]
+            rot = V @ U.T
+            return rot, ct1 - rot @ ct2, 2
+        return H, np.zeros(3), -1
+    return H, np.zeros(3), 0
+
+
+def vo_dist(pset2):                               # ransac_dr_ye.m:20-23
+    nr = np.sqrt(pset2[2] ** 2 + pset2[1] ** 2 + pset2[0] ** 2)
+    minZ = pset2[2, nr > 0.4].min()
+    k = np.nonzero(pset2[2] == minZ)[0][0]
+    return np.sqrt((pset2[:, k] ** 2).sum())
+
+
+def vo_ransac(pset1, pset2, draws):               # vodometry_dr_ye.m:162-236 over ransac_dr_ye.m:48-72
+    pnum = pset1.shape[1]
+    dist = vo_dist(pset2)
+    cn, maxC, nIter = [], 0, float(len(draws))
+    for d in draws:
+        rot, tr, _ = vo_find_transform(pset1[:, d], pset2[:, d])
+        dd = ((rot @ pset2 + tr[:, None] - pset1) ** 2).sum(0)
+        c = int((dd < 0.001 * dist).sum())
+        cn.append(c)
+        if c > maxC:
+            maxC = c
+            with np.errstate(divide="ignore"):
+                nIter = 5 * np.ceil(np.log(0.01) / np.log(1 - (maxC / pnum) ** 4))
+    cn = np.array(cn)
+    best = int(np.argmax(cn))
+    out = dict(cnum=cn, best=best, n_iterations=int(min(len(draws), nIter)), dist=dist)
+    if cn[best] < 3:
+        out.update(sta=4, n_support=int(cn[best]), inliers=np.zeros(pnum, np.int32))
+        return out
+    rot, tr, _ = vo_find_transform(pset1[:, draws[best]], pset2[:, draws[best]])
+    inl = ((rot @ pset2 + tr[:, None] - pset1) ** 2).sum(0) < 0.001 * dist
+    o1, o2 = pset1[:, inl], pset2[:, inl]
+    rot, tr, sta = vo_find_transform(o1, o2)
+    en = np.sqrt(((rot @ o2 + tr[:, None] - o1) ** 2).sum(0))
+    out.update(sta=sta, n_support=int(inl.sum()), inliers=inl.astype(np.int32), rot=rot, trans=tr, error_mean=en.mean(),
+               error_std=en.std(ddof=1) if en.size > 1 else 0.0)
+    if sta >= 1:
+        out["euler"] = np.array([np.arctan2(rot[2, 1], rot[2, 2]), np.arcsin(-rot[2, 0]), np.arctan2(rot[1, 0], rot[0, 0])])
+    return out

@@ -989,3 +989,234 @@ ORC_API int orc_map_convert(int n, int N, const int *lm_type, double threshold, 
     free(X); free(Pc); free(Pn); free(T);
     return cur;
 }
+
+/* =====================================================================================================================
+ * the visual-odometry front end's 4-point 3D-3D RANSAC.  PARITY UNPINNED against reference outputs: the
+ * reference ships no VO golden data (no d1_*.dat range files, no RANSAC_RESULT_*.mat).  The restatement is pinned to
+ * LAPACK's svd (what MATLAB calls) through the numpy twin and to rigid-motion known answers (tests/test_vo_oracle.py).
+ * ===================================================================================================================== */
+
+/* svd(H) for a 3x3 by one-sided Jacobi (Hestenes): H = U diag(sv) V'.  Replaces MATLAB's `[U,S,V] = svd(H)`
+ * (find_transform_matrix_dr_ye.m:19); only V*U' and the singular values are used downstream, and those do not depend
+ * on the ordering / sign conventions of the factorisation when H has full rank. */
+static void orc_svd3(const double H[9], double U[9], double sv[3], double V[9])
+{
+    double A[9];
+    memcpy(A, H, sizeof A);
+    for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        int rotated = 0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int i = 0; i < 3; ++i) { alpha += A[3 * i + p] * A[3 * i + p]; beta += A[3 * i + q] * A[3 * i + q]; gamma += A[3 * i + p] * A[3 * i + q]; }
+                if (gamma == 0.0 || fabs(gamma) <= 2.2e-16 * sqrt(alpha * beta)) continue;
+                rotated = 1;
+                double zeta = (beta - alpha) / (2.0 * gamma);
+                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int i = 0; i < 3; ++i) {
+                    double ap = A[3 * i + p], aq = A[3 * i + q];
+                    A[3 * i + p] = c * ap - s * aq; A[3 * i + q] = s * ap + c * aq;
+                    double vp = V[3 * i + p], vq = V[3 * i + q];
+                    V[3 * i + p] = c * vp - s * vq; V[3 * i + q] = s * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    int ok[3];
+    double big = 0;
+    for (int j = 0; j < 3; ++j) { sv[j] = sqrt(A[j] * A[j] + A[3 + j] * A[3 + j] + A[6 + j] * A[6 + j]); if (sv[j] > big) big = sv[j]; }
+    for (int j = 0; j < 3; ++j) {
+        ok[j] = sv[j] > 1e-300 && sv[j] > 1e-18 * big;
+        if (ok[j]) for (int i = 0; i < 3; ++i) U[3 * i + j] = A[3 * i + j] / sv[j];
+    }
+    /* complete U for (numerically) zero singular values: any orthonormal completion, as LAPACK's is */
+    int nok = ok[0] + ok[1] + ok[2];
+    if (nok == 2) {
+        int j = !ok[0] ? 0 : (!ok[1] ? 1 : 2), a = (j + 1) % 3, b = (j + 2) % 3;
+        U[j] = U[3 + a] * U[6 + b] - U[6 + a] * U[3 + b];
+        U[3 + j] = U[6 + a] * U[b] - U[a] * U[6 + b];
+        U[6 + j] = U[a] * U[3 + b] - U[3 + a] * U[b];
+    } else if (nok < 2) {
+        for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.0 : 0.0;      /* rank <= 1: the caller's state logic rejects it */
+        if (nok == 1) {
+            int j = ok[0] ? 0 : (ok[1] ? 1 : 2);
+            double u[3] = { A[j] / sv[j], A[3 + j] / sv[j], A[6 + j] / sv[j] };
+            int m = fabs(u[0]) < fabs(u[1]) ? (fabs(u[0]) < fabs(u[2]) ? 0 : 2) : (fabs(u[1]) < fabs(u[2]) ? 1 : 2);
+            double e[3] = { 0, 0, 0 }; e[m] = 1;
+            double w[3] = { u[1] * e[2] - u[2] * e[1], u[2] * e[0] - u[0] * e[2], u[0] * e[1] - u[1] * e[0] };
+            double nw = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+            for (int i = 0; i < 3; ++i) w[i] /= nw;
+            double x[3] = { u[1] * w[2] - u[2] * w[1], u[2] * w[0] - u[0] * w[2], u[0] * w[1] - u[1] * w[0] };
+            int a = (j + 1) % 3, b = (j + 2) % 3;
+            for (int i = 0; i < 3; ++i) { U[3 * i + j] = u[i]; U[3 * i + a] = w[i]; U[3 * i + b] = x[i]; }
+        }
+    }
+}
+
+static double orc_det3(const double M[9])
+{
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+/* find_transform_matrix_dr_ye.m:8-41.  pset1, pset2: 3 x pnum column-major; idx (may be NULL) selects columns.
+ * rot row-major 3x3; returns state (1, 2, -1, 0). */
+ORC_API int orc_vo_find_transform(int pnum, const int *idx, const double *pset1, const double *pset2, double *rot, double *trans)
+{
+    double ct1[3] = { 0, 0, 0 }, ct2[3] = { 0, 0, 0 }, H[9] = { 0 };
+    for (int k = 0; k < pnum; ++k) {
+        int c = idx ? idx[k] : k;
+        for (int i = 0; i < 3; ++i) { ct1[i] += pset1[3 * c + i]; ct2[i] += pset2[3 * c + i]; }
+    }
+    for (int i = 0; i < 3; ++i) { ct1[i] /= pnum; ct2[i] /= pnum; }                       /* :12 */
+    for (int k = 0; k < pnum; ++k) {                                                      /* :13-16  H += q2*q1' */
+        int c = idx ? idx[k] : k;
+        double q1[3], q2[3];
+        for (int i = 0; i < 3; ++i) { q1[i] = pset1[3 * c + i] - ct1[i]; q2[i] = pset2[3 * c + i] - ct2[i]; }
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) H[3 * i + j] += q2[i] * q1[j];
+    }
+    double U[9], sv[3], V[9], Xq[9];
+    orc_svd3(H, U, sv, V);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Xq[3 * i + j] = V[3 * i] * U[3 * j] + V[3 * i + 1] * U[3 * j + 1] + V[3 * i + 2] * U[3 * j + 2];   /* :20 */
+    double mdet = orc_det3(Xq);
+    int state;
+    if (round(mdet) == 1) state = 1;                                                       /* :23-26 */
+    else if (round(mdet) == -1) {                                                          /* :27-39 */
+        int zn = -1, cnt = 0;
+        for (int j = 0; j < 3; ++j) if (fabs(sv[j]) < 0.00000000000001) { zn = j; ++cnt; }
+        if (cnt == 1) {
+            for (int i = 0; i < 3; ++i) V[3 * i + zn] = -V[3 * i + zn];
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Xq[3 * i + j] = V[3 * i] * U[3 * j] + V[3 * i + 1] * U[3 * j + 1] + V[3 * i + 2] * U[3 * j + 2];
+            state = 2;
+        } else state = -1;
+    } else state = 0;                                                                      /* :40-44 */
+    if (state >= 1) {
+        memcpy(rot, Xq, sizeof Xq);
+        for (int i = 0; i < 3; ++i) trans[i] = ct1[i] - (rot[3 * i] * ct2[0] + rot[3 * i + 1] * ct2[1] + rot[3 * i + 2] * ct2[2]);
+    } else {
+        memcpy(rot, H, sizeof H);                                                          /* rot = H, trans = 0 */
+        trans[0] = trans[1] = trans[2] = 0;
+    }
+    return state;
+}
+
+/* ransac_dr_ye.m:13-19: pset(:,i) = [-x(ROW,COL); -y(ROW,COL); z(ROW,COL)], ROW = round(pix(2)), COL = round(pix(1)).
+ * frm: ldf x K column-major (rows 1:2 = pixel), sel[pnum]: 1-based keypoint numbers (one row of `match`);
+ * x, y, z: rows x cols column-major.  Returns 0, or -1 when a pixel falls outside the image (MATLAB would error). */
+ORC_API int orc_vo_gather(int rows, int cols, const double *x, const double *y, const double *z, int ldf, const double *frm,
+                          int pnum, const double *sel, double *pset)
+{
+    for (int i = 0; i < pnum; ++i) {
+        int k = (int)sel[i] - 1;
+        int COL = (int)round(frm[(size_t)ldf * k]), ROW = (int)round(frm[(size_t)ldf * k + 1]);
+        if (ROW < 1 || ROW > rows || COL < 1 || COL > cols) return -1;
+        size_t o = (size_t)(COL - 1) * rows + (ROW - 1);
+        pset[3 * i] = -x[o]; pset[3 * i + 1] = -y[o]; pset[3 * i + 2] = z[o];
+    }
+    return 0;
+}
+
+/* ransac_dr_ye.m:20-23: the inlier radius scale.  Returns -1 when no point is farther than 0.4 m (MATLAB errors there). */
+ORC_API int orc_vo_dist(int pnum, const double *pset2, double *dist)
+{
+    double minZ = 0; int have = 0;
+    for (int k = 0; k < pnum; ++k) {
+        double nr = sqrt(pset2[3 * k + 2] * pset2[3 * k + 2] + pset2[3 * k + 1] * pset2[3 * k + 1] + pset2[3 * k] * pset2[3 * k]);
+        if (nr > 0.4 && (!have || pset2[3 * k + 2] < minZ)) { minZ = pset2[3 * k + 2]; have = 1; }
+    }
+    if (!have) return -1;
+    for (int k = 0; k < pnum; ++k)
+        if (pset2[3 * k + 2] == minZ) {                                                    /* pmZ(1): over ALL points, not only the far ones */
+            *dist = sqrt(pset2[3 * k] * pset2[3 * k] + pset2[3 * k + 1] * pset2[3 * k + 1] + pset2[3 * k + 2] * pset2[3 * k + 2]);
+            return 0;
+        }
+    return -1;
+}
+
+/* One hypothesis: ransac_dr_ye.m:48-72 with the 4 sample positions given (0-based).  inl[pnum] flags; returns cnum. */
+ORC_API int orc_vo_hypothesis(int pnum, const double *pset1, const double *pset2, const int *draw, double dist, int *inl, int *state_out)
+{
+    double rot[9], tr[3];
+    int st = orc_vo_find_transform(4, draw, pset1, pset2, rot, tr);
+    if (state_out) *state_out = st;
+    int cnum = 0;
+    for (int k = 0; k < pnum; ++k) {
+        double d = 0;
+        for (int i = 0; i < 3; ++i) {
+            double v = rot[3 * i] * pset2[3 * k] + rot[3 * i + 1] * pset2[3 * k + 1] + rot[3 * i + 2] * pset2[3 * k + 2];
+            v = v + tr[i];
+            d = d + (v - pset1[3 * k + i]) * (v - pset1[3 * k + i]);
+        }
+        inl[k] = d < 0.001 * dist;                                                        /* :67 */
+        cnum += inl[k];
+    }
+    return cnum;
+}
+
+/* vodometry_dr_ye.m:162-236.  draws: n_hyp x 4 (0-based).  out[16]: rot(9, row-major) trans(3) euler(3) errmean;
+ * out2: [errstd, dist]; iout[6]: sta, n_support, n_iterations, best, all-evaluated count, reserved.
+ * cnum_out[n_hyp]; inl_out[pnum] = the winner's inliers.  Returns 0, -1 (dist undefined), -2 (pnum < 4). */
+ORC_API int orc_vo_ransac(int pnum, const double *pset1, const double *pset2, int n_hyp, const int *draws, int *cnum_out, int *inl_out,
+                          double *out, double *out2, int *iout)
+{
+    if (pnum < 4) return -2;
+    double dist;
+    if (orc_vo_dist(pnum, pset2, &dist)) return -1;
+    int *inl = (int *)malloc(sizeof(int) * pnum);
+    int maxC = 0, best = -1, bestc = -1;
+    double nIter = n_hyp;                                                                  /* nIterations = rst (:174) */
+    for (int i = 0; i < n_hyp; ++i) {                                                      /* the for-range is fixed at entry: every draw is evaluated */
+        int c = orc_vo_hypothesis(pnum, pset1, pset2, draws + 4 * i, dist, inl, NULL);
+        cnum_out[i] = c;
+        if (c > maxC) {                                                                    /* :185-188 */
+            maxC = c;
+            nIter = 5 * ceil(log(0.01) / log(1 - pow((double)maxC / pnum, 4)));
+        }
+        if (c > bestc) { bestc = c; best = i; }                                            /* [rs_max, rs_ind] = max(tmp_cnum): first maximum */
+    }
+    iout[2] = (int)(nIter < n_hyp ? nIter : n_hyp); iout[3] = best; iout[4] = n_hyp; iout[5] = 0;
+    out2[1] = dist;
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    out2[0] = 0;
+    if (bestc < 3) { iout[0] = 4; iout[1] = bestc < 0 ? 0 : bestc; memset(inl_out, 0, sizeof(int) * pnum); free(inl); return 0; }   /* :198-205 */
+    orc_vo_hypothesis(pnum, pset1, pset2, draws + 4 * best, dist, inl_out, NULL);
+    int *idx = (int *)malloc(sizeof(int) * pnum), m = 0;
+    for (int k = 0; k < pnum; ++k) if (inl_out[k]) idx[m++] = k;
+    double *rot = out, *tr = out + 9;
+    int sta = orc_vo_find_transform(m, idx, pset1, pset2, rot, tr);                        /* :221 */
+    double sum = 0, *en = (double *)malloc(sizeof(double) * m);
+    for (int a = 0; a < m; ++a) {                                                          /* :222-225 */
+        int k = idx[a]; double s2 = 0;
+        for (int i = 0; i < 3; ++i) {
+            double v = rot[3 * i] * pset2[3 * k] + rot[3 * i + 1] * pset2[3 * k + 1] + rot[3 * i + 2] * pset2[3 * k + 2] + tr[i] - pset1[3 * k + i];
+            s2 += v * v;
+        }
+        en[a] = sqrt(s2); sum += en[a];
+    }
+    double mean = sum / m, var = 0;
+    for (int a = 0; a < m; ++a) var += (en[a] - mean) * (en[a] - mean);
+    out[15] = mean; out2[0] = m > 1 ? sqrt(var / (m - 1)) : 0;
+    if (sta >= 1) {                                                                        /* R2e.m:21-23 */
+        out[12] = atan2(rot[7], rot[8]); out[13] = asin(-rot[6]); out[14] = atan2(rot[3], rot[0]);
+    }
+    iout[0] = sta; iout[1] = m;
+    free(en); free(idx); free(inl);
+    return 0;
+}
+
+/* R2q.m (slamToolbox): q = [a -b -c -d]'.  R row-major. */
+ORC_API void orc_R2q(const double *R, double *q)
+{
+    double T = R[0] + R[4] + R[8] + 1, a, b, c, d, S;
+    if (T > 0.00000001) {
+        S = 2 * sqrt(T); a = 0.25 * S; b = (R[5] - R[7]) / S; c = (R[6] - R[2]) / S; d = (R[1] - R[3]) / S;
+    } else if (R[0] > R[4] && R[0] > R[8]) {
+        S = 2 * sqrt(1.0 + R[0] - R[4] - R[8]); a = (R[5] - R[7]) / S; b = 0.25 * S; c = (R[1] + R[3]) / S; d = (R[6] + R[2]) / S;
+    } else if (R[4] > R[8]) {
+        S = 2 * sqrt(1.0 + R[4] - R[0] - R[8]); a = (R[6] - R[2]) / S; b = (R[1] + R[3]) / S; c = 0.25 * S; d = (R[5] + R[7]) / S;
+    } else {
+        S = 2 * sqrt(1.0 + R[8] - R[0] - R[4]); a = (R[1] - R[3]) / S; b = (R[6] + R[2]) / S; c = (R[5] + R[7]) / S; d = 0.25 * S;
+    }
+    q[0] = a; q[1] = -b; q[2] = -c; q[3] = -d;
+}
