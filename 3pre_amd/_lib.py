@@ -14,7 +14,7 @@ except Exception:  # pragma: no cover - torch is plumbing, not a requirement of 
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpre3.so")
+LIB_PATH = os.environ.get("PRE3_LIB") or os.path.join(_HERE, "lib", "libpre3.so")      # PRE3_LIB: A/B builds while tuning
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -183,7 +183,8 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
             A(dmalloc_bytes(&c->tiles_flat, sizeof(int2) * (inter.size() ? inter.size() : 1)));
             if (rc == PRE3_OK && hipMemcpy(c->tiles_flat, inter.data(), sizeof(int2) * inter.size(), hipMemcpyHostToDevice) != hipSuccess) { set_error("tile table upload failed"); rc = PRE3_E_HIP; }
         }
-        A(dmalloc(&c->tile_ctr, 8)); A(dmalloc(&c->tile_cnt, 8));
+        A(dmalloc(&c->tile_ctr, 8)); A(dmalloc(&c->tile_cnt, 8)); A(dmalloc(&c->chol_arrive, 4));
+        if (rc == PRE3_OK) (void)hipMemset(c->chol_arrive, 0, sizeof(unsigned int) * 4);
         if (rc == PRE3_OK) { (void)hipMemset(c->tile_ctr, 0, sizeof(unsigned int) * 8); (void)hipMemcpy(c->tile_cnt, cnts, sizeof(cnts), hipMemcpyHostToDevice); }
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) c->num_cus = pr.multiProcessorCount; }
         A(dmalloc_bytes(&c->tiles, sizeof(int2) * flat.size()));
@@ -212,7 +213,7 @@ int pre3_destroy(pre3_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
                      c->lm.li, c->lm.hi, c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
-                     c->sel_rows, c->support, c->masks, c->stats, c->li_meas, c->hi_meas, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_pairs, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src };
+                     c->sel_rows, c->support, c->masks, c->stats, c->li_meas, c->hi_meas, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_pairs, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->pinned_stats) (void)hipHostFree(c->pinned_stats);
     if (c->inbox_host) (void)hipHostFree(c->inbox_host);

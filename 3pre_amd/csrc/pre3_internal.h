@@ -80,6 +80,7 @@ struct pre3_ctx {
     int *tile_cnt = nullptr; int tiles_stride = 0;  // per-list lengths [8] and list stride
     bool tile_ctr_clean = false;                  // the 8 counters are zero (k_update_x resets them ahead of K9)
     int num_cus = 256;
+    unsigned int *chol_arrive = nullptr; unsigned int chol_target = 0;   // panel kernels: arrivals of the workgroups that read the raw diagonal block
     int p_which = -1;                             // which estimate P currently holds (-1: none)
     bool x_valid[2] = {false, false};
     pre3::LmBuffers lm;

@@ -173,20 +173,28 @@ __device__ inline double chain_rsqrt(double x) { return fast_rsqrt(x); }
 // Every workgroup factors the diagonal block redundantly; workgroup b then owns X = its 64-row block of
 // [S ; HP'] (b = 0: the diagonal block itself).
 template <typename T>
-__global__ __launch_bounds__(320) void k_chol_panel(T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb,
-                                                    int32_t *__restrict__ status)
+struct ChSmem {
+    T Ls[NB][NB + 1];
+    T Xs[NB][NB + 1];                              // Xs[a][i]
+    __attribute__((aligned(16))) T Pn[2][NB][4];   // published micro-panel columns: Pn[par][i][t] = A[i][C+t]
+    __attribute__((aligned(16))) T Yb[2][NB][4];   // final L[i][C+t]
+    __attribute__((aligned(16))) T Zt[2][NB][4];   // final X[C+t][i]
+    __attribute__((aligned(16))) T Xr[2][4][NB];   // published rows of X
+    T As[NB][NB + 1];                              // operand tiles of the trailing update / of the fused prologue
+    T Bs[NB][NB + 1];                              // Bs[j][a]
+};
+
+// PRO: the workgroup first applies the update of panel J-1 to its own blocks (diagonal block and X), i.e. the K = J
+// column of the trailing update, so that the launch of panel J does not have to wait for a separate trail kernel.
+template <typename T, bool PRO>
+__device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb,
+                                                int32_t *__restrict__ status, const int b, unsigned int *__restrict__ arrive, unsigned int target)
 {
     PROBE_STAMP(0);
     constexpr int MB = 4, NMP = NB / MB;
     typedef T v4_t __attribute__((ext_vector_type(4)));
-    __shared__ T Ls[NB][NB + 1];
-    __shared__ T Xs[NB][NB + 1];                              // Xs[a][i]
-    __shared__ __attribute__((aligned(16))) T Pn[2][NB][MB];  // published micro-panel columns: Pn[par][i][t] = A[i][C+t]
-    __shared__ __attribute__((aligned(16))) T Yb[2][NB][MB];  // final L[i][C+t]
-    __shared__ __attribute__((aligned(16))) T Zt[2][NB][MB];  // final X[C+t][i]
-    __shared__ __attribute__((aligned(16))) T Xr[2][MB][NB];  // published rows of X
+    auto &Ls = sm.Ls; auto &Xs = sm.Xs; auto &Pn = sm.Pn; auto &Yb = sm.Yb; auto &Zt = sm.Zt; auto &Xr = sm.Xr;
     const int tid = threadIdx.x;
-    const int b = blockIdx.x;
     const int nS = nrb - J - 1;
     const bool isW = b > nS;
     const int c0 = isW ? (b - nS - 1) * NB : 0;
@@ -208,6 +216,22 @@ __global__ __launch_bounds__(320) void k_chol_panel(T *__restrict__ S, int lds, 
                 for (int t = 0; t < 16; ++t) gx[t] = W[(size_t)(J * NB + lr + 4 * t) * ldw + c0 + lc];
             }
         }
+        T gb[16], gq[16];
+        if (PRO) {
+            // operands of the pending update from panel J-1: B = M(J, J-1) and this workgroup's own M(b, J-1)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) gb[t] = S[(size_t)(J * NB + lr + 4 * t) * lds + (J - 1) * NB + lc];
+            if (b >= 1) {
+                if (!isW) {
+                    const int rb = J + b;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) gq[t] = S[(size_t)(rb * NB + lr + 4 * t) * lds + (J - 1) * NB + lc];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) gq[t] = W[(size_t)((J - 1) * NB + lr + 4 * t) * ldw + c0 + lc];
+                }
+            }
+        }
 #pragma unroll
         for (int t = 0; t < 16; ++t) Ls[lr + 4 * t][lc] = ga[t];
         if (b >= 1) {
@@ -219,8 +243,111 @@ __global__ __launch_bounds__(320) void k_chol_panel(T *__restrict__ S, int lds, 
                 for (int t = 0; t < 16; ++t) Xs[lr + 4 * t][lc] = gx[t];        // W strip: (a = lr+4t, i = lc)
             }
         }
+        if (PRO) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) sm.Bs[lr + 4 * t][lc] = gb[t];                          // Bs[j][a]
+            if (b >= 1) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) sm.As[lr + 4 * t][lc] = gq[t];                      // As: [i][a] (S) or [a][i] (W)
+            }
+        }
     }
     __syncthreads();
+    // every workgroup reads the raw diagonal block; workgroup 0 overwrites it with L_JJ at the end and must not do so
+    // before all of them have it (they normally start together, but nothing guarantees that for very large grids)
+    if (tid == 0 && b != 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (PRO) {
+        if (worker) {
+            using M = Mfma<T>;
+            constexpr int NBLK = 32 / M::BLK;
+            const int lane = wt & 63, wv = wt >> 6;
+            const int w0 = (wv >> 1) * 32, w1 = (wv & 1) * 32;
+            typename M::acc_t acc[NBLK][NBLK];
+            // diagonal block: A_JJ -= B B'   (rows -> i, lanes -> j; only j <= i is ever read)
+            if (w1 <= w0) {
+#pragma unroll
+                for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+                    for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+                        for (int e = 0; e < M::NREG; ++e) acc[p][q][e] = (T)0;
+#pragma unroll 4
+                for (int k0 = 0; k0 < NB; k0 += M::KS) {
+                    const int k = k0 + M::kk(lane);
+                    T av[NBLK], bv[NBLK];
+#pragma unroll
+                    for (int p = 0; p < NBLK; ++p) { av[p] = sm.Bs[w0 + p * M::BLK + M::col(lane)][k]; bv[p] = sm.Bs[w1 + p * M::BLK + M::col(lane)][k]; }
+#pragma unroll
+                    for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+                        for (int q = 0; q < NBLK; ++q) M::mma(av[p], bv[q], acc[p][q]);
+                }
+#pragma unroll
+                for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+                    for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+                        for (int e = 0; e < M::NREG; ++e) {
+                            const int i = w0 + p * M::BLK + M::row(lane, e), j = w1 + q * M::BLK + M::col(lane);
+                            Ls[i][j] -= acc[p][q][e];
+                        }
+            }
+            if (b >= 1) {
+#pragma unroll
+                for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+                    for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+                        for (int e = 0; e < M::NREG; ++e) acc[p][q][e] = (T)0;
+                if (!isW) {
+                    // X(i, j) -= sum_a A[i][a] B[j][a]; rows -> i, lanes -> j; stored Xs[j][i]
+#pragma unroll 4
+                    for (int k0 = 0; k0 < NB; k0 += M::KS) {
+                        const int k = k0 + M::kk(lane);
+                        T av[NBLK], bv[NBLK];
+#pragma unroll
+                        for (int p = 0; p < NBLK; ++p) { av[p] = sm.As[w0 + p * M::BLK + M::col(lane)][k]; bv[p] = sm.Bs[w1 + p * M::BLK + M::col(lane)][k]; }
+#pragma unroll
+                        for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+                            for (int q = 0; q < NBLK; ++q) M::mma(av[p], bv[q], acc[p][q]);
+                    }
+#pragma unroll
+                    for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+                        for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+                            for (int e = 0; e < M::NREG; ++e) {
+                                const int i = w0 + p * M::BLK + M::row(lane, e), j = w1 + q * M::BLK + M::col(lane);
+                                Xs[j][i] -= acc[p][q][e];
+                            }
+                } else {
+                    // M(i, j) -= sum_a Aw[a][i] B[j][a]; rows -> j, lanes -> i; stored Xs[j][i]
+#pragma unroll 4
+                    for (int k0 = 0; k0 < NB; k0 += M::KS) {
+                        const int k = k0 + M::kk(lane);
+                        T av[NBLK], bv[NBLK];
+#pragma unroll
+                        for (int p = 0; p < NBLK; ++p) { av[p] = sm.Bs[w0 + p * M::BLK + M::col(lane)][k]; bv[p] = sm.As[k][w1 + p * M::BLK + M::col(lane)]; }
+#pragma unroll
+                        for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+                            for (int q = 0; q < NBLK; ++q) M::mma(av[p], bv[q], acc[p][q]);
+                    }
+#pragma unroll
+                    for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+                        for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+                            for (int e = 0; e < M::NREG; ++e) {
+                                const int j = w0 + p * M::BLK + M::row(lane, e), i = w1 + q * M::BLK + M::col(lane);
+                                Xs[j][i] -= acc[p][q][e];
+                            }
+                }
+            }
+        }
+        __syncthreads();
+    }
     PROBE_STAMP(1);
     const int tr = (wt >> 4) & 15, tc = wt & 15;
     T lv[4][4], xs[4][4];
@@ -238,6 +365,9 @@ __global__ __launch_bounds__(320) void k_chol_panel(T *__restrict__ S, int lds, 
     // Software pipeline over micro-panels; iteration mp: workers apply micro-panel mp and publish mp+2, the factor
     // wave works on mp+1.  The two lead-in iterations (mp = -2, -1) only publish / factor.  (Written as one
     // straight-line body -- no lambdas -- so that the register patches stay in VGPRs.)
+    // fully unrolled for both types: the publish step's patch selects fold to constants (measured: fp64 +10 % over the
+    // compiler's own choice of unrolling by 2)
+#pragma unroll
     for (int mp = -2; mp < NMP; ++mp) {
         if (worker) {
             if (mp >= 0) {
@@ -366,6 +496,10 @@ __global__ __launch_bounds__(320) void k_chol_panel(T *__restrict__ S, int lds, 
     PROBE_STAMP(2);
     if (bad && tid == 0 && b == 0) atomicExch(status, 1);
     if (b == 0) {
+        if (tid == 0) {
+            while ((int)(__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(8);
+        }
+        __syncthreads();
         for (int idx = tid; idx < NB * NB; idx += 320) {
             int i = idx >> 6, a2 = idx & 63;
             S[(size_t)(J * NB + i) * lds + J * NB + a2] = a2 <= i ? Ls[i][a2] : (T)0;
@@ -390,30 +524,31 @@ __global__ __launch_bounds__(320) void k_chol_panel(T *__restrict__ S, int lds, 
 // 32 x 32 sub-tile.  S-type tiles keep (row, a) order in LDS and are read with a 65-float stride (conflict
 // free); W-type tiles are stored k-major.  For W strips the operands are swapped so that the accumulator's
 // lane index runs along i, the contiguous direction of W.
+// J: the panel whose columns are the operands; K0: first column block to update (J+1 for the plain trailing update,
+// J+2 when block J+1 is handled by the next panel's prologue); idx: tile number.  Threads >= 256 only keep the barrier.
 template <typename T>
-__global__ __launch_bounds__(256) void k_chol_trail(T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb, int nW)
+__device__ __forceinline__ void chol_trail_body(T (&As)[NB][NB + 1], T (&Bs)[NB][NB + 1], T *__restrict__ S, int lds, T *__restrict__ W, int ldw,
+                                                int J, int K0, int nrb, int nW, int idx)
 {
     using M = Mfma<T>;
     constexpr int NBLK = 32 / M::BLK;
-    __shared__ T As[NB][NB + 1];
-    __shared__ T Bs[NB][NB + 1];   // Bs[j][a]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nK = nrb - J - 1;
+    const bool active = tid < 256;
+    const int nK = nrb - K0;
     const int nSt = nK * (nK + 1) / 2;
-    int idx = blockIdx.x;
     bool isW;
     int rb = 0, K, c0 = 0;
     if (idx < nSt) {
         int bb = 0;
         while ((bb + 1) * (bb + 2) / 2 <= idx) ++bb;
         int kk = idx - bb * (bb + 1) / 2;
-        rb = J + 1 + bb; K = J + 1 + kk; isW = false;
+        rb = K0 + bb; K = K0 + kk; isW = false;
     } else {
         int t = idx - nSt;
-        c0 = (t % nW) * NB; K = J + 1 + t / nW; isW = true;
+        c0 = (t % nW) * NB; K = K0 + t / nW; isW = true;
     }
     const int w0 = (wave >> 1) * 32, w1 = (wave & 1) * 32;
-    {
+    if (active) {
         // all global loads (both operand tiles and the 16 output elements this lane will update) are issued
         // before the first LDS store, so their latencies overlap
         T ga[16], gb[16];
@@ -431,16 +566,19 @@ __global__ __launch_bounds__(256) void k_chol_trail(T *__restrict__ S, int lds, 
         for (int t = 0; t < 16; ++t) { Bs[lr + 4 * t][lc] = gb[t]; As[lr + 4 * t][lc] = ga[t]; }   // As: [i][a] (S) or [a][i] (W)
     }
     T cv[NBLK][NBLK][M::NREG];
+    if (active) {
 #pragma unroll
-    for (int p = 0; p < NBLK; ++p)
+        for (int p = 0; p < NBLK; ++p)
 #pragma unroll
-        for (int q = 0; q < NBLK; ++q)
+            for (int q = 0; q < NBLK; ++q)
 #pragma unroll
-            for (int e = 0; e < M::NREG; ++e) {
-                const int r_ = w0 + p * M::BLK + M::row(lane, e), c_ = w1 + q * M::BLK + M::col(lane);
-                cv[p][q][e] = !isW ? S[(size_t)(rb * NB + r_) * lds + K * NB + c_] : W[(size_t)(K * NB + r_) * ldw + c0 + c_];
-            }
+                for (int e = 0; e < M::NREG; ++e) {
+                    const int r_ = w0 + p * M::BLK + M::row(lane, e), c_ = w1 + q * M::BLK + M::col(lane);
+                    cv[p][q][e] = !isW ? S[(size_t)(rb * NB + r_) * lds + K * NB + c_] : W[(size_t)(K * NB + r_) * ldw + c0 + c_];
+                }
+    }
     __syncthreads();
+    if (!active) return;
     typename M::acc_t acc[NBLK][NBLK];
 #pragma unroll
     for (int p = 0; p < NBLK; ++p)
@@ -492,6 +630,41 @@ __global__ __launch_bounds__(256) void k_chol_trail(T *__restrict__ S, int lds, 
                     int j = w0 + p * M::BLK + M::row(lane, e), i = w1 + q * M::BLK + M::col(lane);
                     W[(size_t)(K * NB + j) * ldw + c0 + i] = cv[p][q][e] - acc[p][q][e];
                 }
+    }
+}
+
+
+template <typename T>
+__global__ __launch_bounds__(320) void k_chol_panel(T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb,
+                                                    int32_t *__restrict__ status, unsigned int *__restrict__ arrive, unsigned int target)
+{
+    __shared__ ChSmem<T> sm;
+    chol_panel_body<T, false>(sm, S, lds, W, ldw, J, nrb, status, blockIdx.x, arrive, target);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_chol_trail(T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb, int nW)
+{
+    __shared__ T As[NB][NB + 1];
+    __shared__ T Bs[NB][NB + 1];
+    chol_trail_body<T>(As, Bs, S, lds, W, ldw, J, J + 1, nrb, nW, blockIdx.x);
+}
+
+// One launch per panel (lookahead form): workgroups [0, nP) factor panel J -- first applying the K = J column of panel
+// J-1's trailing update to their own blocks (PRO) -- while workgroups [nP, ...) apply the rest of panel J-1's trailing
+// update (column blocks >= J+1), which nothing in this launch reads.  The dependent chain is then 1 launch per panel
+// instead of 2, and the wide update runs in the shadow of the (latency-bound) panel.
+template <typename T>
+__global__ __launch_bounds__(320) void k_chol_step(T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb, int nW,
+                                                   int nP, int32_t *__restrict__ status, unsigned int *__restrict__ arrive, unsigned int target)
+{
+    __shared__ ChSmem<T> sm;
+    const int b = blockIdx.x;
+    if (b < nP) {
+        if (J == 0) chol_panel_body<T, false>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target);
+        else chol_panel_body<T, true>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target);
+    } else {
+        chol_trail_body<T>(sm.As, sm.Bs, S, lds, W, ldw, J - 1, J + 1, nrb, nW, b - nP);
     }
 }
 
@@ -876,12 +1049,28 @@ int launch_ell_G(pre3_ctx *c, int r, const void *HPsrc, void *dst, int ldg, int 
 static int launch_chol_solve(pre3_ctx *c, int r_pad)
 {
     int nrb = r_pad / NB, nW = c->ldw / NB;
+    static const int form = [] { const char *e = getenv("PRE3_CHOL_FORM"); return e ? atoi(e) : 1; }();   // 1: lookahead (default), 0: panel + trail launches
+    if (form == 1) {
+        for (int J = 0; J < nrb; ++J) {
+            const int nS = nrb - J - 1, nP = 1 + nS + nW;
+            const int nK = J >= 1 ? nrb - J - 1 : 0;                        // column blocks >= J+1 of panel J-1's update
+            const int nT = nK * (nK + 1) / 2 + nK * nW;
+            dim3 g(nP + nT), bP(320);
+            c->chol_target += (unsigned)(nP - 1);                           // every non-diagonal workgroup of the panel arrives once
+            DISPATCH_T(c,
+                hipLaunchKernelGGL(k_chol_step<double>, g, bP, 0, c->stream, (double *)c->Smat, r_pad, (double *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target),
+                hipLaunchKernelGGL(k_chol_step<float>, g, bP, 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target));
+        }
+        PRE3_HIP(hipGetLastError());
+        return PRE3_OK;
+    }
     for (int J = 0; J < nrb; ++J) {
         int nS = nrb - J - 1;
         dim3 gA(1 + nS + nW), b(256), bP(320);
+        c->chol_target += (unsigned)(nS + nW);
         DISPATCH_T(c,
-            hipLaunchKernelGGL(k_chol_panel<double>, gA, bP, 0, c->stream, (double *)c->Smat, r_pad, (double *)c->W, c->ldw, J, nrb, c->stats + 6),
-            hipLaunchKernelGGL(k_chol_panel<float>, gA, bP, 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J, nrb, c->stats + 6));
+            hipLaunchKernelGGL(k_chol_panel<double>, gA, bP, 0, c->stream, (double *)c->Smat, r_pad, (double *)c->W, c->ldw, J, nrb, c->stats + 6, c->chol_arrive, c->chol_target),
+            hipLaunchKernelGGL(k_chol_panel<float>, gA, bP, 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J, nrb, c->stats + 6, c->chol_arrive, c->chol_target));
         if (nS > 0) {
             dim3 gB(nS * (nS + 1) / 2 + nS * nW);
             DISPATCH_T(c,
