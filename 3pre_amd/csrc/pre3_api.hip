@@ -1,5 +1,6 @@
 // pre3_api.hip -- the C ABI of include/pre3.h: context management, host<->device marshalling, and the
 // stage order of one filter step (mono_slam.m:153-187).  No compute happens on the host.
+#include <time.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -24,7 +25,6 @@ int launch_build_rows_impl(pre3_ctx *c, int nsel, const int32_t *sel_dev, int r_
 int launch_ransac_score_impl(pre3_ctx *c, int k, double threshold, int hyp_begin, int hyp_end, int ldg, int32_t *support_dev, uint32_t *mask_dev, int mask_words);
 int launch_ransac_select_impl(pre3_ctx *c, int n_draw, int k, int early_exit, int32_t *support_dev, const uint32_t *mask_dev, int mask_words);
 int launch_fill_w(pre3_ctx *c, int r_pad);
-int launch_clear_flags(pre3_ctx *c);
 int match_partial(int device, int cls, int ND, int K1, const void *L1, int K2, const void *L2, int k2_offset, double *best, double *second, int32_t *arg);
 int knn_run(int device, int D, int N, const double *data, int M, const double *query, int k, double *ids, double *dist);
 void *match_bench_create(int ND, int K1, const uint8_t *L1, int K2, const uint8_t *L2);
@@ -116,19 +116,26 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
     A(dmalloc(&c->lm.h, 2 * (size_t)c->capN)); A(dmalloc(&c->lm.has_h, c->capN));
     A(dmalloc(&c->lm.Hc, 14 * (size_t)c->capN)); A(dmalloc(&c->lm.Hl, 12 * (size_t)c->capN));
     A(dmalloc(&c->lm.S, 4 * (size_t)c->capN)); A(dmalloc(&c->lm.has_S, c->capN));
-    A(dmalloc(&c->lm.li, c->capN)); A(dmalloc(&c->lm.hi, c->capN));
     {
+        // inbox: [meas | ic | hyp | z] is what the one H2D copy of a step ships (kept under 16 KB at N=500: larger copies
+        // leave the runtime's shader path for the SDMA path, +20 us); the inlier flags [li | hi | li_meas | hi_meas] follow
+        // in the same allocation and are cleared on the device (k_project_innovation in a step, a memset otherwise)
         c->off_meas = 0;
         c->off_ic = c->off_meas + sizeof(int32_t) * c->capm;
         c->off_hyp = c->off_ic + sizeof(int32_t) * c->capN;
         c->off_z = (c->off_hyp + sizeof(int32_t) * (size_t)c->caph * MAXK + 15) / 16 * 16;
-        c->inbox_bytes = c->off_z + sizeof(double) * 2 * c->capN;
+        c->off_flags = c->off_z + sizeof(double) * 2 * c->capN;
+        const size_t off_li = c->off_flags, off_hi = off_li + sizeof(int32_t) * c->capN;
+        const size_t off_lim = off_hi + sizeof(int32_t) * c->capN, off_him = off_lim + sizeof(int32_t) * c->capm;
+        c->flags_bytes = sizeof(int32_t) * (2 * (size_t)c->capN + 2 * (size_t)c->capm);
+        c->inbox_bytes = c->off_flags + c->flags_bytes;
         A(dmalloc_bytes(&c->inbox_dev, c->inbox_bytes));
         if (rc == PRE3_OK && hipHostMalloc((void **)&c->inbox_host, c->inbox_bytes) != hipSuccess) { set_error("hipHostMalloc failed"); rc = PRE3_E_NOMEM; }
         if (rc == PRE3_OK) {
             memset(c->inbox_host, 0, c->inbox_bytes);
             unsigned char *d = (unsigned char *)c->inbox_dev;
             c->meas = (int32_t *)(d + c->off_meas); c->lm.ic = (int32_t *)(d + c->off_ic);
+            c->lm.li = (int32_t *)(d + off_li); c->lm.hi = (int32_t *)(d + off_hi); c->li_meas = (int32_t *)(d + off_lim); c->hi_meas = (int32_t *)(d + off_him);
             c->hyp = (int32_t *)(d + c->off_hyp); c->lm.z = (double *)(d + c->off_z);
         }
     }
@@ -141,7 +148,7 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
     A(dmalloc(&c->sel_rows, c->rcap));
     A(dmalloc(&c->support, c->caph));
     A(dmalloc(&c->masks, (size_t)c->caph * c->mask_words_cap));
-    A(dmalloc(&c->stats, 16)); A(dmalloc(&c->li_meas, c->capm)); A(dmalloc(&c->hi_meas, c->capm));
+    A(dmalloc(&c->stats, 16));
     A(dmalloc(&c->pred_params, 128));
     {
         // K9 tile schedule: upper-triangle 64x64 tiles in 4x4 super-tile order, so that the tiles in flight at
@@ -212,8 +219,8 @@ int pre3_destroy(pre3_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
-                     c->lm.li, c->lm.hi, c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
-                     c->sel_rows, c->support, c->masks, c->stats, c->li_meas, c->hi_meas, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_pairs, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive };
+                     c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
+                     c->sel_rows, c->support, c->masks, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_pairs, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->pinned_stats) (void)hipHostFree(c->pinned_stats);
     if (c->inbox_host) (void)hipHostFree(c->inbox_host);
@@ -363,7 +370,7 @@ int pre3_get_landmark_fields(pre3_ctx *c, double *h, int32_t *has_h, double *Hc,
 
 // Fill the pinned inbox and ship it with ONE async copy: [meas | ic | (hyp) | z].  hyp (n_hyp_ints ints) optional.
 static int install_measurements(pre3_ctx *c, int m, const int32_t *meas_idx, const double *z /* 2m, null: z already on device */,
-                                const int32_t *hyp, int n_hyp_ints)
+                                const int32_t *hyp, int n_hyp_ints, bool flags_clear = false)
 {
     PRE3_CHECK(m >= 0 && m <= c->capm, PRE3_E_ARG, "measurements: m=%d exceeds capacity %d", m, c->capm);
     for (int j = 0; j < m; ++j) {
@@ -390,7 +397,7 @@ static int install_measurements(pre3_ctx *c, int m, const int32_t *meas_idx, con
         PRE3_HIP(hipMemcpyAsync(d, c->inbox_host, c->off_hyp + (hyp ? sizeof(int32_t) * n_hyp_ints : 0), hipMemcpyHostToDevice, c->stream));
     }
     PRE3_HIP(hipEventRecord(c->inbox_copied, c->stream)); c->inbox_pending = true;
-    PRE3_TRY(launch_clear_flags(c));
+    if (!flags_clear) PRE3_HIP(hipMemsetAsync((unsigned char *)c->inbox_dev + c->off_flags, 0, c->flags_bytes, c->stream));
     c->li_from_host = c->hi_from_host = -1; c->li_kernel = c->hi_kernel = false;
     c->hp_all_valid = false;
     c->measurements_set = true;
@@ -617,13 +624,13 @@ int pre3_ransac(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, double thres
 }
 
 // ---- updates --------------------------------------------------------------------------------------
-static int update_selected(pre3_ctx *c, int which_prior, int nsel, const int32_t *sel_dev)
+static int update_selected(pre3_ctx *c, int which_prior, int nsel, const int32_t *sel_dev, bool gathered = false)
 {
     PRE3_CHECK(c->p_which == which_prior, PRE3_E_STATE, "update: the covariance buffer does not hold the required prior");
     int r = 2 * nsel;
     // rows of the predicted-state update that RANSAC already multiplied out: gather instead of recomputing
     const bool reuse = r > 0 && which_prior == PRE3_X_K_KM1 && c->hp_all_valid && sel_dev != nullptr;
-    if (reuse) PRE3_TRY(launch_gather_li(c, nsel, sel_dev, round_up(2 * c->m, NB)));
+    if (reuse) { if (!gathered) PRE3_TRY(launch_gather_li(c, nsel, nsel, sel_dev, round_up(2 * c->m, NB))); }
     else if (r > 0) PRE3_TRY(launch_build_rows_impl(c, nsel, sel_dev, round_up(r, NB)));
     PRE3_TRY(run_update(c, which_prior, r, false, nullptr, reuse));
     c->hp_all_valid = false;                 // P changed
@@ -636,17 +643,25 @@ int pre3_update_li(pre3_ctx *c)
     PRE3_TRY(check_ctx(c));
     PRE3_CHECK(c->measurements_set && c->projected, PRE3_E_STATE, "pre3_update_li: needs projection and measurements");
     int n_li = 0;       // no RANSAC / flags for this measurement set: no low-innovation inliers, update is the identity
+    bool gathered = false;
     if (c->li_from_host >= 0) n_li = c->li_from_host;
-    else if (c->li_kernel) { PRE3_TRY(wait_mail(c, 8, c->seq_select)); n_li = c->mail_host[4]; }
-    return update_selected(c, PRE3_X_K_KM1, n_li, c->sel_rows);
+    else if (c->li_kernel) {
+        // the gather of the LI rows does not need the count on the host: issue it first, with the grid sized for all
+        // measurements, so that the GPU has work while the host polls the mailbox and launches the factorisation
+        if (c->p_which == PRE3_X_K_KM1 && c->hp_all_valid && c->m > 0) {
+            PRE3_TRY(launch_gather_li(c, -1, c->m, c->sel_rows, round_up(2 * c->m, NB)));
+            gathered = true;
+        }
+        PRE3_TRY(wait_mail(c, 8, c->seq_select)); n_li = c->mail_host[4];
+    }
+    return update_selected(c, PRE3_X_K_KM1, n_li, c->sel_rows, gathered);
 }
 
 int pre3_rescue(pre3_ctx *c, double chi2, int32_t *hi_mask)
 {
     PRE3_TRY(check_ctx(c));
     PRE3_CHECK(c->p_which == PRE3_X_K_K && c->x_valid[PRE3_X_K_K], PRE3_E_STATE, "pre3_rescue: needs (x_k_k, p_k_k), i.e. after the LI update");
-    PRE3_TRY(launch_project(c, PRE3_X_K_K, 0));
-    PRE3_TRY(launch_innovation(c, 1, chi2));
+    if (c->N) PRE3_TRY(launch_project_innovation(c, PRE3_X_K_K, 0, 1, chi2));
     c->hi_from_host = -1; c->hi_kernel = true;
     if (hi_mask) {
         PRE3_HIP(hipStreamSynchronize(c->stream));
@@ -706,20 +721,38 @@ int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, co
               double threshold, int early_exit, double chi2, int32_t stats[8])
 {
     PRE3_TRY(check_ctx(c));
+    static const bool trace = getenv("PRE3_STEP_TRACE") != nullptr;     // host-side stage clock (debug): where the host spends a step
+    static double acc[8]; static int nacc = 0;
+    auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; };
+    double t0 = trace ? now() : 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
     PRE3_TRY(pre3_predict(c, u));                                   // mono_slam.m:153
-    PRE3_TRY(pre3_project(c, PRE3_X_K_KM1, 1));                     // search_IC_matches.m:31-32
-    PRE3_TRY(pre3_innovation(c));                                   // search_IC_matches.m:33-44
+    PRE3_CHECK(c->have_cam, PRE3_E_STATE, "pre3_step: camera not set");
+    if (c->N) PRE3_TRY(launch_project_innovation(c, PRE3_X_K_KM1, 1, 0, 0.0));   // search_IC_matches.m:31-44
+    c->projected = true; c->innovated = true;
+    if (trace) t1 = now();
     PRE3_CHECK(m == 0 || (meas_idx && z), PRE3_E_ARG, "pre3_step: null measurement pointers");
     PRE3_CHECK(n_draw >= 1 && n_draw <= c->caph && k >= 1 && k <= MAXK && hyp, PRE3_E_ARG, "pre3_step: bad hypothesis table");
-    PRE3_TRY(install_measurements(c, m, meas_idx, z, hyp, n_draw * k));   // matching_sift_based.m:131-134 outcome (+ the draws)
+    PRE3_TRY(install_measurements(c, m, meas_idx, z, hyp, n_draw * k, c->N > 0));   // matching_sift_based.m:131-134 outcome (+ the draws); flags cleared by k_project_innovation
     int32_t st[8] = { -1, 0, 0, 0, 0, 0, 0, 0 };
     if (m >= k && m > 0) {
         PRE3_TRY(pre3_ransac(c, n_draw, k, (const int32_t *)(c->inbox_host + c->off_hyp), threshold, early_exit, nullptr, nullptr, st));   // mono_slam.m:178
         st[4] = 0;
     }
+    if (trace) t2 = now();
     PRE3_TRY(pre3_update_li(c));                                    // mono_slam.m:181
+    if (trace) t3 = now();
     PRE3_TRY(pre3_rescue(c, chi2, nullptr));                        // mono_slam.m:184
+    if (trace) t4 = now();
     PRE3_TRY(pre3_update_hi(c));                                    // mono_slam.m:187
+    if (trace) {
+        t5 = now();
+        acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += t4 - t3; acc[4] += t5 - t4;
+        if (++nacc == 100) {
+            fprintf(stderr, "[pre3 step trace, us] predict+project+innov launches %.1f | install+ransac launches %.1f | update_li (poll+launches) %.1f | rescue launches %.1f | update_hi (poll) %.1f\n",
+                    acc[0] / nacc, acc[1] / nacc, acc[2] / nacc, acc[3] / nacc, acc[4] / nacc);
+            nacc = 0; for (double &a : acc) a = 0;
+        }
+    }
     st[4] = c->li_from_host >= 0 ? c->li_from_host : (c->li_kernel ? c->mail_host[4] : 0);
     st[5] = c->hi_from_host >= 0 ? c->hi_from_host : (c->hi_kernel ? c->mail_host[5] : 0);
     if (stats) for (int i = 0; i < 8; ++i) stats[i] = st[i];

@@ -43,17 +43,6 @@ __device__ inline void d_q2R_sola(const double *q, double *R)
     R[6] = bd - ac;           R[7] = cd + ab;           R[8] = aa - bb - cc + dd;
 }
 
-// normJac.m:27-38
-__device__ inline void d_normjac(const double *q, double *J)
-{
-    double r = q[0], x = q[1], y = q[2], z = q[3];
-    double s = pow(r * r + x * x + y * y + z * z, -1.5);
-    J[0] = s * (x * x + y * y + z * z); J[1] = s * (-r * x); J[2] = s * (-r * y); J[3] = s * (-r * z);
-    J[4] = s * (-x * r); J[5] = s * (r * r + y * y + z * z); J[6] = s * (-x * y); J[7] = s * (-x * z);
-    J[8] = s * (-y * r); J[9] = s * (-y * x); J[10] = s * (r * r + x * x + z * z); J[11] = s * (-y * z);
-    J[12] = s * (-z * r); J[13] = s * (-z * x); J[14] = s * (-z * y); J[15] = s * (r * r + x * x + y * y);
-}
-
 // hu_my_version.m:41-42 + distort_fm_my_version.m:52-61
 __device__ inline void d_pinhole_distort(const double *hrl, const CamD &cam, double *uvd)
 {
@@ -112,66 +101,65 @@ __device__ inline void d_process_noise(double *Pn)
 }
 
 // pred_params layout: [0..15] A4 = Qq1, [16..31] Jn, [32..80] Q7 = G Pn G' (7x7)
-__global__ void k_predict_x(const double *__restrict__ x_in, double *__restrict__ x_out, int n, U7 u, double *__restrict__ params)
-{
-    int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    // landmarks copied (predict_state_and_covariance.m:79)
-    for (int i = 13 + tid; i < n; i += gridDim.x * blockDim.x) x_out[i] = x_in[i];
-    if (tid != 0) return;
-    const double *q = x_in + 3;
-    double R[9];
-    d_q2R_sola(q, R);
-    double xo[7];
-    for (int i = 0; i < 3; ++i) xo[i] = x_in[i] + (R[i * 3] * u.v[0] + R[i * 3 + 1] * u.v[1] + R[i * 3 + 2] * u.v[2]);
-    // qProd.m:16-33
-    double a = q[0], b = q[1], c = q[2], d = q[3];
-    double w = u.v[3], x = u.v[4], y = u.v[5], z = u.v[6];
-    xo[3] = a * w - b * x - c * y - d * z;
-    xo[4] = a * x + b * w + c * z - d * y;
-    xo[5] = a * y - b * z + c * w + d * x;
-    xo[6] = a * z + b * y - c * x + d * w;
-    double Qq1[16] = { w, -x, -y, -z,  x, w, z, -y,  y, -z, w, x,  z, y, -x, w };
-    double Qq2[16] = { a, -b, -c, -d,  b, a, -d, c,  c, d, a, -b,  d, -c, b, a };
-    // G = [R 0; 0 Qq2] (7x7 non-zero part), Q7 = G Pn G'
-    double G[49], Pn[49], GP[49];
-    for (int i = 0; i < 49; ++i) G[i] = 0;
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) G[i * 7 + j] = R[i * 3 + j];
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) G[(3 + i) * 7 + 3 + j] = Qq2[i * 4 + j];
-    d_process_noise(Pn);
-    for (int i = 0; i < 7; ++i)
-        for (int j = 0; j < 7; ++j) {
-            double s = 0;
-            for (int t = 0; t < 7; ++t) s += G[i * 7 + t] * Pn[t * 7 + j];
-            GP[i * 7 + j] = s;
-        }
-    for (int i = 0; i < 7; ++i)
-        for (int j = 0; j < 7; ++j) {
-            double s = 0;
-            for (int t = 0; t < 7; ++t) s += GP[i * 7 + t] * G[j * 7 + t];
-            params[32 + i * 7 + j] = s;
-        }
-    double Jn[16];
-    d_normjac(xo + 3, Jn);     // at the un-normalised q (predict_state_and_covariance.m:137)
-    for (int i = 0; i < 16; ++i) { params[i] = Qq1[i]; params[16 + i] = Jn[i]; }
-    double nq = sqrt(xo[3] * xo[3] + xo[4] * xo[4] + xo[5] * xo[5] + xo[6] * xo[6]);
-    for (int i = 0; i < 3; ++i) x_out[i] = xo[i];
-    for (int i = 0; i < 4; ++i) x_out[3 + i] = xo[3 + i] / nq;
-    for (int i = 7; i < 13; ++i) x_out[i] = 0;
-}
-
-// One lane per column j: v = P[3:7, j]  ->  Jn*(Qq1*v [+ Q[3:7,j]]) written to P[3:7,j] and P[j,3:7].
-// Block 0 also owns the 7x7 pose block.
+// k_predict_x and k_predict_P in ONE launch (a kernel boundary costs ~5 us on this platform, more than either kernel):
+// lane 0 of every block recomputes the quaternion product and its normalisation Jacobian (a few dozen flops) instead of
+// reading them from a previous kernel; block 0 additionally owns x_out[0:13], the process noise and the 7x7 pose block.
 template <typename T>
-__global__ void k_predict_P(T *__restrict__ P, int n, int ld, const double *__restrict__ params)
+__global__ __launch_bounds__(256) void k_predict(const double *__restrict__ x_in, double *__restrict__ x_out, T *__restrict__ P, int n, int ld, U7 u,
+                                                 double *__restrict__ params)
 {
     __shared__ double sQq1[16], sJn[16], sQ[49];
     __shared__ double corner[49];      // old P[0:7,0:7]
-    if (threadIdx.x < 16) { sQq1[threadIdx.x] = params[threadIdx.x]; sJn[threadIdx.x] = params[16 + threadIdx.x]; }
-    if (threadIdx.x < 49) sQ[threadIdx.x] = params[32 + threadIdx.x];
-    if (blockIdx.x == 0 && threadIdx.x < 49) corner[threadIdx.x] = (double)P[(threadIdx.x / 7) * ld + (threadIdx.x % 7)];
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    // landmarks copied (predict_state_and_covariance.m:79)
+    for (int i = 13 + j; i < n; i += gridDim.x * blockDim.x) x_out[i] = x_in[i];
     double v[4] = { 0, 0, 0, 0 };
     if (j >= 7 && j < n) for (int t = 0; t < 4; ++t) v[t] = (double)P[(3 + t) * ld + j];
+    if (blockIdx.x == 0 && threadIdx.x < 49) corner[threadIdx.x] = (double)P[(threadIdx.x / 7) * ld + (threadIdx.x % 7)];
+    if (threadIdx.x == 0) {
+        const double *q = x_in + 3;
+        // qProd.m:16-33
+        const double a = q[0], b = q[1], c = q[2], d = q[3];
+        const double w = u.v[3], x = u.v[4], y = u.v[5], z = u.v[6];
+        double xo[7];
+        xo[3] = a * w - b * x - c * y - d * z;
+        xo[4] = a * x + b * w + c * z - d * y;
+        xo[5] = a * y - b * z + c * w + d * x;
+        xo[6] = a * z + b * y - c * x + d * w;
+        const double Qq1[16] = { w, -x, -y, -z,  x, w, z, -y,  y, -z, w, x,  z, y, -x, w };
+        double Jn[16];
+        d_normjac(xo + 3, Jn);     // at the un-normalised q (predict_state_and_covariance.m:137)
+        for (int i = 0; i < 16; ++i) { sQq1[i] = Qq1[i]; sJn[i] = Jn[i]; }
+        if (blockIdx.x == 0) {
+            double R[9];
+            d_q2R_sola(q, R);
+            for (int i = 0; i < 3; ++i) xo[i] = x_in[i] + (R[i * 3] * u.v[0] + R[i * 3 + 1] * u.v[1] + R[i * 3 + 2] * u.v[2]);
+            const double Qq2[16] = { a, -b, -c, -d,  b, a, -d, c,  c, d, a, -b,  d, -c, b, a };
+            // G = [R 0; 0 Qq2] (7x7 non-zero part), Q7 = G Pn G'
+            double G[49], Pn[49], GP[49];
+            for (int i = 0; i < 49; ++i) G[i] = 0;
+            for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) G[i * 7 + k] = R[i * 3 + k];
+            for (int i = 0; i < 4; ++i) for (int k = 0; k < 4; ++k) G[(3 + i) * 7 + 3 + k] = Qq2[i * 4 + k];
+            d_process_noise(Pn);
+            for (int i = 0; i < 7; ++i)
+                for (int k = 0; k < 7; ++k) {
+                    double s = 0;
+                    for (int t = 0; t < 7; ++t) s += G[i * 7 + t] * Pn[t * 7 + k];
+                    GP[i * 7 + k] = s;
+                }
+            for (int i = 0; i < 7; ++i)
+                for (int k = 0; k < 7; ++k) {
+                    double s = 0;
+                    for (int t = 0; t < 7; ++t) s += GP[i * 7 + t] * G[k * 7 + t];
+                    sQ[i * 7 + k] = s; params[32 + i * 7 + k] = s;
+                }
+            for (int i = 0; i < 16; ++i) { params[i] = Qq1[i]; params[16 + i] = Jn[i]; }
+            const double nq = sqrt(xo[3] * xo[3] + xo[4] * xo[4] + xo[5] * xo[5] + xo[6] * xo[6]);
+            for (int i = 0; i < 3; ++i) x_out[i] = xo[i];
+            for (int i = 0; i < 4; ++i) x_out[3 + i] = xo[3 + i] / nq;
+            for (int i = 7; i < 13; ++i) x_out[i] = 0;
+        }
+    }
     __syncthreads();
     if (j >= 7 && j < n) {
         double a[4], b[4];
@@ -181,7 +169,6 @@ __global__ void k_predict_P(T *__restrict__ P, int n, int ld, const double *__re
     }
     if (blockIdx.x == 0) {
         // pose block: C = F7 * P7 * F7' + Q7 with F7 = blkdiag(I3, Qq1); then J7 C J7', J7 = blkdiag(I3, Jn).
-        // 49 lanes, one per entry, four product phases through LDS (block-uniform branch: barriers are safe).
         __shared__ double F7[49], J7[49], T1[49], C7[49];
         const int t = threadIdx.x, i = t / 7, k = t % 7;
         if (t < 49) {
@@ -190,13 +177,13 @@ __global__ void k_predict_P(T *__restrict__ P, int n, int ld, const double *__re
             F7[t] = f; J7[t] = jn;
         }
         __syncthreads();
-        if (t < 49) { double s = 0; for (int u = 0; u < 7; ++u) s += F7[i * 7 + u] * corner[u * 7 + k]; T1[t] = s; }
+        if (t < 49) { double s = 0; for (int q2 = 0; q2 < 7; ++q2) s += F7[i * 7 + q2] * corner[q2 * 7 + k]; T1[t] = s; }
         __syncthreads();
-        if (t < 49) { double s = 0; for (int u = 0; u < 7; ++u) s += T1[i * 7 + u] * F7[k * 7 + u]; C7[t] = s + sQ[t]; }
+        if (t < 49) { double s = 0; for (int q2 = 0; q2 < 7; ++q2) s += T1[i * 7 + q2] * F7[k * 7 + q2]; C7[t] = s + sQ[t]; }
         __syncthreads();
-        if (t < 49) { double s = 0; for (int u = 0; u < 7; ++u) s += J7[i * 7 + u] * C7[u * 7 + k]; T1[t] = s; }
+        if (t < 49) { double s = 0; for (int q2 = 0; q2 < 7; ++q2) s += J7[i * 7 + q2] * C7[q2 * 7 + k]; T1[t] = s; }
         __syncthreads();
-        if (t < 49) { double s = 0; for (int u = 0; u < 7; ++u) s += T1[i * 7 + u] * J7[k * 7 + u]; P[i * ld + k] = (T)s; }
+        if (t < 49) { double s = 0; for (int q2 = 0; q2 < 7; ++q2) s += T1[i * 7 + q2] * J7[k * 7 + q2]; P[i * ld + k] = (T)s; }
     }
 }
 
@@ -229,12 +216,10 @@ __global__ void k_jnorm_P(T *__restrict__ P, int n, int ld, const double *__rest
 // ------------------------------------------------------------------------------------------------
 // K2 project + Jacobian: one lane per landmark
 // ------------------------------------------------------------------------------------------------
-__global__ void k_project(int N, const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
-                          const double *__restrict__ x, CamD cam, int clear_first,
-                          double *__restrict__ h, int32_t *__restrict__ has_h, double *__restrict__ Hc, double *__restrict__ Hl)
+__device__ void project_one(const int i, const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
+                            const double *__restrict__ x, const CamD &cam, int clear_first,
+                            double *__restrict__ h, int32_t *__restrict__ has_h, double *__restrict__ Hc, double *__restrict__ Hl)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
     int type = lm_type[i];
     const double *y = x + lm_off[i];
     double Rwc[9];
@@ -309,18 +294,27 @@ __global__ void k_project(int N, const int32_t *__restrict__ lm_type, const int3
     }
 }
 
+__global__ void k_project(int N, const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
+                          const double *__restrict__ x, CamD cam, int clear_first,
+                          double *__restrict__ h, int32_t *__restrict__ has_h, double *__restrict__ Hc, double *__restrict__ Hl)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    project_one(i, lm_type, lm_off, x, cam, clear_first, h, has_h, Hc, Hl);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3 innovation covariance / rescue gate: one lane per landmark gathers the 13x13 (10x10) block of P
 // that H_i's non-zeros select.  mode 0: S_i = H P H' + I for predicted landmarks.
 // mode 1 (rescue_hi_inliers.m:35-46): for ic && !li: d2 = nu' inv(H P H') nu < chi2 -> hi flag.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_innovation(int N, const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
-                                                    const T *__restrict__ P, int ld, const double *__restrict__ Hc, const double *__restrict__ Hl,
-                                                    const int32_t *__restrict__ has_h, int mode, double chi2,
-                                                    const double *__restrict__ h, const double *__restrict__ z,
-                                                    const int32_t *__restrict__ ic, const int32_t *__restrict__ li, int32_t *__restrict__ hi,
-                                                    double *__restrict__ S, int32_t *__restrict__ has_S)
+__device__ __forceinline__ void innovation_body(int N, const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
+                                                const T *__restrict__ P, int ld, const double *Hc, const double *Hl,
+                                                const int32_t *has_h, int mode, double chi2,
+                                                const double *h, const double *__restrict__ z,
+                                                const int32_t *__restrict__ ic, const int32_t *__restrict__ li, int32_t *__restrict__ hi,
+                                                double *__restrict__ S, int32_t *__restrict__ has_S)
 {
     // 16 lanes per landmark: lane b < 13 owns column b of the gathered 13x13 block of P (7 pose + 6 landmark
     // entries; P is symmetric, so the column is read as a row: two contiguous runs), then a 16-lane shuffle sum.
@@ -367,6 +361,37 @@ __global__ __launch_bounds__(256) void k_innovation(int N, const int32_t *__rest
         double d2 = t0 * n0 + t1 * n1;
         hi[i] = d2 < chi2 ? 1 : 0;
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_innovation(int N, const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
+                                                    const T *__restrict__ P, int ld, const double *__restrict__ Hc, const double *__restrict__ Hl,
+                                                    const int32_t *__restrict__ has_h, int mode, double chi2,
+                                                    const double *__restrict__ h, const double *__restrict__ z,
+                                                    const int32_t *__restrict__ ic, const int32_t *__restrict__ li, int32_t *__restrict__ hi,
+                                                    double *__restrict__ S, int32_t *__restrict__ has_S)
+{
+    innovation_body<T>(N, lm_type, lm_off, P, ld, Hc, Hl, has_h, mode, chi2, h, z, ic, li, hi, S, has_S);
+}
+
+// k_project and k_innovation in ONE launch: the first of a landmark's 16 lanes projects it and writes h / H, the block
+// barrier publishes them, then the 16 lanes gather H P H' as before.  Saves a kernel boundary (~5 us) twice per step.
+template <typename T>
+__global__ __launch_bounds__(256) void k_project_innovation(int N, const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
+                                                            const double *__restrict__ x, CamD cam, int clear_first, const T *__restrict__ P, int ld,
+                                                            double *Hc, double *Hl, int32_t *has_h, int mode, double chi2, double *h,
+                                                            const double *__restrict__ z, const int32_t *__restrict__ ic,
+                                                            const int32_t *__restrict__ li, int32_t *__restrict__ hi, double *__restrict__ S,
+                                                            int32_t *__restrict__ has_S, int32_t *__restrict__ clear, int n_clear)
+{
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    // a step's IC search precedes its measurements: clear the inlier flags of the previous frame here (n_clear = 0 otherwise)
+    for (int t = gt; t < n_clear; t += gridDim.x * blockDim.x) clear[t] = 0;
+    // the block's 16 landmarks are projected by the first 16 lanes of its first wave (one wave runs the long fp64 code, not four)
+    if (threadIdx.x < 16 && (int)(blockIdx.x * 16 + threadIdx.x) < N) project_one(blockIdx.x * 16 + threadIdx.x, lm_type, lm_off, x, cam, clear_first, h, has_h, Hc, Hl);
+    __threadfence_block();
+    __syncthreads();
+    innovation_body<T>(N, lm_type, lm_off, P, ld, Hc, Hl, has_h, mode, chi2, h, z, ic, li, hi, S, has_S);
 }
 
 // matching_sift_based.m:119-134
@@ -716,11 +741,10 @@ static CamD to_camd(const pre3_cam &c) { return CamD{ c.f, c.Cx, c.Cy, c.k1, c.k
 int launch_predict_impl(pre3_ctx *c, const double u[7])
 {
     U7 uu; for (int i = 0; i < 7; ++i) uu.v[i] = u[i];
-    hipLaunchKernelGGL(k_predict_x, dim3(ceil_div(c->n, 256)), dim3(256), 0, c->stream, c->x_kk, c->x_km1, c->n, uu, c->pred_params);
     int blocks = ceil_div(c->n, 256);
     DISPATCH_T(c,
-        hipLaunchKernelGGL(k_predict_P<double>, dim3(blocks), dim3(256), 0, c->stream, (double *)c->P, c->n, c->ld, c->pred_params),
-        hipLaunchKernelGGL(k_predict_P<float>, dim3(blocks), dim3(256), 0, c->stream, (float *)c->P, c->n, c->ld, c->pred_params));
+        hipLaunchKernelGGL(k_predict<double>, dim3(blocks), dim3(256), 0, c->stream, c->x_kk, c->x_km1, (double *)c->P, c->n, c->ld, uu, c->pred_params),
+        hipLaunchKernelGGL(k_predict<float>, dim3(blocks), dim3(256), 0, c->stream, c->x_kk, c->x_km1, (float *)c->P, c->n, c->ld, uu, c->pred_params));
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }
@@ -744,6 +768,33 @@ int launch_project(pre3_ctx *c, int which, int clear_first)
     return PRE3_OK;
 }
 
+static int launch_collect_hi(pre3_ctx *c)
+{
+    hipLaunchKernelGGL(k_collect_hi, dim3(1), dim3(64), 0, c->stream, c->m, c->meas, c->lm.ic, c->lm.li, c->lm.hi, c->hi_meas,
+                       c->sel_rows, c->stats, c->mail_dev, ++c->seq_collect);
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
+// project + innovation (+ the HI collection in mode 1) with one kernel boundary less
+int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode, double chi2)
+{
+    const double *x = which == PRE3_X_K_K ? c->x_kk : c->x_km1;
+    int32_t *clr = (int32_t *)((unsigned char *)c->inbox_dev + c->off_flags);
+    const int n_clr = mode == 0 ? (int)(c->flags_bytes / sizeof(int32_t)) : 0;
+    dim3 g(ceil_div(c->N * 16, 256)), b(256);
+    DISPATCH_T(c,
+        hipLaunchKernelGGL(k_project_innovation<double>, g, b, 0, c->stream, c->N, c->lm.type, c->lm.off, x, to_camd(c->cam), clear_first,
+                           (const double *)c->P, c->ld, c->lm.Hc, c->lm.Hl, c->lm.has_h, mode, chi2, c->lm.h, c->lm.z, c->lm.ic, c->lm.li,
+                           c->lm.hi, c->lm.S, c->lm.has_S, clr, n_clr),
+        hipLaunchKernelGGL(k_project_innovation<float>, g, b, 0, c->stream, c->N, c->lm.type, c->lm.off, x, to_camd(c->cam), clear_first,
+                           (const float *)c->P, c->ld, c->lm.Hc, c->lm.Hl, c->lm.has_h, mode, chi2, c->lm.h, c->lm.z, c->lm.ic, c->lm.li,
+                           c->lm.hi, c->lm.S, c->lm.has_S, clr, n_clr));
+    PRE3_HIP(hipGetLastError());
+    if (mode == 1) PRE3_TRY(launch_collect_hi(c));
+    return PRE3_OK;
+}
+
 int launch_innovation(pre3_ctx *c, int mode, double chi2)
 {
     dim3 g(ceil_div(c->N * 16, 256)), b(256);
@@ -753,11 +804,7 @@ int launch_innovation(pre3_ctx *c, int mode, double chi2)
         hipLaunchKernelGGL(k_innovation<float>, g, b, 0, c->stream, c->N, c->lm.type, c->lm.off, (const float *)c->P, c->ld, c->lm.Hc,
                            c->lm.Hl, c->lm.has_h, mode, chi2, c->lm.h, c->lm.z, c->lm.ic, c->lm.li, c->lm.hi, c->lm.S, c->lm.has_S));
     PRE3_HIP(hipGetLastError());
-    if (mode == 1) {
-        hipLaunchKernelGGL(k_collect_hi, dim3(1), dim3(64), 0, c->stream, c->m, c->meas, c->lm.ic, c->lm.li, c->lm.hi, c->hi_meas,
-                           c->sel_rows, c->stats, c->mail_dev, ++c->seq_collect);
-        PRE3_HIP(hipGetLastError());
-    }
+    if (mode == 1) PRE3_TRY(launch_collect_hi(c));
     return PRE3_OK;
 }
 
@@ -815,23 +862,6 @@ int launch_ransac_select_impl(pre3_ctx *c, int n_draw, int k, int early_exit, in
 {
     hipLaunchKernelGGL(k_ransac_select, dim3(1), dim3(256), 0, c->stream, n_draw, k, early_exit, c->m, c->meas, support_dev, mask_dev,
                        mask_words, c->li_meas, c->lm.li, c->sel_rows, c->stats, c->mail_dev, ++c->seq_select);
-    PRE3_HIP(hipGetLastError());
-    return PRE3_OK;
-}
-
-__global__ void k_clear_flags(int N, int m, int32_t *__restrict__ li, int32_t *__restrict__ hi, int32_t *__restrict__ li_meas,
-                              int32_t *__restrict__ hi_meas, int32_t *__restrict__ stats)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) { li[i] = 0; hi[i] = 0; }
-    if (i < m) { li_meas[i] = 0; hi_meas[i] = 0; }
-    if (i == 0) { stats[4] = 0; stats[5] = 0; }
-}
-
-int launch_clear_flags(pre3_ctx *c)
-{
-    int cnt = c->N > c->capm ? c->N : c->capm;
-    hipLaunchKernelGGL(k_clear_flags, dim3(ceil_div(cnt, 256)), dim3(256), 0, c->stream, c->N, c->capm, c->lm.li, c->lm.hi, c->li_meas, c->hi_meas, c->stats);
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }

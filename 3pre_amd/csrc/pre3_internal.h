@@ -115,7 +115,7 @@ struct pre3_ctx {
     bool li_kernel = false, hi_kernel = false;    // a select / collect kernel has run for the current measurement set
     // per-step inbox: [meas | ic | hyp | z] contiguous on the device, mirrored in pinned host memory -> ONE H2D copy
     void *inbox_dev = nullptr; unsigned char *inbox_host = nullptr;
-    size_t inbox_bytes = 0, off_meas = 0, off_ic = 0, off_hyp = 0, off_z = 0;
+    size_t inbox_bytes = 0, off_meas = 0, off_ic = 0, off_hyp = 0, off_z = 0, off_flags = 0, flags_bytes = 0;
     hipEvent_t inbox_copied = nullptr;            // recorded behind every copy out of the pinned inbox
     bool inbox_pending = false;
     // map management (allocated on first use)
@@ -136,6 +136,17 @@ struct pre3_ctx {
 
 namespace pre3 {
 
+// normJac.m:27-38
+__device__ inline void d_normjac(const double *q, double *J)
+{
+    double r = q[0], x = q[1], y = q[2], z = q[3];
+    double s = pow(r * r + x * x + y * y + z * z, -1.5);
+    J[0] = s * (x * x + y * y + z * z); J[1] = s * (-r * x); J[2] = s * (-r * y); J[3] = s * (-r * z);
+    J[4] = s * (-x * r); J[5] = s * (r * r + y * y + z * z); J[6] = s * (-x * y); J[7] = s * (-x * z);
+    J[8] = s * (-y * r); J[9] = s * (-y * x); J[10] = s * (r * r + x * x + z * z); J[11] = s * (-y * z);
+    J[12] = s * (-z * r); J[13] = s * (-z * x); J[14] = s * (-z * y); J[15] = s * (r * r + x * x + y * y);
+}
+
 // ---- IC search (pre3_match.hip)
 int launch_ic_search(pre3_ctx *c, double thresh, int strict);
 int launch_bank_gather(pre3_ctx *c, int N_new, const int32_t *src_host);
@@ -144,6 +155,7 @@ constexpr int DESC_DIM = 128;
 // ---- geometry / RANSAC kernels (pre3_geom.hip)
 int launch_project(pre3_ctx *c, int which, int clear_first);
 int launch_innovation(pre3_ctx *c, int mode /*0: S=HPH'+I for predicted; 1: rescue gate + HI list*/, double chi2);
+int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode, double chi2);
 int launch_update_x(pre3_ctx *c, int which_prior, int r);
 int launch_jnorm(pre3_ctx *c, int which);
 
@@ -151,9 +163,9 @@ int launch_jnorm(pre3_ctx *c, int which);
 // rows: ELL rows [r] in c->row_col/row_val with nu in c->row_nu; computes W = H*P (+ nu column),
 // S = H*P*H' + R, Cholesky, W = L^-1 [HP | nu], x += W' y, P -= W'W, Jnorm + normalise.
 int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_dev /*nullable, r_pad x ldw T*/, bool prebuilt = false);
-int launch_gather_li(pre3_ctx *c, int nsel, const int32_t *sel_dev, int ldg);
+int launch_gather_li(pre3_ctx *c, int nsel /* < 0: count read on the device */, int nsel_max, const int32_t *sel_dev, int ldg);
 int launch_ell_HP(pre3_ctx *c, int r, void *dst /*r_pad x ldw*/, bool with_nu);
 int launch_ell_G(pre3_ctx *c, int r, const void *HPsrc, void *dst, int ldg, int add_identity, const void *Rdense);
-int launch_downdate(pre3_ctx *c, int r, const void *W);
+int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior = -1 /* >= 0: also x <- x_prior + W'y (update.m:36) */);
 
 }  // namespace pre3

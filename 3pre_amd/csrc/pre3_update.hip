@@ -76,31 +76,6 @@ __global__ __launch_bounds__(64) void k_ell_G(int r, int r_pad, const int32_t *_
 
 // LI rows are a subset of the measured rows whose H*P and H*P*H' already exist (computed once per step for RANSAC):
 // gather them instead of recomputing.  sel[s] = measurement index of selected landmark s; row a = 2*sel[a/2] + (a&1).
-template <typename T>
-__global__ __launch_bounds__(256) void k_gather_rows(int r, int r_pad, const int32_t *__restrict__ sel, const T *__restrict__ HP,
-                                                     T *__restrict__ W, int ldw)
-{
-    const int a = blockIdx.y;
-    const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (j >= ldw || a >= r_pad) return;
-    typedef T v4_t __attribute__((ext_vector_type(4)));
-    v4_t v = { (T)0, (T)0, (T)0, (T)0 };
-    if (a < r) v = *reinterpret_cast<const v4_t *>(HP + (size_t)(2 * sel[a >> 1] + (a & 1)) * ldw + j);
-    *reinterpret_cast<v4_t *>(W + (size_t)a * ldw + j) = v;
-}
-
-template <typename T>
-__global__ __launch_bounds__(64) void k_gather_S(int r, int r_pad, const int32_t *__restrict__ sel, const T *__restrict__ G, int ldg,
-                                                 T *__restrict__ S)
-{
-    const int a = blockIdx.y;
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= r_pad || a >= r_pad) return;
-    T out = (a == b) ? (T)1 : (T)0;
-    if (a < r && b < r) out += G[(size_t)(2 * sel[a >> 1] + (a & 1)) * ldg + 2 * sel[b >> 1] + (b & 1)];
-    S[(size_t)a * r_pad + b] = out;
-}
-
 // ------------------------------------------------------------------------------------------------
 // Blocked Cholesky of S fused with the forward solve W = L^-1 [HP | nu].
 // The stacked matrix M = [S ; HP'] (rows: r_pad rows of S, then the ldw columns of HP as rows) is swept
@@ -893,10 +868,45 @@ __device__ __forceinline__ void lds_dma_stage(const T *__restrict__ W, int ldw, 
 // W is staged by LDS-DMA (global_load_lds_dwordx4: the [BK][64] image is lane-linear, 16 B per lane, so no
 // VGPR round trip and no ds_write), double-buffered: stage s+1 is requested when stage s starts and waited for
 // (vmcnt(0) + barrier) when it ends.  Same tile math and mirrored epilogue as k_downdate.
+// update.m:36,42,48 for 64 states per workgroup: x_out = x_prior + W'y (y = column `ld` of W), the normalisation Jacobian
+// at the un-normalised quaternion -> params[16..31], then the quaternion normalised.  Runs as extra workgroups of the K9
+// launch (it only reads W), which removes one kernel boundary from the update chain.
+template <typename T>
+__device__ __forceinline__ void update_x_block(int blk, int n, int r, const T *__restrict__ W, int ldw, int ld,
+                                               const double *__restrict__ x_prior, double *__restrict__ x_out, double *__restrict__ params)
+{
+    __shared__ double red[4][64];
+    __shared__ double q[4];
+    const int ci = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int i = blk * 64 + ci;                   // i < ldw always (ldw >= ld + 64 > n rounded up)
+    double s = 0;
+#pragma unroll 8
+    for (int a = rg; a < r; a += 4) s += (double)W[(size_t)a * ldw + i] * (double)W[(size_t)a * ldw + ld];
+    red[rg][ci] = s;
+    __syncthreads();
+    if (rg == 0) {
+        s = red[0][ci] + red[1][ci] + red[2][ci] + red[3][ci];
+        if (i < n) s += x_prior[i];
+    }
+    if (blk == 0) {                 // block-uniform branch: every thread of the block reaches the barrier
+        if (rg == 0 && i >= 3 && i < 7) q[i - 3] = s;
+        __syncthreads();
+        if (rg == 0 && i == 0) { double Jn[16]; d_normjac(q, Jn); for (int t = 0; t < 16; ++t) params[16 + t] = Jn[t]; }
+        if (rg == 0 && i >= 3 && i < 7) s = s / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    }
+    if (rg == 0 && i < n) x_out[i] = s;
+}
+
+struct XUpd { int n_tiles, n, r; const double *x_prior; double *x_out, *params; };
+
 template <typename T, int BK>
 __global__ __launch_bounds__(256) void k_downdate_1t(T *__restrict__ P, int ld, const T *__restrict__ W, int ldw, int r_pad,
-                                                     const int2 *__restrict__ tiles, int gen_size)
+                                                     const int2 *__restrict__ tiles, int gen_size, XUpd xu)
 {
+    if ((int)blockIdx.x >= xu.n_tiles) {            // the state update rides along (launch_downdate adds these workgroups)
+        update_x_block<T>(blockIdx.x - xu.n_tiles, xu.n, xu.r, W, ldw, ld, xu.x_prior, xu.x_out, xu.params);
+        return;
+    }
     // Workgroups are dispatched in generations of one per CU; give each generation its own wave priority so the
     // tiles sharing a SIMD finish one after another (their epilogue/HBM phases then hide behind the next tile's
     // MFMAs) instead of all together at the end.  Priority is a speed hint only.
@@ -1082,16 +1092,22 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad)
     return PRE3_OK;
 }
 
-int launch_downdate(pre3_ctx *c, int r, const void *W)
+int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
 {
     int r_pad = round_up(r, NB);
     // persistent grid: 2 workgroups per CU (or one per tile when there are fewer tiles); the tile counter is
     // monotonic across launches (each launch consumes grid + n_tiles tickets), reset long before it could wrap
     static const int wgs_per_cu = getenv("PRE3_K9_WGS") ? atoi(getenv("PRE3_K9_WGS")) : 3;
     const int gsz = std::min(c->n_tiles, wgs_per_cu * c->num_cus);
-    if (!c->tile_ctr_clean) PRE3_HIP(hipMemsetAsync(c->tile_ctr, 0, sizeof(unsigned int) * 8, c->stream));   // normally done by k_update_x
-    c->tile_ctr_clean = false;
     dim3 g(gsz), b(256);
+    static const int force = getenv("PRE3_K9_FORM") ? atoi(getenv("PRE3_K9_FORM")) : 0;     // 1: one-tile, 2: persistent (experiments)
+    // all tiles resident at once: 5 workgroups/CU in fp32 (16.9 KB of LDS each), 4 in fp64 (33.8 KB)
+    const bool one_tile = force == 1 || (force == 0 && c->n_tiles <= (c->dtype == PRE3_F32 ? 5 : 4) * c->num_cus);
+    if (!one_tile && which_prior >= 0) PRE3_TRY(launch_update_x(c, which_prior, r));          // (also resets the ticket counters)
+    if (!one_tile) {                                    // ticket counters of the persistent form
+        if (!c->tile_ctr_clean) PRE3_HIP(hipMemsetAsync(c->tile_ctr, 0, sizeof(unsigned int) * 8, c->stream));
+        c->tile_ctr_clean = false;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->kt.enabled) {
         if ((size_t)c->kt.used + 2 > c->kt.ev.size()) {
@@ -1101,14 +1117,12 @@ int launch_downdate(pre3_ctx *c, int r, const void *W)
         c->kt.used += 2;
         PRE3_HIP(hipEventRecord(e0, c->stream));
     }
-    static const int force = getenv("PRE3_K9_FORM") ? atoi(getenv("PRE3_K9_FORM")) : 0;     // 1: one-tile, 2: persistent (experiments)
-    // all tiles resident at once: 5 workgroups/CU in fp32 (16.9 KB of LDS each), 4 in fp64 (33.8 KB)
-    const bool one_tile = force == 1 || (force == 0 && c->n_tiles <= (c->dtype == PRE3_F32 ? 5 : 4) * c->num_cus);
     if (one_tile) {
-        dim3 g1(c->n_tiles);
+        XUpd xu{ c->n_tiles, c->n, r, which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1, c->x_kk, c->pred_params };
+        dim3 g1(c->n_tiles + (which_prior >= 0 ? ceil_div(c->n, 64) : 0));
         DISPATCH_T(c,
-            hipLaunchKernelGGL((k_downdate_1t<double, 16>), g1, b, 0, c->stream, (double *)c->P, c->ld, (const double *)W, c->ldw, r_pad, (const int2 *)c->tiles_flat, c->num_cus),
-            hipLaunchKernelGGL((k_downdate_1t<float, 16>), g1, b, 0, c->stream, (float *)c->P, c->ld, (const float *)W, c->ldw, r_pad, (const int2 *)c->tiles_flat, c->num_cus));
+            hipLaunchKernelGGL((k_downdate_1t<double, 16>), g1, b, 0, c->stream, (double *)c->P, c->ld, (const double *)W, c->ldw, r_pad, (const int2 *)c->tiles_flat, c->num_cus, xu),
+            hipLaunchKernelGGL((k_downdate_1t<float, 16>), g1, b, 0, c->stream, (float *)c->P, c->ld, (const float *)W, c->ldw, r_pad, (const int2 *)c->tiles_flat, c->num_cus, xu));
     } else
     DISPATCH_T(c,
         hipLaunchKernelGGL((k_downdate<double, 32>), g, b, 0, c->stream, (double *)c->P, c->ld, (const double *)W, c->ldw, r_pad, (const int2 *)c->tiles, c->tiles_stride, c->tile_cnt, c->tile_ctr),
@@ -1133,19 +1147,45 @@ int launch_fill_w(pre3_ctx *c, int r_pad)
     return PRE3_OK;
 }
 
-int launch_update_x(pre3_ctx *c, int which_prior, int r);   // pre3_geom.hip
 
 // rows already in c->row_* (r rows).  which_prior selects x prior; P currently holds the prior covariance.
-int launch_gather_li(pre3_ctx *c, int nsel, const int32_t *sel_dev, int ldg)
+// Rows of H*P (with the nu column) and the block of H*P*H' (+I) that the selected measurements pick out of what RANSAC
+// already multiplied out, in ONE launch.  nsel < 0: the count is read on the device (n_dev, written by k_ransac_select),
+// so the launch can be issued before the host has polled it; nsel_max bounds the grid.
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_li(int nsel, const int32_t *__restrict__ n_dev, int gxW, const int32_t *__restrict__ sel,
+                                                   const T *__restrict__ HP, T *__restrict__ W, int ldw, const T *__restrict__ G, int ldg,
+                                                   T *__restrict__ S)
 {
-    const int r = 2 * nsel, r_pad = round_up(r, NB);
-    dim3 g1(ceil_div(c->ldw / 4, 256), r_pad), b1(256), g2(ceil_div(r_pad, 64), r_pad), b2(64);
+    const int r = 2 * (nsel >= 0 ? nsel : n_dev[0]);
+    const int r_pad = (r + NB - 1) / NB * NB;
+    const int a = blockIdx.y;
+    if (a >= r_pad) return;
+    if ((int)blockIdx.x < gxW) {
+        const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
+        if (j >= ldw) return;
+        typedef T v4_t __attribute__((ext_vector_type(4)));
+        v4_t v = { (T)0, (T)0, (T)0, (T)0 };
+        if (a < r) v = *reinterpret_cast<const v4_t *>(HP + (size_t)(2 * sel[a >> 1] + (a & 1)) * ldw + j);
+        *reinterpret_cast<v4_t *>(W + (size_t)a * ldw + j) = v;
+    } else {
+        const int b = (blockIdx.x - gxW) * 256 + threadIdx.x;
+        if (b >= r_pad) return;
+        T out = (a == b) ? (T)1 : (T)0;
+        if (a < r && b < r) out += G[(size_t)(2 * sel[a >> 1] + (a & 1)) * ldg + 2 * sel[b >> 1] + (b & 1)];
+        S[(size_t)a * r_pad + b] = out;
+    }
+}
+
+int launch_gather_li(pre3_ctx *c, int nsel, int nsel_max, const int32_t *sel_dev, int ldg)
+{
+    const int r_pad = round_up(2 * (nsel >= 0 ? nsel : nsel_max), NB);
+    if (r_pad == 0) return PRE3_OK;
+    const int gxW = ceil_div(c->ldw / 4, 256);
+    dim3 g(gxW + ceil_div(r_pad, 256), r_pad), b(256);
     DISPATCH_T(c,
-        hipLaunchKernelGGL(k_gather_rows<double>, g1, b1, 0, c->stream, r, r_pad, sel_dev, (const double *)c->HP, (double *)c->W, c->ldw),
-        hipLaunchKernelGGL(k_gather_rows<float>, g1, b1, 0, c->stream, r, r_pad, sel_dev, (const float *)c->HP, (float *)c->W, c->ldw));
-    DISPATCH_T(c,
-        hipLaunchKernelGGL(k_gather_S<double>, g2, b2, 0, c->stream, r, r_pad, sel_dev, (const double *)c->G, ldg, (double *)c->Smat),
-        hipLaunchKernelGGL(k_gather_S<float>, g2, b2, 0, c->stream, r, r_pad, sel_dev, (const float *)c->G, ldg, (float *)c->Smat));
+        hipLaunchKernelGGL(k_gather_li<double>, g, b, 0, c->stream, nsel, c->stats + 4, gxW, sel_dev, (const double *)c->HP, (double *)c->W, c->ldw, (const double *)c->G, ldg, (double *)c->Smat),
+        hipLaunchKernelGGL(k_gather_li<float>, g, b, 0, c->stream, nsel, c->stats + 4, gxW, sel_dev, (const float *)c->HP, (float *)c->W, c->ldw, (const float *)c->G, ldg, (float *)c->Smat));
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }
@@ -1164,8 +1204,7 @@ int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_d
         PRE3_TRY(launch_ell_G(c, r, c->W, c->Smat, r_pad, 1, dense_R ? c->Rdense : nullptr));
     }
     PRE3_TRY(launch_chol_solve(c, r_pad));
-    PRE3_TRY(launch_update_x(c, which_prior, r));
-    PRE3_TRY(launch_downdate(c, r, c->W));
+    PRE3_TRY(launch_downdate(c, r, c->W, which_prior));
     PRE3_TRY(launch_jnorm(c, 0));
     if (Kt_out_dev) {
         dim3 g(ceil_div(c->n, 256)), b(256);

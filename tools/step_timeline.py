@@ -10,7 +10,7 @@ def short(n):
     n = re.sub(r"\(.*$", "", n)
     return n
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Grid_Size", r.get("Grid_Size_X", "?"))) for r in rows))
-starts = [i for i, e in enumerate(ev) if e[2].startswith("k_predict_x")]
+starts = [i for i, e in enumerate(ev) if e[2].startswith("k_predict")]
 a, b = starts[-back - 1], starts[-back]
 t0 = ev[a][0]
 print("# kernel | grid threads | start us | duration us | gap to previous us")
