@@ -22,7 +22,8 @@ void set_error(const char *fmt, ...)
 int launch_predict_impl(pre3_ctx *c, const double u[7]);
 int launch_window_gate(pre3_ctx *c, int M, const int32_t *pred_idx_dev, const int32_t *k1_dev, const double *zc_dev, int strict, int32_t *accept_dev);
 int launch_build_rows_impl(pre3_ctx *c, int nsel, const int32_t *sel_dev, int r_pad);
-int launch_ransac_score_impl(pre3_ctx *c, int k, double threshold, int hyp_begin, int hyp_end, int ldg, int32_t *support_dev, uint32_t *mask_dev, int mask_words);
+int launch_ransac_score_impl(pre3_ctx *c, int k, double threshold, int hyp_begin, int hyp_end, int ldg, int32_t *support_dev, uint32_t *mask_dev, int mask_words,
+                             int select_n_draw = 0, int early_exit = 0);
 int launch_ransac_select_impl(pre3_ctx *c, int n_draw, int k, int early_exit, int32_t *support_dev, const uint32_t *mask_dev, int mask_words);
 int launch_fill_w(pre3_ctx *c, int r_pad);
 int match_partial(int device, int cls, int ND, int K1, const void *L1, int K2, const void *L2, int k2_offset, double *best, double *second, int32_t *arg);
@@ -551,8 +552,7 @@ static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp)
         PRE3_HIP(hipEventRecord(c->inbox_copied, c->stream)); c->inbox_pending = true;
     }
     int r = 2 * c->m, r_pad = round_up(r, NB);
-    PRE3_TRY(launch_build_rows_impl(c, c->m, nullptr, r_pad));
-    PRE3_TRY(launch_ell_HP(c, r, c->HP, true));
+    PRE3_TRY(launch_ell_HP_build(c, c->HP));
     PRE3_TRY(launch_ell_G(c, r, c->HP, c->G, r_pad, 0, nullptr));
     c->hp_all_valid = true;
     return PRE3_OK;
@@ -575,12 +575,9 @@ int pre3_ransac_score(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, double
     return PRE3_OK;
 }
 
-int pre3_ransac_select(pre3_ctx *c, int n_draw, int k, int early_exit, int32_t *support, int32_t *li_mask, int32_t stats[4])
+// after the selection stage has been enqueued (its own kernel, or the tail of the scoring launch)
+static int ransac_results(pre3_ctx *c, int n_draw, int32_t *support, int32_t *li_mask, int32_t stats[4])
 {
-    PRE3_TRY(check_ctx(c));
-    PRE3_CHECK(n_draw >= 1 && n_draw <= c->caph, PRE3_E_ARG, "ransac: n_draw out of range");
-    int words = ceil_div(c->m, 32);
-    PRE3_TRY(launch_ransac_select_impl(c, n_draw, k, early_exit, c->support, c->masks, words));
     c->li_from_host = -1; c->li_kernel = true;
     if (support || li_mask) {
         PRE3_HIP(hipStreamSynchronize(c->stream));
@@ -589,6 +586,15 @@ int pre3_ransac_select(pre3_ctx *c, int n_draw, int k, int early_exit, int32_t *
     }
     if (stats) { PRE3_TRY(wait_mail(c, 8, c->seq_select)); for (int i = 0; i < 4; ++i) stats[i] = c->mail_host[i]; }
     return PRE3_OK;
+}
+
+int pre3_ransac_select(pre3_ctx *c, int n_draw, int k, int early_exit, int32_t *support, int32_t *li_mask, int32_t stats[4])
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(n_draw >= 1 && n_draw <= c->caph, PRE3_E_ARG, "ransac: n_draw out of range");
+    int words = ceil_div(c->m, 32);
+    PRE3_TRY(launch_ransac_select_impl(c, n_draw, k, early_exit, c->support, c->masks, words));
+    return ransac_results(c, n_draw, support, li_mask, stats);
 }
 
 int pre3_ransac_export(pre3_ctx *c, int n_draw, void *support_dst_dev, void *mask_dst_dev)
@@ -619,8 +625,9 @@ int pre3_ransac(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, double thres
     PRE3_TRY(check_ctx(c));
     PRE3_TRY(ransac_prepare(c, n_draw, k, hyp));
     int words = ceil_div(c->m, 32);
-    PRE3_TRY(launch_ransac_score_impl(c, k, threshold, 0, n_draw, round_up(2 * c->m, NB), c->support, c->masks, words));
-    return pre3_ransac_select(c, n_draw, k, early_exit, support, li_mask, stats);
+    // one launch: every hypothesis scored, the last workgroup to finish replays the reference's loop and picks the winner
+    PRE3_TRY(launch_ransac_score_impl(c, k, threshold, 0, n_draw, round_up(2 * c->m, NB), c->support, c->masks, words, n_draw, early_exit));
+    return ransac_results(c, n_draw, support, li_mask, stats);
 }
 
 // ---- updates --------------------------------------------------------------------------------------
@@ -734,12 +741,15 @@ int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, co
     PRE3_CHECK(n_draw >= 1 && n_draw <= c->caph && k >= 1 && k <= MAXK && hyp, PRE3_E_ARG, "pre3_step: bad hypothesis table");
     PRE3_TRY(install_measurements(c, m, meas_idx, z, hyp, n_draw * k, c->N > 0));   // matching_sift_based.m:131-134 outcome (+ the draws); flags cleared by k_project_innovation
     int32_t st[8] = { -1, 0, 0, 0, 0, 0, 0, 0 };
+    bool ran = false;
     if (m >= k && m > 0) {
-        PRE3_TRY(pre3_ransac(c, n_draw, k, (const int32_t *)(c->inbox_host + c->off_hyp), threshold, early_exit, nullptr, nullptr, st));   // mono_slam.m:178
-        st[4] = 0;
+        // mono_slam.m:178; the statistics are read after pre3_update_li's poll of the same mailbox
+        PRE3_TRY(pre3_ransac(c, n_draw, k, (const int32_t *)(c->inbox_host + c->off_hyp), threshold, early_exit, nullptr, nullptr, nullptr));
+        ran = true;
     }
     if (trace) t2 = now();
     PRE3_TRY(pre3_update_li(c));                                    // mono_slam.m:181
+    if (ran) for (int i = 0; i < 4; ++i) st[i] = c->mail_host[i];
     if (trace) t3 = now();
     PRE3_TRY(pre3_rescue(c, chi2, nullptr));                        // mono_slam.m:184
     if (trace) t4 = now();
@@ -916,7 +926,7 @@ int pre3_timer_stop(pre3_ctx *c, double *ms_out)
 int pre3_kernel_timing(pre3_ctx *c, int enable)
 {
     PRE3_TRY(check_ctx(c));
-    c->kt.enabled = enable != 0; c->kt.used = 0; c->kt.flops = 0; c->kt.bytes = 0;
+    c->kt.enabled = enable != 0; c->kt.every = enable > 1 ? enable : 1; c->kt.seen = 0; c->kt.used = 0; c->kt.flops = 0; c->kt.bytes = 0;
     return PRE3_OK;
 }
 

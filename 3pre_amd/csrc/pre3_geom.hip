@@ -374,6 +374,13 @@ __global__ __launch_bounds__(256) void k_innovation(int N, const int32_t *__rest
     innovation_body<T>(N, lm_type, lm_off, P, ld, Hc, Hl, has_h, mode, chi2, h, z, ic, li, hi, S, has_S);
 }
 
+// the HI collection (k_collect_hi's work) as the tail of the rescue launch: run by the first wave of the LAST workgroup
+struct HiArgs { int fuse, m, seq; const int32_t *meas; int32_t *hi_meas, *sel_rows, *stats, *mail; unsigned int *done; };
+__device__ __forceinline__ void collect_hi_body(int m, const int32_t *__restrict__ meas, const int32_t *__restrict__ lm_ic,
+                                                const int32_t *__restrict__ lm_li, const int32_t *lm_hi,
+                                                int32_t *__restrict__ hi_meas, int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats,
+                                                int32_t *mail, int seq);
+
 // k_project and k_innovation in ONE launch: the first of a landmark's 16 lanes projects it and writes h / H, the block
 // barrier publishes them, then the 16 lanes gather H P H' as before.  Saves a kernel boundary (~5 us) twice per step.
 template <typename T>
@@ -382,7 +389,7 @@ __global__ __launch_bounds__(256) void k_project_innovation(int N, const int32_t
                                                             double *Hc, double *Hl, int32_t *has_h, int mode, double chi2, double *h,
                                                             const double *__restrict__ z, const int32_t *__restrict__ ic,
                                                             const int32_t *__restrict__ li, int32_t *__restrict__ hi, double *__restrict__ S,
-                                                            int32_t *__restrict__ has_S, int32_t *__restrict__ clear, int n_clear)
+                                                            int32_t *__restrict__ has_S, int32_t *__restrict__ clear, int n_clear, HiArgs ha)
 {
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     // a step's IC search precedes its measurements: clear the inlier flags of the previous frame here (n_clear = 0 otherwise)
@@ -392,6 +399,20 @@ __global__ __launch_bounds__(256) void k_project_innovation(int N, const int32_t
     __threadfence_block();
     __syncthreads();
     innovation_body<T>(N, lm_type, lm_off, P, ld, Hc, Hl, has_h, mode, chi2, h, z, ic, li, hi, S, has_S);
+    if (ha.fuse) {
+        __shared__ int s_last;
+        __syncthreads();                                   // this workgroup's hi flags are written
+        if (threadIdx.x == 0) {
+            __threadfence();
+            s_last = atomicAdd(ha.done, 1u) == gridDim.x - 1;
+        }
+        __syncthreads();
+        if (s_last && threadIdx.x < 64) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (threadIdx.x == 0) *ha.done = 0;
+            collect_hi_body(ha.m, ha.meas, ic, li, hi, ha.hi_meas, ha.sel_rows, ha.stats, ha.mail, ha.seq);
+        }
+    }
 }
 
 // matching_sift_based.m:119-134
@@ -456,14 +477,27 @@ __device__ inline int wave_sum(int v)
     return v;
 }
 
+// Arguments of the selection stage when it rides at the end of the scoring launch (fuse != 0): the LAST workgroup to
+// finish (device-wide ticket) replays the reference's loop over all supports -- one kernel boundary less per step.
+struct SelArgs {
+    int fuse, n_draw, k, early_exit, seq;
+    int32_t *li_meas, *lm_li, *sel_rows, *stats, *mail;
+    unsigned int *done;
+};
+__device__ __forceinline__ void select_body(int n_draw, int k, int early_exit, int m, const int32_t *__restrict__ meas,
+                                            int32_t *support, const uint32_t *masks, int mask_words,
+                                            int32_t *__restrict__ li_meas, int32_t *__restrict__ lm_li,
+                                            int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats,
+                                            int32_t *mail, int seq);
+
 template <typename T, int K>
 __global__ __launch_bounds__(256) void k_ransac_score(int hyp_begin, const int32_t *__restrict__ hyp, int m,
                                                       const int32_t *__restrict__ meas, const int32_t *__restrict__ lm_type,
                                                       const int32_t *__restrict__ lm_off, const double *__restrict__ x,
                                                       const T *__restrict__ HP, int ldw, const T *__restrict__ G, int ldg,
                                                       const double *__restrict__ row_nu, const double *__restrict__ z,
-                                                      CamD cam, double threshold, int32_t *__restrict__ support,
-                                                      uint32_t *__restrict__ masks, int mask_words)
+                                                      CamD cam, double threshold, int32_t *support,
+                                                      uint32_t *masks, int mask_words, SelArgs sel)
 {
     constexpr int R = 2 * K;                // compile-time so that every small array stays in registers
     extern __shared__ double s_res[];       // [m] residuals, then mask words
@@ -579,6 +613,21 @@ __global__ __launch_bounds__(256) void k_ransac_score(int hyp_begin, const int32
     __syncthreads();
     if (tid == 0) support[hidx] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     for (int wd = tid; wd < mask_words; wd += blockDim.x) masks[(size_t)hidx * mask_words + wd] = s_mask[wd];
+    if (sel.fuse) {
+        __shared__ int s_last;
+        __syncthreads();                                   // this workgroup's support and mask are written
+        if (tid == 0) {
+            __threadfence();
+            s_last = atomicAdd(sel.done, 1u) == gridDim.x - 1;
+        }
+        __syncthreads();
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // see every other workgroup's results
+            if (tid == 0) *sel.done = 0;
+            select_body(sel.n_draw, sel.k, sel.early_exit, m, meas, support, masks, mask_words, sel.li_meas, sel.lm_li, sel.sel_rows,
+                        sel.stats, sel.mail, sel.seq);
+        }
+    }
 }
 
 // K6: sequential replay of ransac_hypotheses.m:40-80 over the supports (quirk Q1), winner's mask ->
@@ -603,11 +652,11 @@ __device__ inline int ransac_n_hyp(int sup, int m)
 // n_hyp <= k can only become true at an improvement, so the replay walks the improvements in order:
 // wave 0 finds them 64 supports at a time (prefix max by shuffles + ballot) and evaluates the few hits.
 // out[0..5]: written twice -- device stats (for later kernels) and the pinned host mirror (polled by the host).
-__global__ __launch_bounds__(256) void k_ransac_select(int n_draw, int k, int early_exit, int m, const int32_t *__restrict__ meas,
-                                                       int32_t *__restrict__ support, const uint32_t *__restrict__ masks, int mask_words,
-                                                       int32_t *__restrict__ li_meas, int32_t *__restrict__ lm_li,
-                                                       int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats,
-                                                       int32_t *mail, int seq)
+__device__ __forceinline__ void select_body(int n_draw, int k, int early_exit, int m, const int32_t *__restrict__ meas,
+                                            int32_t *support, const uint32_t *masks, int mask_words,
+                                            int32_t *__restrict__ li_meas, int32_t *__restrict__ lm_li,
+                                            int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats,
+                                            int32_t *mail, int seq)
 {
     __shared__ int s_best, s_iters, s_wcnt[4], s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -673,11 +722,20 @@ __global__ __launch_bounds__(256) void k_ransac_select(int n_draw, int k, int ea
     }
 }
 
+__global__ __launch_bounds__(256) void k_ransac_select(int n_draw, int k, int early_exit, int m, const int32_t *__restrict__ meas,
+                                                       int32_t *__restrict__ support, const uint32_t *__restrict__ masks, int mask_words,
+                                                       int32_t *__restrict__ li_meas, int32_t *__restrict__ lm_li,
+                                                       int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats,
+                                                       int32_t *mail, int seq)
+{
+    select_body(n_draw, k, early_exit, m, meas, support, masks, mask_words, li_meas, lm_li, sel_rows, stats, mail, seq);
+}
+
 // hi flags (landmark order, written by k_innovation mode 1) -> measurement order + compacted list
-__global__ __launch_bounds__(64) void k_collect_hi(int m, const int32_t *__restrict__ meas, const int32_t *__restrict__ lm_ic,
-                                                   const int32_t *__restrict__ lm_li, const int32_t *__restrict__ lm_hi,
-                                                   int32_t *__restrict__ hi_meas, int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats,
-                                                   int32_t *mail, int seq)
+__device__ __forceinline__ void collect_hi_body(int m, const int32_t *__restrict__ meas, const int32_t *__restrict__ lm_ic,
+                                                const int32_t *__restrict__ lm_li, const int32_t *lm_hi,
+                                                int32_t *__restrict__ hi_meas, int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats,
+                                                int32_t *mail, int seq)
 {
     const int tid = threadIdx.x;
     int cnt = 0;
@@ -697,6 +755,14 @@ __global__ __launch_bounds__(64) void k_collect_hi(int m, const int32_t *__restr
         __threadfence_system();
         __hip_atomic_store(&mail[9], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+__global__ __launch_bounds__(64) void k_collect_hi(int m, const int32_t *__restrict__ meas, const int32_t *__restrict__ lm_ic,
+                                                   const int32_t *__restrict__ lm_li, const int32_t *__restrict__ lm_hi,
+                                                   int32_t *__restrict__ hi_meas, int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats,
+                                                   int32_t *mail, int seq)
+{
+    collect_hi_body(m, meas, lm_ic, lm_li, lm_hi, hi_meas, sel_rows, stats, mail, seq);
 }
 
 // x_out = x_prior + W' y  (update.m:36), then Jn at the un-normalised quaternion (update.m:42) -> params,
@@ -782,16 +848,17 @@ int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode,
     const double *x = which == PRE3_X_K_K ? c->x_kk : c->x_km1;
     int32_t *clr = (int32_t *)((unsigned char *)c->inbox_dev + c->off_flags);
     const int n_clr = mode == 0 ? (int)(c->flags_bytes / sizeof(int32_t)) : 0;
+    HiArgs ha{};
+    if (mode == 1) ha = HiArgs{ 1, c->m, ++c->seq_collect, c->meas, c->hi_meas, c->sel_rows, c->stats, c->mail_dev, c->chol_arrive + 2 };
     dim3 g(ceil_div(c->N * 16, 256)), b(256);
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_project_innovation<double>, g, b, 0, c->stream, c->N, c->lm.type, c->lm.off, x, to_camd(c->cam), clear_first,
                            (const double *)c->P, c->ld, c->lm.Hc, c->lm.Hl, c->lm.has_h, mode, chi2, c->lm.h, c->lm.z, c->lm.ic, c->lm.li,
-                           c->lm.hi, c->lm.S, c->lm.has_S, clr, n_clr),
+                           c->lm.hi, c->lm.S, c->lm.has_S, clr, n_clr, ha),
         hipLaunchKernelGGL(k_project_innovation<float>, g, b, 0, c->stream, c->N, c->lm.type, c->lm.off, x, to_camd(c->cam), clear_first,
                            (const float *)c->P, c->ld, c->lm.Hc, c->lm.Hl, c->lm.has_h, mode, chi2, c->lm.h, c->lm.z, c->lm.ic, c->lm.li,
-                           c->lm.hi, c->lm.S, c->lm.has_S, clr, n_clr));
+                           c->lm.hi, c->lm.S, c->lm.has_S, clr, n_clr, ha));
     PRE3_HIP(hipGetLastError());
-    if (mode == 1) PRE3_TRY(launch_collect_hi(c));
     return PRE3_OK;
 }
 
@@ -832,10 +899,10 @@ int launch_build_rows_impl(pre3_ctx *c, int nsel, const int32_t *sel_dev, int r_
 
 template <typename T>
 static void launch_score_k(pre3_ctx *c, int k, int nb, size_t shm, int hyp_begin, double threshold, int ldg, int32_t *support_dev,
-                           uint32_t *mask_dev, int mask_words)
+                           uint32_t *mask_dev, int mask_words, const SelArgs &sel)
 {
 #define SCORE_ARGS hyp_begin, c->hyp, c->m, c->meas, c->lm.type, c->lm.off, c->x_km1, (const T *)c->HP, c->ldw, (const T *)c->G, ldg, \
-                   c->row_nu, c->lm.z, to_camd(c->cam), threshold, support_dev, mask_dev, mask_words
+                   c->row_nu, c->lm.z, to_camd(c->cam), threshold, support_dev, mask_dev, mask_words, sel
     switch (k) {
     case 1: hipLaunchKernelGGL((k_ransac_score<T, 1>), dim3(nb), dim3(256), shm, c->stream, SCORE_ARGS); break;
     case 2: hipLaunchKernelGGL((k_ransac_score<T, 2>), dim3(nb), dim3(256), shm, c->stream, SCORE_ARGS); break;
@@ -845,15 +912,20 @@ static void launch_score_k(pre3_ctx *c, int k, int nb, size_t shm, int hyp_begin
 #undef SCORE_ARGS
 }
 
+// select_n_draw > 0: the selection stage (k_ransac_select's work) runs in the last workgroup of this launch
 int launch_ransac_score_impl(pre3_ctx *c, int k, double threshold, int hyp_begin, int hyp_end, int ldg, int32_t *support_dev,
-                             uint32_t *mask_dev, int mask_words)
+                             uint32_t *mask_dev, int mask_words, int select_n_draw, int early_exit)
 {
     int nb = hyp_end - hyp_begin;
     if (nb <= 0) return PRE3_OK;
     size_t shm = sizeof(double) * c->m + sizeof(uint32_t) * mask_words + 16;
+    SelArgs sel{};
+    if (select_n_draw > 0) {
+        sel = SelArgs{ 1, select_n_draw, k, early_exit, ++c->seq_select, c->li_meas, c->lm.li, c->sel_rows, c->stats, c->mail_dev, c->chol_arrive + 1 };
+    }
     DISPATCH_T(c,
-        launch_score_k<double>(c, k, nb, shm, hyp_begin, threshold, ldg, support_dev, mask_dev, mask_words),
-        launch_score_k<float>(c, k, nb, shm, hyp_begin, threshold, ldg, support_dev, mask_dev, mask_words));
+        launch_score_k<double>(c, k, nb, shm, hyp_begin, threshold, ldg, support_dev, mask_dev, mask_words, sel),
+        launch_score_k<float>(c, k, nb, shm, hyp_begin, threshold, ldg, support_dev, mask_dev, mask_words, sel));
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }

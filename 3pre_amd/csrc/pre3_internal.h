@@ -52,6 +52,7 @@ struct LmBuffers {
 
 struct KernelTiming {
     bool enabled = false;
+    int every = 1, seen = 0;        // bracket one K9 launch out of `every` (an event pair costs ~11 us of stream time)
     std::vector<hipEvent_t> ev;     // pairs
     int used = 0;
     double flops = 0, bytes = 0;
@@ -163,6 +164,7 @@ int launch_jnorm(pre3_ctx *c, int which);
 // rows: ELL rows [r] in c->row_col/row_val with nu in c->row_nu; computes W = H*P (+ nu column),
 // S = H*P*H' + R, Cholesky, W = L^-1 [HP | nu], x += W' y, P -= W'W, Jnorm + normalise.
 int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_dev /*nullable, r_pad x ldw T*/, bool prebuilt = false);
+int launch_ell_HP_build(pre3_ctx *c, void *dst);
 int launch_gather_li(pre3_ctx *c, int nsel /* < 0: count read on the device */, int nsel_max, const int32_t *sel_dev, int ldg);
 int launch_ell_HP(pre3_ctx *c, int r, void *dst /*r_pad x ldw*/, bool with_nu);
 int launch_ell_G(pre3_ctx *c, int r, const void *HPsrc, void *dst, int ldg, int add_identity, const void *Rdense);

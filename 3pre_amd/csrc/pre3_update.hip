@@ -51,6 +51,54 @@ __global__ __launch_bounds__(256) void k_ell_HP(int r, int r_pad, const int32_t 
     dst[(size_t)a * ldw + j] = out;
 }
 
+// The same for ALL measured rows, with the ELL rows built on the fly from the per-landmark Jacobians (k_build_rows' work:
+// row 2s+c of measurement s = [Hc(c,:) | Hl(c,:)] at columns [0..6 | off..off+d-1], nu = z - h); block column 0 also
+// stores the rows for the kernels that follow (H*P*H', scoring, the update).  One kernel boundary less per step.
+template <typename T>
+__global__ __launch_bounds__(256) void k_ell_HP_build(int m, int r_pad, const int32_t *__restrict__ meas, const int32_t *__restrict__ lm_type,
+                                                      const int32_t *__restrict__ lm_off, const double *__restrict__ Hc,
+                                                      const double *__restrict__ Hl, const double *__restrict__ z, const double *__restrict__ h,
+                                                      int32_t *__restrict__ row_col, T *__restrict__ row_val, double *__restrict__ row_nu,
+                                                      const T *__restrict__ P, int ld, T *__restrict__ dst, int ldw)
+{
+    const int a = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= r_pad) return;
+    T out = (T)0;
+    if (a < 2 * m) {
+        const int i = meas[a >> 1], c = a & 1;
+        const int d = lm_type[i] == PRE3_INVDEPTH ? 6 : 3, off = lm_off[i];
+        T vv[13]; int cc[13];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) { cc[t] = t; vv[t] = (T)Hc[14 * i + c * 7 + t]; }
+#pragma unroll
+        for (int t = 0; t < 6; ++t) { cc[7 + t] = t < d ? off + t : 0; vv[7 + t] = t < d ? (T)Hl[12 * i + c * 6 + t] : (T)0; }
+        const double nu = z[2 * i + c] - h[2 * i + c];
+        if (blockIdx.x == 0) {
+            if (threadIdx.x < ELLW) {
+                const int t = threadIdx.x;
+                int cv = 0; T vt = (T)0;
+#pragma unroll
+                for (int u = 0; u < 13; ++u) if (u == t) { cv = cc[u]; vt = vv[u]; }
+                row_col[a * ELLW + t] = cv; row_val[a * ELLW + t] = vt;
+            }
+            if (threadIdx.x == 0) row_nu[a] = nu;
+        }
+        if (j < ld) {
+            T s = (T)0;
+#pragma unroll
+            for (int t = 0; t < 13; ++t) s += vv[t] * P[(size_t)cc[t] * ld + j];
+            out = s;
+        } else if (j == ld) {
+            out = (T)nu;
+        }
+    } else if (blockIdx.x == 0) {
+        if (threadIdx.x < ELLW) { row_col[a * ELLW + threadIdx.x] = 0; row_val[a * ELLW + threadIdx.x] = (T)0; }
+        if (threadIdx.x == 0) row_nu[a] = 0;
+    }
+    if (j < ldw) dst[(size_t)a * ldw + j] = out;
+}
+
 // dst[a][b] = sum_t val[b][t] * HP[a][col[b][t]] + (R ? R[a][b] : add_identity*delta_ab); padding = identity
 template <typename T>
 __global__ __launch_bounds__(64) void k_ell_G(int r, int r_pad, const int32_t *__restrict__ row_col, const T *__restrict__ row_val,
@@ -1043,6 +1091,20 @@ int launch_ell_HP(pre3_ctx *c, int r, void *dst, bool with_nu)
     return PRE3_OK;
 }
 
+// rows of all m measurements built and multiplied in one launch (replaces launch_build_rows_impl + launch_ell_HP)
+int launch_ell_HP_build(pre3_ctx *c, void *dst)
+{
+    const int r_pad = round_up(2 * c->m, NB);
+    dim3 g(ceil_div(c->ldw, 256), r_pad), b(256);
+    DISPATCH_T(c,
+        hipLaunchKernelGGL(k_ell_HP_build<double>, g, b, 0, c->stream, c->m, r_pad, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl, c->lm.z, c->lm.h,
+                           c->row_col, (double *)c->row_val, c->row_nu, (const double *)c->P, c->ld, (double *)dst, c->ldw),
+        hipLaunchKernelGGL(k_ell_HP_build<float>, g, b, 0, c->stream, c->m, r_pad, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl, c->lm.z, c->lm.h,
+                           c->row_col, (float *)c->row_val, c->row_nu, (const float *)c->P, c->ld, (float *)dst, c->ldw));
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
 int launch_ell_G(pre3_ctx *c, int r, const void *HPsrc, void *dst, int ldg, int add_identity, const void *Rdense)
 {
     int r_pad = round_up(r, NB);
@@ -1109,7 +1171,8 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
         c->tile_ctr_clean = false;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->kt.enabled) {
+    const bool timed = c->kt.enabled && (c->kt.seen++ % c->kt.every) == 0;
+    if (timed) {
         if ((size_t)c->kt.used + 2 > c->kt.ev.size()) {
             for (int i = 0; i < 2; ++i) { hipEvent_t e; PRE3_HIP(hipEventCreate(&e)); c->kt.ev.push_back(e); }
         }
@@ -1127,7 +1190,7 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
     DISPATCH_T(c,
         hipLaunchKernelGGL((k_downdate<double, 32>), g, b, 0, c->stream, (double *)c->P, c->ld, (const double *)W, c->ldw, r_pad, (const int2 *)c->tiles, c->tiles_stride, c->tile_cnt, c->tile_ctr),
         hipLaunchKernelGGL((k_downdate<float, 32>), g, b, 0, c->stream, (float *)c->P, c->ld, (const float *)W, c->ldw, r_pad, (const int2 *)c->tiles, c->tiles_stride, c->tile_cnt, c->tile_ctr));
-    if (c->kt.enabled) {
+    if (timed) {
         PRE3_HIP(hipEventRecord(e1, c->stream));
         c->kt.flops += (double)c->n * ((double)c->n + 1.0) * r;          // SYRK count n(n+1)r; the survey's un-halved figure is 2 n^2 r
         c->kt.bytes += 1.5 * c->n * (double)c->n * c->esz + (double)c->n * (double)r * c->esz;

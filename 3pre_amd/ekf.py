@@ -259,7 +259,8 @@ class EkfFilter:
         return ms.value
 
     def kernel_timing(self, enable):
-        check(lib.pre3_kernel_timing(self._ctx, int(bool(enable))))
+        """True / 1: time every K9 launch; N > 1: one launch in N; False / 0: off."""
+        check(lib.pre3_kernel_timing(self._ctx, int(enable)))
 
     def kernel_timing_read(self):
         n, ms, fl, by = C.c_int(0), C.c_double(0), C.c_double(0), C.c_double(0)

@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--landmarks", type=int, default=500)
     ap.add_argument("--hyp", type=int, default=200)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--kt-every", type=int, default=4, help="bracket one K9 launch in N with HIP events (an event pair costs ~11 us of stream time); 1 = every launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the sharded-RANSAC and matcher legs")
@@ -159,7 +160,7 @@ def main():
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    f.kernel_timing(True)
+    f.kernel_timing(max(1, args.kt_every))
     f.timer_start()
     t0 = time.perf_counter()
     for s in seq["steps"][W:W + K]:
