@@ -25,6 +25,7 @@ lib = C.CDLL(LIB_PATH)
 lib.pre3_last_error.restype = C.c_char_p
 lib.pre3_version.restype = C.c_char_p
 lib.pre3_match_bench_create.restype = C.c_void_p
+lib.pre3_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_void_p]
 
 F64, F32 = 0, 1
 INVDEPTH, CARTESIAN = 0, 1
@@ -48,6 +49,15 @@ def check(rc):
 
 def dptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def addr(a):
+    """Address of a C-contiguous array as an int: 0.3 us through the buffer protocol instead of 2 us through ndarray.ctypes
+    (the per-step wrapper overhead is GPU idle time); falls back for read-only or empty arrays."""
+    try:
+        return C.addressof(C.c_char.from_buffer(a))
+    except (TypeError, ValueError, BufferError):
+        return a.ctypes.data
 
 
 def f64(a):

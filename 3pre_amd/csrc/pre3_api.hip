@@ -729,7 +729,7 @@ int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, co
 {
     PRE3_TRY(check_ctx(c));
     static const bool trace = getenv("PRE3_STEP_TRACE") != nullptr;     // host-side stage clock (debug): where the host spends a step
-    static double acc[8]; static int nacc = 0;
+    static double acc[8], t_prev_end = 0; static int nacc = 0;
     auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; };
     double t0 = trace ? now() : 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
     PRE3_TRY(pre3_predict(c, u));                                   // mono_slam.m:153
@@ -757,9 +757,11 @@ int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, co
     if (trace) {
         t5 = now();
         acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += t4 - t3; acc[4] += t5 - t4;
+        if (t_prev_end > 0) acc[5] += t0 - t_prev_end;
+        t_prev_end = t5;
         if (++nacc == 100) {
-            fprintf(stderr, "[pre3 step trace, us] predict+project+innov launches %.1f | install+ransac launches %.1f | update_li (poll+launches) %.1f | rescue launches %.1f | update_hi (poll) %.1f\n",
-                    acc[0] / nacc, acc[1] / nacc, acc[2] / nacc, acc[3] / nacc, acc[4] / nacc);
+            fprintf(stderr, "[pre3 step trace, us] predict+project+innov launches %.1f | install+ransac launches %.1f | update_li (poll+launches) %.1f | rescue launches %.1f | update_hi (poll) %.1f | caller between steps %.1f\n",
+                    acc[0] / nacc, acc[1] / nacc, acc[2] / nacc, acc[3] / nacc, acc[4] / nacc, acc[5] / nacc);
             nacc = 0; for (double &a : acc) a = 0;
         }
     }

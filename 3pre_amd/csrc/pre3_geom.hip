@@ -108,7 +108,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_predict(const double *__restrict__ x_in, double *__restrict__ x_out, T *__restrict__ P, int n, int ld, U7 u,
                                                  double *__restrict__ params)
 {
-    __shared__ double sQq1[16], sJn[16], sQ[49];
+    __shared__ double sQq1[16], sJn[16], sQ[49], sG[49], sPn[49], sGP[49];
     __shared__ double corner[49];      // old P[0:7,0:7]
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     // landmarks copied (predict_state_and_covariance.m:79)
@@ -135,24 +135,13 @@ __global__ __launch_bounds__(256) void k_predict(const double *__restrict__ x_in
             d_q2R_sola(q, R);
             for (int i = 0; i < 3; ++i) xo[i] = x_in[i] + (R[i * 3] * u.v[0] + R[i * 3 + 1] * u.v[1] + R[i * 3 + 2] * u.v[2]);
             const double Qq2[16] = { a, -b, -c, -d,  b, a, -d, c,  c, d, a, -b,  d, -c, b, a };
-            // G = [R 0; 0 Qq2] (7x7 non-zero part), Q7 = G Pn G'
-            double G[49], Pn[49], GP[49];
-            for (int i = 0; i < 49; ++i) G[i] = 0;
-            for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) G[i * 7 + k] = R[i * 3 + k];
-            for (int i = 0; i < 4; ++i) for (int k = 0; k < 4; ++k) G[(3 + i) * 7 + 3 + k] = Qq2[i * 4 + k];
+            // G = [R 0; 0 Qq2] (7x7 non-zero part) and the process noise go to LDS; Q7 = G Pn G' is formed by 49 lanes below
+            double Pn[49];
+            for (int i = 0; i < 49; ++i) sG[i] = 0;
+            for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) sG[i * 7 + k] = R[i * 3 + k];
+            for (int i = 0; i < 4; ++i) for (int k = 0; k < 4; ++k) sG[(3 + i) * 7 + 3 + k] = Qq2[i * 4 + k];
             d_process_noise(Pn);
-            for (int i = 0; i < 7; ++i)
-                for (int k = 0; k < 7; ++k) {
-                    double s = 0;
-                    for (int t = 0; t < 7; ++t) s += G[i * 7 + t] * Pn[t * 7 + k];
-                    GP[i * 7 + k] = s;
-                }
-            for (int i = 0; i < 7; ++i)
-                for (int k = 0; k < 7; ++k) {
-                    double s = 0;
-                    for (int t = 0; t < 7; ++t) s += GP[i * 7 + t] * G[k * 7 + t];
-                    sQ[i * 7 + k] = s; params[32 + i * 7 + k] = s;
-                }
+            for (int i = 0; i < 49; ++i) sPn[i] = Pn[i];
             for (int i = 0; i < 16; ++i) { params[i] = Qq1[i]; params[16 + i] = Jn[i]; }
             const double nq = sqrt(xo[3] * xo[3] + xo[4] * xo[4] + xo[5] * xo[5] + xo[6] * xo[6]);
             for (int i = 0; i < 3; ++i) x_out[i] = xo[i];
@@ -171,6 +160,11 @@ __global__ __launch_bounds__(256) void k_predict(const double *__restrict__ x_in
         // pose block: C = F7 * P7 * F7' + Q7 with F7 = blkdiag(I3, Qq1); then J7 C J7', J7 = blkdiag(I3, Jn).
         __shared__ double F7[49], J7[49], T1[49], C7[49];
         const int t = threadIdx.x, i = t / 7, k = t % 7;
+        // Q7 = G Pn G' (same summation order as the serial form: t = 0..6)
+        if (t < 49) { double s = 0; for (int q2 = 0; q2 < 7; ++q2) s += sG[i * 7 + q2] * sPn[q2 * 7 + k]; sGP[t] = s; }
+        __syncthreads();
+        if (t < 49) { double s = 0; for (int q2 = 0; q2 < 7; ++q2) s += sGP[i * 7 + q2] * sG[k * 7 + q2]; sQ[t] = s; params[32 + t] = s; }
+        __syncthreads();
         if (t < 49) {
             double f = (i == k && i < 3) ? 1.0 : 0.0, jn = f;
             if (i >= 3 && k >= 3) { f = sQq1[(i - 3) * 4 + (k - 3)]; jn = sJn[(i - 3) * 4 + (k - 3)]; }

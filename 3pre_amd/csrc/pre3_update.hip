@@ -61,42 +61,49 @@ __global__ __launch_bounds__(256) void k_ell_HP_build(int m, int r_pad, const in
                                                       int32_t *__restrict__ row_col, T *__restrict__ row_val, double *__restrict__ row_nu,
                                                       const T *__restrict__ P, int ld, T *__restrict__ dst, int ldw)
 {
-    const int a = blockIdx.y;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= r_pad) return;
-    T out = (T)0;
-    if (a < 2 * m) {
-        const int i = meas[a >> 1], c = a & 1;
+    // blockIdx.y = measurement s (rows 2s and 2s+1 share their 13 P rows: loaded once); four consecutive columns per lane:
+    // 16-byte (fp32) loads of the gathered P rows, 16-byte stores
+    typedef T v4_t __attribute__((ext_vector_type(4)));
+    const int sIdx = blockIdx.y;
+    const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (2 * sIdx >= r_pad) return;
+    v4_t out0 = { (T)0, (T)0, (T)0, (T)0 }, out1 = out0;
+    if (sIdx < m) {
+        const int i = meas[sIdx];
         const int d = lm_type[i] == PRE3_INVDEPTH ? 6 : 3, off = lm_off[i];
-        T vv[13]; int cc[13];
+        T v0[13], v1[13]; int cc[13];
 #pragma unroll
-        for (int t = 0; t < 7; ++t) { cc[t] = t; vv[t] = (T)Hc[14 * i + c * 7 + t]; }
+        for (int t = 0; t < 7; ++t) { cc[t] = t; v0[t] = (T)Hc[14 * i + t]; v1[t] = (T)Hc[14 * i + 7 + t]; }
 #pragma unroll
-        for (int t = 0; t < 6; ++t) { cc[7 + t] = t < d ? off + t : 0; vv[7 + t] = t < d ? (T)Hl[12 * i + c * 6 + t] : (T)0; }
-        const double nu = z[2 * i + c] - h[2 * i + c];
+        for (int t = 0; t < 6; ++t) { cc[7 + t] = t < d ? off + t : 0; v0[7 + t] = t < d ? (T)Hl[12 * i + t] : (T)0; v1[7 + t] = t < d ? (T)Hl[12 * i + 6 + t] : (T)0; }
+        const double nu0 = z[2 * i] - h[2 * i], nu1 = z[2 * i + 1] - h[2 * i + 1];
         if (blockIdx.x == 0) {
-            if (threadIdx.x < ELLW) {
-                const int t = threadIdx.x;
+            if (threadIdx.x < 2 * ELLW) {
+                const int t = threadIdx.x & (ELLW - 1), c = threadIdx.x >> 4;
                 int cv = 0; T vt = (T)0;
 #pragma unroll
-                for (int u = 0; u < 13; ++u) if (u == t) { cv = cc[u]; vt = vv[u]; }
-                row_col[a * ELLW + t] = cv; row_val[a * ELLW + t] = vt;
+                for (int u = 0; u < 13; ++u) if (u == t) { cv = cc[u]; vt = c ? v1[u] : v0[u]; }
+                row_col[(2 * sIdx + c) * ELLW + t] = cv; row_val[(2 * sIdx + c) * ELLW + t] = vt;
             }
-            if (threadIdx.x == 0) row_nu[a] = nu;
+            if (threadIdx.x == 0) { row_nu[2 * sIdx] = nu0; row_nu[2 * sIdx + 1] = nu1; }
         }
-        if (j < ld) {
-            T s = (T)0;
+        if (j < ld) {                                   // ld is a multiple of 128: the whole quad is inside
+            v4_t pv[13];
 #pragma unroll
-            for (int t = 0; t < 13; ++t) s += vv[t] * P[(size_t)cc[t] * ld + j];
-            out = s;
+            for (int t = 0; t < 13; ++t) pv[t] = *reinterpret_cast<const v4_t *>(P + (size_t)cc[t] * ld + j);
+#pragma unroll
+            for (int t = 0; t < 13; ++t) { out0 += v0[t] * pv[t]; out1 += v1[t] * pv[t]; }
         } else if (j == ld) {
-            out = (T)nu;
+            out0[0] = (T)nu0; out1[0] = (T)nu1;
         }
     } else if (blockIdx.x == 0) {
-        if (threadIdx.x < ELLW) { row_col[a * ELLW + threadIdx.x] = 0; row_val[a * ELLW + threadIdx.x] = (T)0; }
-        if (threadIdx.x == 0) row_nu[a] = 0;
+        if (threadIdx.x < 2 * ELLW) { row_col[2 * sIdx * ELLW + threadIdx.x] = 0; row_val[2 * sIdx * ELLW + threadIdx.x] = (T)0; }
+        if (threadIdx.x == 0) { row_nu[2 * sIdx] = 0; row_nu[2 * sIdx + 1] = 0; }
     }
-    if (j < ldw) dst[(size_t)a * ldw + j] = out;
+    if (j < ldw) {
+        *reinterpret_cast<v4_t *>(dst + (size_t)(2 * sIdx) * ldw + j) = out0;
+        *reinterpret_cast<v4_t *>(dst + (size_t)(2 * sIdx + 1) * ldw + j) = out1;
+    }
 }
 
 // dst[a][b] = sum_t val[b][t] * HP[a][col[b][t]] + (R ? R[a][b] : add_identity*delta_ab); padding = identity
@@ -1095,7 +1102,7 @@ int launch_ell_HP(pre3_ctx *c, int r, void *dst, bool with_nu)
 int launch_ell_HP_build(pre3_ctx *c, void *dst)
 {
     const int r_pad = round_up(2 * c->m, NB);
-    dim3 g(ceil_div(c->ldw, 256), r_pad), b(256);
+    dim3 g(ceil_div(c->ldw / 4, 256), r_pad / 2), b(256);
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_ell_HP_build<double>, g, b, 0, c->stream, c->m, r_pad, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl, c->lm.z, c->lm.h,
                            c->row_col, (double *)c->row_val, c->row_nu, (const double *)c->P, c->ld, (double *)dst, c->ldw),

@@ -22,7 +22,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Cam, Pre3Error, check, dptr, f64, i32, lib
+from ._lib import Cam, Pre3Error, addr, check, dptr, f64, i32, lib
 
 CHI2INV_2_95 = 5.9915          # rescue_hi_inliers.m:29
 
@@ -49,6 +49,8 @@ class EkfFilter:
         self.n = int(lib.pre3_state_size(self._ctx))
         self.lm_type = lm_type
         self.m = 0
+        self._st = np.zeros(8, np.int32)                 # pre3_step's statistics block (kept: the wrapper's time is GPU idle time)
+        self._st_addr = self._st.ctypes.data
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -243,11 +245,13 @@ class EkfFilter:
         u, meas_idx, z, hyp = f64(u), i32(meas_idx), f64(z), i32(hyp)
         self.m = int(meas_idx.shape[0])
         n_draw, k = hyp.shape
-        st = np.zeros(8, np.int32)
-        thr = self.std_z if threshold is None else float(threshold)
-        check(lib.pre3_step(self._ctx, dptr(u), self.m, dptr(meas_idx), dptr(z), n_draw, k, dptr(hyp), C.c_double(thr),
-                            int(bool(early_exit)), C.c_double(chi2), dptr(st)))
-        return dict(best=int(st[0]), iters=int(st[1]), n_hyp=int(st[2]), max_support=int(st[3]), n_li=int(st[4]), n_hi=int(st[5]))
+        st = self._st
+        rc = lib.pre3_step(self._ctx, addr(u), self.m, addr(meas_idx), addr(z), n_draw, k, addr(hyp),
+                           self.std_z if threshold is None else threshold, 1 if early_exit else 0, chi2, self._st_addr)
+        if rc:
+            check(rc)
+        s = st.tolist()
+        return dict(best=s[0], iters=s[1], n_hyp=s[2], max_support=s[3], n_li=s[4], n_hi=s[5])
 
     # ---- measurement hooks
     def timer_start(self):
