@@ -19,7 +19,7 @@ void set_error(const char *fmt, ...)
 }
 
 // launchers defined in the kernel files
-int launch_predict_impl(pre3_ctx *c, const double u[7]);
+int launch_predict_impl(pre3_ctx *c, const double u[7], bool with_projection = false);
 int launch_window_gate(pre3_ctx *c, int M, const int32_t *pred_idx_dev, const int32_t *k1_dev, const double *zc_dev, int strict, int32_t *accept_dev);
 int launch_build_rows_impl(pre3_ctx *c, int nsel, const int32_t *sel_dev, int r_pad);
 int launch_ransac_score_impl(pre3_ctx *c, int k, double threshold, int hyp_begin, int hyp_end, int ldg, int32_t *support_dev, uint32_t *mask_dev, int mask_words,
@@ -191,8 +191,8 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
             A(dmalloc_bytes(&c->tiles_flat, sizeof(int2) * (inter.size() ? inter.size() : 1)));
             if (rc == PRE3_OK && hipMemcpy(c->tiles_flat, inter.data(), sizeof(int2) * inter.size(), hipMemcpyHostToDevice) != hipSuccess) { set_error("tile table upload failed"); rc = PRE3_E_HIP; }
         }
-        A(dmalloc(&c->tile_ctr, 8)); A(dmalloc(&c->tile_cnt, 8)); A(dmalloc(&c->chol_arrive, 4));
-        if (rc == PRE3_OK) (void)hipMemset(c->chol_arrive, 0, sizeof(unsigned int) * 4);
+        A(dmalloc(&c->tile_ctr, 8)); A(dmalloc(&c->tile_cnt, 8)); A(dmalloc(&c->chol_arrive, 8));
+        if (rc == PRE3_OK) (void)hipMemset(c->chol_arrive, 0, sizeof(unsigned int) * 8);
         if (rc == PRE3_OK) { (void)hipMemset(c->tile_ctr, 0, sizeof(unsigned int) * 8); (void)hipMemcpy(c->tile_cnt, cnts, sizeof(cnts), hipMemcpyHostToDevice); }
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) c->num_cus = pr.multiProcessorCount; }
         A(dmalloc_bytes(&c->tiles, sizeof(int2) * flat.size()));
@@ -668,7 +668,11 @@ int pre3_rescue(pre3_ctx *c, double chi2, int32_t *hi_mask)
 {
     PRE3_TRY(check_ctx(c));
     PRE3_CHECK(c->p_which == PRE3_X_K_K && c->x_valid[PRE3_X_K_K], PRE3_E_STATE, "pre3_rescue: needs (x_k_k, p_k_k), i.e. after the LI update");
-    if (c->N) PRE3_TRY(launch_project_innovation(c, PRE3_X_K_K, 0, 1, chi2));
+    if (c->N) {
+        if (c->rescue_projected) PRE3_TRY(launch_innovation(c, 1, chi2));          // h / H at x_k_k came with the K9 launch
+        else PRE3_TRY(launch_project_innovation(c, PRE3_X_K_K, 0, 1, chi2));
+    }
+    c->rescue_projected = false;
     c->hi_from_host = -1; c->hi_kernel = true;
     if (hi_mask) {
         PRE3_HIP(hipStreamSynchronize(c->stream));
@@ -732,9 +736,14 @@ int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, co
     static double acc[8], t_prev_end = 0; static int nacc = 0;
     auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; };
     double t0 = trace ? now() : 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
-    PRE3_TRY(pre3_predict(c, u));                                   // mono_slam.m:153
+    PRE3_CHECK(u != nullptr, PRE3_E_ARG, "pre3_step: null u");
     PRE3_CHECK(c->have_cam, PRE3_E_STATE, "pre3_step: camera not set");
-    if (c->N) PRE3_TRY(launch_project_innovation(c, PRE3_X_K_KM1, 1, 0, 0.0));   // search_IC_matches.m:31-44
+    PRE3_CHECK(c->x_valid[PRE3_X_K_K] && c->p_which == PRE3_X_K_K, PRE3_E_STATE, "pre3_step: needs (x_k_k, p_k_k) on the device");
+    // mono_slam.m:153 + search_IC_matches.m:31-32: prediction, with the projection of every landmark at x_k_km1 riding in the
+    // same launch; then search_IC_matches.m:33-44 (S_i), which also clears the previous frame's inlier flags
+    PRE3_TRY(launch_predict_impl(c, u, true));
+    c->x_valid[PRE3_X_K_KM1] = true; c->p_which = PRE3_X_K_KM1; c->hp_all_valid = false;
+    if (c->N) PRE3_TRY(launch_innovation(c, 0, 0.0, true));
     c->projected = true; c->innovated = true;
     if (trace) t1 = now();
     PRE3_CHECK(m == 0 || (meas_idx && z), PRE3_E_ARG, "pre3_step: null measurement pointers");
@@ -748,7 +757,9 @@ int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, co
         ran = true;
     }
     if (trace) t2 = now();
+    c->ride_rescue_projection = true;                               // the rescue's projection rides in the LI update's K9 launch
     PRE3_TRY(pre3_update_li(c));                                    // mono_slam.m:181
+    c->ride_rescue_projection = false;
     if (ran) for (int i = 0; i < 4; ++i) st[i] = c->mail_host[i];
     if (trace) t3 = now();
     PRE3_TRY(pre3_rescue(c, chi2, nullptr));                        // mono_slam.m:184

@@ -13,68 +13,9 @@
 //   window gate    matching_sift_based.m:119-134
 //   ransac         ransac_hypotheses.m:40-80, compute_hypothesis_support_fast.m:33-110
 #include "pre3_internal.h"
+#include "pre3_geomdev.h"
 
 namespace pre3 {
-
-struct CamD { double f, Cx, Cy, k1, k2, nRows, nCols; };
-struct U7 { double v[7]; };
-
-// ------------------------------------------------------------------------------------------------
-// device math (fp64)
-// ------------------------------------------------------------------------------------------------
-
-// q2r.m:29-36
-__device__ inline void d_q2r(const double *q, double *R)
-{
-    double r = q[0], x = q[1], y = q[2], z = q[3];
-    R[0] = r * r + x * x - y * y - z * z; R[1] = 2 * (x * y - r * z);           R[2] = 2 * (z * x + r * y);
-    R[3] = 2 * (x * y + r * z);           R[4] = r * r - x * x + y * y - z * z; R[5] = 2 * (y * z - r * x);
-    R[6] = 2 * (z * x - r * y);           R[7] = 2 * (y * z + r * x);           R[8] = r * r - x * x - y * y + z * z;
-}
-
-// slamToolbox .../Rotations/q2R.m:18-34
-__device__ inline void d_q2R_sola(const double *q, double *R)
-{
-    double a = q[0], b = q[1], c = q[2], d = q[3];
-    double aa = a * a, ab = 2 * a * b, ac = 2 * a * c, ad = 2 * a * d;
-    double bb = b * b, bc = 2 * b * c, bd = 2 * b * d, cc = c * c, cd = 2 * c * d, dd = d * d;
-    R[0] = aa + bb - cc - dd; R[1] = bc - ad;           R[2] = bd + ac;
-    R[3] = bc + ad;           R[4] = aa - bb + cc - dd; R[5] = cd - ab;
-    R[6] = bd - ac;           R[7] = cd + ab;           R[8] = aa - bb - cc + dd;
-}
-
-// hu_my_version.m:41-42 + distort_fm_my_version.m:52-61
-__device__ inline void d_pinhole_distort(const double *hrl, const CamD &cam, double *uvd)
-{
-    double uu = cam.Cx + (hrl[0] / hrl[2]) * cam.f;
-    double vu = cam.Cy + (hrl[1] / hrl[2]) * cam.f;
-    double xu = (uu - cam.Cx) / cam.f, yu = (vu - cam.Cy) / cam.f;
-    double ru = sqrt(xu * xu + yu * yu);
-    double r2 = ru * ru;
-    double D = 1 + cam.k1 * r2 + cam.k2 * (r2 * r2);
-    uvd[0] = xu * D * cam.f + cam.Cx;
-    uvd[1] = yu * D * cam.f + cam.Cy;
-}
-
-// direction vector of a landmark in the world frame before rotation: (y-r)*rho + m(theta,phi)  or  y-r
-__device__ inline void d_ray(int type, const double *y, const double *t, double *v)
-{
-    if (type == PRE3_INVDEPTH) {
-        double cphi = cos(y[4]);
-        double mi0 = cphi * sin(y[3]), mi1 = -sin(y[4]), mi2 = cphi * cos(y[3]);   // m.m:38-40
-        v[0] = (y[0] - t[0]) * y[5] + mi0;
-        v[1] = (y[1] - t[1]) * y[5] + mi1;
-        v[2] = (y[2] - t[2]) * y[5] + mi2;
-    } else {
-        v[0] = y[0] - t[0]; v[1] = y[1] - t[1]; v[2] = y[2] - t[2];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K1 predict: x_k_km1 from x_k_k and u; P rows/cols 3..6 and the 7x7 pose block in place.
-// F = blkdiag(I3, Qq1, I6) and Jnorm = blkdiag(I3, Jn, I..) only touch rows/cols 3..6, so the
-// reference's full 13 x n products reduce to a 4 x n strip (multiplications by 1/0 are exact).
-// ------------------------------------------------------------------------------------------------
 
 // process noise Pn (7x7), predict_state_and_covariance.m:98-102 (constant)
 __device__ inline void d_process_noise(double *Pn)
@@ -105,14 +46,15 @@ __device__ inline void d_process_noise(double *Pn)
 // lane 0 of every block recomputes the quaternion product and its normalisation Jacobian (a few dozen flops) instead of
 // reading them from a previous kernel; block 0 additionally owns x_out[0:13], the process noise and the 7x7 pose block.
 template <typename T>
-__global__ __launch_bounds__(256) void k_predict(const double *__restrict__ x_in, double *__restrict__ x_out, T *__restrict__ P, int n, int ld, U7 u,
-                                                 double *__restrict__ params)
+__global__ __launch_bounds__(256) void k_predict(const double *__restrict__ x_in, double *x_out, T *__restrict__ P, int n, int ld, U7 u,
+                                                 double *__restrict__ params, int n_pred_blocks, ProjRide pr)
 {
+    if ((int)blockIdx.x >= n_pred_blocks) { proj_ride_block(pr, blockIdx.x - n_pred_blocks); return; }   // IC-search projection rides along
     __shared__ double sQq1[16], sJn[16], sQ[49], sG[49], sPn[49], sGP[49];
     __shared__ double corner[49];      // old P[0:7,0:7]
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     // landmarks copied (predict_state_and_covariance.m:79)
-    for (int i = 13 + j; i < n; i += gridDim.x * blockDim.x) x_out[i] = x_in[i];
+    for (int i = 13 + j; i < n; i += n_pred_blocks * blockDim.x) x_out[i] = x_in[i];
     double v[4] = { 0, 0, 0, 0 };
     if (j >= 7 && j < n) for (int t = 0; t < 4; ++t) v[t] = (double)P[(3 + t) * ld + j];
     if (blockIdx.x == 0 && threadIdx.x < 49) corner[threadIdx.x] = (double)P[(threadIdx.x / 7) * ld + (threadIdx.x % 7)];
@@ -149,7 +91,8 @@ __global__ __launch_bounds__(256) void k_predict(const double *__restrict__ x_in
             for (int i = 7; i < 13; ++i) x_out[i] = 0;
         }
     }
-    __syncthreads();
+    if (pr.n_blocks) ride_signal(pr.ctr);              // this block's share of x_out is written (includes the barrier)
+    else __syncthreads();
     if (j >= 7 && j < n) {
         double a[4], b[4];
         for (int i = 0; i < 4; ++i) a[i] = sQq1[i * 4] * v[0] + sQq1[i * 4 + 1] * v[1] + sQq1[i * 4 + 2] * v[2] + sQq1[i * 4 + 3] * v[3];
@@ -208,86 +151,8 @@ __global__ void k_jnorm_P(T *__restrict__ P, int n, int ld, const double *__rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2 project + Jacobian: one lane per landmark
+// K2 project + Jacobian: one lane per landmark (project_one: pre3_geomdev.h)
 // ------------------------------------------------------------------------------------------------
-__device__ void project_one(const int i, const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
-                            const double *__restrict__ x, const CamD &cam, int clear_first,
-                            double *__restrict__ h, int32_t *__restrict__ has_h, double *__restrict__ Hc, double *__restrict__ Hl)
-{
-    int type = lm_type[i];
-    const double *y = x + lm_off[i];
-    double Rwc[9];
-    d_q2r(x + 3, Rwc);
-    double v[3], hrl[3];
-    d_ray(type, y, x, v);
-    // r_cw = r_wc' (hi_inverse_depth.m:33); hi_cartesian.m:33 uses inv(r_wc) = r_wc' to rounding
-    for (int c = 0; c < 3; ++c) hrl[c] = Rwc[0 * 3 + c] * v[0] + Rwc[1 * 3 + c] * v[1] + Rwc[2 * 3 + c] * v[2];
-    const double PI = 3.141592653589793238462643383279502884;
-    double ax = atan2(hrl[0], hrl[2]) * 180 / PI, ay = atan2(hrl[1], hrl[2]) * 180 / PI;
-    bool ok = !(ax < -60 || ax > 60 || ay < -60 || ay > 60);
-    double uvd[2] = { 0, 0 };
-    if (ok) {
-        d_pinhole_distort(hrl, cam, uvd);
-        ok = (uvd[0] > 0) && (uvd[0] < cam.nCols) && (uvd[1] > 0) && (uvd[1] < cam.nRows);
-    }
-    int had = clear_first ? 0 : has_h[i];
-    double zi[2];
-    if (ok) { zi[0] = uvd[0]; zi[1] = uvd[1]; h[2 * i] = zi[0]; h[2 * i + 1] = zi[1]; }
-    else if (had) { zi[0] = h[2 * i]; zi[1] = h[2 * i + 1]; }      // stale h kept (quirk Q7)
-    int now = ok || had;
-    has_h[i] = now;
-    if (!now) return;
-    // ---- Jacobian (calculate_Hi_*_my_version.m); distortion Jacobian at the stored h (quirk Q8)
-    double u_ = zi[0], v_ = zi[1];
-    double xx = u_ - cam.Cx, yy = v_ - cam.Cy, f2 = cam.f * cam.f;
-    double r2 = (xx * xx + yy * yy) / f2, r4 = r2 * r2;
-    double g = cam.k1 + 2 * cam.k2 * r2, D0 = 1 + cam.k1 * r2 + cam.k2 * r4;
-    double Jd[4] = { D0 + xx * g * (2 * xx / f2), xx * g * (2 * yy / f2), yy * g * (2 * xx / f2), D0 + yy * g * (2 * yy / f2) };
-    // hc = Rrw * a  with Rrw = inv(q2r(q)) = q2r(q)' to rounding
-    double hc[3] = { hrl[0], hrl[1], hrl[2] };
-    double f = cam.f;
-    double dhu[6] = { f / hc[2], 0, -hc[0] * f / (hc[2] * hc[2]),  0, f / hc[2], -hc[1] * f / (hc[2] * hc[2]) };
-    double A[6];   // dh_dhrl = dhd_dhu * dhu_dhrl (2x3)
-    for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) A[r * 3 + c] = Jd[r * 2] * dhu[c] + Jd[r * 2 + 1] * dhu[3 + c];
-    double Rrw[9];
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rrw[r * 3 + c] = Rwc[c * 3 + r];
-    double sc = (type == PRE3_INVDEPTH) ? y[5] : 1.0;
-    double *hc_out = Hc + 14 * i, *hl_out = Hl + 12 * i;
-    // dh_drw = A * (-Rrw*rho)
-    for (int r = 0; r < 2; ++r)
-        for (int c = 0; c < 3; ++c)
-            hc_out[r * 7 + c] = A[r * 3] * (-Rrw[c] * sc) + A[r * 3 + 1] * (-Rrw[3 + c] * sc) + A[r * 3 + 2] * (-Rrw[6 + c] * sc);
-    // dhrl_dqwr = dRq_times_a_by_dq(qconj(q), a) * diag(1,-1,-1,-1)   (dRq_times_a_by_dq.m:29-101)
-    double q0 = x[3], qx = -x[4], qy = -x[5], qz = -x[6];
-    double a0 = v[0], a1 = v[1], a2 = v[2];
-    double dq[12];
-    dq[0] = 2 * q0 * a0 - 2 * qz * a1 + 2 * qy * a2;  dq[4] = 2 * qz * a0 + 2 * q0 * a1 - 2 * qx * a2;  dq[8]  = -2 * qy * a0 + 2 * qx * a1 + 2 * q0 * a2;
-    dq[1] = 2 * qx * a0 + 2 * qy * a1 + 2 * qz * a2;  dq[5] = 2 * qy * a0 - 2 * qx * a1 - 2 * q0 * a2;  dq[9]  = 2 * qz * a0 + 2 * q0 * a1 - 2 * qx * a2;
-    dq[2] = -2 * qy * a0 + 2 * qx * a1 + 2 * q0 * a2; dq[6] = 2 * qx * a0 + 2 * qy * a1 + 2 * qz * a2;  dq[10] = -2 * q0 * a0 + 2 * qz * a1 - 2 * qy * a2;
-    dq[3] = -2 * qz * a0 - 2 * q0 * a1 + 2 * qx * a2; dq[7] = 2 * q0 * a0 - 2 * qz * a1 + 2 * qy * a2;  dq[11] = 2 * qx * a0 + 2 * qy * a1 + 2 * qz * a2;
-    for (int r = 0; r < 3; ++r) { dq[r * 4 + 1] = -dq[r * 4 + 1]; dq[r * 4 + 2] = -dq[r * 4 + 2]; dq[r * 4 + 3] = -dq[r * 4 + 3]; }
-    for (int r = 0; r < 2; ++r)
-        for (int c = 0; c < 4; ++c)
-            hc_out[r * 7 + 3 + c] = A[r * 3] * dq[c] + A[r * 3 + 1] * dq[4 + c] + A[r * 3 + 2] * dq[8 + c];
-    for (int t = 0; t < 12; ++t) hl_out[t] = 0;
-    if (type == PRE3_INVDEPTH) {
-        double theta = y[3], phi = y[4], lambda = y[5];
-        double dth[3] = { cos(phi) * cos(theta), 0, -cos(phi) * sin(theta) };
-        double dph[3] = { -sin(phi) * sin(theta), -cos(phi), -sin(phi) * cos(theta) };
-        double d3[3] = { y[0] - x[0], y[1] - x[1], y[2] - x[2] };
-        double B[18];
-        for (int r = 0; r < 3; ++r) {
-            for (int c = 0; c < 3; ++c) B[r * 6 + c] = lambda * Rrw[r * 3 + c];
-            B[r * 6 + 3] = Rrw[r * 3] * dth[0] + Rrw[r * 3 + 1] * dth[1] + Rrw[r * 3 + 2] * dth[2];
-            B[r * 6 + 4] = Rrw[r * 3] * dph[0] + Rrw[r * 3 + 1] * dph[1] + Rrw[r * 3 + 2] * dph[2];
-            B[r * 6 + 5] = Rrw[r * 3] * d3[0] + Rrw[r * 3 + 1] * d3[1] + Rrw[r * 3 + 2] * d3[2];
-        }
-        for (int r = 0; r < 2; ++r) for (int c = 0; c < 6; ++c) hl_out[r * 6 + c] = A[r * 3] * B[c] + A[r * 3 + 1] * B[6 + c] + A[r * 3 + 2] * B[12 + c];
-    } else {
-        for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) hl_out[r * 6 + c] = A[r * 3] * Rrw[c] + A[r * 3 + 1] * Rrw[3 + c] + A[r * 3 + 2] * Rrw[6 + c];
-    }
-}
-
 __global__ void k_project(int N, const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
                           const double *__restrict__ x, CamD cam, int clear_first,
                           double *__restrict__ h, int32_t *__restrict__ has_h, double *__restrict__ Hc, double *__restrict__ Hl)
@@ -357,23 +222,43 @@ __device__ __forceinline__ void innovation_body(int N, const int32_t *__restrict
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_innovation(int N, const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
-                                                    const T *__restrict__ P, int ld, const double *__restrict__ Hc, const double *__restrict__ Hl,
-                                                    const int32_t *__restrict__ has_h, int mode, double chi2,
-                                                    const double *__restrict__ h, const double *__restrict__ z,
-                                                    const int32_t *__restrict__ ic, const int32_t *__restrict__ li, int32_t *__restrict__ hi,
-                                                    double *__restrict__ S, int32_t *__restrict__ has_S)
-{
-    innovation_body<T>(N, lm_type, lm_off, P, ld, Hc, Hl, has_h, mode, chi2, h, z, ic, li, hi, S, has_S);
-}
-
 // the HI collection (k_collect_hi's work) as the tail of the rescue launch: run by the first wave of the LAST workgroup
 struct HiArgs { int fuse, m, seq; const int32_t *meas; int32_t *hi_meas, *sel_rows, *stats, *mail; unsigned int *done; };
 __device__ __forceinline__ void collect_hi_body(int m, const int32_t *__restrict__ meas, const int32_t *__restrict__ lm_ic,
                                                 const int32_t *__restrict__ lm_li, const int32_t *lm_hi,
                                                 int32_t *__restrict__ hi_meas, int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats,
                                                 int32_t *mail, int seq);
+
+__device__ __forceinline__ void hi_tail(const HiArgs &ha, const int32_t *__restrict__ ic, const int32_t *__restrict__ li, int32_t *hi)
+{
+    if (!ha.fuse) return;
+    __shared__ int s_last;
+    __syncthreads();                                   // this workgroup's hi flags are written
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(ha.done, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x < 64) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (threadIdx.x == 0) *ha.done = 0;
+        collect_hi_body(ha.m, ha.meas, ic, li, hi, ha.hi_meas, ha.sel_rows, ha.stats, ha.mail, ha.seq);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_innovation(int N, const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
+                                                    const T *__restrict__ P, int ld, const double *__restrict__ Hc, const double *__restrict__ Hl,
+                                                    const int32_t *__restrict__ has_h, int mode, double chi2,
+                                                    const double *__restrict__ h, const double *__restrict__ z,
+                                                    const int32_t *__restrict__ ic, const int32_t *__restrict__ li, int32_t *__restrict__ hi,
+                                                    double *__restrict__ S, int32_t *__restrict__ has_S, int32_t *__restrict__ clear, int n_clear,
+                                                    HiArgs ha)
+{
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_clear; t += gridDim.x * blockDim.x) clear[t] = 0;
+    innovation_body<T>(N, lm_type, lm_off, P, ld, Hc, Hl, has_h, mode, chi2, h, z, ic, li, hi, S, has_S);
+    hi_tail(ha, ic, li, hi);
+}
 
 // k_project and k_innovation in ONE launch: the first of a landmark's 16 lanes projects it and writes h / H, the block
 // barrier publishes them, then the 16 lanes gather H P H' as before.  Saves a kernel boundary (~5 us) twice per step.
@@ -393,20 +278,7 @@ __global__ __launch_bounds__(256) void k_project_innovation(int N, const int32_t
     __threadfence_block();
     __syncthreads();
     innovation_body<T>(N, lm_type, lm_off, P, ld, Hc, Hl, has_h, mode, chi2, h, z, ic, li, hi, S, has_S);
-    if (ha.fuse) {
-        __shared__ int s_last;
-        __syncthreads();                                   // this workgroup's hi flags are written
-        if (threadIdx.x == 0) {
-            __threadfence();
-            s_last = atomicAdd(ha.done, 1u) == gridDim.x - 1;
-        }
-        __syncthreads();
-        if (s_last && threadIdx.x < 64) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (threadIdx.x == 0) *ha.done = 0;
-            collect_hi_body(ha.m, ha.meas, ic, li, hi, ha.hi_meas, ha.sel_rows, ha.stats, ha.mail, ha.seq);
-        }
-    }
+    hi_tail(ha, ic, li, hi);
 }
 
 // matching_sift_based.m:119-134
@@ -659,24 +531,31 @@ __device__ __forceinline__ void select_body(int n_draw, int k, int early_exit, i
         const int limit = early_exit ? (n_draw < 1000 ? n_draw : 1000) : n_draw;
         int n_hyp = 1000, max_support = 0, best = -1, iters = limit;
         bool done = false;
-        for (int base = 0; base < limit && !done; base += 64) {
-            const int it = base + lane;
-            const int v = it < limit ? support[it] : -1;
-            int pm = v;                                          // inclusive prefix max over the chunk
+        for (int base0 = 0; base0 < limit && !done; base0 += 8 * 64) {
+            int v8[8];                                               // 8 chunks of supports in flight at once
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(pm, o, 64); if (lane >= o) pm = max(pm, t); }
-            int excl = __shfl_up(pm, 1, 64);
-            if (lane == 0) excl = -1;
-            excl = max(excl, max_support);
-            unsigned long long hits = __ballot(v > excl);        // improvements, in index order
-            while (hits) {
-                const int l = __ffsll((long long)hits) - 1;
-                hits &= hits - 1;
-                const int sup = __shfl(v, l, 64);
-                max_support = sup; best = base + l;
-                if (early_exit) {
-                    n_hyp = ransac_n_hyp(sup, m);
-                    if (n_hyp <= k) { iters = base + l + 1; done = true; break; }
+            for (int q = 0; q < 8; ++q) { const int it = base0 + q * 64 + lane; v8[q] = it < limit ? support[it] : -1; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int base = base0 + q * 64;
+                if (base >= limit || done) continue;
+                const int v = v8[q];
+                int pm = v;                                          // inclusive prefix max over the chunk
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(pm, o, 64); if (lane >= o) pm = max(pm, t); }
+                int excl = __shfl_up(pm, 1, 64);
+                if (lane == 0) excl = -1;
+                excl = max(excl, max_support);
+                unsigned long long hits = __ballot(v > excl);        // improvements, in index order
+                while (hits) {
+                    const int l = __ffsll((long long)hits) - 1;
+                    hits &= hits - 1;
+                    const int sup = __shfl(v, l, 64);
+                    max_support = sup; best = base + l;
+                    if (early_exit) {
+                        n_hyp = ransac_n_hyp(sup, m);
+                        if (n_hyp <= k) { iters = base + l + 1; done = true; break; }
+                    }
                 }
             }
         }
@@ -733,15 +612,27 @@ __device__ __forceinline__ void collect_hi_body(int m, const int32_t *__restrict
 {
     const int tid = threadIdx.x;
     int cnt = 0;
-    for (int base = 0; base < m; base += 64) {
-        int j = base + tid;
-        int in = 0;
-        if (j < m) {
-            int i = meas[j];
-            in = (lm_ic[i] == 1 && lm_li[i] == 0) ? lm_hi[i] : 0;
-            hi_meas[j] = in;
+    // the flag loads (meas -> ic/li/hi: two dependent levels) are issued for 8 chunks at a time so that their latencies overlap;
+    // the ordered compaction then only needs ballots
+    for (int base0 = 0; base0 < m; base0 += 8 * 64) {
+        int in[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int j = base0 + q * 64 + tid;
+            in[q] = 0;
+            if (j < m) {
+                const int i = meas[j];
+                in[q] = (lm_ic[i] == 1 && lm_li[i] == 0) ? lm_hi[i] : 0;
+            }
         }
-        cnt = wave_compact(in, tid, cnt, sel_rows, j);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int j = base0 + q * 64 + tid;
+            if (base0 + q * 64 < m) {
+                if (j < m) hi_meas[j] = in[q];
+                cnt = wave_compact(in[q], tid, cnt, sel_rows, j);
+            }
+        }
     }
     if (tid == 0) {
         stats[5] = cnt;
@@ -798,13 +689,28 @@ static CamD to_camd(const pre3_cam &c) { return CamD{ c.f, c.Cx, c.Cy, c.k1, c.k
 
 #define DISPATCH_T(c, expr_f64, expr_f32) do { if ((c)->dtype == PRE3_F64) { expr_f64; } else { expr_f32; } } while (0)
 
-int launch_predict_impl(pre3_ctx *c, const double u[7])
+ProjRide make_proj_ride(pre3_ctx *c, int which, int clear_first, int slot, int n_producers)
+{
+    ProjRide pr{};
+    pr.n_blocks = ceil_div(c->N, 64); pr.N = c->N; pr.clear_first = clear_first;
+    pr.lm_type = c->lm.type; pr.lm_off = c->lm.off; pr.x = which == PRE3_X_K_K ? c->x_kk : c->x_km1; pr.cam = to_camd(c->cam);
+    pr.h = c->lm.h; pr.has_h = c->lm.has_h; pr.Hc = c->lm.Hc; pr.Hl = c->lm.Hl;
+    pr.ctr = c->chol_arrive + 3 + slot;
+    c->ride_target[slot] += (unsigned)n_producers;
+    pr.target = c->ride_target[slot];
+    return pr;
+}
+
+// with_projection: the IC-search projection at x_k_km1 (clear_first = 1) rides in the same launch
+int launch_predict_impl(pre3_ctx *c, const double u[7], bool with_projection)
 {
     U7 uu; for (int i = 0; i < 7; ++i) uu.v[i] = u[i];
     int blocks = ceil_div(c->n, 256);
+    ProjRide pr{};
+    if (with_projection && c->N > 0) pr = make_proj_ride(c, PRE3_X_K_KM1, 1, 0, blocks);
     DISPATCH_T(c,
-        hipLaunchKernelGGL(k_predict<double>, dim3(blocks), dim3(256), 0, c->stream, c->x_kk, c->x_km1, (double *)c->P, c->n, c->ld, uu, c->pred_params),
-        hipLaunchKernelGGL(k_predict<float>, dim3(blocks), dim3(256), 0, c->stream, c->x_kk, c->x_km1, (float *)c->P, c->n, c->ld, uu, c->pred_params));
+        hipLaunchKernelGGL(k_predict<double>, dim3(blocks + pr.n_blocks), dim3(256), 0, c->stream, c->x_kk, c->x_km1, (double *)c->P, c->n, c->ld, uu, c->pred_params, blocks, pr),
+        hipLaunchKernelGGL(k_predict<float>, dim3(blocks + pr.n_blocks), dim3(256), 0, c->stream, c->x_kk, c->x_km1, (float *)c->P, c->n, c->ld, uu, c->pred_params, blocks, pr));
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }
@@ -856,16 +762,19 @@ int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode,
     return PRE3_OK;
 }
 
-int launch_innovation(pre3_ctx *c, int mode, double chi2)
+int launch_innovation(pre3_ctx *c, int mode, double chi2, bool clear_flags)
 {
+    int32_t *clr = (int32_t *)((unsigned char *)c->inbox_dev + c->off_flags);
+    const int n_clr = clear_flags ? (int)(c->flags_bytes / sizeof(int32_t)) : 0;
+    HiArgs ha{};
+    if (mode == 1) ha = HiArgs{ 1, c->m, ++c->seq_collect, c->meas, c->hi_meas, c->sel_rows, c->stats, c->mail_dev, c->chol_arrive + 2 };
     dim3 g(ceil_div(c->N * 16, 256)), b(256);
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_innovation<double>, g, b, 0, c->stream, c->N, c->lm.type, c->lm.off, (const double *)c->P, c->ld, c->lm.Hc,
-                           c->lm.Hl, c->lm.has_h, mode, chi2, c->lm.h, c->lm.z, c->lm.ic, c->lm.li, c->lm.hi, c->lm.S, c->lm.has_S),
+                           c->lm.Hl, c->lm.has_h, mode, chi2, c->lm.h, c->lm.z, c->lm.ic, c->lm.li, c->lm.hi, c->lm.S, c->lm.has_S, clr, n_clr, ha),
         hipLaunchKernelGGL(k_innovation<float>, g, b, 0, c->stream, c->N, c->lm.type, c->lm.off, (const float *)c->P, c->ld, c->lm.Hc,
-                           c->lm.Hl, c->lm.has_h, mode, chi2, c->lm.h, c->lm.z, c->lm.ic, c->lm.li, c->lm.hi, c->lm.S, c->lm.has_S));
+                           c->lm.Hl, c->lm.has_h, mode, chi2, c->lm.h, c->lm.z, c->lm.ic, c->lm.li, c->lm.hi, c->lm.S, c->lm.has_S, clr, n_clr, ha));
     PRE3_HIP(hipGetLastError());
-    if (mode == 1) PRE3_TRY(launch_collect_hi(c));
     return PRE3_OK;
 }
 

@@ -1,0 +1,182 @@
+// pre3_geomdev.h -- device-side camera geometry shared by pre3_geom.hip and pre3_update.hip (the projection also rides inside
+// the predict and K9 launches, see ProjRide).  fp64 throughout.
+#pragma once
+#include "pre3_internal.h"
+
+namespace pre3 {
+
+struct CamD { double f, Cx, Cy, k1, k2, nRows, nCols; };
+struct U7 { double v[7]; };
+
+// ------------------------------------------------------------------------------------------------
+// device math (fp64)
+// ------------------------------------------------------------------------------------------------
+
+// q2r.m:29-36
+__device__ inline void d_q2r(const double *q, double *R)
+{
+    double r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = r * r + x * x - y * y - z * z; R[1] = 2 * (x * y - r * z);           R[2] = 2 * (z * x + r * y);
+    R[3] = 2 * (x * y + r * z);           R[4] = r * r - x * x + y * y - z * z; R[5] = 2 * (y * z - r * x);
+    R[6] = 2 * (z * x - r * y);           R[7] = 2 * (y * z + r * x);           R[8] = r * r - x * x - y * y + z * z;
+}
+
+// slamToolbox .../Rotations/q2R.m:18-34
+__device__ inline void d_q2R_sola(const double *q, double *R)
+{
+    double a = q[0], b = q[1], c = q[2], d = q[3];
+    double aa = a * a, ab = 2 * a * b, ac = 2 * a * c, ad = 2 * a * d;
+    double bb = b * b, bc = 2 * b * c, bd = 2 * b * d, cc = c * c, cd = 2 * c * d, dd = d * d;
+    R[0] = aa + bb - cc - dd; R[1] = bc - ad;           R[2] = bd + ac;
+    R[3] = bc + ad;           R[4] = aa - bb + cc - dd; R[5] = cd - ab;
+    R[6] = bd - ac;           R[7] = cd + ab;           R[8] = aa - bb - cc + dd;
+}
+
+// hu_my_version.m:41-42 + distort_fm_my_version.m:52-61
+__device__ inline void d_pinhole_distort(const double *hrl, const CamD &cam, double *uvd)
+{
+    double uu = cam.Cx + (hrl[0] / hrl[2]) * cam.f;
+    double vu = cam.Cy + (hrl[1] / hrl[2]) * cam.f;
+    double xu = (uu - cam.Cx) / cam.f, yu = (vu - cam.Cy) / cam.f;
+    double ru = sqrt(xu * xu + yu * yu);
+    double r2 = ru * ru;
+    double D = 1 + cam.k1 * r2 + cam.k2 * (r2 * r2);
+    uvd[0] = xu * D * cam.f + cam.Cx;
+    uvd[1] = yu * D * cam.f + cam.Cy;
+}
+
+// direction vector of a landmark in the world frame before rotation: (y-r)*rho + m(theta,phi)  or  y-r
+__device__ inline void d_ray(int type, const double *y, const double *t, double *v)
+{
+    if (type == PRE3_INVDEPTH) {
+        double cphi = cos(y[4]);
+        double mi0 = cphi * sin(y[3]), mi1 = -sin(y[4]), mi2 = cphi * cos(y[3]);   // m.m:38-40
+        v[0] = (y[0] - t[0]) * y[5] + mi0;
+        v[1] = (y[1] - t[1]) * y[5] + mi1;
+        v[2] = (y[2] - t[2]) * y[5] + mi2;
+    } else {
+        v[0] = y[0] - t[0]; v[1] = y[1] - t[1]; v[2] = y[2] - t[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 predict: x_k_km1 from x_k_k and u; P rows/cols 3..6 and the 7x7 pose block in place.
+// F = blkdiag(I3, Qq1, I6) and Jnorm = blkdiag(I3, Jn, I..) only touch rows/cols 3..6, so the
+// reference's full 13 x n products reduce to a 4 x n strip (multiplications by 1/0 are exact).
+// ------------------------------------------------------------------------------------------------
+
+// ------------------------------------------------------------------------------------------------
+// K2 project + Jacobian of one landmark (predict_camera_measurements.m:27-68, calculate_Hi_*_my_version.m)
+// ------------------------------------------------------------------------------------------------
+__device__ inline void project_one(const int i, const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
+                            const double *__restrict__ x, const CamD &cam, int clear_first,
+                            double *__restrict__ h, int32_t *__restrict__ has_h, double *__restrict__ Hc, double *__restrict__ Hl)
+{
+    int type = lm_type[i];
+    const double *y = x + lm_off[i];
+    double Rwc[9];
+    d_q2r(x + 3, Rwc);
+    double v[3], hrl[3];
+    d_ray(type, y, x, v);
+    // r_cw = r_wc' (hi_inverse_depth.m:33); hi_cartesian.m:33 uses inv(r_wc) = r_wc' to rounding
+    for (int c = 0; c < 3; ++c) hrl[c] = Rwc[0 * 3 + c] * v[0] + Rwc[1 * 3 + c] * v[1] + Rwc[2 * 3 + c] * v[2];
+    const double PI = 3.141592653589793238462643383279502884;
+    double ax = atan2(hrl[0], hrl[2]) * 180 / PI, ay = atan2(hrl[1], hrl[2]) * 180 / PI;
+    bool ok = !(ax < -60 || ax > 60 || ay < -60 || ay > 60);
+    double uvd[2] = { 0, 0 };
+    if (ok) {
+        d_pinhole_distort(hrl, cam, uvd);
+        ok = (uvd[0] > 0) && (uvd[0] < cam.nCols) && (uvd[1] > 0) && (uvd[1] < cam.nRows);
+    }
+    int had = clear_first ? 0 : has_h[i];
+    double zi[2];
+    if (ok) { zi[0] = uvd[0]; zi[1] = uvd[1]; h[2 * i] = zi[0]; h[2 * i + 1] = zi[1]; }
+    else if (had) { zi[0] = h[2 * i]; zi[1] = h[2 * i + 1]; }      // stale h kept (quirk Q7)
+    int now = ok || had;
+    has_h[i] = now;
+    if (!now) return;
+    // ---- Jacobian (calculate_Hi_*_my_version.m); distortion Jacobian at the stored h (quirk Q8)
+    double u_ = zi[0], v_ = zi[1];
+    double xx = u_ - cam.Cx, yy = v_ - cam.Cy, f2 = cam.f * cam.f;
+    double r2 = (xx * xx + yy * yy) / f2, r4 = r2 * r2;
+    double g = cam.k1 + 2 * cam.k2 * r2, D0 = 1 + cam.k1 * r2 + cam.k2 * r4;
+    double Jd[4] = { D0 + xx * g * (2 * xx / f2), xx * g * (2 * yy / f2), yy * g * (2 * xx / f2), D0 + yy * g * (2 * yy / f2) };
+    // hc = Rrw * a  with Rrw = inv(q2r(q)) = q2r(q)' to rounding
+    double hc[3] = { hrl[0], hrl[1], hrl[2] };
+    double f = cam.f;
+    double dhu[6] = { f / hc[2], 0, -hc[0] * f / (hc[2] * hc[2]),  0, f / hc[2], -hc[1] * f / (hc[2] * hc[2]) };
+    double A[6];   // dh_dhrl = dhd_dhu * dhu_dhrl (2x3)
+    for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) A[r * 3 + c] = Jd[r * 2] * dhu[c] + Jd[r * 2 + 1] * dhu[3 + c];
+    double Rrw[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rrw[r * 3 + c] = Rwc[c * 3 + r];
+    double sc = (type == PRE3_INVDEPTH) ? y[5] : 1.0;
+    double *hc_out = Hc + 14 * i, *hl_out = Hl + 12 * i;
+    // dh_drw = A * (-Rrw*rho)
+    for (int r = 0; r < 2; ++r)
+        for (int c = 0; c < 3; ++c)
+            hc_out[r * 7 + c] = A[r * 3] * (-Rrw[c] * sc) + A[r * 3 + 1] * (-Rrw[3 + c] * sc) + A[r * 3 + 2] * (-Rrw[6 + c] * sc);
+    // dhrl_dqwr = dRq_times_a_by_dq(qconj(q), a) * diag(1,-1,-1,-1)   (dRq_times_a_by_dq.m:29-101)
+    double q0 = x[3], qx = -x[4], qy = -x[5], qz = -x[6];
+    double a0 = v[0], a1 = v[1], a2 = v[2];
+    double dq[12];
+    dq[0] = 2 * q0 * a0 - 2 * qz * a1 + 2 * qy * a2;  dq[4] = 2 * qz * a0 + 2 * q0 * a1 - 2 * qx * a2;  dq[8]  = -2 * qy * a0 + 2 * qx * a1 + 2 * q0 * a2;
+    dq[1] = 2 * qx * a0 + 2 * qy * a1 + 2 * qz * a2;  dq[5] = 2 * qy * a0 - 2 * qx * a1 - 2 * q0 * a2;  dq[9]  = 2 * qz * a0 + 2 * q0 * a1 - 2 * qx * a2;
+    dq[2] = -2 * qy * a0 + 2 * qx * a1 + 2 * q0 * a2; dq[6] = 2 * qx * a0 + 2 * qy * a1 + 2 * qz * a2;  dq[10] = -2 * q0 * a0 + 2 * qz * a1 - 2 * qy * a2;
+    dq[3] = -2 * qz * a0 - 2 * q0 * a1 + 2 * qx * a2; dq[7] = 2 * q0 * a0 - 2 * qz * a1 + 2 * qy * a2;  dq[11] = 2 * qx * a0 + 2 * qy * a1 + 2 * qz * a2;
+    for (int r = 0; r < 3; ++r) { dq[r * 4 + 1] = -dq[r * 4 + 1]; dq[r * 4 + 2] = -dq[r * 4 + 2]; dq[r * 4 + 3] = -dq[r * 4 + 3]; }
+    for (int r = 0; r < 2; ++r)
+        for (int c = 0; c < 4; ++c)
+            hc_out[r * 7 + 3 + c] = A[r * 3] * dq[c] + A[r * 3 + 1] * dq[4 + c] + A[r * 3 + 2] * dq[8 + c];
+    for (int t = 0; t < 12; ++t) hl_out[t] = 0;
+    if (type == PRE3_INVDEPTH) {
+        double theta = y[3], phi = y[4], lambda = y[5];
+        double dth[3] = { cos(phi) * cos(theta), 0, -cos(phi) * sin(theta) };
+        double dph[3] = { -sin(phi) * sin(theta), -cos(phi), -sin(phi) * cos(theta) };
+        double d3[3] = { y[0] - x[0], y[1] - x[1], y[2] - x[2] };
+        double B[18];
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) B[r * 6 + c] = lambda * Rrw[r * 3 + c];
+            B[r * 6 + 3] = Rrw[r * 3] * dth[0] + Rrw[r * 3 + 1] * dth[1] + Rrw[r * 3 + 2] * dth[2];
+            B[r * 6 + 4] = Rrw[r * 3] * dph[0] + Rrw[r * 3 + 1] * dph[1] + Rrw[r * 3 + 2] * dph[2];
+            B[r * 6 + 5] = Rrw[r * 3] * d3[0] + Rrw[r * 3 + 1] * d3[1] + Rrw[r * 3 + 2] * d3[2];
+        }
+        for (int r = 0; r < 2; ++r) for (int c = 0; c < 6; ++c) hl_out[r * 6 + c] = A[r * 3] * B[c] + A[r * 3 + 1] * B[6 + c] + A[r * 3 + 2] * B[12 + c];
+    } else {
+        for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) hl_out[r * 6 + c] = A[r * 3] * Rrw[c] + A[r * 3 + 1] * Rrw[3 + c] + A[r * 3 + 2] * Rrw[6 + c];
+    }
+}
+
+
+// ---- riders: work that depends on a few producer workgroups of the SAME launch -----------------------------------------
+// A kernel boundary costs ~5 us here, more than the projection itself hides: the landmarks are projected by extra workgroups
+// appended to the launch that produces the state they need (k_predict for the IC search, the K9 launch -- whose x-update
+// workgroups write x_k_k -- for the rescue).  Producers signal a device counter (monotonic, the host passes the target);
+// riders have higher block indices, so every producer has been dispatched before a rider can spin.
+struct ProjRide {
+    int n_blocks;                       // 0: no rider in this launch
+    int N, clear_first;
+    const int32_t *lm_type, *lm_off; const double *x; CamD cam;
+    double *h; int32_t *has_h; double *Hc, *Hl;
+    unsigned int *ctr; unsigned int target;
+};
+
+__device__ __forceinline__ void ride_signal(unsigned int *ctr)      // call from every thread of a producer workgroup
+{
+    __syncthreads();
+    if (threadIdx.x == 0) { __threadfence(); __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+}
+
+__device__ __forceinline__ void proj_ride_block(const ProjRide &pr, int blk)
+{
+    if (threadIdx.x == 0) {
+        while ((int)(__hip_atomic_load(pr.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - pr.target) < 0) __builtin_amdgcn_s_sleep(4);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int i = blk * 64 + threadIdx.x;
+    if (threadIdx.x < 64 && i < pr.N) project_one(i, pr.lm_type, pr.lm_off, pr.x, pr.cam, pr.clear_first, pr.h, pr.has_h, pr.Hc, pr.Hl);
+}
+
+ProjRide make_proj_ride(pre3_ctx *c, int which, int clear_first, int slot, int n_producers);   // pre3_geom.hip
+
+}  // namespace pre3

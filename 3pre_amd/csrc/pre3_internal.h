@@ -81,7 +81,11 @@ struct pre3_ctx {
     int *tile_cnt = nullptr; int tiles_stride = 0;  // per-list lengths [8] and list stride
     bool tile_ctr_clean = false;                  // the 8 counters are zero (k_update_x resets them ahead of K9)
     int num_cus = 256;
-    unsigned int *chol_arrive = nullptr; unsigned int chol_target = 0;   // panel kernels: arrivals of the workgroups that read the raw diagonal block
+    unsigned int *chol_arrive = nullptr; unsigned int chol_target = 0;   // [0] panel arrivals, [1] scoring done, [2] rescue done, [3],[4] rider producers
+    unsigned int ride_target[2] = { 0, 0 };
+    bool ride_rescue_projection = false;          // request: the next K9 launch also projects at x_k_k (pre3_step sets it before the LI update)
+    bool rescue_projected = false;                // h / H at the current x_k_k are on the device (set by that launch, consumed by pre3_rescue)
+    //   // panel kernels: arrivals of the workgroups that read the raw diagonal block
     int p_which = -1;                             // which estimate P currently holds (-1: none)
     bool x_valid[2] = {false, false};
     pre3::LmBuffers lm;
@@ -155,7 +159,7 @@ constexpr int DESC_DIM = 128;
 
 // ---- geometry / RANSAC kernels (pre3_geom.hip)
 int launch_project(pre3_ctx *c, int which, int clear_first);
-int launch_innovation(pre3_ctx *c, int mode /*0: S=HPH'+I for predicted; 1: rescue gate + HI list*/, double chi2);
+int launch_innovation(pre3_ctx *c, int mode /*0: S=HPH'+I for predicted; 1: rescue gate + HI list*/, double chi2, bool clear_flags = false);
 int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode, double chi2);
 int launch_update_x(pre3_ctx *c, int which_prior, int r);
 int launch_jnorm(pre3_ctx *c, int which);

@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "pre3_internal.h"
+#include "pre3_geomdev.h"
 
 namespace pre3 {
 
@@ -952,14 +953,23 @@ __device__ __forceinline__ void update_x_block(int blk, int n, int r, const T *_
     if (rg == 0 && i < n) x_out[i] = s;
 }
 
-struct XUpd { int n_tiles, n, r; const double *x_prior; double *x_out, *params; };
+struct XUpd { int n_tiles, n, r; const double *x_prior; double *x_out; double *params; };
 
+// waves_per_eu: the riders' fp64 geometry must not raise the register count of the tile path (5 workgroups per CU in fp32,
+// 4 in fp64 -- every tile resident at once); if anything spills, it is the riders.
 template <typename T, int BK>
-__global__ __launch_bounds__(256) void k_downdate_1t(T *__restrict__ P, int ld, const T *__restrict__ W, int ldw, int r_pad,
-                                                     const int2 *__restrict__ tiles, int gen_size, XUpd xu)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 5 : 4))) void k_downdate_1t(T *__restrict__ P, int ld, const T *__restrict__ W, int ldw, int r_pad,
+                                                     const int2 *__restrict__ tiles, int gen_size, XUpd xu, ProjRide pr)
 {
-    if ((int)blockIdx.x >= xu.n_tiles) {            // the state update rides along (launch_downdate adds these workgroups)
-        update_x_block<T>(blockIdx.x - xu.n_tiles, xu.n, xu.r, W, ldw, ld, xu.x_prior, xu.x_out, xu.params);
+    if ((int)blockIdx.x >= xu.n_tiles) {            // riders (launch_downdate adds these workgroups)
+        __builtin_amdgcn_s_setprio(3);              // short dependent chains: must not starve behind the MFMA waves sharing their SIMD
+        const int nx = (xu.n + 63) / 64, rb = blockIdx.x - xu.n_tiles;
+        if (rb < nx) {                              // the state update
+            update_x_block<T>(rb, xu.n, xu.r, W, ldw, ld, xu.x_prior, xu.x_out, xu.params);
+            if (pr.n_blocks) ride_signal(pr.ctr);
+        } else {                                    // the rescue's projection at the updated state, once x is complete
+            proj_ride_block(pr, rb - nx);
+        }
         return;
     }
     // Workgroups are dispatched in generations of one per CU; give each generation its own wave priority so the
@@ -1189,10 +1199,16 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
     }
     if (one_tile) {
         XUpd xu{ c->n_tiles, c->n, r, which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1, c->x_kk, c->pred_params };
-        dim3 g1(c->n_tiles + (which_prior >= 0 ? ceil_div(c->n, 64) : 0));
+        const int nx = which_prior >= 0 ? ceil_div(c->n, 64) : 0;
+        ProjRide pr{};
+        if (nx > 0 && c->ride_rescue_projection && c->N > 0) {      // the rescue's projection (stale h kept: clear_first = 0) rides along
+            pr = make_proj_ride(c, PRE3_X_K_K, 0, 1, nx);
+            c->ride_rescue_projection = false; c->rescue_projected = true;
+        }
+        dim3 g1(c->n_tiles + nx + pr.n_blocks);
         DISPATCH_T(c,
-            hipLaunchKernelGGL((k_downdate_1t<double, 16>), g1, b, 0, c->stream, (double *)c->P, c->ld, (const double *)W, c->ldw, r_pad, (const int2 *)c->tiles_flat, c->num_cus, xu),
-            hipLaunchKernelGGL((k_downdate_1t<float, 16>), g1, b, 0, c->stream, (float *)c->P, c->ld, (const float *)W, c->ldw, r_pad, (const int2 *)c->tiles_flat, c->num_cus, xu));
+            hipLaunchKernelGGL((k_downdate_1t<double, 16>), g1, b, 0, c->stream, (double *)c->P, c->ld, (const double *)W, c->ldw, r_pad, (const int2 *)c->tiles_flat, c->num_cus, xu, pr),
+            hipLaunchKernelGGL((k_downdate_1t<float, 16>), g1, b, 0, c->stream, (float *)c->P, c->ld, (const float *)W, c->ldw, r_pad, (const int2 *)c->tiles_flat, c->num_cus, xu, pr));
     } else
     DISPATCH_T(c,
         hipLaunchKernelGGL((k_downdate<double, 32>), g, b, 0, c->stream, (double *)c->P, c->ld, (const double *)W, c->ldw, r_pad, (const int2 *)c->tiles, c->tiles_stride, c->tile_cnt, c->tile_ctr),
