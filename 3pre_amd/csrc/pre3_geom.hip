@@ -357,7 +357,7 @@ __device__ __forceinline__ void select_body(int n_draw, int k, int early_exit, i
                                             int32_t *mail, int seq);
 
 template <typename T, int K>
-__global__ __launch_bounds__(256) void k_ransac_score(int hyp_begin, const int32_t *__restrict__ hyp, int m,
+__global__ __launch_bounds__(512) void k_ransac_score(int hyp_begin, const int32_t *__restrict__ hyp, int m,
                                                       const int32_t *__restrict__ meas, const int32_t *__restrict__ lm_type,
                                                       const int32_t *__restrict__ lm_off, const double *__restrict__ x,
                                                       const T *__restrict__ HP, int ldw, const T *__restrict__ G, int ldg,
@@ -369,8 +369,8 @@ __global__ __launch_bounds__(256) void k_ransac_score(int hyp_begin, const int32
     extern __shared__ double s_res[];       // [m] residuals, then mask words
     __shared__ double s_w[R];
     __shared__ int s_rows[R];
-    __shared__ double s_red[4];
-    __shared__ int s_cnt[4];
+    __shared__ double s_red[8];
+    __shared__ int s_cnt[8];
     const int hidx = hyp_begin + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid < 64) {
@@ -465,7 +465,8 @@ __global__ __launch_bounds__(256) void k_ransac_score(int hyp_begin, const int32
     uint32_t *s_mask = (uint32_t *)(s_res + m);
     for (int wd = tid; wd < mask_words; wd += blockDim.x) s_mask[wd] = 0;
     __syncthreads();
-    const double minres = fmin(fmin(s_red[0], s_red[1]), fmin(s_red[2], s_red[3]));
+    double minres = s_red[0];
+    for (int w2 = 1; w2 < (int)(blockDim.x >> 6); ++w2) minres = fmin(minres, s_red[w2]);
     int cnt = 0;
     for (int j = tid; j < m; j += blockDim.x) {
         const int type = lm_type[meas[j]];
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(256) void k_ransac_score(int hyp_begin, const int32
     cnt = wave_sum(cnt);
     if (lane == 0) s_cnt[wv] = cnt;
     __syncthreads();
-    if (tid == 0) support[hidx] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (tid == 0) { int sc = 0; for (int w2 = 0; w2 < (int)(blockDim.x >> 6); ++w2) sc += s_cnt[w2]; support[hidx] = sc; }
     for (int wd = tid; wd < mask_words; wd += blockDim.x) masks[(size_t)hidx * mask_words + wd] = s_mask[wd];
     if (sel.fuse) {
         __shared__ int s_last;
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(256) void k_ransac_score(int hyp_begin, const int32
             s_last = atomicAdd(sel.done, 1u) == gridDim.x - 1;
         }
         __syncthreads();
-        if (s_last) {
+        if (s_last && tid < 256) {                                  // the selection stage is written for 4 waves; the others retire
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // see every other workgroup's results
             if (tid == 0) *sel.done = 0;
             select_body(sel.n_draw, sel.k, sel.early_exit, m, meas, support, masks, mask_words, sel.li_meas, sel.lm_li, sel.sel_rows,
@@ -567,7 +568,7 @@ __device__ __forceinline__ void select_body(int n_draw, int k, int early_exit, i
     }
     __syncthreads();
     const int best = s_best, iters = s_iters;
-    for (int it = iters + tid; it < n_draw; it += blockDim.x) support[it] = -1;   // never evaluated by the reference
+    for (int it = iters + tid; it < n_draw; it += 256) support[it] = -1;   // never evaluated by the reference (256 lanes take part)
     // winner's mask -> flags (set_as_most_supported_hypothesis.m:32-52) + ordered compaction of the LI rows
     for (int base = 0; base < m; base += 256) {
         const int j = base + tid;
@@ -800,6 +801,8 @@ int launch_build_rows_impl(pre3_ctx *c, int nsel, const int32_t *sel_dev, int r_
     return PRE3_OK;
 }
 
+constexpr int SCORE_THREADS = 512;      // one measurement per lane up to m = 512 (the per-measurement geometry is the long pole)
+
 template <typename T>
 static void launch_score_k(pre3_ctx *c, int k, int nb, size_t shm, int hyp_begin, double threshold, int ldg, int32_t *support_dev,
                            uint32_t *mask_dev, int mask_words, const SelArgs &sel)
@@ -807,10 +810,10 @@ static void launch_score_k(pre3_ctx *c, int k, int nb, size_t shm, int hyp_begin
 #define SCORE_ARGS hyp_begin, c->hyp, c->m, c->meas, c->lm.type, c->lm.off, c->x_km1, (const T *)c->HP, c->ldw, (const T *)c->G, ldg, \
                    c->row_nu, c->lm.z, to_camd(c->cam), threshold, support_dev, mask_dev, mask_words, sel
     switch (k) {
-    case 1: hipLaunchKernelGGL((k_ransac_score<T, 1>), dim3(nb), dim3(256), shm, c->stream, SCORE_ARGS); break;
-    case 2: hipLaunchKernelGGL((k_ransac_score<T, 2>), dim3(nb), dim3(256), shm, c->stream, SCORE_ARGS); break;
-    case 3: hipLaunchKernelGGL((k_ransac_score<T, 3>), dim3(nb), dim3(256), shm, c->stream, SCORE_ARGS); break;
-    default: hipLaunchKernelGGL((k_ransac_score<T, 4>), dim3(nb), dim3(256), shm, c->stream, SCORE_ARGS); break;
+    case 1: hipLaunchKernelGGL((k_ransac_score<T, 1>), dim3(nb), dim3(SCORE_THREADS), shm, c->stream, SCORE_ARGS); break;
+    case 2: hipLaunchKernelGGL((k_ransac_score<T, 2>), dim3(nb), dim3(SCORE_THREADS), shm, c->stream, SCORE_ARGS); break;
+    case 3: hipLaunchKernelGGL((k_ransac_score<T, 3>), dim3(nb), dim3(SCORE_THREADS), shm, c->stream, SCORE_ARGS); break;
+    default: hipLaunchKernelGGL((k_ransac_score<T, 4>), dim3(nb), dim3(SCORE_THREADS), shm, c->stream, SCORE_ARGS); break;
     }
 #undef SCORE_ARGS
 }

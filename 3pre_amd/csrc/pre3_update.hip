@@ -173,11 +173,13 @@ __device__ inline double fast_rsqrt(double x)
 __device__ unsigned long long g_probe[16];
 __device__ unsigned long long g_k9[64 * 8 * 4];
 __device__ unsigned long long g_k9rt[2048 * 4];     // s_memrealtime (100 MHz, chip-wide) per workgroup of the one-tile kernel
-#define PROBE_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_probe[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PROBE_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 5) g_probe[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #define PROBE_ACC(k, t0) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_probe[k] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
+#define PROBE_T(k, T_) do { if (threadIdx.x == (T_) && blockIdx.x == 5) g_probe[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PROBE_STAMP(k)
 #define PROBE_ACC(k, t0)
+#define PROBE_T(k, T_)
 #endif
 
 // wave-uniform lane read (v_readlane_b32): a few cycles, no LDS round trip
@@ -230,6 +232,8 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
     const bool isW = b > nS;
     const int c0 = isW ? (b - nS - 1) * NB : 0;
     const bool worker = tid >= 64;
+    // the factor wave shares its SIMD with worker wave 4: its (latency-bound) instructions must issue the moment they are ready
+    if (!worker) __builtin_amdgcn_s_setprio(3);
     const int wt = tid - 64;                                  // worker lane id 0..255
     if (worker) {
         // all 32 global loads of the two blocks are issued before the first LDS store
@@ -284,6 +288,7 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
         }
     }
     __syncthreads();
+    PROBE_STAMP(4);
     // every workgroup reads the raw diagonal block; workgroup 0 overwrites it with L_JJ at the end and must not do so
     // before all of them have it (they normally start together, but nothing guarantees that for very large grids)
     if (tid == 0 && b != 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -400,6 +405,7 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
     // compiler's own choice of unrolling by 2)
 #pragma unroll
     for (int mp = -2; mp < NMP; ++mp) {
+        if (mp == 6) { PROBE_T(8, 64); PROBE_T(10, 0); }
         if (worker) {
             if (mp >= 0) {
                 const int C = MB * mp, par = mp & 1;
@@ -522,7 +528,9 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
                 for (int t = 0; t < MB; ++t) Xs[C + t][i] = zprev[t];
             }
         }
+        if (mp == 6) { PROBE_T(9, 64); PROBE_T(11, 0); }
         __syncthreads();
+        if (mp == 6) { PROBE_T(12, 0); }
     }
     PROBE_STAMP(2);
     if (bad && tid == 0 && b == 0) atomicExch(status, 1);
@@ -549,6 +557,7 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
             W[(size_t)(J * NB + a2) * ldw + c0 + i] = Xs[a2][i];
         }
     }
+    PROBE_STAMP(3);
 }
 
 // Trailing update on the matrix cores: one 64 x 64 tile  C -= A B'  (K = 64) per workgroup, 4 waves, each a
