@@ -938,10 +938,11 @@ __device__ __forceinline__ void lds_dma_stage(const T *__restrict__ W, int ldw, 
 // launch (it only reads W), which removes one kernel boundary from the update chain.
 template <typename T>
 __device__ __forceinline__ void update_x_block(int blk, int n, int r, const T *__restrict__ W, int ldw, int ld,
-                                               const double *__restrict__ x_prior, double *__restrict__ x_out, double *__restrict__ params)
+                                               const double *__restrict__ x_prior, double *__restrict__ x_out, double *__restrict__ params,
+                                               double *scratch /* >= 4*64+4 doubles of LDS: the tile path's staging buffer, no extra allocation */)
 {
-    __shared__ double red[4][64];
-    __shared__ double q[4];
+    double (*red)[64] = reinterpret_cast<double (*)[64]>(scratch);
+    double *q = scratch + 4 * 64;
     const int ci = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int i = blk * 64 + ci;                   // i < ldw always (ldw >= ld + 64 > n rounded up)
     double s = 0;
@@ -970,11 +971,23 @@ template <typename T, int BK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 5 : 4))) void k_downdate_1t(T *__restrict__ P, int ld, const T *__restrict__ W, int ldw, int r_pad,
                                                      const int2 *__restrict__ tiles, int gen_size, XUpd xu, ProjRide pr)
 {
+    using M = Mfma<T>;
+    constexpr int TS = 64;
+    constexpr int NBLK = 32 / M::BLK;
+    constexpr int VEC = 16 / sizeof(T);               // elements per 16-byte LDS-DMA granule
+    constexpr int ROWV = TS / VEC;                    // granules per staged row
+    constexpr int NLD = (BK * ROWV) / 256;            // granules per lane per operand per stage
+    constexpr int HS = BK / M::KS / 2;                // k-steps per half stage
+    static_assert((BK * ROWV) % 256 == 0 && NLD >= 1, "stage must divide over the workgroup");
+    constexpr int STG = BK * TS;                      // elements of one operand stage
+    constexpr int SMEM = 4 * STG > 4 * 32 * 33 ? 4 * STG : 4 * 32 * 33;     // staging buffers, reused by the 4 epilogue patches
+    __shared__ __attribute__((aligned(16))) T smem[SMEM];                   // [A0 | A1 | B0 | B1], each [BK][64]
+    static_assert(sizeof(T) * SMEM >= sizeof(double) * (4 * 64 + 4), "the riders borrow the staging buffer");
     if ((int)blockIdx.x >= xu.n_tiles) {            // riders (launch_downdate adds these workgroups)
         __builtin_amdgcn_s_setprio(3);              // short dependent chains: must not starve behind the MFMA waves sharing their SIMD
         const int nx = (xu.n + 63) / 64, rb = blockIdx.x - xu.n_tiles;
         if (rb < nx) {                              // the state update
-            update_x_block<T>(rb, xu.n, xu.r, W, ldw, ld, xu.x_prior, xu.x_out, xu.params);
+            update_x_block<T>(rb, xu.n, xu.r, W, ldw, ld, xu.x_prior, xu.x_out, xu.params, reinterpret_cast<double *>(smem));
             if (pr.n_blocks) ride_signal(pr.ctr);
         } else {                                    // the rescue's projection at the updated state, once x is complete
             proj_ride_block(pr, rb - nx);
@@ -991,17 +1004,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         else if (gen == 2) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
     }
-    using M = Mfma<T>;
-    constexpr int TS = 64;
-    constexpr int NBLK = 32 / M::BLK;
-    constexpr int VEC = 16 / sizeof(T);               // elements per 16-byte LDS-DMA granule
-    constexpr int ROWV = TS / VEC;                    // granules per staged row
-    constexpr int NLD = (BK * ROWV) / 256;            // granules per lane per operand per stage
-    constexpr int HS = BK / M::KS / 2;                // k-steps per half stage
-    static_assert((BK * ROWV) % 256 == 0 && NLD >= 1, "stage must divide over the workgroup");
-    constexpr int STG = BK * TS;                      // elements of one operand stage
-    constexpr int SMEM = 4 * STG > 4 * 32 * 33 ? 4 * STG : 4 * 32 * 33;     // staging buffers, reused by the 4 epilogue patches
-    __shared__ __attribute__((aligned(16))) T smem[SMEM];                   // [A0 | A1 | B0 | B1], each [BK][64]
     T (*patch)[33] = reinterpret_cast<T (*)[33]>(smem + (threadIdx.x >> 6) * (32 * 33));
     const int2 ij = tiles[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

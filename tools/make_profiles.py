@@ -1,0 +1,51 @@
+"""Turn the rocprofv3 outputs of one measurement session into the committed summaries under profiles/.
+
+    gpurun_out/r1_trace/      rocprofv3 --kernel-trace --stats  -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extra-legs
+    gpurun_out/r1_pmc_fetch/  rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra-legs
+    gpurun_out/r1_pmc_write/  the same with WRITE_SIZE            (separate passes: the two counters do not fit one, MI355X_MICROARCH.md)
+
+usage: python tools/make_profiles.py [tag]      (tag defaults to r1)"""
+import csv, json, os, shutil, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+K9 = "k_downdate_1t"
+
+shutil.copy(os.path.join(G, "%s_trace" % tag, "%s_kernel_stats.csv" % tag), os.path.join(P, "%s_bench_kernel_stats.csv" % tag))
+tl = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_timeline.py"), os.path.join(G, "%s_trace" % tag, "%s_kernel_trace.csv" % tag), "3"],
+                    capture_output=True, text=True, check=True).stdout
+with open(os.path.join(P, "%s_bench_one_step_timeline.txt" % tag), "w") as fh:
+    fh.write("# one filter step (N=500, n=3013, 200 hypotheses, f32) from rocprofv3 --kernel-trace of `python3 bench.py --steps 40 --warmup 5 "
+             "--no-cpu-baseline --no-extra-legs`\n# (the profiler adds ~10 % to the step; unprofiled numbers are in DESIGN.md section 8)\n" + tl)
+
+
+def counter(dirname, prefix, name):
+    rows = [r for r in csv.DictReader(open(os.path.join(G, dirname, "%s_counter_collection.csv" % prefix))) if K9 in r["Kernel_Name"] and r["Counter_Name"] == name]
+    v = [float(r["Counter_Value"]) for r in rows]
+    big = [x for x in v if x > 0.8 * max(v)]                 # the r ~ 640 launches (LI updates); HI updates are far smaller
+    return dict(launches=len(v), avg_KB=sum(v) / len(v), max_KB=max(v), li_launch_avg_KB=sum(big) / len(big))
+
+
+fs, ws = counter("%s_pmc_fetch" % tag, "f", "FETCH_SIZE"), counter("%s_pmc_write" % tag, "w", "WRITE_SIZE")
+tr = [r for r in csv.DictReader(open(os.path.join(G, "%s_trace" % tag, "%s_kernel_trace.csv" % tag))) if K9 in r["Kernel_Name"]]
+dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
+big = [d for d in dur if d > 0.6 * max(dur)]
+out = {
+    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra-legs (two separate passes)",
+    "kernel": "k_downdate_1t<float,16> (K9, one 64x64 tile per workgroup; the x-update and rescue-projection workgroups ride in the same launch)",
+    "counters_KB": {"FETCH_SIZE": fs, "WRITE_SIZE": ws},
+    "k9_trace_durations_us": {"launches": len(dur), "avg": sum(dur) / len(dur), "li_launch_avg": sum(big) / len(big)},
+    "notes": [
+        "WRITE_SIZE of an LI launch = ld^2*4 B (ld = 3072): the whole padded P is written once per launch (upper tile + mirrored tile).",
+        "FETCH_SIZE on gfx950 reports half the bytes of 16 B/lane streams (MI355X_MICROARCH.md, HBM section); the W staging loads are 16 B/lane LDS-DMA, "
+        "the P-tile prefetch is 4 B/lane (uncalibrated), so the read side lies between the raw figure and twice it.",
+        "algorithmic per LI launch (r=640, n=3013): P upper triangle read 18.2 MB + P written 36.3 MB + W 7.7 MB = 62 MB",
+    ],
+    "hbm_bytes_per_li_launch": {"raw": 1024.0 * (fs["li_launch_avg_KB"] + ws["li_launch_avg_KB"]),
+                                "fetch_doubled": 1024.0 * (2 * fs["li_launch_avg_KB"] + ws["li_launch_avg_KB"])},
+}
+with open(os.path.join(P, "%s_pmc_k9.json" % tag), "w") as fh:
+    json.dump(out, fh, indent=1)
+print(json.dumps(out["counters_KB"], indent=1), out["k9_trace_durations_us"], out["hbm_bytes_per_li_launch"])
