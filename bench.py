@@ -200,7 +200,7 @@ def main():
                        "measured_per_step": int(np.mean([len(s["meas_idx"]) for s in seq["steps"][W:W + K]])),
                        "mean_li_rows": 2 * n_li, "mean_hi_rows": 2 * n_hi, "parallelism": "replicas x%d" % world,
                        "hip_event_ms_per_step": ev_ms / K},
-            "roofline": {"kernel": "k_downdate (K9: P <- P - W'W)", "bound": "mfma", "achieved": achieved, "peak": PEAK[args.dtype],
+            "roofline": {"kernel": "k_downdate_1t (K9: P <- P - W'W, one 64x64 tile per workgroup; the x-update and rescue-projection riders share the launch)", "bound": "mfma", "achieved": achieved, "peak": PEAK[args.dtype],
                          "unit": "TFLOP/s", "frac": achieved / PEAK[args.dtype], "traffic": traffic, "traffic_source": traffic_src,
                          "launches": kt["launches"], "avg_launch_us": 1e3 * kt["total_ms"] / max(kt["launches"], 1),
                          "algorithmic": "symmetric rank-r down-date (SYRK): n(n+1)r flop per launch, r = rows of that update, averaged over "
