@@ -758,8 +758,11 @@ int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, co
     }
     if (trace) t2 = now();
     c->ride_rescue_projection = true;                               // the rescue's projection rides in the LI update's K9 launch
-    PRE3_TRY(pre3_update_li(c));                                    // mono_slam.m:181
-    c->ride_rescue_projection = false;
+    {
+        const int rc_li = pre3_update_li(c);                        // mono_slam.m:181
+        c->ride_rescue_projection = false;                          // (also on failure: a later K9 launch must not carry the riders)
+        if (rc_li != PRE3_OK) { c->rescue_projected = false; return rc_li; }
+    }
     if (ran) for (int i = 0; i < 4; ++i) st[i] = c->mail_host[i];
     if (trace) t3 = now();
     PRE3_TRY(pre3_rescue(c, chi2, nullptr));                        // mono_slam.m:184

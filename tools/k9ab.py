@@ -1,6 +1,6 @@
 import importlib, sys, os
 import numpy as np
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pre3 = importlib.import_module("3pre_amd")
 N=500; n=13+6*N
 f = pre3.EkfFilter([250.0, 90, 70, 0, 0, 144, 176], np.zeros(N, np.int32), dtype="f32", max_hyp=4)
