@@ -50,6 +50,11 @@ static int check_ctx(pre3_ctx *c)
 {
     PRE3_CHECK(c != nullptr, PRE3_E_ARG, "null context");
     PRE3_HIP(hipSetDevice(c->device));
+    if (c->hi_pending) {                 // PRE3_OPT_DEFER_HI: the previous step's HI update is completed by whatever call comes next
+        c->hi_pending = false;
+        PRE3_TRY(pre3_update_hi(c));
+        c->last_n_hi = c->hi_from_host >= 0 ? c->hi_from_host : (c->hi_kernel ? c->mail_host[5] : 0);
+    }
     return PRE3_OK;
 }
 
@@ -233,6 +238,15 @@ int pre3_destroy(pre3_ctx *c)
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PRE3_OK;
+}
+
+int pre3_set_option(pre3_ctx *c, int option, int value)
+{
+    PRE3_TRY(check_ctx(c));
+    switch (option) {
+    case PRE3_OPT_DEFER_HI: c->defer_hi = value != 0; return PRE3_OK;
+    default: set_error("pre3_set_option: unknown option %d", option); return PRE3_E_ARG;
+    }
 }
 
 int pre3_sync(pre3_ctx *c)
@@ -767,7 +781,8 @@ int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, co
     if (trace) t3 = now();
     PRE3_TRY(pre3_rescue(c, chi2, nullptr));                        // mono_slam.m:184
     if (trace) t4 = now();
-    PRE3_TRY(pre3_update_hi(c));                                    // mono_slam.m:187
+    if (c->defer_hi) c->hi_pending = true;                          // mono_slam.m:187, completed at the next call on this context
+    else PRE3_TRY(pre3_update_hi(c));                               // mono_slam.m:187
     if (trace) {
         t5 = now();
         acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += t4 - t3; acc[4] += t5 - t4;
@@ -780,7 +795,8 @@ int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, co
         }
     }
     st[4] = c->li_from_host >= 0 ? c->li_from_host : (c->li_kernel ? c->mail_host[4] : 0);
-    st[5] = c->hi_from_host >= 0 ? c->hi_from_host : (c->hi_kernel ? c->mail_host[5] : 0);
+    st[5] = c->defer_hi ? c->last_n_hi : (c->hi_from_host >= 0 ? c->hi_from_host : (c->hi_kernel ? c->mail_host[5] : 0));
+    st[7] = c->defer_hi ? 1 : 0;          // 1: st[5] is the HI count of the PREVIOUS step (this step's is still on the device)
     if (stats) for (int i = 0; i < 8; ++i) stats[i] = st[i];
     return PRE3_OK;
 }

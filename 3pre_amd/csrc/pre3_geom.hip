@@ -643,13 +643,6 @@ __device__ __forceinline__ void collect_hi_body(int m, const int32_t *__restrict
     }
 }
 
-__global__ __launch_bounds__(64) void k_collect_hi(int m, const int32_t *__restrict__ meas, const int32_t *__restrict__ lm_ic,
-                                                   const int32_t *__restrict__ lm_li, const int32_t *__restrict__ lm_hi,
-                                                   int32_t *__restrict__ hi_meas, int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats,
-                                                   int32_t *mail, int seq)
-{
-    collect_hi_body(m, meas, lm_ic, lm_li, lm_hi, hi_meas, sel_rows, stats, mail, seq);
-}
 
 // x_out = x_prior + W' y  (update.m:36), then Jn at the un-normalised quaternion (update.m:42) -> params,
 // then normalise (update.m:48).  W: r_pad x ldw, y = column `ld` of W.
@@ -735,13 +728,6 @@ int launch_project(pre3_ctx *c, int which, int clear_first)
     return PRE3_OK;
 }
 
-static int launch_collect_hi(pre3_ctx *c)
-{
-    hipLaunchKernelGGL(k_collect_hi, dim3(1), dim3(64), 0, c->stream, c->m, c->meas, c->lm.ic, c->lm.li, c->lm.hi, c->hi_meas,
-                       c->sel_rows, c->stats, c->mail_dev, ++c->seq_collect);
-    PRE3_HIP(hipGetLastError());
-    return PRE3_OK;
-}
 
 // project + innovation (+ the HI collection in mode 1) with one kernel boundary less
 int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode, double chi2)

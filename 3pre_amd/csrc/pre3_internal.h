@@ -83,6 +83,7 @@ struct pre3_ctx {
     int num_cus = 256;
     unsigned int *chol_arrive = nullptr; unsigned int chol_target = 0;   // [0] panel arrivals, [1] scoring done, [2] rescue done, [3],[4] rider producers
     unsigned int ride_target[2] = { 0, 0 };
+    bool defer_hi = false, hi_pending = false; int last_n_hi = 0;   // PRE3_OPT_DEFER_HI (pre3_set_option)
     bool ride_rescue_projection = false;          // request: the next K9 launch also projects at x_k_k (pre3_step sets it before the LI update)
     bool rescue_projected = false;                // h / H at the current x_k_k are on the device (set by that launch, consumed by pre3_rescue)
     //   // panel kernels: arrivals of the workgroups that read the raw diagonal block
@@ -112,7 +113,7 @@ struct pre3_ctx {
     int32_t *li_meas = nullptr, *hi_meas = nullptr;   // [capm] flags in measurement order
     double *pred_params = nullptr;                // [64] predict: Qq1(16) Jn(16) Q(49->7x7) etc.
     int32_t *pinned_stats = nullptr;              // host pinned [16]
-    // mailbox: pinned, host-coherent; k_ransac_select / k_collect_hi store their counts here and bump a
+    // mailbox: pinned, host-coherent; the selection and HI-collection stages store their counts here and bump a
     // sequence word, so the host learns r for the next launches by polling instead of a copy + stream sync
     int32_t *mail_host = nullptr, *mail_dev = nullptr;
     int32_t seq_select = 0, seq_collect = 0;

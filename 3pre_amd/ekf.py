@@ -89,6 +89,11 @@ class EkfFilter:
     def sync(self):
         check(lib.pre3_sync(self._ctx))
 
+    def defer_hi_update(self, on=True):
+        """PRE3_OPT_DEFER_HI: step() returns once the rescue stage is enqueued; the HI update is completed by the next call.
+        step()'s n_hi then belongs to the previous step."""
+        check(lib.pre3_set_option(self._ctx, 1, int(bool(on))))
+
     # ---- map management between steps (map_management.m:27-79); the policy stays with the caller
     def _refresh_map(self):
         self.N = int(lib.pre3_get_map(self._ctx, None))

@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--hyp", type=int, default=200)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--kt-every", type=int, default=4, help="bracket one K9 launch in N with HIP events (an event pair costs ~11 us of stream time); 1 = every launch")
+    ap.add_argument("--sync-hi", action="store_true", help="complete every step's HI update inside the step call (default: deferred to the next call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the sharded-RANSAC and matcher legs")
@@ -161,6 +162,9 @@ def main():
     if dist is not None:
         dist.barrier()
     f.kernel_timing(max(1, args.kt_every))
+    if not args.sync_hi:
+        f.defer_hi_update(True)                    # PRE3_OPT_DEFER_HI: the HI update of step k is completed by the call of step k+1 (same results;
+                                                   # the caller's time between steps overlaps the rescue stage); the final timer_stop() flushes the last one
     f.timer_start()
     t0 = time.perf_counter()
     for s in seq["steps"][W:W + K]:

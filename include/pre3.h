@@ -159,6 +159,13 @@ PRE3_API int pre3_update_ell(int device, int dtype, int n, int r, const double *
                              const int32_t *nnz, const int32_t *col, const double *val, const double *R,
                              const double *z, const double *h, double *x_out, double *P_out, double *K_out);
 
+/* Options.  PRE3_OPT_DEFER_HI = 1: pre3_step returns as soon as the rescue stage is enqueued; the HI count is polled and the HI
+ * update (ekf_update_hi_inliers.m) launched by the NEXT call on the context (any entry point: step, get_state, sync ...), so the
+ * caller's own time between two steps overlaps the device's rescue stage.  Results are identical; stats[5] of pre3_step then
+ * reports the previous step's HI count and stats[7] = 1 says so.  Default 0: pre3_step completes the HI update itself. */
+#define PRE3_OPT_DEFER_HI 1
+PRE3_API int pre3_set_option(pre3_ctx *ctx, int option, int value);
+
 /* ---- map management on the device (map_management.m:27-79) ----------------------------- */
 /* These act on (x_k_k, p_k_k) between steps, as map_management.m:140 does, and keep P resident: P <- A P A' (+D) with
  * a sparse A (selection rows / the 6x13 and 3x6 Jacobians of the reference), evaluated by two gather passes through a

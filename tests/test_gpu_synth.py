@@ -176,3 +176,26 @@ def test_full_size_properties_config3(pre3):
         f.close()
     assert np.array_equal(res["f64"][0][0][0], res["f32"][0][0][0])     # first-step LI sets identical
     assert np.abs(res["f64"][2] - res["f32"][2]).max() < 2e-3 * np.abs(res["f64"][2]).max()
+
+
+def test_deferred_hi_update_gives_identical_results(pre3, orc):
+    """PRE3_OPT_DEFER_HI: the HI update of step k is completed by the next call on the context; states and flags are the same."""
+    N = 60
+    seq = synth.make_sequence(N, 12, 30, seed=77, sigma_z=0.6)          # noisier pixels: several steps rescue HI inliers
+    types, off, n = orc.landmark_table(np.zeros(N, int))
+    outs = []
+    for defer in (False, True):
+        f = pre3.EkfFilter(seq["cam"], types, dtype="f64", max_hyp=30, std_z=1.0)
+        f.set_x_p_k_k(seq["x0"], seq["P0"])
+        f.defer_hi_update(defer)
+        n_hi = []
+        for s in seq["steps"]:
+            st = f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=1.0)
+            n_hi.append(st["n_hi"])
+        li, hi = f.get_flags()                                        # any call completes the pending update
+        outs.append((f.get_x_k_k(), f.get_p_k_k(), li, hi, n_hi))
+        f.close()
+    (x0, P0, li0, hi0, nh0), (x1, P1, li1, hi1, nh1) = outs
+    assert np.array_equal(x0, x1) and np.array_equal(P0, P1) and np.array_equal(li0, li1) and np.array_equal(hi0, hi1)
+    assert sum(nh0) > 0, "the sequence must exercise HI updates"
+    assert nh1[1:] == nh0[:-1]                                        # deferred mode reports the previous step's count
