@@ -118,6 +118,26 @@ def matcher_leg(pre3, reps=20):
             "int8_mfma_TOPS": 2.0 * K * K * 128 / (ms.value * 1e-3) / 1e12}
 
 
+def vo_leg(pre3, pnum=500, n_hyp=700, reps=50):
+    """the VO front end's 4-point RANSAC (vodometry_dr_ye.m:171-236), 700 hypotheses over pnum matched 3-D points,
+    inputs resident (pre3_vo_bench: the dist / score / final kernels, HIP events)."""
+    vo = importlib.import_module("3pre_amd.vo")
+    rng = np.random.default_rng(6000)
+    a = rng.normal(0, 0.1, 3); th = np.linalg.norm(a); kx = a / th
+    Kx = np.array([[0, -kx[2], kx[1]], [kx[2], 0, -kx[0]], [-kx[1], kx[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    p2 = np.stack([rng.uniform(-1.5, 1.5, pnum), rng.uniform(-1, 1, pnum), rng.uniform(0.6, 5, pnum)])
+    p1 = R @ p2 + rng.normal(0, 0.05, 3)[:, None] + rng.normal(0, 0.002, (3, pnum))
+    bad = rng.choice(pnum, int(0.3 * pnum), replace=False)
+    p1[:, bad] += rng.normal(0, 0.5, (3, len(bad)))
+    match = np.stack([np.arange(1, pnum + 1), rng.permutation(pnum) + 1])
+    draws = vo.draw_hypotheses(match, n_hyp, rng)
+    ms = vo.vo_bench(p1, p2, draws, reps=reps)
+    out = vo.vo_ransac(p1, p2, draws)
+    return {"workload": "VO 4-point 3D-3D RANSAC: %d matches, %d hypotheses, 30 %% outliers" % (pnum, n_hyp), "us_per_ransac": 1e3 * ms,
+            "hypotheses_per_s": n_hyp / (ms * 1e-3), "n_support": out["n_support"], "sta": out["sta"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,7 +228,8 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / PEAK[args.dtype], "traffic": traffic, "traffic_source": traffic_src,
                          "launches": kt["launches"], "avg_launch_us": 1e3 * kt["total_ms"] / max(kt["launches"], 1),
                          "algorithmic": "symmetric rank-r down-date (SYRK): n(n+1)r flop per launch, r = rows of that update, averaged over "
-                                        "ALL K9 launches of the timed region (LI updates with r~640 and HI updates with r<=64); "
+                                        "the K9 launches of the timed region that were bracketed with HIP events (one in --kt-every; LI updates "
+                                        "with r~640 and HI updates with r<=64 alike); "
                                         "SURVEY 8(d)'s un-halved convention 2n^2r gives twice this figure",
                          "survey_2n2r_equivalent": 2.0 * achieved * n / (n + 1.0)},
         }
@@ -229,6 +250,10 @@ def main():
                 out["matcher"] = matcher_leg(pre3)
             except Exception as e:                              # pragma: no cover
                 out["matcher"] = {"error": repr(e)[:300]}
+            try:
+                out["vo_ransac"] = vo_leg(pre3)
+            except Exception as e:                              # pragma: no cover
+                out["vo_ransac"] = {"error": repr(e)[:300]}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
