@@ -139,3 +139,47 @@ def test_map_calls_need_the_posterior(pre3, orc):
         check_idx = [10]
         f.delete_features(check_idx)                        # out of range
     f.close()
+
+
+def test_map_management_and_steps_over_several_frames(pre3, orc):
+    """Three frames of [step -> delete -> convert -> add] on the device against the oracle doing the same on the host:
+    the map layouts, the inlier sets of every step and the final state must agree (fp64)."""
+    N0 = 40
+    seq = synth.make_sequence(N0, 4, 30, seed=101)
+    cam = seq["cam"]
+    types = np.zeros(N0, np.int32)
+    f = pre3.EkfFilter(cam, types, dtype="f64", max_hyp=30, max_landmarks=N0 + 8)
+    x, P = seq["x0"].copy(), seq["P0"].copy()
+    f.set_x_p_k_k(x, P)
+    ids = list(range(N0))                                   # identity of each current landmark in the synthetic world (-1: added)
+    rng = np.random.default_rng(5)
+    for frame, s in enumerate(seq["steps"][:3]):
+        to, off, n = orc.landmark_table(types)
+        keep = [(j, ids.index(int(i))) for j, i in enumerate(s["meas_idx"]) if int(i) in ids]
+        order = sorted(keep, key=lambda t: t[1])
+        meas = np.array([t[1] for t in order], np.int32)
+        z = s["z"][[t[0] for t in order]]
+        hyp = np.stack([rng.permutation(len(meas))[:3] for _ in range(30)]).astype(np.int32)
+        st = f.step(s["u"], meas, z, hyp, threshold=1.0)
+        ref = orc.step(to, off, cam, x, P, s["u"], meas, z, hyp, 1.0)
+        li, hi = f.get_flags()
+        assert np.array_equal(li, ref["li"]) and np.array_equal(hi, ref["hi"]), "frame %d" % frame
+        x, P = ref["x_kk"], ref["P_kk"]
+        # delete two landmarks, convert what is convertible (threshold raised so that something converts), add two
+        d = sorted(rng.choice(len(types), 2, replace=False).tolist())
+        f.delete_features(d)
+        x, P, types = orc.map_delete(to, off, x, P, d)
+        ids = [v for k, v in enumerate(ids) if k not in d]
+        thr = 0.1 if frame else 2.0
+        conv = f.inversedepth_2_cartesian(thr)
+        x, P, types, c2 = orc.map_convert(types, x, P, thr)
+        assert np.array_equal(conv, c2)
+        uvd = np.stack([rng.uniform(20, 150, 2), rng.uniform(20, 120, 2)], 1)
+        f.add_features_inverse_depth(uvd, 1.0, 0.5)
+        x, P = orc.map_add(x, P, cam, uvd, 1.0, 0.5)
+        types = np.r_[types, [0, 0]].astype(np.int32)
+        ids += [-1, -1]
+        assert np.array_equal(f.lm_type, types) and f.n == x.shape[0]
+        assert np.abs(f.get_x_k_k() - x).max() < 1e-9 and np.abs(f.get_p_k_k() - P).max() < 1e-9 * np.abs(P).max(), "frame %d" % frame
+    assert (types == 1).any() and len(types) == N0
+    f.close()
