@@ -26,6 +26,7 @@ int launch_ransac_score_impl(pre3_ctx *c, int k, double threshold, int hyp_begin
                              int select_n_draw = 0, int early_exit = 0);
 int launch_ransac_select_impl(pre3_ctx *c, int n_draw, int k, int early_exit, int32_t *support_dev, const uint32_t *mask_dev, int mask_words);
 int launch_fill_w(pre3_ctx *c, int r_pad);
+void release_scratch();
 int match_partial(int device, int cls, int ND, int K1, const void *L1, int K2, const void *L2, int k2_offset, double *best, double *second, int32_t *arg);
 int knn_run(int device, int D, int N, const double *data, int M, const double *query, int k, double *ids, double *dist);
 void *match_bench_create(int ND, int K1, const uint8_t *L1, int K2, const uint8_t *L2);
@@ -869,6 +870,8 @@ int pre3_update_ell(int device, int dtype, int n, int r, const double *x, const 
 }
 
 // ---- matcher ------------------------------------------------------------------------------------------
+int pre3_release_scratch(void) { release_scratch(); return PRE3_OK; }
+
 int pre3_siftmatch_merge(int cls, int G, int K1, const double *best, const double *second, const int32_t *arg, double thresh_d,
                          double *pairs_out, double *score_out, int *M_out)
 {

@@ -260,6 +260,8 @@ PRE3_API int pre3_siftmatch_merge(int cls, int G, int K1, const double *best, co
 /* ---- a11: kNearestNeighbors.m:29-39 ------------------------------------------------------------- */
 /* data: N x D, query: M x D, MATLAB column-major.  ids_out (M x k, column-major, 1-based doubles),
  * dist_out (M x k, Euclidean).  Ties: lowest index first (MATLAB's stable sort). */
+/* the stateless matcher / kNN calls keep their device scratch in a small per-thread pool between calls; this frees the idle part */
+PRE3_API int pre3_release_scratch(void);
 PRE3_API int pre3_knn_f64(int device, int D, int N, const double *data, int M, const double *query, int k,
                           double *ids_out, double *dist_out);
 

@@ -65,6 +65,14 @@ def test_edge_shapes(pre3, orc):
         m, d = pre3.siftmatch(L1, L2, 1.1, return_scores=True)
         mr, dr = orc.siftmatch(L1, L2, 1.1)
         assert np.array_equal(m, mr) and np.array_equal(d, dr)
+    # the tiled float kernels (>= 64*64*16 pairs): ragged tiles, ND not a multiple of the 32-bin chunk, exact ties
+    for dt, ND, K1, K2 in ((np.float32, 36, 257, 300), (np.float64, 130, 300, 257), (np.float32, 128, 64, 1024), (np.float64, 5, 1025, 65)):
+        L1 = rng.random((ND, K1)).astype(dt)
+        L2 = rng.random((ND, K2)).astype(dt)
+        L2[:, 7] = L1[:, 3]; L2[:, K2 - 1] = L1[:, 3]          # two exact zero-distance candidates: first index wins, ratio test fails
+        m, d = pre3.siftmatch(L1, L2, 1.2, return_scores=True)
+        mr, dr = orc.siftmatch(L1, L2, 1.2)
+        assert np.array_equal(m, mr) and np.array_equal(d, dr), (dt, ND, K1, K2)
     # maximum distance for uint8: 128 * 255^2 stays inside int32
     L1 = np.zeros((128, 2), np.uint8)
     L2 = np.full((128, 2), 255, np.uint8)

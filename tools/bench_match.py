@@ -12,6 +12,7 @@ for dt in (np.uint8, np.float32, np.float64):
     if dt != np.uint8:
         a = a / np.linalg.norm(a, axis=0, keepdims=True); b = b / np.linalg.norm(b, axis=0, keepdims=True)
         a, b = a.astype(dt), b.astype(dt)
+    a, b = np.asfortranarray(a), np.asfortranarray(b)          # MATLAB's own layout (one descriptor per column, contiguous): no per-call transpose
     pre3.siftmatch(a, b)
     t0 = time.perf_counter()
     for _ in range(3): m = pre3.siftmatch(a, b)
