@@ -227,7 +227,7 @@ int pre3_destroy(pre3_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
                      c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
-                     c->sel_rows, c->support, c->masks, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_pairs, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive };
+                     c->sel_rows, c->support, c->masks, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->pinned_stats) (void)hipHostFree(c->pinned_stats);
     if (c->inbox_host) (void)hipHostFree(c->inbox_host);
@@ -469,7 +469,10 @@ static int ensure_ic_buffers(pre3_ctx *c)
     if (c->bank) return PRE3_OK;
     const size_t N = (size_t)c->capN;
     PRE3_TRY(dmalloc(&c->bank, N * DESC_DIM)); PRE3_TRY(dmalloc(&c->bank_alt, N * DESC_DIM));
-    PRE3_TRY(dmalloc(&c->ic_pred, N)); PRE3_TRY(dmalloc(&c->ic_counts, 4)); PRE3_TRY(dmalloc(&c->ic_arg, N)); PRE3_TRY(dmalloc(&c->ic_pairs, 3 * N));
+    // result block, fetched with ONE copy: [counts(4) | meas(capN) | pairs(3 capN) | z(2 capN doubles)]
+    PRE3_TRY(dmalloc(&c->ic_pred, N)); PRE3_TRY(dmalloc(&c->ic_counts, 4 + 4 * N + 4 * N)); PRE3_TRY(dmalloc(&c->ic_arg, N));
+    c->ic_pairs = c->ic_counts + 4 + N;
+    PRE3_HIP(hipMemset(c->ic_counts, 0, sizeof(int32_t) * (4 + 8 * N)));
     PRE3_TRY(dmalloc(&c->ic_newk2, N)); PRE3_TRY(dmalloc(&c->ic_best, N)); PRE3_TRY(dmalloc(&c->ic_second, N)); PRE3_TRY(dmalloc(&c->bank_src, N));
     PRE3_HIP(hipMemset(c->bank, 0, sizeof(double) * N * DESC_DIM));
     return PRE3_OK;
@@ -504,9 +507,14 @@ int pre3_set_scan(pre3_ctx *c, int K2, const double *descriptor_raw, const doubl
     if (K2 > c->scan_cap) {
         if (c->scan_desc) (void)hipFree(c->scan_desc);
         if (c->scan_pos) (void)hipFree(c->scan_pos);
-        c->scan_desc = c->scan_pos = nullptr; c->scan_cap = 0;
+        if (c->ic_pb) (void)hipFree(c->ic_pb);
+        if (c->ic_ps) (void)hipFree(c->ic_ps);
+        if (c->ic_pa) (void)hipFree(c->ic_pa);
+        c->scan_desc = c->scan_pos = nullptr; c->ic_pb = c->ic_ps = nullptr; c->ic_pa = nullptr; c->scan_cap = 0;
         const int cap = round_up(K2, 256);
         PRE3_TRY(dmalloc(&c->scan_desc, (size_t)cap * DESC_DIM)); PRE3_TRY(dmalloc(&c->scan_pos, (size_t)cap * 4));
+        const size_t np = (size_t)(cap / 64) * c->capN;
+        PRE3_TRY(dmalloc(&c->ic_pb, np)); PRE3_TRY(dmalloc(&c->ic_ps, np)); PRE3_TRY(dmalloc(&c->ic_pa, np));
         c->scan_cap = cap;
     }
     if (K2) {
@@ -527,26 +535,25 @@ int pre3_ic_search(pre3_ctx *c, double thresh, int strict_reference, int32_t *n_
     PRE3_CHECK(m_out != nullptr, PRE3_E_ARG, "pre3_ic_search: null m_out");
     const int N = c->N;
     // search_IC_matches.m:31-44: h, H and S for every landmark at the prediction
-    PRE3_TRY(pre3_project(c, PRE3_X_K_KM1, 1));
-    PRE3_TRY(pre3_innovation(c));
+    PRE3_CHECK(c->have_cam, PRE3_E_STATE, "pre3_ic_search: camera not set");
+    if (N) PRE3_TRY(launch_project_innovation(c, PRE3_X_K_KM1, 1, 0, 0.0));
+    c->projected = true; c->innovated = true;
     PRE3_HIP(hipMemsetAsync(c->lm.ic, 0, sizeof(int32_t) * (N ? N : 1), c->stream));
     PRE3_TRY(launch_ic_search(c, thresh, strict_reference));
+    // one D2H copy of the result block [counts | meas | pairs | z]
+    const size_t capN = (size_t)c->capN, blk_bytes = sizeof(int32_t) * (4 + 4 * capN) + sizeof(double) * 2 * capN;
+    std::vector<int32_t> blk(4 + 4 * capN + 4 * capN);
+    PRE3_HIP(hipMemcpyAsync(blk.data(), c->ic_counts, blk_bytes, hipMemcpyDeviceToHost, c->stream));
     PRE3_HIP(hipStreamSynchronize(c->stream));
-    int32_t counts[4] = { 0, 0, 0, 0 };
-    PRE3_HIP(hipMemcpy(counts, c->ic_counts, sizeof(counts), hipMemcpyDeviceToHost));
-    std::vector<int32_t> ic(N ? N : 1, 0), meas;
-    if (N) PRE3_HIP(hipMemcpy(ic.data(), c->lm.ic, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
-    for (int i = 0; i < N; ++i) if (ic[i]) meas.push_back(i);
-    PRE3_CHECK((int)meas.size() == counts[2], PRE3_E_STATE, "pre3_ic_search: accepted-count mismatch (%zu vs %d)", meas.size(), counts[2]);
-    if (n_matches_out) *n_matches_out = counts[1];
-    if (pairs_out && counts[1]) PRE3_HIP(hipMemcpy(pairs_out, c->ic_pairs, sizeof(int32_t) * 3 * counts[1], hipMemcpyDeviceToHost));
-    *m_out = (int)meas.size();
-    if (meas_idx_out) for (size_t j = 0; j < meas.size(); ++j) meas_idx_out[j] = meas[j];
-    if (z_out && !meas.empty()) {
-        std::vector<double> z(2 * (size_t)N);
-        PRE3_HIP(hipMemcpy(z.data(), c->lm.z, sizeof(double) * 2 * N, hipMemcpyDeviceToHost));
-        for (size_t j = 0; j < meas.size(); ++j) { z_out[2 * j] = z[2 * meas[j]]; z_out[2 * j + 1] = z[2 * meas[j] + 1]; }
-    }
+    const int32_t *counts = blk.data();
+    const int n_match = c->scan_K2 > 0 ? counts[1] : 0, m = c->scan_K2 > 0 ? counts[2] : 0;
+    PRE3_CHECK(m >= 0 && m <= N && n_match >= 0 && n_match <= N, PRE3_E_STATE, "pre3_ic_search: inconsistent counts (%d matches, %d accepted)", n_match, m);
+    std::vector<int32_t> meas(blk.begin() + 4, blk.begin() + 4 + m);
+    if (n_matches_out) *n_matches_out = n_match;
+    if (pairs_out) for (int i = 0; i < 3 * n_match; ++i) pairs_out[i] = blk[4 + capN + i];
+    *m_out = m;
+    if (meas_idx_out) for (int j = 0; j < m; ++j) meas_idx_out[j] = meas[j];
+    if (z_out) { const double *zz = (const double *)(blk.data() + 4 + 4 * capN); for (int j = 0; j < 2 * m; ++j) z_out[j] = zz[j]; }
     return install_measurements(c, (int)meas.size(), meas.data(), nullptr, nullptr, 0);
 }
 

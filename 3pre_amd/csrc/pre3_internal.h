@@ -133,6 +133,7 @@ struct pre3_ctx {
     double *scan_desc = nullptr, *scan_pos = nullptr; int scan_K2 = 0, scan_cap = 0;
     int32_t *ic_pred = nullptr, *ic_counts = nullptr, *ic_arg = nullptr, *ic_pairs = nullptr, *ic_newk2 = nullptr; double *ic_best = nullptr, *ic_second = nullptr;
     int32_t *bank_src = nullptr;
+    double *ic_pb = nullptr, *ic_ps = nullptr; int32_t *ic_pa = nullptr;     // per (column tile, landmark) partials of the tiled matcher [scan_cap/64][capN]
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;
     pre3::KernelTiming kt;

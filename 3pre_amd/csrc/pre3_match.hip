@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256) void k_match_exact(int ND, int K2, const T *__
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_match_exact_tiled(int ND, int K1, int K2, const T *__restrict__ L1, const T *__restrict__ L2,
-                                                           T *__restrict__ pbest, T *__restrict__ psecond, int32_t *__restrict__ parg, int ntile_n)
+                                                           T *__restrict__ pbest, T *__restrict__ psecond, int32_t *__restrict__ parg, int ntile_n,
+                                                           const int32_t *__restrict__ qidx = nullptr, const int32_t *__restrict__ nq = nullptr)
 {
 #pragma clang fp contract(off)
     constexpr int TQ = 64, TK = 64, CB = 32, LDP = 68;
@@ -111,18 +112,21 @@ __global__ __launch_bounds__(256) void k_match_exact_tiled(int ND, int K1, int K
     typedef T v4_t __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, tq = tid >> 4, tk = tid & 15;
     const int q0 = blockIdx.y * TQ, k0 = blockIdx.x * TK;
+    const int nQ = nq ? *nq : K1;                          // IC search: the query count is only known on the device (K1 bounds the grid)
+    if (q0 >= nQ) return;
     T acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (T)0;
     const int lq = tid >> 2, lb = (tid & 3) * 8;           // loader: descriptor lq of the tile, bins lb..lb+7 of the chunk
+    const size_t qcol = q0 + lq < nQ ? (qidx ? (size_t)qidx[q0 + lq] : (size_t)(q0 + lq)) : 0;
     for (int c0 = 0; c0 < ND; c0 += CB) {
         T qv[8], bv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int bin = c0 + lb + e;
-            qv[e] = (q0 + lq < K1 && bin < ND) ? L1[(size_t)(q0 + lq) * ND + bin] : (T)0;
+            qv[e] = (q0 + lq < nQ && bin < ND) ? L1[qcol * ND + bin] : (T)0;
             bv[e] = (k0 + lq < K2 && bin < ND) ? L2[(size_t)(k0 + lq) * ND + bin] : (T)0;
         }
         __syncthreads();                                    // the previous chunk has been consumed
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256) void k_match_exact_tiled(int ND, int K1, int K
             merge3(best, second, bk, ob, os, ok);
         }
         const int q = q0 + tq * 4 + a;
-        if (tk == 0 && q < K1) {
+        if (tk == 0 && q < nQ) {
             const size_t o = (size_t)blockIdx.x * K1 + q;             // [column tile][query]: the reduce kernel reads it coalesced
             pbest[o] = best; psecond[o] = second; parg[o] = bk;
         }
@@ -508,7 +512,8 @@ __global__ void k_ic_gate(const int32_t *__restrict__ pred, const double *__rest
                           const double *__restrict__ second, const int32_t *__restrict__ arg, float thresh, int strict,
                           const double *__restrict__ pos, const double *__restrict__ h, const double *__restrict__ S,
                           const int32_t *__restrict__ has_S, double *__restrict__ z, int32_t *__restrict__ ic,
-                          int32_t *__restrict__ pairs, int32_t *__restrict__ newk2, int32_t *counts)
+                          int32_t *__restrict__ pairs, int32_t *__restrict__ newk2, int32_t *counts,
+                          int32_t *__restrict__ meas_out, double *__restrict__ z_out)
 {
     const int lane = threadIdx.x, npred = counts[0];
     int base = 0, m = 0;
@@ -531,7 +536,13 @@ __global__ void k_ic_gate(const int32_t *__restrict__ pred, const double *__rest
             if (acc) { ic[lm] = 1; z[2 * lm] = pos[4 * (size_t)k2]; z[2 * lm + 1] = pos[4 * (size_t)k2 + 1]; newk2[lm] = k2; }
         }
         base += __popcll(b);
-        m += __popcll(__ballot(acc));
+        // accepted matches arrive in increasing landmark order (pred is sorted): compact the measurement list for the host
+        const unsigned long long ab = __ballot(acc);
+        if (acc) {
+            const int pm = m + __popcll(ab & ((1ull << lane) - 1));
+            meas_out[pm] = pred[k1]; z_out[2 * pm] = pos[4 * (size_t)k2]; z_out[2 * pm + 1] = pos[4 * (size_t)k2 + 1];
+        }
+        m += __popcll(ab);
     }
     if (lane == 0) { counts[1] = base; counts[2] = m; }
 }
@@ -555,12 +566,16 @@ int launch_ic_search(pre3_ctx *c, double thresh, int strict)
     const int N = c->N;
     hipLaunchKernelGGL(k_ic_stack, dim3(1), dim3(64), 0, c->stream, N, c->lm.has_h, c->ic_pred, c->ic_counts, c->ic_newk2);
     if (c->scan_K2 > 0) {
-        hipLaunchKernelGGL((k_match_exact<double, double>), dim3(N), dim3(256), sizeof(double) * DESC_DIM, c->stream, DESC_DIM, c->scan_K2,
-                           (const double *)c->bank, (const double *)c->scan_desc, 0, c->ic_best, c->ic_second, c->ic_arg,
+        const int ntn = ceil_div(c->scan_K2, 64);
+        hipLaunchKernelGGL((k_match_exact_tiled<double>), dim3(ntn, ceil_div(N, 64)), dim3(256), 0, c->stream, DESC_DIM, N, c->scan_K2,
+                           (const double *)c->bank, (const double *)c->scan_desc, c->ic_pb, c->ic_ps, c->ic_pa, ntn,
                            (const int32_t *)c->ic_pred, (const int32_t *)c->ic_counts);
+        // rows >= the device-side query count hold stale partials; k_ic_gate only reads the first counts[0] results
+        hipLaunchKernelGGL((k_match_reduce_f<double>), dim3(ceil_div(N, 256)), dim3(256), 0, c->stream, N, ntn, (const double *)c->ic_pb,
+                           (const double *)c->ic_ps, (const int32_t *)c->ic_pa, 0, c->ic_best, c->ic_second, c->ic_arg);
         hipLaunchKernelGGL(k_ic_gate, dim3(1), dim3(64), 0, c->stream, c->ic_pred, c->ic_best, c->ic_second, c->ic_arg,
                            (float)thresh, strict, c->scan_pos, c->lm.h, c->lm.S, c->lm.has_S, c->lm.z, c->lm.ic, c->ic_pairs, c->ic_newk2,
-                           c->ic_counts);
+                           c->ic_counts, c->ic_counts + 4, (double *)(c->ic_counts + 4 + 4 * (size_t)c->capN));
         hipLaunchKernelGGL(k_ic_refresh, dim3(N), dim3(DESC_DIM), 0, c->stream, c->ic_newk2, c->scan_desc, c->bank);
     }
     PRE3_HIP(hipGetLastError());

@@ -20,7 +20,7 @@ for pnum in (150, 500, 2000):
     print("vo pnum=%d hyp=700: kernels %.1f us, call incl. transfers %.0f us, oracle (1 core) %.0f us, same winner %s" %
           (pnum, ms * 1e3, wall * 1e6, cpu * 1e6, out["best"] == ref["best"]), flush=True)
 
-for N, K2 in ((500, 600), (2000, 2500)):
+for N, K2 in ((500, 600),):
     rng, seq, bank = _scene(N, 23)
     s = seq["steps"][0]
     types, off, n = oracle.landmark_table(np.zeros(N, int))
