@@ -156,32 +156,38 @@ __global__ void k_map_fill(int n_new, const int32_t *__restrict__ desc, const do
 
 // T = A P : dst[a][j] = sum_t val[a][t] * P[col[a][t]][j]   (a < n_new; zero rows beyond)
 template <typename T>
-__global__ __launch_bounds__(256) void k_map_rows(int n_new, const int32_t *__restrict__ col, const T *__restrict__ val,
-                                                  const T *__restrict__ P, int ld, T *__restrict__ dst)
+__global__ __launch_bounds__(256) void k_map_rows(int n_new, const int32_t *__restrict__ desc, const int32_t *__restrict__ col,
+                                                  const T *__restrict__ val, const T *__restrict__ P, int ld, T *__restrict__ dst)
 {
     const int a = blockIdx.y;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ld) return;
     T s = (T)0;
     if (a < n_new) {
+        if (desc[3 * a] == 0) s = P[(size_t)col[a * MAPW] * ld + j];          // plain copy row (almost all of them): one load
+        else {
 #pragma unroll
-        for (int t = 0; t < MAPW; ++t) s += val[a * MAPW + t] * P[(size_t)col[a * MAPW + t] * ld + j];
+            for (int t = 0; t < MAPW; ++t) s += val[a * MAPW + t] * P[(size_t)col[a * MAPW + t] * ld + j];
+        }
     }
     dst[(size_t)a * ld + j] = s;
 }
 
 // P = T A' : dst[a][b] = sum_t val[b][t] * Tm[a][col[b][t]]   (a, b < n_new; zero elsewhere)
 template <typename T>
-__global__ __launch_bounds__(256) void k_map_cols(int n_new, const int32_t *__restrict__ col, const T *__restrict__ val,
-                                                  const T *__restrict__ Tm, int ld, T *__restrict__ dst)
+__global__ __launch_bounds__(256) void k_map_cols(int n_new, const int32_t *__restrict__ desc, const int32_t *__restrict__ col,
+                                                  const T *__restrict__ val, const T *__restrict__ Tm, int ld, T *__restrict__ dst)
 {
     const int a = blockIdx.y;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= ld) return;
     T s = (T)0;
     if (a < n_new && b < n_new) {
+        if (desc[3 * b] == 0) s = Tm[(size_t)a * ld + col[b * MAPW]];
+        else {
 #pragma unroll
-        for (int t = 0; t < MAPW; ++t) s += val[b * MAPW + t] * Tm[(size_t)a * ld + col[b * MAPW + t]];
+            for (int t = 0; t < MAPW; ++t) s += val[b * MAPW + t] * Tm[(size_t)a * ld + col[b * MAPW + t]];
+        }
     }
     dst[(size_t)a * ld + b] = s;
 }
@@ -224,11 +230,11 @@ static int apply_map(pre3_ctx *c, const std::vector<int32_t> &desc, int n_new, c
         hipLaunchKernelGGL(k_map_fill<float>, dim3(ceil_div(n_new, 256)), dim3(256), 0, c->stream, n_new, c->map_desc, c->x_kk, feat, feat, c->lm.off, c->map_col, (float *)c->map_val, c->x_alt));
     dim3 g(ceil_div(c->ld, 256), c->ld), b(256);
     DISPATCH_T(c,
-        hipLaunchKernelGGL(k_map_rows<double>, g, b, 0, c->stream, n_new, c->map_col, (const double *)c->map_val, (const double *)c->P, c->ld, (double *)c->P_alt),
-        hipLaunchKernelGGL(k_map_rows<float>, g, b, 0, c->stream, n_new, c->map_col, (const float *)c->map_val, (const float *)c->P, c->ld, (float *)c->P_alt));
+        hipLaunchKernelGGL(k_map_rows<double>, g, b, 0, c->stream, n_new, c->map_desc, c->map_col, (const double *)c->map_val, (const double *)c->P, c->ld, (double *)c->P_alt),
+        hipLaunchKernelGGL(k_map_rows<float>, g, b, 0, c->stream, n_new, c->map_desc, c->map_col, (const float *)c->map_val, (const float *)c->P, c->ld, (float *)c->P_alt));
     DISPATCH_T(c,
-        hipLaunchKernelGGL(k_map_cols<double>, g, b, 0, c->stream, n_new, c->map_col, (const double *)c->map_val, (const double *)c->P_alt, c->ld, (double *)c->P),
-        hipLaunchKernelGGL(k_map_cols<float>, g, b, 0, c->stream, n_new, c->map_col, (const float *)c->map_val, (const float *)c->P_alt, c->ld, (float *)c->P));
+        hipLaunchKernelGGL(k_map_cols<double>, g, b, 0, c->stream, n_new, c->map_desc, c->map_col, (const double *)c->map_val, (const double *)c->P_alt, c->ld, (double *)c->P),
+        hipLaunchKernelGGL(k_map_cols<float>, g, b, 0, c->stream, n_new, c->map_desc, c->map_col, (const float *)c->map_val, (const float *)c->P_alt, c->ld, (float *)c->P));
     if (n_feat > 0) {
         DISPATCH_T(c,
             hipLaunchKernelGGL(k_map_add_noise<double>, dim3(ceil_div(n_feat * 36, 256)), dim3(256), 0, c->stream, n_feat, first_new_off, feat, (double *)c->P, c->ld),
@@ -242,14 +248,15 @@ static int apply_map(pre3_ctx *c, const std::vector<int32_t> &desc, int n_new, c
     int n = 13;
     for (int i = 0; i < N; ++i) { off[i] = n; n += new_types[i] == PRE3_INVDEPTH ? 6 : 3; }
     PRE3_CHECK(n == n_new, PRE3_E_STATE, "map management: internal size mismatch (%d vs %d)", n, n_new);
-    PRE3_HIP(hipStreamSynchronize(c->stream));
+    // landmark table + cleared per-landmark fields, all on the stream; ONE synchronisation at the end (the host vectors are locals)
     if (N) {
-        PRE3_HIP(hipMemcpy(c->lm.type, new_types.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice));
-        PRE3_HIP(hipMemcpy(c->lm.off, off.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice));
+        PRE3_HIP(hipMemcpyAsync(c->lm.type, new_types.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice, c->stream));
+        PRE3_HIP(hipMemcpyAsync(c->lm.off, off.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice, c->stream));
     }
-    PRE3_HIP(hipMemset(c->lm.has_h, 0, sizeof(int32_t) * c->capN)); PRE3_HIP(hipMemset(c->lm.has_S, 0, sizeof(int32_t) * c->capN));
-    PRE3_HIP(hipMemset(c->inbox_dev, 0, c->inbox_bytes)); PRE3_HIP(hipMemset(c->lm.li, 0, sizeof(int32_t) * c->capN));
-    PRE3_HIP(hipMemset(c->lm.hi, 0, sizeof(int32_t) * c->capN));
+    PRE3_HIP(hipMemsetAsync(c->lm.has_h, 0, sizeof(int32_t) * c->capN, c->stream));
+    PRE3_HIP(hipMemsetAsync(c->lm.has_S, 0, sizeof(int32_t) * c->capN, c->stream));
+    PRE3_HIP(hipMemsetAsync(c->inbox_dev, 0, c->inbox_bytes, c->stream));          // meas / ic / z and the inlier flags
+    PRE3_HIP(hipStreamSynchronize(c->stream));
     PRE3_TRY(launch_bank_gather(c, N, lm_src.data()));
     c->N = N; c->n = n; c->lm_type_host = new_types;
     c->m = 0; c->meas_host.clear(); c->measurements_set = false; c->projected = false; c->innovated = false; c->hp_all_valid = false;
