@@ -1219,7 +1219,7 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
         dim3 g1(c->n_tiles + nx + pr.n_blocks);
         DISPATCH_T(c,
             hipLaunchKernelGGL((k_downdate_1t<double, 16>), g1, b, 0, c->stream, (double *)c->P, c->ld, (const double *)W, c->ldw, r_pad, (const int2 *)c->tiles_flat, c->num_cus, xu, pr),
-            hipLaunchKernelGGL((k_downdate_1t<float, 16>), g1, b, 0, c->stream, (float *)c->P, c->ld, (const float *)W, c->ldw, r_pad, (const int2 *)c->tiles_flat, c->num_cus, xu, pr));
+            hipLaunchKernelGGL((k_downdate_1t<float, 32>), g1, b, 0, c->stream, (float *)c->P, c->ld, (const float *)W, c->ldw, r_pad, (const int2 *)c->tiles_flat, c->num_cus, xu, pr));
     } else
     DISPATCH_T(c,
         hipLaunchKernelGGL((k_downdate<double, 32>), g, b, 0, c->stream, (double *)c->P, c->ld, (const double *)W, c->ldw, r_pad, (const int2 *)c->tiles, c->tiles_stride, c->tile_cnt, c->tile_ctr),
