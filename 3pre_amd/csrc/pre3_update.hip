@@ -406,6 +406,9 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
 #pragma unroll
     for (int mp = -2; mp < NMP; ++mp) {
         if (mp == 6) { PROBE_T(8, 64); PROBE_T(10, 0); }
+#ifdef PRE3_PROBE
+        if (mp >= 0 && mp < 16 && blockIdx.x == 5) { if (threadIdx.x == 64) g_k9[2 * mp] = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) g_k9[64 + 2 * mp] = __builtin_amdgcn_s_memtime(); }
+#endif
         if (worker) {
             if (mp >= 0) {
                 const int C = MB * mp, par = mp & 1;
@@ -529,6 +532,9 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
             }
         }
         if (mp == 6) { PROBE_T(9, 64); PROBE_T(11, 0); }
+#ifdef PRE3_PROBE
+        if (mp >= 0 && mp < 16 && blockIdx.x == 5) { if (threadIdx.x == 64) g_k9[2 * mp + 1] = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) g_k9[64 + 2 * mp + 1] = __builtin_amdgcn_s_memtime(); }
+#endif
         __syncthreads();
         if (mp == 6) { PROBE_T(12, 0); }
     }

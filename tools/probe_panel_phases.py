@@ -23,3 +23,7 @@ print("64-column chain         %6d ticks" % (a[2] - a[1]))
 print("store                   %6d ticks" % (a[3] - a[2]))
 print("total                   %6d ticks" % (a[3] - a[0]))
 print("iteration mp=6: worker wave  %6d ticks, factor wave %6d ticks, factor start->after barrier %6d ticks" % (a[9] - a[8], a[11] - a[10], a[12] - a[10]))
+buf2 = (C.c_ulonglong * (64 * 8 * 4))()
+lib.pre3_debug_k9_stamps(buf2)
+b = np.array(buf2[:128], dtype=np.int64)
+print("per micro-panel (worker wave 1 | factor wave) ticks:", " ".join("%d|%d" % (b[2 * m + 1] - b[2 * m], b[64 + 2 * m + 1] - b[64 + 2 * m]) for m in range(16)))
