@@ -141,8 +141,8 @@ def vo_leg(pre3, pnum=500, n_hyp=700, reps=50):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--landmarks", type=int, default=500)
     ap.add_argument("--hyp", type=int, default=200)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
