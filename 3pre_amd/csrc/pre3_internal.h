@@ -154,6 +154,10 @@ __device__ inline void d_normjac(const double *q, double *J)
     J[12] = s * (-z * r); J[13] = s * (-z * x); J[14] = s * (-z * y); J[15] = s * (r * r + x * x + y * y);
 }
 
+// ---- pooled device scratch of the stateless entry points (pre3_match.hip)
+int scratch_acquire(size_t bytes, void **p_out, int *slot_out);
+void scratch_release(int slot, void *p);
+
 // ---- IC search (pre3_match.hip)
 int launch_ic_search(pre3_ctx *c, double thresh, int strict);
 int launch_bank_gather(pre3_ctx *c, int N_new, const int32_t *src_host);

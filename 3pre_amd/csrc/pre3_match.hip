@@ -338,9 +338,9 @@ __global__ __launch_bounds__(256) void k_knn(int D, int N, int M, const double *
 // ------------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------------
-// Scratch for the stateless matcher / kNN entry points.  hipMalloc + hipFree cost ~0.2 ms a pair, eight pairs per call dwarf a
+// Scratch for the stateless matcher / kNN / VO entry points.  hipMalloc + hipFree cost ~0.2 ms a pair, eight pairs per call dwarf a
 // 45 us kernel, and the reference calls siftmatch once per frame: buffers are kept in a small per-device pool
-// (grow-only, at most 16 entries, shared by all threads under a mutex, released by pre3_release_scratch or at exit).
+// (grow-only, at most 32 entries, shared by all threads under a mutex, released by pre3_release_scratch or at exit).
 struct ScratchPool {
     struct Ent { void *p; size_t cap; int dev; bool used; };
     std::vector<Ent> ents;
@@ -350,38 +350,45 @@ struct ScratchPool {
 static ScratchPool g_scratch;
 static std::mutex g_scratch_mu;
 
+// pooled allocation (also used by pre3_vo.hip): *slot >= 0 -> return it with scratch_release(); *slot < 0 -> plain hipMalloc
+int scratch_acquire(size_t bytes, void **p_out, int *slot_out)
+{
+    if (bytes == 0) bytes = 16;
+    int dev = 0; (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    int best = -1, freeslot = -1;
+    for (int i = 0; i < (int)g_scratch.ents.size(); ++i) {
+        ScratchPool::Ent &e = g_scratch.ents[i];
+        if (e.used) continue;
+        if (!e.p) { freeslot = i; continue; }
+        if (e.dev == dev && e.cap >= bytes && (best < 0 || e.cap < g_scratch.ents[best].cap)) best = i;
+    }
+    if (best >= 0) { *slot_out = best; g_scratch.ents[best].used = true; *p_out = g_scratch.ents[best].p; return PRE3_OK; }
+    const size_t cap = bytes + bytes / 4;                         // a little headroom: frame-to-frame sizes vary
+    void *p = nullptr;
+    if (hipMalloc(&p, cap) != hipSuccess) { *p_out = nullptr; *slot_out = -1; set_error("hipMalloc of %zu bytes failed", cap); return PRE3_E_NOMEM; }
+    if (freeslot < 0 && g_scratch.ents.size() < 32) { g_scratch.ents.push_back({ nullptr, 0, 0, false }); freeslot = (int)g_scratch.ents.size() - 1; }
+    if (freeslot < 0) {                                              // pool full: recycle the smallest idle entry
+        for (int i = 0; i < (int)g_scratch.ents.size(); ++i)
+            if (!g_scratch.ents[i].used && (freeslot < 0 || g_scratch.ents[i].cap < g_scratch.ents[freeslot].cap)) freeslot = i;
+        if (freeslot >= 0 && g_scratch.ents[freeslot].p) (void)hipFree(g_scratch.ents[freeslot].p);
+    }
+    if (freeslot >= 0) g_scratch.ents[freeslot] = { p, cap, dev, true };
+    *p_out = p; *slot_out = freeslot;                                // (slot < 0: not pooled, the caller frees it)
+    return PRE3_OK;
+}
+
+void scratch_release(int slot, void *p)
+{
+    if (slot >= 0) { std::lock_guard<std::mutex> lk(g_scratch_mu); g_scratch.ents[slot].used = false; }
+    else if (p) (void)hipFree(p);
+}
+
 struct DevBuf {
     void *p = nullptr;
     int slot = -1;
-    ~DevBuf()
-    {
-        if (slot >= 0) { std::lock_guard<std::mutex> lk(g_scratch_mu); g_scratch.ents[slot].used = false; }
-        else if (p) (void)hipFree(p);
-    }
-    int alloc(size_t bytes)
-    {
-        if (bytes == 0) bytes = 16;
-        int dev = 0; (void)hipGetDevice(&dev);
-        std::lock_guard<std::mutex> lk(g_scratch_mu);
-        int best = -1, freeslot = -1;
-        for (int i = 0; i < (int)g_scratch.ents.size(); ++i) {
-            ScratchPool::Ent &e = g_scratch.ents[i];
-            if (e.used) continue;
-            if (!e.p) { freeslot = i; continue; }
-            if (e.dev == dev && e.cap >= bytes && (best < 0 || e.cap < g_scratch.ents[best].cap)) best = i;
-        }
-        if (best >= 0) { slot = best; g_scratch.ents[best].used = true; p = g_scratch.ents[best].p; return PRE3_OK; }
-        const size_t cap = bytes + bytes / 4;                     // a little headroom: frame-to-frame sizes vary
-        if (hipMalloc(&p, cap) != hipSuccess) { p = nullptr; set_error("hipMalloc of %zu bytes failed", cap); return PRE3_E_NOMEM; }
-        if (freeslot < 0 && g_scratch.ents.size() < 16) { g_scratch.ents.push_back({ nullptr, 0, 0, false }); freeslot = (int)g_scratch.ents.size() - 1; }
-        if (freeslot < 0) {                                          // pool full: recycle the smallest idle entry
-            for (int i = 0; i < (int)g_scratch.ents.size(); ++i)
-                if (!g_scratch.ents[i].used && (freeslot < 0 || g_scratch.ents[i].cap < g_scratch.ents[freeslot].cap)) freeslot = i;
-            if (freeslot >= 0 && g_scratch.ents[freeslot].p) (void)hipFree(g_scratch.ents[freeslot].p);
-        }
-        if (freeslot >= 0) { g_scratch.ents[freeslot] = { p, cap, dev, true }; slot = freeslot; }
-        return PRE3_OK;                                              // (slot < 0: plain allocation, freed by the destructor)
-    }
+    ~DevBuf() { scratch_release(slot, p); }
+    int alloc(size_t bytes) { return scratch_acquire(bytes, &p, &slot); }
 };
 
 void release_scratch() { std::lock_guard<std::mutex> lk(g_scratch_mu); g_scratch.release(); }

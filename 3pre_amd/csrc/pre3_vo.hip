@@ -274,10 +274,11 @@ __global__ void k_vo_final(int pnum, int n_hyp, const double *__restrict__ pset1
     }
 }
 
-struct DevMem {
+struct DevMem {                    // pooled device scratch (pre3_match.hip): no hipMalloc / hipFree per call once warm
     void *p = nullptr;
-    ~DevMem() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) { if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { p = nullptr; set_error("hipMalloc of %zu bytes failed", bytes); return PRE3_E_NOMEM; } return PRE3_OK; }
+    int slot = -1;
+    ~DevMem() { scratch_release(slot, p); }
+    int alloc(size_t bytes) { return scratch_acquire(bytes, &p, &slot); }
     template <typename T> T *as() { return (T *)p; }
 };
 
