@@ -49,8 +49,9 @@ __device__ inline void d_pinhole_distort(const double *hrl, const CamD &cam, dou
 __device__ inline void d_ray(int type, const double *y, const double *t, double *v)
 {
     if (type == PRE3_INVDEPTH) {
-        double cphi = cos(y[4]);
-        double mi0 = cphi * sin(y[3]), mi1 = -sin(y[4]), mi2 = cphi * cos(y[3]);   // m.m:38-40
+        double sth, cth, sphi, cphi;                       // one shared range reduction per angle instead of four separate calls
+        sincos(y[3], &sth, &cth); sincos(y[4], &sphi, &cphi);
+        double mi0 = cphi * sth, mi1 = -sphi, mi2 = cphi * cth;   // m.m:38-40
         v[0] = (y[0] - t[0]) * y[5] + mi0;
         v[1] = (y[1] - t[1]) * y[5] + mi1;
         v[2] = (y[2] - t[2]) * y[5] + mi2;
@@ -130,8 +131,10 @@ __device__ inline void project_one(const int i, const int32_t *__restrict__ lm_t
     for (int t = 0; t < 12; ++t) hl_out[t] = 0;
     if (type == PRE3_INVDEPTH) {
         double theta = y[3], phi = y[4], lambda = y[5];
-        double dth[3] = { cos(phi) * cos(theta), 0, -cos(phi) * sin(theta) };
-        double dph[3] = { -sin(phi) * sin(theta), -cos(phi), -sin(phi) * cos(theta) };
+        double sth, cth, sph, cph;
+        sincos(theta, &sth, &cth); sincos(phi, &sph, &cph);
+        double dth[3] = { cph * cth, 0, -cph * sth };
+        double dph[3] = { -sph * sth, -cph, -sph * cth };
         double d3[3] = { y[0] - x[0], y[1] - x[1], y[2] - x[2] };
         double B[18];
         for (int r = 0; r < 3; ++r) {
