@@ -575,7 +575,7 @@ static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp)
     }
     int r = 2 * c->m, r_pad = round_up(r, NB);
     PRE3_TRY(launch_ell_HP_build(c, c->HP));
-    PRE3_TRY(launch_ell_G(c, r, c->HP, c->G, r_pad, 0, nullptr));
+    PRE3_TRY(launch_ell_G(c, r, c->HP, c->G, r_pad, 0, nullptr, true));      // lower triangle: the scorer and the LI gather read (max, min)
     c->hp_all_valid = true;
     return PRE3_OK;
 }

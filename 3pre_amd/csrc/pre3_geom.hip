@@ -382,7 +382,10 @@ __global__ __launch_bounds__(512) void k_ransac_score(int hyp_begin, const int32
 #pragma unroll
         for (int a = 0; a < R; ++a) {
 #pragma unroll
-            for (int b = 0; b < R; ++b) A[a][b] = (double)G[(size_t)rows[a] * ldg + rows[b]] + (a == b ? 1.0 : 0.0);
+            for (int b = 0; b < R; ++b) {                      // G holds its lower triangle: entry (max, min)
+                const int ra = rows[a] > rows[b] ? rows[a] : rows[b], rb = rows[a] > rows[b] ? rows[b] : rows[a];
+                A[a][b] = (double)G[(size_t)ra * ldg + rb] + (a == b ? 1.0 : 0.0);
+            }
             A[a][R] = row_nu[rows[a]];
         }
         if (tid == 0) {

@@ -111,13 +111,15 @@ __global__ __launch_bounds__(256) void k_ell_HP_build(int m, int r_pad, const in
 template <typename T>
 __global__ __launch_bounds__(64) void k_ell_G(int r, int r_pad, const int32_t *__restrict__ row_col, const T *__restrict__ row_val,
                                               const T *__restrict__ HP, int ldw, T *__restrict__ dst, int ldg, int add_identity,
-                                              const T *__restrict__ Rd)
+                                              const T *__restrict__ Rd, int lower_only)
 {
     int a = blockIdx.y;
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= r_pad || a >= r_pad) return;
     T out;
-    if (a < r && b < r) {
+    if (lower_only && (int)(blockIdx.x * blockDim.x) > a) {
+        out = (T)0;                   // strictly above the diagonal: every reader takes (max, min) -- no gathers, defined contents
+    } else if (a < r && b < r) {
         T s = (T)0;
 #pragma unroll
         for (int t = 0; t < ELLW; ++t) s += row_val[b * ELLW + t] * HP[(size_t)a * ldw + row_col[b * ELLW + t]];
@@ -1139,15 +1141,15 @@ int launch_ell_HP_build(pre3_ctx *c, void *dst)
     return PRE3_OK;
 }
 
-int launch_ell_G(pre3_ctx *c, int r, const void *HPsrc, void *dst, int ldg, int add_identity, const void *Rdense)
+int launch_ell_G(pre3_ctx *c, int r, const void *HPsrc, void *dst, int ldg, int add_identity, const void *Rdense, bool lower_only)
 {
     int r_pad = round_up(r, NB);
     dim3 g(ceil_div(r_pad, 64), r_pad), b(64);
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_ell_G<double>, g, b, 0, c->stream, r, r_pad, c->row_col, (const double *)c->row_val, (const double *)HPsrc,
-                           c->ldw, (double *)dst, ldg, add_identity, (const double *)Rdense),
+                           c->ldw, (double *)dst, ldg, add_identity, (const double *)Rdense, lower_only ? 1 : 0),
         hipLaunchKernelGGL(k_ell_G<float>, g, b, 0, c->stream, r, r_pad, c->row_col, (const float *)c->row_val, (const float *)HPsrc,
-                           c->ldw, (float *)dst, ldg, add_identity, (const float *)Rdense));
+                           c->ldw, (float *)dst, ldg, add_identity, (const float *)Rdense, lower_only ? 1 : 0));
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }
@@ -1275,7 +1277,9 @@ __global__ __launch_bounds__(256) void k_gather_li(int nsel, const int32_t *__re
         const int b = (blockIdx.x - gxW) * 256 + threadIdx.x;
         if (b >= r_pad) return;
         T out = (a == b) ? (T)1 : (T)0;
-        if (a < r && b < r) out += G[(size_t)(2 * sel[a >> 1] + (a & 1)) * ldg + 2 * sel[b >> 1] + (b & 1)];
+        // G holds its lower triangle (64-column granularity); sel is ascending, so b <= a maps to a lower entry; the factorisation
+        // never reads S above the diagonal (kept at 0 / 1 there)
+        if (a < r && b < r && b <= a) out += G[(size_t)(2 * sel[a >> 1] + (a & 1)) * ldg + 2 * sel[b >> 1] + (b & 1)];
         S[(size_t)a * r_pad + b] = out;
     }
 }
