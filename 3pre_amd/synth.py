@@ -68,8 +68,17 @@ def make_map(N, seed=None):
     sl = np.array([0.02, 0.02, 0.02, 0.005, 0.005, 0.02])
     s[13:] = np.tile(sl, N)
     A = A * s[:, None] / np.sqrt(32.0)
-    P0 = A @ A.T + np.diag((0.1 * s) ** 2)
-    P0 = 0.5 * (P0 + P0.T)
+    P0 = A @ A.T                                   # in place from here on: at N=2000 every extra n x n temporary is 1.15 GB
+    P0[np.diag_indices(n)] += (0.1 * s) ** 2
+    iu = np.triu_indices(n, 1, m=n) if n <= 600 else None
+    if iu is not None:
+        P0[iu] = P0.T[iu]                          # exact symmetry (mirror the lower triangle)
+    else:
+        for i0 in range(0, n, 1024):               # blockwise mirror: no n x n index arrays
+            i1 = min(i0 + 1024, n)
+            P0[i0:i1, i1:] = P0[i1:, i0:i1].T
+            blk = P0[i0:i1, i0:i1]
+            blk[np.triu_indices(i1 - i0, 1)] = blk.T[np.triu_indices(i1 - i0, 1)]
     xi = rngP.standard_normal(32)
     x_true = x0 + 0.7 * (A @ xi) + 0.07 * s * rngP.standard_normal(n)
     x_true[7:13] = 0
