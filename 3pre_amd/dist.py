@@ -90,7 +90,8 @@ def siftmatch_sharded(L1, L2, thresh=1.5, partial=None, merge=None, return_score
     Defaults are the GPU kernels of this package."""
     if partial is None or merge is None:
         from . import matcher
-        partial = partial or matcher.siftmatch_partial
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else 0     # one process per GPU: the rank's own device
+        partial = partial or (lambda a, b, off: matcher.siftmatch_partial(a, b, off, device=dev))
         merge = merge or (lambda dt, B, S, A, th: matcher.siftmatch_merge(dt, B, S, A, th, return_scores=True))
     rank, world = _world()
     L1, L2 = np.asarray(L1), np.asarray(L2)

@@ -58,20 +58,65 @@ def cpu_baseline(seq, n_steps, threshold):
                       "fp64, all hypotheses evaluated)" % (done, N, seq["steps"][0]["hyp"].shape[0])}
 
 
+def all_ranks_ok(dist, ok):
+    """True iff `ok` on every rank (one tiny all-reduce): a leg whose set-up failed somewhere is skipped everywhere, so that no
+    rank waits in a collective the others never enter."""
+    if dist is None:
+        return ok
+    import torch
+    t = torch.tensor([1 if ok else 0], device="cuda", dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+def matcher_shard_leg(pre3, dist, rank, world, K=4096, reps=10):
+    """BASELINE.json configs[3] over the ranks: the database columns are sharded, every rank matches all 4096 queries against its
+    slice, one all-gather of (best, second, arg) and the order-independent merge (3pre_amd/dist.siftmatch_sharded).  Whole
+    stateless calls from host arrays (PCIe and the collective inside the timed region): descriptor pairs/s of the whole job."""
+    import torch
+    pd = importlib.import_module("3pre_amd.dist")
+    rng = np.random.default_rng(5000)                   # same data on every rank
+    L1 = np.minimum(np.round(np.abs(rng.standard_normal((K, 128))) * 40), 255).astype(np.uint8)
+    L2 = np.clip(L1[rng.permutation(K)].astype(int) + rng.integers(-2, 3, (K, 128)), 0, 255).astype(np.uint8)
+    L1c, L2c = np.asfortranarray(L1.T), np.asfortranarray(L2.T)      # 128 x K, column-major like the reference
+    for _ in range(2):
+        m = pd.siftmatch_sharded(L1c, L2c, 1.5)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m = pd.siftmatch_sharded(L1c, L2c, 1.5)
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return {"workload": "configs[3]: 4096x4096x128 uint8, database columns sharded over %d GPU(s), whole call from host arrays" % world,
+            "ms_per_match": 1e3 * el / reps, "pairs_per_s": reps * K * K / el, "matches": int(np.asarray(m).shape[1]), "n_gpus": world, "scaling": "strong"}
+
+
 def ransac_shard_leg(pre3, synth, dist, rank, world, local_rank, N=2000, n_hyp=1000, reps=10):
     """BASELINE.json configs[4]: N=2000 landmarks (n=12013), 1000 hypotheses sharded over the ranks with an RCCL
     all-reduce of supports + inlier masks (3pre_amd/dist.ransac_sharded); state replicated.  Whole-job
     hypotheses/s at this number of GPUs (the all-reduce and the replay are inside the timed region)."""
     import torch
     pd = importlib.import_module("3pre_amd.dist")
-    seq = synth.make_sequence(N, 1, n_hyp)              # same seed on every rank: identical replicas
-    s = seq["steps"][0]
-    f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", device=local_rank, max_hyp=n_hyp)
+    f, err = None, None
     try:
+        seq = synth.make_sequence(N, 1, n_hyp)          # same seed on every rank: identical replicas
+        s = seq["steps"][0]
+        f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", device=local_rank, max_hyp=n_hyp)
         f.set_x_p_k_k(seq["x0"], seq["P0"])
         f.ekf_prediction(s["u"])
         f.search_IC_matches()
         f.set_measurements(s["meas_idx"], s["z"])
+    except Exception as e:                              # pragma: no cover
+        err = e
+    if not all_ranks_ok(dist, err is None):             # nobody enters the collectives unless everybody can
+        if f is not None:
+            f.close()
+        raise RuntimeError("sharded-RANSAC leg skipped: set-up failed on a rank (%r)" % (err,))
+    try:
         for _ in range(2):
             out = pd.ransac_sharded(f, s["hyp"], 1.0, early_exit=False)
         f.sync()
@@ -236,7 +281,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(seq, args.cpu_steps, thr)
     f.close()
-    # secondary legs (never allowed to break the headline line): sharded RANSAC at every N, matcher at N=1
+    # secondary legs (never allowed to break the headline line): sharded RANSAC and sharded matcher at every N, kernel-only
+    # matcher and VO RANSAC at N=1
     if not args.no_extra_legs:
         try:
             leg = ransac_shard_leg(pre3, synth, dist, rank, world, local_rank)
@@ -245,6 +291,13 @@ def main():
         except Exception as e:                                  # pragma: no cover
             if rank == 0:
                 out["ransac_shard"] = {"error": repr(e)[:300]}
+        try:
+            leg = matcher_shard_leg(pre3, dist, rank, world)
+            if rank == 0:
+                out["matcher_shard"] = leg
+        except Exception as e:                                  # pragma: no cover
+            if rank == 0:
+                out["matcher_shard"] = {"error": repr(e)[:300]}
         if world == 1:
             try:
                 out["matcher"] = matcher_leg(pre3)
