@@ -204,6 +204,54 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
         A(dmalloc_bytes(&c->tiles, sizeof(int2) * flat.size()));
         if (rc == PRE3_OK && hipMemcpy(c->tiles, flat.data(), sizeof(int2) * flat.size(), hipMemcpyHostToDevice) != hipSuccess) { set_error("tile table upload failed"); rc = PRE3_E_HIP; }
     }
+    if (dtype == PRE3_F32) {
+        { const char *e = getenv("PRE3_K9_B3"); c->k9_b3 = e ? atoi(e) != 0 : true; }
+        // k_downdate_b3: bf16 planes of W and the 128x128 tile list (4x4 super-tiles dealt to 8 lists, lists interleaved: block b runs
+        // on XCD b % 8, so a super-tile's 8 column blocks of planes stay in one L2)
+        A(dmalloc_bytes(&c->Wp, (size_t)c->ld * c->rcap * 6));
+        const int nt = c->ld / 128, ns = ceil_div(nt, 4);
+        std::vector<std::vector<int2>> lists(8);
+        for (int SI = 0; SI < ns; ++SI)
+            for (int SJ = SI; SJ < ns; ++SJ) {
+                int best = 0;
+                for (int x = 1; x < 8; ++x) if (lists[x].size() < lists[best].size()) best = x;
+                for (int i = SI * 4; i < std::min(nt, SI * 4 + 4); ++i)
+                    for (int j = SJ * 4; j < std::min(nt, SJ * 4 + 4); ++j)
+                        if (j >= i) lists[best].push_back(make_int2(i, j));
+            }
+        for (;;) {
+            int lo = 0, hi = 0;
+            for (int x = 1; x < 8; ++x) { if (lists[x].size() < lists[lo].size()) lo = x; if (lists[x].size() > lists[hi].size()) hi = x; }
+            if (lists[hi].size() <= lists[lo].size() + 1) break;
+            lists[lo].push_back(lists[hi].back());
+            lists[hi].pop_back();
+        }
+        // whole rounds of large tiles; the left-over tiles (diagonal ones first: a quarter of each is below the diagonal) as 64x64
+        std::vector<int2> inter;
+        const int total = nt * (nt + 1) / 2;
+        size_t pos[8] = { 0 };
+        while ((int)inter.size() < total)
+            for (int x = 0; x < 8 && (int)inter.size() < total; ++x)
+                if (pos[x] < lists[x].size()) inter.push_back(lists[x][pos[x]++]);
+        const int n_big = total <= c->num_cus ? total : total / c->num_cus * c->num_cus;
+        int n_small_src = total - n_big;
+        std::vector<int2> big, small;
+        for (int pass = 0; pass < 2; ++pass)                         // pass 0: pick diagonal tiles for splitting, from the back of the order
+            for (int k2 = (int)inter.size() - 1; k2 >= 0 && n_small_src > 0; --k2) {
+                int2 &t = inter[k2];
+                if (t.x < 0 || (pass == 0 && t.x != t.y)) continue;
+                for (int a2 = 0; a2 < 2; ++a2)
+                    for (int b2 = 0; b2 < 2; ++b2)
+                        if (t.x != t.y || b2 >= a2) small.push_back(make_int2(2 * t.x + a2, 2 * t.y + b2));
+                t.x = -1; --n_small_src;
+            }
+        for (const int2 &t : inter) if (t.x >= 0) big.push_back(make_int2((2 * t.x) | (1 << 16), 2 * t.y));
+        inter = big;
+        inter.insert(inter.end(), small.begin(), small.end());
+        c->n_tiles128 = (int)inter.size();
+        A(dmalloc_bytes(&c->tiles128, sizeof(int2) * inter.size()));
+        if (rc == PRE3_OK && hipMemcpy(c->tiles128, inter.data(), sizeof(int2) * inter.size(), hipMemcpyHostToDevice) != hipSuccess) { set_error("tile table upload failed"); rc = PRE3_E_HIP; }
+    }
     if (rc == PRE3_OK && hipHostMalloc((void **)&c->pinned_stats, sizeof(int32_t) * 16) != hipSuccess) { set_error("hipHostMalloc failed"); rc = PRE3_E_NOMEM; }
     if (rc == PRE3_OK && hipHostMalloc((void **)&c->mail_host, sizeof(int32_t) * 16, hipHostMallocMapped) != hipSuccess) { set_error("hipHostMalloc failed"); rc = PRE3_E_NOMEM; }
     if (rc == PRE3_OK) {
@@ -227,7 +275,7 @@ int pre3_destroy(pre3_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
                      c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
-                     c->sel_rows, c->support, c->masks, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa };
+                     c->sel_rows, c->support, c->masks, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->tiles128 };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->pinned_stats) (void)hipHostFree(c->pinned_stats);
     if (c->inbox_host) (void)hipHostFree(c->inbox_host);

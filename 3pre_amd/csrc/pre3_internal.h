@@ -81,6 +81,10 @@ struct pre3_ctx {
     int *tile_cnt = nullptr; int tiles_stride = 0;  // per-list lengths [8] and list stride
     bool tile_ctr_clean = false;                  // the 8 counters are zero (k_update_x resets them ahead of K9)
     int num_cus = 256;
+    void *Wp = nullptr;                           // fp32 path: bf16 planes of W in stage-image order (k_split_w), ld x rcap x 6 B
+    bool k9_b3 = false;                           // fp32: K9 as three-way bf16 split on the bf16 matrix cores (PRE3_K9_B3=0 turns it off)
+    int split_rows = 0;                           // rows of W whose bf16 planes the factorisation launches have already produced
+    void *tiles128 = nullptr; int n_tiles128 = 0; // int2[n_tiles128]: 128x128 upper-triangle tiles of k_downdate_b3, XCD-interleaved
     unsigned int *chol_arrive = nullptr; unsigned int chol_target = 0;   // [0] panel arrivals, [1] scoring done, [2] rescue done, [3],[4] rider producers
     unsigned int ride_target[2] = { 0, 0 };
     bool defer_hi = false, hi_pending = false; int last_n_hi = 0;   // PRE3_OPT_DEFER_HI (pre3_set_option)

@@ -143,6 +143,38 @@ __global__ __launch_bounds__(64) void k_ell_G(int r, int r_pad, const int32_t *_
 //   k_chol_trail : M_bK -= M_bJ M_KJ'  for K > J                         (S lower tiles and all W strips)
 // W strip c holds M(i,a) = W[a][c*64+i] (transposed storage), so its loads/stores are coalesced in i.
 // ------------------------------------------------------------------------------------------------
+// three-way bf16 split of W into the stage image of k_downdate_b3 (layout: see "K9 on the bf16 matrix cores" below)
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+#ifndef B3_NBUF
+#define B3_NBUF 2
+#endif
+constexpr int B3_T = 128, B3_BK = 16, B3_GRAN = 3 * 4 * 64;        // granules (16 B) of one operand block of one stage
+// x[0..7] = eight consecutive k of one column -> this lane's granule of the three planes (dst: plane 0; planes are 256 granules apart)
+__device__ __forceinline__ void b3_split_store(const float (&x)[8], bf16x8_t *__restrict__ dst)
+{
+    bf16x8_t a, b, c;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 ha = (__bf16)x[j];
+        const float r1 = x[j] - (float)ha;          // exact
+        const __bf16 hb = (__bf16)r1;
+        const float r2 = r1 - (float)hb;            // exact
+        a[j] = ha; b[j] = hb; c[j] = (__bf16)r2;
+    }
+    dst[0] = a; dst[256] = b; dst[512] = c;
+}
+// one (128 columns x 16 k) block from W in global memory; 256 threads
+__device__ __forceinline__ void b3_split_block(const float *__restrict__ W, int ldw, bf16x8_t *__restrict__ Wp, int nst_total, int cb, int st, int tid)
+{
+    const int f = tid >> 6, l = tid & 63, r = l & 31, h = l >> 5;
+    const float *src = W + (size_t)(st * B3_BK + 8 * h) * ldw + cb * B3_T + f * 32 + r;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = src[(size_t)j * ldw];
+    b3_split_store(x, Wp + ((size_t)cb * nst_total + st) * B3_GRAN + f * 64 + l);
+}
+
 template <typename T> struct Mfma;
 template <> struct Mfma<float> {
     static constexpr int BLK = 32, KS = 2, NREG = 16;
@@ -223,7 +255,8 @@ struct ChSmem {
 // column of the trailing update, so that the launch of panel J does not have to wait for a separate trail kernel.
 template <typename T, bool PRO>
 __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb,
-                                                int32_t *__restrict__ status, const int b, unsigned int *__restrict__ arrive, unsigned int target)
+                                                int32_t *__restrict__ status, const int b, unsigned int *__restrict__ arrive, unsigned int target,
+                                                void *__restrict__ Wp = nullptr, int nst_total = 0, int ld = 0)
 {
     PROBE_STAMP(0);
     constexpr int MB = 4, NMP = NB / MB;
@@ -564,6 +597,21 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
             int a2 = idx >> 6, i = idx & 63;
             W[(size_t)(J * NB + a2) * ldw + c0 + i] = Xs[a2][i];
         }
+        if constexpr (sizeof(T) == 4) {
+            // last panel, k_downdate_b3 in use: this strip's share of the bf16 planes of the last row block straight from LDS (the
+            // earlier row blocks are split by riders of the following launches), so that no split launch stands between the
+            // factorisation and the down-date.  Strip = half a 128-column block: fragments 2*half, 2*half+1 of 4 stages.
+            if (Wp != nullptr && J == nrb - 1 && c0 < ld) {
+                bf16x8_t *base = static_cast<bf16x8_t *>(Wp) + ((size_t)(c0 >> 7) * nst_total + 4 * J) * B3_GRAN + ((c0 >> 6) & 1) * 128;
+                for (int idx = tid; idx < 512; idx += 320) {
+                    const int q = idx >> 7, fl = (idx >> 6) & 1, l = idx & 63, r = l & 31, h = l >> 5;
+                    float x[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = Xs[16 * q + 8 * h + j][fl * 32 + r];
+                    b3_split_store(x, base + (size_t)q * B3_GRAN + fl * 64 + l);
+                }
+            }
+        }
     }
     PROBE_STAMP(3);
 }
@@ -704,13 +752,23 @@ __global__ __launch_bounds__(256) void k_chol_trail(T *__restrict__ S, int lds, 
 // instead of 2, and the wide update runs in the shadow of the (latency-bound) panel.
 template <typename T>
 __global__ __launch_bounds__(320) void k_chol_step(T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb, int nW,
-                                                   int nP, int32_t *__restrict__ status, unsigned int *__restrict__ arrive, unsigned int target)
+                                                   int nP, int32_t *__restrict__ status, unsigned int *__restrict__ arrive, unsigned int target,
+                                                   int nPT, void *__restrict__ Wp, int nst_total, int ncb, int ld_split)
 {
     __shared__ ChSmem<T> sm;
     const int b = blockIdx.x;
+    if (b >= nPT) {
+        // riders (fp32, k_downdate_b3 in use): row block J-1 of W is final since the previous launch; its bf16 planes are produced here,
+        // in the shadow of the panel, so that only the last row block is left for the split launch in front of the down-date
+        if constexpr (sizeof(T) == 4) {
+            const int idx = b - nPT;
+            if (threadIdx.x < 256) b3_split_block(W, ldw, static_cast<bf16x8_t *>(Wp), nst_total, idx % ncb, 4 * (J - 1) + idx / ncb, threadIdx.x);
+        }
+        return;
+    }
     if (b < nP) {
-        if (J == 0) chol_panel_body<T, false>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target);
-        else chol_panel_body<T, true>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target);
+        if (J == 0) chol_panel_body<T, false>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target, Wp, nst_total, ld_split);
+        else chol_panel_body<T, true>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target, Wp, nst_total, ld_split);
     } else {
         chol_trail_body<T>(sm.As, sm.Bs, S, lds, W, ldw, J - 1, J + 1, nrb, nW, b - nP);
     }
@@ -1098,6 +1156,196 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     RT_STAMP(3);
 }
 
+// ------------------------------------------------------------------------------------------------
+// K9 on the bf16 matrix cores (fp32 covariance path).  gfx950's f32-input MFMA runs at the vector rate, 1/16 of the
+// bf16 MFMA; an fp32 value is the exact sum of three bf16 values (8 + 8 + 8 significand bits, round-to-nearest at each
+// step), so W = a + b + c and  W'W = a'a + (a'b + b'a) + (a'c + c'a + b'b) + O(2^-27 |W|'|W|): six bf16 products with f32
+// accumulation instead of one f32 product, 16/6 = 2.7x the f32 matrix rate at f32 accuracy (the dropped b'c, c'b, c'c
+// terms are below the rounding of the f32 accumulation itself).
+//   k_split_w      W (f32, k-major) -> three bf16 planes, stored in the order the tile kernel's LDS stage image has:
+//                  block (cb, s) = 128 columns x 16 k = [plane 3][fragment 4][lane 64][8 bf16] (12 KB, contiguous), where
+//                  lane (r = l & 31, h = l >> 5) of fragment f holds k = 16 s + 8 h + 0..7 of column 128 cb + 32 f + r:
+//                  exactly the A / B operand of v_mfma_f32_32x32x16_bf16, so the tile kernel's staging is a linear
+//                  LDS-DMA copy and its fragment reads are conflict-free ds_read_b128.
+//   k_downdate_b3  one 128x128 tile of the upper triangle per workgroup (4 waves x 64x64), three-deep LDS-DMA ring of
+//                  24 KB stages, 24 MFMAs per wave and stage; mirrored epilogue through wave-private LDS patches.
+//                  Bytes per tile-stage: 24 KB for 128x128x16x6 MACs -- 64x64 tiles would need 4x the L2 bandwidth.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_split_w(const float *__restrict__ W, int ldw, bf16x8_t *__restrict__ Wp, int nst_total, int st0)
+{
+    b3_split_block(W, ldw, Wp, nst_total, blockIdx.x, st0 + blockIdx.y, threadIdx.x);
+}
+
+// One operand of one stage into the ring.  TM = 128: the whole 768-granule block, copied linearly (3 instructions per wave).
+// TM = 64: fragments 2*half, 2*half+1 of every plane (3 x 128 granules -> image [plane][fragment 2][lane]): one instruction in every
+// wave + a second one in waves 0 and 1.
+template <int TM>
+__device__ __forceinline__ void b3_dma(const bf16x8_t *__restrict__ src, int half, bf16x8_t *dst, int tid, int wave)
+{
+    if (TM == 128) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+            __builtin_amdgcn_global_load_lds(src + l * 256 + tid, (__attribute__((address_space(3))) void *)(dst + l * 256 + wave * 64), 16, 0, 0);
+    } else {
+        __builtin_amdgcn_global_load_lds(src + (tid >> 7) * 256 + half * 128 + (tid & 127), (__attribute__((address_space(3))) void *)(dst + wave * 64), 16, 0, 0);
+        if (wave < 2)
+            __builtin_amdgcn_global_load_lds(src + 512 + half * 128 + tid, (__attribute__((address_space(3))) void *)(dst + 256 + wave * 64), 16, 0, 0);
+    }
+}
+
+// wait until at most the DMA instructions of LEFT stages (this wave's share) are outstanding
+template <int N> __device__ __forceinline__ void vmwait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int TM, int LEFT>
+__device__ __forceinline__ void b3_wait(int wave)
+{
+    if (TM == 128) vmwait<6 * LEFT>();
+    else if (wave < 2) vmwait<4 * LEFT>();
+    else vmwait<2 * LEFT>();
+}
+
+// TM x TM tile at 64-column block (bi, bj): 4 waves x (TM/2 x TM/2), i.e. NB x NB accumulators of 32x32 per wave
+template <int TM>
+__device__ __forceinline__ void b3_tile(float *__restrict__ P, int ld, const bf16x8_t *__restrict__ Wp, int nst_total, int nst, int bi, int bj,
+                                        bf16x8_t *smem /* ring: [3][2][768 granules] */)
+{
+    constexpr int NB = TM / 64, PL = (TM / 32) * 64;       // blocks per wave and dimension; granules per plane of an operand stage
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int R0 = bi * 64 + wi * (TM / 2), C0 = bj * 64 + wj * (TM / 2);
+    const bool diag = bi == bj;
+    const bf16x8_t *srcA = Wp + (size_t)(bi >> 1) * nst_total * B3_GRAN;
+    const bf16x8_t *srcB = Wp + (size_t)(bj >> 1) * nst_total * B3_GRAN;
+    const int hA = bi & 1, hB = bj & 1;
+#ifdef B3_EXP_SAMESRC
+    srcA = Wp; srcB = Wp;
+#endif
+    const int lrow = 4 * (lane >> 5), lcol = lane & 31;                 // 32x32 accumulator: row = (e & 3) + 8 (e >> 2) + lrow, col = lcol
+    constexpr int D = B3_NBUF - 1;                                      // stages in flight ahead of the one being consumed
+    auto ring = [&](int slot, int operand) { return smem + (slot * 2 + operand) * B3_GRAN; };
+    // the P tile first (consumed in the epilogue), then the first two stages of the ring
+    float pv[NB][NB][16];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                pv[i][j][e] = P[(size_t)(R0 + i * 32 + (e & 3) + 8 * (e >> 2) + lrow) * ld + C0 + j * 32 + lcol];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < nst) {
+            b3_dma<TM>(srcA + (size_t)d * B3_GRAN, hA, ring(d, 0), tid, wave);
+            b3_dma<TM>(srcB + (size_t)d * B3_GRAN, hB, ring(d, 1), tid, wave);
+        }
+    if (nst >= D) b3_wait<TM, D - 1>(wave); else vmwait<0>();
+    __syncthreads();
+    f32x16_t acc[NB][NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int buf = 0;
+    for (int s = 0; s < nst; ++s) {
+        const bf16x8_t *sA = ring(buf, 0) + (NB * wi) * 64 + lane, *sB = ring(buf, 1) + (NB * wj) * 64 + lane;
+        bf16x8_t A[3][NB], B[3][NB];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < NB; ++i) { A[p][i] = sA[p * PL + i * 64]; B[p][i] = sB[p * PL + i * 64]; }
+        if (s + D < nst) {                       // its slot was read in stage s-1: every wave is past that barrier
+            const int nb = buf == 0 ? B3_NBUF - 1 : buf - 1;
+            b3_dma<TM>(srcA + (size_t)(s + D) * B3_GRAN, hA, ring(nb, 0), tid, wave);
+            b3_dma<TM>(srcB + (size_t)(s + D) * B3_GRAN, hB, ring(nb, 1), tid, wave);
+        }
+#ifdef B3_EXP_NOMFMA
+        if (nst > 100000)
+#endif
+        {
+        // largest terms first: they need only the first plane's fragments, the reads of the other planes land meanwhile
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][i], B[0][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][i], B[1][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][i], B[0][j], acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][i], B[1][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][i], B[2][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2][i], B[0][j], acc[i][j], 0, 0, 0);
+            }
+        }
+#ifdef B3_EXP_NOMFMA
+        acc[0][0][0] += (float)A[0][0][0] + (float)B[2][NB - 1][1];
+#endif
+        if (s + D < nst) b3_wait<TM, D - 1>(wave);     // stage s+1 has landed (this wave's granules)
+        else vmwait<0>();
+        __syncthreads();
+        buf = buf == B3_NBUF - 1 ? 0 : buf + 1;
+    }
+    // epilogue: new = P - acc to (row, col) and, through a wave-private patch, to (col, row).  On a diagonal tile only the upper
+    // triangle is written directly and its mirror image copied, so P stays exactly symmetric whatever the order of the six products.
+    float (*patch)[33] = reinterpret_cast<float (*)[33]>(reinterpret_cast<float *>(smem) + wave * (32 * 33));
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int gi = NB * wi + i, gj = NB * wj + j;
+            if (diag && gi > gj) continue;                               // below the diagonal: the mirror of another block
+            const bool dblk = diag && gi == gj;
+            const int r0 = R0 + i * 32, c0 = C0 + j * 32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int lr = (e & 3) + 8 * (e >> 2) + lrow;
+                const float v = pv[i][j][e] - acc[i][j][e];
+                if (!dblk || lr <= lcol) P[(size_t)(r0 + lr) * ld + c0 + lcol] = v;
+                patch[lr][lcol] = v;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            const int rr = lane & 31, half = lane >> 5;
+#pragma unroll
+            for (int cc = 0; cc < 32; cc += 2) {
+                const int c = cc + half;
+                if (!dblk || rr < c) P[(size_t)(c0 + c) * ld + r0 + rr] = patch[rr][c];
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+}
+
+// tiles[b] = (bi | big << 16, bj) in 64-column block units: the launch holds whole rounds of 128x128 tiles (one per CU and round)
+// and covers what is left over with 64x64 tiles, so that no CU ends up with a second large tile while the others idle.
+__global__ __launch_bounds__(256) void k_downdate_b3(float *__restrict__ P, int ld, const bf16x8_t *__restrict__ Wp, int nst_total, int nst,
+                                                      const float *__restrict__ W, int ldw, const int2 *__restrict__ tiles, XUpd xu, ProjRide pr)
+{
+    __shared__ __attribute__((aligned(16))) bf16x8_t smem[B3_NBUF * 2 * B3_GRAN];       // 24 KB per ring slot: [slot][A | B][plane][fragment][lane]
+    static_assert(sizeof(smem) >= 4 * 32 * 33 * sizeof(float) && sizeof(smem) >= sizeof(double) * (4 * 64 + 4), "patches and riders borrow the ring");
+    if ((int)blockIdx.x >= xu.n_tiles) {            // riders, as in k_downdate_1t
+        __builtin_amdgcn_s_setprio(3);
+        const int nx = (xu.n + 63) / 64, rb = blockIdx.x - xu.n_tiles;
+        if (rb < nx) {
+            update_x_block<float>(rb, xu.n, xu.r, W, ldw, ld, xu.x_prior, xu.x_out, xu.params, reinterpret_cast<double *>(smem));
+            if (pr.n_blocks) ride_signal(pr.ctr);
+        } else {
+            proj_ride_block(pr, rb - nx);
+        }
+        return;
+    }
+    const int2 t = tiles[blockIdx.x];
+    if (t.x >> 16) b3_tile<128>(P, ld, Wp, nst_total, nst, t.x & 0xffff, t.y, smem);
+    else b3_tile<64>(P, ld, Wp, nst_total, nst, t.x, t.y, smem);
+}
+
 // synthetic W for the roofline probe
 template <typename T>
 __global__ void k_fill_w(T *W, size_t count, float scale)
@@ -1158,17 +1406,23 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad)
 {
     int nrb = r_pad / NB, nW = c->ldw / NB;
     static const int form = [] { const char *e = getenv("PRE3_CHOL_FORM"); return e ? atoi(e) : 1; }();   // 1: lookahead (default), 0: panel + trail launches
+    c->split_rows = 0;
     if (form == 1) {
+        const bool split = c->k9_b3 && c->dtype == PRE3_F32 && c->Wp != nullptr;
         for (int J = 0; J < nrb; ++J) {
             const int nS = nrb - J - 1, nP = 1 + nS + nW;
             const int nK = J >= 1 ? nrb - J - 1 : 0;                        // column blocks >= J+1 of panel J-1's update
             const int nT = nK * (nK + 1) / 2 + nK * nW;
-            dim3 g(nP + nT), bP(320);
+            const int ncb = (split && J >= 1) ? c->ld / B3_T : 0;           // split riders: 4 stages x ncb column blocks of row block J-1
+            dim3 g(nP + nT + 4 * ncb), bP(320);
             c->chol_target += (unsigned)(nP - 1);                           // every non-diagonal workgroup of the panel arrives once
             DISPATCH_T(c,
-                hipLaunchKernelGGL(k_chol_step<double>, g, bP, 0, c->stream, (double *)c->Smat, r_pad, (double *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target),
-                hipLaunchKernelGGL(k_chol_step<float>, g, bP, 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target));
+                hipLaunchKernelGGL(k_chol_step<double>, g, bP, 0, c->stream, (double *)c->Smat, r_pad, (double *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
+                                   nP + nT, nullptr, 0, 0, 0),
+                hipLaunchKernelGGL(k_chol_step<float>, g, bP, 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
+                                   nP + nT, split ? c->Wp : nullptr, c->rcap / B3_BK, ncb, c->ld));
         }
+        if (split) c->split_rows = nrb * NB;
         PRE3_HIP(hipGetLastError());
         return PRE3_OK;
     }
@@ -1201,8 +1455,10 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
     static const int force = getenv("PRE3_K9_FORM") ? atoi(getenv("PRE3_K9_FORM")) : 0;     // 1: one-tile, 2: persistent (experiments)
     // all tiles resident at once: 5 workgroups/CU in fp32 (16.9 KB of LDS each), 4 in fp64 (33.8 KB)
     const bool one_tile = force == 1 || (force == 0 && c->n_tiles <= (c->dtype == PRE3_F32 ? 5 : 4) * c->num_cus);
-    if (!one_tile && which_prior >= 0) PRE3_TRY(launch_update_x(c, which_prior, r));          // (also resets the ticket counters)
-    if (!one_tile) {                                    // ticket counters of the persistent form
+    // fp32: three-way bf16 split on the bf16 matrix cores (k_split_w + k_downdate_b3); PRE3_K9_B3=0 keeps the f32-MFMA forms
+    const bool use_b3 = c->k9_b3 && c->dtype == PRE3_F32 && c->Wp != nullptr;
+    if (!use_b3 && !one_tile && which_prior >= 0) PRE3_TRY(launch_update_x(c, which_prior, r));          // (also resets the ticket counters)
+    if (!use_b3 && !one_tile) {                                    // ticket counters of the persistent form
         if (!c->tile_ctr_clean) PRE3_HIP(hipMemsetAsync(c->tile_ctr, 0, sizeof(unsigned int) * 8, c->stream));
         c->tile_ctr_clean = false;
     }
@@ -1216,7 +1472,25 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
         c->kt.used += 2;
         PRE3_HIP(hipEventRecord(e0, c->stream));
     }
-    if (one_tile) {
+    if (use_b3) {
+        const int nst = r_pad / B3_BK, nst_total = c->rcap / B3_BK;
+        const int st0 = c->split_rows / B3_BK;                         // row blocks the factorisation's riders have already split
+        c->split_rows = 0;
+        if (st0 < nst) {
+            dim3 gs(c->ld / B3_T, nst - st0);
+            hipLaunchKernelGGL(k_split_w, gs, b, 0, c->stream, (const float *)W, c->ldw, (bf16x8_t *)c->Wp, nst_total, st0);
+        }
+        XUpd xu{ c->n_tiles128, c->n, r, which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1, c->x_kk, c->pred_params };
+        const int nx = which_prior >= 0 ? ceil_div(c->n, 64) : 0;
+        ProjRide pr{};
+        if (nx > 0 && c->ride_rescue_projection && c->N > 0) {
+            pr = make_proj_ride(c, PRE3_X_K_K, 0, 1, nx);
+            c->ride_rescue_projection = false; c->rescue_projected = true;
+        }
+        dim3 g1(c->n_tiles128 + nx + pr.n_blocks);
+        hipLaunchKernelGGL(k_downdate_b3, g1, b, 0, c->stream, (float *)c->P, c->ld, (const bf16x8_t *)c->Wp, nst_total, nst, (const float *)W, c->ldw,
+                           (const int2 *)c->tiles128, xu, pr);
+    } else if (one_tile) {
         XUpd xu{ c->n_tiles, c->n, r, which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1, c->x_kk, c->pred_params };
         const int nx = which_prior >= 0 ? ceil_div(c->n, 64) : 0;
         ProjRide pr{};
