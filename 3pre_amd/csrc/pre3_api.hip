@@ -294,7 +294,18 @@ int pre3_set_option(pre3_ctx *c, int option, int value)
     PRE3_TRY(check_ctx(c));
     switch (option) {
     case PRE3_OPT_DEFER_HI: c->defer_hi = value != 0; return PRE3_OK;
+    case PRE3_OPT_K9_BF16X3: c->k9_b3 = value != 0 && c->dtype == PRE3_F32 && c->Wp != nullptr; return PRE3_OK;
     default: set_error("pre3_set_option: unknown option %d", option); return PRE3_E_ARG;
+    }
+}
+
+int pre3_get_option(pre3_ctx *c, int option, int *value_out)
+{
+    PRE3_CHECK(c != nullptr && value_out != nullptr, PRE3_E_ARG, "pre3_get_option: null argument");
+    switch (option) {
+    case PRE3_OPT_DEFER_HI: *value_out = c->defer_hi ? 1 : 0; return PRE3_OK;
+    case PRE3_OPT_K9_BF16X3: *value_out = c->k9_b3 ? 1 : 0; return PRE3_OK;
+    default: set_error("pre3_get_option: unknown option %d", option); return PRE3_E_ARG;
     }
 }
 

@@ -1183,8 +1183,13 @@ template <int TM>
 __device__ __forceinline__ void b3_dma(const bf16x8_t *__restrict__ src, int half, bf16x8_t *dst, int tid, int wave)
 {
     if (TM == 128) {
+#ifdef B3_EXP_TWOPLANES
+#define B3_NPL 2
+#else
+#define B3_NPL 3
+#endif
 #pragma unroll
-        for (int l = 0; l < 3; ++l)
+        for (int l = 0; l < B3_NPL; ++l)
             __builtin_amdgcn_global_load_lds(src + l * 256 + tid, (__attribute__((address_space(3))) void *)(dst + l * 256 + wave * 64), 16, 0, 0);
     } else {
         __builtin_amdgcn_global_load_lds(src + (tid >> 7) * 256 + half * 128 + (tid & 127), (__attribute__((address_space(3))) void *)(dst + wave * 64), 16, 0, 0);
@@ -1198,7 +1203,7 @@ template <int N> __device__ __forceinline__ void vmwait() { asm volatile("s_wait
 template <int TM, int LEFT>
 __device__ __forceinline__ void b3_wait(int wave)
 {
-    if (TM == 128) vmwait<6 * LEFT>();
+    if (TM == 128) vmwait<2 * B3_NPL * LEFT>();
     else if (wave < 2) vmwait<4 * LEFT>();
     else vmwait<2 * LEFT>();
 }

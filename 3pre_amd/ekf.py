@@ -94,6 +94,15 @@ class EkfFilter:
         step()'s n_hi then belongs to the previous step."""
         check(lib.pre3_set_option(self._ctx, 1, int(bool(on))))
 
+    def k9_bf16x3(self, on=None):
+        """PRE3_OPT_K9_BF16X3 (fp32 contexts): P <- P - W'W as a three-way bf16 split on the bf16 matrix cores (default) or, off,
+        on the f32 MFMA.  Returns the setting in force."""
+        if on is not None:
+            check(lib.pre3_set_option(self._ctx, 2, int(bool(on))))
+        v = C.c_int(0)
+        check(lib.pre3_get_option(self._ctx, 2, C.byref(v)))
+        return bool(v.value)
+
     # ---- map management between steps (map_management.m:27-79); the policy stays with the caller
     def _refresh_map(self):
         self.N = int(lib.pre3_get_map(self._ctx, None))

@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK = {"f32": 157.3, "f64": 78.6}       # dense MFMA TFLOP/s, MI355X_MICROARCH.md "Chip-level parameters" / "Matrix cores"
+PEAK = {"f32": 157.3, "f64": 78.6, "bf16": 2500.0}       # dense MFMA TFLOP/s, MI355X_MICROARCH.md "Chip-level parameters" / "Matrix cores"
 
 
 def cpu_baseline(seq, n_steps, threshold):
@@ -193,6 +193,7 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--kt-every", type=int, default=4, help="bracket one K9 launch in N with HIP events (an event pair costs ~11 us of stream time); 1 = every launch")
     ap.add_argument("--sync-hi", action="store_true", help="complete every step's HI update inside the step call (default: deferred to the next call)")
+    ap.add_argument("--k9-f32", action="store_true", help="fp32 path: K9 on the f32 MFMA instead of the three-way bf16 split (PRE3_OPT_K9_BF16X3 = 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the sharded-RANSAC and matcher legs")
@@ -218,6 +219,7 @@ def main():
     thr = 1.0
     seq = synth.make_sequence(N, K + W, args.hyp, seed=None if rank == 0 else 10_000 * rank + N)
     f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype=args.dtype, device=local_rank, max_hyp=args.hyp, std_z=thr)
+    b3 = f.k9_bf16x3(False if args.k9_f32 else None) if args.dtype == "f32" else False
     f.set_x_p_k_k(seq["x0"], seq["P0"])
     stats = []
     for s in seq["steps"][:W]:
@@ -259,6 +261,26 @@ def main():
             traffic_src = "profiles/r1_pmc_k9.json (raw FETCH_SIZE+WRITE_SIZE of the r=640 launches; FETCH_SIZE under-reports 16 B/lane reads by up to 2x on gfx950)"
         except Exception:
             pass
+        algo = ("symmetric rank-r down-date (SYRK): n(n+1)r flop per launch, r = rows of that update, averaged over the K9 launches of "
+                "the timed region that were bracketed with HIP events (one in --kt-every; LI updates with r~640 and HI updates with "
+                "r<=64 alike); SURVEY 8(d)'s un-halved convention 2n^2r gives twice this figure")
+        common = {"unit": "TFLOP/s", "traffic": traffic, "traffic_source": traffic_src, "launches": kt["launches"],
+                  "avg_launch_us": 1e3 * kt["total_ms"] / max(kt["launches"], 1), "algorithmic": algo,
+                  "survey_2n2r_equivalent": 2.0 * achieved * n / (n + 1.0)}
+        if b3:
+            # the launch executes six bf16 products per f32 product (three-way split of W): priced against the
+            # bf16 dense peak on the flops it executes; the f32-equivalent rate is reported next to it
+            roofline = dict(kernel="k_downdate_b3 (K9: P <- P - W'W; W split exactly into three bf16 planes, six bf16 MFMA products with "
+                                   "f32 accumulation per f32 product; 128x128 + 64x64 tiles; the x-update and rescue-projection riders "
+                                   "share the launch)",
+                            bound="mfma", dtype="bf16 operands (3-way split of f32), f32 accumulate", achieved=6.0 * achieved, peak=PEAK["bf16"],
+                            frac=6.0 * achieved / PEAK["bf16"],
+                            f32_equivalent={"achieved": achieved, "f32_mfma_peak": PEAK["f32"], "ratio": achieved / PEAK["f32"],
+                                            "note": "the same launches priced as the f32 SYRK they replace: n(n+1)r flop / time"}, **common)
+        else:
+            roofline = dict(kernel="k_downdate_1t / k_downdate (K9: P <- P - W'W on the %s MFMA; the x-update and rescue-projection riders "
+                                   "share the one-tile launch)" % args.dtype,
+                            bound="mfma", dtype=args.dtype, achieved=achieved, peak=PEAK[args.dtype], frac=achieved / PEAK[args.dtype], **common)
         out = {
             "metric": "EKF steps/sec (predict+RANSAC+update) at N=500 landmarks; P-update %MFMA peak",
             "value": world * K / elapsed, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -269,14 +291,7 @@ def main():
                        "measured_per_step": int(np.mean([len(s["meas_idx"]) for s in seq["steps"][W:W + K]])),
                        "mean_li_rows": 2 * n_li, "mean_hi_rows": 2 * n_hi, "parallelism": "replicas x%d" % world,
                        "hip_event_ms_per_step": ev_ms / K},
-            "roofline": {"kernel": "k_downdate_1t (K9: P <- P - W'W, one 64x64 tile per workgroup; the x-update and rescue-projection riders share the launch)", "bound": "mfma", "achieved": achieved, "peak": PEAK[args.dtype],
-                         "unit": "TFLOP/s", "frac": achieved / PEAK[args.dtype], "traffic": traffic, "traffic_source": traffic_src,
-                         "launches": kt["launches"], "avg_launch_us": 1e3 * kt["total_ms"] / max(kt["launches"], 1),
-                         "algorithmic": "symmetric rank-r down-date (SYRK): n(n+1)r flop per launch, r = rows of that update, averaged over "
-                                        "the K9 launches of the timed region that were bracketed with HIP events (one in --kt-every; LI updates "
-                                        "with r~640 and HI updates with r<=64 alike); "
-                                        "SURVEY 8(d)'s un-halved convention 2n^2r gives twice this figure",
-                         "survey_2n2r_equivalent": 2.0 * achieved * n / (n + 1.0)},
+            "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(seq, args.cpu_steps, thr)

@@ -164,7 +164,13 @@ PRE3_API int pre3_update_ell(int device, int dtype, int n, int r, const double *
  * caller's own time between two steps overlaps the device's rescue stage.  Results are identical; stats[5] of pre3_step then
  * reports the previous step's HI count and stats[7] = 1 says so.  Default 0: pre3_step completes the HI update itself. */
 #define PRE3_OPT_DEFER_HI 1
+/* PRE3_OPT_K9_BF16X3 (fp32 contexts; default 1, or the environment's PRE3_K9_B3): the covariance down-date of update.m:38-46,
+ * P <- P - W'W, multiplies on the bf16 matrix cores: every f32 entry of W is split exactly into three bf16 values and six of
+ * the nine partial products are accumulated in f32 (the dropped ones are below f32 rounding), 16/6 of the f32 matrix rate at
+ * f32 accuracy.  0: plain f32 MFMA (bitwise an fmaf chain).  No effect on fp64 contexts. */
+#define PRE3_OPT_K9_BF16X3 2
 PRE3_API int pre3_set_option(pre3_ctx *ctx, int option, int value);
+PRE3_API int pre3_get_option(pre3_ctx *ctx, int option, int *value_out);
 
 /* ---- map management on the device (map_management.m:27-79) ----------------------------- */
 /* These act on (x_k_k, p_k_k) between steps, as map_management.m:140 does, and keep P resident: P <- A P A' (+D) with
