@@ -146,8 +146,11 @@ __global__ __launch_bounds__(64) void k_ell_G(int r, int r_pad, const int32_t *_
 // three-way bf16 split of W into the stage image of k_downdate_b3 (layout: see "K9 on the bf16 matrix cores" below)
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
+#ifndef B3_PIPE
+#define B3_PIPE 1
+#endif
 #ifndef B3_NBUF
-#define B3_NBUF 2
+#define B3_NBUF (B3_PIPE ? 3 : 2)
 #endif
 constexpr int B3_T = 128, B3_BK = 16, B3_GRAN = 3 * 4 * 64;        // granules (16 B) of one operand block of one stage
 // x[0..7] = eight consecutive k of one column -> this lane's granule of the three planes (dst: plane 0; planes are 256 granules apart)
@@ -207,6 +210,7 @@ __device__ inline double fast_rsqrt(double x)
 __device__ unsigned long long g_probe[16];
 __device__ unsigned long long g_k9[64 * 8 * 4];
 __device__ unsigned long long g_k9rt[2048 * 4];     // s_memrealtime (100 MHz, chip-wide) per workgroup of the one-tile kernel
+__device__ unsigned int g_k9hw[2048];               // HW_ID of wave 0 (CU / SE / XCC placement)
 #define PROBE_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 5) g_probe[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #define PROBE_ACC(k, t0) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_probe[k] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
 #define PROBE_T(k, T_) do { if (threadIdx.x == (T_) && blockIdx.x == 5) g_probe[k] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -1225,8 +1229,11 @@ __device__ __forceinline__ void b3_tile(float *__restrict__ P, int ld, const bf1
     srcA = Wp; srcB = Wp;
 #endif
     const int lrow = 4 * (lane >> 5), lcol = lane & 31;                 // 32x32 accumulator: row = (e & 3) + 8 (e >> 2) + lrow, col = lcol
+#if !B3_PIPE
     constexpr int D = B3_NBUF - 1;                                      // stages in flight ahead of the one being consumed
+#endif
     auto ring = [&](int slot, int operand) { return smem + (slot * 2 + operand) * B3_GRAN; };
+#if !B3_PIPE
     // the P tile first (consumed in the epilogue), then the first two stages of the ring
     float pv[NB][NB][16];
 #pragma unroll
@@ -1236,6 +1243,90 @@ __device__ __forceinline__ void b3_tile(float *__restrict__ P, int ld, const bf1
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 pv[i][j][e] = P[(size_t)(R0 + i * 32 + (e & 3) + 8 * (e >> 2) + lrow) * ld + C0 + j * 32 + lcol];
+#endif
+#if B3_PIPE
+    // Register-level pipeline: the fragments of stage s+1 are read from the ring while the MFMAs of stage s run from registers, and
+    // the ring runs two stages ahead of that (slot s%3 is free as soon as stage s sits in registers):
+    //   top of stage s:  wait DMA(s+1) [DMA(s+2) may still fly], barrier -> issue DMA(s+3) into slot s%3 -> ds_read stage s+1 -> MFMAs(s)
+    // so neither the LDS-DMA latency (about 1.5 stages) nor the ds_read latency stands in front of an MFMA.
+    static_assert(B3_NBUF == 3, "the register pipeline wants a three-slot ring");
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        if (d < nst) {
+            b3_dma<TM>(srcA + (size_t)d * B3_GRAN, hA, ring(d, 0), tid, wave);
+            b3_dma<TM>(srcB + (size_t)d * B3_GRAN, hB, ring(d, 1), tid, wave);
+        }
+    b3_wait<TM, 2>(wave);                         // nst >= 4: three stages requested, the first one has landed
+    __syncthreads();
+#ifdef PRE3_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < 2048) g_k9rt[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && blockIdx.x == 7) { g_probe[0] = __builtin_amdgcn_s_memtime(); g_probe[2] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    f32x16_t acc[NB][NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // fragments are carried as 4 x i32 (the same 16 bytes): loop-carried <8 x bf16> values get legalised element by element
+    typedef int frag_t __attribute__((ext_vector_type(4)));
+    frag_t A[3][NB], B[3][NB], A2[3][NB], B2[3][NB];
+#define B3_READ_FRAGS(slot, FA, FB) do { \
+        const frag_t *sA_ = reinterpret_cast<const frag_t *>(ring(slot, 0)) + (NB * wi) * 64 + lane; \
+        const frag_t *sB_ = reinterpret_cast<const frag_t *>(ring(slot, 1)) + (NB * wj) * 64 + lane; \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) \
+            _Pragma("unroll") for (int i = 0; i < NB; ++i) { FA[p][i] = sA_[p * PL + i * 64]; FB[p][i] = sB_[p * PL + i * 64]; } \
+    } while (0)
+#define B3_MMA(FA, pa, FB, pb) \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) \
+            _Pragma("unroll") for (int j = 0; j < NB; ++j) \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, FA[pa][i]), __builtin_bit_cast(bf16x8_t, FB[pb][j]), acc[i][j], 0, 0, 0)
+    // largest terms first; six of the nine partial products
+#define B3_MFMAS(FA, FB) do { B3_MMA(FA, 0, FB, 0); B3_MMA(FA, 0, FB, 1); B3_MMA(FA, 1, FB, 0); B3_MMA(FA, 1, FB, 1); B3_MMA(FA, 0, FB, 2); B3_MMA(FA, 2, FB, 0); } while (0)
+    // one stage: FA/FB hold stage s, GA/GB receive stage s+1 (ping-pong over two unrolled stages: no register copies).
+    // LEFT: stages that may still be in flight once stage s+1 has landed; DMA: whether stage s+3 exists.  nst is a multiple of 4.
+#define B3_STAGE(s_, FA, FB, GA, GB, LEFT, DMA) do { \
+        const int nxt_ = buf == 2 ? 0 : buf + 1; \
+        b3_wait<TM, LEFT>(wave);                                             /* stage s+1 has landed (this wave's granules) */ \
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                  /* this wave's reads of stage s are in registers: its slot may be refilled */ \
+        __builtin_amdgcn_s_barrier();                                        /* raw barrier: __syncthreads() would add vmcnt(0) for the DMAs still in flight */ \
+        if (DMA) { \
+            b3_dma<TM>(srcA + (size_t)((s_) + 3) * B3_GRAN, hA, ring(buf, 0), tid, wave); \
+            b3_dma<TM>(srcB + (size_t)((s_) + 3) * B3_GRAN, hB, ring(buf, 1), tid, wave); \
+        } \
+        B3_READ_FRAGS(nxt_, GA, GB); \
+        B3_MFMAS(FA, FB); \
+        buf = nxt_; \
+    } while (0)
+    B3_READ_FRAGS(0, A, B);
+    __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): the loop's first MFMA must not inherit a wait that also covers the next reads
+    int buf = 0;                                  // slot of stage s
+    int s = 0;
+    for (; s + 5 < nst; s += 2) {
+        B3_STAGE(s, A, B, A2, B2, 1, true);
+        B3_STAGE(s + 1, A2, B2, A, B, 1, true);
+    }
+    // the last four stages, straight-line: s = nst - 4
+    B3_STAGE(s, A, B, A2, B2, 1, true);
+    B3_STAGE(s + 1, A2, B2, A, B, 1, false);
+    B3_STAGE(s + 2, A, B, A2, B2, 0, false);
+    B3_MFMAS(A2, B2);
+#undef B3_STAGE
+#undef B3_MFMAS
+#undef B3_MMA
+#undef B3_READ_FRAGS
+    // the P tile: requested behind the last MFMAs (its registers are the fragment registers, dead by now)
+    float pv[NB][NB][16];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                pv[i][j][e] = P[(size_t)(R0 + i * 32 + (e & 3) + 8 * (e >> 2) + lrow) * ld + C0 + j * 32 + lcol];
+    __syncthreads();                              // the patches below alias the ring
+#else
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (d < nst) {
@@ -1244,6 +1335,9 @@ __device__ __forceinline__ void b3_tile(float *__restrict__ P, int ld, const bf1
         }
     if (nst >= D) b3_wait<TM, D - 1>(wave); else vmwait<0>();
     __syncthreads();
+#ifdef PRE3_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < 2048) g_k9rt[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
     f32x16_t acc[NB][NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i)
@@ -1297,6 +1391,11 @@ __device__ __forceinline__ void b3_tile(float *__restrict__ P, int ld, const bf1
         __syncthreads();
         buf = buf == B3_NBUF - 1 ? 0 : buf + 1;
     }
+#endif
+#ifdef PRE3_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < 2048) g_k9rt[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && blockIdx.x == 7) { g_probe[1] = __builtin_amdgcn_s_memtime(); g_probe[3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     // epilogue: new = P - acc to (row, col) and, through a wave-private patch, to (col, row).  On a diagonal tile only the upper
     // triangle is written directly and its mirror image copied, so P stays exactly symmetric whatever the order of the six products.
     float (*patch)[33] = reinterpret_cast<float (*)[33]>(reinterpret_cast<float *>(smem) + wave * (32 * 33));
@@ -1347,8 +1446,20 @@ __global__ __launch_bounds__(256) void k_downdate_b3(float *__restrict__ P, int 
         return;
     }
     const int2 t = tiles[blockIdx.x];
+#ifdef PRE3_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < 2048) {
+        g_k9rt[blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime();
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_k9hw[blockIdx.x] = (hw & 0xffff) | ((xcc & 0xf) << 16) | ((unsigned)(t.x >> 16) << 24);
+    }
+#endif
     if (t.x >> 16) b3_tile<128>(P, ld, Wp, nst_total, nst, t.x & 0xffff, t.y, smem);
     else b3_tile<64>(P, ld, Wp, nst_total, nst, t.x, t.y, smem);
+#ifdef PRE3_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < 2048) g_k9rt[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // synthetic W for the roofline probe
@@ -1610,6 +1721,10 @@ extern "C" __attribute__((visibility("default"))) int pre3_debug_k9_stamps(unsig
 extern "C" __attribute__((visibility("default"))) int pre3_debug_k9rt(unsigned long long *out)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k9rt), sizeof(unsigned long long) * 2048 * 4) == hipSuccess ? 0 : -3;
+}
+extern "C" __attribute__((visibility("default"))) int pre3_debug_k9hw(unsigned int *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k9hw), sizeof(unsigned int) * 2048) == hipSuccess ? 0 : -3;
 }
 extern "C" __attribute__((visibility("default"))) int pre3_debug_probe(unsigned long long *out)
 {

@@ -199,3 +199,33 @@ def test_deferred_hi_update_gives_identical_results(pre3, orc):
     assert np.array_equal(x0, x1) and np.array_equal(P0, P1) and np.array_equal(li0, li1) and np.array_equal(hi0, hi1)
     assert sum(nh0) > 0, "the sequence must exercise HI updates"
     assert nh1[1:] == nh0[:-1]                                        # deferred mode reports the previous step's count
+
+
+def test_k9_bf16_split_matches_f32_mfma_and_fp64(pre3, orc):
+    """PRE3_OPT_K9_BF16X3: the down-date as a three-way bf16 split (six bf16 MFMA products, f32 accumulate) against the plain f32 MFMA
+    and against the fp64 path, over whole steps (several panels, 128x128 and 64x64 tiles, LI and HI updates).  Tolerance: the
+    split form may not be further from fp64 than 1.5x the f32 form's own distance (+ a floor), and P stays exactly symmetric."""
+    N = 120                                                            # n = 733 -> ld = 768: 21 tiles of 128, a partial last block
+    seq = synth.make_sequence(N, 4, 40, seed=91)
+    types = np.zeros(N, np.int32)
+    res = {}
+    for tag, dtype, b3 in (("f64", "f64", None), ("mfma", "f32", False), ("b3", "f32", True)):
+        f = pre3.EkfFilter(seq["cam"], types, dtype=dtype, max_hyp=40, std_z=1.0)
+        if b3 is not None:
+            assert f.k9_bf16x3(b3) == b3
+        else:
+            assert f.k9_bf16x3() is False and f.k9_bf16x3(True) is False        # no effect on an fp64 context
+        f.set_x_p_k_k(seq["x0"], seq["P0"])
+        for s in seq["steps"]:
+            st = f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=1.0, early_exit=False)
+        res[tag] = (f.get_x_k_k(), f.get_p_k_k(), st)
+        f.close()
+    x64, P64, s64 = res["f64"]
+    scale = np.abs(P64).max()
+    e_mfma, e_b3 = np.abs(res["mfma"][1] - P64).max() / scale, np.abs(res["b3"][1] - P64).max() / scale
+    assert res["mfma"][2]["n_li"] == res["b3"][2]["n_li"] == s64["n_li"] and s64["n_li"] > 64          # more than one panel
+    assert e_b3 <= 1.5 * e_mfma + 2e-6, (e_b3, e_mfma)
+    assert e_b3 < 1e-3
+    assert np.array_equal(res["b3"][1], res["b3"][1].T)
+    sig = np.sqrt(np.diag(P64))
+    assert (np.abs(res["b3"][0] - x64) / sig).max() < 5e-3

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
-K9 = "k_downdate_1t"
+K9 = "k_downdate_b3"
 
 shutil.copy(os.path.join(G, "%s_trace" % tag, "%s_kernel_stats.csv" % tag), os.path.join(P, "%s_bench_kernel_stats.csv" % tag))
 tl = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_timeline.py"), os.path.join(G, "%s_trace" % tag, "%s_kernel_trace.csv" % tag), "3"],
@@ -34,14 +34,14 @@ dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
 big = [d for d in dur if d > 0.6 * max(dur)]
 out = {
     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra-legs (two separate passes)",
-    "kernel": "k_downdate_1t<float,16> (K9, one 64x64 tile per workgroup; the x-update and rescue-projection workgroups ride in the same launch)",
+    "kernel": "k_downdate_b3 (K9 as a three-way bf16 split on the bf16 MFMA, 128x128 + 64x64 tiles; the x-update and rescue-projection workgroups ride in the same launch)",
     "counters_KB": {"FETCH_SIZE": fs, "WRITE_SIZE": ws},
     "k9_trace_durations_us": {"launches": len(dur), "avg": sum(dur) / len(dur), "li_launch_avg": sum(big) / len(big)},
     "notes": [
         "WRITE_SIZE of an LI launch = ld^2*4 B (ld = 3072): the whole padded P is written once per launch (upper tile + mirrored tile).",
-        "FETCH_SIZE on gfx950 reports half the bytes of 16 B/lane streams (MI355X_MICROARCH.md, HBM section); the W staging loads are 16 B/lane LDS-DMA, "
+        "FETCH_SIZE on gfx950 reports half the bytes of 16 B/lane streams (MI355X_MICROARCH.md, HBM section); the plane staging loads are 16 B/lane LDS-DMA, "
         "the P-tile prefetch is 4 B/lane (uncalibrated), so the read side lies between the raw figure and twice it.",
-        "algorithmic per LI launch (r=640, n=3013): P upper triangle read 18.2 MB + P written 36.3 MB + W 7.7 MB = 62 MB",
+        "algorithmic per LI launch (r=640, n=3013): P upper triangle read 18.2 MB + P written 36.3 MB + bf16 planes of W 11.6 MB = 66 MB",
     ],
     "hbm_bytes_per_li_launch": {"raw": 1024.0 * (fs["li_launch_avg_KB"] + ws["li_launch_avg_KB"]),
                                 "fetch_doubled": 1024.0 * (2 * fs["li_launch_avg_KB"] + ws["li_launch_avg_KB"])},

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the K9 launch (separate passes; tools/k9ab.py runs bench_downdate at r=320/640)
+# SQ counters of the K9 launch (k_downdate_b3; PRE3_K9_B3=0 + the filter below for the f32 MFMA form) (separate passes; tools/k9ab.py runs bench_downdate at r=320/640)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA GRBM_GUI_ACTIVE"; do
@@ -12,7 +12,7 @@ R=os.environ["GRAFT_REPO_ROOT"]
 for f in sorted(glob.glob(R+"/gpurun_out/pmc_k9/*/p_counter_collection.csv")):
     acc=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "k_downdate_1t" in r["Kernel_Name"]:
+        if "k_downdate_b3" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"])-int(r["Start_Timestamp"])))
     for k,v in acc.items():
         big=[x for x in v if x[1] > 0.8*max(y[1] for y in v)]      # r=640 launches
