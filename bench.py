@@ -276,7 +276,8 @@ def main():
                             bound="mfma", dtype="bf16 operands (3-way split of f32), f32 accumulate", achieved=6.0 * achieved, peak=PEAK["bf16"],
                             frac=6.0 * achieved / PEAK["bf16"],
                             f32_equivalent={"achieved": achieved, "f32_mfma_peak": PEAK["f32"], "ratio": achieved / PEAK["f32"],
-                                            "note": "the same launches priced as the f32 SYRK they replace: n(n+1)r flop / time"}, **common)
+                                            "note": "the same launches priced as the f32 SYRK they replace: n(n+1)r flop / time; BASELINE.json's "
+                                                    "north star asks for the P-update at >= 60 % of the fp32 MFMA roofline -- this ratio is that figure"}, **common)
         else:
             roofline = dict(kernel="k_downdate_1t / k_downdate (K9: P <- P - W'W on the %s MFMA; the x-update and rescue-projection riders "
                                    "share the one-tile launch)" % args.dtype,
