@@ -208,7 +208,8 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
         { const char *e = getenv("PRE3_K9_B3"); c->k9_b3 = e ? atoi(e) != 0 : true; }
         // k_downdate_b3: bf16 planes of W and the 128x128 tile list (4x4 super-tiles dealt to 8 lists, lists interleaved: block b runs
         // on XCD b % 8, so a super-tile's 8 column blocks of planes stay in one L2)
-        A(dmalloc_bytes(&c->Wp, (size_t)c->ld * c->rcap * 6));
+        A(dmalloc_bytes(&c->Wp, (size_t)(c->ld + 128) * c->rcap * 6));       // + one column block for the nu strip's planes
+        A(dmalloc_bytes(&c->Sp, (size_t)(c->rcap / NB) * (c->rcap / NB) * 1536 * 16));
         const int nt = c->ld / 128, ns = ceil_div(nt, 4);
         std::vector<std::vector<int2>> lists(8);
         for (int SI = 0; SI < ns; ++SI)
@@ -275,7 +276,7 @@ int pre3_destroy(pre3_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
                      c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
-                     c->sel_rows, c->support, c->masks, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->tiles128 };
+                     c->sel_rows, c->support, c->masks, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128 };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->pinned_stats) (void)hipHostFree(c->pinned_stats);
     if (c->inbox_host) (void)hipHostFree(c->inbox_host);

@@ -84,6 +84,7 @@ struct pre3_ctx {
     void *Wp = nullptr;                           // fp32 path: bf16 planes of W in stage-image order (k_split_w), ld x rcap x 6 B
     bool k9_b3 = false;                           // fp32: K9 as three-way bf16 split on the bf16 matrix cores (PRE3_K9_B3=0 turns it off)
     int split_rows = 0;                           // rows of W whose bf16 planes the factorisation launches have already produced
+    void *Sp = nullptr;                           // fp32 path: bf16 planes of the factorisation's S blocks (pending updates), rcap/64 x rcap/64 x 24 KB
     void *tiles128 = nullptr; int n_tiles128 = 0; // int2[n_tiles128]: 128x128 upper-triangle tiles of k_downdate_b3, XCD-interleaved
     unsigned int *chol_arrive = nullptr; unsigned int chol_target = 0;   // [0] panel arrivals, [1] scoring done, [2] rescue done, [3],[4] rider producers
     unsigned int ride_target[2] = { 0, 0 };

@@ -154,6 +154,7 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 #endif
 constexpr int B3_T = 128, B3_BK = 16, B3_GRAN = 3 * 4 * 64;        // granules (16 B) of one operand block of one stage
 // x[0..7] = eight consecutive k of one column -> this lane's granule of the three planes (dst: plane 0; planes are 256 granules apart)
+template <int PSTRIDE = 256>
 __device__ __forceinline__ void b3_split_store(const float (&x)[8], bf16x8_t *__restrict__ dst)
 {
     bf16x8_t a, b, c;
@@ -165,8 +166,9 @@ __device__ __forceinline__ void b3_split_store(const float (&x)[8], bf16x8_t *__
         const float r2 = r1 - (float)hb;            // exact
         a[j] = ha; b[j] = hb; c[j] = (__bf16)r2;
     }
-    dst[0] = a; dst[256] = b; dst[512] = c;
+    dst[0] = a; dst[PSTRIDE] = b; dst[2 * PSTRIDE] = c;
 }
+constexpr int B3_SGRAN = 4 * 3 * 2 * 64;          // granules of one 64x64 S block's planes: [k-step 4][plane 3][32-row half 2][lane 64]
 // one (128 columns x 16 k) block from W in global memory; 256 threads
 __device__ __forceinline__ void b3_split_block(const float *__restrict__ W, int ldw, bf16x8_t *__restrict__ Wp, int nst_total, int cb, int st, int tid)
 {
@@ -260,7 +262,7 @@ struct ChSmem {
 template <typename T, bool PRO>
 __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb,
                                                 int32_t *__restrict__ status, const int b, unsigned int *__restrict__ arrive, unsigned int target,
-                                                void *__restrict__ Wp = nullptr, int nst_total = 0, int ld = 0)
+                                                void *__restrict__ Wp = nullptr, int nst_total = 0, int ld = 0, void *__restrict__ Sp = nullptr, int sp_stride = 0)
 {
     PROBE_STAMP(0);
     constexpr int MB = 4, NMP = NB / MB;
@@ -274,6 +276,9 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
     // the factor wave shares its SIMD with worker wave 4: its (latency-bound) instructions must issue the moment they are ready
     if (!worker) __builtin_amdgcn_s_setprio(3);
     const int wt = tid - 64;                                  // worker lane id 0..255
+    typedef int frag_t __attribute__((ext_vector_type(4)));      // 8 bf16
+    const bool planes = sizeof(T) == 4 && Sp != nullptr;       // fp32 with the bf16-split down-date: the pending update multiplies on the bf16 MFMA too
+    frag_t fBa[4][3], fBb[4][3], fO[4][3];
     if (worker) {
         // all 32 global loads of the two blocks are issued before the first LDS store
         T ga[16], gx[16];
@@ -291,7 +296,26 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
             }
         }
         T gb[16], gq[16];
-        if (PRO) {
+        if (PRO && planes) {
+            // the pending update's operands as bf16 planes (written by the store epilogues of launch J-1): this wave's fragments
+            // straight into registers -- B = M(J, J-1) for rows w0.. and w1.., and the workgroup's own block
+            const int lane = wt & 63, wv = wt >> 6, fa = wv >> 1, fb = wv & 1;
+            const frag_t *Bp = static_cast<const frag_t *>(Sp) + ((size_t)J * sp_stride + (J - 1)) * B3_SGRAN + lane;
+            const frag_t *Op = nullptr;
+            int ostage = 0, oplane = 0;
+            if (b >= 1) {
+                if (!isW) { Op = static_cast<const frag_t *>(Sp) + ((size_t)(J + b) * sp_stride + (J - 1)) * B3_SGRAN + fa * 64 + lane; ostage = 384; oplane = 128; }
+                else { Op = static_cast<const frag_t *>(Wp) + ((size_t)(c0 >> 7) * nst_total + 4 * (J - 1)) * B3_GRAN + (2 * ((c0 >> 6) & 1) + fb) * 64 + lane; ostage = B3_GRAN; oplane = 256; }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    fBa[q][pl] = Bp[q * 384 + pl * 128 + fa * 64];
+                    fBb[q][pl] = Bp[q * 384 + pl * 128 + fb * 64];
+                    if (b >= 1) fO[q][pl] = Op[q * ostage + pl * oplane];
+                }
+        } else if (PRO) {
             // operands of the pending update from panel J-1: B = M(J, J-1) and this workgroup's own M(b, J-1)
 #pragma unroll
             for (int t = 0; t < 16; ++t) gb[t] = S[(size_t)(J * NB + lr + 4 * t) * lds + (J - 1) * NB + lc];
@@ -317,7 +341,7 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
                 for (int t = 0; t < 16; ++t) Xs[lr + 4 * t][lc] = gx[t];        // W strip: (a = lr+4t, i = lc)
             }
         }
-        if (PRO) {
+        if (PRO && !planes) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) sm.Bs[lr + 4 * t][lc] = gb[t];                          // Bs[j][a]
             if (b >= 1) {
@@ -331,7 +355,44 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
     // every workgroup reads the raw diagonal block; workgroup 0 overwrites it with L_JJ at the end and must not do so
     // before all of them have it (they normally start together, but nothing guarantees that for very large grids)
     if (tid == 0 && b != 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (PRO) {
+    if (PRO && planes) {
+        if constexpr (sizeof(T) == 4) {
+            if (worker) {
+                // six bf16 products per f32 product (see k_downdate_b3), K = 64 = 4 k-steps: 24 MFMAs of 32 cycles per 64x64x64 product
+                // and wave instead of 32 of 64 cycles
+                const int lane = wt & 63, wv = wt >> 6;
+                const int w0 = (wv >> 1) * 32, w1 = (wv & 1) * 32;
+                const int lrow = 4 * (lane >> 5), lcol = lane & 31;
+#define PRO_MMA(X, Y, px, py) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, X[q][px]), __builtin_bit_cast(bf16x8_t, Y[q][py]), acc, 0, 0, 0)
+#define PRO_SIX(X, Y) do { _Pragma("unroll") for (int q = 0; q < 4; ++q) { PRO_MMA(X, Y, 0, 0); PRO_MMA(X, Y, 0, 1); PRO_MMA(X, Y, 1, 0); PRO_MMA(X, Y, 1, 1); PRO_MMA(X, Y, 0, 2); PRO_MMA(X, Y, 2, 0); } } while (0)
+                if (w1 <= w0) {                 // diagonal block: A_JJ -= B B'  (only j <= i is ever read)
+                    f32x16_t acc;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                    PRO_SIX(fBa, fBb);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) Ls[w0 + (e & 3) + 8 * (e >> 2) + lrow][w1 + lcol] -= acc[e];
+                }
+                if (b >= 1) {
+                    f32x16_t acc;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                    if (!isW) {                 // X(i, j) -= sum_a A[i][a] B[j][a]: rows -> i (own block), lanes -> j; stored Xs[j][i]
+                        PRO_SIX(fO, fBb);
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) Xs[w1 + lcol][w0 + (e & 3) + 8 * (e >> 2) + lrow] -= acc[e];
+                    } else {                    // M(i, j) -= sum_a Aw[a][i] B[j][a]: rows -> j, lanes -> i (own strip); stored Xs[j][i]
+                        PRO_SIX(fBa, fO);
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) Xs[w0 + (e & 3) + 8 * (e >> 2) + lrow][w1 + lcol] -= acc[e];
+                    }
+                }
+#undef PRO_SIX
+#undef PRO_MMA
+            }
+        }
+        __syncthreads();
+    } else if (PRO) {
         if (worker) {
             using M = Mfma<T>;
             constexpr int NBLK = 32 / M::BLK;
@@ -596,16 +657,28 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
             int i = idx >> 6, a2 = idx & 63;
             S[(size_t)(rb * NB + i) * lds + J * NB + a2] = Xs[a2][i];
         }
+        if constexpr (sizeof(T) == 4) {
+            if (Sp != nullptr) {           // the next launches' pending updates read this block as bf16 planes: [k-step][plane][32-row half][lane]
+                bf16x8_t *base = static_cast<bf16x8_t *>(Sp) + ((size_t)rb * sp_stride + J) * B3_SGRAN;
+                for (int idx = tid; idx < 512; idx += 320) {
+                    const int q = idx >> 7, fl = (idx >> 6) & 1, l = idx & 63, r = l & 31, h = l >> 5;
+                    float x[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = Xs[16 * q + 8 * h + j][fl * 32 + r];
+                    b3_split_store<128>(x, base + q * 384 + fl * 64 + l);
+                }
+            }
+        }
     } else {
         for (int idx = tid; idx < NB * NB; idx += 320) {
             int a2 = idx >> 6, i = idx & 63;
             W[(size_t)(J * NB + a2) * ldw + c0 + i] = Xs[a2][i];
         }
         if constexpr (sizeof(T) == 4) {
-            // last panel, k_downdate_b3 in use: this strip's share of the bf16 planes of the last row block straight from LDS (the
-            // earlier row blocks are split by riders of the following launches), so that no split launch stands between the
-            // factorisation and the down-date.  Strip = half a 128-column block: fragments 2*half, 2*half+1 of 4 stages.
-            if (Wp != nullptr && J == nrb - 1 && c0 < ld) {
+            // k_downdate_b3 in use: this strip's share of the bf16 planes of row block J straight from LDS, for the down-date and for the
+            // next launch's pending update (Sp set; without it only the last panel does this and riders split the earlier row blocks).
+            // Strip = half a 128-column block: fragments 2*half, 2*half+1 of 4 stages; the nu strip lives in an extra column block.
+            if (Wp != nullptr && (Sp != nullptr || J == nrb - 1) && c0 < ld + NB) {
                 bf16x8_t *base = static_cast<bf16x8_t *>(Wp) + ((size_t)(c0 >> 7) * nst_total + 4 * J) * B3_GRAN + ((c0 >> 6) & 1) * 128;
                 for (int idx = tid; idx < 512; idx += 320) {
                     const int q = idx >> 7, fl = (idx >> 6) & 1, l = idx & 63, r = l & 31, h = l >> 5;
@@ -757,7 +830,7 @@ __global__ __launch_bounds__(256) void k_chol_trail(T *__restrict__ S, int lds, 
 template <typename T>
 __global__ __launch_bounds__(320) void k_chol_step(T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb, int nW,
                                                    int nP, int32_t *__restrict__ status, unsigned int *__restrict__ arrive, unsigned int target,
-                                                   int nPT, void *__restrict__ Wp, int nst_total, int ncb, int ld_split)
+                                                   int nPT, void *__restrict__ Wp, int nst_total, int ncb, int ld_split, void *__restrict__ Sp, int sp_stride)
 {
     __shared__ ChSmem<T> sm;
     const int b = blockIdx.x;
@@ -771,8 +844,8 @@ __global__ __launch_bounds__(320) void k_chol_step(T *__restrict__ S, int lds, T
         return;
     }
     if (b < nP) {
-        if (J == 0) chol_panel_body<T, false>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target, Wp, nst_total, ld_split);
-        else chol_panel_body<T, true>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target, Wp, nst_total, ld_split);
+        if (J == 0) chol_panel_body<T, false>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target, Wp, nst_total, ld_split, Sp, sp_stride);
+        else chol_panel_body<T, true>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target, Wp, nst_total, ld_split, Sp, sp_stride);
     } else {
         chol_trail_body<T>(sm.As, sm.Bs, S, lds, W, ldw, J - 1, J + 1, nrb, nW, b - nP);
     }
@@ -1525,18 +1598,20 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad)
     c->split_rows = 0;
     if (form == 1) {
         const bool split = c->k9_b3 && c->dtype == PRE3_F32 && c->Wp != nullptr;
+        static const int pro_env = getenv("PRE3_CHOL_PRO_B3") ? atoi(getenv("PRE3_CHOL_PRO_B3")) : 1;
+        const bool pro_planes = split && pro_env && c->Sp != nullptr;       // pending updates on the bf16 MFMA as well
         for (int J = 0; J < nrb; ++J) {
             const int nS = nrb - J - 1, nP = 1 + nS + nW;
             const int nK = J >= 1 ? nrb - J - 1 : 0;                        // column blocks >= J+1 of panel J-1's update
             const int nT = nK * (nK + 1) / 2 + nK * nW;
-            const int ncb = (split && J >= 1) ? c->ld / B3_T : 0;           // split riders: 4 stages x ncb column blocks of row block J-1
+            const int ncb = (split && !pro_planes && J >= 1) ? c->ld / B3_T : 0;   // split riders: 4 stages x ncb column blocks of row block J-1
             dim3 g(nP + nT + 4 * ncb), bP(320);
             c->chol_target += (unsigned)(nP - 1);                           // every non-diagonal workgroup of the panel arrives once
             DISPATCH_T(c,
                 hipLaunchKernelGGL(k_chol_step<double>, g, bP, 0, c->stream, (double *)c->Smat, r_pad, (double *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
-                                   nP + nT, nullptr, 0, 0, 0),
+                                   nP + nT, nullptr, 0, 0, 0, nullptr, 0),
                 hipLaunchKernelGGL(k_chol_step<float>, g, bP, 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
-                                   nP + nT, split ? c->Wp : nullptr, c->rcap / B3_BK, ncb, c->ld));
+                                   nP + nT, split ? c->Wp : nullptr, c->rcap / B3_BK, ncb, c->ld, pro_planes ? c->Sp : nullptr, c->rcap / NB));
         }
         if (split) c->split_rows = nrb * NB;
         PRE3_HIP(hipGetLastError());
