@@ -653,9 +653,10 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
     }
     if (!isW) {
         int rb = J + b;
-        for (int idx = tid; idx < NB * NB; idx += 320) {
-            int i = idx >> 6, a2 = idx & 63;
-            S[(size_t)(rb * NB + i) * lds + J * NB + a2] = Xs[a2][i];
+        typedef T st4_t __attribute__((ext_vector_type(4)));
+        for (int idx = tid; idx < NB * NB / 4; idx += 320) {             // 16- / 32-byte stores: a quarter of the store instructions
+            const int i = idx >> 4, a2 = (idx & 15) * 4;
+            *reinterpret_cast<st4_t *>(S + (size_t)(rb * NB + i) * lds + J * NB + a2) = st4_t{ Xs[a2][i], Xs[a2 + 1][i], Xs[a2 + 2][i], Xs[a2 + 3][i] };
         }
         if constexpr (sizeof(T) == 4) {
             if (Sp != nullptr) {           // the next launches' pending updates read this block as bf16 planes: [k-step][plane][32-row half][lane]
@@ -670,9 +671,10 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
             }
         }
     } else {
-        for (int idx = tid; idx < NB * NB; idx += 320) {
-            int a2 = idx >> 6, i = idx & 63;
-            W[(size_t)(J * NB + a2) * ldw + c0 + i] = Xs[a2][i];
+        typedef T st4_t __attribute__((ext_vector_type(4)));
+        for (int idx = tid; idx < NB * NB / 4; idx += 320) {
+            const int a2 = idx >> 4, i = (idx & 15) * 4;
+            *reinterpret_cast<st4_t *>(W + (size_t)(J * NB + a2) * ldw + c0 + i) = st4_t{ Xs[a2][i], Xs[a2][i + 1], Xs[a2][i + 2], Xs[a2][i + 3] };
         }
         if constexpr (sizeof(T) == 4) {
             // k_downdate_b3 in use: this strip's share of the bf16 planes of row block J straight from LDS, for the down-date and for the
