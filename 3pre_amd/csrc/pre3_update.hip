@@ -1385,13 +1385,15 @@ __device__ __forceinline__ void b3_tile(float *__restrict__ P, int ld, const bf1
     // the last four stages, straight-line: s = nst - 4
     B3_STAGE(s, A, B, A2, B2, 1, true);
     B3_STAGE(s + 1, A2, B2, A, B, 1, false);
-    B3_STAGE(s + 2, A, B, A2, B2, 0, false);
-    B3_MFMAS(A2, B2);
-#undef B3_STAGE
-#undef B3_MFMAS
-#undef B3_MMA
-#undef B3_READ_FRAGS
-    // the P tile: requested behind the last MFMAs (its registers are the fragment registers, dead by now)
+    {   // stage nst-2, with the P tile requested behind its synchronisation: two stages of MFMAs cover the loads' latency, and from
+        // here on only two fragment sets' worth of registers are live besides the accumulators
+        const int nxt_ = buf == 2 ? 0 : buf + 1;
+        b3_wait<TM, 0>(wave);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        B3_READ_FRAGS(nxt_, A2, B2);
+        buf = nxt_;
+    }
     float pv[NB][NB][16];
 #pragma unroll
     for (int i = 0; i < NB; ++i)
@@ -1400,6 +1402,12 @@ __device__ __forceinline__ void b3_tile(float *__restrict__ P, int ld, const bf1
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 pv[i][j][e] = P[(size_t)(R0 + i * 32 + (e & 3) + 8 * (e >> 2) + lrow) * ld + C0 + j * 32 + lcol];
+    B3_MFMAS(A, B);
+    B3_MFMAS(A2, B2);
+#undef B3_STAGE
+#undef B3_MFMAS
+#undef B3_MMA
+#undef B3_READ_FRAGS
     __syncthreads();                              // the patches below alias the ring
 #else
 #pragma unroll
@@ -1473,7 +1481,12 @@ __device__ __forceinline__ void b3_tile(float *__restrict__ P, int ld, const bf1
 #endif
     // epilogue: new = P - acc to (row, col) and, through a wave-private patch, to (col, row).  On a diagonal tile only the upper
     // triangle is written directly and its mirror image copied, so P stays exactly symmetric whatever the order of the six products.
-    float (*patch)[33] = reinterpret_cast<float (*)[33]>(reinterpret_cast<float *>(smem) + wave * (32 * 33));
+    // Off the diagonal both images leave as 16-byte stores (a quarter of the store instructions: the tail of this kernel is store-issue
+    // bound): the block goes through two wave-private LDS patches, one as is and one transposed ([32][36] floats each: rows 16-byte aligned).
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    float (*patch)[36] = reinterpret_cast<float (*)[36]>(reinterpret_cast<float *>(smem) + wave * (2 * 32 * 36));
+    float (*patchT)[36] = patch + 32;
+    static_assert(B3_NBUF * 2 * B3_GRAN * 16 >= 4 * 2 * 32 * 36 * 4, "patches must fit in the ring");
 #pragma unroll
     for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -1482,20 +1495,39 @@ __device__ __forceinline__ void b3_tile(float *__restrict__ P, int ld, const bf1
             if (diag && gi > gj) continue;                               // below the diagonal: the mirror of another block
             const bool dblk = diag && gi == gj;
             const int r0 = R0 + i * 32, c0 = C0 + j * 32;
+            if (dblk) {                                                   // diagonal 32x32 block: element-wise predicates
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int lr = (e & 3) + 8 * (e >> 2) + lrow;
-                const float v = pv[i][j][e] - acc[i][j][e];
-                if (!dblk || lr <= lcol) P[(size_t)(r0 + lr) * ld + c0 + lcol] = v;
-                patch[lr][lcol] = v;
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            const int rr = lane & 31, half = lane >> 5;
+                for (int e = 0; e < 16; ++e) {
+                    const int lr = (e & 3) + 8 * (e >> 2) + lrow;
+                    const float v = pv[i][j][e] - acc[i][j][e];
+                    if (lr <= lcol) P[(size_t)(r0 + lr) * ld + c0 + lcol] = v;
+                    patch[lr][lcol] = v;
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                const int rr = lane & 31, half = lane >> 5;
 #pragma unroll
-            for (int cc = 0; cc < 32; cc += 2) {
-                const int c = cc + half;
-                if (!dblk || rr < c) P[(size_t)(c0 + c) * ld + r0 + rr] = patch[rr][c];
+                for (int cc = 0; cc < 32; cc += 2) {
+                    const int c = cc + half;
+                    if (rr < c) P[(size_t)(c0 + c) * ld + r0 + rr] = patch[rr][c];
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {                             // e = 4g..4g+3: rows 8g + lrow + 0..3 of column lcol
+                    f4_t v;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { v[t] = pv[i][j][4 * g + t] - acc[i][j][4 * g + t]; patch[8 * g + lrow + t][lcol] = v[t]; }
+                    *reinterpret_cast<f4_t *>(&patchT[lcol][8 * g + lrow]) = v;
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                const int rr = lane >> 3, c4 = (lane & 7) * 4;            // 8 rows x 128 B per instruction
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = rr + 8 * it;
+                    *reinterpret_cast<f4_t *>(P + (size_t)(r0 + row) * ld + c0 + c4) = *reinterpret_cast<const f4_t *>(&patch[row][c4]);
+                    *reinterpret_cast<f4_t *>(P + (size_t)(c0 + row) * ld + r0 + c4) = *reinterpret_cast<const f4_t *>(&patchT[row][c4]);
+                }
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
