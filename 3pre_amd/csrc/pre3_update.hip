@@ -703,7 +703,8 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
 // J+2 when block J+1 is handled by the next panel's prologue); idx: tile number.  Threads >= 256 only keep the barrier.
 template <typename T>
 __device__ __forceinline__ void chol_trail_body(T (&As)[NB][NB + 1], T (&Bs)[NB][NB + 1], T *__restrict__ S, int lds, T *__restrict__ W, int ldw,
-                                                int J, int K0, int nrb, int nW, int idx)
+                                                int J, int K0, int nrb, int nW, int idx,
+                                                const void *__restrict__ Wp = nullptr, int nst_total = 0, const void *__restrict__ Sp = nullptr, int sp_stride = 0)
 {
     using M = Mfma<T>;
     constexpr int NBLK = 32 / M::BLK;
@@ -723,6 +724,45 @@ __device__ __forceinline__ void chol_trail_body(T (&As)[NB][NB + 1], T (&Bs)[NB]
         c0 = (t % nW) * NB; K = K0 + t / nW; isW = true;
     }
     const int w0 = (wave >> 1) * 32, w1 = (wave & 1) * 32;
+    if constexpr (sizeof(T) == 4) {
+        if (Sp != nullptr) {
+            // operands as bf16 planes (written by the store epilogues of the launch that solved panel J): fragments straight from global
+            // memory, six bf16 products per f32 product, no LDS and no barrier -- a third of the matrix-pipe time of the f32 form, which
+            // matters because these tiles share CUs with the latency-bound panel workgroups of the same launch
+            if (!active) return;
+            typedef int frag_t __attribute__((ext_vector_type(4)));
+            const int fa = wave >> 1, fb = wave & 1, lrow = 4 * (lane >> 5), lcol = lane & 31;
+            const frag_t *Ap, *Bp;
+            int bstage, bplane;
+            if (!isW) {
+                Ap = static_cast<const frag_t *>(Sp) + ((size_t)rb * sp_stride + J) * B3_SGRAN + fa * 64 + lane;
+                Bp = static_cast<const frag_t *>(Sp) + ((size_t)K * sp_stride + J) * B3_SGRAN + fb * 64 + lane; bstage = 384; bplane = 128;
+            } else {
+                Ap = static_cast<const frag_t *>(Sp) + ((size_t)K * sp_stride + J) * B3_SGRAN + fa * 64 + lane;
+                Bp = static_cast<const frag_t *>(Wp) + ((size_t)(c0 >> 7) * nst_total + 4 * J) * B3_GRAN + (2 * ((c0 >> 6) & 1) + fb) * 64 + lane; bstage = B3_GRAN; bplane = 256;
+            }
+            frag_t fA[4][3], fB[4][3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) { fA[q][pl] = Ap[q * 384 + pl * 128]; fB[q][pl] = Bp[q * bstage + pl * bplane]; }
+            float cvv[16];
+            float *Cbase = !isW ? S + (size_t)(rb * NB + w0) * lds + K * NB + w1 + lcol : W + (size_t)(K * NB + w0) * ldw + c0 + w1 + lcol;
+            const int cld = !isW ? lds : ldw;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) cvv[e] = Cbase[(size_t)((e & 3) + 8 * (e >> 2) + lrow) * cld];
+            f32x16_t acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#define TR_MMA(px, py) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fA[q][px]), __builtin_bit_cast(bf16x8_t, fB[q][py]), acc, 0, 0, 0)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { TR_MMA(0, 0); TR_MMA(0, 1); TR_MMA(1, 0); TR_MMA(1, 1); TR_MMA(0, 2); TR_MMA(2, 0); }
+#undef TR_MMA
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Cbase[(size_t)((e & 3) + 8 * (e >> 2) + lrow) * cld] = cvv[e] - acc[e];
+            return;
+        }
+    }
     if (active) {
         // all global loads (both operand tiles and the 16 output elements this lane will update) are issued
         // before the first LDS store, so their latencies overlap
@@ -849,7 +889,7 @@ __global__ __launch_bounds__(320) void k_chol_step(T *__restrict__ S, int lds, T
         if (J == 0) chol_panel_body<T, false>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target, Wp, nst_total, ld_split, Sp, sp_stride);
         else chol_panel_body<T, true>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target, Wp, nst_total, ld_split, Sp, sp_stride);
     } else {
-        chol_trail_body<T>(sm.As, sm.Bs, S, lds, W, ldw, J - 1, J + 1, nrb, nW, b - nP);
+        chol_trail_body<T>(sm.As, sm.Bs, S, lds, W, ldw, J - 1, J + 1, nrb, nW, b - nP, Wp, nst_total, Sp, sp_stride);
     }
 }
 
