@@ -163,3 +163,15 @@ def test_maximum_configured_size_properties(pre3):
     A[3:7, :] = 0; A[:, 3:7] = 0
     assert A.max() == 0.0 and P.diagonal().min() > 0 and np.trace(P) < np.trace(seq["P0"])
     f.close()
+    # the same step with the down-date (and the factorisation's pending updates) on the f32 MFMA instead of the bf16 split: 17 rounds of
+    # 128x128 tiles + 64x64 left-overs against the persistent 64x64 form -- same inlier sets, P equal to f32 rounding
+    g = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", max_hyp=n_hyp)
+    assert g.k9_bf16x3(False) is False
+    g.set_x_p_k_k(seq["x0"], seq["P0"])
+    st2 = g.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=1.0, early_exit=False)
+    li2, hi2 = g.get_flags()
+    P2 = g.get_p_k_k()
+    g.close()
+    assert np.array_equal(li, li2) and np.array_equal(hi, hi2) and st2["n_li"] == st["n_li"]
+    d = np.sqrt(P.diagonal())
+    assert (np.abs(P - P2) / np.outer(d, d)).max() < 2e-3
