@@ -1728,7 +1728,9 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
         c->tile_ctr_clean = false;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool timed = c->kt.enabled && (c->kt.seen++ % c->kt.every) == 0;
+    // only launches in the matrix-bound regime are bracketed (r_pad >= 128: the LI updates); an HI update's r <= 64 launch is a
+    // read-modify-write of P at HBM speed and would only dilute the figure -- and with 'one in N' it would alias with the LI/HI alternation
+    const bool timed = c->kt.enabled && r_pad >= 2 * NB && (c->kt.seen++ % c->kt.every) == 0;
     if (timed) {
         if ((size_t)c->kt.used + 2 > c->kt.ev.size()) {
             for (int i = 0; i < 2; ++i) { hipEvent_t e; PRE3_HIP(hipEventCreate(&e)); c->kt.ev.push_back(e); }

@@ -262,8 +262,9 @@ def main():
         except Exception:
             pass
         algo = ("symmetric rank-r down-date (SYRK): n(n+1)r flop per launch, r = rows of that update, averaged over the K9 launches of "
-                "the timed region that were bracketed with HIP events (one in --kt-every; LI updates with r~640 and HI updates with "
-                "r<=64 alike); SURVEY 8(d)'s un-halved convention 2n^2r gives twice this figure")
+                "the timed region that were bracketed with HIP events: one in --kt-every of the launches with >= 128 rows, i.e. the LI "
+                "updates (r ~ 640); the HI updates' launches (r <= 64) are HBM-bound read-modify-writes of P and are not priced against the "
+                "matrix roofline; SURVEY 8(d)'s un-halved convention 2n^2r gives twice this figure")
         common = {"unit": "TFLOP/s", "traffic": traffic, "traffic_source": traffic_src, "launches": kt["launches"],
                   "avg_launch_us": 1e3 * kt["total_ms"] / max(kt["launches"], 1), "algorithmic": algo,
                   "survey_2n2r_equivalent": 2.0 * achieved * n / (n + 1.0)}

@@ -276,7 +276,7 @@ PRE3_API int pre3_knn_f64(int device, int D, int N, const double *data, int M, c
  * the covariance down-date kernel (K9) are measured with these, not with torch events. */
 PRE3_API int pre3_timer_start(pre3_ctx *ctx);
 PRE3_API int pre3_timer_stop(pre3_ctx *ctx, double *ms_out);             /* synchronises */
-PRE3_API int pre3_kernel_timing(pre3_ctx *ctx, int enable);             /* 1: bracket every K9 launch with events; N > 1: one launch in N; 0: off */
+PRE3_API int pre3_kernel_timing(pre3_ctx *ctx, int enable);             /* 1: bracket every K9 launch of >= 128 rows (the matrix-bound ones) with events; N > 1: one such launch in N; 0: off */
 PRE3_API int pre3_kernel_timing_read(pre3_ctx *ctx, int *launches_out, double *total_ms_out, double *flops_out,
                                      double *bytes_out);                /* synchronises, then resets */
 /* run only the K9 down-date P <- P - W'W with a synthetic W of r rows `reps` times (roofline probe) */
