@@ -214,6 +214,23 @@ __global__ __launch_bounds__(256) void k_match_i8_mfma(int NDp, int K1, int K2, 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[p][q][e] = 0;
     const int r = lane & 31, kg = lane >> 5;
+    if (NDp == 128) {
+        // SIFT's 128 bins: all 16 fragment loads of the tile are issued before the first MFMA (one memory latency instead of four)
+        v4i av[4][2], bv[4][2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                av[ks][p] = *reinterpret_cast<const v4i *>(A + (size_t)(I0 + wi * 64 + p * 32 + r) * 128 + ks * 32 + 16 * kg);
+                bv[ks][p] = *reinterpret_cast<const v4i *>(B + (size_t)(J0 + wj * 64 + p * 32 + r) * 128 + ks * 32 + 16 * kg);
+            }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[p][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[ks][p], bv[ks][q], acc[p][q], 0, 0, 0);
+    } else
     for (int k0 = 0; k0 < NDp; k0 += 32) {
         v4i av[2], bv[2];
 #pragma unroll
@@ -226,10 +243,15 @@ __global__ __launch_bounds__(256) void k_match_i8_mfma(int NDp, int K1, int K2, 
 #pragma unroll
             for (int q = 0; q < 2; ++q) acc[p][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[p], bv[q], acc[p][q], 0, 0, 0);
     }
-    // epilogue: each lane holds, per block, column (lane&31) and 16 rows.  Stage d2 through LDS so that one
-    // lane scans one query row over the tile's 128 columns in increasing column order.
+    // epilogue: each lane holds, per block, column (lane&31) and 16 rows.  Stage d2 through LDS (64 rows at a time); then wave q scans
+    // columns [32q, 32q+32) of every row in increasing column order -- one lane per row, conflict-free (row stride 129) -- and writes its
+    // own partial: 4 partials per 128-column tile, stored [partial][query] so that the merge kernel reads them coalesced.
     __shared__ int sd[64][129];
+    const int K1p = gridDim.y * 128;
+    // |a|^2 is constant along a row: the scan orders nb - 2 a.b and the row's norm is added to (best, second) when they are written
+    const int nbq[2] = { nb[J0 + wj * 64 + (lane & 31)], nb[J0 + wj * 64 + 32 + (lane & 31)] };
     for (int half = 0; half < 2; ++half) {
+        const int na_row = na[I0 + half * 64 + lane];
         if (wi == half) {
 #pragma unroll
             for (int p = 0; p < 2; ++p)
@@ -239,37 +261,78 @@ __global__ __launch_bounds__(256) void k_match_i8_mfma(int NDp, int K1, int K2, 
                     for (int e = 0; e < 16; ++e) {
                         int row = p * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                         int col = wj * 64 + q * 32 + (lane & 31);
-                        sd[row][col] = na[I0 + half * 64 + row] + nb[J0 + col] - 2 * acc[p][q][e];
+                        sd[row][col] = nbq[q] - 2 * acc[p][q][e];
                     }
         }
         __syncthreads();
-        if (tid < 64) {
-            int row = tid;
+        {
+            const int row = lane, c0 = wave * 32;
             int best = 0x7fffffff, second = 0x7fffffff, bk = -1;
-            int ncol = K2 - J0 < 128 ? K2 - J0 : 128;
-            for (int cidx = 0; cidx < ncol; ++cidx) push3(best, second, bk, sd[row][cidx], J0 + cidx);
-            size_t o = (size_t)(I0 + half * 64 + row) * ntile_n + blockIdx.x;
-            pbest[o] = best; psecond[o] = second; parg[o] = bk;
+            const int ncol = K2 - J0 < 128 ? K2 - J0 : 128;
+            const int cend = c0 + 32 < ncol ? c0 + 32 : ncol;
+            for (int cidx = c0; cidx < cend; ++cidx) push3(best, second, bk, sd[row][cidx], J0 + cidx);
+            const size_t o = (size_t)(blockIdx.x * 4 + wave) * K1p + I0 + half * 64 + row;
+            pbest[o] = best == 0x7fffffff ? best : best + na_row; psecond[o] = second == 0x7fffffff ? second : second + na_row; parg[o] = bk;
         }
         __syncthreads();
     }
 }
 
-__global__ void k_match_reduce_i32(int K1, int ntile_n, const int *__restrict__ pbest, const int *__restrict__ psecond,
+// sixteen lanes per query, each merging every sixteenth partial, loads issued 8 at a time (the merge is a dependent chain: one partial
+// per load latency was 0.46 us each), then four shuffle merges
+__global__ __launch_bounds__(256) void k_match_reduce_i32(int K1, int K1p, int npart, const int *__restrict__ pbest, const int *__restrict__ psecond,
                                    const int *__restrict__ parg, int k2_offset, double *__restrict__ obest, double *__restrict__ osecond,
                                    int32_t *__restrict__ oarg)
 {
-    int k1 = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k1 >= K1) return;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k1 = g >> 4, sub = g & 15;
+    const bool live = k1 < K1;
     int best = 0x7fffffff, second = 0x7fffffff, bk = -1;
-    for (int t = 0; t < ntile_n; ++t) {
-        size_t o = (size_t)k1 * ntile_n + t;
-        merge3(best, second, bk, pbest[o], psecond[o], parg[o]);
+    if (live) {
+        for (int t0 = sub; t0 < npart; t0 += 128) {
+            int vb[8], vs[8], va[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + 16 * u;
+                const size_t o = (size_t)(t < npart ? t : 0) * K1p + k1;
+                vb[u] = pbest[o]; vs[u] = psecond[o]; va[u] = t < npart ? parg[o] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) merge3(best, second, bk, vb[u], vs[u], va[u]);
+        }
     }
-    obest[k1] = (double)best; osecond[k1] = (double)second; oarg[k1] = bk < 0 ? -1 : bk + k2_offset;
+#pragma unroll
+    for (int o = 1; o <= 8; o <<= 1) {
+        const int ob = __shfl_xor(best, o, 64), os = __shfl_xor(second, o, 64), ok = __shfl_xor(bk, o, 64);
+        merge3(best, second, bk, ob, os, ok);
+    }
+    if (live && sub == 0) { obest[k1] = (double)best; osecond[k1] = (double)second; oarg[k1] = bk < 0 ? -1 : bk + k2_offset; }
 }
 
-// pack ND x K (column-major, one descriptor per column) uint8/int8 into K_pad x NDp int8 rows (+ norms)
+// pack ND x K (column-major, one descriptor per column) uint8/int8 into K_pad x NDp int8 rows (+ norms): one thread per 16 bins (one
+// 16-byte store), the NDp/16 threads of a descriptor are neighbours in a wave and add up the norm with shuffles (NDp/16 is a power
+// of two <= 64 here: NDp is a multiple of 32; other shapes take the generic one-thread-per-descriptor path)
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_i8_v(int ND, int NDp, int K, int Kp, const T *__restrict__ L, int center, int8_t *__restrict__ out,
+                                                    int *__restrict__ norm)
+{
+    const int cpd = NDp / 16;                                   // chunks per descriptor
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int kcol = g / cpd, ch = g - kcol * cpd;
+    if (kcol >= Kp) return;
+    int8_t v[16];
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int b = ch * 16 + j;
+        const int x = (kcol < K && b < ND) ? (int)L[(size_t)kcol * ND + b] - center : 0;
+        v[j] = (int8_t)x; s += x * x;
+    }
+    *reinterpret_cast<int4 *>(out + (size_t)kcol * NDp + ch * 16) = *reinterpret_cast<const int4 *>(v);
+    for (int o = cpd >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (ch == 0) norm[kcol] = s;
+}
+
 template <typename T>
 __global__ void k_pack_i8(int ND, int NDp, int K, int Kp, const T *__restrict__ L, int center, int8_t *__restrict__ out, int *__restrict__ norm)
 {
@@ -282,6 +345,16 @@ __global__ void k_pack_i8(int ND, int NDp, int K, int Kp, const T *__restrict__ 
         s += v * v;
     }
     norm[kcol] = s;
+}
+
+template <typename T>
+static void launch_pack_i8(int ND, int NDp, int K, int Kp, const T *L, int center, int8_t *out, int *norm)
+{
+    const int cpd = NDp / 16;
+    if (cpd >= 2 && cpd <= 64 && (cpd & (cpd - 1)) == 0 && ((size_t)Kp * cpd) % 256 == 0)
+        hipLaunchKernelGGL(k_pack_i8_v<T>, dim3((unsigned)((size_t)Kp * cpd / 256)), dim3(256), 0, 0, ND, NDp, K, Kp, L, center, out, norm);
+    else
+        hipLaunchKernelGGL(k_pack_i8<T>, dim3(ceil_div(Kp, 64)), dim3(64), 0, 0, ND, NDp, K, Kp, L, center, out, norm);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -440,11 +513,11 @@ static int i8_prepare(I8Match &m, int ND, int K1, const T *L1, int K2, const T *
     if (K2) PRE3_HIP(hipMemcpy(r2.p, L2, (size_t)ND * K2, hipMemcpyHostToDevice));
     PRE3_TRY(m.A.alloc((size_t)m.K1p * m.NDp)); PRE3_TRY(m.B.alloc((size_t)m.K2p * m.NDp));
     PRE3_TRY(m.na.alloc(sizeof(int) * m.K1p)); PRE3_TRY(m.nb.alloc(sizeof(int) * m.K2p));
-    size_t np = (size_t)m.K1p * m.ntn;
+    size_t np = (size_t)m.K1p * m.ntn * 4;            // four partials (32-column chunks) per 128-column tile
     PRE3_TRY(m.pb.alloc(sizeof(int) * np)); PRE3_TRY(m.ps.alloc(sizeof(int) * np)); PRE3_TRY(m.pa.alloc(sizeof(int) * np));
     PRE3_TRY(m.ob.alloc(sizeof(double) * K1)); PRE3_TRY(m.os.alloc(sizeof(double) * K1)); PRE3_TRY(m.oa.alloc(sizeof(int32_t) * K1));
-    hipLaunchKernelGGL(k_pack_i8<T>, dim3(ceil_div(m.K1p, 64)), dim3(64), 0, 0, ND, m.NDp, K1, m.K1p, (const T *)r1.p, center, (int8_t *)m.A.p, (int *)m.na.p);
-    hipLaunchKernelGGL(k_pack_i8<T>, dim3(ceil_div(m.K2p, 64)), dim3(64), 0, 0, ND, m.NDp, K2, m.K2p, (const T *)r2.p, center, (int8_t *)m.B.p, (int *)m.nb.p);
+    launch_pack_i8<T>(ND, m.NDp, K1, m.K1p, (const T *)r1.p, center, (int8_t *)m.A.p, (int *)m.na.p);
+    launch_pack_i8<T>(ND, m.NDp, K2, m.K2p, (const T *)r2.p, center, (int8_t *)m.B.p, (int *)m.nb.p);
     PRE3_HIP(hipGetLastError());
     PRE3_HIP(hipDeviceSynchronize());
     return PRE3_OK;
@@ -455,7 +528,7 @@ static int i8_run(I8Match &m, int k2_offset, hipStream_t st)
     dim3 g(m.ntn, m.K1p / 128), b(256);
     hipLaunchKernelGGL(k_match_i8_mfma, g, b, 0, st, m.NDp, m.K1, m.K2, (const int8_t *)m.A.p, (const int8_t *)m.B.p, (const int *)m.na.p,
                        (const int *)m.nb.p, m.ntn, (int *)m.pb.p, (int *)m.ps.p, (int *)m.pa.p);
-    hipLaunchKernelGGL(k_match_reduce_i32, dim3(ceil_div(m.K1, 256)), dim3(256), 0, st, m.K1, m.ntn, (const int *)m.pb.p, (const int *)m.ps.p,
+    hipLaunchKernelGGL(k_match_reduce_i32, dim3(ceil_div(16 * m.K1, 256)), dim3(256), 0, st, m.K1, m.K1p, m.ntn * 4, (const int *)m.pb.p, (const int *)m.ps.p,
                        (const int *)m.pa.p, k2_offset, (double *)m.ob.p, (double *)m.os.p, (int32_t *)m.oa.p);
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
