@@ -171,19 +171,38 @@ __global__ __launch_bounds__(256) void k_match_exact_tiled(int ND, int K1, int K
     }
 }
 
+// sixteen lanes per query, each merging every sixteenth column tile with its loads issued 8 at a time (the merge is a dependent chain:
+// one tile per load latency cost 42 us at 64 tiles), then four shuffle merges; launch with 16 * K1 threads
 template <typename T>
-__global__ void k_match_reduce_f(int K1, int ntile_n, const T *__restrict__ pbest, const T *__restrict__ psecond, const int32_t *__restrict__ parg,
+__global__ __launch_bounds__(256) void k_match_reduce_f(int K1, int ntile_n, const T *__restrict__ pbest, const T *__restrict__ psecond, const int32_t *__restrict__ parg,
                                  int k2_offset, double *__restrict__ obest, double *__restrict__ osecond, int32_t *__restrict__ oarg)
 {
-    const int k1 = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k1 >= K1) return;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k1 = g >> 4, sub = g & 15;
+    const bool live = k1 < K1;
     T best = acc_max<T>(), second = acc_max<T>();
     int bk = -1;
-    for (int t = 0; t < ntile_n; ++t) {
-        const size_t o = (size_t)t * K1 + k1;
-        merge3(best, second, bk, pbest[o], psecond[o], parg[o]);
+    if (live) {
+        for (int t0 = sub; t0 < ntile_n; t0 += 128) {
+            T vb[8], vs[8];
+            int va[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + 16 * u;
+                const size_t o = (size_t)(t < ntile_n ? t : 0) * K1 + k1;
+                vb[u] = pbest[o]; vs[u] = psecond[o]; va[u] = t < ntile_n ? parg[o] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) merge3(best, second, bk, vb[u], vs[u], va[u]);
+        }
     }
-    obest[k1] = (double)best; osecond[k1] = (double)second; oarg[k1] = bk < 0 ? -1 : bk + k2_offset;
+#pragma unroll
+    for (int o = 1; o <= 8; o <<= 1) {
+        const T ob = __shfl_xor(best, o, 64), os = __shfl_xor(second, o, 64);
+        const int ok = __shfl_xor(bk, o, 64);
+        merge3(best, second, bk, ob, os, ok);
+    }
+    if (live && sub == 0) { obest[k1] = (double)best; osecond[k1] = (double)second; oarg[k1] = bk < 0 ? -1 : bk + k2_offset; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -481,7 +500,7 @@ static int partial_exact(int ND, int K1, const T *L1, int K2, const T *L2, int k
         PRE3_TRY(pb.alloc(sizeof(T) * (size_t)K1 * ntn)); PRE3_TRY(ps.alloc(sizeof(T) * (size_t)K1 * ntn)); PRE3_TRY(pa.alloc(sizeof(int32_t) * (size_t)K1 * ntn));
         hipLaunchKernelGGL((k_match_exact_tiled<T>), dim3(ntn, ceil_div(K1, 64)), dim3(256), 0, 0, ND, K1, K2, (const T *)d1.p, (const T *)d2.p,
                            (T *)pb.p, (T *)ps.p, (int32_t *)pa.p, ntn);
-        hipLaunchKernelGGL((k_match_reduce_f<T>), dim3(ceil_div(K1, 256)), dim3(256), 0, 0, K1, ntn, (const T *)pb.p, (const T *)ps.p, (const int32_t *)pa.p,
+        hipLaunchKernelGGL((k_match_reduce_f<T>), dim3(ceil_div(16 * K1, 256)), dim3(256), 0, 0, K1, ntn, (const T *)pb.p, (const T *)ps.p, (const int32_t *)pa.p,
                            k2_offset, (double *)db.p, (double *)ds.p, (int32_t *)da.p);
         PRE3_HIP(hipGetLastError());
         PRE3_HIP(hipDeviceSynchronize());          // the partial buffers go out of scope below
@@ -651,7 +670,7 @@ int launch_ic_search(pre3_ctx *c, double thresh, int strict)
                            (const double *)c->bank, (const double *)c->scan_desc, c->ic_pb, c->ic_ps, c->ic_pa, ntn,
                            (const int32_t *)c->ic_pred, (const int32_t *)c->ic_counts);
         // rows >= the device-side query count hold stale partials; k_ic_gate only reads the first counts[0] results
-        hipLaunchKernelGGL((k_match_reduce_f<double>), dim3(ceil_div(N, 256)), dim3(256), 0, c->stream, N, ntn, (const double *)c->ic_pb,
+        hipLaunchKernelGGL((k_match_reduce_f<double>), dim3(ceil_div(16 * N, 256)), dim3(256), 0, c->stream, N, ntn, (const double *)c->ic_pb,
                            (const double *)c->ic_ps, (const int32_t *)c->ic_pa, 0, c->ic_best, c->ic_second, c->ic_arg);
         hipLaunchKernelGGL(k_ic_gate, dim3(1), dim3(64), 0, c->stream, c->ic_pred, c->ic_best, c->ic_second, c->ic_arg,
                            (float)thresh, strict, c->scan_pos, c->lm.h, c->lm.S, c->lm.has_S, c->lm.z, c->lm.ic, c->ic_pairs, c->ic_newk2,
