@@ -695,6 +695,71 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
     PROBE_STAMP(3);
 }
 
+// One 64x64 tile of the trailing update with its operands as bf16 planes (written by the store epilogues of the launch that solved panel J):
+// fragments straight from global memory, six bf16 products per f32 product, no LDS and no barrier -- a third of the matrix-pipe time of
+// the f32 form.  256 threads.
+__device__ __forceinline__ void chol_trail_b3_tile(float *__restrict__ S, int lds, float *__restrict__ W, int ldw, int J, bool isW, int rb, int K, int c0,
+                                       const void *__restrict__ Wp, int nst_total, const void *__restrict__ Sp, int sp_stride)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w0 = (wave >> 1) * 32, w1 = (wave & 1) * 32;
+    typedef int frag_t __attribute__((ext_vector_type(4)));
+    const int fa = wave >> 1, fb = wave & 1, lrow = 4 * (lane >> 5), lcol = lane & 31;
+    const frag_t *Ap, *Bp;
+    int bstage, bplane;
+    if (!isW) {
+        Ap = static_cast<const frag_t *>(Sp) + ((size_t)rb * sp_stride + J) * B3_SGRAN + fa * 64 + lane;
+        Bp = static_cast<const frag_t *>(Sp) + ((size_t)K * sp_stride + J) * B3_SGRAN + fb * 64 + lane; bstage = 384; bplane = 128;
+    } else {
+        Ap = static_cast<const frag_t *>(Sp) + ((size_t)K * sp_stride + J) * B3_SGRAN + fa * 64 + lane;
+        Bp = static_cast<const frag_t *>(Wp) + ((size_t)(c0 >> 7) * nst_total + 4 * J) * B3_GRAN + (2 * ((c0 >> 6) & 1) + fb) * 64 + lane; bstage = B3_GRAN; bplane = 256;
+    }
+    frag_t fA[4][3], fB[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { fA[q][pl] = Ap[q * 384 + pl * 128]; fB[q][pl] = Bp[q * bstage + pl * bplane]; }
+    float cvv[16];
+    float *Cbase = !isW ? S + (size_t)(rb * NB + w0) * lds + K * NB + w1 + lcol : W + (size_t)(K * NB + w0) * ldw + c0 + w1 + lcol;
+    const int cld = !isW ? lds : ldw;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cvv[e] = Cbase[(size_t)((e & 3) + 8 * (e >> 2) + lrow) * cld];
+    f32x16_t acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#define TR_MMA(px, py) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fA[q][px]), __builtin_bit_cast(bf16x8_t, fB[q][py]), acc, 0, 0, 0)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { TR_MMA(0, 0); TR_MMA(0, 1); TR_MMA(1, 0); TR_MMA(1, 1); TR_MMA(0, 2); TR_MMA(2, 0); }
+#undef TR_MMA
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Cbase[(size_t)((e & 3) + 8 * (e >> 2) + lrow) * cld] = cvv[e] - acc[e];
+}
+
+// tile number -> (S tile (rb, K) | W tile (K, c0)) of the update of panel J applied to column blocks >= K0
+__device__ __forceinline__ void chol_trail_decode(int idx, int K0, int nrb, int nW, bool &isW, int &rb, int &K, int &c0)
+{
+    const int nK = nrb - K0, nSt = nK * (nK + 1) / 2;
+    rb = 0; c0 = 0;
+    if (idx < nSt) {
+        int bb = 0;
+        while ((bb + 1) * (bb + 2) / 2 <= idx) ++bb;
+        rb = K0 + bb; K = K0 + idx - bb * (bb + 1) / 2; isW = false;
+    } else {
+        const int t = idx - nSt;
+        c0 = (t % nW) * NB; K = K0 + t / nW; isW = true;
+    }
+}
+
+// The trailing update as a launch of its own (no LDS: 8 workgroups per CU instead of the 2 that k_chol_step's 75 KB allow): used when
+// the update has far more tiles than the chip has slots (large r and n), where it -- not the panel's chain -- sets the pace.
+__global__ __launch_bounds__(256) void k_chol_trail_b3(float *__restrict__ S, int lds, float *__restrict__ W, int ldw, int J, int K0, int nrb, int nW,
+                                                       const void *__restrict__ Wp, int nst_total, const void *__restrict__ Sp, int sp_stride)
+{
+    bool isW; int rb, K, c0;
+    chol_trail_decode(blockIdx.x, K0, nrb, nW, isW, rb, K, c0);
+    chol_trail_b3_tile(S, lds, W, ldw, J, isW, rb, K, c0, Wp, nst_total, Sp, sp_stride);
+}
+
 // Trailing update on the matrix cores: one 64 x 64 tile  C -= A B'  (K = 64) per workgroup, 4 waves, each a
 // 32 x 32 sub-tile.  S-type tiles keep (row, a) order in LDS and are read with a 65-float stride (conflict
 // free); W-type tiles are stored k-major.  For W strips the operands are swapped so that the accumulator's
@@ -726,40 +791,7 @@ __device__ __forceinline__ void chol_trail_body(T (&As)[NB][NB + 1], T (&Bs)[NB]
     const int w0 = (wave >> 1) * 32, w1 = (wave & 1) * 32;
     if constexpr (sizeof(T) == 4) {
         if (Sp != nullptr) {
-            // operands as bf16 planes (written by the store epilogues of the launch that solved panel J): fragments straight from global
-            // memory, six bf16 products per f32 product, no LDS and no barrier -- a third of the matrix-pipe time of the f32 form, which
-            // matters because these tiles share CUs with the latency-bound panel workgroups of the same launch
-            if (!active) return;
-            typedef int frag_t __attribute__((ext_vector_type(4)));
-            const int fa = wave >> 1, fb = wave & 1, lrow = 4 * (lane >> 5), lcol = lane & 31;
-            const frag_t *Ap, *Bp;
-            int bstage, bplane;
-            if (!isW) {
-                Ap = static_cast<const frag_t *>(Sp) + ((size_t)rb * sp_stride + J) * B3_SGRAN + fa * 64 + lane;
-                Bp = static_cast<const frag_t *>(Sp) + ((size_t)K * sp_stride + J) * B3_SGRAN + fb * 64 + lane; bstage = 384; bplane = 128;
-            } else {
-                Ap = static_cast<const frag_t *>(Sp) + ((size_t)K * sp_stride + J) * B3_SGRAN + fa * 64 + lane;
-                Bp = static_cast<const frag_t *>(Wp) + ((size_t)(c0 >> 7) * nst_total + 4 * J) * B3_GRAN + (2 * ((c0 >> 6) & 1) + fb) * 64 + lane; bstage = B3_GRAN; bplane = 256;
-            }
-            frag_t fA[4][3], fB[4][3];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) { fA[q][pl] = Ap[q * 384 + pl * 128]; fB[q][pl] = Bp[q * bstage + pl * bplane]; }
-            float cvv[16];
-            float *Cbase = !isW ? S + (size_t)(rb * NB + w0) * lds + K * NB + w1 + lcol : W + (size_t)(K * NB + w0) * ldw + c0 + w1 + lcol;
-            const int cld = !isW ? lds : ldw;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) cvv[e] = Cbase[(size_t)((e & 3) + 8 * (e >> 2) + lrow) * cld];
-            f32x16_t acc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#define TR_MMA(px, py) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fA[q][px]), __builtin_bit_cast(bf16x8_t, fB[q][py]), acc, 0, 0, 0)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { TR_MMA(0, 0); TR_MMA(0, 1); TR_MMA(1, 0); TR_MMA(1, 1); TR_MMA(0, 2); TR_MMA(2, 0); }
-#undef TR_MMA
-#pragma unroll
-            for (int e = 0; e < 16; ++e) Cbase[(size_t)((e & 3) + 8 * (e >> 2) + lrow) * cld] = cvv[e] - acc[e];
+            if (active) chol_trail_b3_tile(S, lds, W, ldw, J, isW, rb, K, c0, Wp, nst_total, Sp, sp_stride);
             return;
         }
     }
@@ -1679,13 +1711,21 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad)
             const int nK = J >= 1 ? nrb - J - 1 : 0;                        // column blocks >= J+1 of panel J-1's update
             const int nT = nK * (nK + 1) / 2 + nK * nW;
             const int ncb = (split && !pro_planes && J >= 1) ? c->ld / B3_T : 0;   // split riders: 4 stages x ncb column blocks of row block J-1
-            dim3 g(nP + nT + 4 * ncb), bP(320);
+            // a trailing update with far more tiles than k_chol_step has slots (2 workgroups per CU: its 75 KB of LDS) goes out as a launch
+            // of its own in front of the panel (no LDS, 8 workgroups per CU); both only depend on the previous launch
+            static const int trail_split = getenv("PRE3_CHOL_TRAIL_SPLIT") ? atoi(getenv("PRE3_CHOL_TRAIL_SPLIT")) : 4;
+            const bool own_trail = pro_planes && trail_split > 0 && nT > trail_split * 2 * c->num_cus;
+            if (own_trail)
+                hipLaunchKernelGGL(k_chol_trail_b3, dim3(nT), dim3(256), 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J - 1, J + 1, nrb, nW,
+                                   c->Wp, c->rcap / B3_BK, c->Sp, c->rcap / NB);
+            const int nT_in = own_trail ? 0 : nT;
+            dim3 g(nP + nT_in + 4 * ncb), bP(320);
             c->chol_target += (unsigned)(nP - 1);                           // every non-diagonal workgroup of the panel arrives once
             DISPATCH_T(c,
                 hipLaunchKernelGGL(k_chol_step<double>, g, bP, 0, c->stream, (double *)c->Smat, r_pad, (double *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
-                                   nP + nT, nullptr, 0, 0, 0, nullptr, 0),
+                                   nP + nT_in, nullptr, 0, 0, 0, nullptr, 0),
                 hipLaunchKernelGGL(k_chol_step<float>, g, bP, 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
-                                   nP + nT, split ? c->Wp : nullptr, c->rcap / B3_BK, ncb, c->ld, pro_planes ? c->Sp : nullptr, c->rcap / NB));
+                                   nP + nT_in, split ? c->Wp : nullptr, c->rcap / B3_BK, ncb, c->ld, pro_planes ? c->Sp : nullptr, c->rcap / NB));
         }
         if (split) c->split_rows = nrb * NB;
         PRE3_HIP(hipGetLastError());
