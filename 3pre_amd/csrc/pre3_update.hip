@@ -1185,7 +1185,7 @@ struct XUpd { int n_tiles, n, r; const double *x_prior; double *x_out; double *p
 // waves_per_eu: the riders' fp64 geometry must not raise the register count of the tile path (5 workgroups per CU in fp32,
 // 4 in fp64 -- every tile resident at once); if anything spills, it is the riders.
 template <typename T, int BK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 5 : 4))) void k_downdate_1t(T *__restrict__ P, int ld, const T *__restrict__ W, int ldw, int r_pad,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_downdate_1t(T *__restrict__ P, int ld, const T *__restrict__ W, int ldw, int r_pad,
                                                      const int2 *__restrict__ tiles, int gen_size, XUpd xu, ProjRide pr)
 {
     using M = Mfma<T>;
@@ -1197,7 +1197,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     constexpr int HS = BK / M::KS / 2;                // k-steps per half stage
     static_assert((BK * ROWV) % 256 == 0 && NLD >= 1, "stage must divide over the workgroup");
     constexpr int STG = BK * TS;                      // elements of one operand stage
-    constexpr int SMEM = 4 * STG > 4 * 32 * 33 ? 4 * STG : 4 * 32 * 33;     // staging buffers, reused by the 4 epilogue patches
+    // epilogue patches: fp32 [32][33] (padded); fp64 [32][32] with the column XOR-ed by the row -- conflict-free both ways without the
+    // padding, so that the patches fit the 32 KB of staging and five workgroups still share a CU's 160 KB
+    constexpr int PS = sizeof(T) == 4 ? 33 : 32;
+    constexpr int SMEM = 4 * STG > 4 * 32 * PS ? 4 * STG : 4 * 32 * PS;     // staging buffers, reused by the 4 epilogue patches
     __shared__ __attribute__((aligned(16))) T smem[SMEM];                   // [A0 | A1 | B0 | B1], each [BK][64]
     static_assert(sizeof(T) * SMEM >= sizeof(double) * (4 * 64 + 4), "the riders borrow the staging buffer");
     if ((int)blockIdx.x >= xu.n_tiles) {            // riders (launch_downdate adds these workgroups)
@@ -1221,7 +1224,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         else if (gen == 2) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
     }
-    T (*patch)[33] = reinterpret_cast<T (*)[33]>(smem + (threadIdx.x >> 6) * (32 * 33));
+    T *patch = smem + (threadIdx.x >> 6) * (32 * PS);
+    auto pat = [&](int r, int c) -> T & { return patch[r * PS + (sizeof(T) == 4 ? c : (c ^ r))]; };
     const int2 ij = tiles[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef PRE3_PROBE
@@ -1292,7 +1296,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 const size_t o = (size_t)(I0 + wi * 32 + lr) * ld + J0 + wj * 32 + lc;
                 const T v = pv[p][q][e] - acc[p][q][e];
                 P[o] = v;
-                if (mirror) patch[lr][lc] = v;
+                if (mirror) pat(lr, lc) = v;
             }
     if (mirror) {
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -1301,7 +1305,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 #pragma unroll
         for (int cc = 0; cc < 32; cc += 2) {
             const int c = cc + half;
-            P[(size_t)(J0 + wj * 32 + c) * ld + I0 + wi * 32 + rr] = patch[rr][c];
+            P[(size_t)(J0 + wj * 32 + c) * ld + I0 + wi * 32 + rr] = pat(rr, c);
         }
     }
     RT_STAMP(3);
@@ -1759,7 +1763,7 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
     dim3 g(gsz), b(256);
     static const int force = getenv("PRE3_K9_FORM") ? atoi(getenv("PRE3_K9_FORM")) : 0;     // 1: one-tile, 2: persistent (experiments)
     // all tiles resident at once: 5 workgroups/CU in fp32 (16.9 KB of LDS each), 4 in fp64 (33.8 KB)
-    const bool one_tile = force == 1 || (force == 0 && c->n_tiles <= (c->dtype == PRE3_F32 ? 5 : 4) * c->num_cus);
+    const bool one_tile = force == 1 || (force == 0 && c->n_tiles <= 5 * c->num_cus);
     // fp32: three-way bf16 split on the bf16 matrix cores (k_split_w + k_downdate_b3); PRE3_K9_B3=0 keeps the f32-MFMA forms
     const bool use_b3 = c->k9_b3 && c->dtype == PRE3_F32 && c->Wp != nullptr;
     if (!use_b3 && !one_tile && which_prior >= 0) PRE3_TRY(launch_update_x(c, which_prior, r));          // (also resets the ticket counters)
