@@ -152,7 +152,7 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
     A(dmalloc_bytes(&c->W, (size_t)c->rcap * c->ldw * c->esz));
     A(dmalloc_bytes(&c->G, (size_t)c->rcap * c->rcap * c->esz));
     A(dmalloc_bytes(&c->Smat, (size_t)c->rcap * c->rcap * c->esz));
-    A(dmalloc(&c->sel_rows, c->rcap));
+    A(dmalloc(&c->sel_rows, c->rcap)); A(dmalloc(&c->need, c->capm));
     A(dmalloc(&c->support, c->caph));
     A(dmalloc(&c->masks, (size_t)c->caph * c->mask_words_cap));
     A(dmalloc(&c->stats, 16));
@@ -276,7 +276,7 @@ int pre3_destroy(pre3_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
                      c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
-                     c->sel_rows, c->support, c->masks, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128 };
+                     c->sel_rows, c->support, c->masks, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128, c->need };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->pinned_stats) (void)hipHostFree(c->pinned_stats);
     if (c->inbox_host) (void)hipHostFree(c->inbox_host);
@@ -618,7 +618,14 @@ int pre3_ic_search(pre3_ctx *c, double thresh, int strict_reference, int32_t *n_
 }
 
 // ---- RANSAC ---------------------------------------------------------------------------------------
-static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp)
+// need[s] = 1 for every measurement position a hypothesis of [lo, hi) draws (need was cleared)
+__global__ void k_mark_needed(const int32_t *__restrict__ hyp, int k, int lo, int hi, int32_t *__restrict__ need)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < (hi - lo) * k) need[hyp[lo * k + t]] = 1;
+}
+
+static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, int lo = 0, int hi = -1)
 {
     PRE3_CHECK(c->measurements_set && c->projected, PRE3_E_STATE, "ransac: needs pre3_project and measurements");
     PRE3_CHECK(c->p_which == PRE3_X_K_KM1, PRE3_E_STATE, "ransac: needs the predicted estimate (call pre3_predict or set x_k_km1)");
@@ -634,6 +641,18 @@ static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp)
         PRE3_HIP(hipEventRecord(c->inbox_copied, c->stream)); c->inbox_pending = true;
     }
     int r = 2 * c->m, r_pad = round_up(r, NB);
+    if (hi < 0) hi = n_draw;
+    if (lo > 0 || hi < n_draw) {
+        // a rank's slice of a sharded round: H*P and H*P*H' only for the measurements its hypotheses draw (the scorer of hypothesis h
+        // reads the 2k rows of its own landmarks and the entries of G among them, nothing else) -- the part of the round that
+        // shrinks with the number of ranks.  The LI update must not gather from these partial products: hp_all_valid stays false.
+        PRE3_HIP(hipMemsetAsync(c->need, 0, sizeof(int32_t) * c->m, c->stream));
+        if (hi > lo) hipLaunchKernelGGL(k_mark_needed, dim3(ceil_div((hi - lo) * k, 256)), dim3(256), 0, c->stream, c->hyp, k, lo, hi, c->need);
+        PRE3_TRY(launch_ell_HP_build(c, c->HP, c->need));
+        PRE3_TRY(launch_ell_G(c, r, c->HP, c->G, r_pad, 0, nullptr, true, c->need));
+        c->hp_all_valid = false;
+        return PRE3_OK;
+    }
     PRE3_TRY(launch_ell_HP_build(c, c->HP));
     PRE3_TRY(launch_ell_G(c, r, c->HP, c->G, r_pad, 0, nullptr, true));      // lower triangle: the scorer and the LI gather read (max, min)
     c->hp_all_valid = true;
@@ -645,7 +664,7 @@ int pre3_ransac_score(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, double
 {
     PRE3_TRY(check_ctx(c));
     PRE3_CHECK(hyp_begin >= 0 && hyp_begin <= hyp_end && hyp_end <= n_draw, PRE3_E_ARG, "ransac: bad hypothesis range [%d,%d) of %d", hyp_begin, hyp_end, n_draw);
-    PRE3_TRY(ransac_prepare(c, n_draw, k, hyp));
+    PRE3_TRY(ransac_prepare(c, n_draw, k, hyp, hyp_begin, hyp_end));
     int words = ceil_div(c->m, 32);
     PRE3_HIP(hipMemsetAsync(c->support, 0, sizeof(int32_t) * n_draw, c->stream));
     PRE3_HIP(hipMemsetAsync(c->masks, 0, sizeof(uint32_t) * (size_t)n_draw * words, c->stream));

@@ -60,8 +60,10 @@ __global__ __launch_bounds__(256) void k_ell_HP_build(int m, int r_pad, const in
                                                       const int32_t *__restrict__ lm_off, const double *__restrict__ Hc,
                                                       const double *__restrict__ Hl, const double *__restrict__ z, const double *__restrict__ h,
                                                       int32_t *__restrict__ row_col, T *__restrict__ row_val, double *__restrict__ row_nu,
-                                                      const T *__restrict__ P, int ld, T *__restrict__ dst, int ldw)
+                                                      const T *__restrict__ P, int ld, T *__restrict__ dst, int ldw, const int32_t *__restrict__ need = nullptr)
 {
+    // need != nullptr (a rank's slice of a sharded RANSAC round): only the measurements that slice's hypotheses draw are multiplied out
+    if (need != nullptr && (int)blockIdx.y < m && !need[blockIdx.y]) return;
     // blockIdx.y = measurement s (rows 2s and 2s+1 share their 13 P rows: loaded once); four consecutive columns per lane:
     // 16-byte (fp32) loads of the gathered P rows, 16-byte stores
     typedef T v4_t __attribute__((ext_vector_type(4)));
@@ -111,11 +113,12 @@ __global__ __launch_bounds__(256) void k_ell_HP_build(int m, int r_pad, const in
 template <typename T>
 __global__ __launch_bounds__(64) void k_ell_G(int r, int r_pad, const int32_t *__restrict__ row_col, const T *__restrict__ row_val,
                                               const T *__restrict__ HP, int ldw, T *__restrict__ dst, int ldg, int add_identity,
-                                              const T *__restrict__ Rd, int lower_only)
+                                              const T *__restrict__ Rd, int lower_only, const int32_t *__restrict__ need = nullptr)
 {
     int a = blockIdx.y;
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= r_pad || a >= r_pad) return;
+    if (need != nullptr && a < r && !need[a >> 1]) return;      // sharded RANSAC: rows of measurements this rank's hypotheses do not draw
     T out;
     if (lower_only && (int)(blockIdx.x * blockDim.x) > a) {
         out = (T)0;                   // strictly above the diagonal: every reader takes (max, min) -- no gathers, defined contents
@@ -1675,28 +1678,28 @@ int launch_ell_HP(pre3_ctx *c, int r, void *dst, bool with_nu)
 }
 
 // rows of all m measurements built and multiplied in one launch (replaces launch_build_rows_impl + launch_ell_HP)
-int launch_ell_HP_build(pre3_ctx *c, void *dst)
+int launch_ell_HP_build(pre3_ctx *c, void *dst, const int32_t *need)
 {
     const int r_pad = round_up(2 * c->m, NB);
     dim3 g(ceil_div(c->ldw / 4, 256), r_pad / 2), b(256);
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_ell_HP_build<double>, g, b, 0, c->stream, c->m, r_pad, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl, c->lm.z, c->lm.h,
-                           c->row_col, (double *)c->row_val, c->row_nu, (const double *)c->P, c->ld, (double *)dst, c->ldw),
+                           c->row_col, (double *)c->row_val, c->row_nu, (const double *)c->P, c->ld, (double *)dst, c->ldw, need),
         hipLaunchKernelGGL(k_ell_HP_build<float>, g, b, 0, c->stream, c->m, r_pad, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl, c->lm.z, c->lm.h,
-                           c->row_col, (float *)c->row_val, c->row_nu, (const float *)c->P, c->ld, (float *)dst, c->ldw));
+                           c->row_col, (float *)c->row_val, c->row_nu, (const float *)c->P, c->ld, (float *)dst, c->ldw, need));
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }
 
-int launch_ell_G(pre3_ctx *c, int r, const void *HPsrc, void *dst, int ldg, int add_identity, const void *Rdense, bool lower_only)
+int launch_ell_G(pre3_ctx *c, int r, const void *HPsrc, void *dst, int ldg, int add_identity, const void *Rdense, bool lower_only, const int32_t *need)
 {
     int r_pad = round_up(r, NB);
     dim3 g(ceil_div(r_pad, 64), r_pad), b(64);
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_ell_G<double>, g, b, 0, c->stream, r, r_pad, c->row_col, (const double *)c->row_val, (const double *)HPsrc,
-                           c->ldw, (double *)dst, ldg, add_identity, (const double *)Rdense, lower_only ? 1 : 0),
+                           c->ldw, (double *)dst, ldg, add_identity, (const double *)Rdense, lower_only ? 1 : 0, need),
         hipLaunchKernelGGL(k_ell_G<float>, g, b, 0, c->stream, r, r_pad, c->row_col, (const float *)c->row_val, (const float *)HPsrc,
-                           c->ldw, (float *)dst, ldg, add_identity, (const float *)Rdense, lower_only ? 1 : 0));
+                           c->ldw, (float *)dst, ldg, add_identity, (const float *)Rdense, lower_only ? 1 : 0, need));
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }

@@ -175,3 +175,37 @@ def test_maximum_configured_size_properties(pre3):
     assert np.array_equal(li, li2) and np.array_equal(hi, hi2) and st2["n_li"] == st["n_li"]
     d = np.sqrt(P.diagonal())
     assert (np.abs(P - P2) / np.outer(d, d)).max() < 2e-3
+
+
+def test_ransac_slices_with_partial_products_equal_the_full_round(pre3, orc):
+    """pre3_ransac_score on a slice multiplies out H*P / H*P*H' only for the measurements that slice draws; supports and inlier masks of
+    the slices, put together, must be those of the full round -- and an LI update after a sliced round must not use the partial products."""
+    import torch
+    N, n_hyp = 90, 64
+    seq = synth.make_sequence(N, 1, n_hyp, seed=123)
+    s = seq["steps"][0]
+    outs = {}
+    for mode in ("full", "sliced"):
+        f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f64", max_hyp=n_hyp)
+        f.set_x_p_k_k(seq["x0"], seq["P0"])
+        f.ekf_prediction(s["u"]); f.search_IC_matches(); f.set_measurements(s["meas_idx"], s["z"])
+        if mode == "full":
+            res = f.ransac_hypotheses(s["hyp"], 1.0, early_exit=False)
+        else:
+            words = (len(s["meas_idx"]) + 31) // 32
+            sup = torch.zeros(n_hyp, dtype=torch.int32, device="cuda")
+            msk = torch.zeros(n_hyp * words, dtype=torch.int32, device="cuda")
+            tot_s, tot_m = torch.zeros_like(sup), torch.zeros_like(msk)
+            for lo, hi in ((0, 7), (7, 8), (8, 40), (40, 64)):                  # ragged slices, one of a single hypothesis
+                f.ransac_score_shard(s["hyp"], 1.0, lo, hi)
+                f.ransac_export(n_hyp, sup.data_ptr(), msk.data_ptr())
+                torch.cuda.synchronize()
+                tot_s += sup; tot_m += msk
+            f.ransac_import(n_hyp, tot_s.data_ptr(), tot_m.data_ptr())
+            res = f.ransac_select(n_hyp, 3, early_exit=False)
+        f.ekf_update_li_inliers()
+        outs[mode] = (res, f.get_x_k_k(), f.get_p_k_k())
+        f.close()
+    a, b = outs["full"], outs["sliced"]
+    assert np.array_equal(a[0]["support"], b[0]["support"]) and np.array_equal(a[0]["li_mask"], b[0]["li_mask"]) and a[0]["best"] == b[0]["best"]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
