@@ -17,6 +17,12 @@ import torch
 import torch.distributed as dist
 
 
+class _DevView:
+    """int32 device memory owned by a pre3 context, for torch.as_tensor (no copy)"""
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i4", "data": (int(ptr), False), "version": 3}
+
+
 def shard_range(n, rank, world):
     """contiguous slice [lo, hi) of n items for `rank` (sizes differ by at most one)"""
     base, rem = divmod(n, world)
@@ -41,18 +47,26 @@ def ransac_sharded(f, hyp, threshold, early_exit=True, device=None):
     hyp = np.ascontiguousarray(hyp, np.int32)
     n_draw, k = hyp.shape
     lo, hi = shard_range(n_draw, rank, world)
-    _, _, words = f.ransac_score_shard(hyp, threshold, lo, hi)
+    sup_ptr, msk_ptr, words = f.ransac_score_shard(hyp, threshold, lo, hi)
     if world > 1:
         backend = dist.get_backend()
         if backend == "nccl":
+            # all-reduce in place on the context's own support / mask buffers (zero-copy views): no export / import copies, no extra syncs
             dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
-            sup = torch.empty(n_draw, dtype=torch.int32, device=dev)
-            msk = torch.empty(n_draw * max(words, 1), dtype=torch.int32, device=dev)
-            f.ransac_export(n_draw, sup.data_ptr(), msk.data_ptr())
+            try:
+                sup = torch.as_tensor(_DevView(sup_ptr, n_draw), device=dev)
+                msk = torch.as_tensor(_DevView(msk_ptr, n_draw * max(words, 1)), device=dev)
+                staged = False
+            except Exception:                               # a torch build without __cuda_array_interface__ import: stage through copies
+                sup = torch.empty(n_draw, dtype=torch.int32, device=dev)
+                msk = torch.empty(n_draw * max(words, 1), dtype=torch.int32, device=dev)
+                f.ransac_export(n_draw, sup.data_ptr(), msk.data_ptr())
+                staged = True
             dist.all_reduce(sup, op=dist.ReduceOp.SUM)
             dist.all_reduce(msk, op=dist.ReduceOp.SUM)      # slices are disjoint: integer sum == bitwise or
             torch.cuda.synchronize()
-            f.ransac_import(n_draw, sup.data_ptr(), msk.data_ptr())
+            if staged:
+                f.ransac_import(n_draw, sup.data_ptr(), msk.data_ptr())
         else:                                               # gloo rehearsal: stage through the host
             sup = torch.empty(n_draw, dtype=torch.int32, device="cuda")
             msk = torch.empty(n_draw * max(words, 1), dtype=torch.int32, device="cuda")
