@@ -153,8 +153,10 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
     A(dmalloc_bytes(&c->G, (size_t)c->rcap * c->rcap * c->esz));
     A(dmalloc_bytes(&c->Smat, (size_t)c->rcap * c->rcap * c->esz));
     A(dmalloc(&c->sel_rows, c->rcap)); A(dmalloc(&c->need, c->capm));
-    A(dmalloc(&c->support, c->caph));
-    A(dmalloc(&c->masks, (size_t)c->caph * c->mask_words_cap));
+    // supports and inlier masks in ONE allocation, the masks right behind the n_draw supports of the current round (ransac_prepare sets
+    // c->masks): a sharded round all-reduces both with a single collective over one contiguous range
+    A(dmalloc(&c->support, (size_t)c->caph + 4 + (size_t)c->caph * c->mask_words_cap));
+    if (rc == PRE3_OK) c->masks = reinterpret_cast<uint32_t *>(c->support + c->caph + 4);
     A(dmalloc(&c->stats, 16));
     A(dmalloc(&c->pred_params, 128));
     {
@@ -276,7 +278,7 @@ int pre3_destroy(pre3_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
                      c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
-                     c->sel_rows, c->support, c->masks, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128, c->need };
+                     c->sel_rows, c->support, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128, c->need };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->pinned_stats) (void)hipHostFree(c->pinned_stats);
     if (c->inbox_host) (void)hipHostFree(c->inbox_host);
@@ -640,6 +642,7 @@ static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, in
         PRE3_HIP(hipMemcpyAsync(c->hyp, c->inbox_host + c->off_hyp, sizeof(int32_t) * n_draw * k, hipMemcpyHostToDevice, c->stream));
         PRE3_HIP(hipEventRecord(c->inbox_copied, c->stream)); c->inbox_pending = true;
     }
+    c->masks = reinterpret_cast<uint32_t *>(c->support + round_up(n_draw, 4));
     int r = 2 * c->m, r_pad = round_up(r, NB);
     if (hi < 0) hi = n_draw;
     if (lo > 0 || hi < n_draw) {
@@ -666,8 +669,7 @@ int pre3_ransac_score(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, double
     PRE3_CHECK(hyp_begin >= 0 && hyp_begin <= hyp_end && hyp_end <= n_draw, PRE3_E_ARG, "ransac: bad hypothesis range [%d,%d) of %d", hyp_begin, hyp_end, n_draw);
     PRE3_TRY(ransac_prepare(c, n_draw, k, hyp, hyp_begin, hyp_end));
     int words = ceil_div(c->m, 32);
-    PRE3_HIP(hipMemsetAsync(c->support, 0, sizeof(int32_t) * n_draw, c->stream));
-    PRE3_HIP(hipMemsetAsync(c->masks, 0, sizeof(uint32_t) * (size_t)n_draw * words, c->stream));
+    PRE3_HIP(hipMemsetAsync(c->support, 0, sizeof(int32_t) * ((size_t)round_up(n_draw, 4) + (size_t)n_draw * words), c->stream));   // supports + masks
     PRE3_TRY(launch_ransac_score_impl(c, k, threshold, hyp_begin, hyp_end, round_up(2 * c->m, NB), c->support, c->masks, words));
     if (support_dev) *support_dev = c->support;
     if (mask_dev) *mask_dev = c->masks;

@@ -53,19 +53,23 @@ def ransac_sharded(f, hyp, threshold, early_exit=True, device=None):
         if backend == "nccl":
             # all-reduce in place on the context's own support / mask buffers (zero-copy views): no export / import copies, no extra syncs
             dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
-            try:
-                sup = torch.as_tensor(_DevView(sup_ptr, n_draw), device=dev)
-                msk = torch.as_tensor(_DevView(msk_ptr, n_draw * max(words, 1)), device=dev)
-                staged = False
-            except Exception:                               # a torch build without __cuda_array_interface__ import: stage through copies
+            gap = (msk_ptr - sup_ptr) // 4                  # the masks follow the supports in one allocation (pre3_ransac_score)
+            both = None
+            if n_draw <= gap <= n_draw + 4:
+                try:
+                    both = torch.as_tensor(_DevView(sup_ptr, gap + n_draw * max(words, 1)), device=dev)
+                except Exception:                           # a torch build that cannot import __cuda_array_interface__ objects
+                    both = None
+            if both is not None:
+                dist.all_reduce(both, op=dist.ReduceOp.SUM)  # ONE collective, in place; slices are disjoint: integer sum == bitwise or
+                torch.cuda.synchronize()
+            else:                                           # stage through copies
                 sup = torch.empty(n_draw, dtype=torch.int32, device=dev)
                 msk = torch.empty(n_draw * max(words, 1), dtype=torch.int32, device=dev)
                 f.ransac_export(n_draw, sup.data_ptr(), msk.data_ptr())
-                staged = True
-            dist.all_reduce(sup, op=dist.ReduceOp.SUM)
-            dist.all_reduce(msk, op=dist.ReduceOp.SUM)      # slices are disjoint: integer sum == bitwise or
-            torch.cuda.synchronize()
-            if staged:
+                dist.all_reduce(sup, op=dist.ReduceOp.SUM)
+                dist.all_reduce(msk, op=dist.ReduceOp.SUM)
+                torch.cuda.synchronize()
                 f.ransac_import(n_draw, sup.data_ptr(), msk.data_ptr())
         else:                                               # gloo rehearsal: stage through the host
             sup = torch.empty(n_draw, dtype=torch.int32, device="cuda")
