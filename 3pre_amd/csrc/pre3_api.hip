@@ -153,6 +153,7 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
     A(dmalloc_bytes(&c->G, (size_t)c->rcap * c->rcap * c->esz));
     A(dmalloc_bytes(&c->Smat, (size_t)c->rcap * c->rcap * c->esz));
     A(dmalloc(&c->sel_rows, c->rcap)); A(dmalloc(&c->need, c->capm));
+    if (rc == PRE3_OK) (void)hipMemset(c->need, 0, sizeof(int32_t) * c->capm);
     // supports and inlier masks in ONE allocation, the masks right behind the n_draw supports of the current round (ransac_prepare sets
     // c->masks): a sharded round all-reduces both with a single collective over one contiguous range
     A(dmalloc(&c->support, (size_t)c->caph + 4 + (size_t)c->caph * c->mask_words_cap));
@@ -620,11 +621,11 @@ int pre3_ic_search(pre3_ctx *c, double thresh, int strict_reference, int32_t *n_
 }
 
 // ---- RANSAC ---------------------------------------------------------------------------------------
-// need[s] = 1 for every measurement position a hypothesis of [lo, hi) draws (need was cleared)
-__global__ void k_mark_needed(const int32_t *__restrict__ hyp, int k, int lo, int hi, int32_t *__restrict__ need)
+// need[s] = tag for every measurement position a hypothesis of [lo, hi) draws (a fresh tag per round: nothing to clear)
+__global__ void k_mark_needed(const int32_t *__restrict__ hyp, int k, int lo, int hi, int32_t *__restrict__ need, int tag)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < (hi - lo) * k) need[hyp[lo * k + t]] = 1;
+    if (t < (hi - lo) * k) need[hyp[lo * k + t]] = tag;
 }
 
 static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, int lo = 0, int hi = -1)
@@ -649,10 +650,10 @@ static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, in
         // a rank's slice of a sharded round: H*P and H*P*H' only for the measurements its hypotheses draw (the scorer of hypothesis h
         // reads the 2k rows of its own landmarks and the entries of G among them, nothing else) -- the part of the round that
         // shrinks with the number of ranks.  The LI update must not gather from these partial products: hp_all_valid stays false.
-        PRE3_HIP(hipMemsetAsync(c->need, 0, sizeof(int32_t) * c->m, c->stream));
-        if (hi > lo) hipLaunchKernelGGL(k_mark_needed, dim3(ceil_div((hi - lo) * k, 256)), dim3(256), 0, c->stream, c->hyp, k, lo, hi, c->need);
-        PRE3_TRY(launch_ell_HP_build(c, c->HP, c->need));
-        PRE3_TRY(launch_ell_G(c, r, c->HP, c->G, r_pad, 0, nullptr, true, c->need));
+        ++c->need_tag;
+        if (hi > lo) hipLaunchKernelGGL(k_mark_needed, dim3(ceil_div((hi - lo) * k, 256)), dim3(256), 0, c->stream, c->hyp, k, lo, hi, c->need, c->need_tag);
+        PRE3_TRY(launch_ell_HP_build(c, c->HP, c->need, c->need_tag));
+        PRE3_TRY(launch_ell_G_hyp(c, k, lo, hi, r_pad));
         c->hp_all_valid = false;
         return PRE3_OK;
     }
@@ -667,9 +668,10 @@ int pre3_ransac_score(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, double
 {
     PRE3_TRY(check_ctx(c));
     PRE3_CHECK(hyp_begin >= 0 && hyp_begin <= hyp_end && hyp_end <= n_draw, PRE3_E_ARG, "ransac: bad hypothesis range [%d,%d) of %d", hyp_begin, hyp_end, n_draw);
-    PRE3_TRY(ransac_prepare(c, n_draw, k, hyp, hyp_begin, hyp_end));
     int words = ceil_div(c->m, 32);
+    PRE3_CHECK(n_draw >= 1 && n_draw <= c->caph, PRE3_E_ARG, "ransac: n_draw=%d exceeds capacity %d", n_draw, c->caph);
     PRE3_HIP(hipMemsetAsync(c->support, 0, sizeof(int32_t) * ((size_t)round_up(n_draw, 4) + (size_t)n_draw * words), c->stream));   // supports + masks
+    PRE3_TRY(ransac_prepare(c, n_draw, k, hyp, hyp_begin, hyp_end));
     PRE3_TRY(launch_ransac_score_impl(c, k, threshold, hyp_begin, hyp_end, round_up(2 * c->m, NB), c->support, c->masks, words));
     if (support_dev) *support_dev = c->support;
     if (mask_dev) *mask_dev = c->masks;

@@ -143,7 +143,7 @@ struct pre3_ctx {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     pre3::KernelTiming kt;
     bool measurements_set = false, projected = false, innovated = false;
-    int32_t *need = nullptr;                      // [capm] sharded RANSAC: 1 where this rank's hypothesis slice draws the measurement
+    int32_t *need = nullptr; int need_tag = 0;    // [capm] sharded RANSAC: need[s] == need_tag where this rank's hypothesis slice draws measurement s
     bool hp_all_valid = false;                    // HP / G hold H*P, H*P*H' of ALL measured rows at the current prior (ransac_prepare)
 };
 
@@ -180,10 +180,11 @@ int launch_jnorm(pre3_ctx *c, int which);
 // rows: ELL rows [r] in c->row_col/row_val with nu in c->row_nu; computes W = H*P (+ nu column),
 // S = H*P*H' + R, Cholesky, W = L^-1 [HP | nu], x += W' y, P -= W'W, Jnorm + normalise.
 int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_dev /*nullable, r_pad x ldw T*/, bool prebuilt = false);
-int launch_ell_HP_build(pre3_ctx *c, void *dst, const int32_t *need = nullptr /* sharded RANSAC: only the measurements flagged here */);
+int launch_ell_HP_build(pre3_ctx *c, void *dst, const int32_t *need = nullptr, int need_tag = 0 /* sharded RANSAC: only the measurements with need[s] == need_tag */);
+int launch_ell_G_hyp(pre3_ctx *c, int k, int lo, int hi, int ldg);                 /* H*P*H' entries among each hypothesis' own rows, hypotheses [lo, hi) */
 int launch_gather_li(pre3_ctx *c, int nsel /* < 0: count read on the device */, int nsel_max, const int32_t *sel_dev, int ldg);
 int launch_ell_HP(pre3_ctx *c, int r, void *dst /*r_pad x ldw*/, bool with_nu);
-int launch_ell_G(pre3_ctx *c, int r, const void *HPsrc, void *dst, int ldg, int add_identity, const void *Rdense, bool lower_only = false, const int32_t *need = nullptr);
+int launch_ell_G(pre3_ctx *c, int r, const void *HPsrc, void *dst, int ldg, int add_identity, const void *Rdense, bool lower_only = false);
 int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior = -1 /* >= 0: also x <- x_prior + W'y (update.m:36) */);
 
 }  // namespace pre3

@@ -60,10 +60,11 @@ __global__ __launch_bounds__(256) void k_ell_HP_build(int m, int r_pad, const in
                                                       const int32_t *__restrict__ lm_off, const double *__restrict__ Hc,
                                                       const double *__restrict__ Hl, const double *__restrict__ z, const double *__restrict__ h,
                                                       int32_t *__restrict__ row_col, T *__restrict__ row_val, double *__restrict__ row_nu,
-                                                      const T *__restrict__ P, int ld, T *__restrict__ dst, int ldw, const int32_t *__restrict__ need = nullptr)
+                                                      const T *__restrict__ P, int ld, T *__restrict__ dst, int ldw, const int32_t *__restrict__ need = nullptr, int need_tag = 0)
 {
-    // need != nullptr (a rank's slice of a sharded RANSAC round): only the measurements that slice's hypotheses draw are multiplied out
-    if (need != nullptr && (int)blockIdx.y < m && !need[blockIdx.y]) return;
+    // need != nullptr (a rank's slice of a sharded RANSAC round): only the measurements that slice's hypotheses draw (need[s] == tag of
+    // this round: no clearing between rounds) are multiplied out
+    if (need != nullptr && (int)blockIdx.y < m && need[blockIdx.y] != need_tag) return;
     // blockIdx.y = measurement s (rows 2s and 2s+1 share their 13 P rows: loaded once); four consecutive columns per lane:
     // 16-byte (fp32) loads of the gathered P rows, 16-byte stores
     typedef T v4_t __attribute__((ext_vector_type(4)));
@@ -113,12 +114,11 @@ __global__ __launch_bounds__(256) void k_ell_HP_build(int m, int r_pad, const in
 template <typename T>
 __global__ __launch_bounds__(64) void k_ell_G(int r, int r_pad, const int32_t *__restrict__ row_col, const T *__restrict__ row_val,
                                               const T *__restrict__ HP, int ldw, T *__restrict__ dst, int ldg, int add_identity,
-                                              const T *__restrict__ Rd, int lower_only, const int32_t *__restrict__ need = nullptr)
+                                              const T *__restrict__ Rd, int lower_only)
 {
     int a = blockIdx.y;
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= r_pad || a >= r_pad) return;
-    if (need != nullptr && a < r && !need[a >> 1]) return;      // sharded RANSAC: rows of measurements this rank's hypotheses do not draw
     T out;
     if (lower_only && (int)(blockIdx.x * blockDim.x) > a) {
         out = (T)0;                   // strictly above the diagonal: every reader takes (max, min) -- no gathers, defined contents
@@ -133,6 +133,27 @@ __global__ __launch_bounds__(64) void k_ell_G(int r, int r_pad, const int32_t *_
         out = (a == b) ? (T)1 : (T)0;
     }
     dst[(size_t)a * ldg + b] = out;
+}
+
+// H*P*H' for a slice of a sharded RANSAC round: only the entries among the 2k rows of each hypothesis of [lo, hi) (the scorer reads nothing
+// else of G), one thread per (hypothesis, pair); the arithmetic of k_ell_G entry by entry, so the values are the full build's.
+template <typename T>
+__global__ __launch_bounds__(256) void k_ell_G_hyp(const int32_t *__restrict__ hyp, int k, int lo, int hi, const int32_t *__restrict__ row_col,
+                                                   const T *__restrict__ row_val, const T *__restrict__ HP, int ldw, T *__restrict__ dst, int ldg)
+{
+    const int np = k * (2 * k + 1);                       // pairs (i >= j) of 2k rows
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (hi - lo) * np) return;
+    const int h = lo + g / np, p = g - (g / np) * np;
+    int i = 0;
+    while ((i + 1) * (i + 2) / 2 <= p) ++i;
+    const int j = p - i * (i + 1) / 2;
+    const int ri = 2 * hyp[h * k + (i >> 1)] + (i & 1), rj = 2 * hyp[h * k + (j >> 1)] + (j & 1);
+    const int a = ri > rj ? ri : rj, b = ri > rj ? rj : ri;
+    T s = (T)0;
+#pragma unroll
+    for (int t = 0; t < ELLW; ++t) s += row_val[b * ELLW + t] * HP[(size_t)a * ldw + row_col[b * ELLW + t]];
+    dst[(size_t)a * ldg + b] = s;
 }
 
 // LI rows are a subset of the measured rows whose H*P and H*P*H' already exist (computed once per step for RANSAC):
@@ -1678,28 +1699,39 @@ int launch_ell_HP(pre3_ctx *c, int r, void *dst, bool with_nu)
 }
 
 // rows of all m measurements built and multiplied in one launch (replaces launch_build_rows_impl + launch_ell_HP)
-int launch_ell_HP_build(pre3_ctx *c, void *dst, const int32_t *need)
+int launch_ell_HP_build(pre3_ctx *c, void *dst, const int32_t *need, int need_tag)
 {
     const int r_pad = round_up(2 * c->m, NB);
     dim3 g(ceil_div(c->ldw / 4, 256), r_pad / 2), b(256);
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_ell_HP_build<double>, g, b, 0, c->stream, c->m, r_pad, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl, c->lm.z, c->lm.h,
-                           c->row_col, (double *)c->row_val, c->row_nu, (const double *)c->P, c->ld, (double *)dst, c->ldw, need),
+                           c->row_col, (double *)c->row_val, c->row_nu, (const double *)c->P, c->ld, (double *)dst, c->ldw, need, need_tag),
         hipLaunchKernelGGL(k_ell_HP_build<float>, g, b, 0, c->stream, c->m, r_pad, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl, c->lm.z, c->lm.h,
-                           c->row_col, (float *)c->row_val, c->row_nu, (const float *)c->P, c->ld, (float *)dst, c->ldw, need));
+                           c->row_col, (float *)c->row_val, c->row_nu, (const float *)c->P, c->ld, (float *)dst, c->ldw, need, need_tag));
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }
 
-int launch_ell_G(pre3_ctx *c, int r, const void *HPsrc, void *dst, int ldg, int add_identity, const void *Rdense, bool lower_only, const int32_t *need)
+int launch_ell_G(pre3_ctx *c, int r, const void *HPsrc, void *dst, int ldg, int add_identity, const void *Rdense, bool lower_only)
 {
     int r_pad = round_up(r, NB);
     dim3 g(ceil_div(r_pad, 64), r_pad), b(64);
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_ell_G<double>, g, b, 0, c->stream, r, r_pad, c->row_col, (const double *)c->row_val, (const double *)HPsrc,
-                           c->ldw, (double *)dst, ldg, add_identity, (const double *)Rdense, lower_only ? 1 : 0, need),
+                           c->ldw, (double *)dst, ldg, add_identity, (const double *)Rdense, lower_only ? 1 : 0),
         hipLaunchKernelGGL(k_ell_G<float>, g, b, 0, c->stream, r, r_pad, c->row_col, (const float *)c->row_val, (const float *)HPsrc,
-                           c->ldw, (float *)dst, ldg, add_identity, (const float *)Rdense, lower_only ? 1 : 0, need));
+                           c->ldw, (float *)dst, ldg, add_identity, (const float *)Rdense, lower_only ? 1 : 0));
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
+int launch_ell_G_hyp(pre3_ctx *c, int k, int lo, int hi, int ldg)
+{
+    if (hi <= lo) return PRE3_OK;
+    dim3 g(ceil_div((hi - lo) * k * (2 * k + 1), 256)), b(256);
+    DISPATCH_T(c,
+        hipLaunchKernelGGL(k_ell_G_hyp<double>, g, b, 0, c->stream, c->hyp, k, lo, hi, c->row_col, (const double *)c->row_val, (const double *)c->HP, c->ldw, (double *)c->G, ldg),
+        hipLaunchKernelGGL(k_ell_G_hyp<float>, g, b, 0, c->stream, c->hyp, k, lo, hi, c->row_col, (const float *)c->row_val, (const float *)c->HP, c->ldw, (float *)c->G, ldg));
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }
