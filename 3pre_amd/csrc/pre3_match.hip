@@ -607,26 +607,35 @@ __global__ void k_ic_stack(int N, const int32_t *__restrict__ has_h, int32_t *__
 
 // Lowe's test (siftmatch.c:122, in float), then the window gate of matching_sift_based.m:119-133 on the i-th match
 // (quirk Q5 needs the RANK of the match: S is read from index_in_info(i)).  One wave, ordered.
-__global__ void k_ic_gate(const int32_t *__restrict__ pred, const double *__restrict__ best,
+__global__ __launch_bounds__(512) void k_ic_gate(const int32_t *__restrict__ pred, const double *__restrict__ best,
                           const double *__restrict__ second, const int32_t *__restrict__ arg, float thresh, int strict,
                           const double *__restrict__ pos, const double *__restrict__ h, const double *__restrict__ S,
                           const int32_t *__restrict__ has_S, double *__restrict__ z, int32_t *__restrict__ ic,
                           int32_t *__restrict__ pairs, int32_t *__restrict__ newk2, int32_t *counts,
                           int32_t *__restrict__ meas_out, double *__restrict__ z_out)
 {
-    const int lane = threadIdx.x, npred = counts[0];
+    // one workgroup, 512 predictions per pass (all of them at N <= 512): the rank of a match among the matches and of an accepted
+    // measurement among the accepted ones come from wave ballots + a prefix over the 8 waves, so the three dependent load levels
+    // (arg -> pos / pred -> S, h) are paid once per pass instead of once per 64 predictions
+    __shared__ int s_ok[8], s_acc[8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, npred = counts[0];
     int base = 0, m = 0;
-    for (int k0 = 0; k0 < npred; k0 += 64) {
-        const int k1 = k0 + lane;
+    for (int k0 = 0; k0 < npred; k0 += 512) {
+        const int k1 = k0 + tid;
         int ok = 0, k2 = -1;
         if (k1 < npred) {
             k2 = arg[k1];
             ok = k2 >= 0 && thresh * (float)best[k1] <= (float)second[k1];
         }
         const unsigned long long b = __ballot(ok);
+        if (lane == 0) s_ok[wv] = __popcll(b);
+        __syncthreads();
+        int off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { const int cw = s_ok[w]; if (w < wv) off += cw; tot += cw; }
         int acc = 0;
         if (ok) {
-            const int c = base + __popcll(b & ((1ull << lane) - 1));
+            const int c = base + off + __popcll(b & ((1ull << lane) - 1));
             const int lm = pred[k1], slm = strict ? pred[c] : lm;
             const double half = has_S[slm] ? ceil(3 * sqrt(S[4 * slm])) : 40.0;
             const double dx = pos[4 * (size_t)k2] - h[2 * lm], dy = pos[4 * (size_t)k2 + 1] - h[2 * lm + 1];
@@ -634,16 +643,22 @@ __global__ void k_ic_gate(const int32_t *__restrict__ pred, const double *__rest
             pairs[3 * c] = k1; pairs[3 * c + 1] = k2; pairs[3 * c + 2] = acc;
             if (acc) { ic[lm] = 1; z[2 * lm] = pos[4 * (size_t)k2]; z[2 * lm + 1] = pos[4 * (size_t)k2 + 1]; newk2[lm] = k2; }
         }
-        base += __popcll(b);
+        base += tot;
         // accepted matches arrive in increasing landmark order (pred is sorted): compact the measurement list for the host
         const unsigned long long ab = __ballot(acc);
+        if (lane == 0) s_acc[wv] = __popcll(ab);
+        __syncthreads();
+        int off2 = 0, tot2 = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { const int cw = s_acc[w]; if (w < wv) off2 += cw; tot2 += cw; }
         if (acc) {
-            const int pm = m + __popcll(ab & ((1ull << lane) - 1));
+            const int pm = m + off2 + __popcll(ab & ((1ull << lane) - 1));
             meas_out[pm] = pred[k1]; z_out[2 * pm] = pos[4 * (size_t)k2]; z_out[2 * pm + 1] = pos[4 * (size_t)k2 + 1];
         }
-        m += __popcll(ab);
+        m += tot2;
+        __syncthreads();                          // s_ok / s_acc are rewritten by the next pass
     }
-    if (lane == 0) { counts[1] = base; counts[2] = m; }
+    if (tid == 0) { counts[1] = base; counts[2] = m; }
 }
 
 // matching_sift_based.m:135: the accepted landmark takes the scan's descriptor
@@ -672,7 +687,7 @@ int launch_ic_search(pre3_ctx *c, double thresh, int strict)
         // rows >= the device-side query count hold stale partials; k_ic_gate only reads the first counts[0] results
         hipLaunchKernelGGL((k_match_reduce_f<double>), dim3(ceil_div(16 * N, 256)), dim3(256), 0, c->stream, N, ntn, (const double *)c->ic_pb,
                            (const double *)c->ic_ps, (const int32_t *)c->ic_pa, 0, c->ic_best, c->ic_second, c->ic_arg);
-        hipLaunchKernelGGL(k_ic_gate, dim3(1), dim3(64), 0, c->stream, c->ic_pred, c->ic_best, c->ic_second, c->ic_arg,
+        hipLaunchKernelGGL(k_ic_gate, dim3(1), dim3(512), 0, c->stream, c->ic_pred, c->ic_best, c->ic_second, c->ic_arg,
                            (float)thresh, strict, c->scan_pos, c->lm.h, c->lm.S, c->lm.has_S, c->lm.z, c->lm.ic, c->ic_pairs, c->ic_newk2,
                            c->ic_counts, c->ic_counts + 4, (double *)(c->ic_counts + 4 + 4 * (size_t)c->capN));
         hipLaunchKernelGGL(k_ic_refresh, dim3(N), dim3(DESC_DIM), 0, c->stream, c->ic_newk2, c->scan_desc, c->bank);
