@@ -240,7 +240,10 @@ __device__ unsigned int g_k9hw[2048];               // HW_ID of wave 0 (CU / SE 
 #define PROBE_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 5) g_probe[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #define PROBE_ACC(k, t0) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_probe[k] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
 #define PROBE_T(k, T_) do { if (threadIdx.x == (T_) && blockIdx.x == 5) g_probe[k] = __builtin_amdgcn_s_memtime(); } while (0)
+// per pipeline step of the panel chain: start / end-of-work stamps of the factor wave (0), the z wave (1) and the first worker wave (2)
+#define PROBE_STEP(k, e) do { if ((threadIdx.x & 63) == 0 && threadIdx.x < 192 && blockIdx.x == 5) g_k9[((k) + 1) * 8 + (threadIdx.x >> 6) * 2 + (e)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
+#define PROBE_STEP(k, e)
 #define PROBE_STAMP(k)
 #define PROBE_ACC(k, t0)
 #define PROBE_T(k, T_)
@@ -259,25 +262,38 @@ __device__ inline float chain_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); 
 __device__ inline double chain_rsqrt(double x) { return fast_rsqrt(x); }
 
 // Panel kernel.  What bounds it is the dependent chain of the 64 columns, not flops, so the chain runs on a
-// dedicated wave with one-step lookahead and everything else is kept off it:
-//   wave 0  (factor wave; lane = row i of the L block and column i of the X block): per 4-column micro-panel it
-//           takes the micro-panel as published by the workers (updated through micro-panel s-1), applies the
-//           update of micro-panel s itself, factors the 4x4 diagonal block in registers, finishes its row of L
-//           (y <- y L4^-T) and its column of X (z <- L4^-1 x) and publishes both;
-//   waves 1-4 (workers; 16x16 lanes, a register-resident 4x4 patch of each 64x64 block per lane) apply the
-//           rank-4 update of micro-panel s to all patches and publish micro-panel s+2 -- concurrently with the
-//           factor wave working on s+1.  ONE workgroup barrier per micro-panel (16 per 64 columns).
-// Every workgroup factors the diagonal block redundantly; workgroup b then owns X = its 64-row block of
-// [S ; HP'] (b = 0: the diagonal block itself).
+// dedicated wave and everything else is kept off it.  The 64 columns are swept in 8 sub-panels of MB = 8:
+//   wave 0  (factor wave; lane = row i of the L block): per sub-panel s it takes the columns as published by the
+//           workers (updated through sub-panel s-2), applies sub-panel s-1's update itself (lookahead; the 8x8
+//           multipliers are a broadcast LDS read of what the wave wrote one step earlier -- no cross-lane VALU work),
+//           then factors right-looking inside the sub-panel: per column one pivot v_readlane, v_rsq, a multiply and
+//           7-c (v_readlane, fma) pairs.  Writes its row of L into Ls and the eight 1/sqrt(pivot) into Rs.
+//   wave 1  (z wave; lane = column i of the workgroup's X block), ONE step behind: x <- L8^-1 (x - lookahead), all
+//           coefficients (the 8x8 diagonal sub-block, the 8x8 block left of it, Rs) broadcast from LDS.
+//   waves 2-5 (workers; 16x16 lanes, a register-resident 4x4 patch of each 64x64 block per lane) apply the rank-8
+//           updates of finished sub-panels to the patches that still matter (patch sets are compile-time: no
+//           predicates -- entries above the diagonal / left of the front carry garbage that nothing reads) and
+//           publish the next sub-panel's columns of L (Pn) and rows of X (Xr).
+// ONE workgroup barrier per step, 10 steps per 64 columns (was 18 with 4-column micro-panels and the X solve on the
+// factor wave).  Every workgroup factors the diagonal block redundantly; workgroup b then owns X = its 64-row block
+// of [S ; HP'] (b = 0: the diagonal block itself).
+constexpr int CH_MB = 8, CH_NSP = NB / CH_MB, CH_NTH = 384;
+template <typename T> struct ChLs { static constexpr int STRIDE = sizeof(T) == 4 ? NB + 4 : NB + 2; };   // rows 16-byte aligned
+template <typename T>
+struct ChPipe {
+    __attribute__((aligned(16))) T Pn[2][NB][CH_MB];   // published sub-panel columns: Pn[par][i][t] = A[i][C+t], updated through sub-panel s-2
+    __attribute__((aligned(16))) T Zt[2][NB][CH_MB];   // final X[C+t][i], transposed for the workers
+    __attribute__((aligned(16))) T Xr[2][CH_MB][NB];   // published rows of X: Xr[par][t][i] = X[C+t][i]
+    __attribute__((aligned(16))) T Rs[2][CH_MB];       // 1/sqrt(pivot) of the sub-panel's columns
+};
 template <typename T>
 struct ChSmem {
-    T Ls[NB][NB + 1];
+    __attribute__((aligned(16))) T Ls[NB][ChLs<T>::STRIDE];
     T Xs[NB][NB + 1];                              // Xs[a][i]
-    __attribute__((aligned(16))) T Pn[2][NB][4];   // published micro-panel columns: Pn[par][i][t] = A[i][C+t]
-    __attribute__((aligned(16))) T Yb[2][NB][4];   // final L[i][C+t]
-    __attribute__((aligned(16))) T Zt[2][NB][4];   // final X[C+t][i]
-    __attribute__((aligned(16))) T Xr[2][4][NB];   // published rows of X
-    T As[NB][NB + 1];                              // operand tiles of the trailing update / of the fused prologue
+    union {
+        T As[NB][NB + 1];                          // operand tiles of the trailing update / of the fused prologue
+        ChPipe<T> pipe;                            // the chain's hand-off buffers (the prologue is over by then)
+    };
     T Bs[NB][NB + 1];                              // Bs[j][a]
 };
 
@@ -289,17 +305,19 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
                                                 void *__restrict__ Wp = nullptr, int nst_total = 0, int ld = 0, void *__restrict__ Sp = nullptr, int sp_stride = 0)
 {
     PROBE_STAMP(0);
-    constexpr int MB = 4, NMP = NB / MB;
-    typedef T v4_t __attribute__((ext_vector_type(4)));
-    auto &Ls = sm.Ls; auto &Xs = sm.Xs; auto &Pn = sm.Pn; auto &Yb = sm.Yb; auto &Zt = sm.Zt; auto &Xr = sm.Xr;
+    constexpr int MB = CH_MB, NSP = CH_NSP;
+    typedef T v4_t __attribute__((ext_vector_type(4), aligned(16)));
+    auto &Ls = sm.Ls; auto &Xs = sm.Xs; auto &Pn = sm.pipe.Pn; auto &Zt = sm.pipe.Zt; auto &Xr = sm.pipe.Xr; auto &Rs = sm.pipe.Rs;
     const int tid = threadIdx.x;
     const int nS = nrb - J - 1;
     const bool isW = b > nS;
     const int c0 = isW ? (b - nS - 1) * NB : 0;
-    const bool worker = tid >= 64;
-    // the factor wave shares its SIMD with worker wave 4: its (latency-bound) instructions must issue the moment they are ready
-    if (!worker) __builtin_amdgcn_s_setprio(3);
-    const int wt = tid - 64;                                  // worker lane id 0..255
+    const int role = tid >> 6;                                // 0: factor wave, 1: z wave, 2..5: workers
+    const bool worker = role >= 2;
+    // the chain waves share their SIMDs with worker waves: their (latency-bound) instructions must issue the moment they are ready
+    if (role == 0) __builtin_amdgcn_s_setprio(3);
+    else if (role == 1) __builtin_amdgcn_s_setprio(2);
+    const int wt = tid - 128;                                 // worker lane id 0..255
     typedef int frag_t __attribute__((ext_vector_type(4)));      // 8 bf16
     const bool planes = sizeof(T) == 4 && Sp != nullptr;       // fp32 with the bf16-split down-date: the pending update multiplies on the bf16 MFMA too
     frag_t fBa[4][3], fBb[4][3], fO[4][3];
@@ -520,147 +538,164 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
                 xs[p][q] = b >= 1 ? Xs[tr + 16 * p][tc + 16 * q] : (T)0;      // xs: row = panel column index a, col = i
             }
     }
-    bool bad = false;
-    T yprev[MB] = { 0, 0, 0, 0 }, zprev[MB] = { 0, 0, 0, 0 };     // factor wave: its row of Y(s) / column of Z(s)
-    // Software pipeline over micro-panels; iteration mp: workers apply micro-panel mp and publish mp+2, the factor
-    // wave works on mp+1.  The two lead-in iterations (mp = -2, -1) only publish / factor.  (Written as one
-    // straight-line body -- no lambdas -- so that the register patches stay in VGPRs.)
-    // fully unrolled for both types: the publish step's patch selects fold to constants (measured: fp64 +10 % over the
-    // compiler's own choice of unrolling by 2)
+    bool bad = false;                               // (As, the prologue's operand tile, is the chain's hand-off buffer from here on)
+    T yprev[MB], zprev[MB];                          // factor wave: its row of Y(s-1); z wave: its column of Z(s-1)
 #pragma unroll
-    for (int mp = -2; mp < NMP; ++mp) {
-        if (mp == 6) { PROBE_T(8, 64); PROBE_T(10, 0); }
-#ifdef PRE3_PROBE
-        if (mp >= 0 && mp < 16 && blockIdx.x == 5) { if (threadIdx.x == 64) g_k9[2 * mp] = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) g_k9[64 + 2 * mp] = __builtin_amdgcn_s_memtime(); }
-#endif
+    for (int t = 0; t < MB; ++t) { yprev[t] = (T)0; zprev[t] = (T)0; }
+    // Software pipeline, fully unrolled (every index below is a compile-time constant).  Step k:
+    //   factor wave: sub-panel k (0 <= k < NSP);   z wave: sub-panel k-1 (1 <= k <= NSP);
+    //   workers: D patches -= Y(k-1) Y(k-1)' for columns >= 8(k+1) (sub-panel k's own columns get it from the factor wave's
+    //            lookahead), publish Pn(k+1);  X patches -= Y(k-2) Z(k-2) for rows >= 8k, publish Xr(k).
+#pragma unroll
+    for (int k = -1; k <= NSP; ++k) {
+        PROBE_STEP(k, 0);
         if (worker) {
-            if (mp >= 0) {
-                const int C = MB * mp, par = mp & 1;
+            if (k >= 1 && k + 1 <= NSP - 1) {
+                const int C = MB * (k - 1), q0 = (C + 2 * MB) >> 4;
                 T Yi[4][MB], Yj[4][MB];
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const v4_t a4 = *reinterpret_cast<const v4_t *>(&Yb[par][tr + 16 * p][0]);
-                    const v4_t b4 = *reinterpret_cast<const v4_t *>(&Yb[par][tc + 16 * p][0]);
+                for (int p = q0; p < 4; ++p) {
+                    const v4_t a0 = *reinterpret_cast<const v4_t *>(&Ls[tr + 16 * p][C]), a1 = *reinterpret_cast<const v4_t *>(&Ls[tr + 16 * p][C + 4]);
+                    const v4_t b0 = *reinterpret_cast<const v4_t *>(&Ls[tc + 16 * p][C]), b1 = *reinterpret_cast<const v4_t *>(&Ls[tc + 16 * p][C + 4]);
 #pragma unroll
-                    for (int t = 0; t < MB; ++t) { Yi[p][t] = a4[t]; Yj[p][t] = b4[t]; }
+                    for (int t = 0; t < 4; ++t) { Yi[p][t] = a0[t]; Yi[p][4 + t] = a1[t]; Yj[p][t] = b0[t]; Yj[p][4 + t] = b1[t]; }
                 }
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
+                for (int p = q0; p < 4; ++p)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int i = tr + 16 * p, j = tc + 16 * q;
-                        if (j >= C + MB && j <= i) {
-                            T acc = lv[p][q];
+                    for (int q = q0; q <= p; ++q) {
+                        T acc = lv[p][q];
 #pragma unroll
-                            for (int t = 0; t < MB; ++t) acc -= Yi[p][t] * Yj[q][t];
-                            lv[p][q] = acc;
-                        }
-                    }
-                if (b >= 1) {
-                    T Zc[4][MB];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const v4_t z4 = *reinterpret_cast<const v4_t *>(&Zt[par][tc + 16 * q][0]);
-#pragma unroll
-                        for (int t = 0; t < MB; ++t) Zc[q][t] = z4[t];
-                    }
-#pragma unroll
-                    for (int p = 0; p < 4; ++p)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (tr + 16 * p >= C + MB) {
-                                T acc = xs[p][q];
-#pragma unroll
-                                for (int t = 0; t < MB; ++t) acc -= Yi[p][t] * Zc[q][t];
-                                xs[p][q] = acc;
-                            }
-                }
-            }
-            if (mp + 2 < NMP) {
-                // publish micro-panel mp+2: columns C..C+3 of L (all rows) and rows C..C+3 of X, from the patches
-                const int C = MB * (mp + 2), par = (mp + 2) & 1, hq = C >> 4, grp = (C >> 2) & 3;
-                if ((tc >> 2) == grp) {
-                    const int t = tc & 3;
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) Pn[par][tr + 16 * p][t] = hq == 0 ? lv[p][0] : hq == 1 ? lv[p][1] : hq == 2 ? lv[p][2] : lv[p][3];
-                }
-                if (b >= 1 && (tr >> 2) == grp) {
-                    const int t = tr & 3;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) Xr[par][t][tc + 16 * q] = hq == 0 ? xs[0][q] : hq == 1 ? xs[1][q] : hq == 2 ? xs[2][q] : xs[3][q];
-                }
-            }
-        } else if (mp + 1 >= 0 && mp + 1 < NMP) {
-            // factor wave, micro-panel mp+1
-            const int fm = mp + 1, C = MB * fm, par = fm & 1, i = tid;
-            T pr[MB], xr[MB];
-            {
-                const v4_t v = *reinterpret_cast<const v4_t *>(&Pn[par][i][0]);
-#pragma unroll
-                for (int t = 0; t < MB; ++t) pr[t] = v[t];
-            }
-#pragma unroll
-            for (int t = 0; t < MB; ++t) xr[t] = b >= 1 ? Xr[par][t][i] : (T)0;
-            if (fm > 0) {
-                // lookahead: the published values carry the updates of micro-panels < fm-1; apply micro-panel fm-1
-                // here.  L[C+t][C-4+u] is lane C+t's own yprev[u]: wave-uniform lane reads, no LDS.
-#pragma unroll
-                for (int t = 0; t < MB; ++t)
-#pragma unroll
-                    for (int u = 0; u < MB; ++u) {
-                        const T l = rdlane(yprev[u], C + t);
-                        pr[t] -= yprev[u] * l; xr[t] -= l * zprev[u];
+                        for (int t = 0; t < MB; ++t) acc -= Yi[p][t] * Yj[q][t];
+                        lv[p][q] = acc;
                     }
             }
-            // the 4x4 diagonal block = rows C..C+3 of the updated micro-panel, i.e. lanes C..C+3
-            T d[MB][MB], rs[MB];
+            if (k + 1 <= NSP - 1) {
+                // publish sub-panel k+1: columns C..C+7 of L (all rows), from the patches
+                const int C = MB * (k + 1), par = (k + 1) & 1, hq = C >> 4, half = (C >> 3) & 1;
+                if ((tc >> 3) == half) {
 #pragma unroll
-            for (int u = 0; u < MB; ++u)
-#pragma unroll
-                for (int w2 = 0; w2 <= u; ++w2) d[u][w2] = rdlane(pr[w2], C + u);
-#pragma unroll
-            for (int c = 0; c < MB; ++c) {
-                T piv = d[c][c];
-                if (!(piv > (T)0)) { bad = true; piv = (T)1; }
-                rs[c] = chain_rsqrt(piv);
-#pragma unroll
-                for (int u = c + 1; u < MB; ++u) d[u][c] *= rs[c];
-#pragma unroll
-                for (int u = c + 1; u < MB; ++u)
-#pragma unroll
-                    for (int w2 = c + 1; w2 <= u; ++w2) d[u][w2] -= d[u][c] * d[w2][c];
-            }
-            // row of L: y <- y L4^-T ; column of X: z <- L4^-1 x   (entries u < t are already this micro-panel's)
-#pragma unroll
-            for (int t = 0; t < MB; ++t) {
-                T ay = pr[t], az = xr[t];
-#pragma unroll
-                for (int u = 0; u < t; ++u) { ay -= yprev[u] * d[t][u]; az -= d[t][u] * zprev[u]; }
-                yprev[t] = ay * rs[t];
-                zprev[t] = az * rs[t];
-            }
-            if (i < C + MB) {          // rows of the diagonal block: entries right of the diagonal are zero
-#pragma unroll
-                for (int t = 0; t < MB; ++t) if (t > i - C) yprev[t] = (T)0;
-            }
-            __builtin_amdgcn_wave_barrier();
-            *reinterpret_cast<v4_t *>(&Yb[par][i][0]) = v4_t{ yprev[0], yprev[1], yprev[2], yprev[3] };
-            if (i >= C) {
-#pragma unroll
-                for (int t = 0; t < MB; ++t) Ls[i][C + t] = yprev[t];
+                    for (int p = 0; p < 4; ++p) Pn[par][tr + 16 * p][tc & 7] = lv[p][hq];
+                }
             }
             if (b >= 1) {
-                *reinterpret_cast<v4_t *>(&Zt[par][i][0]) = v4_t{ zprev[0], zprev[1], zprev[2], zprev[3] };
+                if (k >= 2 && k <= NSP - 1) {
+                    const int C = MB * (k - 2), par = (k - 2) & 1, p0 = (C + 2 * MB) >> 4;
+                    T Yi[4][MB], Zc[4][MB];
 #pragma unroll
-                for (int t = 0; t < MB; ++t) Xs[C + t][i] = zprev[t];
+                    for (int p = p0; p < 4; ++p) {
+                        const v4_t a0 = *reinterpret_cast<const v4_t *>(&Ls[tr + 16 * p][C]), a1 = *reinterpret_cast<const v4_t *>(&Ls[tr + 16 * p][C + 4]);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { Yi[p][t] = a0[t]; Yi[p][4 + t] = a1[t]; }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const v4_t z0 = *reinterpret_cast<const v4_t *>(&Zt[par][tc + 16 * q][0]), z1 = *reinterpret_cast<const v4_t *>(&Zt[par][tc + 16 * q][4]);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { Zc[q][t] = z0[t]; Zc[q][4 + t] = z1[t]; }
+                    }
+#pragma unroll
+                    for (int p = p0; p < 4; ++p)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            T acc = xs[p][q];
+#pragma unroll
+                            for (int t = 0; t < MB; ++t) acc -= Yi[p][t] * Zc[q][t];
+                            xs[p][q] = acc;
+                        }
+                }
+                if (k >= 0 && k <= NSP - 1) {
+                    // publish rows C..C+7 of X
+                    const int C = MB * k, par = k & 1, hp = C >> 4, half = (C >> 3) & 1;
+                    if ((tr >> 3) == half) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) Xr[par][tr & 7][tc + 16 * q] = xs[hp][q];
+                    }
+                }
             }
+        } else if (role == 0) {
+            if (k >= 0 && k < NSP) {
+                const int C = MB * k, par = k & 1, i = tid;
+                T a[MB], y[MB], rsv[MB];
+                {
+                    const v4_t v0 = *reinterpret_cast<const v4_t *>(&Pn[par][i][0]), v1 = *reinterpret_cast<const v4_t *>(&Pn[par][i][4]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { a[t] = v0[t]; a[4 + t] = v1[t]; }
+                }
+                if (k > 0) {
+                    // lookahead: the published columns carry the updates of sub-panels < k-1; sub-panel k-1 is applied here.  The
+                    // multipliers L[C+t][C-8+u] are rows C..C+7 of what this wave stored one step ago: a broadcast read.
+#pragma unroll
+                    for (int t = 0; t < MB; ++t) {
+                        const v4_t l0 = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB]), l1 = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB + 4]);
+                        T acc = a[t];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc -= yprev[u] * l0[u];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc -= yprev[4 + u] * l1[u];
+                        a[t] = acc;
+                    }
+                }
+                // right-looking inside the sub-panel; rows above the diagonal compute garbage that nothing reads
+#pragma unroll
+                for (int c = 0; c < MB; ++c) {
+                    T piv = rdlane(a[c], C + c);
+                    if (!(piv > (T)0)) { bad = true; piv = (T)1; }
+                    rsv[c] = chain_rsqrt(piv);
+                    y[c] = a[c] * rsv[c];
+#pragma unroll
+                    for (int t = c + 1; t < MB; ++t) a[t] -= y[c] * rdlane(y[c], C + t);
+                }
+                *reinterpret_cast<v4_t *>(&Ls[i][C]) = v4_t{ y[0], y[1], y[2], y[3] };
+                *reinterpret_cast<v4_t *>(&Ls[i][C + 4]) = v4_t{ y[4], y[5], y[6], y[7] };
+                if (i == 0) {
+                    *reinterpret_cast<v4_t *>(&Rs[par][0]) = v4_t{ rsv[0], rsv[1], rsv[2], rsv[3] };
+                    *reinterpret_cast<v4_t *>(&Rs[par][4]) = v4_t{ rsv[4], rsv[5], rsv[6], rsv[7] };
+                }
+#pragma unroll
+                for (int t = 0; t < MB; ++t) yprev[t] = y[t];
+            }
+        } else if (b >= 1 && k >= 1 && k <= NSP) {
+            // z wave, sub-panel k-1: z <- L8^-1 (x - lookahead)
+            const int s2 = k - 1, C = MB * s2, par = s2 & 1, i = tid - 64;
+            T x[MB], z[MB];
+#pragma unroll
+            for (int t = 0; t < MB; ++t) x[t] = Xr[par][t][i];
+            if (s2 > 0) {
+#pragma unroll
+                for (int t = 0; t < MB; ++t) {
+                    const v4_t l0 = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB]), l1 = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB + 4]);
+                    T acc = x[t];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc -= l0[u] * zprev[u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc -= l1[u] * zprev[4 + u];
+                    x[t] = acc;
+                }
+            }
+            const v4_t r0 = *reinterpret_cast<const v4_t *>(&Rs[par][0]), r1 = *reinterpret_cast<const v4_t *>(&Rs[par][4]);
+#pragma unroll
+            for (int t = 0; t < MB; ++t) {
+                T acc = x[t];
+                if (t > 0) {
+                    const v4_t l0 = *reinterpret_cast<const v4_t *>(&Ls[C + t][C]);
+#pragma unroll
+                    for (int u = 0; u < 4 && u < t; ++u) acc -= l0[u] * z[u];
+                }
+                if (t > 4) {
+                    const v4_t l1 = *reinterpret_cast<const v4_t *>(&Ls[C + t][C + 4]);
+#pragma unroll
+                    for (int u = 4; u < t; ++u) acc -= l1[u - 4] * z[u];
+                }
+                z[t] = acc * (t < 4 ? r0[t & 3] : r1[t & 3]);
+            }
+            *reinterpret_cast<v4_t *>(&Zt[par][i][0]) = v4_t{ z[0], z[1], z[2], z[3] };
+            *reinterpret_cast<v4_t *>(&Zt[par][i][4]) = v4_t{ z[4], z[5], z[6], z[7] };
+#pragma unroll
+            for (int t = 0; t < MB; ++t) { Xs[C + t][i] = z[t]; zprev[t] = z[t]; }
         }
-        if (mp == 6) { PROBE_T(9, 64); PROBE_T(11, 0); }
-#ifdef PRE3_PROBE
-        if (mp >= 0 && mp < 16 && blockIdx.x == 5) { if (threadIdx.x == 64) g_k9[2 * mp + 1] = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) g_k9[64 + 2 * mp + 1] = __builtin_amdgcn_s_memtime(); }
-#endif
+        PROBE_STEP(k, 1);
         __syncthreads();
-        if (mp == 6) { PROBE_T(12, 0); }
     }
     PROBE_STAMP(2);
     if (bad && tid == 0 && b == 0) atomicExch(status, 1);
@@ -669,7 +704,7 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
             while ((int)(__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(8);
         }
         __syncthreads();
-        for (int idx = tid; idx < NB * NB; idx += 320) {
+        for (int idx = tid; idx < NB * NB; idx += CH_NTH) {
             int i = idx >> 6, a2 = idx & 63;
             S[(size_t)(J * NB + i) * lds + J * NB + a2] = a2 <= i ? Ls[i][a2] : (T)0;
         }
@@ -678,14 +713,14 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
     if (!isW) {
         int rb = J + b;
         typedef T st4_t __attribute__((ext_vector_type(4)));
-        for (int idx = tid; idx < NB * NB / 4; idx += 320) {             // 16- / 32-byte stores: a quarter of the store instructions
+        for (int idx = tid; idx < NB * NB / 4; idx += CH_NTH) {             // 16- / 32-byte stores: a quarter of the store instructions
             const int i = idx >> 4, a2 = (idx & 15) * 4;
             *reinterpret_cast<st4_t *>(S + (size_t)(rb * NB + i) * lds + J * NB + a2) = st4_t{ Xs[a2][i], Xs[a2 + 1][i], Xs[a2 + 2][i], Xs[a2 + 3][i] };
         }
         if constexpr (sizeof(T) == 4) {
             if (Sp != nullptr) {           // the next launches' pending updates read this block as bf16 planes: [k-step][plane][32-row half][lane]
                 bf16x8_t *base = static_cast<bf16x8_t *>(Sp) + ((size_t)rb * sp_stride + J) * B3_SGRAN;
-                for (int idx = tid; idx < 512; idx += 320) {
+                for (int idx = tid; idx < 512; idx += CH_NTH) {
                     const int q = idx >> 7, fl = (idx >> 6) & 1, l = idx & 63, r = l & 31, h = l >> 5;
                     float x[8];
 #pragma unroll
@@ -696,7 +731,7 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
         }
     } else {
         typedef T st4_t __attribute__((ext_vector_type(4)));
-        for (int idx = tid; idx < NB * NB / 4; idx += 320) {
+        for (int idx = tid; idx < NB * NB / 4; idx += CH_NTH) {
             const int a2 = idx >> 4, i = (idx & 15) * 4;
             *reinterpret_cast<st4_t *>(W + (size_t)(J * NB + a2) * ldw + c0 + i) = st4_t{ Xs[a2][i], Xs[a2][i + 1], Xs[a2][i + 2], Xs[a2][i + 3] };
         }
@@ -706,7 +741,7 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
             // Strip = half a 128-column block: fragments 2*half, 2*half+1 of 4 stages; the nu strip lives in an extra column block.
             if (Wp != nullptr && (Sp != nullptr || J == nrb - 1) && c0 < ld + NB) {
                 bf16x8_t *base = static_cast<bf16x8_t *>(Wp) + ((size_t)(c0 >> 7) * nst_total + 4 * J) * B3_GRAN + ((c0 >> 6) & 1) * 128;
-                for (int idx = tid; idx < 512; idx += 320) {
+                for (int idx = tid; idx < 512; idx += CH_NTH) {
                     const int q = idx >> 7, fl = (idx >> 6) & 1, l = idx & 63, r = l & 31, h = l >> 5;
                     float x[8];
 #pragma unroll
@@ -905,28 +940,12 @@ __device__ __forceinline__ void chol_trail_body(T (&As)[NB][NB + 1], T (&Bs)[NB]
 }
 
 
-template <typename T>
-__global__ __launch_bounds__(320) void k_chol_panel(T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb,
-                                                    int32_t *__restrict__ status, unsigned int *__restrict__ arrive, unsigned int target)
-{
-    __shared__ ChSmem<T> sm;
-    chol_panel_body<T, false>(sm, S, lds, W, ldw, J, nrb, status, blockIdx.x, arrive, target);
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_chol_trail(T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb, int nW)
-{
-    __shared__ T As[NB][NB + 1];
-    __shared__ T Bs[NB][NB + 1];
-    chol_trail_body<T>(As, Bs, S, lds, W, ldw, J, J + 1, nrb, nW, blockIdx.x);
-}
-
 // One launch per panel (lookahead form): workgroups [0, nP) factor panel J -- first applying the K = J column of panel
 // J-1's trailing update to their own blocks (PRO) -- while workgroups [nP, ...) apply the rest of panel J-1's trailing
 // update (column blocks >= J+1), which nothing in this launch reads.  The dependent chain is then 1 launch per panel
 // instead of 2, and the wide update runs in the shadow of the (latency-bound) panel.
 template <typename T>
-__global__ __launch_bounds__(320) void k_chol_step(T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb, int nW,
+__global__ __launch_bounds__(CH_NTH) void k_chol_step(T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb, int nW,
                                                    int nP, int32_t *__restrict__ status, unsigned int *__restrict__ arrive, unsigned int target,
                                                    int nPT, void *__restrict__ Wp, int nst_total, int ncb, int ld_split, void *__restrict__ Sp, int sp_stride)
 {
@@ -1739,9 +1758,8 @@ int launch_ell_G_hyp(pre3_ctx *c, int k, int lo, int hi, int ldg)
 static int launch_chol_solve(pre3_ctx *c, int r_pad)
 {
     int nrb = r_pad / NB, nW = c->ldw / NB;
-    static const int form = [] { const char *e = getenv("PRE3_CHOL_FORM"); return e ? atoi(e) : 1; }();   // 1: lookahead (default), 0: panel + trail launches
     c->split_rows = 0;
-    if (form == 1) {
+    {
         const bool split = c->k9_b3 && c->dtype == PRE3_F32 && c->Wp != nullptr;
         static const int pro_env = getenv("PRE3_CHOL_PRO_B3") ? atoi(getenv("PRE3_CHOL_PRO_B3")) : 1;
         const bool pro_planes = split && pro_env && c->Sp != nullptr;       // pending updates on the bf16 MFMA as well
@@ -1758,7 +1776,7 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad)
                 hipLaunchKernelGGL(k_chol_trail_b3, dim3(nT), dim3(256), 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J - 1, J + 1, nrb, nW,
                                    c->Wp, c->rcap / B3_BK, c->Sp, c->rcap / NB);
             const int nT_in = own_trail ? 0 : nT;
-            dim3 g(nP + nT_in + 4 * ncb), bP(320);
+            dim3 g(nP + nT_in + 4 * ncb), bP(CH_NTH);
             c->chol_target += (unsigned)(nP - 1);                           // every non-diagonal workgroup of the panel arrives once
             DISPATCH_T(c,
                 hipLaunchKernelGGL(k_chol_step<double>, g, bP, 0, c->stream, (double *)c->Smat, r_pad, (double *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
@@ -1770,22 +1788,6 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad)
         PRE3_HIP(hipGetLastError());
         return PRE3_OK;
     }
-    for (int J = 0; J < nrb; ++J) {
-        int nS = nrb - J - 1;
-        dim3 gA(1 + nS + nW), b(256), bP(320);
-        c->chol_target += (unsigned)(nS + nW);
-        DISPATCH_T(c,
-            hipLaunchKernelGGL(k_chol_panel<double>, gA, bP, 0, c->stream, (double *)c->Smat, r_pad, (double *)c->W, c->ldw, J, nrb, c->stats + 6, c->chol_arrive, c->chol_target),
-            hipLaunchKernelGGL(k_chol_panel<float>, gA, bP, 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J, nrb, c->stats + 6, c->chol_arrive, c->chol_target));
-        if (nS > 0) {
-            dim3 gB(nS * (nS + 1) / 2 + nS * nW);
-            DISPATCH_T(c,
-                hipLaunchKernelGGL(k_chol_trail<double>, gB, b, 0, c->stream, (double *)c->Smat, r_pad, (double *)c->W, c->ldw, J, nrb, nW),
-                hipLaunchKernelGGL(k_chol_trail<float>, gB, b, 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J, nrb, nW));
-        }
-    }
-    PRE3_HIP(hipGetLastError());
-    return PRE3_OK;
 }
 
 int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
