@@ -234,15 +234,24 @@ __device__ inline double fast_rsqrt(double x)
 
 #ifdef PRE3_PROBE
 __device__ unsigned long long g_probe[16];
+__device__ int g_probe_block = 5;
+__device__ int g_rt_on = 0;                         // pre3_debug_rt(1): stamp every workgroup of the panel-2 launch                   // the workgroup whose panel phases are stamped
 __device__ unsigned long long g_k9[64 * 8 * 4];
 __device__ unsigned long long g_k9rt[2048 * 4];     // s_memrealtime (100 MHz, chip-wide) per workgroup of the one-tile kernel
 __device__ unsigned int g_k9hw[2048];               // HW_ID of wave 0 (CU / SE / XCC placement)
-#define PROBE_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 5) g_probe[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PROBE_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == g_probe_block) { g_probe[k] = __builtin_amdgcn_s_memtime(); g_k9[256 + J * 8 + (k)] = g_probe[k]; } } while (0)    /* inside chol_panel_body: per panel J */
 #define PROBE_ACC(k, t0) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_probe[k] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
-#define PROBE_T(k, T_) do { if (threadIdx.x == (T_) && blockIdx.x == 5) g_probe[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PROBE_T(k, T_) do { if (threadIdx.x == (T_) && blockIdx.x == g_probe_block) g_probe[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifdef PRE3_PROBE_STEPS
 // per pipeline step of the panel chain: start / end-of-work stamps of the factor wave (0), the z wave (1) and the first worker wave (2)
-#define PROBE_STEP(k, e) do { if ((threadIdx.x & 63) == 0 && threadIdx.x < 192 && blockIdx.x == 5) g_k9[((k) + 1) * 8 + (threadIdx.x >> 6) * 2 + (e)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PROBE_STEP(k, e) do { if ((threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) >= 4) && blockIdx.x == g_probe_block) g_k9[((k) + 1) * 8 + ((threadIdx.x >> 6) == 4 ? 0 : (threadIdx.x >> 6) == 5 ? 1 : 2) * 2 + (e)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PROBE_F(k, j) do { if ((k) == 3 && (threadIdx.x & 63) == 0 && blockIdx.x == g_probe_block) { __builtin_amdgcn_sched_barrier(0); g_k9[100 + (j)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
+#define PROBE_F(k, j)
+#define PROBE_STEP(k, e)
+#endif
+#else
+#define PROBE_F(k, j)
 #define PROBE_STEP(k, e)
 #define PROBE_STAMP(k)
 #define PROBE_ACC(k, t0)
@@ -260,6 +269,9 @@ __device__ inline double rdlane(double v, int l)
 // hardware 1/sqrt: fp32 takes v_rsq_f32 as is (1 ulp), fp64 refines v_rsq_f64 twice
 __device__ inline float chain_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ inline double chain_rsqrt(double x) { return fast_rsqrt(x); }
+// hardware 1/x for the pivots: fp32 takes v_rcp_f32 as is (1 ulp), fp64 refines v_rcp_f64 twice
+__device__ inline float chain_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ inline double chain_rcp(double x) { double r = __builtin_amdgcn_rcp(x); r = r * (2.0 - x * r); return r * (2.0 - x * r); }
 
 // Panel kernel.  What bounds it is the dependent chain of the 64 columns, not flops, so the chain runs on a
 // dedicated wave and everything else is kept off it.  The 64 columns are swept in 8 sub-panels of MB = 8:
@@ -278,6 +290,11 @@ __device__ inline double chain_rsqrt(double x) { return fast_rsqrt(x); }
 // factor wave).  Every workgroup factors the diagonal block redundantly; workgroup b then owns X = its 64-row block
 // of [S ; HP'] (b = 0: the diagonal block itself).
 constexpr int CH_MB = 8, CH_NSP = NB / CH_MB, CH_NTH = 384;
+#ifndef CH_EXP_Z
+#define CH_EXP_Z 1          // timing experiments (tools/probe_panel.hip): 0 = the z wave idles
+#define CH_EXP_WX 1         // 0 = the workers skip the X tiles
+#define CH_EXP_F 1          // 0 = the factor wave idles
+#endif
 template <typename T> struct ChLs { static constexpr int STRIDE = sizeof(T) == 4 ? NB + 4 : NB + 2; };   // rows 16-byte aligned
 template <typename T>
 struct ChPipe {
@@ -297,6 +314,117 @@ struct ChSmem {
     T Bs[NB][NB + 1];                              // Bs[j][a]
 };
 
+// Worker waves of the panel chain.  The four 32x32 tiles of the diagonal block D and of the workgroup's X block live as MFMA
+// accumulators (wave WV owns tile (WV>>1, WV&1) of both; D's tile above the diagonal is dead).  A finished sub-panel is a rank-8
+// update: D -= Y Y', X -= Y Z on the fp32 / fp64 matrix cores (the f32-input MFMA is an exact fma chain).  MFMA step j multiplies
+// k = NJ*kk(lane) + j, so that a lane's NJ operand values are contiguous: ONE 16-byte LDS read per operand and rank-8 update,
+// against 26 per lane and step with register patches on the VALU -- the LDS queue, not arithmetic, was what the chain waited for.
+template <typename T> struct ChW {
+    using M = Mfma<T>;
+    static constexpr int NBLK = 32 / M::BLK, NJ = CH_MB / M::KS;
+    typedef T vk_t __attribute__((ext_vector_type(CH_MB / M::KS), aligned(16)));
+    typedef typename M::acc_t acc_t;
+};
+
+template <typename T, int WV>
+__device__ __forceinline__ void ch_worker_load(ChSmem<T> &sm, typename ChW<T>::acc_t (&accD)[ChW<T>::NBLK][ChW<T>::NBLK],
+                                               typename ChW<T>::acc_t (&accX)[ChW<T>::NBLK][ChW<T>::NBLK], const int lane, const bool hasX)
+{
+    using M = Mfma<T>;
+    constexpr int NBLK = ChW<T>::NBLK, w0 = (WV >> 1) * 32, w1 = (WV & 1) * 32;
+    const int cl = M::col(lane);
+#pragma unroll
+    for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+        for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+            for (int e = 0; e < M::NREG; ++e) {
+                const int r = p * M::BLK + M::row(lane, e), c = q * M::BLK + cl;
+                accD[p][q][e] = WV != 1 ? sm.Ls[w0 + r][w1 + c] : (T)0;
+                accX[p][q][e] = hasX ? sm.Xs[w0 + r][w1 + c] : (T)0;           // Xs[a][i]: tile rows = panel columns a, tile columns = i
+            }
+}
+
+template <typename T, int WV>
+__device__ __forceinline__ void ch_worker_step(const int k, ChSmem<T> &sm, typename ChW<T>::acc_t (&accD)[ChW<T>::NBLK][ChW<T>::NBLK],
+                                               typename ChW<T>::acc_t (&accX)[ChW<T>::NBLK][ChW<T>::NBLK], const int lane, const bool hasX)
+{
+    using M = Mfma<T>;
+    typedef typename ChW<T>::vk_t vk_t;
+    constexpr int NBLK = ChW<T>::NBLK, NJ = ChW<T>::NJ, MB = CH_MB, NSP = CH_NSP, w0 = (WV >> 1) * 32, w1 = (WV & 1) * 32;
+    const int cl = M::col(lane), kq = M::kk(lane) * NJ;
+    // D -= Y(k-1) Y(k-1)' where the tile still has columns >= 8(k+1) (sub-panel k's own columns get it from the factor wave's lookahead);
+    // X -= Y(k-2) Z(k-2) where the tile still has rows >= 8k (sub-panel k-1's rows get it from the z wave's lookahead).
+    // All operands are requested first, the X products issue first and the D products behind them, so that ONE LDS round trip and
+    // the matrix pipe's latency are paid per step (the two dependent read -> MFMA -> store sequences used to run back to back).
+    const bool doD = WV != 1 && k >= 1 && k + 1 <= NSP - 1 && w1 + 32 > MB * (k + 1);
+    const bool doX = hasX && CH_EXP_WX && k >= 2 && k <= NSP - 1 && w0 + 32 > MB * k;
+    vk_t aD[NBLK], bD[NBLK], aX[NBLK], bX[NBLK];
+    if (doD) {
+        const int C = MB * (k - 1);
+#pragma unroll
+        for (int p = 0; p < NBLK; ++p) {
+            aD[p] = *reinterpret_cast<const vk_t *>(&sm.Ls[w0 + p * M::BLK + cl][C + kq]);
+            bD[p] = *reinterpret_cast<const vk_t *>(&sm.Ls[w1 + p * M::BLK + cl][C + kq]);
+        }
+    }
+    if (doX) {
+        const int C = MB * (k - 2), par = (k - 2) & 1;
+#pragma unroll
+        for (int p = 0; p < NBLK; ++p) {
+            aX[p] = *reinterpret_cast<const vk_t *>(&sm.Ls[w0 + p * M::BLK + cl][C + kq]);
+            bX[p] = *reinterpret_cast<const vk_t *>(&sm.pipe.Zt[par][w1 + p * M::BLK + cl][kq]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (doX) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+                for (int q = 0; q < NBLK; ++q) M::mma(-aX[p][j], bX[q][j], accX[p][q]);
+    }
+    if (doD) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+                for (int q = 0; q < NBLK; ++q) M::mma(-aD[p][j], bD[q][j], accD[p][q]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // publish rows Cr..Cr+7 of X (their products were issued first)
+    if (hasX && CH_EXP_WX && k >= 0 && k <= NSP - 1) {
+        const int Cr = MB * k, par = k & 1;
+        if (Cr >= w0 && Cr < w0 + 32) {
+            const int r8 = Cr - w0;
+#pragma unroll
+            for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+                for (int e = 0; e < M::NREG; ++e)
+                    if ((p * M::BLK + M::row(0, e)) / MB * MB == r8) {       // the 8-row group this register belongs to (same for all lanes)
+                        const int t = p * M::BLK + M::row(lane, e) - r8;
+#pragma unroll
+                        for (int q = 0; q < NBLK; ++q) sm.pipe.Xr[par][t][w1 + q * M::BLK + cl] = accX[p][q][e];
+                    }
+        }
+    }
+    // publish sub-panel k+1: columns Cn..Cn+7 of D (the tile's rows), from the accumulators
+    if (WV != 1 && k + 1 <= NSP - 1) {
+        const int Cn = MB * (k + 1), par = (k + 1) & 1;
+        if (Cn >= w1 && Cn < w1 + 32) {
+            const int q = (Cn - w1) / M::BLK, c8 = (Cn - w1) % M::BLK;
+            if (cl >= c8 && cl < c8 + MB) {
+#pragma unroll
+                for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+                    for (int e = 0; e < M::NREG; ++e) sm.pipe.Pn[par][w0 + p * M::BLK + M::row(lane, e)][cl - c8] = accD[p][q][e];
+            }
+        }
+    }
+}
+
 // PRO: the workgroup first applies the update of panel J-1 to its own blocks (diagonal block and X), i.e. the K = J
 // column of the trailing update, so that the launch of panel J does not have to wait for a separate trail kernel.
 template <typename T, bool PRO>
@@ -307,17 +435,21 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
     PROBE_STAMP(0);
     constexpr int MB = CH_MB, NSP = CH_NSP;
     typedef T v4_t __attribute__((ext_vector_type(4), aligned(16)));
+    typedef T T2 __attribute__((ext_vector_type(2)));
     auto &Ls = sm.Ls; auto &Xs = sm.Xs; auto &Pn = sm.pipe.Pn; auto &Zt = sm.pipe.Zt; auto &Xr = sm.pipe.Xr; auto &Rs = sm.pipe.Rs;
     const int tid = threadIdx.x;
     const int nS = nrb - J - 1;
     const bool isW = b > nS;
     const int c0 = isW ? (b - nS - 1) * NB : 0;
-    const int role = tid >> 6;                                // 0: factor wave, 1: z wave, 2..5: workers
+    // A workgroup's waves are dealt to the CU's four SIMDs cyclically, so waves w and w+4 share one.  Waves 0-3 are the workers (one
+    // per SIMD: they carry the prologue's and the chain's MFMA work, and the matrix pipe is per SIMD); the two chain waves (4: factor,
+    // 5: z) each share a SIMD with a worker whose chain work is MFMA only, so their vector instructions issue unhindered.
+    const int wave = tid >> 6;
+    const int role = wave == 4 ? 0 : wave == 5 ? 1 : 2;        // 0: factor wave, 1: z wave, 2: worker
     const bool worker = role >= 2;
-    // the chain waves share their SIMDs with worker waves: their (latency-bound) instructions must issue the moment they are ready
     if (role == 0) __builtin_amdgcn_s_setprio(3);
     else if (role == 1) __builtin_amdgcn_s_setprio(2);
-    const int wt = tid - 128;                                 // worker lane id 0..255
+    const int wt = tid & 255;                                  // worker lane id 0..255
     typedef int frag_t __attribute__((ext_vector_type(4)));      // 8 bf16
     const bool planes = sizeof(T) == 4 && Sp != nullptr;       // fp32 with the bf16-split down-date: the pending update multiplies on the bf16 MFMA too
     frag_t fBa[4][3], fBb[4][3], fO[4][3];
@@ -527,16 +659,13 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
         __syncthreads();
     }
     PROBE_STAMP(1);
-    const int tr = (wt >> 4) & 15, tc = wt & 15;
-    T lv[4][4], xs[4][4];
+    const int wv = wt >> 6, wl = wt & 63;            // worker wave 0..3 and its lane
+    typename ChW<T>::acc_t accD[ChW<T>::NBLK][ChW<T>::NBLK], accX[ChW<T>::NBLK][ChW<T>::NBLK];
     if (worker) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                lv[p][q] = Ls[tr + 16 * p][tc + 16 * q];
-                xs[p][q] = b >= 1 ? Xs[tr + 16 * p][tc + 16 * q] : (T)0;      // xs: row = panel column index a, col = i
-            }
+        if (wv == 0) ch_worker_load<T, 0>(sm, accD, accX, wl, b >= 1);
+        else if (wv == 1) ch_worker_load<T, 1>(sm, accD, accX, wl, b >= 1);
+        else if (wv == 2) ch_worker_load<T, 2>(sm, accD, accX, wl, b >= 1);
+        else ch_worker_load<T, 3>(sm, accD, accX, wl, b >= 1);
     }
     bool bad = false;                               // (As, the prologue's operand tile, is the chain's hand-off buffer from here on)
     T yprev[MB], zprev[MB];                          // factor wave: its row of Y(s-1); z wave: its column of Z(s-1)
@@ -544,108 +673,79 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
     for (int t = 0; t < MB; ++t) { yprev[t] = (T)0; zprev[t] = (T)0; }
     // Software pipeline, fully unrolled (every index below is a compile-time constant).  Step k:
     //   factor wave: sub-panel k (0 <= k < NSP);   z wave: sub-panel k-1 (1 <= k <= NSP);
-    //   workers: D patches -= Y(k-1) Y(k-1)' for columns >= 8(k+1) (sub-panel k's own columns get it from the factor wave's
-    //            lookahead), publish Pn(k+1);  X patches -= Y(k-2) Z(k-2) for rows >= 8k, publish Xr(k).
+    //   workers (ch_worker_step): D tiles -= Y(k-1) Y(k-1)' for columns >= 8(k+1) (sub-panel k's own columns get it from the factor
+    //            wave's lookahead), publish Pn(k+1);  X tiles -= Y(k-2) Z(k-2) for rows >= 8k, publish Xr(k).
+    // LDS latency is what a step costs: every role issues ALL the reads of a phase first and waits once (LDS_GROUP keeps the
+    // compiler from re-interleaving reads, waits and arithmetic, which serialised a dozen LDS round trips per step).
+#define LDS_GROUP() do { if constexpr (sizeof(T) == 4) __builtin_amdgcn_sched_barrier(0); } while (0)      // (fp64: the register budget does not allow it)
 #pragma unroll
     for (int k = -1; k <= NSP; ++k) {
         PROBE_STEP(k, 0);
         if (worker) {
-            if (k >= 1 && k + 1 <= NSP - 1) {
-                const int C = MB * (k - 1), q0 = (C + 2 * MB) >> 4;
-                T Yi[4][MB], Yj[4][MB];
-#pragma unroll
-                for (int p = q0; p < 4; ++p) {
-                    const v4_t a0 = *reinterpret_cast<const v4_t *>(&Ls[tr + 16 * p][C]), a1 = *reinterpret_cast<const v4_t *>(&Ls[tr + 16 * p][C + 4]);
-                    const v4_t b0 = *reinterpret_cast<const v4_t *>(&Ls[tc + 16 * p][C]), b1 = *reinterpret_cast<const v4_t *>(&Ls[tc + 16 * p][C + 4]);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) { Yi[p][t] = a0[t]; Yi[p][4 + t] = a1[t]; Yj[p][t] = b0[t]; Yj[p][4 + t] = b1[t]; }
-                }
-#pragma unroll
-                for (int p = q0; p < 4; ++p)
-#pragma unroll
-                    for (int q = q0; q <= p; ++q) {
-                        T acc = lv[p][q];
-#pragma unroll
-                        for (int t = 0; t < MB; ++t) acc -= Yi[p][t] * Yj[q][t];
-                        lv[p][q] = acc;
-                    }
-            }
-            if (k + 1 <= NSP - 1) {
-                // publish sub-panel k+1: columns C..C+7 of L (all rows), from the patches
-                const int C = MB * (k + 1), par = (k + 1) & 1, hq = C >> 4, half = (C >> 3) & 1;
-                if ((tc >> 3) == half) {
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) Pn[par][tr + 16 * p][tc & 7] = lv[p][hq];
-                }
-            }
-            if (b >= 1) {
-                if (k >= 2 && k <= NSP - 1) {
-                    const int C = MB * (k - 2), par = (k - 2) & 1, p0 = (C + 2 * MB) >> 4;
-                    T Yi[4][MB], Zc[4][MB];
-#pragma unroll
-                    for (int p = p0; p < 4; ++p) {
-                        const v4_t a0 = *reinterpret_cast<const v4_t *>(&Ls[tr + 16 * p][C]), a1 = *reinterpret_cast<const v4_t *>(&Ls[tr + 16 * p][C + 4]);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) { Yi[p][t] = a0[t]; Yi[p][4 + t] = a1[t]; }
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const v4_t z0 = *reinterpret_cast<const v4_t *>(&Zt[par][tc + 16 * q][0]), z1 = *reinterpret_cast<const v4_t *>(&Zt[par][tc + 16 * q][4]);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) { Zc[q][t] = z0[t]; Zc[q][4 + t] = z1[t]; }
-                    }
-#pragma unroll
-                    for (int p = p0; p < 4; ++p)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            T acc = xs[p][q];
-#pragma unroll
-                            for (int t = 0; t < MB; ++t) acc -= Yi[p][t] * Zc[q][t];
-                            xs[p][q] = acc;
-                        }
-                }
-                if (k >= 0 && k <= NSP - 1) {
-                    // publish rows C..C+7 of X
-                    const int C = MB * k, par = k & 1, hp = C >> 4, half = (C >> 3) & 1;
-                    if ((tr >> 3) == half) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) Xr[par][tr & 7][tc + 16 * q] = xs[hp][q];
-                    }
-                }
-            }
+#ifdef CH_STAGGER
+            __builtin_amdgcn_s_sleep(CH_STAGGER);            // the chain waves' LDS reads go first
+#endif
+            if (wv == 0) ch_worker_step<T, 0>(k, sm, accD, accX, wl, b >= 1);
+            else if (wv == 1) ch_worker_step<T, 1>(k, sm, accD, accX, wl, b >= 1);
+            else if (wv == 2) ch_worker_step<T, 2>(k, sm, accD, accX, wl, b >= 1);
+            else ch_worker_step<T, 3>(k, sm, accD, accX, wl, b >= 1);
         } else if (role == 0) {
-            if (k >= 0 && k < NSP) {
-                const int C = MB * k, par = k & 1, i = tid;
-                T a[MB], y[MB], rsv[MB];
-                {
-                    const v4_t v0 = *reinterpret_cast<const v4_t *>(&Pn[par][i][0]), v1 = *reinterpret_cast<const v4_t *>(&Pn[par][i][4]);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) { a[t] = v0[t]; a[4 + t] = v1[t]; }
-                }
-                if (k > 0) {
-                    // lookahead: the published columns carry the updates of sub-panels < k-1; sub-panel k-1 is applied here.  The
-                    // multipliers L[C+t][C-8+u] are rows C..C+7 of what this wave stored one step ago: a broadcast read.
+            if (k >= 0 && k < NSP && CH_EXP_F) {
+                const int C = MB * k, par = k & 1, i = tid & 63;
+                T2 a2[MB / 2];
+                T y[MB], rsv[MB];
+                PROBE_F(k, 0);
+                // the published columns (updated through sub-panel k-2) and, for the lookahead, rows C..C+7 of what this wave stored one
+                // step ago (broadcast reads): all requested at once, one wait
+                const v4_t v0 = *reinterpret_cast<const v4_t *>(&Pn[par][i][0]), v1 = *reinterpret_cast<const v4_t *>(&Pn[par][i][4]);
+                v4_t Lh[MB][2];
+                if (k > 0 && sizeof(T) == 4) {
 #pragma unroll
                     for (int t = 0; t < MB; ++t) {
-                        const v4_t l0 = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB]), l1 = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB + 4]);
-                        T acc = a[t];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) acc -= yprev[u] * l0[u];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) acc -= yprev[4 + u] * l1[u];
-                        a[t] = acc;
+                        Lh[t][0] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB]); Lh[t][1] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB + 4]);
                     }
                 }
-                // right-looking inside the sub-panel; rows above the diagonal compute garbage that nothing reads
+                LDS_GROUP();
+                a2[0] = T2{ v0[0], v0[1] }; a2[1] = T2{ v0[2], v0[3] }; a2[2] = T2{ v1[0], v1[1] }; a2[3] = T2{ v1[2], v1[3] };
+                PROBE_F(k, 1);
+                if (k > 0) {
+                    // lookahead: sub-panel k-1's update of these eight columns, a[t] -= sum_u y[u] L[C+t][C-8+u]; adjacent u pair up in
+                    // packed fmas (operands are register pairs as loaded)
+                    const T2 yp[4] = { T2{ yprev[0], yprev[1] }, T2{ yprev[2], yprev[3] }, T2{ yprev[4], yprev[5] }, T2{ yprev[6], yprev[7] } };
+#pragma unroll
+                    for (int t = 0; t < MB; ++t) {
+                        if constexpr (sizeof(T) == 8) { Lh[t][0] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB]); Lh[t][1] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB + 4]); }
+                        T2 acc = yp[0] * T2{ Lh[t][0][0], Lh[t][0][1] };
+                        acc += yp[1] * T2{ Lh[t][0][2], Lh[t][0][3] };
+                        acc += yp[2] * T2{ Lh[t][1][0], Lh[t][1][1] };
+                        acc += yp[3] * T2{ Lh[t][1][2], Lh[t][1][3] };
+                        a2[t >> 1][t & 1] -= acc[0] + acc[1];
+                    }
+                }
+                PROBE_F(k, 2);
+                // right-looking inside the sub-panel, division-free on the dependent chain: per column ONE v_readlane of the pivot,
+                // v_rcp, and a[t] -= a[c] * (a[c]@row(C+t) / pivot), two columns t per packed instruction; y = a * rsqrt(pivot) is off the
+                // chain (measured on one wave, tools/probe_chain.hip: 467 cycles per sub-panel against 738 for rsq -> mul -> readlane ->
+                // fma).  Rows above the diagonal compute garbage that nothing reads; a non-positive pivot poisons the values and raises
+                // the status flag.
 #pragma unroll
                 for (int c = 0; c < MB; ++c) {
-                    T piv = rdlane(a[c], C + c);
-                    if (!(piv > (T)0)) { bad = true; piv = (T)1; }
-                    rsv[c] = chain_rsqrt(piv);
-                    y[c] = a[c] * rsv[c];
+                    const T ac = a2[c >> 1][c & 1];
+                    const T piv = rdlane(ac, C + c);
+                    T so = (T)0;
+                    T2 st2[MB / 2];
+                    if ((c & 1) == 0) so = rdlane(ac, C + c + 1);
 #pragma unroll
-                    for (int t = c + 1; t < MB; ++t) a[t] -= y[c] * rdlane(y[c], C + t);
+                    for (int m = (c >> 1) + 1; m < MB / 2; ++m) st2[m] = T2{ rdlane(ac, C + 2 * m), rdlane(ac, C + 2 * m + 1) };
+                    const T rinv = chain_rcp(piv);
+                    rsv[c] = chain_rsqrt(piv);
+                    bad |= !(piv > (T)0);
+                    if ((c & 1) == 0) a2[c >> 1][1] -= ac * (so * rinv);
+#pragma unroll
+                    for (int m = (c >> 1) + 1; m < MB / 2; ++m) a2[m] -= T2{ ac, ac } * (st2[m] * T2{ rinv, rinv });
+                    y[c] = ac * rsv[c];
                 }
+                PROBE_F(k, 3);
                 *reinterpret_cast<v4_t *>(&Ls[i][C]) = v4_t{ y[0], y[1], y[2], y[3] };
                 *reinterpret_cast<v4_t *>(&Ls[i][C + 4]) = v4_t{ y[4], y[5], y[6], y[7] };
                 if (i == 0) {
@@ -654,39 +754,56 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
                 }
 #pragma unroll
                 for (int t = 0; t < MB; ++t) yprev[t] = y[t];
+                PROBE_F(k, 4);
             }
-        } else if (b >= 1 && k >= 1 && k <= NSP) {
+        } else if (b >= 1 && k >= 1 && k <= NSP && CH_EXP_Z) {
             // z wave, sub-panel k-1: z <- L8^-1 (x - lookahead)
-            const int s2 = k - 1, C = MB * s2, par = s2 & 1, i = tid - 64;
+            const int s2 = k - 1, C = MB * s2, par = s2 & 1, i = tid & 63;
+#ifdef CH_STAGGER
+            __builtin_amdgcn_s_sleep(CH_STAGGER);            // the factor wave's LDS reads go first (this wave has slack)
+#endif
             T x[MB], z[MB];
+            v4_t Lh[MB][2], Ld[MB][2];
 #pragma unroll
             for (int t = 0; t < MB; ++t) x[t] = Xr[par][t][i];
-            if (s2 > 0) {
+            if (s2 > 0 && sizeof(T) == 4) {
 #pragma unroll
                 for (int t = 0; t < MB; ++t) {
-                    const v4_t l0 = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB]), l1 = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB + 4]);
-                    T acc = x[t];
+                    Lh[t][0] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB]); Lh[t][1] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB + 4]);
+                }
+            }
+            if constexpr (sizeof(T) == 4) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc -= l0[u] * zprev[u];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) acc -= l1[u] * zprev[4 + u];
-                    x[t] = acc;
+                for (int t = 1; t < MB; ++t) {
+                    Ld[t][0] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C]);
+                    if (t > 4) Ld[t][1] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C + 4]);
                 }
             }
             const v4_t r0 = *reinterpret_cast<const v4_t *>(&Rs[par][0]), r1 = *reinterpret_cast<const v4_t *>(&Rs[par][4]);
+            LDS_GROUP();
+            if (s2 > 0) {
+                const T2 zp[4] = { T2{ zprev[0], zprev[1] }, T2{ zprev[2], zprev[3] }, T2{ zprev[4], zprev[5] }, T2{ zprev[6], zprev[7] } };
+#pragma unroll
+                for (int t = 0; t < MB; ++t) {
+                    if constexpr (sizeof(T) == 8) { Lh[t][0] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB]); Lh[t][1] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB + 4]); }
+                    T2 acc = zp[0] * T2{ Lh[t][0][0], Lh[t][0][1] };
+                    acc += zp[1] * T2{ Lh[t][0][2], Lh[t][0][3] };
+                    acc += zp[2] * T2{ Lh[t][1][0], Lh[t][1][1] };
+                    acc += zp[3] * T2{ Lh[t][1][2], Lh[t][1][3] };
+                    x[t] -= acc[0] + acc[1];
+                }
+            }
 #pragma unroll
             for (int t = 0; t < MB; ++t) {
                 T acc = x[t];
-                if (t > 0) {
-                    const v4_t l0 = *reinterpret_cast<const v4_t *>(&Ls[C + t][C]);
-#pragma unroll
-                    for (int u = 0; u < 4 && u < t; ++u) acc -= l0[u] * z[u];
+                if constexpr (sizeof(T) == 8) {
+                    if (t > 0) Ld[t][0] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C]);
+                    if (t > 4) Ld[t][1] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C + 4]);
                 }
-                if (t > 4) {
-                    const v4_t l1 = *reinterpret_cast<const v4_t *>(&Ls[C + t][C + 4]);
 #pragma unroll
-                    for (int u = 4; u < t; ++u) acc -= l1[u - 4] * z[u];
-                }
+                for (int u = 0; u < 4 && u < t; ++u) acc -= Ld[t][0][u] * z[u];
+#pragma unroll
+                for (int u = 4; u < t; ++u) acc -= Ld[t][1][u - 4] * z[u];
                 z[t] = acc * (t < 4 ? r0[t & 3] : r1[t & 3]);
             }
             *reinterpret_cast<v4_t *>(&Zt[par][i][0]) = v4_t{ z[0], z[1], z[2], z[3] };
@@ -697,8 +814,9 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
         PROBE_STEP(k, 1);
         __syncthreads();
     }
+#undef LDS_GROUP
     PROBE_STAMP(2);
-    if (bad && tid == 0 && b == 0) atomicExch(status, 1);
+    if (bad && role == 0 && (tid & 63) == 0 && b == 0) atomicExch(status, 1);
     if (b == 0) {
         if (tid == 0) {
             while ((int)(__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(8);
@@ -951,6 +1069,12 @@ __global__ __launch_bounds__(CH_NTH) void k_chol_step(T *__restrict__ S, int lds
 {
     __shared__ ChSmem<T> sm;
     const int b = blockIdx.x;
+#ifdef PRE3_PROBE
+    // wall-clock (100 MHz) begin / end of every workgroup of the launch of panel 2: which workgroups are the launch's long pole
+    struct RtStamp { int b, on; __device__ RtStamp(int b_, int on_) : b(b_), on(on_) { stamp(0); }
+                     __device__ void stamp(int j) { __builtin_amdgcn_sched_barrier(0); if (on && threadIdx.x == 0 && b < 1024) { unsigned long long t; asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); g_k9rt[b * 4 + j] = t; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); g_k9rt[b * 4 + 2 + j] = t; } __builtin_amdgcn_sched_barrier(0); }
+                     __device__ ~RtStamp() { stamp(1); } } rt_stamp(b, J == 2 && g_rt_on);
+#endif
     if (b >= nPT) {
         // riders (fp32, k_downdate_b3 in use): row block J-1 of W is final since the previous launch; its bf16 planes are produced here,
         // in the shadow of the panel, so that only the last row block is left for the split launch in front of the down-date
@@ -1953,6 +2077,12 @@ extern "C" __attribute__((visibility("default"))) int pre3_debug_k9_stamps(unsig
 extern "C" __attribute__((visibility("default"))) int pre3_debug_k9rt(unsigned long long *out)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k9rt), sizeof(unsigned long long) * 2048 * 4) == hipSuccess ? 0 : -3;
+}
+extern "C" __attribute__((visibility("default"))) int pre3_debug_rt(int on)
+{
+    static unsigned long long z[2048 * 4];
+    if (on && hipMemcpyToSymbol(HIP_SYMBOL(g_k9rt), z, sizeof z) != hipSuccess) return -3;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_rt_on), &on, sizeof on) == hipSuccess ? 0 : -3;
 }
 extern "C" __attribute__((visibility("default"))) int pre3_debug_k9hw(unsigned int *out)
 {
