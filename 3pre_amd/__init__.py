@@ -10,9 +10,10 @@ the CPU and nothing imports oracle/.
 """
 from . import _lib
 from ._lib import CARTESIAN, F32, F64, INVDEPTH, LIB_PATH, X_K_K, X_K_KM1, Pre3Error, device_count
-from .ekf import CHI2INV_2_95, EkfFilter, predict_state_and_covariance, update
+from .ekf import (CHI2INV_2_95, EkfFilter, compute_hypothesis_support_fast, generate_state_vector_pattern,
+                  predict_state_and_covariance, update)
 from .matcher import kNearestNeighbors, siftmatch, siftmatch_merge, siftmatch_partial
 
-__all__ = ["EkfFilter", "update", "predict_state_and_covariance", "siftmatch", "siftmatch_partial", "siftmatch_merge",
+__all__ = ["EkfFilter", "update", "predict_state_and_covariance", "compute_hypothesis_support_fast", "generate_state_vector_pattern", "siftmatch", "siftmatch_partial", "siftmatch_merge",
            "kNearestNeighbors", "Pre3Error", "device_count", "LIB_PATH", "F64", "F32", "INVDEPTH", "CARTESIAN", "X_K_K", "X_K_KM1",
            "CHI2INV_2_95"]

@@ -25,6 +25,7 @@ lib = C.CDLL(LIB_PATH)
 lib.pre3_last_error.restype = C.c_char_p
 lib.pre3_version.restype = C.c_char_p
 lib.pre3_match_bench_create.restype = C.c_void_p
+lib.pre3_hypothesis_support.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
 lib.pre3_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_void_p]
 
 F64, F32 = 0, 1
@@ -75,8 +76,8 @@ def device_count():
 # every symbol include/pre3.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = [
     "pre3_last_error", "pre3_device_count", "pre3_version", "pre3_create", "pre3_destroy", "pre3_sync", "pre3_set_cam",
-    "pre3_set_map", "pre3_state_size", "pre3_set_state", "pre3_get_state", "pre3_predict", "pre3_project", "pre3_innovation",
-    "pre3_get_landmark_fields", "pre3_window_gate", "pre3_set_measurements", "pre3_ransac", "pre3_ransac_score",
+    "pre3_set_map", "pre3_state_size", "pre3_set_state", "pre3_get_state", "pre3_predict", "pre3_predict_dense", "pre3_project", "pre3_innovation",
+    "pre3_get_landmark_fields", "pre3_window_gate", "pre3_set_measurements", "pre3_ransac", "pre3_hypothesis_support", "pre3_ransac_score",
     "pre3_ransac_select", "pre3_ransac_export", "pre3_ransac_import", "pre3_update_li", "pre3_rescue", "pre3_update_hi", "pre3_update_all", "pre3_get_flags",
     "pre3_set_flags", "pre3_step", "pre3_set_option", "pre3_get_option", "pre3_map_delete", "pre3_map_add_inverse_depth", "pre3_map_inversedepth_2_cartesian", "pre3_get_map", "pre3_set_descriptors", "pre3_get_descriptors", "pre3_set_scan", "pre3_ic_search", "pre3_vo_ransac", "pre3_vo_ransac_frames", "pre3_vo_bench", "pre3_update_ell", "pre3_siftmatch_f64", "pre3_siftmatch_f32", "pre3_siftmatch_u8",
     "pre3_siftmatch_i8", "pre3_siftmatch_partial", "pre3_siftmatch_merge", "pre3_release_scratch", "pre3_knn_f64", "pre3_timer_start",

@@ -38,12 +38,16 @@ template <typename T> static int dmalloc(T **p, size_t count)
 {
     void *q = nullptr;
     if (hipMalloc(&q, sizeof(T) * (count ? count : 1)) != hipSuccess) { set_error("hipMalloc of %zu bytes failed", sizeof(T) * count); return PRE3_E_NOMEM; }
+    // defined contents: a recycled allocation must not leak a previous context's data into fields the reference leaves empty
+    // (a measured landmark that is not predicted has h = [] there; its h/H were whatever the allocator returned here)
+    if (hipMemset(q, 0, sizeof(T) * (count ? count : 1)) != hipSuccess) { (void)hipFree(q); set_error("hipMemset failed"); return PRE3_E_HIP; }
     *p = (T *)q;
     return PRE3_OK;
 }
 static int dmalloc_bytes(void **p, size_t bytes)
 {
     if (hipMalloc(p, bytes ? bytes : 16) != hipSuccess) { set_error("hipMalloc of %zu bytes failed", bytes); return PRE3_E_NOMEM; }
+    if (hipMemset(*p, 0, bytes ? bytes : 16) != hipSuccess) { (void)hipFree(*p); *p = nullptr; set_error("hipMemset failed"); return PRE3_E_HIP; }
     return PRE3_OK;
 }
 
@@ -77,6 +81,7 @@ static int fetch_stats(pre3_ctx *c)
 {
     PRE3_HIP(hipMemcpyAsync(c->pinned_stats, c->stats, sizeof(int32_t) * 16, hipMemcpyDeviceToHost, c->stream));
     PRE3_HIP(hipStreamSynchronize(c->stream));
+    PRE3_CHECK(c->pinned_stats[7] == 0, PRE3_E_HIP, "a device-side wait on another workgroup gave up (counter never arrived): results are invalid");
     PRE3_CHECK(c->pinned_stats[6] == 0, PRE3_E_NUMERIC, "innovation covariance S is not positive definite");
     return PRE3_OK;
 }
@@ -349,6 +354,9 @@ int pre3_set_map(pre3_ctx *c, int N, const int32_t *lm_type)
     c->lm_type_host.assign(lm_type, lm_type + N);
     // the P buffer keeps its capacity-sized leading dimension; entries beyond n stay zero
     PRE3_HIP(hipMemset(c->lm.has_h, 0, sizeof(int32_t) * c->capN)); PRE3_HIP(hipMemset(c->lm.has_S, 0, sizeof(int32_t) * c->capN));
+    // update_features_info.m:30-44 empties h, H, S, z: a landmark that is measured but never predicted must read zeros, not a previous map's values
+    PRE3_HIP(hipMemset(c->lm.h, 0, sizeof(double) * 2 * c->capN)); PRE3_HIP(hipMemset(c->lm.Hc, 0, sizeof(double) * 14 * c->capN));
+    PRE3_HIP(hipMemset(c->lm.Hl, 0, sizeof(double) * 12 * c->capN)); PRE3_HIP(hipMemset(c->lm.S, 0, sizeof(double) * 4 * c->capN));
     PRE3_HIP(hipMemset(c->inbox_dev, 0, c->inbox_bytes)); PRE3_HIP(hipMemset(c->lm.li, 0, sizeof(int32_t) * c->capN));
     PRE3_HIP(hipMemset(c->lm.hi, 0, sizeof(int32_t) * c->capN));
     c->m = 0; c->meas_host.clear(); c->measurements_set = false; c->projected = false; c->innovated = false;
@@ -504,17 +512,20 @@ int pre3_window_gate(pre3_ctx *c, int M, const int32_t *k1, const double *zc, in
     for (int q = 0; q < M; ++q) PRE3_CHECK(k1[q] >= 0 && k1[q] < (int)pred.size(), PRE3_E_ARG, "pre3_window_gate: k1[%d]=%d out of range", q, k1[q]);
     std::vector<int32_t> acc(M ? M : 1, 0);
     if (M) {
+        // temporaries are released on every exit path (an early PRE3_TRY / PRE3_HIP return used to leak them)
+        struct Tmp { void *p[4] = { nullptr, nullptr, nullptr, nullptr }; ~Tmp() { for (void *q : p) if (q) (void)hipFree(q); } } tmp;
         int32_t *d_pred = nullptr, *d_k1 = nullptr, *d_acc = nullptr; double *d_zc = nullptr;
-        PRE3_TRY(dmalloc(&d_pred, pred.size())); PRE3_TRY(dmalloc(&d_k1, M)); PRE3_TRY(dmalloc(&d_acc, M)); PRE3_TRY(dmalloc(&d_zc, 2 * (size_t)M));
+        PRE3_TRY(dmalloc(&d_pred, pred.size())); tmp.p[0] = d_pred;
+        PRE3_TRY(dmalloc(&d_k1, M)); tmp.p[1] = d_k1;
+        PRE3_TRY(dmalloc(&d_acc, M)); tmp.p[2] = d_acc;
+        PRE3_TRY(dmalloc(&d_zc, 2 * (size_t)M)); tmp.p[3] = d_zc;
         PRE3_HIP(hipMemcpy(d_pred, pred.data(), sizeof(int32_t) * pred.size(), hipMemcpyHostToDevice));
         PRE3_HIP(hipMemcpy(d_k1, k1, sizeof(int32_t) * M, hipMemcpyHostToDevice));
         PRE3_HIP(hipMemcpy(d_zc, zc, sizeof(double) * 2 * M, hipMemcpyHostToDevice));
         PRE3_HIP(hipMemsetAsync(c->lm.ic, 0, sizeof(int32_t) * N, c->stream));
-        int rc = launch_window_gate(c, M, d_pred, d_k1, d_zc, strict_reference, d_acc);
-        if (rc == PRE3_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = PRE3_E_HIP;
-        if (rc == PRE3_OK && hipMemcpy(acc.data(), d_acc, sizeof(int32_t) * M, hipMemcpyDeviceToHost) != hipSuccess) rc = PRE3_E_HIP;
-        (void)hipFree(d_pred); (void)hipFree(d_k1); (void)hipFree(d_acc); (void)hipFree(d_zc);
-        PRE3_TRY(rc);
+        PRE3_TRY(launch_window_gate(c, M, d_pred, d_k1, d_zc, strict_reference, d_acc));
+        PRE3_HIP(hipStreamSynchronize(c->stream));
+        PRE3_HIP(hipMemcpy(acc.data(), d_acc, sizeof(int32_t) * M, hipMemcpyDeviceToHost));
     }
     // accepted candidates become the measurement list (ascending landmark order; one match per landmark)
     std::vector<int32_t> flag(N ? N : 1, 0);
@@ -597,6 +608,13 @@ int pre3_ic_search(pre3_ctx *c, double thresh, int strict_reference, int32_t *n_
     PRE3_CHECK(c->x_valid[PRE3_X_K_KM1] && c->p_which == PRE3_X_K_KM1, PRE3_E_STATE, "pre3_ic_search: needs the predicted estimate (call pre3_predict first)");
     PRE3_CHECK(m_out != nullptr, PRE3_E_ARG, "pre3_ic_search: null m_out");
     const int N = c->N;
+    if (N == 0) {
+        // matching_sift_based.m:115 `if isempty(des1) return`: a SLAM run starts with an empty map -- nothing to match, no measurements
+        if (n_matches_out) *n_matches_out = 0;
+        *m_out = 0;
+        c->projected = true; c->innovated = true;
+        return install_measurements(c, 0, nullptr, nullptr, nullptr, 0);
+    }
     // search_IC_matches.m:31-44: h, H and S for every landmark at the prediction
     PRE3_CHECK(c->have_cam, PRE3_E_STATE, "pre3_ic_search: camera not set");
     if (N) PRE3_TRY(launch_project_innovation(c, PRE3_X_K_KM1, 1, 0, 0.0));
@@ -644,6 +662,7 @@ static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, in
         PRE3_HIP(hipEventRecord(c->inbox_copied, c->stream)); c->inbox_pending = true;
     }
     c->masks = reinterpret_cast<uint32_t *>(c->support + round_up(n_draw, 4));
+    c->scored_n_draw = n_draw; c->scored_k = k;         // the mask offset depends on n_draw: select / export / import must use the same
     int r = 2 * c->m, r_pad = round_up(r, NB);
     if (hi < 0) hi = n_draw;
     if (lo > 0 || hi < n_draw) {
@@ -697,6 +716,7 @@ int pre3_ransac_select(pre3_ctx *c, int n_draw, int k, int early_exit, int32_t *
 {
     PRE3_TRY(check_ctx(c));
     PRE3_CHECK(n_draw >= 1 && n_draw <= c->caph, PRE3_E_ARG, "ransac: n_draw out of range");
+    PRE3_CHECK(n_draw == c->scored_n_draw && k == c->scored_k, PRE3_E_STATE, "pre3_ransac_select: n_draw=%d, k=%d differs from the scored round (n_draw=%d, k=%d): the mask buffer is laid out for that round", n_draw, k, c->scored_n_draw, c->scored_k);
     int words = ceil_div(c->m, 32);
     PRE3_TRY(launch_ransac_select_impl(c, n_draw, k, early_exit, c->support, c->masks, words));
     return ransac_results(c, n_draw, support, li_mask, stats);
@@ -706,6 +726,7 @@ int pre3_ransac_export(pre3_ctx *c, int n_draw, void *support_dst_dev, void *mas
 {
     PRE3_TRY(check_ctx(c));
     PRE3_CHECK(n_draw >= 1 && n_draw <= c->caph, PRE3_E_ARG, "ransac: n_draw out of range");
+    PRE3_CHECK(n_draw == c->scored_n_draw, PRE3_E_STATE, "pre3_ransac_export: n_draw=%d differs from the scored round (n_draw=%d): the mask buffer is laid out for that round", n_draw, c->scored_n_draw);
     int words = ceil_div(c->m, 32);
     if (support_dst_dev) PRE3_HIP(hipMemcpyAsync(support_dst_dev, c->support, sizeof(int32_t) * n_draw, hipMemcpyDeviceToDevice, c->stream));
     if (mask_dst_dev) PRE3_HIP(hipMemcpyAsync(mask_dst_dev, c->masks, sizeof(uint32_t) * (size_t)n_draw * words, hipMemcpyDeviceToDevice, c->stream));
@@ -717,6 +738,7 @@ int pre3_ransac_import(pre3_ctx *c, int n_draw, const void *support_src_dev, con
 {
     PRE3_TRY(check_ctx(c));
     PRE3_CHECK(n_draw >= 1 && n_draw <= c->caph, PRE3_E_ARG, "ransac: n_draw out of range");
+    PRE3_CHECK(n_draw == c->scored_n_draw, PRE3_E_STATE, "pre3_ransac_import: n_draw=%d differs from the scored round (n_draw=%d): the mask buffer is laid out for that round", n_draw, c->scored_n_draw);
     int words = ceil_div(c->m, 32);
     if (support_src_dev) PRE3_HIP(hipMemcpyAsync(c->support, support_src_dev, sizeof(int32_t) * n_draw, hipMemcpyDeviceToDevice, c->stream));
     if (mask_src_dev) PRE3_HIP(hipMemcpyAsync(c->masks, mask_src_dev, sizeof(uint32_t) * (size_t)n_draw * words, hipMemcpyDeviceToDevice, c->stream));
@@ -960,6 +982,54 @@ int pre3_update_ell(int device, int dtype, int n, int r, const double *x, const 
 }
 
 // ---- matcher ------------------------------------------------------------------------------------------
+// Stateless drop-in for compute_hypothesis_support_fast.m:27 (caller: ransac_hypotheses.m:72).
+int pre3_hypothesis_support(int device, int n, const double *xi, const pre3_cam *cam, const double *state_vector_pattern,
+                            int n_id, const double *z_id, int n_euc, const double *z_euc, double threshold,
+                            int32_t *support_out, int32_t *positions_li_inliers_id, int32_t *positions_li_inliers_euc)
+{
+    PRE3_CHECK(n >= 13 && xi && cam && state_vector_pattern && support_out, PRE3_E_ARG, "pre3_hypothesis_support: bad arguments");
+    PRE3_CHECK(n_id >= 0 && n_euc >= 0 && (n_id == 0 || z_id) && (n_euc == 0 || z_euc), PRE3_E_ARG, "pre3_hypothesis_support: bad measurement arrays");
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) { set_error("no HIP device available (libpre3 has no CPU fallback)"); return PRE3_E_NODEVICE; }
+    PRE3_CHECK(device >= 0 && device < nd, PRE3_E_ARG, "pre3_hypothesis_support: device %d of %d", device, nd);
+    // xi(logical(state_vector_pattern(:,c))): the selected entries in state order, column c of the n x 4 column-major pattern
+    std::vector<int32_t> idx[4];
+    for (int c = 0; c < 4; ++c)
+        for (int i = 0; i < n; ++i) if (state_vector_pattern[(size_t)c * n + i] != 0.0) idx[c].push_back(i);
+    // reshape(ri,3,n_id) etc. (:40-43, :84) fail in MATLAB on a count mismatch; so does this
+    PRE3_CHECK((int)idx[0].size() == 3 * n_id && (int)idx[1].size() == 2 * n_id && (int)idx[2].size() == n_id, PRE3_E_ARG,
+               "pre3_hypothesis_support: pattern selects %zu/%zu/%zu entries for %d inverse-depth measurements (needs 3/2/1 each)",
+               idx[0].size(), idx[1].size(), idx[2].size(), n_id);
+    PRE3_CHECK((int)idx[3].size() == 3 * n_euc, PRE3_E_ARG, "pre3_hypothesis_support: pattern selects %zu entries for %d cartesian measurements", idx[3].size(), n_euc);
+    if (n_id + n_euc == 0) { *support_out = 0; return PRE3_OK; }                       // :29, both branches empty
+    PRE3_HIP(hipSetDevice(device));
+    std::vector<int32_t> out(1 + (size_t)n_id + n_euc);
+    PRE3_TRY(run_hypothesis_support(n, xi, *cam, n_id, idx[0].data(), idx[1].data(), idx[2].data(), z_id, n_euc, idx[3].data(), z_euc, threshold, out.data()));
+    *support_out = out[0];
+    if (positions_li_inliers_id) for (int j = 0; j < n_id; ++j) positions_li_inliers_id[j] = out[1 + j];
+    if (positions_li_inliers_euc) for (int j = 0; j < n_euc; ++j) positions_li_inliers_euc[j] = out[1 + n_id + j];
+    return PRE3_OK;
+}
+
+// Stateless drop-in for `[X_km1_k, P_km1_k] = predict_state_and_covariance(X_k, P_k, type, SD_A, SD_alpha)`
+// (predict_state_and_covariance.m:27, caller @ekf_filter/ekf_prediction.m:29) with the odometry increment made explicit.
+int pre3_predict_dense(int device, int dtype, int n, const double *x, const double *P, const double u[7], double *x_out, double *P_out)
+{
+    PRE3_CHECK(n >= 13 && (n - 13) % 3 == 0 && x && P && u && x_out && P_out, PRE3_E_ARG, "pre3_predict_dense: bad arguments (n = 13 + 6 N_id + 3 N_euc)");
+    int capL = std::max((n - 13 + 5) / 6, 1);
+    pre3_ctx *c = nullptr;
+    PRE3_TRY(pre3_create(&c, device, dtype, capL, 1));
+    int rc = PRE3_OK;
+    do {
+        c->n = n; c->N = 0;                       // the prediction touches the 13 camera entries and rows/columns 1:13 only: no landmark table needed
+        if ((rc = pre3_set_state(c, PRE3_X_K_K, n, x, P)) != PRE3_OK) break;
+        if ((rc = pre3_predict(c, u)) != PRE3_OK) break;
+        rc = pre3_get_state(c, PRE3_X_K_KM1, n, x_out, P_out);
+    } while (0);
+    pre3_destroy(c);
+    return rc;
+}
+
 int pre3_release_scratch(void) { release_scratch(); return PRE3_OK; }
 
 int pre3_siftmatch_merge(int cls, int G, int K1, const double *best, const double *second, const int32_t *arg, double thresh_d,

@@ -491,7 +491,7 @@ __global__ __launch_bounds__(512) void k_ransac_score(int hyp_begin, const int32
             s_last = atomicAdd(sel.done, 1u) == gridDim.x - 1;
         }
         __syncthreads();
-        if (s_last && tid < 256) {                                  // the selection stage is written for 4 waves; the others retire
+        if (s_last) {                                               // every thread enters (the stage's barriers are reached by all 512); 256 lanes work
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // see every other workgroup's results
             if (tid == 0) *sel.done = 0;
             select_body(sel.n_draw, sel.k, sel.early_exit, m, meas, support, masks, mask_words, sel.li_meas, sel.lm_li, sel.sel_rows,
@@ -571,20 +571,21 @@ __device__ __forceinline__ void select_body(int n_draw, int k, int early_exit, i
     }
     __syncthreads();
     const int best = s_best, iters = s_iters;
-    for (int it = iters + tid; it < n_draw; it += 256) support[it] = -1;   // never evaluated by the reference (256 lanes take part)
+    const bool act = tid < 256;                                            // the launch may have more waves (k_ransac_score: 8): they only keep the barriers
+    for (int it = iters + tid; act && it < n_draw; it += 256) support[it] = -1;   // never evaluated by the reference
     // winner's mask -> flags (set_as_most_supported_hypothesis.m:32-52) + ordered compaction of the LI rows
     for (int base = 0; base < m; base += 256) {
         const int j = base + tid;
         int in = 0;
-        if (j < m) {
+        if (act && j < m) {
             in = best >= 0 ? (masks[(size_t)best * mask_words + (j >> 5)] >> (j & 31)) & 1 : 0;
             li_meas[j] = in; lm_li[meas[j]] = in;
         }
         const unsigned long long bal = __ballot(in);
-        if (lane == 0) s_wcnt[wv] = __popcll(bal);
+        if (act && lane == 0) s_wcnt[wv] = __popcll(bal);
         __syncthreads();
         int pre = s_base;
-        for (int w2 = 0; w2 < wv; ++w2) pre += s_wcnt[w2];
+        for (int w2 = 0; w2 < wv && w2 < 4; ++w2) pre += s_wcnt[w2];
         if (in) sel_rows[pre + __popcll(bal & ((1ull << lane) - 1ull))] = j;
         __syncthreads();
         if (tid == 0) s_base += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
@@ -693,6 +694,7 @@ ProjRide make_proj_ride(pre3_ctx *c, int which, int clear_first, int slot, int n
     pr.lm_type = c->lm.type; pr.lm_off = c->lm.off; pr.x = which == PRE3_X_K_K ? c->x_kk : c->x_km1; pr.cam = to_camd(c->cam);
     pr.h = c->lm.h; pr.has_h = c->lm.has_h; pr.Hc = c->lm.Hc; pr.Hl = c->lm.Hl;
     pr.ctr = c->chol_arrive + 3 + slot;
+    pr.guard = c->stats + 7;
     c->ride_target[slot] += (unsigned)n_producers;
     pr.target = c->ride_target[slot];
     return pr;
@@ -842,6 +844,81 @@ int launch_update_x(pre3_ctx *c, int which_prior, int r)
         hipLaunchKernelGGL(k_update_x<float>, g, b, 0, c->stream, c->n, r, (const float *)c->W, c->ldw, c->ld, xp, c->x_kk, c->pred_params, c->tile_ctr));
     c->tile_ctr_clean = true;
     PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
+
+// ---- stateless compute_hypothesis_support_fast.m:27-116 ------------------------------------------------------------------
+// One workgroup (the reference evaluates one hypothesis per call; a frame has a few hundred measurements): lane j projects
+// measurement j of the hypothesis state xi exactly as k_ransac_score does (un-normalised quaternion, quirk Q4), the workgroup takes
+// min(residual) over the inverse-depth measurements and applies `residual < min + threshold` (:70) / `residual < threshold` (:109).
+// i1/i2/i3/i4: the state entries the four columns of state_vector_pattern select, in order (xi(logical(pattern(:,c)))).
+__global__ __launch_bounds__(256) void k_hyp_support(const double *__restrict__ xi, CamD cam, int n_id, const int32_t *__restrict__ i1,
+                                                     const int32_t *__restrict__ i2, const int32_t *__restrict__ i3, const double *__restrict__ z_id,
+                                                     int n_euc, const int32_t *__restrict__ i4, const double *__restrict__ z_euc, double threshold,
+                                                     double *__restrict__ res, int32_t *__restrict__ out /* [0] support, then pos_id[n_id], pos_euc[n_euc] */)
+{
+    __shared__ double s_red[4];
+    __shared__ int s_cnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double rot[9];
+    d_q2r(xi + 3, rot);
+    double lmin = INFINITY;
+    for (int j = tid; j < n_id + n_euc; j += 256) {
+        const bool id = j < n_id;
+        const int e = j - n_id;
+        double y[6];
+        if (id) { y[0] = xi[i1[3 * j]]; y[1] = xi[i1[3 * j + 1]]; y[2] = xi[i1[3 * j + 2]]; y[3] = xi[i2[2 * j]]; y[4] = xi[i2[2 * j + 1]]; y[5] = xi[i3[j]]; }
+        else { y[0] = xi[i4[3 * e]]; y[1] = xi[i4[3 * e + 1]]; y[2] = xi[i4[3 * e + 2]]; y[3] = y[4] = y[5] = 0; }
+        double v[3], hc[3], uvd[2];
+        d_ray(id ? PRE3_INVDEPTH : PRE3_CARTESIAN, y, xi, v);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) hc[c] = rot[0 * 3 + c] * v[0] + rot[1 * 3 + c] * v[1] + rot[2 * 3 + c] * v[2];
+        d_pinhole_distort(hc, cam, uvd);
+        const double *z = id ? z_id + 2 * j : z_euc + 2 * e;
+        const double n0 = z[0] - uvd[0], n1 = z[1] - uvd[1];
+        const double r = sqrt(n0 * n0 + n1 * n1);
+        res[j] = r;
+        if (id) lmin = fmin(lmin, r);
+    }
+    lmin = wave_min(lmin);
+    if (lane == 0) s_red[wv] = lmin;
+    __syncthreads();
+    const double minres = fmin(fmin(s_red[0], s_red[1]), fmin(s_red[2], s_red[3]));
+    int cnt = 0;
+    for (int j = tid; j < n_id + n_euc; j += 256) {
+        const int in = j < n_id ? (res[j] < (minres + threshold)) : (res[j] < threshold);      // NaN compares false, as in MATLAB
+        out[1 + j] = in; cnt += in;
+    }
+    cnt = wave_sum(cnt);
+    if (lane == 0) s_cnt[wv] = cnt;
+    __syncthreads();
+    if (tid == 0) out[0] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+int run_hypothesis_support(int n, const double *xi, const pre3_cam &cam, int n_id, const int32_t *i1, const int32_t *i2, const int32_t *i3,
+                           const double *z_id, int n_euc, const int32_t *i4, const double *z_euc, double threshold, int32_t *out_host)
+{
+    const int m = n_id + n_euc;
+    // one pooled device block: [xi n | z 2m | res m] doubles, then [i1 3n_id | i2 2n_id | i3 n_id | i4 3n_euc | out 1+m] int32
+    const size_t nd = (size_t)n + 3 * (size_t)m, ni = 6 * (size_t)n_id + 3 * (size_t)n_euc + 1 + m;
+    void *blk = nullptr; int slot = -1;
+    PRE3_TRY(scratch_acquire(sizeof(double) * nd + sizeof(int32_t) * ni, &blk, &slot));
+    struct Rel { int slot; void *p; ~Rel() { scratch_release(slot, p); } } rel{ slot, blk };
+    std::vector<double> hd(nd, 0.0);
+    std::vector<int32_t> hi(ni, 0);
+    memcpy(hd.data(), xi, sizeof(double) * n);
+    if (n_id) memcpy(hd.data() + n, z_id, sizeof(double) * 2 * n_id);
+    if (n_euc) memcpy(hd.data() + n + 2 * (size_t)n_id, z_euc, sizeof(double) * 2 * n_euc);
+    if (n_id) { memcpy(hi.data(), i1, sizeof(int32_t) * 3 * n_id); memcpy(hi.data() + 3 * (size_t)n_id, i2, sizeof(int32_t) * 2 * n_id); memcpy(hi.data() + 5 * (size_t)n_id, i3, sizeof(int32_t) * n_id); }
+    if (n_euc) memcpy(hi.data() + 6 * (size_t)n_id, i4, sizeof(int32_t) * 3 * n_euc);
+    double *dd = (double *)blk; int32_t *di = (int32_t *)(dd + nd);
+    PRE3_HIP(hipMemcpy(dd, hd.data(), sizeof(double) * nd, hipMemcpyHostToDevice));
+    PRE3_HIP(hipMemcpy(di, hi.data(), sizeof(int32_t) * ni, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_hyp_support, dim3(1), dim3(256), 0, 0, dd, to_camd(cam), n_id, di, di + 3 * (size_t)n_id, di + 5 * (size_t)n_id, dd + n,
+                       n_euc, di + 6 * (size_t)n_id, dd + n + 2 * (size_t)n_id, threshold, dd + n + 2 * (size_t)m, di + 6 * (size_t)n_id + 3 * (size_t)n_euc);
+    PRE3_HIP(hipGetLastError());
+    PRE3_HIP(hipMemcpy(out_host, di + 6 * (size_t)n_id + 3 * (size_t)n_euc, sizeof(int32_t) * (1 + m), hipMemcpyDeviceToHost));
     return PRE3_OK;
 }
 

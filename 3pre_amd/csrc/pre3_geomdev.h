@@ -161,7 +161,21 @@ struct ProjRide {
     const int32_t *lm_type, *lm_off; const double *x; CamD cam;
     double *h; int32_t *has_h; double *Hc, *Hl;
     unsigned int *ctr; unsigned int target;
+    int32_t *guard;                     // device error word (stats[7]): set when a wait gives up
 };
+
+// every device-side wait on another workgroup is bounded: HIP promises no dispatch order, so a counter that never arrives must not hang
+// the GPU.  ~2^21 polls with s_sleep in between are of the order of a second; the host then reports PRE3_E_HIP (pre3_api.hip, fetch_stats).
+constexpr int SPIN_LIMIT = 1 << 21;
+__device__ __forceinline__ bool bounded_wait(const unsigned int *ctr, unsigned int target, int32_t *guard)
+{
+    for (int spin = 0; spin < SPIN_LIMIT; ++spin) {
+        if ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) return true;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (guard) atomicExch(guard, 1);
+    return false;
+}
 
 __device__ __forceinline__ void ride_signal(unsigned int *ctr)      // call from every thread of a producer workgroup
 {
@@ -171,9 +185,7 @@ __device__ __forceinline__ void ride_signal(unsigned int *ctr)      // call from
 
 __device__ __forceinline__ void proj_ride_block(const ProjRide &pr, int blk)
 {
-    if (threadIdx.x == 0) {
-        while ((int)(__hip_atomic_load(pr.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - pr.target) < 0) __builtin_amdgcn_s_sleep(4);
-    }
+    if (threadIdx.x == 0) bounded_wait(pr.ctr, pr.target, pr.guard);
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const int i = blk * 64 + threadIdx.x;

@@ -114,6 +114,7 @@ struct pre3_ctx {
     int32_t *support = nullptr;                   // [caph]
     uint32_t *masks = nullptr;                    // [caph*mask_words_cap]
     int mask_words_cap = 0;
+    int scored_n_draw = 0, scored_k = 0;          // the round pre3_ransac_score / pre3_ransac laid the support + mask buffer out for
     int32_t *stats = nullptr;                     // [16] device: best, iters, n_hyp, max_support, n_li, n_hi, status
     int32_t *li_meas = nullptr, *hi_meas = nullptr;   // [capm] flags in measurement order
     double *pred_params = nullptr;                // [64] predict: Qq1(16) Jn(16) Q(49->7x7) etc.
@@ -175,6 +176,9 @@ int launch_innovation(pre3_ctx *c, int mode /*0: S=HPH'+I for predicted; 1: resc
 int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode, double chi2);
 int launch_update_x(pre3_ctx *c, int which_prior, int r);
 int launch_jnorm(pre3_ctx *c, int which);
+
+int run_hypothesis_support(int n, const double *xi, const pre3_cam &cam, int n_id, const int32_t *i1, const int32_t *i2, const int32_t *i3,
+                           const double *z_id, int n_euc, const int32_t *i4, const double *z_euc, double threshold, int32_t *out_host /* [1 + n_id + n_euc] */);
 
 // ---- dense update kernels (pre3_update.hip)
 // rows: ELL rows [r] in c->row_col/row_val with nu in c->row_nu; computes W = H*P (+ nu column),

@@ -170,12 +170,7 @@ __global__ __launch_bounds__(256) void k_ell_G_hyp(const int32_t *__restrict__ h
 // three-way bf16 split of W into the stage image of k_downdate_b3 (layout: see "K9 on the bf16 matrix cores" below)
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
-#ifndef B3_PIPE
-#define B3_PIPE 1
-#endif
-#ifndef B3_NBUF
-#define B3_NBUF (B3_PIPE ? 3 : 2)
-#endif
+#define B3_NBUF 3                  // LDS ring slots of k_downdate_b3 (the register pipeline runs two stages ahead)
 constexpr int B3_T = 128, B3_BK = 16, B3_GRAN = 3 * 4 * 64;        // granules (16 B) of one operand block of one stage
 // x[0..7] = eight consecutive k of one column -> this lane's granule of the three planes (dst: plane 0; planes are 256 granules apart)
 template <int PSTRIDE = 256>
@@ -819,7 +814,7 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
     if (bad && role == 0 && (tid & 63) == 0 && b == 0) atomicExch(status, 1);
     if (b == 0) {
         if (tid == 0) {
-            while ((int)(__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(8);
+            bounded_wait(arrive, target, status + 1);        // status + 1 = stats[7], the wait guard (a give-up is reported as PRE3_E_HIP)
         }
         __syncthreads();
         for (int idx = tid; idx < NB * NB; idx += CH_NTH) {
@@ -1505,11 +1500,7 @@ template <int TM>
 __device__ __forceinline__ void b3_dma(const bf16x8_t *__restrict__ src, int half, bf16x8_t *dst, int tid, int wave)
 {
     if (TM == 128) {
-#ifdef B3_EXP_TWOPLANES
-#define B3_NPL 2
-#else
 #define B3_NPL 3
-#endif
 #pragma unroll
         for (int l = 0; l < B3_NPL; ++l)
             __builtin_amdgcn_global_load_lds(src + l * 256 + tid, (__attribute__((address_space(3))) void *)(dst + l * 256 + wave * 64), 16, 0, 0);
@@ -1543,26 +1534,8 @@ __device__ __forceinline__ void b3_tile(float *__restrict__ P, int ld, const bf1
     const bf16x8_t *srcA = Wp + (size_t)(bi >> 1) * nst_total * B3_GRAN;
     const bf16x8_t *srcB = Wp + (size_t)(bj >> 1) * nst_total * B3_GRAN;
     const int hA = bi & 1, hB = bj & 1;
-#ifdef B3_EXP_SAMESRC
-    srcA = Wp; srcB = Wp;
-#endif
     const int lrow = 4 * (lane >> 5), lcol = lane & 31;                 // 32x32 accumulator: row = (e & 3) + 8 (e >> 2) + lrow, col = lcol
-#if !B3_PIPE
-    constexpr int D = B3_NBUF - 1;                                      // stages in flight ahead of the one being consumed
-#endif
     auto ring = [&](int slot, int operand) { return smem + (slot * 2 + operand) * B3_GRAN; };
-#if !B3_PIPE
-    // the P tile first (consumed in the epilogue), then the first two stages of the ring
-    float pv[NB][NB][16];
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                pv[i][j][e] = P[(size_t)(R0 + i * 32 + (e & 3) + 8 * (e >> 2) + lrow) * ld + C0 + j * 32 + lcol];
-#endif
-#if B3_PIPE
     // Register-level pipeline: the fragments of stage s+1 are read from the ring while the MFMAs of stage s run from registers, and
     // the ring runs two stages ahead of that (slot s%3 is free as soon as stage s sits in registers):
     //   top of stage s:  wait DMA(s+1) [DMA(s+2) may still fly], barrier -> issue DMA(s+3) into slot s%3 -> ds_read stage s+1 -> MFMAs(s)
@@ -1652,72 +1625,6 @@ __device__ __forceinline__ void b3_tile(float *__restrict__ P, int ld, const bf1
 #undef B3_MMA
 #undef B3_READ_FRAGS
     __syncthreads();                              // the patches below alias the ring
-#else
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (d < nst) {
-            b3_dma<TM>(srcA + (size_t)d * B3_GRAN, hA, ring(d, 0), tid, wave);
-            b3_dma<TM>(srcB + (size_t)d * B3_GRAN, hB, ring(d, 1), tid, wave);
-        }
-    if (nst >= D) b3_wait<TM, D - 1>(wave); else vmwait<0>();
-    __syncthreads();
-#ifdef PRE3_PROBE
-    if (threadIdx.x == 0 && blockIdx.x < 2048) g_k9rt[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-#endif
-    f32x16_t acc[NB][NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    int buf = 0;
-    for (int s = 0; s < nst; ++s) {
-        const bf16x8_t *sA = ring(buf, 0) + (NB * wi) * 64 + lane, *sB = ring(buf, 1) + (NB * wj) * 64 + lane;
-        bf16x8_t A[3][NB], B[3][NB];
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int i = 0; i < NB; ++i) { A[p][i] = sA[p * PL + i * 64]; B[p][i] = sB[p * PL + i * 64]; }
-        if (s + D < nst) {                       // its slot was read in stage s-1: every wave is past that barrier
-            const int nb = buf == 0 ? B3_NBUF - 1 : buf - 1;
-            b3_dma<TM>(srcA + (size_t)(s + D) * B3_GRAN, hA, ring(nb, 0), tid, wave);
-            b3_dma<TM>(srcB + (size_t)(s + D) * B3_GRAN, hB, ring(nb, 1), tid, wave);
-        }
-#ifdef B3_EXP_NOMFMA
-        if (nst > 100000)
-#endif
-        {
-        // largest terms first: they need only the first plane's fragments, the reads of the other planes land meanwhile
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-#pragma unroll
-            for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][i], B[0][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][i], B[1][j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][i], B[0][j], acc[i][j], 0, 0, 0);
-            }
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][i], B[1][j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][i], B[2][j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2][i], B[0][j], acc[i][j], 0, 0, 0);
-            }
-        }
-#ifdef B3_EXP_NOMFMA
-        acc[0][0][0] += (float)A[0][0][0] + (float)B[2][NB - 1][1];
-#endif
-        if (s + D < nst) b3_wait<TM, D - 1>(wave);     // stage s+1 has landed (this wave's granules)
-        else vmwait<0>();
-        __syncthreads();
-        buf = buf == B3_NBUF - 1 ? 0 : buf + 1;
-    }
-#endif
 #ifdef PRE3_PROBE
     if (threadIdx.x == 0 && blockIdx.x < 2048) g_k9rt[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0 && blockIdx.x == 7) { g_probe[1] = __builtin_amdgcn_s_memtime(); g_probe[3] = __builtin_amdgcn_s_memrealtime(); }

@@ -352,19 +352,55 @@ def update(x_km1_k, p_km1_k, H, R, z, h, dtype="f64", device=0, want_K=True):
 
 
 def predict_state_and_covariance(X_k, P_k, u, cam=None, dtype="f64", device=0):
-    """[X_km1_k, P_km1_k] = predict_state_and_covariance(X_k, P_k, ...) with u = [dX; dq] explicit."""
-    X_k, P_k = f64(X_k).ravel(), f64(P_k)
+    """[X_km1_k, P_km1_k] = predict_state_and_covariance(X_k, P_k, type, SD_A, SD_alpha) (predict_state_and_covariance.m:27) with
+    u = [dX; dq] explicit (the .m file reads it from disk through fv.m:47).  Stateless: host arrays in, host arrays out
+    (pre3_predict_dense).  `cam` is accepted for symmetry with the other mirrors and unused, as in the reference."""
+    X_k, P_k, u = f64(X_k).ravel(), f64(P_k), f64(u).ravel()
     n = X_k.shape[0]
-    if (n - 13) % 6 == 0:
-        types = np.zeros((n - 13) // 6, np.int32)
-    elif (n - 13) % 3 == 0:
-        types = np.ones((n - 13) // 3, np.int32)
-    else:
-        raise Pre3Error(-1, "predict: state size %d is not 13 + 6a + 3b" % n)
-    f = EkfFilter(cam if cam is not None else [1, 0, 0, 0, 0, 1, 1], types, dtype=dtype, device=device, max_hyp=1)
-    try:
-        f.set_x_p_k_k(X_k, P_k)
-        f.ekf_prediction(u)
-        return f.get_x_k_km1(), f.get_p_k_km1()
-    finally:
-        f.close()
+    if P_k.shape != (n, n) or u.shape[0] != 7:
+        raise Pre3Error(-1, "predict_state_and_covariance: P must be %d x %d and u = [dX(3); dq(4)]" % (n, n))
+    xo, Po = np.empty(n), np.empty((n, n))
+    check(lib.pre3_predict_dense(int(device), {"f64": _lib.F64, "f32": _lib.F32}[dtype], n, dptr(X_k), dptr(P_k), dptr(u), dptr(xo), dptr(Po)))
+    return xo, Po
+
+
+def generate_state_vector_pattern(lm_type, has_z, z, n=None):
+    """[state_vector_pattern, z_id, z_euc] = generate_state_vector_pattern(features_info, x) (generate_state_vector_pattern.m:29-53):
+    lm_type[N] (0 inverse depth, 1 cartesian), has_z[N] (features_info(i).z non-empty), z[N][2].  Host bookkeeping (index arithmetic)."""
+    lm_type = np.asarray(lm_type).astype(int)
+    if n is None:
+        n = 13 + int(np.sum(np.where(lm_type == _lib.INVDEPTH, 6, 3)))
+    pat = np.zeros((n, 4))
+    z_id, z_euc, pos = [], [], 13
+    for i, t in enumerate(lm_type):
+        if t == _lib.INVDEPTH:
+            if has_z[i]:
+                pat[pos:pos + 3, 0] = 1; pat[pos + 3:pos + 5, 1] = 1; pat[pos + 5, 2] = 1
+                z_id.append(z[i])
+            pos += 6
+        else:
+            if has_z[i]:
+                pat[pos:pos + 3, 3] = 1
+                z_euc.append(z[i])
+            pos += 3
+    return pat, np.array(z_id, float).reshape(-1, 2).T, np.array(z_euc, float).reshape(-1, 2).T
+
+
+def compute_hypothesis_support_fast(xi, cam, state_vector_pattern, z_id, z_euc, threshold, device=0):
+    """[hypothesis_support, positions_li_inliers_id, positions_li_inliers_euc] = compute_hypothesis_support_fast(xi, cam,
+    state_vector_pattern, z_id, z_euc, threshold) (compute_hypothesis_support_fast.m:27).  z_id / z_euc are 2 x n as in MATLAB
+    (empty arrays allowed); the masks come back as boolean vectors ([] for an empty class, as the reference returns)."""
+    xi = f64(xi).ravel()
+    n = xi.shape[0]
+    pat = np.asfortranarray(np.asarray(state_vector_pattern, dtype=np.float64))
+    if pat.shape != (n, 4):
+        raise Pre3Error(-1, "compute_hypothesis_support_fast: state_vector_pattern must be %d x 4" % n)
+    zi = np.asfortranarray(np.asarray(z_id, dtype=np.float64).reshape(2, -1)) if np.size(z_id) else np.zeros((2, 0), order="F")
+    ze = np.asfortranarray(np.asarray(z_euc, dtype=np.float64).reshape(2, -1)) if np.size(z_euc) else np.zeros((2, 0), order="F")
+    n_id, n_euc = zi.shape[1], ze.shape[1]
+    sup = C.c_int32(0)
+    pid, peu = np.zeros(max(n_id, 1), np.int32), np.zeros(max(n_euc, 1), np.int32)
+    c = _cam(cam)
+    check(lib.pre3_hypothesis_support(int(device), n, dptr(xi), C.addressof(c), dptr(pat), n_id, dptr(zi) if n_id else None, n_euc,
+                                      dptr(ze) if n_euc else None, float(threshold), C.addressof(sup), dptr(pid), dptr(peu)))
+    return int(sup.value), pid[:n_id].astype(bool), peu[:n_euc].astype(bool)

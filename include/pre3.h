@@ -80,6 +80,13 @@ PRE3_API int pre3_get_state(pre3_ctx *ctx, int which, int n, double *x, double *
  * and the 7x7 pose block change), so p_k_k is no longer available afterwards. */
 PRE3_API int pre3_predict(pre3_ctx *ctx, const double u[7]);
 
+/* Stateless drop-in for `[X_km1_k, P_km1_k] = predict_state_and_covariance(X_k, P_k, type, SD_A_component_filter,
+ * SD_alpha_component_filter)` (predict_state_and_covariance.m:27, caller @ekf_filter/ekf_prediction.m:29): host in, host out.
+ * `type` is 'constant_velocity' in every call of the reference and the two standard deviations are unused by this fork (:98-102 hard-
+ * code Pn); the increment u = [dX; dq] the .m file reads from disk through fv.m:47 is an explicit argument (the MEX gateway resolves it,
+ * INTEGRATION.md).  n = 13 + 6 N_id + 3 N_euc; P, P_out: n x n. */
+PRE3_API int pre3_predict_dense(int device, int dtype, int n, const double *x, const double *P, const double u[7], double *x_out, double *P_out);
+
 /* ---- a3/a4: predict_camera_measurements.m:27-68 + calculate_derivatives.m:27-60 ------------------ */
 /* Projects every landmark at the chosen estimate and linearises it (compact H_i = 2x7 pose block +
  * 2x6 landmark block; columns 8:13 of the reference's H are zero).  clear_first=1 empties h/H first
@@ -115,6 +122,18 @@ PRE3_API int pre3_set_measurements(pre3_ctx *ctx, int m, const int32_t *meas_idx
  * li_mask[m] (int32 0/1 in measurement order), stats[4] = {best, iterations, n_hyp, max_support}. */
 PRE3_API int pre3_ransac(pre3_ctx *ctx, int n_draw, int k, const int32_t *hyp, double threshold, int early_exit,
                          int32_t *support, int32_t *li_mask, int32_t stats[4]);
+
+/* Stateless drop-in for `[hypothesis_support, positions_li_inliers_id, positions_li_inliers_euc] =
+ * compute_hypothesis_support_fast(xi, cam, state_vector_pattern, z_id, z_euc, threshold)` (compute_hypothesis_support_fast.m:27,
+ * called from ransac_hypotheses.m:72): host in, host out.  xi: hypothesis state (n); state_vector_pattern: n x 4 column-major
+ * 0/1 doubles exactly as generate_state_vector_pattern.m:29-53 builds it (columns: inverse-depth position / angles / rho, cartesian
+ * xyz -- xi(logical(pattern(:,c))) is taken in state order); z_id: 2 x n_id, z_euc: 2 x n_euc column-major.  Inverse-depth rule
+ * residual < min(residual) + threshold (:70), cartesian rule residual < threshold (:109); the quaternion is used un-normalised (:46).
+ * positions_*: int32 0/1 per measurement (may be NULL).  A pattern whose counts do not match n_id / n_euc is PRE3_E_ARG
+ * (MATLAB's reshape at :40 fails there too). */
+PRE3_API int pre3_hypothesis_support(int device, int n, const double *xi, const pre3_cam *cam, const double *state_vector_pattern,
+                                     int n_id, const double *z_id, int n_euc, const double *z_euc, double threshold,
+                                     int32_t *support_out, int32_t *positions_li_inliers_id, int32_t *positions_li_inliers_euc);
 
 /* Sharded form: score hypotheses [hyp_begin,hyp_end) only, leaving their supports (int32, others 0)
  * and inlier bitmasks in device buffers; *support_dev / *mask_dev receive DEVICE pointers to

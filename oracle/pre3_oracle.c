@@ -17,6 +17,9 @@
  * sequence (MATLAB's legacy RNG is an input here), orc_knn beyond its docstring example.
  */
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
@@ -30,16 +33,52 @@ enum { ORC_INVDEPTH = 0, ORC_CARTESIAN = 1 };
 
 /* ------------------------------------------------------------------ small dense helpers */
 
-/* C(m x n) = A(m x k) * B(k x n), row-major */
+/* C(m x n) = A(m x k) * B(k x n), row-major.  Every C(i,j) is the sum over t = 0..k-1 in that order; B is transposed once so the
+ * inner loop is contiguous, and rows are independent (OpenMP over i): the bits of C do not depend on the thread count. */
 static void mm(const double *A, const double *B, double *C, int m, int k, int n)
 {
+    double *Bt = (double *)malloc(sizeof(double) * (size_t)k * n);
+    for (int t = 0; t < k; ++t) for (int j = 0; j < n; ++j) Bt[(size_t)j * k + t] = B[(size_t)t * n + j];
+#pragma omp parallel for schedule(static) if ((long)m * n * k > 2000000L)
     for (int i = 0; i < m; ++i)
         for (int j = 0; j < n; ++j) {
             double s = 0;
-            for (int t = 0; t < k; ++t) s += A[i * k + t] * B[t * n + j];
-            C[i * n + j] = s;
+            const double *a = A + (size_t)i * k, *b = Bt + (size_t)j * k;
+            for (int t = 0; t < k; ++t) s += a[t] * b[t];
+            C[(size_t)i * n + j] = s;
         }
+    free(Bt);
 }
+
+/* thread count of the OpenMP loops (bench.py times the restatement at 1 thread and at all cores; results are identical) */
+ORC_API void orc_set_threads(int t) {
+#ifdef _OPENMP
+    omp_set_num_threads(t > 0 ? t : omp_get_num_procs());
+#else
+    (void)t;
+#endif
+}
+ORC_API int orc_get_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* positions of the non-zeros of each of the r rows of a dense r x n matrix, ascending: MATLAB's sparse H*P visits exactly these, and
+ * skipping the zeros leaves every partial sum unchanged (0*x contributes an exact 0) */
+typedef struct { int *idx; int *start; } nzrows;
+static nzrows nz_build(const double *H, int r, int n)
+{
+    nzrows z; z.start = (int *)malloc(sizeof(int) * (r + 1)); int cnt = 0;
+    for (int a = 0; a < r; ++a) for (int t = 0; t < n; ++t) if (H[(size_t)a * n + t] != 0.0) ++cnt;
+    z.idx = (int *)malloc(sizeof(int) * (cnt ? cnt : 1)); cnt = 0;
+    for (int a = 0; a < r; ++a) { z.start[a] = cnt; for (int t = 0; t < n; ++t) if (H[(size_t)a * n + t] != 0.0) z.idx[cnt++] = t; }
+    z.start[r] = cnt;
+    return z;
+}
+static void nz_free(nzrows z) { free(z.idx); free(z.start); }
 
 /* general inverse by LU with partial pivoting (MATLAB `inv` is LAPACK dgetrf+dgetri) */
 static int inv_lu(const double *A, double *Ainv, int n)
@@ -64,21 +103,27 @@ static int inv_lu(const double *A, double *Ainv, int n)
             if (l != 0.0) for (int j = c + 1; j < n; ++j) M[r * n + j] -= l * M[c * n + j];
         }
     }
-    /* solve for each unit vector */
-    double *y = (double *)malloc(sizeof(double) * n);
-    for (int e = 0; e < n; ++e) {
-        for (int i = 0; i < n; ++i) {
-            double s = (piv[i] == e) ? 1.0 : 0.0;
-            for (int j = 0; j < i; ++j) s -= M[i * n + j] * y[j];
-            y[i] = s;
+    /* solve for each unit vector (columns are independent: OpenMP over e, same arithmetic per column) */
+#pragma omp parallel if (n > 128)
+    {
+        double *y = (double *)malloc(sizeof(double) * n), *c = (double *)malloc(sizeof(double) * n);
+#pragma omp for schedule(static)
+        for (int e = 0; e < n; ++e) {
+            for (int i = 0; i < n; ++i) {
+                double s = (piv[i] == e) ? 1.0 : 0.0;
+                for (int j = 0; j < i; ++j) s -= M[i * n + j] * y[j];
+                y[i] = s;
+            }
+            for (int i = n - 1; i >= 0; --i) {
+                double s = y[i];
+                for (int j = i + 1; j < n; ++j) s -= M[i * n + j] * c[j];
+                c[i] = s / M[i * n + i];
+            }
+            for (int i = 0; i < n; ++i) Ainv[i * n + e] = c[i];
         }
-        for (int i = n - 1; i >= 0; --i) {
-            double s = y[i];
-            for (int j = i + 1; j < n; ++j) s -= M[i * n + j] * Ainv[j * n + e];
-            Ainv[i * n + e] = s / M[i * n + i];
-        }
+        free(y); free(c);
     }
-    free(y); free(M); free(piv);
+    free(M); free(piv);
     return 0;
 }
 
@@ -451,20 +496,24 @@ static void expand_H(int n, int type, int off, const double *Hc, const double *H
 static void HPHt(int n, int r, const double *H, const double *P, double *S, double *HP_out)
 {
     double *HP = HP_out ? HP_out : (double *)malloc(sizeof(double) * (size_t)r * n);
-    for (int a = 0; a < r; ++a)
+    nzrows nz = nz_build(H, r, n);
+#pragma omp parallel for schedule(static) if ((long)r * n > 100000L)
+    for (int a = 0; a < r; ++a) {
+        const double *Ha = H + (size_t)a * n;
         for (int j = 0; j < n; ++j) {
             double s = 0;
-            const double *Ha = H + (size_t)a * n;
-            for (int t = 0; t < n; ++t) if (Ha[t] != 0.0) s += Ha[t] * P[(size_t)t * n + j];   /* sparse rows: zeros contribute exact 0 */
+            for (int q = nz.start[a]; q < nz.start[a + 1]; ++q) { const int t = nz.idx[q]; s += Ha[t] * P[(size_t)t * n + j]; }   /* sparse rows: zeros contribute exact 0 */
             HP[(size_t)a * n + j] = s;
         }
+    }
     for (int a = 0; a < r; ++a)
         for (int b = 0; b < r; ++b) {
             double s = 0;
             const double *Hb = H + (size_t)b * n;
-            for (int t = 0; t < n; ++t) if (Hb[t] != 0.0) s += HP[(size_t)a * n + t] * Hb[t];
+            for (int q = nz.start[b]; q < nz.start[b + 1]; ++q) { const int t = nz.idx[q]; s += HP[(size_t)a * n + t] * Hb[t]; }
             S[a * r + b] = s;
         }
+    nz_free(nz);
     if (!HP_out) free(HP);
 }
 
@@ -551,13 +600,16 @@ ORC_API int orc_update(int n, int r, const double *x, const double *P, const dou
     /* :33 K = P*H'*inv(S).  (P*H')(i,a) = sum_t P(i,t) H(a,t) */
     if (inv_lu(S, Sinv, r)) return -2;
     double *PHt = (double *)malloc(sizeof(double) * (size_t)n * r);
+    nzrows nz = nz_build(H, r, n);
+#pragma omp parallel for schedule(static) if ((long)r * n > 100000L)
     for (int i = 0; i < n; ++i)
         for (int a = 0; a < r; ++a) {
             double s = 0;
             const double *Ha = H + (size_t)a * n;
-            for (int t = 0; t < n; ++t) if (Ha[t] != 0.0) s += P[(size_t)i * n + t] * Ha[t];
+            for (int q = nz.start[a]; q < nz.start[a + 1]; ++q) { const int t = nz.idx[q]; s += P[(size_t)i * n + t] * Ha[t]; }
             PHt[(size_t)i * r + a] = s;
         }
+    nz_free(nz);
     mm(PHt, Sinv, K, n, r, r);
     free(PHt);
     /* :36 x = x + K*(z-h) */
@@ -568,6 +620,7 @@ ORC_API int orc_update(int n, int r, const double *x, const double *P, const dou
     }
     /* :37 P = P - K*S*K' */
     mm(K, S, KS, n, r, r);
+#pragma omp parallel for schedule(static) if ((long)n * n > 100000L)
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) {
             double s = 0;
@@ -677,13 +730,15 @@ ORC_API int orc_hypothesis_state(int n, int k, const int *sel, const int *lm_typ
     HPHt(n, r, H, P, S, NULL);
     for (int a = 0; a < r; ++a) S[a * r + a] += 1.0;         /* kalman_R = blkdiag(R_j) = I */
     inv_lu(S, Sinv, r);
+    nzrows nz = nz_build(H, r, n);
     for (int i = 0; i < n; ++i)
         for (int a = 0; a < r; ++a) {
             double s = 0;
             const double *Ha = H + (size_t)a * n;
-            for (int t = 0; t < n; ++t) if (Ha[t] != 0.0) s += P[(size_t)i * n + t] * Ha[t];
+            for (int q = nz.start[a]; q < nz.start[a + 1]; ++q) { const int t = nz.idx[q]; s += P[(size_t)i * n + t] * Ha[t]; }
             PHt[(size_t)i * r + a] = s;
         }
+    nz_free(nz);
     for (int i = 0; i < n; ++i) {
         double acc = 0;
         for (int b = 0; b < r; ++b) {
