@@ -297,6 +297,101 @@ __global__ __launch_bounds__(256) void k_match_i8_mfma(int NDp, int K1, int K2, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// int8 MFMA distance kernel, query-per-lane form (the default for 128-bin descriptors).
+// The operands are swapped with respect to k_match_i8_mfma: the DATABASE block is the A operand and the QUERY block the B operand of
+// v_mfma_i32_16x16x64_i8, so the accumulator's lane index (column l & 15) is the query and its 4 registers are 4 database columns
+// (rows 4(l>>4) + e).  A lane therefore runs siftmatch.c:110-116's scan over ITS OWN registers:
+//     d = nb - 2 a.b ; arg' = d < best ? e : arg ; second' = med3(best, d, second) ; best' = min(best, d)        (5 vector ops per pair)
+// with no LDS round trip per tile, no serial one-lane-per-row walk and no second launch.
+// Workgroup = 16 waves that share ONE block of 16 queries (its fragments, all 128 bins, stay in 8 VGPRs for the kernel's life) and split
+// the database between them (wave w takes 16-column blocks w, w+16, ...; the next three blocks' fragments are in flight behind the current
+// block's MFMAs, four register sets in rotation); operands are pre-packed in fragment order (k_pack_i8_v), so a fragment load is 1 KB
+// contiguous.  At the end the four lane groups of a query (interleaved database rows) and the 16 waves
+// are merged with the order-independent (best, second, first-arg) statistic through 3 KB of LDS.  4096 queries = 256 workgroups: one
+// per CU.  Measured at 4096 x 4096 x 128 (tools/match_ab.py): 11.4 us against 25.6 us for the row-scan form; of that 2.6 us is an empty
+// launch, ~3 us the scan's vector instructions, ~1 us the matrix pipe, the rest the stream of the database through L2 (every workgroup
+// reads all of it: K2 x 128 B at ~64 B/clk/CU) and the prologue's dependent loads.  (Tried: 32-query workgroups on the 32x32x32 MFMA with
+// the database split between workgroups + a ticket merge -- 15-20 us; norms in LDS -- no change; three blocks in flight -- this form.)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int med3i(int a, int b, int c) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+constexpr int I8_NONE = 0x3fffffff;       // = I8_NONE_NORM, the norm the pack kernels give padded database rows: never below a real distance (<= 128 * 255^2)
+constexpr int I8Q_WAVES = 16, I8Q_Q = 16;
+
+__global__ __launch_bounds__(64 * I8Q_WAVES) void k_match_i8_q(int K1, int K2p, const int8_t *__restrict__ Q, const int8_t *__restrict__ D,
+                                                     const int *__restrict__ nq, const int *__restrict__ nd, int k2_offset,
+                                                     double *__restrict__ obest, double *__restrict__ osecond, int32_t *__restrict__ oarg)
+{
+    __shared__ int mg[3 * I8Q_WAVES * I8Q_Q];                              // merge area [best | second | arg][16 waves][16 queries]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    const int nblk = K2p / 16;
+    // Q and D are in fragment order (k_pack_i8_v, frag = 1): [block of 16][k-step of 64 bins][lane] x 16 bytes
+    v4i fq[2], fa[2], fb[2], fc[2], fd[2], na_, nb_, nc_, nd_, nq_;
+    auto load = [&](const int8_t *base, int blk, v4i (&f)[2], v4i &n, const int *norms) {
+        const v4i *src = reinterpret_cast<const v4i *>(base) + (size_t)blk * 128 + lane;
+        f[0] = src[0]; f[1] = src[64];
+        n = *reinterpret_cast<const v4i *>(norms + blk * 16 + 4 * g);          // norms of this lane's 4 rows (16 lanes share an address)
+    };
+    load(Q, blockIdx.x, fq, nq_, nq);
+    if (wave < nblk) load(D, wave, fa, na_, nd);
+    int best = 0x7fffffff, second = 0x7fffffff, bk = -1, be = 0;
+    auto scan = [&](int blk, const v4i (&f)[2], const v4i &n) {
+        v4i acc = { 0, 0, 0, 0 };
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(f[0], fq[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(f[1], fq[1], acc, 0, 0, 0);
+        const int best0 = best;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int d = n[e] - 2 * acc[e];                           // |b|^2 - 2 a.b (the query's norm is added once at the end)
+            be = d < best ? e : be;                                    // strict: the first index wins ties (siftmatch.c:110); e is an inline constant
+            second = med3i(best, d, second);                           // best <= second always: the median is the new second best
+            best = d < best ? d : best;
+        }
+        bk = best < best0 ? blk : bk;                                  // the block the running best lives in (its row is rebuilt from (bk, be) at the end)
+    };
+    // (the prefetches are unconditional -- past the end they re-read the wave's last block -- because a branch around a load makes
+    //  the compiler's s_waitcnt cover the not-taken path, i.e. wait for the prefetch itself)
+    if (wave < nblk) {
+        // four register sets in rotation, three blocks in flight: one L2 round trip is longer than three blocks' worth of MFMA + scan
+        const int last = wave + (nblk - 1 - wave) / I8Q_WAVES * I8Q_WAVES;
+        auto at = [&](int b) { return b < last ? b : last; };
+        load(D, at(wave + I8Q_WAVES), fb, nb_, nd);
+        load(D, at(wave + 2 * I8Q_WAVES), fc, nc_, nd);
+        for (int blk = wave; blk < nblk; blk += 4 * I8Q_WAVES) {
+            load(D, at(blk + 3 * I8Q_WAVES), fd, nd_, nd);
+            scan(blk, fa, na_);
+            if (blk + I8Q_WAVES >= nblk) break;
+            load(D, at(blk + 4 * I8Q_WAVES), fa, na_, nd);
+            scan(blk + I8Q_WAVES, fb, nb_);
+            if (blk + 2 * I8Q_WAVES >= nblk) break;
+            load(D, at(blk + 5 * I8Q_WAVES), fb, nb_, nd);
+            scan(blk + 2 * I8Q_WAVES, fc, nc_);
+            if (blk + 3 * I8Q_WAVES >= nblk) break;
+            load(D, at(blk + 6 * I8Q_WAVES), fc, nc_, nd);
+            scan(blk + 3 * I8Q_WAVES, fd, nd_);
+        }
+    }
+    bk = bk < 0 ? -1 : bk * 16 + 4 * g + be;                             // database row of the best: block, lane group, register
+    // the other three lane groups hold the interleaved database rows of the same query
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        const int ob = __shfl_xor(best, o, 64), os = __shfl_xor(second, o, 64), ok = __shfl_xor(bk, o, 64);
+        merge3(best, second, bk, ob, os, ok);
+    }
+    if (g == 0) { mg[wave * 16 + lane] = best; mg[256 + wave * 16 + lane] = second; mg[512 + wave * 16 + lane] = bk; }
+    __syncthreads();
+    const int q = blockIdx.x * I8Q_Q + tid;
+    if (tid < I8Q_Q && q < K1) {
+        int B = mg[tid], S2 = mg[256 + tid], Kk = mg[512 + tid];
+#pragma unroll
+        for (int w = 1; w < I8Q_WAVES; ++w) merge3(B, S2, Kk, mg[w * 16 + tid], mg[256 + w * 16 + tid], mg[512 + w * 16 + tid]);
+        // padded database rows carry the norm I8_NONE: a best / second at or above it means "no such column"
+        const int qn = nq[q];
+        const bool hb = Kk >= 0 && B < I8_NONE / 2, hs = S2 < I8_NONE / 2;
+        obest[q] = hb ? (double)(B + qn) : 2147483647.0; osecond[q] = hs ? (double)(S2 + qn) : 2147483647.0; oarg[q] = hb ? Kk + k2_offset : -1;
+    }
+}
+
 // sixteen lanes per query, each merging every sixteenth partial, loads issued 8 at a time (the merge is a dependent chain: one partial
 // per load latency was 0.46 us each), then four shuffle merges
 __global__ __launch_bounds__(256) void k_match_reduce_i32(int K1, int K1p, int npart, const int *__restrict__ pbest, const int *__restrict__ psecond,
@@ -328,12 +423,13 @@ __global__ __launch_bounds__(256) void k_match_reduce_i32(int K1, int K1p, int n
     if (live && sub == 0) { obest[k1] = (double)best; osecond[k1] = (double)second; oarg[k1] = bk < 0 ? -1 : bk + k2_offset; }
 }
 
+constexpr int I8_NONE_NORM = 0x3fffffff;
 // pack ND x K (column-major, one descriptor per column) uint8/int8 into K_pad x NDp int8 rows (+ norms): one thread per 16 bins (one
 // 16-byte store), the NDp/16 threads of a descriptor are neighbours in a wave and add up the norm with shuffles (NDp/16 is a power
 // of two <= 64 here: NDp is a multiple of 32; other shapes take the generic one-thread-per-descriptor path)
 template <typename T>
 __global__ __launch_bounds__(256) void k_pack_i8_v(int ND, int NDp, int K, int Kp, const T *__restrict__ L, int center, int8_t *__restrict__ out,
-                                                    int *__restrict__ norm)
+                                                    int *__restrict__ norm, int frag)
 {
     const int cpd = NDp / 16;                                   // chunks per descriptor
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -347,9 +443,12 @@ __global__ __launch_bounds__(256) void k_pack_i8_v(int ND, int NDp, int K, int K
         const int x = (kcol < K && b < ND) ? (int)L[(size_t)kcol * ND + b] - center : 0;
         v[j] = (int8_t)x; s += x * x;
     }
-    *reinterpret_cast<int4 *>(out + (size_t)kcol * NDp + ch * 16) = *reinterpret_cast<const int4 *>(v);
+    // frag: the operand order of v_mfma_i32_16x16x64_i8 for NDp = 128 -- block of 16 descriptors, k-step of 64 bins, lane (descriptor & 15)
+    // + 16 * (16-bin quarter of the k-step): a wave's fragment load is then 1 KB contiguous instead of 16 B out of each of 64 places
+    const size_t o = frag ? ((size_t)((kcol >> 4) * 2 + (ch >> 2)) * 64 + (kcol & 15) + 16 * (ch & 3)) * 16 : (size_t)kcol * NDp + ch * 16;
+    *reinterpret_cast<int4 *>(out + o) = *reinterpret_cast<const int4 *>(v);
     for (int o = cpd >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (ch == 0) norm[kcol] = s;
+    if (ch == 0) norm[kcol] = kcol < K ? s : I8_NONE_NORM;          // padded rows: a norm no real distance reaches (k_match_i8_q)
 }
 
 template <typename T>
@@ -363,15 +462,15 @@ __global__ void k_pack_i8(int ND, int NDp, int K, int Kp, const T *__restrict__ 
         out[(size_t)kcol * NDp + b] = (int8_t)v;
         s += v * v;
     }
-    norm[kcol] = s;
+    norm[kcol] = kcol < K ? s : I8_NONE_NORM;
 }
 
 template <typename T>
-static void launch_pack_i8(int ND, int NDp, int K, int Kp, const T *L, int center, int8_t *out, int *norm)
+static void launch_pack_i8(int ND, int NDp, int K, int Kp, const T *L, int center, int8_t *out, int *norm, bool frag = false)
 {
     const int cpd = NDp / 16;
     if (cpd >= 2 && cpd <= 64 && (cpd & (cpd - 1)) == 0 && ((size_t)Kp * cpd) % 256 == 0)
-        hipLaunchKernelGGL(k_pack_i8_v<T>, dim3((unsigned)((size_t)Kp * cpd / 256)), dim3(256), 0, 0, ND, NDp, K, Kp, L, center, out, norm);
+        hipLaunchKernelGGL(k_pack_i8_v<T>, dim3((unsigned)((size_t)Kp * cpd / 256)), dim3(256), 0, 0, ND, NDp, K, Kp, L, center, out, norm, frag ? 1 : 0);
     else
         hipLaunchKernelGGL(k_pack_i8<T>, dim3(ceil_div(Kp, 64)), dim3(64), 0, 0, ND, NDp, K, Kp, L, center, out, norm);
 }
@@ -518,6 +617,7 @@ static int partial_exact(int ND, int K1, const T *L1, int K2, const T *L2, int k
 // device-resident int8 MFMA matcher state, reusable across calls (bench: inputs resident in HBM)
 struct I8Match {
     int ND = 0, NDp = 0, K1 = 0, K2 = 0, K1p = 0, K2p = 0, ntn = 0;
+    bool frag = false;                            // operands packed in MFMA fragment order for k_match_i8_q (128-bin descriptors)
     DevBuf A, B, na, nb, pb, ps, pa, ob, os, oa;
 };
 
@@ -532,11 +632,13 @@ static int i8_prepare(I8Match &m, int ND, int K1, const T *L1, int K2, const T *
     if (K2) PRE3_HIP(hipMemcpy(r2.p, L2, (size_t)ND * K2, hipMemcpyHostToDevice));
     PRE3_TRY(m.A.alloc((size_t)m.K1p * m.NDp)); PRE3_TRY(m.B.alloc((size_t)m.K2p * m.NDp));
     PRE3_TRY(m.na.alloc(sizeof(int) * m.K1p)); PRE3_TRY(m.nb.alloc(sizeof(int) * m.K2p));
-    size_t np = (size_t)m.K1p * m.ntn * 4;            // four partials (32-column chunks) per 128-column tile
+    size_t np = (size_t)m.K1p * m.ntn * 4;            // four partials (32-column chunks) per 128-column tile (row-scan form)
     PRE3_TRY(m.pb.alloc(sizeof(int) * np)); PRE3_TRY(m.ps.alloc(sizeof(int) * np)); PRE3_TRY(m.pa.alloc(sizeof(int) * np));
     PRE3_TRY(m.ob.alloc(sizeof(double) * K1)); PRE3_TRY(m.os.alloc(sizeof(double) * K1)); PRE3_TRY(m.oa.alloc(sizeof(int32_t) * K1));
-    launch_pack_i8<T>(ND, m.NDp, K1, m.K1p, (const T *)r1.p, center, (int8_t *)m.A.p, (int *)m.na.p);
-    launch_pack_i8<T>(ND, m.NDp, K2, m.K2p, (const T *)r2.p, center, (int8_t *)m.B.p, (int *)m.nb.p);
+    static const int form = getenv("PRE3_MATCH_I8_FORM") ? atoi(getenv("PRE3_MATCH_I8_FORM")) : 1;     // 0: row-scan form (k_match_i8_mfma + reduce), A/B
+    m.frag = form == 1 && m.NDp == 128;
+    launch_pack_i8<T>(ND, m.NDp, K1, m.K1p, (const T *)r1.p, center, (int8_t *)m.A.p, (int *)m.na.p, m.frag);
+    launch_pack_i8<T>(ND, m.NDp, K2, m.K2p, (const T *)r2.p, center, (int8_t *)m.B.p, (int *)m.nb.p, m.frag);
     PRE3_HIP(hipGetLastError());
     PRE3_HIP(hipDeviceSynchronize());
     return PRE3_OK;
@@ -544,6 +646,12 @@ static int i8_prepare(I8Match &m, int ND, int K1, const T *L1, int K2, const T *
 
 static int i8_run(I8Match &m, int k2_offset, hipStream_t st)
 {
+    if (m.frag) {
+        hipLaunchKernelGGL(k_match_i8_q, dim3(m.K1p / I8Q_Q), dim3(64 * I8Q_WAVES), 0, st, m.K1, m.K2p, (const int8_t *)m.A.p, (const int8_t *)m.B.p,
+                           (const int *)m.na.p, (const int *)m.nb.p, k2_offset, (double *)m.ob.p, (double *)m.os.p, (int32_t *)m.oa.p);
+        PRE3_HIP(hipGetLastError());
+        return PRE3_OK;
+    }
     dim3 g(m.ntn, m.K1p / 128), b(256);
     hipLaunchKernelGGL(k_match_i8_mfma, g, b, 0, st, m.NDp, m.K1, m.K2, (const int8_t *)m.A.p, (const int8_t *)m.B.p, (const int *)m.na.p,
                        (const int *)m.nb.p, m.ntn, (int *)m.pb.p, (int *)m.ps.p, (int *)m.pa.p);
@@ -724,6 +832,107 @@ int knn_run(int device, int D, int N, const double *data, int M, const double *q
     PRE3_HIP(hipMemcpy(dist, ds.p, sizeof(double) * (size_t)M * k, hipMemcpyDeviceToHost));
     return PRE3_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Device-resident database shard of the sharded matcher (DESIGN.md "multi-GPU", C2): the queries (replicated) and this GPU's slice of
+// the database stay packed in HBM; a match is the distance kernel on the slice, an all-gather of the per-query partials (done by the
+// caller on DEVICE memory: RCCL), and the merge + Lowe's test + ordered compaction on the device.  Only the final pair list crosses PCIe.
+// ------------------------------------------------------------------------------------------------
+struct MatchShard {
+    I8Match m; int device = 0, k2_offset = 0;
+    DevBuf part;            // double [3][K1]: best | second | arg (as double) -- the all-gather payload
+    DevBuf res;             // double [1 + 3 K1]: count | pairs (2 K1) | scores (K1)
+};
+
+__global__ void k_shard_pack(int K1, const double *__restrict__ b, const double *__restrict__ s2, const int32_t *__restrict__ a, double *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K1) { out[i] = b[i]; out[K1 + i] = s2[i]; out[2 * K1 + i] = (double)a[i]; }
+}
+
+// pre3_siftmatch_merge on the device for the integer classes: per query the G partials are merged (ties -> lowest global index), the ratio
+// test is done in float on int-valued distances (siftmatch.c:122), and the matches are compacted in increasing k1 (one workgroup, ballots).
+__global__ __launch_bounds__(1024) void k_shard_merge(int G, int K1, const double *__restrict__ gathered, float thresh, double *__restrict__ res)
+{
+    __shared__ int s_cnt[16];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < K1; k0 += 1024) {
+        const int k1 = k0 + tid;
+        int ok = 0, K = -1; double B = 0, S2 = 0;
+        if (k1 < K1) {
+            for (int g = 0; g < G; ++g) {
+                const double *p = gathered + (size_t)g * 3 * K1;
+                const double ob = p[k1], os = p[K1 + k1]; const int oa = (int)p[2 * K1 + k1];
+                if (oa < 0) continue;
+                if (K < 0) { B = ob; S2 = os; K = oa; continue; }
+                if (ob < B || (ob == B && oa < K)) { S2 = os < B ? os : B; B = ob; K = oa; }
+                else { S2 = ob < S2 ? ob : S2; }
+            }
+            if (K >= 0) ok = thresh * (float)(int)B <= (float)(int)S2;
+        }
+        const unsigned long long bal = __ballot(ok);
+        if (lane == 0) s_cnt[wv] = __popcll(bal);
+        __syncthreads();
+        int off = s_base, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int c = s_cnt[w]; if (w < wv) off += c; tot += c; }
+        if (ok) {
+            const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+            res[1 + 2 * pos] = k1 + 1; res[2 + 2 * pos] = K + 1; res[1 + 2 * (size_t)K1 + pos] = B;
+        }
+        __syncthreads();
+        if (tid == 0) s_base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) res[0] = (double)s_base;
+}
+
+void *match_shard_create(int device, int ND, int K1, const uint8_t *L1, int K2, const uint8_t *L2, int k2_offset)
+{
+    if (ND <= 0 || K1 <= 0 || K2 < 0 || !L1 || (K2 && !L2)) { set_error("match shard: bad arguments"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { set_error("no HIP device %d", device); return nullptr; }
+    MatchShard *sh = new MatchShard();
+    sh->device = device; sh->k2_offset = k2_offset;
+    if (i8_prepare(sh->m, ND, K1, L1, K2, L2, 128) != PRE3_OK || sh->part.alloc(sizeof(double) * 3 * (size_t)K1) != PRE3_OK ||
+        sh->res.alloc(sizeof(double) * (1 + 3 * (size_t)K1)) != PRE3_OK) { delete sh; return nullptr; }
+    return sh;
+}
+int match_shard_run(void *h, void **partial_dev, int *n_doubles)
+{
+    MatchShard *sh = (MatchShard *)h;
+    PRE3_HIP(hipSetDevice(sh->device));
+    if (sh->m.K2 > 0) PRE3_TRY(i8_run(sh->m, sh->k2_offset, 0));
+    else { PRE3_HIP(hipMemsetAsync(sh->m.oa.p, 0xff, sizeof(int32_t) * sh->m.K1, 0)); }                      // empty slice: arg = -1 everywhere
+    hipLaunchKernelGGL(k_shard_pack, dim3(ceil_div(sh->m.K1, 256)), dim3(256), 0, 0, sh->m.K1, (const double *)sh->m.ob.p, (const double *)sh->m.os.p,
+                       (const int32_t *)sh->m.oa.p, (double *)sh->part.p);
+    PRE3_HIP(hipGetLastError());
+    PRE3_HIP(hipStreamSynchronize(0));              // the caller's collective runs on another stream
+    if (partial_dev) *partial_dev = sh->part.p;
+    if (n_doubles) *n_doubles = 3 * sh->m.K1;
+    return PRE3_OK;
+}
+int match_shard_merge(void *h, int G, const void *gathered_dev, double thresh, double *pairs_out, double *score_out, int *M_out)
+{
+    MatchShard *sh = (MatchShard *)h;
+    PRE3_CHECK(G >= 1 && gathered_dev && pairs_out && M_out, PRE3_E_ARG, "match shard merge: bad arguments");
+    PRE3_HIP(hipSetDevice(sh->device));
+    const int K1 = sh->m.K1;
+    hipLaunchKernelGGL(k_shard_merge, dim3(1), dim3(1024), 0, 0, G, K1, (const double *)gathered_dev, (float)thresh, (double *)sh->res.p);
+    PRE3_HIP(hipGetLastError());
+    double cnt = 0;
+    PRE3_HIP(hipMemcpy(&cnt, sh->res.p, sizeof(double), hipMemcpyDeviceToHost));
+    const int M = (int)cnt;
+    if (M > 0) {
+        PRE3_HIP(hipMemcpy(pairs_out, (const double *)sh->res.p + 1, sizeof(double) * 2 * M, hipMemcpyDeviceToHost));
+        if (score_out) PRE3_HIP(hipMemcpy(score_out, (const double *)sh->res.p + 1 + 2 * (size_t)K1, sizeof(double) * M, hipMemcpyDeviceToHost));
+    }
+    *M_out = M;
+    return PRE3_OK;
+}
+void match_shard_destroy(void *h) { delete (MatchShard *)h; }
 
 // matcher bench handle (inputs resident in HBM): uint8 descriptors, MFMA path
 struct MatchBench { I8Match m; };

@@ -18,9 +18,15 @@ import torch.distributed as dist
 
 
 class _DevView:
-    """int32 device memory owned by a pre3 context, for torch.as_tensor (no copy)"""
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i4", "data": (int(ptr), False), "version": 3}
+    """device memory owned by libpre3 (a context's support / mask buffer, a matcher shard's partials), for torch.as_tensor (no copy)"""
+    def __init__(self, ptr, n, typestr="<i4"):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 3}
+
+
+def dev_tensor(ptr, n, typestr="<i4", device=None):
+    """zero-copy torch view of `n` elements of libpre3 device memory at `ptr` (int32 by default, "<f8" for doubles)"""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    return torch.as_tensor(_DevView(ptr, n, typestr), device=dev)
 
 
 def shard_range(n, rank, world):
@@ -39,31 +45,48 @@ def _world():
 # ---------------------------------------------------------------------------------------------------
 # C1: sharded RANSAC scoring
 # ---------------------------------------------------------------------------------------------------
-def ransac_sharded(f, hyp, threshold, early_exit=True, device=None):
+_ZERO_COPY = {}         # (backend, world) -> bool: the path every rank agreed on (decided ONCE, collectively)
+
+
+def _agree_zero_copy(ok_here):
+    """All ranks must issue the same collectives: the zero-copy in-place all-reduce is used only if it works on EVERY rank (one MIN
+    all-reduce, the first time; a rank-local choice could leave ranks in collectives of different count and size)."""
+    key = (dist.get_backend(), dist.get_world_size())
+    if key not in _ZERO_COPY:
+        t = torch.tensor([1 if ok_here else 0], dtype=torch.int32, device="cuda" if key[0] == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        _ZERO_COPY[key] = bool(t.item())
+    return _ZERO_COPY[key]
+
+
+def ransac_sharded(f, hyp, threshold, early_exit=True, device=None, timing=None):
     """f: EkfFilter with projection + measurements installed (identical on every rank).
     Scores this rank's slice on the GPU, all-reduces supports and masks, selects.  Returns the same dict as
-    EkfFilter.ransac_hypotheses on every rank."""
+    EkfFilter.ransac_hypotheses on every rank.  timing: optional dict that receives the round's split (compute / collective / select, s)."""
+    import time
     rank, world = _world()
     hyp = np.ascontiguousarray(hyp, np.int32)
     n_draw, k = hyp.shape
     lo, hi = shard_range(n_draw, rank, world)
-    sup_ptr, msk_ptr, words = f.ransac_score_shard(hyp, threshold, lo, hi)
+    t0 = time.perf_counter()
+    sup_ptr, msk_ptr, words = f.ransac_score_shard(hyp, threshold, lo, hi)          # synchronous on return
+    t1 = time.perf_counter()
     if world > 1:
         backend = dist.get_backend()
         if backend == "nccl":
-            # all-reduce in place on the context's own support / mask buffers (zero-copy views): no export / import copies, no extra syncs
+            # all-reduce in place on the context's own support / mask buffers (zero-copy view): no export / import copies, no extra syncs
             dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
             gap = (msk_ptr - sup_ptr) // 4                  # the masks follow the supports in one allocation (pre3_ransac_score)
             both = None
             if n_draw <= gap <= n_draw + 4:
                 try:
-                    both = torch.as_tensor(_DevView(sup_ptr, gap + n_draw * max(words, 1)), device=dev)
+                    both = dev_tensor(sup_ptr, gap + n_draw * max(words, 1), "<i4", dev)
                 except Exception:                           # a torch build that cannot import __cuda_array_interface__ objects
                     both = None
-            if both is not None:
+            if _agree_zero_copy(both is not None):
                 dist.all_reduce(both, op=dist.ReduceOp.SUM)  # ONE collective, in place; slices are disjoint: integer sum == bitwise or
                 torch.cuda.synchronize()
-            else:                                           # stage through copies
+            else:                                           # stage through copies (every rank takes this branch together)
                 sup = torch.empty(n_draw, dtype=torch.int32, device=dev)
                 msk = torch.empty(n_draw * max(words, 1), dtype=torch.int32, device=dev)
                 f.ransac_export(n_draw, sup.data_ptr(), msk.data_ptr())
@@ -81,7 +104,14 @@ def ransac_sharded(f, hyp, threshold, early_exit=True, device=None):
             sup.copy_(sup_h); msk.copy_(msk_h)
             torch.cuda.synchronize()
             f.ransac_import(n_draw, sup.data_ptr(), msk.data_ptr())
-    return f.ransac_select(n_draw, k, early_exit)
+    t2 = time.perf_counter()
+    out = f.ransac_select(n_draw, k, early_exit)
+    if timing is not None:
+        t3 = time.perf_counter()
+        timing["compute"] = timing.get("compute", 0.0) + (t1 - t0)
+        timing["collective"] = timing.get("collective", 0.0) + (t2 - t1)
+        timing["select"] = timing.get("select", 0.0) + (t3 - t2)
+    return out
 
 
 def ransac_sharded_generic(score_slice, select, n_draw, words):
@@ -129,3 +159,25 @@ def siftmatch_sharded(L1, L2, thresh=1.5, partial=None, merge=None, return_score
     B, S, A = allp[:, :K1], allp[:, K1:2 * K1], allp[:, 2 * K1:].astype(np.int32)
     m, d = merge(L1.dtype, B, S, A, thresh)
     return (m, d) if return_scores else m
+
+
+def siftmatch_sharded_resident(shard, thresh=1.5, return_scores=False):
+    """The sharded matcher with everything resident on the GPUs (matcher.MatchShard: queries replicated, this rank's database slice packed
+    in HBM): distance kernel on the slice, ONE all-gather of the per-query partials as device tensors (RCCL; gloo stages through the
+    host), merge + ratio test + compaction on the device.  Only the match list crosses PCIe.  Identical to the unsharded match."""
+    rank, world = _world()
+    ptr, n = shard.run()
+    part = dev_tensor(ptr, n, "<f8")
+    if world > 1:
+        if dist.get_backend() == "nccl":
+            allp = torch.empty(world * n, dtype=torch.float64, device=part.device)
+            dist.all_gather_into_tensor(allp, part)
+        else:
+            ph = part.cpu()
+            outs = [torch.empty_like(ph) for _ in range(world)]
+            dist.all_gather(outs, ph)
+            allp = torch.cat(outs).to(part.device)
+        torch.cuda.synchronize()
+    else:
+        allp = part
+    return shard.merge(world, allp.data_ptr(), thresh, return_scores)

@@ -88,3 +88,37 @@ def kNearestNeighbors(dataMatrix, queryMatrix, k, device=0):
     check(lib.pre3_knn_f64(int(device), D, N, data.ctypes.data_as(C.c_void_p), M, query.ctypes.data_as(C.c_void_p), int(k),
                            ids.ctypes.data_as(C.c_void_p), dist.ctypes.data_as(C.c_void_p)))
     return np.ascontiguousarray(ids), np.ascontiguousarray(dist)
+
+
+class MatchShard:
+    """Device-resident database shard of the sharded matcher (pre3_match_shard_*): uint8 descriptors, L1 (128 x K1) replicated, L2_local
+    (128 x K2_local) = this rank's columns [k2_offset, ...) of the database.  run() leaves the per-query partials on the device and returns
+    (device pointer, number of doubles) for the caller's all-gather; merge() takes the DEVICE address of the gathered double[G][3][K1]."""
+
+    def __init__(self, L1, L2_local, k2_offset, device=0):
+        L1, L2 = np.asarray(L1), np.asarray(L2_local)
+        if L1.dtype != np.uint8 or L2.dtype != np.uint8:
+            raise Pre3Error(-1, "MatchShard: uint8 descriptors (the class of BASELINE.json configs[3])")
+        a, b = np.asfortranarray(L1), np.asfortranarray(L2)          # one descriptor per column, contiguous (MATLAB's layout)
+        self.K1, self.ND = int(L1.shape[1]), int(L1.shape[0])
+        self._h = C.c_void_p()
+        check(lib.pre3_match_shard_create(C.byref(self._h), int(device), self.ND, self.K1, a.ctypes.data_as(C.c_void_p), int(L2.shape[1]),
+                                     b.ctypes.data_as(C.c_void_p) if L2.shape[1] else None, int(k2_offset)))
+
+    def run(self):
+        p, n = C.c_void_p(), C.c_int(0)
+        check(lib.pre3_match_shard_run(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def merge(self, G, gathered_ptr, thresh=1.5, return_scores=False):
+        pairs, sc, M = np.zeros((self.K1, 2)), np.zeros(self.K1), C.c_int(0)
+        check(lib.pre3_match_shard_merge(self._h, int(G), C.c_void_p(int(gathered_ptr)), C.c_double(float(thresh)), dptr(pairs), dptr(sc), C.byref(M)))
+        m = pairs[:M.value].T.copy()
+        return (m, sc[:M.value].copy()) if return_scores else m
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.pre3_match_shard_destroy(self._h)
+            self._h = None
+
+    __del__ = close

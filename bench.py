@@ -28,34 +28,67 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK = {"f32": 157.3, "f64": 78.6, "bf16": 2500.0}       # dense MFMA TFLOP/s, MI355X_MICROARCH.md "Chip-level parameters" / "Matrix cores"
+PEAK = {"f32": 157.3, "f64": 78.6, "bf16": 2500.0, "i8": 5000.0}       # dense MFMA TFLOP/s, MI355X_MICROARCH.md "Chip-level parameters" / "Matrix cores"
 
 
-def cpu_baseline(seq, n_steps, threshold):
-    """The oracle's numpy twin (interpreter + multithreaded BLAS: the MATLAB-equivalent restatement) timed on
-    the host cores over a bounded sample of the SAME sequence.  Checker code, used here only as a baseline."""
-    twin = importlib.import_module("oracle.np_twin")
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(seq, threshold, budget_s=12.0):
+    """The reference's algorithm on the host cores, timed over a bounded sample of the SAME sequence (checker code, used here only as a
+    baseline).  Three legs, as BASELINE.md section 3 asks: the C restatement (oracle/pre3_oracle.c: explicit inv(S), K*S*K' as two
+    products, sparse-H row products, sequential per-hypothesis loop; scalar C loops -- the image has no host BLAS to link -- with
+    OpenMP over independent output rows) at ONE thread and at ALL cores, and the numpy twin (interpreter + OpenBLAS), the closest
+    thing to MATLAB's own execution model.  `value` is the fastest of the three."""
     import oracle as orc
+    twin = importlib.import_module("oracle.np_twin")
+    orc.build()
+    lib = orc.lib()
     N = seq["N"]
     types, off, _ = orc.landmark_table(np.zeros(N, int))
-    x, P = seq["x0"], seq["P0"]
-    t_tot, done = 0.0, 0
-    for s in seq["steps"][:n_steps]:
-        t0 = time.perf_counter()
-        o = twin.step(types, off, seq["cam"], x, P, s["u"], s["meas_idx"], s["z"], s["hyp"], threshold, early_exit=False)
-        t_tot += time.perf_counter() - t0
-        done += 1
-        x, P = o["x_kk"], o["P_kk"]
-        if t_tot > 30.0:
-            break
+    n_hyp = seq["steps"][0]["hyp"].shape[0]
+
+    def run(step_fn, budget):
+        x, P = seq["x0"], seq["P0"]
+        t_tot, done = 0.0, 0
+        for s in seq["steps"]:
+            t0 = time.perf_counter()
+            o = step_fn(types, off, seq["cam"], x, P, s["u"], s["meas_idx"], s["z"], s["hyp"], threshold, early_exit=False)
+            t_tot += time.perf_counter() - t0
+            done += 1
+            x, P = o["x_kk"], o["P_kk"]
+            if t_tot > budget:
+                break
+        return done / t_tot, done
+
+    ncores = os.cpu_count() or 1
+    lib.orc_set_threads(1)
+    c1, n1 = run(orc.step, budget_s)
+    lib.orc_set_threads(0)
+    call, nall = run(orc.step, budget_s)
+    threads_all = int(lib.orc_get_max_threads())
+    tw, ntw = run(twin.step, budget_s * 0.7)
     try:
         import threadpoolctl
-        cores = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+        blas_threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
     except Exception:
-        cores = os.cpu_count() or 1
-    return {"value": done / t_tot, "unit": "steps/s", "cores": int(cores), "kind": "port",
-            "sample": "%d steps of the same N=%d, %d-hypothesis sequence; numpy twin of the oracle (Python loops + OpenBLAS, "
-                      "fp64, all hypotheses evaluated)" % (done, N, seq["steps"][0]["hyp"].shape[0])}
+        blas_threads = ncores
+    legs = {"c_restatement_1_thread": {"value": c1, "steps": n1, "cores": 1},
+            "c_restatement_all_cores": {"value": call, "steps": nall, "cores": threads_all},
+            "numpy_twin_openblas": {"value": tw, "steps": ntw, "cores": int(blas_threads)}}
+    best = max(legs, key=lambda k: legs[k]["value"])
+    return {"value": legs[best]["value"], "unit": "steps/s", "cores": legs[best]["cores"], "kind": "port", "fastest_leg": best,
+            "cpu_model": _cpu_model(), "host_cores": ncores, "legs": legs,
+            "sample": "first steps of the same N=%d, %d-hypothesis sequence (all hypotheses evaluated, fp64), ~%d s per leg: C restatement of "
+                      "the reference at 1 thread and at all cores (scalar loops, OpenMP over rows; no host BLAS in the image), and the numpy "
+                      "twin (Python loops + OpenBLAS); MATLAB itself is unavailable" % (N, n_hyp, int(budget_s))}
 
 
 def all_ranks_ok(dist, ok):
@@ -69,29 +102,39 @@ def all_ranks_ok(dist, ok):
     return bool(t.item())
 
 
-def matcher_shard_leg(pre3, dist, rank, world, K=4096, reps=10):
-    """BASELINE.json configs[3] over the ranks: the database columns are sharded, every rank matches all 4096 queries against its
-    slice, one all-gather of (best, second, arg) and the order-independent merge (3pre_amd/dist.siftmatch_sharded).  Whole
-    stateless calls from host arrays (PCIe and the collective inside the timed region): descriptor pairs/s of the whole job."""
+def matcher_shard_leg(pre3, dist, rank, world, local_rank=0, K=4096, reps=20):
+    """BASELINE.json configs[3] over the ranks, device resident: the queries are replicated and every rank keeps its slice of the
+    database packed in HBM (matcher.MatchShard); a match = int8-MFMA distance kernel on the slice, ONE all-gather of the per-query
+    partials as device tensors (RCCL over xGMI), merge + ratio test + compaction on the device; only the match list crosses PCIe.
+    Whole-job descriptor pairs/s (the collective and the merge are inside the timed region)."""
     import torch
     pd = importlib.import_module("3pre_amd.dist")
+    mt = importlib.import_module("3pre_amd.matcher")
     rng = np.random.default_rng(5000)                   # same data on every rank
     L1 = np.minimum(np.round(np.abs(rng.standard_normal((K, 128))) * 40), 255).astype(np.uint8)
     L2 = np.clip(L1[rng.permutation(K)].astype(int) + rng.integers(-2, 3, (K, 128)), 0, 255).astype(np.uint8)
     L1c, L2c = np.asfortranarray(L1.T), np.asfortranarray(L2.T)      # 128 x K, column-major like the reference
-    for _ in range(2):
-        m = pd.siftmatch_sharded(L1c, L2c, 1.5)
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        m = pd.siftmatch_sharded(L1c, L2c, 1.5)
-    el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    return {"workload": "configs[3]: 4096x4096x128 uint8, database columns sharded over %d GPU(s), whole call from host arrays" % world,
+    lo, hi = pd.shard_range(K, rank, world)
+    sh = mt.MatchShard(L1c, L2c[:, lo:hi], lo, device=local_rank)
+    try:
+        for _ in range(3):
+            m = pd.siftmatch_sharded_resident(sh, 1.5)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            m = pd.siftmatch_sharded_resident(sh, 1.5)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+    finally:
+        sh.close()
+    return {"workload": "configs[3]: 4096x4096x128 uint8, database columns sharded over %d GPU(s), operands resident in HBM, partials "
+                        "all-gathered as device tensors, merge on the device" % world,
             "ms_per_match": 1e3 * el / reps, "pairs_per_s": reps * K * K / el, "matches": int(np.asarray(m).shape[1]), "n_gpus": world, "scaling": "strong"}
 
 
@@ -123,9 +166,10 @@ def ransac_shard_leg(pre3, synth, dist, rank, world, local_rank, N=2000, n_hyp=1
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
+        split = {}
         t0 = time.perf_counter()
         for _ in range(reps):
-            out = pd.ransac_sharded(f, s["hyp"], 1.0, early_exit=False)
+            out = pd.ransac_sharded(f, s["hyp"], 1.0, early_exit=False, timing=split)
         f.sync()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
@@ -137,14 +181,15 @@ def ransac_shard_leg(pre3, synth, dist, rank, world, local_rank, N=2000, n_hyp=1
         return {"workload": "configs[4]: N=%d (n=%d), %d hypotheses (k=3), m=%d measured, f32; per round: H*P and H*P*H' gathers, "
                             "sharded scoring, all-reduce, replay" % (N, seq["n"], n_hyp, len(s["meas_idx"])),
                 "value": reps * n_hyp / el, "unit": "hypotheses/s", "n_gpus": world, "ms_per_round": 1e3 * el / reps,
-                "max_support": int(out["max_support"]), "scaling": "strong"}
+                "max_support": int(out["max_support"]), "scaling": "strong",
+                "ms_split_rank0": {k_: 1e3 * v / reps for k_, v in split.items()}}
     finally:
         f.close()
 
 
 def matcher_leg(pre3, reps=20):
-    """BASELINE.json configs[3]: 4096 x 4096 x 128 uint8 descriptors, int8-MFMA distance kernel + fused
-    best/second-best scan, inputs resident in HBM (kernel time, HIP events)."""
+    """BASELINE.json configs[3]: 4096 x 4096 x 128 uint8 descriptors, int8-MFMA distance kernel with the best/second-best scan fused
+    (one launch), inputs resident in HBM (HIP events around back-to-back launches: ~2.6 us of each is an empty launch)."""
     import ctypes as C
     rng = np.random.default_rng(5000)
     K = 4096
@@ -159,8 +204,13 @@ def matcher_leg(pre3, reps=20):
     lib.pre3_match_bench_destroy(C.c_void_p(h))
     if rc != 0:
         return None
+    tops = 2.0 * K * K * 128 / (ms.value * 1e-3) / 1e12
     return {"workload": "configs[3]: 4096x4096x128 uint8, 1 GPU", "ms_per_match": ms.value, "pairs_per_s": K * K / (ms.value * 1e-3),
-            "int8_mfma_TOPS": 2.0 * K * K * 128 / (ms.value * 1e-3) / 1e12}
+            "int8_mfma_TOPS": tops,
+            "roofline": {"kernel": "k_match_i8_q (v_mfma_i32_16x16x64_i8, query-per-lane scan fused, one launch)", "bound": "mfma", "unit": "TOP/s",
+                         "achieved": tops, "peak": PEAK["i8"], "frac": tops / PEAK["i8"], "traffic": None,
+                         "algorithmic": "2 * K1 * K2 * 128 integer ops per match; the kernel is bound by its scan's vector instructions and by "
+                                        "streaming the database through L2, not by the matrix pipe (DESIGN.md section 4, K11)"}}
 
 
 def vo_leg(pre3, pnum=500, n_hyp=700, reps=50):
@@ -183,6 +233,57 @@ def vo_leg(pre3, pnum=500, n_hyp=700, reps=50):
             "hypotheses_per_s": n_hyp / (ms * 1e-3), "n_support": out["n_support"], "sta": out["sta"]}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher environment: start the N ranks ourselves, as a child `torch.distributed.run`, BEFORE this
+    process touches the GPU (a process that has initialised HIP must not exec), relay its output and exit with its code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def legs_agree(dist, err, name):
+    """Collective-safe error hand-off after a leg's collectives: if the leg failed on ANY rank, every rank learns it here (one MIN
+    all-reduce) and the job stops with a non-zero exit instead of walking into further collectives with a rank missing."""
+    if dist is None:
+        return                                  # one process: the leg's error is recorded in the line, nothing can be left waiting
+    ok = all_ranks_ok(dist, err is None)
+    if not ok:
+        sys.stderr.write("bench.py: leg %r failed on a rank (%r) -- aborting, no further collectives\n" % (name, err))
+        sys.stderr.flush()
+        os._exit(3)
+
+
+def check_step(pre3, f, seq, s, thr, dtype):
+    """One more step behind the timed region, replayed on the numpy twin from the SAME starting state (the filter's own x_k_k, p_k_k):
+    inlier sets and RANSAC statistics must be identical, state and covariance within the fp tolerance of the dtype."""
+    twin = importlib.import_module("oracle.np_twin")
+    import oracle as orc
+    N = seq["N"]
+    types, off, _ = orc.landmark_table(np.zeros(N, int))
+    f.defer_hi_update(False)
+    x0, P0 = f.get_x_k_k(), f.get_p_k_k()
+    st = f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=thr, early_exit=False)
+    li, hi = f.get_flags()
+    xg, Pg = f.get_x_k_k(), f.get_p_k_k()
+    ref = twin.step(types, off, seq["cam"], x0, P0, s["u"], s["meas_idx"], s["z"], s["hyp"], thr, early_exit=False)
+    scale = float(np.abs(ref["P_kk"]).max())
+    eP, ex = float(np.abs(Pg - ref["P_kk"]).max() / scale), float(np.abs(xg - ref["x_kk"]).max())
+    tolP, tolx = (3e-4, 2e-5) if dtype == "f32" else (1e-11, 1e-10)
+    li_ok, hi_ok = bool(np.array_equal(li, ref["li"])), bool(np.array_equal(hi, ref["hi"]))
+    r = ref["ransac"]
+    st_ok = (st["best"], st["max_support"]) == (r["best"], r["max_support"])
+    return {"checked": bool(li_ok and hi_ok and st_ok and eP < tolP and ex < tolx), "li_set_equal": li_ok, "hi_set_equal": hi_ok,
+            "ransac_winner_equal": bool(st_ok), "n_li": int(st["n_li"]), "n_hi": int(st["n_hi"]), "P_rel_err": eP, "x_abs_err": ex,
+            "tolerance": {"P_rel": tolP, "x_abs": tolx},
+            "how": "the step after the timed region, GPU vs oracle/np_twin.py from the filter's own state (LI/HI sets and the RANSAC winner exact)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,20 +296,28 @@ def main():
     ap.add_argument("--sync-hi", action="store_true", help="complete every step's HI update inside the step call (default: deferred to the next call)")
     ap.add_argument("--k9-f32", action="store_true", help="fp32 path: K9 on the f32 MFMA instead of the three-way bf16 split (PRE3_OPT_K9_BF16X3 = 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of host work per CPU-baseline leg (three legs)")
+    ap.add_argument("--no-check", action="store_true", help="skip the parity check of one step behind the timed region")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the sharded-RANSAC and matcher legs")
     args = ap.parse_args()
 
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        sys.exit(self_launch(args))                 # nothing in this process has touched the GPU yet
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s); refusing to print a line that would claim the wrong n_gpus\n" % (args.gpus, world))
+        sys.exit(2)
     import torch
     dist = None
-    if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):     # launched by torch.distributed.run (any N)
+    if world > 1 or launched:                       # launched by torch.distributed.run (any N)
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=180))
     pre3 = importlib.import_module("3pre_amd")
     synth = importlib.import_module("3pre_amd.synth")
     if pre3.device_count() < 1:
@@ -217,7 +326,7 @@ def main():
 
     N, K, W = args.landmarks, args.steps, args.warmup
     thr = 1.0
-    seq = synth.make_sequence(N, K + W, args.hyp, seed=None if rank == 0 else 10_000 * rank + N)
+    seq = synth.make_sequence(N, K + W + 1, args.hyp, seed=None if rank == 0 else 10_000 * rank + N)     # + 1: the checked step
     f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype=args.dtype, device=local_rank, max_hyp=args.hyp, std_z=thr)
     b3 = f.k9_bf16x3(False if args.k9_f32 else None) if args.dtype == "f32" else False
     f.set_x_p_k_k(seq["x0"], seq["P0"])
@@ -254,13 +363,16 @@ def main():
         n_hi = float(np.mean([s["n_hi"] for s in stats]))
         achieved = kt["flops"] / (kt["total_ms"] * 1e-3) / 1e12 if kt["total_ms"] > 0 else 0.0
         traffic, traffic_src = None, None
-        try:    # HBM bytes per LI launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
-            with open(os.path.join(ROOT, "profiles", "r1_pmc_k9.json")) as fh:
-                pj = json.load(fh)
-            traffic = pj["hbm_bytes_per_li_launch"]["raw"]
-            traffic_src = "profiles/r1_pmc_k9.json (raw FETCH_SIZE+WRITE_SIZE of the r=640 launches; FETCH_SIZE under-reports 16 B/lane reads by up to 2x on gfx950)"
-        except Exception:
-            pass
+        for tag in ("r2", "r1"):    # HBM bytes per LI launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
+            try:
+                with open(os.path.join(ROOT, "profiles", "%s_pmc_k9.json" % tag)) as fh:
+                    pj = json.load(fh)
+                traffic = pj["hbm_bytes_per_li_launch"]["fetch_doubled"]
+                traffic_src = ("profiles/%s_pmc_k9.json (WRITE_SIZE + 2 x FETCH_SIZE of the r=640 launches: gfx950 reports half the bytes of 16 B/lane "
+                               "reads, MI355X_MICROARCH.md; raw sum %.1f MB)" % (tag, pj["hbm_bytes_per_li_launch"]["raw"] / 1e6))
+                break
+            except Exception:
+                pass
         algo = ("symmetric rank-r down-date (SYRK): n(n+1)r flop per launch, r = rows of that update, averaged over the K9 launches of "
                 "the timed region that were bracketed with HIP events: one in --kt-every of the launches with >= 128 rows, i.e. the LI "
                 "updates (r ~ 640); the HI updates' launches (r <= 64) are HBM-bound read-modify-writes of P and are not priced against the "
@@ -283,10 +395,16 @@ def main():
             roofline = dict(kernel="k_downdate_1t / k_downdate (K9: P <- P - W'W on the %s MFMA; the x-update and rescue-projection riders "
                                    "share the one-tile launch)" % args.dtype,
                             bound="mfma", dtype=args.dtype, achieved=achieved, peak=PEAK[args.dtype], frac=achieved / PEAK[args.dtype], **common)
+        ms_step = 1e3 * elapsed / K
+        # the step's ideal = its algorithmic flops at the MFMA peak of the dtype, no latency: F_upd(r) = 2*19*n*r + 2*19*r^2 + r^3/3
+        # + 2*n*r^2 + 2*n^2*r + 2*n*r for the LI and the HI update (r = measured mean rows)
+        def f_upd(r):
+            return 2 * 19 * n * r + 2 * 19 * r * r + r ** 3 / 3.0 + 2 * n * r * r + 2.0 * n * n * r + 2 * n * r
+        ideal_us = (f_upd(2 * n_li) + f_upd(2 * n_hi)) / (PEAK[args.dtype] * 1e12) * 1e6
         out = {
             "metric": "EKF steps/sec (predict+RANSAC+update) at N=500 landmarks; P-update %MFMA peak",
             "value": world * K / elapsed, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "configs[2]: N=%d inverse-depth landmarks (n=%d), %d RANSAC hypotheses (k=3, all evaluated), "
                                    "%s covariance path, full 1PRE step" % (N, n, args.hyp, args.dtype),
@@ -294,36 +412,37 @@ def main():
                        "mean_li_rows": 2 * n_li, "mean_hi_rows": 2 * n_hi, "parallelism": "replicas x%d" % world,
                        "hip_event_ms_per_step": ev_ms / K},
             "roofline": roofline,
+            "step_ideal": {"ideal_us": ideal_us, "achieved_us": 1e3 * ms_step, "step_ideal_frac": ideal_us / (1e3 * ms_step),
+                           "note": "SURVEY 8(d): algorithmic flops of the LI + HI updates at the %s MFMA peak, no latency" % args.dtype},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(seq, args.cpu_steps, thr)
+    # parity of what was timed: one more step of the same sequence, GPU vs the numpy twin (outside the timed region)
+    if rank == 0 and not args.no_check:
+        try:
+            out.update(check_step(pre3, f, seq, seq["steps"][W + K], thr, args.dtype))
+        except Exception as e:                                  # pragma: no cover
+            out.update({"checked": False, "check_error": repr(e)[:300]})
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(seq, thr, args.cpu_budget)
     f.close()
-    # secondary legs (never allowed to break the headline line): sharded RANSAC and sharded matcher at every N, kernel-only
-    # matcher and VO RANSAC at N=1
+    # secondary legs: sharded RANSAC and sharded matcher at every N, kernel-only matcher and VO RANSAC at N=1.  A leg that fails on any
+    # rank stops the job (legs_agree): the other ranks must not be left inside a collective.
     if not args.no_extra_legs:
-        try:
-            leg = ransac_shard_leg(pre3, synth, dist, rank, world, local_rank)
+        for name, fn in (("ransac_shard", lambda: ransac_shard_leg(pre3, synth, dist, rank, world, local_rank)),
+                         ("matcher_shard", lambda: matcher_shard_leg(pre3, dist, rank, world, local_rank))):
+            leg, err = None, None
+            try:
+                leg = fn()
+            except Exception as e:                              # pragma: no cover
+                err = e
+            legs_agree(dist, err, name)
             if rank == 0:
-                out["ransac_shard"] = leg
-        except Exception as e:                                  # pragma: no cover
-            if rank == 0:
-                out["ransac_shard"] = {"error": repr(e)[:300]}
-        try:
-            leg = matcher_shard_leg(pre3, dist, rank, world)
-            if rank == 0:
-                out["matcher_shard"] = leg
-        except Exception as e:                                  # pragma: no cover
-            if rank == 0:
-                out["matcher_shard"] = {"error": repr(e)[:300]}
+                out[name] = leg if err is None else {"error": repr(err)[:300]}
         if world == 1:
-            try:
-                out["matcher"] = matcher_leg(pre3)
-            except Exception as e:                              # pragma: no cover
-                out["matcher"] = {"error": repr(e)[:300]}
-            try:
-                out["vo_ransac"] = vo_leg(pre3)
-            except Exception as e:                              # pragma: no cover
-                out["vo_ransac"] = {"error": repr(e)[:300]}
+            for name, fn in (("matcher", lambda: matcher_leg(pre3)), ("vo_ransac", lambda: vo_leg(pre3))):
+                try:
+                    out[name] = fn()
+                except Exception as e:                          # pragma: no cover
+                    out[name] = {"error": repr(e)[:300]}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

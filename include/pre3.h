@@ -282,6 +282,19 @@ PRE3_API int pre3_siftmatch_partial(int device, int cls, int ND, int K1, const v
 PRE3_API int pre3_siftmatch_merge(int cls, int G, int K1, const double *best, const double *second, const int32_t *arg,
                                   double thresh, double *pairs_out, double *score_out, int *M_out);
 
+/* Device-resident database shard of the sharded matcher (uint8 class: BASELINE.json configs[3]).  The queries L1 (replicated on every
+ * rank) and this rank's database slice L2_local = columns [k2_offset, k2_offset + K2_local) of the whole L2 are packed once into HBM.
+ * pre3_match_shard_run leaves the slice's per-query partials on the DEVICE as double[3][K1] = best | second | global arg (arg < 0: none)
+ * and returns their address: the caller all-gathers them with RCCL (device memory, no host staging) into double[G][3][K1] and hands that
+ * DEVICE buffer to pre3_match_shard_merge, which merges (ties -> lowest index), applies Lowe's test in float (siftmatch.c:122) and
+ * compacts the matches in increasing k1 on the device; only the M pairs cross PCIe.  Results are identical to pre3_siftmatch_u8 on the
+ * whole database for any number of shards. */
+typedef struct pre3_match_shard pre3_match_shard;
+PRE3_API int pre3_match_shard_create(pre3_match_shard **out, int device, int ND, int K1, const uint8_t *L1, int K2_local, const uint8_t *L2_local, int k2_offset);
+PRE3_API int pre3_match_shard_run(pre3_match_shard *s, void **partial_dev, int *n_doubles);
+PRE3_API int pre3_match_shard_merge(pre3_match_shard *s, int G, const void *gathered_dev, double thresh, double *pairs_out, double *score_out, int *M_out);
+PRE3_API int pre3_match_shard_destroy(pre3_match_shard *s);
+
 /* ---- a11: kNearestNeighbors.m:29-39 ------------------------------------------------------------- */
 /* data: N x D, query: M x D, MATLAB column-major.  ids_out (M x k, column-major, 1-based doubles),
  * dist_out (M x k, Euclidean).  Ties: lowest index first (MATLAB's stable sort). */

@@ -51,6 +51,15 @@ def main():
         m, d = pd.siftmatch_sharded(L1.astype(dt), L2.astype(dt), 1.5, return_scores=True)
         mr, dr = orc.siftmatch(L1.astype(dt), L2.astype(dt), 1.5)
         assert np.array_equal(m, mr) and np.array_equal(d, dr)
+    # the device-resident sharded matcher (matcher.MatchShard): slice packed in HBM, partials gathered as tensors, merge on the device
+    mt = importlib.import_module("3pre_amd.matcher")
+    lo, hi = pd.shard_range(L2.shape[1], rank, world)
+    sh = mt.MatchShard(L1, L2[:, lo:hi], lo, device=0)
+    for thr in (1.5, 1.1):
+        m, d = pd.siftmatch_sharded_resident(sh, thr, return_scores=True)
+        mr, dr = orc.siftmatch(L1, L2, thr)
+        assert np.array_equal(m, mr) and np.array_equal(d, dr), "resident sharded matcher differs from the oracle"
+    sh.close()
     dist.barrier()
     dist.destroy_process_group()
     print("rank %d/%d OK" % (rank, world))
