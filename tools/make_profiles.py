@@ -1,4 +1,4 @@
-"""Turn the rocprofv3 outputs of one measurement session into the committed summaries under profiles/.
+"""Turn the rocprofv3 outputs of one measurement session (tools/collect_profiles.sh <tag>) into the committed summaries under profiles/.
 
     gpurun_out/r1_trace/      rocprofv3 --kernel-trace --stats  -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extra-legs
     gpurun_out/r1_pmc_fetch/  rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra-legs
@@ -8,13 +8,20 @@ usage: python tools/make_profiles.py [tag]      (tag defaults to r1)"""
 import csv, json, os, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 K9 = "k_downdate_b3"
 
-shutil.copy(os.path.join(G, "%s_trace" % tag, "%s_kernel_stats.csv" % tag), os.path.join(P, "%s_bench_kernel_stats.csv" % tag))
-tl = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_timeline.py"), os.path.join(G, "%s_trace" % tag, "%s_kernel_trace.csv" % tag), "3"],
+def find(d, name):
+    for dp, _, fs in os.walk(os.path.join(G, d)):
+        if name in fs:
+            return os.path.join(dp, name)
+    raise FileNotFoundError("%s/%s" % (d, name))
+
+
+shutil.copy(find("%s_trace" % tag, "%s_kernel_stats.csv" % tag), os.path.join(P, "%s_bench_kernel_stats.csv" % tag))
+tl = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_timeline.py"), find("%s_trace" % tag, "%s_kernel_trace.csv" % tag), "3"],
                     capture_output=True, text=True, check=True).stdout
 with open(os.path.join(P, "%s_bench_one_step_timeline.txt" % tag), "w") as fh:
     fh.write("# one filter step (N=500, n=3013, 200 hypotheses, f32) from rocprofv3 --kernel-trace of `python3 bench.py --steps 40 --warmup 5 "
@@ -22,14 +29,14 @@ with open(os.path.join(P, "%s_bench_one_step_timeline.txt" % tag), "w") as fh:
 
 
 def counter(dirname, prefix, name):
-    rows = [r for r in csv.DictReader(open(os.path.join(G, dirname, "%s_counter_collection.csv" % prefix))) if K9 in r["Kernel_Name"] and r["Counter_Name"] == name]
+    rows = [r for r in csv.DictReader(open(find(dirname, "%s_counter_collection.csv" % prefix))) if K9 in r["Kernel_Name"] and r["Counter_Name"] == name]
     v = [float(r["Counter_Value"]) for r in rows]
     big = [x for x in v if x > 0.8 * max(v)]                 # the r ~ 640 launches (LI updates); HI updates are far smaller
     return dict(launches=len(v), avg_KB=sum(v) / len(v), max_KB=max(v), li_launch_avg_KB=sum(big) / len(big))
 
 
 fs, ws = counter("%s_pmc_fetch" % tag, "f", "FETCH_SIZE"), counter("%s_pmc_write" % tag, "w", "WRITE_SIZE")
-tr = [r for r in csv.DictReader(open(os.path.join(G, "%s_trace" % tag, "%s_kernel_trace.csv" % tag))) if K9 in r["Kernel_Name"]]
+tr = [r for r in csv.DictReader(open(find("%s_trace" % tag, "%s_kernel_trace.csv" % tag))) if K9 in r["Kernel_Name"]]
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
 big = [d for d in dur if d > 0.6 * max(dur)]
 out = {
@@ -49,3 +56,45 @@ out = {
 with open(os.path.join(P, "%s_pmc_k9.json" % tag), "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps(out["counters_KB"], indent=1), out["k9_trace_durations_us"], out["hbm_bytes_per_li_launch"])
+
+# ---- the factorisation (k_chol_step): per-launch durations by panel and the SQ counters of its launches
+import collections
+by = collections.defaultdict(list)
+for r in csv.DictReader(open(find("%s_trace" % tag, "%s_kernel_trace.csv" % tag))):
+    if "k_chol_step" in r["Kernel_Name"]:
+        by[int(r.get("Grid_Size", r.get("Grid_Size_X", 0)))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+lines = ["# k_chol_step (K8) in `bench.py --steps 40` (N=500, n=3013, r ~ 640: ten 64-column panels per LI update), rocprofv3 --kernel-trace",
+         "# grid threads | launches | median us | mean us"]
+tot = 0.0
+for g in sorted(by, reverse=True):
+    v = sorted(by[g])
+    if len(v) > 20:
+        lines.append("%8d %6d %8.2f %8.2f" % (g, len(v), v[len(v) // 2], sum(v) / len(v)))
+        tot += v[len(v) // 2]
+lines.append("# sum of the medians of one LI update's panels: %.1f us" % tot)
+sq = os.path.join(G, "%s_pmc_sq" % tag)
+if os.path.isdir(sq):
+    lines.append("# SQ counters per launch (separate --pmc passes, means over the k_chol_step launches of 10 steps)")
+    for dp, _, fs in sorted(os.walk(sq)):
+        for fn in fs:
+            if fn.endswith("counter_collection.csv"):
+                acc = collections.defaultdict(list)
+                for r in csv.DictReader(open(os.path.join(dp, fn))):
+                    if "k_chol_step" in r["Kernel_Name"]:
+                        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                for k_, v in sorted(acc.items()):
+                    lines.append("%-28s %12.5g  (%d launches)" % (k_, sum(v) / len(v), len(v)))
+with open(os.path.join(P, "%s_chol_launches.txt" % tag), "w") as fh:
+    fh.write("\n".join(lines) + "\n")
+print("\n".join(lines[-14:]))
+
+# ---- the matcher (k_match_i8_q)
+try:
+    shutil.copy(find("%s_match" % tag, "m_kernel_stats.csv"), os.path.join(P, "%s_match_kernel_stats.csv" % tag))
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(find("%s_match" % tag, "m_kernel_trace.csv"))) if "k_match_i8_q" in r["Kernel_Name"]]
+    big = [x for x in d if x > 0.7 * max(d)]
+    with open(os.path.join(P, "%s_match_kernel_stats.csv" % tag), "a") as fh:
+        fh.write("# k_match_i8_q at 4096 x 4096 x 128 uint8 (the %d largest launches of tools/match_ab.py child): mean %.2f us, min %.2f us\n" % (len(big), sum(big) / len(big), min(big)))
+    print("matcher 4096^2 launches: mean %.2f us" % (sum(big) / len(big)))
+except FileNotFoundError as e:
+    print("no matcher trace:", e)
