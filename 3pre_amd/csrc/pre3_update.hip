@@ -239,7 +239,7 @@ __device__ unsigned int g_k9hw[2048];               // HW_ID of wave 0 (CU / SE 
 #define PROBE_T(k, T_) do { if (threadIdx.x == (T_) && blockIdx.x == g_probe_block) g_probe[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #ifdef PRE3_PROBE_STEPS
 // per pipeline step of the panel chain: start / end-of-work stamps of the factor wave (0), the z wave (1) and the first worker wave (2)
-#define PROBE_STEP(k, e) do { if ((threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) >= 4) && blockIdx.x == g_probe_block) g_k9[((k) + 1) * 8 + ((threadIdx.x >> 6) == 4 ? 0 : (threadIdx.x >> 6) == 5 ? 1 : 2) * 2 + (e)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PROBE_STEP(k, e) do { if ((threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) >= 8) && blockIdx.x == g_probe_block) g_k9[((k) + 1) * 8 + ((threadIdx.x >> 6) == 8 ? 0 : (threadIdx.x >> 6) == 9 ? 1 : 2) * 2 + (e)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define PROBE_F(k, j) do { if ((k) == 3 && (threadIdx.x & 63) == 0 && blockIdx.x == g_probe_block) { __builtin_amdgcn_sched_barrier(0); g_k9[100 + (j)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define PROBE_F(k, j)
@@ -284,7 +284,7 @@ __device__ inline double chain_rcp(double x) { double r = __builtin_amdgcn_rcp(x
 // ONE workgroup barrier per step, 10 steps per 64 columns (was 18 with 4-column micro-panels and the X solve on the
 // factor wave).  Every workgroup factors the diagonal block redundantly; workgroup b then owns X = its 64-row block
 // of [S ; HP'] (b = 0: the diagonal block itself).
-constexpr int CH_MB = 8, CH_NSP = NB / CH_MB, CH_NTH = 384;
+constexpr int CH_MB = 8, CH_NSP = NB / CH_MB, CH_NTH = 640;
 #ifndef CH_EXP_Z
 #define CH_EXP_Z 1          // timing experiments (tools/probe_panel.hip): 0 = the z wave idles
 #define CH_EXP_WX 1         // 0 = the workers skip the X tiles
@@ -321,9 +321,9 @@ template <typename T> struct ChW {
     typedef typename M::acc_t acc_t;
 };
 
-template <typename T, int WV>
-__device__ __forceinline__ void ch_worker_load(ChSmem<T> &sm, typename ChW<T>::acc_t (&accD)[ChW<T>::NBLK][ChW<T>::NBLK],
-                                               typename ChW<T>::acc_t (&accX)[ChW<T>::NBLK][ChW<T>::NBLK], const int lane, const bool hasX)
+// raw tile from LDS (the D tile of Ls, or the X tile of Xs[a][i]: tile rows = panel columns a, tile columns = i)
+template <typename T, int WV, bool XSIDE>
+__device__ __forceinline__ void ch_worker_load(ChSmem<T> &sm, typename ChW<T>::acc_t (&acc)[ChW<T>::NBLK][ChW<T>::NBLK], const int lane, const bool live)
 {
     using M = Mfma<T>;
     constexpr int NBLK = ChW<T>::NBLK, w0 = (WV >> 1) * 32, w1 = (WV & 1) * 32;
@@ -335,86 +335,82 @@ __device__ __forceinline__ void ch_worker_load(ChSmem<T> &sm, typename ChW<T>::a
 #pragma unroll
             for (int e = 0; e < M::NREG; ++e) {
                 const int r = p * M::BLK + M::row(lane, e), c = q * M::BLK + cl;
-                accD[p][q][e] = WV != 1 ? sm.Ls[w0 + r][w1 + c] : (T)0;
-                accX[p][q][e] = hasX ? sm.Xs[w0 + r][w1 + c] : (T)0;           // Xs[a][i]: tile rows = panel columns a, tile columns = i
+                acc[p][q][e] = !live ? (T)0 : XSIDE ? sm.Xs[w0 + r][w1 + c] : sm.Ls[w0 + r][w1 + c];
             }
 }
 
-template <typename T, int WV>
-__device__ __forceinline__ void ch_worker_step(const int k, ChSmem<T> &sm, typename ChW<T>::acc_t (&accD)[ChW<T>::NBLK][ChW<T>::NBLK],
-                                               typename ChW<T>::acc_t (&accX)[ChW<T>::NBLK][ChW<T>::NBLK], const int lane, const bool hasX)
+// One pipeline step of a worker wave.  D side (waves 0-3; the tile above the diagonal, WV = 1, is dead): D -= Y(k-1) Y(k-1)' where the tile
+// still has columns >= 8(k+1) (sub-panel k's own columns get it from the factor wave's lookahead), then publish sub-panel k+1's columns.
+// X side (waves 4-7): X -= Y(k-2) Z(k-2) where the tile still has rows >= 8k (sub-panel k-1's rows get it from the z wave's lookahead), then
+// publish rows 8k..8k+7.  One LDS round trip and one MFMA chain per wave and step (the two sides used to share a wave, back to back).
+template <typename T, int WV, bool XSIDE>
+__device__ __forceinline__ void ch_worker_step(const int k, ChSmem<T> &sm, typename ChW<T>::acc_t (&acc)[ChW<T>::NBLK][ChW<T>::NBLK], const int lane, const bool live)
 {
     using M = Mfma<T>;
     typedef typename ChW<T>::vk_t vk_t;
     constexpr int NBLK = ChW<T>::NBLK, NJ = ChW<T>::NJ, MB = CH_MB, NSP = CH_NSP, w0 = (WV >> 1) * 32, w1 = (WV & 1) * 32;
     const int cl = M::col(lane), kq = M::kk(lane) * NJ;
-    // D -= Y(k-1) Y(k-1)' where the tile still has columns >= 8(k+1) (sub-panel k's own columns get it from the factor wave's lookahead);
-    // X -= Y(k-2) Z(k-2) where the tile still has rows >= 8k (sub-panel k-1's rows get it from the z wave's lookahead).
-    // All operands are requested first, the X products issue first and the D products behind them, so that ONE LDS round trip and
-    // the matrix pipe's latency are paid per step (the two dependent read -> MFMA -> store sequences used to run back to back).
-    const bool doD = WV != 1 && k >= 1 && k + 1 <= NSP - 1 && w1 + 32 > MB * (k + 1);
-    const bool doX = hasX && CH_EXP_WX && k >= 2 && k <= NSP - 1 && w0 + 32 > MB * k;
-    vk_t aD[NBLK], bD[NBLK], aX[NBLK], bX[NBLK];
-    if (doD) {
-        const int C = MB * (k - 1);
+    if (!live) return;
+    if constexpr (!XSIDE) {
+        if (WV == 1) return;
+        if (k >= 1 && k + 1 <= NSP - 1 && w1 + 32 > MB * (k + 1)) {
+            const int C = MB * (k - 1);
+            vk_t a[NBLK], bb[NBLK];
 #pragma unroll
-        for (int p = 0; p < NBLK; ++p) {
-            aD[p] = *reinterpret_cast<const vk_t *>(&sm.Ls[w0 + p * M::BLK + cl][C + kq]);
-            bD[p] = *reinterpret_cast<const vk_t *>(&sm.Ls[w1 + p * M::BLK + cl][C + kq]);
-        }
-    }
-    if (doX) {
-        const int C = MB * (k - 2), par = (k - 2) & 1;
+            for (int p = 0; p < NBLK; ++p) {
+                a[p] = *reinterpret_cast<const vk_t *>(&sm.Ls[w0 + p * M::BLK + cl][C + kq]);
+                bb[p] = *reinterpret_cast<const vk_t *>(&sm.Ls[w1 + p * M::BLK + cl][C + kq]);
+            }
 #pragma unroll
-        for (int p = 0; p < NBLK; ++p) {
-            aX[p] = *reinterpret_cast<const vk_t *>(&sm.Ls[w0 + p * M::BLK + cl][C + kq]);
-            bX[p] = *reinterpret_cast<const vk_t *>(&sm.pipe.Zt[par][w1 + p * M::BLK + cl][kq]);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (doX) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int p = 0; p < NBLK; ++p)
-#pragma unroll
-                for (int q = 0; q < NBLK; ++q) M::mma(-aX[p][j], bX[q][j], accX[p][q]);
-    }
-    if (doD) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int p = 0; p < NBLK; ++p)
-#pragma unroll
-                for (int q = 0; q < NBLK; ++q) M::mma(-aD[p][j], bD[q][j], accD[p][q]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // publish rows Cr..Cr+7 of X (their products were issued first)
-    if (hasX && CH_EXP_WX && k >= 0 && k <= NSP - 1) {
-        const int Cr = MB * k, par = k & 1;
-        if (Cr >= w0 && Cr < w0 + 32) {
-            const int r8 = Cr - w0;
-#pragma unroll
-            for (int p = 0; p < NBLK; ++p)
-#pragma unroll
-                for (int e = 0; e < M::NREG; ++e)
-                    if ((p * M::BLK + M::row(0, e)) / MB * MB == r8) {       // the 8-row group this register belongs to (same for all lanes)
-                        const int t = p * M::BLK + M::row(lane, e) - r8;
-#pragma unroll
-                        for (int q = 0; q < NBLK; ++q) sm.pipe.Xr[par][t][w1 + q * M::BLK + cl] = accX[p][q][e];
-                    }
-        }
-    }
-    // publish sub-panel k+1: columns Cn..Cn+7 of D (the tile's rows), from the accumulators
-    if (WV != 1 && k + 1 <= NSP - 1) {
-        const int Cn = MB * (k + 1), par = (k + 1) & 1;
-        if (Cn >= w1 && Cn < w1 + 32) {
-            const int q = (Cn - w1) / M::BLK, c8 = (Cn - w1) % M::BLK;
-            if (cl >= c8 && cl < c8 + MB) {
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int p = 0; p < NBLK; ++p)
 #pragma unroll
-                    for (int e = 0; e < M::NREG; ++e) sm.pipe.Pn[par][w0 + p * M::BLK + M::row(lane, e)][cl - c8] = accD[p][q][e];
+                    for (int q = 0; q < NBLK; ++q) M::mma(-a[p][j], bb[q][j], acc[p][q]);
+        }
+        if (k + 1 <= NSP - 1) {
+            // publish sub-panel k+1: columns Cn..Cn+7 of D (the tile's rows), from the accumulators
+            const int Cn = MB * (k + 1), par = (k + 1) & 1;
+            if (Cn >= w1 && Cn < w1 + 32) {
+                const int q = (Cn - w1) / M::BLK, c8 = (Cn - w1) % M::BLK;
+                if (cl >= c8 && cl < c8 + MB) {
+#pragma unroll
+                    for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+                        for (int e = 0; e < M::NREG; ++e) sm.pipe.Pn[par][w0 + p * M::BLK + M::row(lane, e)][cl - c8] = acc[p][q][e];
+                }
+            }
+        }
+    } else {
+        if (CH_EXP_WX && k >= 2 && k <= NSP - 1 && w0 + 32 > MB * k) {
+            const int C = MB * (k - 2), par = (k - 2) & 1;
+            vk_t a[NBLK], bb[NBLK];
+#pragma unroll
+            for (int p = 0; p < NBLK; ++p) {
+                a[p] = *reinterpret_cast<const vk_t *>(&sm.Ls[w0 + p * M::BLK + cl][C + kq]);
+                bb[p] = *reinterpret_cast<const vk_t *>(&sm.pipe.Zt[par][w1 + p * M::BLK + cl][kq]);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+                    for (int q = 0; q < NBLK; ++q) M::mma(-a[p][j], bb[q][j], acc[p][q]);
+        }
+        if (CH_EXP_WX && k >= 0 && k <= NSP - 1) {
+            // publish rows Cr..Cr+7 of X
+            const int Cr = MB * k, par = k & 1;
+            if (Cr >= w0 && Cr < w0 + 32) {
+                const int r8 = Cr - w0;
+#pragma unroll
+                for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+                    for (int e = 0; e < M::NREG; ++e)
+                        if ((p * M::BLK + M::row(0, e)) / MB * MB == r8) {       // the 8-row group this register belongs to (same for all lanes)
+                            const int t = p * M::BLK + M::row(lane, e) - r8;
+#pragma unroll
+                            for (int q = 0; q < NBLK; ++q) sm.pipe.Xr[par][t][w1 + q * M::BLK + cl] = acc[p][q][e];
+                        }
             }
         }
     }
@@ -436,86 +432,89 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
     const int nS = nrb - J - 1;
     const bool isW = b > nS;
     const int c0 = isW ? (b - nS - 1) * NB : 0;
-    // A workgroup's waves are dealt to the CU's four SIMDs cyclically, so waves w and w+4 share one.  Waves 0-3 are the workers (one
-    // per SIMD: they carry the prologue's and the chain's MFMA work, and the matrix pipe is per SIMD); the two chain waves (4: factor,
-    // 5: z) each share a SIMD with a worker whose chain work is MFMA only, so their vector instructions issue unhindered.
-    const int wave = tid >> 6;
-    const int role = wave == 4 ? 0 : wave == 5 ? 1 : 2;        // 0: factor wave, 1: z wave, 2: worker
-    const bool worker = role >= 2;
+    // Ten waves.  0-3: D workers (tile (w>>1, w&1) of the diagonal block), 4-7: X workers (the same tiles of the workgroup's X block),
+    // 8: factor wave, 9: z wave.  A workgroup's waves are dealt to the CU's four SIMDs cyclically (w, w+4, w+8 share one): every SIMD
+    // gets one D and one X worker -- the prologue's and the chain's MFMA work, and the matrix pipe is per SIMD -- and the two chain waves
+    // sit beside workers whose chain work is MFMA only, so their vector instructions issue unhindered.
+    const int wave = tid >> 6, lane = tid & 63;
+    const int role = wave == 8 ? 0 : wave == 9 ? 1 : 2;        // 0: factor wave, 1: z wave, 2: worker
+    const bool worker = role >= 2, xside = wave >= 4 && wave < 8, hasX = b >= 1;
     if (role == 0) __builtin_amdgcn_s_setprio(3);
     else if (role == 1) __builtin_amdgcn_s_setprio(2);
-    const int wt = tid & 255;                                  // worker lane id 0..255
+    const int wv = wave & 3;                                   // worker tile
+    const int wl = tid & 255;                                  // lane id within the D (or X) worker group: 256 lanes load one 64x64 block
     typedef int frag_t __attribute__((ext_vector_type(4)));      // 8 bf16
     const bool planes = sizeof(T) == 4 && Sp != nullptr;       // fp32 with the bf16-split down-date: the pending update multiplies on the bf16 MFMA too
-    frag_t fBa[4][3], fBb[4][3], fO[4][3];
+    frag_t fA[4][3], fB[4][3];                                 // pending update of this wave's tile: A operand (rows) and B operand (columns)
+    const int w0 = (wv >> 1) * 32, w1 = (wv & 1) * 32, fa = wv >> 1, fb = wv & 1;
+    const bool tile_live = worker && (xside ? hasX : wv != 1);  // (the D tile above the diagonal is never read)
     if (worker) {
-        // all 32 global loads of the two blocks are issued before the first LDS store
-        T ga[16], gx[16];
-        const int lr = wt >> 6, lc = wt & 63;
+        // every global load of the wave is issued before its first LDS store: the raw 64x64 block (D workers: the diagonal block,
+        // X workers: the workgroup's own block) and, for the pending update of panel J-1, the operands of THIS wave's tile
+        T g[16], gp[16];
+        const int lr = wl >> 6, lc = wl & 63;
+        if (!xside) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) ga[t] = S[(size_t)(J * NB + lr + 4 * t) * lds + J * NB + lc];
-        if (b >= 1) {
+            for (int t = 0; t < 16; ++t) g[t] = S[(size_t)(J * NB + lr + 4 * t) * lds + J * NB + lc];
+        } else if (hasX) {
             if (!isW) {
                 const int rb = J + b;
 #pragma unroll
-                for (int t = 0; t < 16; ++t) gx[t] = S[(size_t)(rb * NB + lr + 4 * t) * lds + J * NB + lc];
+                for (int t = 0; t < 16; ++t) g[t] = S[(size_t)(rb * NB + lr + 4 * t) * lds + J * NB + lc];
             } else {
 #pragma unroll
-                for (int t = 0; t < 16; ++t) gx[t] = W[(size_t)(J * NB + lr + 4 * t) * ldw + c0 + lc];
+                for (int t = 0; t < 16; ++t) g[t] = W[(size_t)(J * NB + lr + 4 * t) * ldw + c0 + lc];
             }
         }
-        T gb[16], gq[16];
         if (PRO && planes) {
-            // the pending update's operands as bf16 planes (written by the store epilogues of launch J-1): this wave's fragments
-            // straight into registers -- B = M(J, J-1) for rows w0.. and w1.., and the workgroup's own block
-            const int lane = wt & 63, wv = wt >> 6, fa = wv >> 1, fb = wv & 1;
-            const frag_t *Bp = static_cast<const frag_t *>(Sp) + ((size_t)J * sp_stride + (J - 1)) * B3_SGRAN + lane;
-            const frag_t *Op = nullptr;
-            int ostage = 0, oplane = 0;
-            if (b >= 1) {
-                if (!isW) { Op = static_cast<const frag_t *>(Sp) + ((size_t)(J + b) * sp_stride + (J - 1)) * B3_SGRAN + fa * 64 + lane; ostage = 384; oplane = 128; }
+            // operands as bf16 planes (written by the store epilogues of launch J-1), this wave's fragments straight into registers.
+            // A operand: rows w0.. of B = M(J, J-1).  B operand: D tile -> rows w1.. of B;  X tile -> the own block's rows / columns w1..
+            if (tile_live) {
+                const frag_t *Bp = static_cast<const frag_t *>(Sp) + ((size_t)J * sp_stride + (J - 1)) * B3_SGRAN + lane;
+                const frag_t *Op; int ostage, oplane;
+                if (!xside) { Op = Bp + fb * 64; ostage = 384; oplane = 128; }
+                else if (!isW) { Op = static_cast<const frag_t *>(Sp) + ((size_t)(J + b) * sp_stride + (J - 1)) * B3_SGRAN + fb * 64 + lane; ostage = 384; oplane = 128; }
                 else { Op = static_cast<const frag_t *>(Wp) + ((size_t)(c0 >> 7) * nst_total + 4 * (J - 1)) * B3_GRAN + (2 * ((c0 >> 6) & 1) + fb) * 64 + lane; ostage = B3_GRAN; oplane = 256; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) { fA[q][pl] = Bp[q * 384 + pl * 128 + fa * 64]; fB[q][pl] = Op[q * ostage + pl * oplane]; }
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    fBa[q][pl] = Bp[q * 384 + pl * 128 + fa * 64];
-                    fBb[q][pl] = Bp[q * 384 + pl * 128 + fb * 64];
-                    if (b >= 1) fO[q][pl] = Op[q * ostage + pl * oplane];
-                }
         } else if (PRO) {
-            // operands of the pending update from panel J-1: B = M(J, J-1) and this workgroup's own M(b, J-1)
+            // operands of the pending update through LDS: D workers bring B = M(J, J-1), X workers the workgroup's own M(b, J-1)
+            if (!xside) {
 #pragma unroll
-            for (int t = 0; t < 16; ++t) gb[t] = S[(size_t)(J * NB + lr + 4 * t) * lds + (J - 1) * NB + lc];
-            if (b >= 1) {
+                for (int t = 0; t < 16; ++t) gp[t] = S[(size_t)(J * NB + lr + 4 * t) * lds + (J - 1) * NB + lc];
+            } else if (hasX) {
                 if (!isW) {
                     const int rb = J + b;
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) gq[t] = S[(size_t)(rb * NB + lr + 4 * t) * lds + (J - 1) * NB + lc];
+                    for (int t = 0; t < 16; ++t) gp[t] = S[(size_t)(rb * NB + lr + 4 * t) * lds + (J - 1) * NB + lc];
                 } else {
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) gq[t] = W[(size_t)((J - 1) * NB + lr + 4 * t) * ldw + c0 + lc];
+                    for (int t = 0; t < 16; ++t) gp[t] = W[(size_t)((J - 1) * NB + lr + 4 * t) * ldw + c0 + lc];
                 }
             }
         }
+        if (!xside) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) Ls[lr + 4 * t][lc] = ga[t];
-        if (b >= 1) {
+            for (int t = 0; t < 16; ++t) Ls[lr + 4 * t][lc] = g[t];
+        } else if (hasX) {
             if (!isW) {
 #pragma unroll
-                for (int t = 0; t < 16; ++t) Xs[lc][lr + 4 * t] = gx[t];        // S block: (i = lr+4t, a = lc) -> Xs[a][i]
+                for (int t = 0; t < 16; ++t) Xs[lc][lr + 4 * t] = g[t];        // S block: (i = lr+4t, a = lc) -> Xs[a][i]
             } else {
 #pragma unroll
-                for (int t = 0; t < 16; ++t) Xs[lr + 4 * t][lc] = gx[t];        // W strip: (a = lr+4t, i = lc)
+                for (int t = 0; t < 16; ++t) Xs[lr + 4 * t][lc] = g[t];        // W strip: (a = lr+4t, i = lc)
             }
         }
         if (PRO && !planes) {
+            if (!xside) {
 #pragma unroll
-            for (int t = 0; t < 16; ++t) sm.Bs[lr + 4 * t][lc] = gb[t];                          // Bs[j][a]
-            if (b >= 1) {
+                for (int t = 0; t < 16; ++t) sm.Bs[lr + 4 * t][lc] = gp[t];                      // Bs[j][a]
+            } else if (hasX) {
 #pragma unroll
-                for (int t = 0; t < 16; ++t) sm.As[lr + 4 * t][lc] = gq[t];                      // As: [i][a] (S) or [a][i] (W)
+                for (int t = 0; t < 16; ++t) sm.As[lr + 4 * t][lc] = gp[t];                      // As: [i][a] (S) or [a][i] (W)
             }
         }
     }
@@ -524,143 +523,82 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
     // every workgroup reads the raw diagonal block; workgroup 0 overwrites it with L_JJ at the end and must not do so
     // before all of them have it (they normally start together, but nothing guarantees that for very large grids)
     if (tid == 0 && b != 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    typename ChW<T>::acc_t acc[ChW<T>::NBLK][ChW<T>::NBLK];        // this worker wave's tile of D or X, in MFMA accumulator layout
+    bool acc_loaded = false;
     if (PRO && planes) {
         if constexpr (sizeof(T) == 4) {
-            if (worker) {
-                // six bf16 products per f32 product (see k_downdate_b3), K = 64 = 4 k-steps: 24 MFMAs of 32 cycles per 64x64x64 product
-                // and wave instead of 32 of 64 cycles
-                const int lane = wt & 63, wv = wt >> 6;
-                const int w0 = (wv >> 1) * 32, w1 = (wv & 1) * 32;
-                const int lrow = 4 * (lane >> 5), lcol = lane & 31;
-#define PRO_MMA(X, Y, px, py) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, X[q][px]), __builtin_bit_cast(bf16x8_t, Y[q][py]), acc, 0, 0, 0)
-#define PRO_SIX(X, Y) do { _Pragma("unroll") for (int q = 0; q < 4; ++q) { PRO_MMA(X, Y, 0, 0); PRO_MMA(X, Y, 0, 1); PRO_MMA(X, Y, 1, 0); PRO_MMA(X, Y, 1, 1); PRO_MMA(X, Y, 0, 2); PRO_MMA(X, Y, 2, 0); } } while (0)
-                if (w1 <= w0) {                 // diagonal block: A_JJ -= B B'  (only j <= i is ever read)
-                    f32x16_t acc;
+            if (tile_live) {
+                // six bf16 products per f32 product (see k_downdate_b3), K = 64 = 4 k-steps: 24 MFMAs of 32 cycles per wave.  The 32x32
+                // result has the accumulator layout the chain keeps its tile in: tile = raw block - product, no LDS round trip.
+                f32x16_t pacc;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-                    PRO_SIX(fBa, fBb);
+                for (int e = 0; e < 16; ++e) pacc[e] = 0.f;
+#define PRO_MMA(px, py) pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fA[q][px]), __builtin_bit_cast(bf16x8_t, fB[q][py]), pacc, 0, 0, 0)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) Ls[w0 + (e & 3) + 8 * (e >> 2) + lrow][w1 + lcol] -= acc[e];
-                }
-                if (b >= 1) {
-                    f32x16_t acc;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-                    if (!isW) {                 // X(i, j) -= sum_a A[i][a] B[j][a]: rows -> i (own block), lanes -> j; stored Xs[j][i]
-                        PRO_SIX(fO, fBb);
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) Xs[w1 + lcol][w0 + (e & 3) + 8 * (e >> 2) + lrow] -= acc[e];
-                    } else {                    // M(i, j) -= sum_a Aw[a][i] B[j][a]: rows -> j, lanes -> i (own strip); stored Xs[j][i]
-                        PRO_SIX(fBa, fO);
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) Xs[w0 + (e & 3) + 8 * (e >> 2) + lrow][w1 + lcol] -= acc[e];
-                    }
-                }
-#undef PRO_SIX
+                for (int q = 0; q < 4; ++q) { PRO_MMA(0, 0); PRO_MMA(0, 1); PRO_MMA(1, 0); PRO_MMA(1, 1); PRO_MMA(0, 2); PRO_MMA(2, 0); }
 #undef PRO_MMA
+                const int lrow = 4 * (lane >> 5), lcol = lane & 31;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int r = w0 + (e & 3) + 8 * (e >> 2) + lrow, c = w1 + lcol;
+                    acc[0][0][e] = (xside ? Xs[r][c] : Ls[r][c]) - pacc[e];
+                }
             }
+            acc_loaded = true;
         }
-        __syncthreads();
     } else if (PRO) {
-        if (worker) {
+        if (tile_live) {
             using M = Mfma<T>;
             constexpr int NBLK = 32 / M::BLK;
-            const int lane = wt & 63, wv = wt >> 6;
-            const int w0 = (wv >> 1) * 32, w1 = (wv & 1) * 32;
-            typename M::acc_t acc[NBLK][NBLK];
-            // diagonal block: A_JJ -= B B'   (rows -> i, lanes -> j; only j <= i is ever read)
-            if (w1 <= w0) {
+            typename M::acc_t pacc[NBLK][NBLK];
 #pragma unroll
-                for (int p = 0; p < NBLK; ++p)
+            for (int p = 0; p < NBLK; ++p)
 #pragma unroll
-                    for (int q = 0; q < NBLK; ++q)
+                for (int q = 0; q < NBLK; ++q)
 #pragma unroll
-                        for (int e = 0; e < M::NREG; ++e) acc[p][q][e] = (T)0;
+                    for (int e = 0; e < M::NREG; ++e) pacc[p][q][e] = (T)0;
+            // tile(r, c) -= sum_k A[r][k] B[c][k]: A = rows w0.. of Bs (= M(J, J-1));  B = rows w1.. of Bs (D tile), of As[i][k] (S block: the
+            // own block's rows) or the columns of As[k][i] (W strip)
 #pragma unroll 4
-                for (int k0 = 0; k0 < NB; k0 += M::KS) {
-                    const int k = k0 + M::kk(lane);
-                    T av[NBLK], bv[NBLK];
+            for (int k0 = 0; k0 < NB; k0 += M::KS) {
+                const int kx = k0 + M::kk(lane);
+                T av[NBLK], bv[NBLK];
 #pragma unroll
-                    for (int p = 0; p < NBLK; ++p) { av[p] = sm.Bs[w0 + p * M::BLK + M::col(lane)][k]; bv[p] = sm.Bs[w1 + p * M::BLK + M::col(lane)][k]; }
-#pragma unroll
-                    for (int p = 0; p < NBLK; ++p)
-#pragma unroll
-                        for (int q = 0; q < NBLK; ++q) M::mma(av[p], bv[q], acc[p][q]);
+                for (int p = 0; p < NBLK; ++p) {
+                    av[p] = sm.Bs[w0 + p * M::BLK + M::col(lane)][kx];
+                    bv[p] = !xside ? sm.Bs[w1 + p * M::BLK + M::col(lane)][kx] : !isW ? sm.As[w1 + p * M::BLK + M::col(lane)][kx] : sm.As[kx][w1 + p * M::BLK + M::col(lane)];
                 }
 #pragma unroll
                 for (int p = 0; p < NBLK; ++p)
 #pragma unroll
-                    for (int q = 0; q < NBLK; ++q)
-#pragma unroll
-                        for (int e = 0; e < M::NREG; ++e) {
-                            const int i = w0 + p * M::BLK + M::row(lane, e), j = w1 + q * M::BLK + M::col(lane);
-                            Ls[i][j] -= acc[p][q][e];
-                        }
+                    for (int q = 0; q < NBLK; ++q) M::mma(av[p], bv[q], pacc[p][q]);
             }
-            if (b >= 1) {
 #pragma unroll
-                for (int p = 0; p < NBLK; ++p)
+            for (int p = 0; p < NBLK; ++p)
 #pragma unroll
-                    for (int q = 0; q < NBLK; ++q)
+                for (int q = 0; q < NBLK; ++q)
 #pragma unroll
-                        for (int e = 0; e < M::NREG; ++e) acc[p][q][e] = (T)0;
-                if (!isW) {
-                    // X(i, j) -= sum_a A[i][a] B[j][a]; rows -> i, lanes -> j; stored Xs[j][i]
-#pragma unroll 4
-                    for (int k0 = 0; k0 < NB; k0 += M::KS) {
-                        const int k = k0 + M::kk(lane);
-                        T av[NBLK], bv[NBLK];
-#pragma unroll
-                        for (int p = 0; p < NBLK; ++p) { av[p] = sm.As[w0 + p * M::BLK + M::col(lane)][k]; bv[p] = sm.Bs[w1 + p * M::BLK + M::col(lane)][k]; }
-#pragma unroll
-                        for (int p = 0; p < NBLK; ++p)
-#pragma unroll
-                            for (int q = 0; q < NBLK; ++q) M::mma(av[p], bv[q], acc[p][q]);
+                    for (int e = 0; e < M::NREG; ++e) {
+                        const int r = w0 + p * M::BLK + M::row(lane, e), c = w1 + q * M::BLK + M::col(lane);
+                        acc[p][q][e] = (xside ? Xs[r][c] : Ls[r][c]) - pacc[p][q][e];
                     }
-#pragma unroll
-                    for (int p = 0; p < NBLK; ++p)
-#pragma unroll
-                        for (int q = 0; q < NBLK; ++q)
-#pragma unroll
-                            for (int e = 0; e < M::NREG; ++e) {
-                                const int i = w0 + p * M::BLK + M::row(lane, e), j = w1 + q * M::BLK + M::col(lane);
-                                Xs[j][i] -= acc[p][q][e];
-                            }
-                } else {
-                    // M(i, j) -= sum_a Aw[a][i] B[j][a]; rows -> j, lanes -> i; stored Xs[j][i]
-#pragma unroll 4
-                    for (int k0 = 0; k0 < NB; k0 += M::KS) {
-                        const int k = k0 + M::kk(lane);
-                        T av[NBLK], bv[NBLK];
-#pragma unroll
-                        for (int p = 0; p < NBLK; ++p) { av[p] = sm.Bs[w0 + p * M::BLK + M::col(lane)][k]; bv[p] = sm.As[k][w1 + p * M::BLK + M::col(lane)]; }
-#pragma unroll
-                        for (int p = 0; p < NBLK; ++p)
-#pragma unroll
-                            for (int q = 0; q < NBLK; ++q) M::mma(av[p], bv[q], acc[p][q]);
-                    }
-#pragma unroll
-                    for (int p = 0; p < NBLK; ++p)
-#pragma unroll
-                        for (int q = 0; q < NBLK; ++q)
-#pragma unroll
-                            for (int e = 0; e < M::NREG; ++e) {
-                                const int j = w0 + p * M::BLK + M::row(lane, e), i = w1 + q * M::BLK + M::col(lane);
-                                Xs[j][i] -= acc[p][q][e];
-                            }
-                }
-            }
         }
-        __syncthreads();
+        acc_loaded = true;
+        __syncthreads();                            // As (an operand of the products above) is the chain's hand-off buffer from here on
     }
     PROBE_STAMP(1);
-    const int wv = wt >> 6, wl = wt & 63;            // worker wave 0..3 and its lane
-    typename ChW<T>::acc_t accD[ChW<T>::NBLK][ChW<T>::NBLK], accX[ChW<T>::NBLK][ChW<T>::NBLK];
-    if (worker) {
-        if (wv == 0) ch_worker_load<T, 0>(sm, accD, accX, wl, b >= 1);
-        else if (wv == 1) ch_worker_load<T, 1>(sm, accD, accX, wl, b >= 1);
-        else if (wv == 2) ch_worker_load<T, 2>(sm, accD, accX, wl, b >= 1);
-        else ch_worker_load<T, 3>(sm, accD, accX, wl, b >= 1);
+    if (worker && !acc_loaded) {
+        if (xside) {
+            if (wv == 0) ch_worker_load<T, 0, true>(sm, acc, lane, tile_live);
+            else if (wv == 1) ch_worker_load<T, 1, true>(sm, acc, lane, tile_live);
+            else if (wv == 2) ch_worker_load<T, 2, true>(sm, acc, lane, tile_live);
+            else ch_worker_load<T, 3, true>(sm, acc, lane, tile_live);
+        } else {
+            if (wv == 0) ch_worker_load<T, 0, false>(sm, acc, lane, tile_live);
+            else if (wv == 1) ch_worker_load<T, 1, false>(sm, acc, lane, tile_live);
+            else if (wv == 2) ch_worker_load<T, 2, false>(sm, acc, lane, tile_live);
+            else ch_worker_load<T, 3, false>(sm, acc, lane, tile_live);
+        }
     }
     bool bad = false;                               // (As, the prologue's operand tile, is the chain's hand-off buffer from here on)
     T yprev[MB], zprev[MB];                          // factor wave: its row of Y(s-1); z wave: its column of Z(s-1)
@@ -677,13 +615,17 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
     for (int k = -1; k <= NSP; ++k) {
         PROBE_STEP(k, 0);
         if (worker) {
-#ifdef CH_STAGGER
-            __builtin_amdgcn_s_sleep(CH_STAGGER);            // the chain waves' LDS reads go first
-#endif
-            if (wv == 0) ch_worker_step<T, 0>(k, sm, accD, accX, wl, b >= 1);
-            else if (wv == 1) ch_worker_step<T, 1>(k, sm, accD, accX, wl, b >= 1);
-            else if (wv == 2) ch_worker_step<T, 2>(k, sm, accD, accX, wl, b >= 1);
-            else ch_worker_step<T, 3>(k, sm, accD, accX, wl, b >= 1);
+            if (xside) {
+                if (wv == 0) ch_worker_step<T, 0, true>(k, sm, acc, lane, tile_live);
+                else if (wv == 1) ch_worker_step<T, 1, true>(k, sm, acc, lane, tile_live);
+                else if (wv == 2) ch_worker_step<T, 2, true>(k, sm, acc, lane, tile_live);
+                else ch_worker_step<T, 3, true>(k, sm, acc, lane, tile_live);
+            } else {
+                if (wv == 0) ch_worker_step<T, 0, false>(k, sm, acc, lane, tile_live);
+                else if (wv == 1) ch_worker_step<T, 1, false>(k, sm, acc, lane, tile_live);
+                else if (wv == 2) ch_worker_step<T, 2, false>(k, sm, acc, lane, tile_live);
+                else ch_worker_step<T, 3, false>(k, sm, acc, lane, tile_live);
+            }
         } else if (role == 0) {
             if (k >= 0 && k < NSP && CH_EXP_F) {
                 const int C = MB * k, par = k & 1, i = tid & 63;
@@ -754,9 +696,6 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
         } else if (b >= 1 && k >= 1 && k <= NSP && CH_EXP_Z) {
             // z wave, sub-panel k-1: z <- L8^-1 (x - lookahead)
             const int s2 = k - 1, C = MB * s2, par = s2 & 1, i = tid & 63;
-#ifdef CH_STAGGER
-            __builtin_amdgcn_s_sleep(CH_STAGGER);            // the factor wave's LDS reads go first (this wave has slack)
-#endif
             T x[MB], z[MB];
             v4_t Lh[MB][2], Ld[MB][2];
 #pragma unroll
