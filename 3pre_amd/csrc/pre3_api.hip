@@ -20,6 +20,7 @@ void set_error(const char *fmt, ...)
 
 // launchers defined in the kernel files
 int launch_predict_impl(pre3_ctx *c, const double u[7], bool with_projection = false);
+int launch_inbox_pull(pre3_ctx *c, const void *src_host_mapped, void *dst_dev, size_t n16, int32_t seq);
 int launch_window_gate(pre3_ctx *c, int M, const int32_t *pred_idx_dev, const int32_t *k1_dev, const double *zc_dev, int strict, int32_t *accept_dev);
 int launch_build_rows_impl(pre3_ctx *c, int nsel, const int32_t *sel_dev, int r_pad);
 int launch_ransac_score_impl(pre3_ctx *c, int k, double threshold, int hyp_begin, int hyp_end, int ldg, int32_t *support_dev, uint32_t *mask_dev, int mask_words,
@@ -138,7 +139,7 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
         // in the same allocation and are cleared on the device (k_project_innovation in a step, a memset otherwise)
         c->off_meas = 0;
         c->off_ic = c->off_meas + sizeof(int32_t) * c->capm;
-        c->off_hyp = c->off_ic + sizeof(int32_t) * c->capN;
+        c->off_hyp = (c->off_ic + sizeof(int32_t) * c->capN + 15) / 16 * 16;
         c->off_z = (c->off_hyp + sizeof(int32_t) * (size_t)c->caph * MAXK + 15) / 16 * 16;
         c->off_flags = c->off_z + sizeof(double) * 2 * c->capN;
         const size_t off_li = c->off_flags, off_hi = off_li + sizeof(int32_t) * c->capN;
@@ -146,7 +147,8 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
         c->flags_bytes = sizeof(int32_t) * (2 * (size_t)c->capN + 2 * (size_t)c->capm);
         c->inbox_bytes = c->off_flags + c->flags_bytes;
         A(dmalloc_bytes(&c->inbox_dev, c->inbox_bytes));
-        if (rc == PRE3_OK && hipHostMalloc((void **)&c->inbox_host, c->inbox_bytes) != hipSuccess) { set_error("hipHostMalloc failed"); rc = PRE3_E_NOMEM; }
+        if (rc == PRE3_OK && hipHostMalloc((void **)&c->inbox_host, c->inbox_bytes, hipHostMallocMapped) != hipSuccess) { set_error("hipHostMalloc failed"); rc = PRE3_E_NOMEM; }
+        if (rc == PRE3_OK && hipHostGetDevicePointer((void **)&c->inbox_host_dev, c->inbox_host, 0) != hipSuccess) { set_error("hipHostGetDevicePointer failed"); rc = PRE3_E_HIP; }
         if (rc == PRE3_OK) {
             memset(c->inbox_host, 0, c->inbox_bytes);
             unsigned char *d = (unsigned char *)c->inbox_dev;
@@ -271,8 +273,7 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
         memset(c->mail_host, 0, sizeof(int32_t) * 16);
         if (hipHostGetDevicePointer((void **)&c->mail_dev, c->mail_host, 0) != hipSuccess) { set_error("hipHostGetDevicePointer failed"); rc = PRE3_E_HIP; }
     }
-    if (rc == PRE3_OK && (hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess ||
-                          hipEventCreateWithFlags(&c->inbox_copied, hipEventDisableTiming) != hipSuccess)) { set_error("hipEventCreate failed"); rc = PRE3_E_HIP; }
+    if (rc == PRE3_OK && (hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess)) { set_error("hipEventCreate failed"); rc = PRE3_E_HIP; }
     if (rc != PRE3_OK) { pre3_destroy(c); return rc; }
     (void)hipMemsetAsync(c->stats, 0, sizeof(int32_t) * 16, c->stream);
     (void)hipMemsetAsync(c->P, 0, (size_t)c->ld * c->ld * c->esz, c->stream);
@@ -296,7 +297,6 @@ int pre3_destroy(pre3_ctx *c)
     for (hipEvent_t e : c->kt.ev) (void)hipEventDestroy(e);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
-    if (c->inbox_copied) (void)hipEventDestroy(c->inbox_copied);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PRE3_OK;
@@ -468,9 +468,10 @@ static int install_measurements(pre3_ctx *c, int m, const int32_t *meas_idx, con
         PRE3_CHECK(meas_idx[j] >= 0 && meas_idx[j] < c->N, PRE3_E_ARG, "measurements: landmark index %d out of range", meas_idx[j]);
         PRE3_CHECK(j == 0 || meas_idx[j] > meas_idx[j - 1], PRE3_E_ARG, "measurements: landmark indices must be strictly ascending");
     }
-    // the previous copy out of the pinned inbox must have completed before the host overwrites it (it has, a whole
-    // step ago: this returns immediately and -- unlike a stream sync -- does not wait for the kernels queued since)
-    if (c->inbox_pending) { PRE3_HIP(hipEventSynchronize(c->inbox_copied)); c->inbox_pending = false; }
+    // the previous pull out of the pinned inbox must have completed before the host overwrites it (it has, a whole step ago: the pull
+    // kernel publishes its sequence number in mailbox word 10, so this is one read of host memory -- no event, whose record would put
+    // a barrier packet into the stream -- and, unlike a stream sync, it does not wait for the kernels queued since)
+    if (c->inbox_pending) { PRE3_TRY(wait_mail(c, 10, c->seq_inbox)); c->inbox_pending = false; }
     c->m = m; c->meas_host.assign(meas_idx, meas_idx + m);
     int32_t *hm = (int32_t *)(c->inbox_host + c->off_meas), *hic = (int32_t *)(c->inbox_host + c->off_ic);
     double *hz = (double *)(c->inbox_host + c->off_z);
@@ -481,13 +482,10 @@ static int install_measurements(pre3_ctx *c, int m, const int32_t *meas_idx, con
         for (int j = 0; j < m; ++j) { hz[2 * meas_idx[j]] = z[2 * j]; hz[2 * meas_idx[j] + 1] = z[2 * j + 1]; }
     }
     if (hyp) memcpy(c->inbox_host + c->off_hyp, hyp, sizeof(int32_t) * n_hyp_ints);
-    unsigned char *d = (unsigned char *)c->inbox_dev;
-    if (z) {
-        PRE3_HIP(hipMemcpyAsync(d, c->inbox_host, c->off_z + sizeof(double) * 2 * c->N, hipMemcpyHostToDevice, c->stream));
-    } else {
-        PRE3_HIP(hipMemcpyAsync(d, c->inbox_host, c->off_hyp + (hyp ? sizeof(int32_t) * n_hyp_ints : 0), hipMemcpyHostToDevice, c->stream));
-    }
-    PRE3_HIP(hipEventRecord(c->inbox_copied, c->stream)); c->inbox_pending = true;
+    // The inbox crosses PCIe by a KERNEL that reads the pinned, device-mapped host buffer (14 KB at N=500): a hipMemcpyAsync between
+    // kernels is a blit with barrier packets on both sides and opened two ~10 us holes in the stream around a 3 us copy.
+    const size_t nbytes = z ? c->off_z + sizeof(double) * 2 * c->N : c->off_hyp + (hyp ? sizeof(int32_t) * n_hyp_ints : 0);
+    PRE3_TRY(launch_inbox_pull(c, c->inbox_host_dev, c->inbox_dev, (nbytes + 15) / 16, ++c->seq_inbox)); c->inbox_pending = true;
     if (!flags_clear) PRE3_HIP(hipMemsetAsync((unsigned char *)c->inbox_dev + c->off_flags, 0, c->flags_bytes, c->stream));
     c->li_from_host = c->hi_from_host = -1; c->li_kernel = c->hi_kernel = false;
     c->hp_all_valid = false;
@@ -660,10 +658,10 @@ static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, in
     PRE3_CHECK(c->m >= k, PRE3_E_ARG, "ransac: %d measurements but k=%d", c->m, k);
     for (int i = 0; i < n_draw * k; ++i) PRE3_CHECK(hyp[i] >= 0 && hyp[i] < c->m, PRE3_E_ARG, "ransac: hyp[%d]=%d not a position in the IC list (m=%d)", i, hyp[i], c->m);
     if (hyp != (const int32_t *)(c->inbox_host + c->off_hyp)) {       // not already shipped with the measurements
-        if (c->inbox_pending) { PRE3_HIP(hipEventSynchronize(c->inbox_copied)); c->inbox_pending = false; }
+        if (c->inbox_pending) { PRE3_TRY(wait_mail(c, 10, c->seq_inbox)); c->inbox_pending = false; }
         memcpy(c->inbox_host + c->off_hyp, hyp, sizeof(int32_t) * n_draw * k);
-        PRE3_HIP(hipMemcpyAsync(c->hyp, c->inbox_host + c->off_hyp, sizeof(int32_t) * n_draw * k, hipMemcpyHostToDevice, c->stream));
-        PRE3_HIP(hipEventRecord(c->inbox_copied, c->stream)); c->inbox_pending = true;
+        PRE3_TRY(launch_inbox_pull(c, (const unsigned char *)c->inbox_host_dev + c->off_hyp, c->hyp, (sizeof(int32_t) * n_draw * k + 15) / 16, ++c->seq_inbox));
+        c->inbox_pending = true;
     }
     c->masks = reinterpret_cast<uint32_t *>(c->support + round_up(n_draw, 4));
     c->scored_n_draw = n_draw; c->scored_k = k;         // the mask offset depends on n_draw: select / export / import must use the same

@@ -848,6 +848,21 @@ int launch_update_x(pre3_ctx *c, int which_prior, int r)
 }
 
 
+// The per-step inbox [meas | ic | hyp | z]: pinned host memory, read over PCIe by the device itself (16 bytes per lane, ONE workgroup so
+// that its last act can be to publish `seq` in the pinned mailbox: the host may overwrite the inbox once it reads that number back).
+__global__ __launch_bounds__(1024) void k_inbox_pull(const int4 *__restrict__ src, int4 *__restrict__ dst, size_t n16, int32_t *__restrict__ mail, int32_t seq)
+{
+    for (size_t i = threadIdx.x; i < n16; i += 1024) dst[i] = src[i];
+    __syncthreads();
+    if (threadIdx.x == 0) { __threadfence_system(); __hip_atomic_store(mail + 10, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+}
+int launch_inbox_pull(pre3_ctx *c, const void *src_host_mapped, void *dst_dev, size_t n16, int32_t seq)
+{
+    hipLaunchKernelGGL(k_inbox_pull, dim3(1), dim3(1024), 0, c->stream, (const int4 *)src_host_mapped, (int4 *)dst_dev, n16, c->mail_dev, seq);
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
 // ---- stateless compute_hypothesis_support_fast.m:27-116 ------------------------------------------------------------------
 // One workgroup (the reference evaluates one hypothesis per call; a frame has a few hundred measurements): lane j projects
 // measurement j of the hypothesis state xi exactly as k_ransac_score does (un-normalised quaternion, quirk Q4), the workgroup takes

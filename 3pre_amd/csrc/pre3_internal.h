@@ -126,9 +126,9 @@ struct pre3_ctx {
     int li_from_host = -1, hi_from_host = -1;     // row counts forced through pre3_set_flags (-1: use the kernels' counts)
     bool li_kernel = false, hi_kernel = false;    // a select / collect kernel has run for the current measurement set
     // per-step inbox: [meas | ic | hyp | z] contiguous on the device, mirrored in pinned host memory -> ONE H2D copy
-    void *inbox_dev = nullptr; unsigned char *inbox_host = nullptr;
+    void *inbox_dev = nullptr; unsigned char *inbox_host = nullptr; void *inbox_host_dev = nullptr;   // pinned + device-mapped: the device address of inbox_host
     size_t inbox_bytes = 0, off_meas = 0, off_ic = 0, off_hyp = 0, off_z = 0, off_flags = 0, flags_bytes = 0;
-    hipEvent_t inbox_copied = nullptr;            // recorded behind every copy out of the pinned inbox
+    int32_t seq_inbox = 0;                        // sequence number of the last inbox pull (published by the kernel in mailbox word 10)
     bool inbox_pending = false;
     // map management (allocated on first use)
     void *P_alt = nullptr; double *x_alt = nullptr; int32_t *map_col = nullptr; void *map_val = nullptr; int32_t *map_desc = nullptr;
