@@ -25,6 +25,7 @@ lib = C.CDLL(LIB_PATH)
 lib.pre3_last_error.restype = C.c_char_p
 lib.pre3_version.restype = C.c_char_p
 lib.pre3_match_bench_create.restype = C.c_void_p
+lib.pre3_match_bench_create_cls.restype = C.c_void_p
 lib.pre3_hypothesis_support.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
 lib.pre3_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_void_p]
 

@@ -30,7 +30,8 @@ int launch_fill_w(pre3_ctx *c, int r_pad);
 void release_scratch();
 int match_partial(int device, int cls, int ND, int K1, const void *L1, int K2, const void *L2, int k2_offset, double *best, double *second, int32_t *arg);
 int knn_run(int device, int D, int N, const double *data, int M, const double *query, int k, double *ids, double *dist);
-void *match_bench_create(int ND, int K1, const uint8_t *L1, int K2, const uint8_t *L2);
+void *match_bench_create(int cls, int ND, int K1, const void *L1, int K2, const void *L2);
+int match_bench_info(void *h, int32_t info[3]);
 int match_bench_run(void *h, int reps, double *ms_per);
 int match_bench_fetch(void *h, double *best, double *second, int32_t *arg);
 void match_bench_destroy(void *h);
@@ -1182,8 +1183,16 @@ int pre3_match_shard_destroy(pre3_match_shard *s) { if (s) match_shard_destroy(s
 PRE3_API void *pre3_match_bench_create(int device, int ND, int K1, const uint8_t *L1, int K2, const uint8_t *L2)
 {
     if (hipSetDevice(device) != hipSuccess) { set_error("no HIP device %d", device); return nullptr; }
-    return match_bench_create(ND, K1, L1, K2, L2);
+    return match_bench_create(2, ND, K1, L1, K2, L2);
 }
+// the same probe for any class (0 double, 1 float, 2 uint8); pre3_match_bench_info: [route (0 exact kernels, 1 int8 MFMA, 2 bf16 rank +
+// exact re-evaluation), queries scanned in full, candidates re-evaluated] of the last run
+PRE3_API void *pre3_match_bench_create_cls(int device, int cls, int ND, int K1, const void *L1, int K2, const void *L2)
+{
+    if (hipSetDevice(device) != hipSuccess) { set_error("no HIP device %d", device); return nullptr; }
+    return match_bench_create(cls, ND, K1, L1, K2, L2);
+}
+PRE3_API int pre3_match_bench_info(void *h, int32_t info[3]) { return h ? match_bench_info(h, info) : PRE3_E_ARG; }
 PRE3_API int pre3_match_bench_run(void *h, int reps, double *ms_per) { return h ? match_bench_run(h, reps, ms_per) : PRE3_E_ARG; }
 PRE3_API int pre3_match_bench_fetch(void *h, double *best, double *second, int32_t *arg) { return h ? match_bench_fetch(h, best, second, arg) : PRE3_E_ARG; }
 PRE3_API void pre3_match_bench_destroy(void *h) { if (h) match_bench_destroy(h); }

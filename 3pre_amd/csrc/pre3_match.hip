@@ -476,6 +476,264 @@ static void launch_pack_i8(int ND, int NDp, int K, int Kp, const T *L, int cente
 }
 
 // ------------------------------------------------------------------------------------------------
+// float / double classes on the matrix cores: rank with a distance GEMM, then re-evaluate exactly.
+//
+// matching_sift_based.m:104-118 hands siftmatch DOUBLE descriptors.  The reference's result for a query is the order-independent statistic
+// (best, second best counting duplicates, first arg-best) of the distances d_j accumulated bin by bin in the class's own arithmetic
+// (siftmatch.c:97-116).  Here:
+//   pack    every descriptor x is split into two bf16 planes, hi = bf16(x), lo = bf16(x - hi)  (|x - hi - lo| <= 2^-16 |x|), stored in the
+//           fragment order of v_mfma_f32_16x16x32_bf16, with its squared norm n (accumulated in double) as the two floats n(1+E), n(1-E);
+//   phase 1 dt_j = n_j - 2 (qh.bh + qh.bl + ql.bh)  (three bf16 products per 16x16 block, f32 accumulation; the query's own norm is a
+//           per-query constant and stays out of the scan).  |d_j - dt_j - nq| <= eps_j = E (nq + n_j): 3*2^-16 |q||b| from the planes and
+//           the dropped ql.bl, <= 2*384*2^-24 |q||b| from the f32 accumulation of 384 products (a bound linear in the count, truncation
+//           allowed), 2^-16 (nq + n_j) for the float class's own bin-by-bin rounding, 2^-21 for the norms; together < 2^-13.2 (nq + n_j),
+//           E = 1.8e-4 > 2^-12.5 leaves a further 1.6x.  Each lane (= query, as in k_match_i8_q) keeps the two smallest UPPER bounds
+//           dt_j + eps_j over its share of the database; merged over the workgroup that gives U2, an upper bound of the true second best;
+//   phase 2 the same products again (the database is L2 resident): every column whose LOWER bound dt_j - eps_j is <= U2 is a candidate.
+//           The true best, the true second best and everything tied with them have d_j <= U2, so they are all candidates;
+//   tail    one wave per query re-evaluates its candidates (<= 64, one per lane) from the ORIGINAL descriptors in the reference's
+//           accumulation order and arithmetic (bin 0..ND-1, subtract, multiply, add, contraction off) and merges them with merge3: the
+//           outputs are bit-identical to k_match_exact's.  A query with more than 64 candidates is scanned in full by its wave.
+// Data the bounds do not cover (NaN / Inf, |x| > 2^60, 0 < |x| < 2^-40: squares or planes leaving the f32 range) set a flag in the pack
+// kernel and the host takes the exact kernels; descriptors that are integers in [0, 255] in every bin (what vl_sift produces, cast to
+// double) set another and go to the int8 kernel, whose integer distances are exactly the reference's double / float sums.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr double RK_E = 1.8e-4;
+constexpr float RK_PAD_NORM = 3.0e38f;
+constexpr int RK_WAVES = 16, RK_Q = 16, RK_CAP = 64;
+
+// one thread per 16 bins of one descriptor (8 threads per descriptor: 128 bins, zero padded); K_pad descriptors
+template <typename T>
+__global__ __launch_bounds__(256) void k_rank_pack(int ND, int K, int Kp, const T *__restrict__ L, v4i *__restrict__ hi, v4i *__restrict__ lo,
+                                                    float *__restrict__ nU, float *__restrict__ nL, float *__restrict__ nrm,
+                                                    int8_t *__restrict__ i8, int *__restrict__ i8norm, int *__restrict__ flags)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int kcol = g >> 3, ch = g & 7;
+    if (kcol >= Kp) return;
+    double s = 0;
+    int si = 0, fl = 0;
+    int8_t v8[16];
+    bf16x8 h[2], l[2];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int b = ch * 16 + j;
+        const double x = (kcol < K && b < ND) ? (double)L[(size_t)kcol * ND + b] : 0.0;
+        const double ax = fabs(x);
+        if (!(ax <= 0x1p60) || (ax != 0.0 && ax < 0x1p-40)) fl |= 1;
+        const bool isb = x >= 0.0 && x <= 255.0 && x == floor(x);
+        if (!isb) fl |= 2;
+        const int xi = (isb ? (int)x : 0) - 128;                   // the int8 route re-centres by -128 like the uint8 class (a - b unchanged)
+        v8[j] = (int8_t)xi; si += xi * xi;
+        const __bf16 hb = (__bf16)(float)x;
+        const double r = x - (double)(float)hb;
+        h[j >> 3][j & 7] = hb; l[j >> 3][j & 7] = (__bf16)(float)r;
+        s += x * x;
+    }
+    if (kcol >= K) si = 0;
+    // fragment order, 8-bin chunks c8 = 2 ch, 2 ch + 1: [block of 16 descriptors][k-step of 32 bins][lane = (descriptor & 15) + 16 (chunk & 3)]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int c8 = 2 * ch + t;
+        const size_t o = ((size_t)(kcol >> 4) * 4 + (c8 >> 2)) * 64 + (kcol & 15) + 16 * (c8 & 3);
+        hi[o] = __builtin_bit_cast(v4i, h[t]); lo[o] = __builtin_bit_cast(v4i, l[t]);
+    }
+    // the int8 operands in k_match_i8_q's order (k_pack_i8_v, frag = 1)
+    *reinterpret_cast<int4 *>(i8 + (((size_t)(kcol >> 4) * 2 + (ch >> 2)) * 64 + (kcol & 15) + 16 * (ch & 3)) * 16) = *reinterpret_cast<const int4 *>(v8);
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); si += __shfl_xor(si, o, 64); }
+    if (ch == 0) {
+        const bool real = kcol < K;
+        nU[kcol] = real ? (float)(s * (1.0 + RK_E)) : RK_PAD_NORM; nL[kcol] = real ? (float)(s * (1.0 - RK_E)) : RK_PAD_NORM;
+        nrm[kcol] = real ? (float)s : 0.f;
+        i8norm[kcol] = real ? si : I8_NONE_NORM;
+    }
+    if (fl) atomicOr(flags, fl);
+}
+
+template <typename T>
+__global__ __launch_bounds__(64 * RK_WAVES) void k_match_rank(int ND, int K1, int K2, int K2p, const v4i *__restrict__ Qh, const v4i *__restrict__ Ql,
+                                                                const v4i *__restrict__ Dh, const v4i *__restrict__ Dl, const float *__restrict__ nq,
+                                                                const float *__restrict__ nU, const float *__restrict__ nL, const T *__restrict__ L1,
+                                                                const T *__restrict__ L2, int k2_offset, double *__restrict__ obest,
+                                                                double *__restrict__ osecond, int32_t *__restrict__ oarg, int *__restrict__ stats)
+{
+#pragma clang fp contract(off)
+    __shared__ float mb[RK_WAVES * RK_Q], ms[RK_WAVES * RK_Q], thr_s[RK_Q];
+    __shared__ int cnt[RK_Q], cand[RK_Q][RK_CAP];
+    constexpr int RK_CH = 32 / sizeof(T), RK_LDT = 128 + 16 / sizeof(T);    // candidate columns per tail pass (1 KB each) and their LDS stride
+    __shared__ T qs[RK_Q][128], cols[RK_WAVES][RK_CH][RK_LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, qi = lane & 15;
+    for (int i = tid; i < RK_Q * ND; i += 64 * RK_WAVES) {                  // the workgroup's queries as the caller gave them, for the tail
+        const int w = i / ND, b = i - w * ND, qq = blockIdx.x * RK_Q + w;
+        qs[w][b] = qq < K1 ? L1[(size_t)qq * ND + b] : (T)0;
+    }
+    const int nblk = K2p / 16;
+    struct Set { v4i h[4], l[4]; v4f n; };
+    v4i fqh[4], fql[4];
+    {
+        const v4i *qh = Qh + (size_t)blockIdx.x * 256 + lane, *ql = Ql + (size_t)blockIdx.x * 256 + lane;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { fqh[s] = qh[64 * s]; fql[s] = ql[64 * s]; }
+    }
+    auto load = [&](int blk, Set &S, const float *__restrict__ norms) {
+        const v4i *dh = Dh + (size_t)blk * 256 + lane, *dl = Dl + (size_t)blk * 256 + lane;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { S.h[s] = dh[64 * s]; S.l[s] = dl[64 * s]; }
+        S.n = *reinterpret_cast<const v4f *>(norms + blk * 16 + 4 * g);
+    };
+    // database block = A operand (accumulator rows 4 (lane >> 4) + e), query block = B operand (accumulator column lane & 15)
+    auto dots = [&](const Set &S) {
+        v4f acc = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, S.h[s]), __builtin_bit_cast(bf16x8, fqh[s]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, S.h[s]), __builtin_bit_cast(bf16x8, fql[s]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, S.l[s]), __builtin_bit_cast(bf16x8, fqh[s]), acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    const int last = wave < nblk ? wave + (nblk - 1 - wave) / RK_WAVES * RK_WAVES : 0;
+    auto at = [&](int b) { return b < last ? b : last; };
+    Set A, B;
+    // ---- phase 1: the two smallest upper bounds per lane
+    float best = INFINITY, second = INFINITY;
+    if (wave < nblk) {
+        auto scan = [&](const Set &S) {
+            const v4f acc = dots(S);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float u = fmaf(-2.f, acc[e], S.n[e]);
+                second = __builtin_amdgcn_fmed3f(best, u, second);
+                best = fminf(best, u);
+            }
+        };
+        load(wave, A, nU);
+        for (int blk = wave; blk < nblk; blk += 2 * RK_WAVES) {
+            load(at(blk + RK_WAVES), B, nU);
+            scan(A);
+            if (blk + RK_WAVES >= nblk) break;
+            load(at(blk + 2 * RK_WAVES), A, nU);
+            scan(B);
+        }
+    }
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        const float ob = __shfl_xor(best, o, 64), os = __shfl_xor(second, o, 64);
+        second = fminf(fmaxf(best, ob), fminf(second, os));
+        best = fminf(best, ob);
+    }
+    if (g == 0) { mb[wave * RK_Q + lane] = best; ms[wave * RK_Q + lane] = second; }
+    __syncthreads();
+    if (tid < RK_Q) {
+        float b = mb[tid], s2 = ms[tid];
+#pragma unroll
+        for (int w = 1; w < RK_WAVES; ++w) {
+            const float ob = mb[w * RK_Q + tid], os = ms[w * RK_Q + tid];
+            s2 = fminf(fmaxf(b, ob), fminf(s2, os));
+            b = fminf(b, ob);
+        }
+        const int q = blockIdx.x * RK_Q + tid;
+        thr_s[tid] = s2 + (float)(2.0 * RK_E) * (q < K1 ? nq[q] : 0.f);       // lower bound <= upper bound of the second best, the query's norm moved across
+        cnt[tid] = 0;
+    }
+    __syncthreads();
+    // ---- phase 2: the candidates
+    if (wave < nblk) {
+        const float thr = thr_s[qi];
+        auto emit = [&](int blk, const Set &S) {
+            const v4f acc = dots(S);
+            float lw[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lw[e] = fmaf(-2.f, acc[e], S.n[e]);
+            if (fminf(fminf(lw[0], lw[1]), fminf(lw[2], lw[3])) <= thr) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int idx = blk * 16 + 4 * g + e;
+                    if (lw[e] <= thr && idx < K2) {
+                        const int p = atomicAdd(&cnt[qi], 1);
+                        if (p < RK_CAP) cand[qi][p] = idx;
+                    }
+                }
+            }
+        };
+        load(wave, A, nL);
+        for (int blk = wave; blk < nblk; blk += 2 * RK_WAVES) {
+            load(at(blk + RK_WAVES), B, nL);
+            emit(blk, A);
+            if (blk + RK_WAVES >= nblk) break;
+            load(at(blk + 2 * RK_WAVES), A, nL);
+            emit(blk + RK_WAVES, B);
+        }
+    }
+    __syncthreads();
+    // ---- tail: wave w re-evaluates query w's candidates in the reference's arithmetic (siftmatch.c:97-116).  The accumulation is a
+    // chain over the bins, the loads are not: the wave fetches RK_CH candidate columns at a time into LDS with coalesced loads (all in
+    // flight together), then lane c walks column c and the query (LDS broadcast) bin by bin.
+    const int q = blockIdx.x * RK_Q + wave;
+    if (q >= K1) return;
+    const int n = cnt[wave];
+    const T *qrow = qs[wave];
+    T *cb = &cols[wave][0][0];
+    T eb = acc_max<T>(), es = acc_max<T>();
+    int ek = -1;
+    if (n <= RK_CAP) {
+        for (int c0 = 0; c0 < n; c0 += RK_CH) {
+            const int nc = n - c0 < RK_CH ? n - c0 : RK_CH;
+            for (int i = lane; i < nc * ND; i += 64) {
+                const int c = i / ND, b = i - c * ND;
+                cb[c * RK_LDT + b] = L2[(size_t)cand[wave][c0 + c] * ND + b];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < nc) {
+                const T *bp = cb + lane * RK_LDT;
+                T acc = 0;
+                for (int bin = 0; bin < ND; ++bin) {
+                    const T delta = qrow[bin] - bp[bin];
+                    const T sq = delta * delta;
+                    acc = acc + sq;
+                }
+                merge3(eb, es, ek, acc, acc_max<T>(), cand[wave][c0 + lane]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        // more near-ties than the list holds (duplicated descriptors): the wave scans the whole database, 16 bins of 64 columns in flight
+        for (int k0 = 0; k0 < K2; k0 += 64) {
+            const int k2 = k0 + lane;
+            const T *bp = L2 + (size_t)(k2 < K2 ? k2 : 0) * ND;
+            T acc = 0;
+            for (int b0 = 0; b0 < ND; b0 += 16) {
+                T bv[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) bv[j] = b0 + j < ND ? bp[b0 + j] : (T)0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (b0 + j < ND) {
+                        const T delta = qrow[b0 + j] - bv[j];
+                        const T sq = delta * delta;
+                        acc = acc + sq;
+                    }
+                }
+            }
+            if (k2 < K2) push3(eb, es, ek, acc, k2);
+        }
+        if (lane == 0 && stats) atomicAdd(stats, 1);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const T ob = __shfl_xor(eb, o, 64), os = __shfl_xor(es, o, 64);
+        const int ok = __shfl_xor(ek, o, 64);
+        merge3(eb, es, ek, ob, os, ok);
+    }
+    if (lane == 0) { obest[q] = (double)eb; osecond[q] = (double)es; oarg[q] = ek < 0 ? -1 : ek + k2_offset; if (stats) atomicAdd(stats + 1, n < RK_CAP ? n : RK_CAP); }
+}
+
+// ------------------------------------------------------------------------------------------------
 // kNearestNeighbors.m:29-39: block per query; distances in the reference's accumulation order, then k
 // selection rounds (stable: lowest index first on ties).  data N x D, query M x D column-major.
 // ------------------------------------------------------------------------------------------------
@@ -673,6 +931,76 @@ static int partial_i8(int ND, int K1, const T *L1, int K2, const T *L2, int cent
     return PRE3_OK;
 }
 
+// device-resident state of the float-class matcher (k_rank_pack / k_match_rank / the int8 route), reusable across calls
+struct RankMatch {
+    int cls = 0, ND = 0, K1 = 0, K2 = 0, K1p = 0, K2p = 0, route = 0;     // route 0: exact kernels (data outside the bounds), 1: int8 MFMA, 2: bf16 rank + re-evaluation
+    DevBuf L1, L2, qh, ql, dh, dl, nq, nqU, nqL, nU, nL, nd, fl;
+    I8Match m;                                                            // int8 operands + the outputs (ob, os, oa) of every route
+};
+static int float_form()
+{
+    const char *e = getenv("PRE3_MATCH_FLOAT_FORM");           // 0: exact VALU kernels only, 1: auto, 2: never the int8 route (A/B, tests); read per call
+    return e ? atoi(e) : 1;
+}
+template <typename T>
+static bool rank_applies(int ND, int K1, int K2) { return float_form() != 0 && ND <= 128 && (size_t)K1 * K2 >= (size_t)64 * 64 * 16; }
+
+template <typename T>
+static int rank_prepare(RankMatch &r, int ND, int K1, const T *L1, int K2, const T *L2)
+{
+    r.ND = ND; r.K1 = K1; r.K2 = K2; r.K1p = round_up(K1, 128); r.K2p = round_up(K2, 128);
+    I8Match &m = r.m;
+    m.ND = ND; m.NDp = 128; m.K1 = K1; m.K2 = K2; m.K1p = r.K1p; m.K2p = r.K2p; m.ntn = m.K2p / 128; m.frag = true;
+    PRE3_TRY(r.L1.alloc(sizeof(T) * (size_t)ND * K1)); PRE3_TRY(r.L2.alloc(sizeof(T) * (size_t)ND * K2));
+    PRE3_HIP(hipMemcpy(r.L1.p, L1, sizeof(T) * (size_t)ND * K1, hipMemcpyHostToDevice));
+    PRE3_HIP(hipMemcpy(r.L2.p, L2, sizeof(T) * (size_t)ND * K2, hipMemcpyHostToDevice));
+    PRE3_TRY(r.qh.alloc((size_t)r.K1p * 256)); PRE3_TRY(r.ql.alloc((size_t)r.K1p * 256)); PRE3_TRY(r.dh.alloc((size_t)r.K2p * 256)); PRE3_TRY(r.dl.alloc((size_t)r.K2p * 256));
+    PRE3_TRY(r.nq.alloc(sizeof(float) * r.K1p)); PRE3_TRY(r.nqU.alloc(sizeof(float) * r.K1p)); PRE3_TRY(r.nqL.alloc(sizeof(float) * r.K1p));
+    PRE3_TRY(r.nU.alloc(sizeof(float) * r.K2p)); PRE3_TRY(r.nL.alloc(sizeof(float) * r.K2p)); PRE3_TRY(r.nd.alloc(sizeof(float) * r.K2p));
+    PRE3_TRY(r.fl.alloc(sizeof(int) * 4));
+    PRE3_TRY(m.A.alloc((size_t)m.K1p * 128)); PRE3_TRY(m.B.alloc((size_t)m.K2p * 128));
+    PRE3_TRY(m.na.alloc(sizeof(int) * m.K1p)); PRE3_TRY(m.nb.alloc(sizeof(int) * m.K2p));
+    PRE3_TRY(m.ob.alloc(sizeof(double) * K1)); PRE3_TRY(m.os.alloc(sizeof(double) * K1)); PRE3_TRY(m.oa.alloc(sizeof(int32_t) * K1));
+    PRE3_HIP(hipMemset(r.fl.p, 0, sizeof(int) * 4));
+    hipLaunchKernelGGL((k_rank_pack<T>), dim3(r.K1p * 8 / 256), dim3(256), 0, 0, ND, K1, r.K1p, (const T *)r.L1.p, (v4i *)r.qh.p, (v4i *)r.ql.p,
+                       (float *)r.nqU.p, (float *)r.nqL.p, (float *)r.nq.p, (int8_t *)m.A.p, (int *)m.na.p, (int *)r.fl.p);
+    hipLaunchKernelGGL((k_rank_pack<T>), dim3(r.K2p * 8 / 256), dim3(256), 0, 0, ND, K2, r.K2p, (const T *)r.L2.p, (v4i *)r.dh.p, (v4i *)r.dl.p,
+                       (float *)r.nU.p, (float *)r.nL.p, (float *)r.nd.p, (int8_t *)m.B.p, (int *)m.nb.p, (int *)r.fl.p);
+    PRE3_HIP(hipGetLastError());
+    int fl = 0;
+    PRE3_HIP(hipMemcpy(&fl, r.fl.p, sizeof(int), hipMemcpyDeviceToHost));
+    r.route = (fl & 1) ? 0 : ((fl & 2) == 0 && float_form() != 2) ? 1 : 2;
+    return PRE3_OK;
+}
+
+template <typename T>
+static int rank_run(RankMatch &r, int k2_offset, hipStream_t st, bool count = false)
+{
+    if (r.route == 1) return i8_run(r.m, k2_offset, st);
+    PRE3_CHECK(r.route == 2, PRE3_E_STATE, "float-class matcher: the data is outside the ranked path's bounds");
+    hipLaunchKernelGGL((k_match_rank<T>), dim3(r.K1p / RK_Q), dim3(64 * RK_WAVES), 0, st, r.ND, r.K1, r.K2, r.K2p, (const v4i *)r.qh.p, (const v4i *)r.ql.p,
+                       (const v4i *)r.dh.p, (const v4i *)r.dl.p, (const float *)r.nq.p, (const float *)r.nU.p, (const float *)r.nL.p, (const T *)r.L1.p,
+                       (const T *)r.L2.p, k2_offset, (double *)r.m.ob.p, (double *)r.m.os.p, (int32_t *)r.m.oa.p, count ? (int *)r.fl.p + 2 : nullptr);
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
+// float / double classes: the ranked MFMA path when the shape and the data allow it, else the exact kernels
+template <typename T>
+static int partial_float(int ND, int K1, const T *L1, int K2, const T *L2, int k2_offset, double *best, double *second, int32_t *arg)
+{
+    if (!rank_applies<T>(ND, K1, K2)) return partial_exact<T, T>(ND, K1, L1, K2, L2, k2_offset, best, second, arg);
+    RankMatch r;
+    PRE3_TRY(rank_prepare<T>(r, ND, K1, L1, K2, L2));
+    if (r.route == 0) return partial_exact<T, T>(ND, K1, L1, K2, L2, k2_offset, best, second, arg);
+    PRE3_TRY(rank_run<T>(r, k2_offset, 0));
+    PRE3_HIP(hipMemcpy(best, r.m.ob.p, sizeof(double) * K1, hipMemcpyDeviceToHost));
+    PRE3_HIP(hipMemcpy(second, r.m.os.p, sizeof(double) * K1, hipMemcpyDeviceToHost));
+    PRE3_HIP(hipMemcpy(arg, r.m.oa.p, sizeof(int32_t) * K1, hipMemcpyDeviceToHost));
+    if (r.route == 1 && sizeof(T) == 4) {}                        // (int-valued sums < 2^24: the float class's own sums are the same integers)
+    return PRE3_OK;
+}
+
 int match_partial(int device, int cls, int ND, int K1, const void *L1, int K2, const void *L2, int k2_offset, double *best, double *second,
                   int32_t *arg)
 {
@@ -685,8 +1013,8 @@ int match_partial(int device, int cls, int ND, int K1, const void *L1, int K2, c
         return PRE3_OK;
     }
     switch (cls) {
-    case 0: return partial_exact<double, double>(ND, K1, (const double *)L1, K2, (const double *)L2, k2_offset, best, second, arg);
-    case 1: return partial_exact<float, float>(ND, K1, (const float *)L1, K2, (const float *)L2, k2_offset, best, second, arg);
+    case 0: return partial_float<double>(ND, K1, (const double *)L1, K2, (const double *)L2, k2_offset, best, second, arg);
+    case 1: return partial_float<float>(ND, K1, (const float *)L1, K2, (const float *)L2, k2_offset, best, second, arg);
     case 2: return partial_i8<uint8_t>(ND, K1, (const uint8_t *)L1, K2, (const uint8_t *)L2, 128, k2_offset, best, second, arg);
     case 3: return partial_i8<int8_t>(ND, K1, (const int8_t *)L1, K2, (const int8_t *)L2, 0, k2_offset, best, second, arg);
     default: set_error("siftmatch: unsupported class %d", cls); return PRE3_E_ARG;
@@ -934,22 +1262,36 @@ int match_shard_merge(void *h, int G, const void *gathered_dev, double thresh, d
 }
 void match_shard_destroy(void *h) { delete (MatchShard *)h; }
 
-// matcher bench handle (inputs resident in HBM): uint8 descriptors, MFMA path
-struct MatchBench { I8Match m; };
-void *match_bench_create(int ND, int K1, const uint8_t *L1, int K2, const uint8_t *L2)
+// matcher bench handle (inputs resident in HBM): cls 2 = uint8 descriptors on the int8 MFMA path; cls 0 / 1 = double / float descriptors on
+// the route their data selects (info: [route, queries scanned in full, candidates re-evaluated] of the last run)
+struct MatchBench { int cls = 2; I8Match m; RankMatch r; };
+void *match_bench_create(int cls, int ND, int K1, const void *L1, int K2, const void *L2)
 {
     MatchBench *b = new MatchBench();
-    if (i8_prepare(b->m, ND, K1, L1, K2, L2, 128) != PRE3_OK) { delete b; return nullptr; }
+    b->cls = cls;
+    int rc = PRE3_E_ARG;
+    if (cls == 2) rc = i8_prepare(b->m, ND, K1, (const uint8_t *)L1, K2, (const uint8_t *)L2, 128);
+    else if (cls == 0 && rank_applies<double>(ND, K1, K2)) rc = rank_prepare<double>(b->r, ND, K1, (const double *)L1, K2, (const double *)L2);
+    else if (cls == 1 && rank_applies<float>(ND, K1, K2)) rc = rank_prepare<float>(b->r, ND, K1, (const float *)L1, K2, (const float *)L2);
+    else set_error("matcher bench: class %d / shape not on an MFMA path", cls);
+    if (rc == PRE3_OK && cls != 2 && b->r.route == 0) { set_error("matcher bench: the data is outside the ranked path's bounds"); rc = PRE3_E_ARG; }
+    if (rc != PRE3_OK) { delete b; return nullptr; }
     return b;
+}
+static int bench_once(MatchBench *b, bool count = false)
+{
+    if (b->cls == 2) return i8_run(b->m, 0, 0);
+    if (count) PRE3_HIP(hipMemsetAsync((int *)b->r.fl.p + 2, 0, 2 * sizeof(int), 0));
+    return b->cls == 0 ? rank_run<double>(b->r, 0, 0, count) : rank_run<float>(b->r, 0, 0, count);
 }
 int match_bench_run(void *h, int reps, double *ms_per)
 {
     MatchBench *b = (MatchBench *)h;
     hipEvent_t e0, e1;
     PRE3_HIP(hipEventCreate(&e0)); PRE3_HIP(hipEventCreate(&e1));
-    PRE3_TRY(i8_run(b->m, 0, 0));
+    PRE3_TRY(bench_once(b, true));             // (the untimed warm-up run also counts the candidates for match_bench_info)
     PRE3_HIP(hipEventRecord(e0, 0));
-    for (int i = 0; i < reps; ++i) PRE3_TRY(i8_run(b->m, 0, 0));
+    for (int i = 0; i < reps; ++i) PRE3_TRY(bench_once(b));
     PRE3_HIP(hipEventRecord(e1, 0));
     PRE3_HIP(hipEventSynchronize(e1));
     float ms = 0; PRE3_HIP(hipEventElapsedTime(&ms, e0, e1));
@@ -960,9 +1302,17 @@ int match_bench_run(void *h, int reps, double *ms_per)
 int match_bench_fetch(void *h, double *best, double *second, int32_t *arg)
 {
     MatchBench *b = (MatchBench *)h;
-    PRE3_HIP(hipMemcpy(best, b->m.ob.p, sizeof(double) * b->m.K1, hipMemcpyDeviceToHost));
-    PRE3_HIP(hipMemcpy(second, b->m.os.p, sizeof(double) * b->m.K1, hipMemcpyDeviceToHost));
-    PRE3_HIP(hipMemcpy(arg, b->m.oa.p, sizeof(int32_t) * b->m.K1, hipMemcpyDeviceToHost));
+    I8Match &m = b->cls == 2 ? b->m : b->r.m;
+    PRE3_HIP(hipMemcpy(best, m.ob.p, sizeof(double) * m.K1, hipMemcpyDeviceToHost));
+    PRE3_HIP(hipMemcpy(second, m.os.p, sizeof(double) * m.K1, hipMemcpyDeviceToHost));
+    PRE3_HIP(hipMemcpy(arg, m.oa.p, sizeof(int32_t) * m.K1, hipMemcpyDeviceToHost));
+    return PRE3_OK;
+}
+int match_bench_info(void *h, int32_t info[3])
+{
+    MatchBench *b = (MatchBench *)h;
+    info[0] = b->cls == 2 ? 1 : b->r.route; info[1] = info[2] = 0;
+    if (b->cls != 2) { int st[2] = { 0, 0 }; PRE3_HIP(hipMemcpy(st, (int *)b->r.fl.p + 2, sizeof(st), hipMemcpyDeviceToHost)); info[1] = st[0]; info[2] = st[1]; }
     return PRE3_OK;
 }
 void match_bench_destroy(void *h) { delete (MatchBench *)h; }

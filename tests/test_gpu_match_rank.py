@@ -1,0 +1,143 @@
+"""The float / double classes of siftmatch on the matrix cores (pre3_match.hip: k_rank_pack, k_match_rank): a bf16 distance GEMM ranks the
+database, the candidates inside the guard band are re-evaluated in the reference's own arithmetic (sift/siftmatch.c:97-116).  Everything
+here must be BIT-identical to the oracle / to the exact VALU kernels, including scores, ties and the second-best value."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class _Form:
+    """PRE3_MATCH_FLOAT_FORM for the duration of a block (0: exact kernels only, 2: never the int8 route; read by the library per call)"""
+    def __init__(self, v):
+        self.v = v
+
+    def __enter__(self):
+        self.old = os.environ.get("PRE3_MATCH_FLOAT_FORM")
+        os.environ["PRE3_MATCH_FLOAT_FORM"] = str(self.v)
+
+    def __exit__(self, *a):
+        if self.old is None:
+            del os.environ["PRE3_MATCH_FLOAT_FORM"]
+        else:
+            os.environ["PRE3_MATCH_FLOAT_FORM"] = self.old
+
+
+def _route(pre3, L1, L2):
+    """[route, queries scanned in full, candidates re-evaluated] of one resident run (pre3_match_bench_*), or None when the data is refused"""
+    lib = pre3._lib.lib
+    cls = {np.dtype(np.float64): 0, np.dtype(np.float32): 1}[L1.dtype]
+    a, b = np.asfortranarray(L1), np.asfortranarray(L2)
+    h = lib.pre3_match_bench_create_cls(0, cls, a.shape[0], a.shape[1], a.ctypes.data_as(C.c_void_p), b.shape[1], b.ctypes.data_as(C.c_void_p))
+    if not h:
+        return None
+    ms = C.c_double(0)
+    assert lib.pre3_match_bench_run(C.c_void_p(h), 1, C.byref(ms)) == 0
+    info = (C.c_int32 * 3)()
+    assert lib.pre3_match_bench_info(C.c_void_p(h), info) == 0
+    K1 = a.shape[1]
+    best, second, arg = np.zeros(K1), np.zeros(K1), np.zeros(K1, np.int32)
+    assert lib.pre3_match_bench_fetch(C.c_void_p(h), best.ctypes.data_as(C.c_void_p), second.ctypes.data_as(C.c_void_p), arg.ctypes.data_as(C.c_void_p)) == 0
+    lib.pre3_match_bench_destroy(C.c_void_p(h))
+    return list(info), (best, second, arg)
+
+
+def _exact_partial(pre3, L1, L2):
+    with _Form(0):
+        return pre3.siftmatch_partial(L1, L2, 0)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_routes(pre3, dt):
+    rng = np.random.default_rng(1)
+    L1, L2 = rng.random((128, 256)).astype(dt), rng.random((128, 512)).astype(dt)
+    info, got = _route(pre3, L1, L2)
+    assert info[0] == 2 and info[1] == 0 and 2 * 256 <= info[2] <= 8 * 256          # bf16 rank; a handful of candidates per query
+    ref = _exact_partial(pre3, L1, L2)
+    assert all(np.array_equal(g, r) for g, r in zip(got, ref))
+    Li1, Li2 = np.floor(L1 * 256).astype(dt), np.floor(L2 * 256).astype(dt)        # what vl_sift hands matching_sift_based.m:104-118, as doubles
+    info, got = _route(pre3, Li1, Li2)
+    assert info[0] == 1                                                              # integers in [0, 255]: the int8 kernel is exact
+    ref = _exact_partial(pre3, Li1, Li2)
+    assert all(np.array_equal(g, r) for g, r in zip(got, ref))
+    bad = L2.copy(); bad[5, 7] = np.nan
+    assert _route(pre3, L1, bad) is None                                             # outside the bounds: the stateless entry takes the exact kernels
+    big = L2.copy(); big[0, 0] = 1e30
+    assert _route(pre3, L1, big) is None
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_near_ties_and_duplicates_bit_exact(pre3, orc, dt):
+    """perturbations far below the GEMM's resolution, exact duplicates (first index wins, second == best), more duplicates than the
+    candidate list holds (the wave scans the whole database), against the oracle with scores"""
+    rng = np.random.default_rng(2)
+    K1, K2 = 192, 1100
+    eps = np.finfo(dt).eps
+    L1 = (rng.random((128, K1)) * 3).astype(dt)
+    L2 = (rng.random((128, K2)) * 3).astype(dt)
+    L2[:, 10:74] = L1[:, :64] * (1 + 4 * eps * rng.integers(-3, 4, (128, 64))).astype(dt)       # a few ulps away from the query
+    L2[:, 200:264] = L2[:, 10:74]                                                              # ... twice: exact duplicates of the best
+    L2[:, 300:364] = L1[:, :64] * (1 + 1e-5 * rng.standard_normal((128, 64))).astype(dt)        # inside the guard band, ordered only exactly
+    L2[:, 400:500] = L1[:, 100][:, None]                                                       # 100 copies of query 100 (> 64 candidates)
+    L2[:, 1099] = L1[:, 191]
+    for th in (1.5, 1.0):
+        m, d = pre3.siftmatch(L1, L2, th, return_scores=True)
+        mr, dr = orc.siftmatch(L1, L2, th)
+        assert np.array_equal(m, mr) and np.array_equal(d, dr)
+    info, got = _route(pre3, L1, L2)
+    assert info[0] == 2 and info[1] >= 1                                                        # query 100 overflowed its list
+    ref = _exact_partial(pre3, L1, L2)
+    assert all(np.array_equal(g, r) for g, r in zip(got, ref))
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_scales_and_forced_rank(pre3, orc, dt):
+    rng = np.random.default_rng(3)
+    base1, base2 = rng.standard_normal((128, 130)), rng.standard_normal((128, 700))
+    base2[:, 50:100] = base1[:, :50] + 0.01 * rng.standard_normal((128, 50))
+    for scale in (1.0, 1e9, 1e-9, 3e17 if dt == np.float64 else 1e15):                          # squares stay inside f32 for the GEMM
+        L1, L2 = (base1 * scale).astype(dt), (base2 * scale).astype(dt)
+        m, d = pre3.siftmatch(L1, L2, 1.3, return_scores=True)
+        mr, dr = orc.siftmatch(L1, L2, 1.3)
+        assert np.array_equal(m, mr) and np.array_equal(d, dr), scale
+    # mixed magnitudes inside one descriptor, negative values, a zero column
+    L1 = (base1 * np.logspace(-3, 3, 128)[:, None]).astype(dt)
+    L2 = (base2 * np.logspace(-3, 3, 128)[:, None]).astype(dt)
+    L2[:, 5] = 0
+    m, d = pre3.siftmatch(L1, L2, 1.1, return_scores=True)
+    mr, dr = orc.siftmatch(L1, L2, 1.1)
+    assert np.array_equal(m, mr) and np.array_equal(d, dr)
+    # integer-valued descriptors forced through the bf16 rank (integer distances: dense ties)
+    Li1 = rng.integers(0, 256, (128, 140)).astype(dt)
+    Li2 = rng.integers(0, 256, (128, 600)).astype(dt)
+    Li2[:, 100:200] = np.clip(Li1[:, :100] + rng.integers(-1, 2, (128, 100)), 0, 255)
+    Li2[:, 300] = Li2[:, 100]
+    with _Form(2):
+        m, d = pre3.siftmatch(Li1, Li2, 1.5, return_scores=True)
+    mr, dr = orc.siftmatch(Li1, Li2, 1.5)
+    assert np.array_equal(m, mr) and np.array_equal(d, dr)
+    m1, d1 = pre3.siftmatch(Li1, Li2, 1.5, return_scores=True)                                   # the int8 route
+    assert np.array_equal(m1, mr) and np.array_equal(d1, dr)
+
+
+def test_full_size_double_class(pre3):
+    """BASELINE configs[3] shape in the class the reference calls (double, matching_sift_based.m:104-118): 4096 x 4096 x 128 real-valued
+    descriptors; (best, second, arg) of the ranked path == the exact kernels for every query, and the planted matches are found"""
+    rng = np.random.default_rng(4)
+    K = 4096
+    L1 = np.abs(rng.standard_normal((128, K))) * 40
+    perm = rng.permutation(K)
+    L2 = L1[:, perm] + rng.uniform(-2, 2, (128, K))
+    info, got = _route(pre3, L1, L2)
+    assert info[0] == 2 and info[1] == 0
+    ref = _exact_partial(pre3, L1, L2)
+    assert all(np.array_equal(g, r) for g, r in zip(got, ref))
+    inv = np.empty(K, int); inv[perm] = np.arange(K)
+    assert np.array_equal(got[2], inv)
+    L1f, L2f = L1.astype(np.float32), L2.astype(np.float32)
+    info, got = _route(pre3, L1f, L2f)
+    ref = _exact_partial(pre3, L1f, L2f)
+    assert info[0] == 2 and all(np.array_equal(g, r) for g, r in zip(got, ref))
