@@ -269,18 +269,18 @@ __device__ inline float chain_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ inline double chain_rcp(double x) { double r = __builtin_amdgcn_rcp(x); r = r * (2.0 - x * r); return r * (2.0 - x * r); }
 
 // Panel kernel.  What bounds it is the dependent chain of the 64 columns, not flops, so the chain runs on a
-// dedicated wave and everything else is kept off it.  The 64 columns are swept in 8 sub-panels of MB = 8:
-//   wave 0  (factor wave; lane = row i of the L block): per sub-panel s it takes the columns as published by the
-//           workers (updated through sub-panel s-2), applies sub-panel s-1's update itself (lookahead; the 8x8
+// dedicated wave and everything else is kept off it.  The 64 columns are swept in 8 sub-panels of MB = 8; a workgroup is TEN waves:
+//   wave 8  (factor wave; lane = row i of the L block): per sub-panel s it takes the columns as published by the
+//           D workers (updated through sub-panel s-2), applies sub-panel s-1's update itself (lookahead; the 8x8
 //           multipliers are a broadcast LDS read of what the wave wrote one step earlier -- no cross-lane VALU work),
-//           then factors right-looking inside the sub-panel: per column one pivot v_readlane, v_rsq, a multiply and
-//           7-c (v_readlane, fma) pairs.  Writes its row of L into Ls and the eight 1/sqrt(pivot) into Rs.
-//   wave 1  (z wave; lane = column i of the workgroup's X block), ONE step behind: x <- L8^-1 (x - lookahead), all
+//           then factors right-looking inside the sub-panel, division-free: per column one pivot v_readlane, v_rcp, v_rsq and
+//           7-c (v_readlane, multiply, fma) triples.  Writes its row of L into Ls and the eight 1/sqrt(pivot) into Rs.
+//   wave 9  (z wave; lane = column i of the workgroup's X block), ONE step behind: x <- L8^-1 (x - lookahead), all
 //           coefficients (the 8x8 diagonal sub-block, the 8x8 block left of it, Rs) broadcast from LDS.
-//   waves 2-5 (workers; 16x16 lanes, a register-resident 4x4 patch of each 64x64 block per lane) apply the rank-8
-//           updates of finished sub-panels to the patches that still matter (patch sets are compile-time: no
-//           predicates -- entries above the diagonal / left of the front carry garbage that nothing reads) and
-//           publish the next sub-panel's columns of L (Pn) and rows of X (Xr).
+//   waves 0-3 (D workers) and 4-7 (X workers): wave w holds 32x32 tile (w>>1 & 1, w&1) of the diagonal block D / of the workgroup's X
+//           block as MFMA accumulators and applies the rank-8 updates of finished sub-panels on the matrix cores (ch_worker_step below),
+//           then publishes the next sub-panel's columns of L (Pn) / rows of X (Xr).  The pending update of panel J-1 (the launch's
+//           prologue) is accumulated by the same waves straight into these tiles: acc = raw tile - (products from the bf16 planes).
 // ONE workgroup barrier per step, 10 steps per 64 columns (was 18 with 4-column micro-panels and the X solve on the
 // factor wave).  Every workgroup factors the diagonal block redundantly; workgroup b then owns X = its 64-row block
 // of [S ; HP'] (b = 0: the diagonal block itself).

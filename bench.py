@@ -205,8 +205,24 @@ def matcher_leg(pre3, reps=20):
     if rc != 0:
         return None
     tops = 2.0 * K * K * 128 / (ms.value * 1e-3) / 1e12
+    # the class matching_sift_based.m:104-118 actually passes (double): the same descriptors as doubles (integer-valued: int8 route) and a
+    # real-valued set (bf16 distance GEMM ranks, guard-band candidates re-evaluated exactly); pre3_match.hip "float / double classes"
+    fl = {}
+    real1 = np.abs(rng.standard_normal((K, 128))) * 40
+    real2 = real1[rng.permutation(K)] + rng.uniform(-2, 2, (K, 128))
+    for name, A, B in (("double_integer_valued", L1.astype(np.float64), L2.astype(np.float64)), ("double_real_valued", real1, real2),
+                       ("float_real_valued", real1.astype(np.float32), real2.astype(np.float32))):
+        hf = lib.pre3_match_bench_create_cls(0, 0 if A.dtype == np.float64 else 1, 128, K, A.ctypes.data_as(C.c_void_p), K, B.ctypes.data_as(C.c_void_p))
+        if not hf:
+            continue
+        msf, info = C.c_double(0), (C.c_int32 * 3)()
+        ok = lib.pre3_match_bench_run(C.c_void_p(hf), reps, C.byref(msf)) == 0 and lib.pre3_match_bench_info(C.c_void_p(hf), info) == 0
+        lib.pre3_match_bench_destroy(C.c_void_p(hf))
+        if ok:
+            fl[name] = {"us_per_match": 1e3 * msf.value, "route": {0: "exact kernels", 1: "int8 MFMA", 2: "bf16 MFMA rank + exact re-evaluation"}[info[0]],
+                        "candidates_per_query": info[2] / K, "queries_scanned_in_full": info[1]}
     return {"workload": "configs[3]: 4096x4096x128 uint8, 1 GPU", "ms_per_match": ms.value, "pairs_per_s": K * K / (ms.value * 1e-3),
-            "int8_mfma_TOPS": tops,
+            "int8_mfma_TOPS": tops, "float_classes": fl,
             "roofline": {"kernel": "k_match_i8_q (v_mfma_i32_16x16x64_i8, query-per-lane scan fused, one launch)", "bound": "mfma", "unit": "TOP/s",
                          "achieved": tops, "peak": PEAK["i8"], "frac": tops / PEAK["i8"], "traffic": None,
                          "algorithmic": "2 * K1 * K2 * 128 integer ops per match; the kernel is bound by its scan's vector instructions and by "

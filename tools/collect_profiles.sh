@@ -10,6 +10,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_tra
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${tag}_pmc_fetch -o f -- $B --steps 10 --warmup 2 > $R/gpurun_out/${tag}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${tag}_pmc_write -o w -- $B --steps 10 --warmup 2 > $R/gpurun_out/${tag}_pmc_write.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_match -o m -- python3 $R/tools/match_ab.py child > $R/gpurun_out/${tag}_match.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_matchf -o mf -- python3 $R/tools/match_float.py > $R/gpurun_out/${tag}_matchf.log 2>&1
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
   t=$(echo $set | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/${tag}_pmc_sq/$t -o p -- $B --steps 10 --warmup 2 > $R/gpurun_out/${tag}_pmc_sq_$t.log 2>&1 || echo "failed: $set"

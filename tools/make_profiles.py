@@ -98,3 +98,18 @@ try:
     print("matcher 4096^2 launches: mean %.2f us" % (sum(big) / len(big)))
 except FileNotFoundError as e:
     print("no matcher trace:", e)
+
+# ---- the float / double classes on the matrix cores (k_rank_pack, k_match_rank; tools/match_float.py)
+try:
+    shutil.copy(find("%s_matchf" % tag, "mf_kernel_stats.csv"), os.path.join(P, "%s_match_float_kernel_stats.csv" % tag))
+    by = {}
+    for r in csv.DictReader(open(find("%s_matchf" % tag, "mf_kernel_trace.csv"))):
+        for k_ in ("k_match_rank<double>", "k_match_rank<float>", "k_match_i8_q", "k_match_exact_tiled<double>", "k_match_exact_tiled<float>"):
+            if k_ in r["Kernel_Name"]:
+                by.setdefault(k_, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    with open(os.path.join(P, "%s_match_float_kernel_stats.csv" % tag), "a") as fh:
+        for k_, v in sorted(by.items()):
+            fh.write("# %s at 4096 x 4096 x 128 (tools/match_float.py): %d launches, mean %.2f us, min %.2f us\n" % (k_, len(v), sum(v) / len(v), min(v)))
+            print("%s: mean %.2f us over %d launches" % (k_, sum(v) / len(v), len(v)))
+except FileNotFoundError as e:
+    print("no float-class matcher trace:", e)
