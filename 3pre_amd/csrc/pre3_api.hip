@@ -761,7 +761,7 @@ int pre3_ransac(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, double thres
 }
 
 // ---- updates --------------------------------------------------------------------------------------
-static int update_selected(pre3_ctx *c, int which_prior, int nsel, const int32_t *sel_dev, bool gathered = false)
+static int update_selected(pre3_ctx *c, int which_prior, int nsel, const int32_t *sel_dev, bool gathered = false, bool first_done = false)
 {
     PRE3_CHECK(c->p_which == which_prior, PRE3_E_STATE, "update: the covariance buffer does not hold the required prior");
     int r = 2 * nsel;
@@ -769,7 +769,7 @@ static int update_selected(pre3_ctx *c, int which_prior, int nsel, const int32_t
     const bool reuse = r > 0 && which_prior == PRE3_X_K_KM1 && c->hp_all_valid && sel_dev != nullptr;
     if (reuse) { if (!gathered) PRE3_TRY(launch_gather_li(c, nsel, nsel, sel_dev, round_up(2 * c->m, NB))); }
     else if (r > 0) PRE3_TRY(launch_build_rows_impl(c, nsel, sel_dev, round_up(r, NB)));
-    PRE3_TRY(run_update(c, which_prior, r, false, nullptr, reuse));
+    PRE3_TRY(run_update(c, which_prior, r, false, nullptr, reuse, first_done && reuse));
     c->hp_all_valid = false;                 // P changed
     c->x_valid[PRE3_X_K_K] = true; c->p_which = PRE3_X_K_K;
     return PRE3_OK;
@@ -780,7 +780,7 @@ int pre3_update_li(pre3_ctx *c)
     PRE3_TRY(check_ctx(c));
     PRE3_CHECK(c->measurements_set && c->projected, PRE3_E_STATE, "pre3_update_li: needs projection and measurements");
     int n_li = 0;       // no RANSAC / flags for this measurement set: no low-innovation inliers, update is the identity
-    bool gathered = false;
+    bool gathered = false, first_done = false;
     if (c->li_from_host >= 0) n_li = c->li_from_host;
     else if (c->li_kernel) {
         // the gather of the LI rows does not need the count on the host: issue it first, with the grid sized for all
@@ -788,10 +788,13 @@ int pre3_update_li(pre3_ctx *c)
         if (c->p_which == PRE3_X_K_KM1 && c->hp_all_valid && c->m > 0) {
             PRE3_TRY(launch_gather_li(c, -1, c->m, c->sel_rows, round_up(2 * c->m, NB)));
             gathered = true;
+            // ... and so does the first panel of the factorisation (row count read on the device, grid sized for all measurements)
+            static const int spec_env = getenv("PRE3_CHOL_SPEC0") ? atoi(getenv("PRE3_CHOL_SPEC0")) : 1;
+            if (spec_env && round_up(2 * c->m, NB) <= c->rcap) { PRE3_TRY(launch_chol_first_spec(c, c->m)); first_done = true; }
         }
         PRE3_TRY(wait_mail(c, 8, c->seq_select)); n_li = c->mail_host[4];
     }
-    return update_selected(c, PRE3_X_K_KM1, n_li, c->sel_rows, gathered);
+    return update_selected(c, PRE3_X_K_KM1, n_li, c->sel_rows, gathered, first_done);
 }
 
 int pre3_rescue(pre3_ctx *c, double chi2, int32_t *hi_mask)

@@ -1026,6 +1026,27 @@ __global__ __launch_bounds__(CH_NTH) void k_chol_step(T *__restrict__ S, int lds
     }
 }
 
+// Panel 0 launched BEFORE the host knows the number of rows (LI update of a step: the count is still on its way through the mailbox):
+// the grid is sized for all measurements, the row count is read on the device (as k_gather_li in front of it does), and the workgroups of
+// S row blocks that do not exist arrive and leave.  The host polls the count while this launch runs and sizes the launches of the
+// panels >= 1 exactly; without it the stream sat idle for the mailbox round trip + a launch (~6 us) between the gather and the first panel.
+template <typename T>
+__global__ __launch_bounds__(CH_NTH) void k_chol_step0_spec(T *__restrict__ S, T *__restrict__ W, int ldw, int nS_max, const int32_t *__restrict__ n_dev,
+                                                            int32_t *__restrict__ status, unsigned int *__restrict__ arrive, unsigned int target,
+                                                            void *__restrict__ Wp, int nst_total, int ld_split, void *__restrict__ Sp, int sp_stride)
+{
+    __shared__ ChSmem<T> sm;
+    const int n = *n_dev;
+    const int nrb = (2 * n + NB - 1) / NB, nS = nrb - 1;
+    int b = blockIdx.x;
+    if (n <= 0 || (b > nS && b <= nS_max)) {          // no update at all / a row block beyond the selected rows: keep the arrival count the host assumed
+        if (b != 0 && threadIdx.x == 0) atomicAdd(arrive, 1u);
+        return;
+    }
+    if (b > nS_max) b -= nS_max - nS;                 // the W strips follow the S row blocks that exist
+    chol_panel_body<T, false>(sm, S, nrb * NB, W, ldw, 0, nrb, status, b, arrive, target, Wp, nst_total, ld_split, Sp, sp_stride);
+}
+
 // K' = L^-T W  (so that K = W' L^-1 ... = P H' inv(S)); slow back substitution, one lane per state row.
 // Only the stateless drop-in returns K (no caller in the reference uses it).  Kt: r_pad x ldw.
 template <typename T>
@@ -1725,7 +1746,7 @@ int launch_ell_G_hyp(pre3_ctx *c, int k, int lo, int hi, int ldg)
     return PRE3_OK;
 }
 
-static int launch_chol_solve(pre3_ctx *c, int r_pad)
+static int launch_chol_solve(pre3_ctx *c, int r_pad, bool first_done = false)
 {
     int nrb = r_pad / NB, nW = c->ldw / NB;
     c->split_rows = 0;
@@ -1733,7 +1754,7 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad)
         const bool split = c->k9_b3 && c->dtype == PRE3_F32 && c->Wp != nullptr;
         static const int pro_env = getenv("PRE3_CHOL_PRO_B3") ? atoi(getenv("PRE3_CHOL_PRO_B3")) : 1;
         const bool pro_planes = split && pro_env && c->Sp != nullptr;       // pending updates on the bf16 MFMA as well
-        for (int J = 0; J < nrb; ++J) {
+        for (int J = first_done ? 1 : 0; J < nrb; ++J) {
             const int nS = nrb - J - 1, nP = 1 + nS + nW;
             const int nK = J >= 1 ? nrb - J - 1 : 0;                        // column blocks >= J+1 of panel J-1's update
             const int nT = nK * (nK + 1) / 2 + nK * nW;
@@ -1889,8 +1910,27 @@ int launch_gather_li(pre3_ctx *c, int nsel, int nsel_max, const int32_t *sel_dev
     return PRE3_OK;
 }
 
-// prebuilt: W (H*P with the nu column) and Smat (S) are already in place (launch_gather_li)
-int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_dev, bool prebuilt)
+// panel 0 of the factorisation of an update whose row count is still on the device (c->stats[4]); nsel_max bounds it
+int launch_chol_first_spec(pre3_ctx *c, int nsel_max)
+{
+    const int nrb_max = round_up(2 * nsel_max, NB) / NB, nS_max = nrb_max - 1, nW = c->ldw / NB;
+    if (nrb_max <= 0) return PRE3_OK;
+    const bool split = c->k9_b3 && c->dtype == PRE3_F32 && c->Wp != nullptr;
+    static const int pro_env = getenv("PRE3_CHOL_PRO_B3") ? atoi(getenv("PRE3_CHOL_PRO_B3")) : 1;
+    const bool pro_planes = split && pro_env && c->Sp != nullptr;
+    const int nP = 1 + nS_max + nW;
+    c->chol_target += (unsigned)(nP - 1);
+    DISPATCH_T(c,
+        hipLaunchKernelGGL(k_chol_step0_spec<double>, dim3(nP), dim3(CH_NTH), 0, c->stream, (double *)c->Smat, (double *)c->W, c->ldw, nS_max, c->stats + 4, c->stats + 6,
+                           c->chol_arrive, c->chol_target, nullptr, 0, 0, nullptr, 0),
+        hipLaunchKernelGGL(k_chol_step0_spec<float>, dim3(nP), dim3(CH_NTH), 0, c->stream, (float *)c->Smat, (float *)c->W, c->ldw, nS_max, c->stats + 4, c->stats + 6,
+                           c->chol_arrive, c->chol_target, split ? c->Wp : nullptr, c->rcap / B3_BK, c->ld, pro_planes ? c->Sp : nullptr, c->rcap / NB));
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
+// prebuilt: W (H*P with the nu column) and Smat (S) are already in place (launch_gather_li); first_done: so is panel 0 (launch_chol_first_spec)
+int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_dev, bool prebuilt, bool first_done)
 {
     if (r == 0) {   // update.m:50-55: x_k_k = x_km1_k, p_k_k = p_km1_k
         if (which_prior == PRE3_X_K_KM1) PRE3_HIP(hipMemcpyAsync(c->x_kk, c->x_km1, sizeof(double) * c->n, hipMemcpyDeviceToDevice, c->stream));
@@ -1902,7 +1942,7 @@ int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_d
         PRE3_TRY(launch_ell_HP(c, r, c->W, true));
         PRE3_TRY(launch_ell_G(c, r, c->W, c->Smat, r_pad, 1, dense_R ? c->Rdense : nullptr));
     }
-    PRE3_TRY(launch_chol_solve(c, r_pad));
+    PRE3_TRY(launch_chol_solve(c, r_pad, first_done));
     PRE3_TRY(launch_downdate(c, r, c->W, which_prior));
     PRE3_TRY(launch_jnorm(c, 0));
     if (Kt_out_dev) {

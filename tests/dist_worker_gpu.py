@@ -14,9 +14,11 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    dist.init_process_group(backend="gloo")
+    backend = os.environ.get("PRE3_TEST_BACKEND", "gloo")          # "nccl" (= RCCL): one GPU per rank, needs >= world GPUs
+    dev = int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend=backend)
     rank, world = dist.get_rank(), dist.get_world_size()
-    torch.cuda.set_device(0)
     import oracle as orc
     pre3 = importlib.import_module("3pre_amd")
     pd = importlib.import_module("3pre_amd.dist")
@@ -26,7 +28,7 @@ def main():
     s = seq["steps"][0]
     types, off, n = orc.landmark_table(np.zeros(N, int))
     for dtype in ("f64", "f32"):
-        f = pre3.EkfFilter(seq["cam"], types, dtype=dtype, max_hyp=n_draw)
+        f = pre3.EkfFilter(seq["cam"], types, dtype=dtype, max_hyp=n_draw, device=dev)
         f.set_x_p_k_k(seq["x0"], seq["P0"])
         f.ekf_prediction(s["u"])
         f.search_IC_matches()
@@ -40,8 +42,10 @@ def main():
         f.ekf_update_li_inliers()
         P = f.get_p_k_k()
         t = torch.from_numpy(P.copy())
+        if backend == "nccl":
+            t = t.cuda()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        assert np.array_equal(t.numpy(), P), "ranks diverged after the replicated update"
+        assert np.array_equal(t.cpu().numpy(), P), "ranks diverged after the replicated update"
         f.close()
     rng = np.random.default_rng(3)
     L1 = rng.integers(0, 255, (128, 130)).astype(np.uint8)
@@ -54,7 +58,7 @@ def main():
     # the device-resident sharded matcher (matcher.MatchShard): slice packed in HBM, partials gathered as tensors, merge on the device
     mt = importlib.import_module("3pre_amd.matcher")
     lo, hi = pd.shard_range(L2.shape[1], rank, world)
-    sh = mt.MatchShard(L1, L2[:, lo:hi], lo, device=0)
+    sh = mt.MatchShard(L1, L2[:, lo:hi], lo, device=dev)
     for thr in (1.5, 1.1):
         m, d = pd.siftmatch_sharded_resident(sh, thr, return_scores=True)
         mr, dr = orc.siftmatch(L1, L2, thr)

@@ -11,17 +11,31 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_sharded_ransac_and_matcher_two_ranks_one_gpu():
+def _run_two_ranks(backend):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1", PRE3_TEST_BACKEND=backend,
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_gpu.py")]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("OK") == 2
+
+
+def test_sharded_ransac_and_matcher_two_ranks_one_gpu():
+    _run_two_ranks("gloo")
+
+
+def test_sharded_ransac_and_matcher_two_ranks_rccl():
+    """the nccl (= RCCL) branch itself: the in-place all-reduce on the zero-copy view, the device all-gather of the matcher partials, and
+    bit-identical replicas after the update -- needs two GPUs (RCCL refuses two ranks on one device), so it runs on multi-GPU nodes only"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    _run_two_ranks("nccl")
 
 
 def test_zero_copy_device_view_round_trip():
