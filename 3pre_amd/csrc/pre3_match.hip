@@ -504,6 +504,82 @@ constexpr double RK_E = 1.8e-4;
 constexpr float RK_PAD_NORM = 3.0e38f;
 constexpr int RK_WAVES = 16, RK_Q = 16, RK_CAP = 64;
 
+// One wave re-evaluates one query's candidates in the reference's arithmetic (siftmatch.c:97-116: bin 0..ND-1, subtract, multiply, add,
+// contraction off).  The accumulation is a chain over the bins, the loads are not: the wave fetches RK_CH candidate columns at a time into
+// LDS with coalesced loads (all in flight together), then lane c walks column c and the query (LDS broadcast), eight bins' reads ahead of
+// their use.  More than RK_CAP candidates (duplicated descriptors): the wave scans the whole database, 16 bins of 64 columns in flight.
+template <typename T> struct RankTail { static constexpr int CH = 32 / sizeof(T), LDT = 128 + 16 / sizeof(T); };
+template <typename T>
+__device__ __forceinline__ void rank_tail_wave(int ND, int K2, int n, const int *cd /* LDS: the wave's candidate list */, const T *qrow /* LDS */, T *cb /* LDS [CH][LDT] */,
+                                               const T *__restrict__ L2, int lane, T &eb, T &es, int &ek, int *__restrict__ stats)
+{
+#pragma clang fp contract(off)
+    constexpr int RK_CH = RankTail<T>::CH, RK_LDT = RankTail<T>::LDT;
+    eb = acc_max<T>(); es = acc_max<T>(); ek = -1;
+    if (n <= RK_CAP) {
+        for (int c0 = 0; c0 < n; c0 += RK_CH) {
+            const int nc = n - c0 < RK_CH ? n - c0 : RK_CH;
+            for (int i = lane; i < nc * ND; i += 64) {
+                const int c = i / ND, b = i - c * ND;
+                cb[c * RK_LDT + b] = L2[(size_t)cd[c0 + c] * ND + b];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < nc) {
+                const T *bp = cb + lane * RK_LDT;
+                T acc = 0;
+                int bin = 0;
+                for (; bin + 8 <= ND; bin += 8) {
+                    T qv[8], bv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { qv[j] = qrow[bin + j]; bv[j] = bp[bin + j]; }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const T delta = qv[j] - bv[j];
+                        const T sq = delta * delta;
+                        acc = acc + sq;
+                    }
+                }
+                for (; bin < ND; ++bin) {
+                    const T delta = qrow[bin] - bp[bin];
+                    const T sq = delta * delta;
+                    acc = acc + sq;
+                }
+                merge3(eb, es, ek, acc, acc_max<T>(), cd[c0 + lane]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        for (int k0 = 0; k0 < K2; k0 += 64) {
+            const int k2 = k0 + lane;
+            const T *bp = L2 + (size_t)(k2 < K2 ? k2 : 0) * ND;
+            T acc = 0;
+            for (int b0 = 0; b0 < ND; b0 += 16) {
+                T bv[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) bv[j] = b0 + j < ND ? bp[b0 + j] : (T)0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (b0 + j < ND) {
+                        const T delta = qrow[b0 + j] - bv[j];
+                        const T sq = delta * delta;
+                        acc = acc + sq;
+                    }
+                }
+            }
+            if (k2 < K2) push3(eb, es, ek, acc, k2);
+        }
+        if (lane == 0 && stats) atomicAdd(stats, 1);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const T ob = __shfl_xor(eb, o, 64), os = __shfl_xor(es, o, 64);
+        const int ok = __shfl_xor(ek, o, 64);
+        merge3(eb, es, ek, ob, os, ok);
+    }
+}
+
 // one thread per 16 bins of one descriptor (8 threads per descriptor: 128 bins, zero padded); K_pad descriptors
 template <typename T>
 __global__ __launch_bounds__(256) void k_rank_pack(int ND, int K, int Kp, const T *__restrict__ L, v4i *__restrict__ hi, v4i *__restrict__ lo,
@@ -669,67 +745,178 @@ __global__ __launch_bounds__(64 * RK_WAVES) void k_match_rank(int ND, int K1, in
         }
     }
     __syncthreads();
-    // ---- tail: wave w re-evaluates query w's candidates in the reference's arithmetic (siftmatch.c:97-116).  The accumulation is a
-    // chain over the bins, the loads are not: the wave fetches RK_CH candidate columns at a time into LDS with coalesced loads (all in
-    // flight together), then lane c walks column c and the query (LDS broadcast) bin by bin.
+    // ---- tail: wave w re-evaluates query w's candidates (rank_tail_wave)
     const int q = blockIdx.x * RK_Q + wave;
     if (q >= K1) return;
     const int n = cnt[wave];
-    const T *qrow = qs[wave];
-    T *cb = &cols[wave][0][0];
-    T eb = acc_max<T>(), es = acc_max<T>();
-    int ek = -1;
-    if (n <= RK_CAP) {
-        for (int c0 = 0; c0 < n; c0 += RK_CH) {
-            const int nc = n - c0 < RK_CH ? n - c0 : RK_CH;
-            for (int i = lane; i < nc * ND; i += 64) {
-                const int c = i / ND, b = i - c * ND;
-                cb[c * RK_LDT + b] = L2[(size_t)cand[wave][c0 + c] * ND + b];
+    T eb, es; int ek;
+    rank_tail_wave<T>(ND, K2, n, cand[wave], qs[wave], &cols[wave][0][0], L2, lane, eb, es, ek, stats);
+    if (lane == 0) { obest[q] = (double)eb; osecond[q] = (double)es; oarg[q] = ek < 0 ? -1 : ek + k2_offset; if (stats) atomicAdd(stats + 1, n < RK_CAP ? n : RK_CAP); }
+}
+
+// ---- the same two phases tiled BOTH ways (the form used when there is enough work for it) -----------------------------------------
+// k_match_rank streams the whole database (K2 x 512 B of planes) into every 16-query workgroup, twice: at 4096 x 4096 that is 2 x 512 MB
+// through the L2 -> CU paths and sets its time (phase 1 23 us, phase 2 20 us).  Here a workgroup (8 waves) owns RT_NQB x 16 = 64 queries and
+// ONE slice of the database; every wave keeps the fragments of all 64 queries in registers (4 query blocks x 2 planes x 4 k-steps = 128 VGPRs)
+// and walks its share of the slice's blocks, so one 8 KB database fragment set feeds 4 x 12 = 48 MFMAs instead of 12 and the launch is bound by
+// the matrix pipe, not by operand delivery.  The price is that a query's database is spread over several workgroups:
+//   k_rank_bounds   phase 1 per (query group, slice): the two smallest upper bounds -> pb / ps [slice][query]; zeroes the candidate counters
+//   k_rank_emit     merges the slices' bounds into U2, phase 2 on its slice, candidates appended to per-query lists in global memory
+//   k_rank_tail     one wave per query: exact re-evaluation of the listed candidates (the tail of k_match_rank)
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int RT_NQB = 4, RT_WAVES = 8, RT_Q = 16 * RT_NQB;
+
+struct RtSet { v4i h[4], l[4]; v4f n; };
+
+// phase: 0 = bounds (norms = nU), 1 = emit (norms = nL)
+template <int PHASE>
+__global__ __launch_bounds__(64 * RT_WAVES) void k_rank_tiled(int K1, int K2, int K2p, int nsl, const v4i *__restrict__ Qh, const v4i *__restrict__ Ql,
+                                                                const v4i *__restrict__ Dh, const v4i *__restrict__ Dl, const float *__restrict__ nq,
+                                                                const float *__restrict__ norms, float *__restrict__ pb, float *__restrict__ ps, int K1p,
+                                                                int *__restrict__ gcnt, int *__restrict__ gcand)
+{
+    __shared__ float mb[RT_WAVES][RT_Q], ms[RT_WAVES][RT_Q];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, qi = lane & 15;
+    const int qg = blockIdx.x, sl = blockIdx.y;
+    const int nblk = K2p / 16;
+    const int b0 = (int)((long long)nblk * sl / nsl), b1 = (int)((long long)nblk * (sl + 1) / nsl);      // this slice's 16-column blocks
+    auto load = [&](int blk, RtSet &S) {
+        const v4i *dh = Dh + (size_t)blk * 256 + lane, *dl = Dl + (size_t)blk * 256 + lane;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { S.h[s] = dh[64 * s]; S.l[s] = dl[64 * s]; }
+        S.n = *reinterpret_cast<const v4f *>(norms + blk * 16 + 4 * g);
+    };
+    RtSet A, B;
+    const int first = b0 + wave;
+    if (first < b1) load(first, A);                   // in flight behind the staging of the queries
+    // the 64 queries' fragments (32 KB) cross L2 -> CU once per workgroup and reach the eight waves' registers through LDS
+    __shared__ v4i qst[2][RT_NQB * 256];
+    for (int i = tid; i < RT_NQB * 256; i += 64 * RT_WAVES) {
+        qst[0][i] = Qh[(size_t)qg * RT_NQB * 256 + i]; qst[1][i] = Ql[(size_t)qg * RT_NQB * 256 + i];
+    }
+    __syncthreads();
+    v4i fqh[RT_NQB][4], fql[RT_NQB][4];
+#pragma unroll
+    for (int t = 0; t < RT_NQB; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { fqh[t][s] = qst[0][t * 256 + 64 * s + lane]; fql[t][s] = qst[1][t * 256 + 64 * s + lane]; }
+    float thr[RT_NQB];
+    if (PHASE == 1) {
+        // U2 of a query = second smallest upper bound over all slices; the query's own norm moved across (see k_match_rank)
+#pragma unroll
+        for (int t = 0; t < RT_NQB; ++t) {
+            const int q = qg * RT_Q + 16 * t + qi;
+            float b = INFINITY, s2 = INFINITY;
+            for (int x = 0; x < nsl; ++x) {
+                const float ob = pb[(size_t)x * K1p + q], os = ps[(size_t)x * K1p + q];
+                s2 = fminf(fmaxf(b, ob), fminf(s2, os));
+                b = fminf(b, ob);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane < nc) {
-                const T *bp = cb + lane * RK_LDT;
-                T acc = 0;
-                for (int bin = 0; bin < ND; ++bin) {
-                    const T delta = qrow[bin] - bp[bin];
-                    const T sq = delta * delta;
-                    acc = acc + sq;
-                }
-                merge3(eb, es, ek, acc, acc_max<T>(), cand[wave][c0 + lane]);
-            }
-            __builtin_amdgcn_wave_barrier();
+            thr[t] = s2 + (float)(2.0 * RK_E) * (q < K1 ? nq[q] : 0.f);
         }
-    } else {
-        // more near-ties than the list holds (duplicated descriptors): the wave scans the whole database, 16 bins of 64 columns in flight
-        for (int k0 = 0; k0 < K2; k0 += 64) {
-            const int k2 = k0 + lane;
-            const T *bp = L2 + (size_t)(k2 < K2 ? k2 : 0) * ND;
-            T acc = 0;
-            for (int b0 = 0; b0 < ND; b0 += 16) {
-                T bv[16];
+    } else if (sl == 0 && tid < RT_Q) gcnt[qg * RT_Q + tid] = 0;
+    float best[RT_NQB], second[RT_NQB];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) bv[j] = b0 + j < ND ? bp[b0 + j] : (T)0;
+    for (int t = 0; t < RT_NQB; ++t) best[t] = second[t] = INFINITY;
+    auto work = [&](int blk, const RtSet &S) {
+        // four independent accumulator chains (one per query block), interleaved: a dependent MFMA never issues right behind its producer
+        v4f acc[RT_NQB];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    if (b0 + j < ND) {
-                        const T delta = qrow[b0 + j] - bv[j];
-                        const T sq = delta * delta;
-                        acc = acc + sq;
+        for (int t = 0; t < RT_NQB; ++t) acc[t] = v4f{ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int t = 0; t < RT_NQB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, S.h[s]), __builtin_bit_cast(bf16x8, fqh[t][s]), acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < RT_NQB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, S.h[s]), __builtin_bit_cast(bf16x8, fql[t][s]), acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < RT_NQB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, S.l[s]), __builtin_bit_cast(bf16x8, fqh[t][s]), acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < RT_NQB; ++t) {
+            if (PHASE == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u = fmaf(-2.f, acc[t][e], S.n[e]);
+                    second[t] = __builtin_amdgcn_fmed3f(best[t], u, second[t]);
+                    best[t] = fminf(best[t], u);
+                }
+            } else {
+                float lw[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lw[e] = fmaf(-2.f, acc[t][e], S.n[e]);
+                if (fminf(fminf(lw[0], lw[1]), fminf(lw[2], lw[3])) <= thr[t]) {
+                    const int q = qg * RT_Q + 16 * t + qi;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int idx = blk * 16 + 4 * g + e;
+                        if (lw[e] <= thr[t] && idx < K2 && q < K1) {
+                            const int p = atomicAdd(&gcnt[q], 1);
+                            if (p < RK_CAP) gcand[(size_t)q * RK_CAP + p] = idx;
+                        }
                     }
                 }
             }
-            if (k2 < K2) push3(eb, es, ek, acc, k2);
         }
-        if (lane == 0 && stats) atomicAdd(stats, 1);
+    };
+    if (first < b1) {
+        const int last = first + (b1 - 1 - first) / RT_WAVES * RT_WAVES;
+        auto at = [&](int b) { return b < last ? b : last; };
+        for (int blk = first; blk < b1; blk += 2 * RT_WAVES) {
+            load(at(blk + RT_WAVES), B);
+            work(blk, A);
+            if (blk + RT_WAVES >= b1) break;
+            load(at(blk + 2 * RT_WAVES), A);
+            work(blk + RT_WAVES, B);
+        }
     }
+    if (PHASE == 0) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const T ob = __shfl_xor(eb, o, 64), os = __shfl_xor(es, o, 64);
-        const int ok = __shfl_xor(ek, o, 64);
-        merge3(eb, es, ek, ob, os, ok);
+        for (int t = 0; t < RT_NQB; ++t) {
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float ob = __shfl_xor(best[t], o, 64), os = __shfl_xor(second[t], o, 64);
+                second[t] = fminf(fmaxf(best[t], ob), fminf(second[t], os));
+                best[t] = fminf(best[t], ob);
+            }
+            if (g == 0) { mb[wave][16 * t + lane] = best[t]; ms[wave][16 * t + lane] = second[t]; }
+        }
+        __syncthreads();
+        if (tid < RT_Q) {
+            float b = mb[0][tid], s2 = ms[0][tid];
+#pragma unroll
+            for (int w = 1; w < RT_WAVES; ++w) {
+                const float ob = mb[w][tid], os = ms[w][tid];
+                s2 = fminf(fmaxf(b, ob), fminf(s2, os));
+                b = fminf(b, ob);
+            }
+            pb[(size_t)sl * K1p + qg * RT_Q + tid] = b; ps[(size_t)sl * K1p + qg * RT_Q + tid] = s2;
+        }
     }
+}
+
+// one wave per query: the candidates of k_rank_tiled<1>, re-evaluated as the tail of k_match_rank does
+template <typename T>
+__global__ __launch_bounds__(256) void k_rank_tail(int ND, int K1, int K2, const T *__restrict__ L1, const T *__restrict__ L2, const int *__restrict__ gcnt,
+                                                    const int *__restrict__ gcand, int k2_offset, double *__restrict__ obest, double *__restrict__ osecond,
+                                                    int32_t *__restrict__ oarg, int *__restrict__ stats)
+{
+#pragma clang fp contract(off)
+    constexpr int RK_CH = 32 / sizeof(T), RK_LDT = 128 + 16 / sizeof(T);
+    __shared__ T qs[4][128], cols[4][RK_CH][RK_LDT];
+    __shared__ int cd[4][RK_CAP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x * 4 + wave;
+    if (q >= K1) return;
+    const int n = gcnt[q];
+    static_assert(RK_CAP == 64, "one candidate slot per lane");
+    for (int b = lane; b < ND; b += 64) qs[wave][b] = L1[(size_t)q * ND + b];
+    cd[wave][lane] = gcand[(size_t)q * RK_CAP + lane];          // (the whole list, without waiting for the count: entries >= n are never read)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    T eb, es; int ek;
+    rank_tail_wave<T>(ND, K2, n, cd[wave], qs[wave], &cols[wave][0][0], L2, lane, eb, es, ek, stats);
     if (lane == 0) { obest[q] = (double)eb; osecond[q] = (double)es; oarg[q] = ek < 0 ? -1 : ek + k2_offset; if (stats) atomicAdd(stats + 1, n < RK_CAP ? n : RK_CAP); }
 }
 
@@ -934,7 +1121,8 @@ static int partial_i8(int ND, int K1, const T *L1, int K2, const T *L2, int cent
 // device-resident state of the float-class matcher (k_rank_pack / k_match_rank / the int8 route), reusable across calls
 struct RankMatch {
     int cls = 0, ND = 0, K1 = 0, K2 = 0, K1p = 0, K2p = 0, route = 0;     // route 0: exact kernels (data outside the bounds), 1: int8 MFMA, 2: bf16 rank + re-evaluation
-    DevBuf L1, L2, qh, ql, dh, dl, nq, nqU, nqL, nU, nL, nd, fl;
+    DevBuf L1, L2, qh, ql, dh, dl, nq, nqU, nqL, nU, nL, nd, fl, pb, ps, gcnt, gcand;
+    int nsl = 1;                                                          // database slices of the tiled form (k_rank_tiled)
     I8Match m;                                                            // int8 operands + the outputs (ob, os, oa) of every route
 };
 static int float_form()
@@ -958,6 +1146,16 @@ static int rank_prepare(RankMatch &r, int ND, int K1, const T *L1, int K2, const
     PRE3_TRY(r.nq.alloc(sizeof(float) * r.K1p)); PRE3_TRY(r.nqU.alloc(sizeof(float) * r.K1p)); PRE3_TRY(r.nqL.alloc(sizeof(float) * r.K1p));
     PRE3_TRY(r.nU.alloc(sizeof(float) * r.K2p)); PRE3_TRY(r.nL.alloc(sizeof(float) * r.K2p)); PRE3_TRY(r.nd.alloc(sizeof(float) * r.K2p));
     PRE3_TRY(r.fl.alloc(sizeof(int) * 4));
+    // tiled form: K1p / 64 query groups x nsl database slices ~ one workgroup per CU (and at least 8 blocks of 16 columns per wave-round)
+    {
+        int ncu = 256;
+        hipDeviceProp_t prop; int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+        const int groups = r.K1p / RT_Q, nblk = r.K2p / 16;
+        r.nsl = std::max(1, std::min(std::min(ceil_div(ncu, groups), nblk / RT_WAVES), 64));
+    }
+    PRE3_TRY(r.pb.alloc(sizeof(float) * (size_t)r.nsl * r.K1p)); PRE3_TRY(r.ps.alloc(sizeof(float) * (size_t)r.nsl * r.K1p));
+    PRE3_TRY(r.gcnt.alloc(sizeof(int) * r.K1p)); PRE3_TRY(r.gcand.alloc(sizeof(int) * (size_t)r.K1p * RK_CAP));
     PRE3_TRY(m.A.alloc((size_t)m.K1p * 128)); PRE3_TRY(m.B.alloc((size_t)m.K2p * 128));
     PRE3_TRY(m.na.alloc(sizeof(int) * m.K1p)); PRE3_TRY(m.nb.alloc(sizeof(int) * m.K2p));
     PRE3_TRY(m.ob.alloc(sizeof(double) * K1)); PRE3_TRY(m.os.alloc(sizeof(double) * K1)); PRE3_TRY(m.oa.alloc(sizeof(int32_t) * K1));
@@ -978,6 +1176,18 @@ static int rank_run(RankMatch &r, int k2_offset, hipStream_t st, bool count = fa
 {
     if (r.route == 1) return i8_run(r.m, k2_offset, st);
     PRE3_CHECK(r.route == 2, PRE3_E_STATE, "float-class matcher: the data is outside the ranked path's bounds");
+    const char *fe = getenv("PRE3_MATCH_RANK_FORM");                      // 1 (default): tiled both ways, three launches; 0: one launch, database streamed per 16 queries
+    if (!fe || atoi(fe) != 0) {
+        dim3 g(r.K1p / RT_Q, r.nsl), b(64 * RT_WAVES);
+        hipLaunchKernelGGL((k_rank_tiled<0>), g, b, 0, st, r.K1, r.K2, r.K2p, r.nsl, (const v4i *)r.qh.p, (const v4i *)r.ql.p, (const v4i *)r.dh.p, (const v4i *)r.dl.p,
+                           (const float *)r.nq.p, (const float *)r.nU.p, (float *)r.pb.p, (float *)r.ps.p, r.K1p, (int *)r.gcnt.p, (int *)r.gcand.p);
+        hipLaunchKernelGGL((k_rank_tiled<1>), g, b, 0, st, r.K1, r.K2, r.K2p, r.nsl, (const v4i *)r.qh.p, (const v4i *)r.ql.p, (const v4i *)r.dh.p, (const v4i *)r.dl.p,
+                           (const float *)r.nq.p, (const float *)r.nL.p, (float *)r.pb.p, (float *)r.ps.p, r.K1p, (int *)r.gcnt.p, (int *)r.gcand.p);
+        hipLaunchKernelGGL((k_rank_tail<T>), dim3(ceil_div(r.K1, 4)), dim3(256), 0, st, r.ND, r.K1, r.K2, (const T *)r.L1.p, (const T *)r.L2.p, (const int *)r.gcnt.p,
+                           (const int *)r.gcand.p, k2_offset, (double *)r.m.ob.p, (double *)r.m.os.p, (int32_t *)r.m.oa.p, count ? (int *)r.fl.p + 2 : nullptr);
+        PRE3_HIP(hipGetLastError());
+        return PRE3_OK;
+    }
     hipLaunchKernelGGL((k_match_rank<T>), dim3(r.K1p / RK_Q), dim3(64 * RK_WAVES), 0, st, r.ND, r.K1, r.K2, r.K2p, (const v4i *)r.qh.p, (const v4i *)r.ql.p,
                        (const v4i *)r.dh.p, (const v4i *)r.dl.p, (const float *)r.nq.p, (const float *)r.nU.p, (const float *)r.nL.p, (const T *)r.L1.p,
                        (const T *)r.L2.p, k2_offset, (double *)r.m.ob.p, (double *)r.m.os.p, (int32_t *)r.m.oa.p, count ? (int *)r.fl.p + 2 : nullptr);
