@@ -19,7 +19,7 @@ void set_error(const char *fmt, ...)
 }
 
 // launchers defined in the kernel files
-int launch_predict_impl(pre3_ctx *c, const double u[7], bool with_projection = false);
+int launch_predict_impl(pre3_ctx *c, const double u[7], bool with_projection = false, size_t inbox_n16 = 0, int32_t inbox_seq = 0);
 int launch_inbox_pull(pre3_ctx *c, const void *src_host_mapped, void *dst_dev, size_t n16, int32_t seq);
 int launch_window_gate(pre3_ctx *c, int M, const int32_t *pred_idx_dev, const int32_t *k1_dev, const double *zc_dev, int strict, int32_t *accept_dev);
 int launch_build_rows_impl(pre3_ctx *c, int nsel, const int32_t *sel_dev, int r_pad);
@@ -461,8 +461,10 @@ int pre3_get_landmark_fields(pre3_ctx *c, double *h, int32_t *has_h, double *Hc,
 }
 
 // Fill the pinned inbox and ship it with ONE async copy: [meas | ic | (hyp) | z].  hyp (n_hyp_ints ints) optional.
+// pull == false: the inbox is filled and the context updated, but no pull is launched: the caller's next launch carries it (pre3_step: k_predict);
+// *nbytes_out = what that pull must copy
 static int install_measurements(pre3_ctx *c, int m, const int32_t *meas_idx, const double *z /* 2m, null: z already on device */,
-                                const int32_t *hyp, int n_hyp_ints, bool flags_clear = false)
+                                const int32_t *hyp, int n_hyp_ints, bool flags_clear = false, bool pull = true, size_t *nbytes_out = nullptr)
 {
     PRE3_CHECK(m >= 0 && m <= c->capm, PRE3_E_ARG, "measurements: m=%d exceeds capacity %d", m, c->capm);
     for (int j = 0; j < m; ++j) {
@@ -486,7 +488,8 @@ static int install_measurements(pre3_ctx *c, int m, const int32_t *meas_idx, con
     // The inbox crosses PCIe by a KERNEL that reads the pinned, device-mapped host buffer (14 KB at N=500): a hipMemcpyAsync between
     // kernels is a blit with barrier packets on both sides and opened two ~10 us holes in the stream around a 3 us copy.
     const size_t nbytes = z ? c->off_z + sizeof(double) * 2 * c->N : c->off_hyp + (hyp ? sizeof(int32_t) * n_hyp_ints : 0);
-    PRE3_TRY(launch_inbox_pull(c, c->inbox_host_dev, c->inbox_dev, (nbytes + 15) / 16, ++c->seq_inbox)); c->inbox_pending = true;
+    if (pull) { PRE3_TRY(launch_inbox_pull(c, c->inbox_host_dev, c->inbox_dev, (nbytes + 15) / 16, ++c->seq_inbox)); c->inbox_pending = true; }
+    if (nbytes_out) *nbytes_out = nbytes;
     if (!flags_clear) PRE3_HIP(hipMemsetAsync((unsigned char *)c->inbox_dev + c->off_flags, 0, c->flags_bytes, c->stream));
     c->li_from_host = c->hi_from_host = -1; c->li_kernel = c->hi_kernel = false;
     c->hp_all_valid = false;
@@ -872,21 +875,37 @@ int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, co
     PRE3_CHECK(u != nullptr, PRE3_E_ARG, "pre3_step: null u");
     PRE3_CHECK(c->have_cam, PRE3_E_STATE, "pre3_step: camera not set");
     PRE3_CHECK(c->x_valid[PRE3_X_K_K] && c->p_which == PRE3_X_K_K, PRE3_E_STATE, "pre3_step: needs (x_k_k, p_k_k) on the device");
-    // mono_slam.m:153 + search_IC_matches.m:31-32: prediction, with the projection of every landmark at x_k_km1 riding in the
-    // same launch; then search_IC_matches.m:33-44 (S_i), which also clears the previous frame's inlier flags
-    PRE3_TRY(launch_predict_impl(c, u, true));
-    c->x_valid[PRE3_X_K_KM1] = true; c->p_which = PRE3_X_K_KM1; c->hp_all_valid = false;
-    if (c->N) PRE3_TRY(launch_innovation(c, 0, 0.0, true));
-    c->projected = true; c->innovated = true;
-    if (trace) t1 = now();
     PRE3_CHECK(m == 0 || (meas_idx && z), PRE3_E_ARG, "pre3_step: null measurement pointers");
     PRE3_CHECK(n_draw >= 1 && n_draw <= c->caph && k >= 1 && k <= MAXK && hyp, PRE3_E_ARG, "pre3_step: bad hypothesis table");
-    PRE3_TRY(install_measurements(c, m, meas_idx, z, hyp, n_draw * k, c->N > 0));   // matching_sift_based.m:131-134 outcome (+ the draws); flags cleared by k_project_innovation
+    // matching_sift_based.m:131-134 outcome (+ the draws) into the pinned inbox; it crosses PCIe in one extra block of the prediction's
+    // launch (nothing in that launch reads it), so the copy costs neither a launch nor stream time.  Flags cleared by k_innovation.
+    size_t inbox_bytes = 0;
+    PRE3_TRY(install_measurements(c, m, meas_idx, z, hyp, n_draw * k, c->N > 0, false, &inbox_bytes));
+    // mono_slam.m:153 + search_IC_matches.m:31-32: prediction, with the projection of every landmark at x_k_km1 riding in the
+    // same launch; then search_IC_matches.m:33-44 (S_i), which also clears the previous frame's inlier flags
+    {
+        const int rc_p = launch_predict_impl(c, u, true, (inbox_bytes + 15) / 16, ++c->seq_inbox);
+        c->inbox_pending = rc_p == PRE3_OK;
+        if (rc_p != PRE3_OK) { c->measurements_set = false; return rc_p; }
+    }
+    c->x_valid[PRE3_X_K_KM1] = true; c->p_which = PRE3_X_K_KM1; c->hp_all_valid = false;
+    c->projected = true;
+    // S_i (which also clears last frame's inlier flags) rides in the H*P launch of the RANSAC stage when there is one
+    static const int ride_env = getenv("PRE3_RIDE_INNOV") ? atoi(getenv("PRE3_RIDE_INNOV")) : 1;
+    c->ride_innovation = ride_env && c->N > 0 && m >= k && m > 0;
+    if (c->N && !c->ride_innovation) PRE3_TRY(launch_innovation(c, 0, 0.0, true));
+    c->innovated = true;
+    if (trace) t1 = now();
     int32_t st[8] = { -1, 0, 0, 0, 0, 0, 0, 0 };
     bool ran = false;
     if (m >= k && m > 0) {
         // mono_slam.m:178; the statistics are read after pre3_update_li's poll of the same mailbox
-        PRE3_TRY(pre3_ransac(c, n_draw, k, (const int32_t *)(c->inbox_host + c->off_hyp), threshold, early_exit, nullptr, nullptr, nullptr));
+        const int rc_r = pre3_ransac(c, n_draw, k, (const int32_t *)(c->inbox_host + c->off_hyp), threshold, early_exit, nullptr, nullptr, nullptr);
+        if (c->ride_innovation) {                                   // the H*P launch did not go out (error before it): S_i on its own, flags cleared
+            c->ride_innovation = false;
+            PRE3_TRY(launch_innovation(c, 0, 0.0, true));
+        }
+        PRE3_TRY(rc_r);
         ran = true;
     }
     if (trace) t2 = now();

@@ -42,13 +42,24 @@ __device__ inline void d_process_noise(double *Pn)
 }
 
 // pred_params layout: [0..15] A4 = Qq1, [16..31] Jn, [32..80] Q7 = G Pn G' (7x7)
+// The per-step inbox [meas | ic | hyp | z]: pinned host memory, read over PCIe by the device itself (16 bytes per lane).  ONE workgroup, so
+// that its last act can be to publish `seq` in the pinned mailbox: the host may overwrite the inbox once it reads that number back.
+struct InboxRide { const int4 *src; int4 *dst; int n16; int32_t *mail; int32_t seq; };        // n16 == 0: no pull in this launch
+__device__ __forceinline__ void inbox_pull_block(const InboxRide &ib)
+{
+    for (int i = threadIdx.x; i < ib.n16; i += blockDim.x) ib.dst[i] = ib.src[i];
+    __syncthreads();
+    if (threadIdx.x == 0) { __threadfence_system(); __hip_atomic_store(ib.mail + 10, ib.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+}
+
 // k_predict_x and k_predict_P in ONE launch (a kernel boundary costs ~5 us on this platform, more than either kernel):
 // lane 0 of every block recomputes the quaternion product and its normalisation Jacobian (a few dozen flops) instead of
 // reading them from a previous kernel; block 0 additionally owns x_out[0:13], the process noise and the 7x7 pose block.
 template <typename T>
 __global__ __launch_bounds__(256) void k_predict(const double *__restrict__ x_in, double *x_out, T *__restrict__ P, int n, int ld, U7 u,
-                                                 double *__restrict__ params, int n_pred_blocks, ProjRide pr)
+                                                 double *__restrict__ params, int n_pred_blocks, ProjRide pr, InboxRide ib)
 {
+    if ((int)blockIdx.x >= n_pred_blocks + pr.n_blocks) { inbox_pull_block(ib); return; }               // the step's inbox crosses PCIe beside the prediction
     if ((int)blockIdx.x >= n_pred_blocks) { proj_ride_block(pr, blockIdx.x - n_pred_blocks); return; }   // IC-search projection rides along
     __shared__ double sQq1[16], sJn[16], sQ[49], sG[49], sPn[49], sGP[49];
     __shared__ double corner[49];      // old P[0:7,0:7]
@@ -167,60 +178,6 @@ __global__ void k_project(int N, const int32_t *__restrict__ lm_type, const int3
 // that H_i's non-zeros select.  mode 0: S_i = H P H' + I for predicted landmarks.
 // mode 1 (rescue_hi_inliers.m:35-46): for ic && !li: d2 = nu' inv(H P H') nu < chi2 -> hi flag.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ void innovation_body(int N, const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
-                                                const T *__restrict__ P, int ld, const double *Hc, const double *Hl,
-                                                const int32_t *has_h, int mode, double chi2,
-                                                const double *h, const double *__restrict__ z,
-                                                const int32_t *__restrict__ ic, const int32_t *__restrict__ li, int32_t *__restrict__ hi,
-                                                double *__restrict__ S, int32_t *__restrict__ has_S)
-{
-    // 16 lanes per landmark: lane b < 13 owns column b of the gathered 13x13 block of P (7 pose + 6 landmark
-    // entries; P is symmetric, so the column is read as a row: two contiguous runs), then a 16-lane shuffle sum.
-    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = gt >> 4, b = gt & 15;
-    const bool valid = i < N;
-    const int ii = valid ? i : 0;
-    bool active = valid;
-    if (mode == 0) active = active && has_h[ii];
-    else active = active && (ic[ii] == 1 && li[ii] == 0);
-    const int d = lm_type[ii] == PRE3_INVDEPTH ? 6 : 3;
-    const int off = lm_off[ii];
-    const int nn = 7 + d;
-    double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
-    if (active && b < nn) {
-        const int ib = b < 7 ? b : off + b - 7;
-        const T *prow = P + (size_t)ib * ld;
-        double hp0 = 0, hp1 = 0;
-#pragma unroll
-        for (int a = 0; a < 7; ++a) { double p = (double)prow[a]; hp0 += Hc[14 * ii + a] * p; hp1 += Hc[14 * ii + 7 + a] * p; }
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-            if (a < d) { double p = (double)prow[off + a]; hp0 += Hl[12 * ii + a] * p; hp1 += Hl[12 * ii + 6 + a] * p; }
-        const double h0b = b < 7 ? Hc[14 * ii + b] : Hl[12 * ii + b - 7];
-        const double h1b = b < 7 ? Hc[14 * ii + 7 + b] : Hl[12 * ii + 6 + b - 7];
-        s00 = hp0 * h0b; s01 = hp0 * h1b; s10 = hp1 * h0b; s11 = hp1 * h1b;
-    }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-        s00 += __shfl_xor(s00, o, 16); s01 += __shfl_xor(s01, o, 16);
-        s10 += __shfl_xor(s10, o, 16); s11 += __shfl_xor(s11, o, 16);
-    }
-    if (!valid || b != 0) return;
-    if (mode == 0) {
-        if (!active) { has_S[i] = 0; return; }
-        S[4 * i + 0] = s00 + 1; S[4 * i + 1] = s01; S[4 * i + 2] = s10; S[4 * i + 3] = s11 + 1;
-        has_S[i] = 1;
-    } else {
-        if (!active) return;
-        double det = s00 * s11 - s01 * s10;
-        double i00 = s11 / det, i01 = -s01 / det, i10 = -s10 / det, i11 = s00 / det;
-        double n0 = z[2 * i] - h[2 * i], n1 = z[2 * i + 1] - h[2 * i + 1];
-        double t0 = n0 * i00 + n1 * i10, t1 = n0 * i01 + n1 * i11;
-        double d2 = t0 * n0 + t1 * n1;
-        hi[i] = d2 < chi2 ? 1 : 0;
-    }
-}
 
 // the HI collection (k_collect_hi's work) as the tail of the rescue launch: run by the first wave of the LAST workgroup
 struct HiArgs { int fuse, m, seq; const int32_t *meas; int32_t *hi_meas, *sel_rows, *stats, *mail; unsigned int *done; };
@@ -256,7 +213,7 @@ __global__ __launch_bounds__(256) void k_innovation(int N, const int32_t *__rest
                                                     HiArgs ha)
 {
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_clear; t += gridDim.x * blockDim.x) clear[t] = 0;
-    innovation_body<T>(N, lm_type, lm_off, P, ld, Hc, Hl, has_h, mode, chi2, h, z, ic, li, hi, S, has_S);
+    innovation_body<T>(N, lm_type, lm_off, P, ld, Hc, Hl, has_h, mode, chi2, h, z, ic, li, hi, S, has_S, blockIdx.x * blockDim.x + threadIdx.x);
     hi_tail(ha, ic, li, hi);
 }
 
@@ -277,7 +234,7 @@ __global__ __launch_bounds__(256) void k_project_innovation(int N, const int32_t
     if (threadIdx.x < 16 && (int)(blockIdx.x * 16 + threadIdx.x) < N) project_one(blockIdx.x * 16 + threadIdx.x, lm_type, lm_off, x, cam, clear_first, h, has_h, Hc, Hl);
     __threadfence_block();
     __syncthreads();
-    innovation_body<T>(N, lm_type, lm_off, P, ld, Hc, Hl, has_h, mode, chi2, h, z, ic, li, hi, S, has_S);
+    innovation_body<T>(N, lm_type, lm_off, P, ld, Hc, Hl, has_h, mode, chi2, h, z, ic, li, hi, S, has_S, blockIdx.x * blockDim.x + threadIdx.x);
     hi_tail(ha, ic, li, hi);
 }
 
@@ -701,15 +658,17 @@ ProjRide make_proj_ride(pre3_ctx *c, int which, int clear_first, int slot, int n
 }
 
 // with_projection: the IC-search projection at x_k_km1 (clear_first = 1) rides in the same launch
-int launch_predict_impl(pre3_ctx *c, const double u[7], bool with_projection)
+int launch_predict_impl(pre3_ctx *c, const double u[7], bool with_projection, size_t inbox_n16, int32_t inbox_seq)
 {
     U7 uu; for (int i = 0; i < 7; ++i) uu.v[i] = u[i];
     int blocks = ceil_div(c->n, 256);
     ProjRide pr{};
     if (with_projection && c->N > 0) pr = make_proj_ride(c, PRE3_X_K_KM1, 1, 0, blocks);
+    InboxRide ib{ (const int4 *)c->inbox_host_dev, (int4 *)c->inbox_dev, (int)inbox_n16, c->mail_dev, inbox_seq };     // one more block when inbox_n16 > 0
+    const int nb = blocks + pr.n_blocks + (inbox_n16 ? 1 : 0);
     DISPATCH_T(c,
-        hipLaunchKernelGGL(k_predict<double>, dim3(blocks + pr.n_blocks), dim3(256), 0, c->stream, c->x_kk, c->x_km1, (double *)c->P, c->n, c->ld, uu, c->pred_params, blocks, pr),
-        hipLaunchKernelGGL(k_predict<float>, dim3(blocks + pr.n_blocks), dim3(256), 0, c->stream, c->x_kk, c->x_km1, (float *)c->P, c->n, c->ld, uu, c->pred_params, blocks, pr));
+        hipLaunchKernelGGL(k_predict<double>, dim3(nb), dim3(256), 0, c->stream, c->x_kk, c->x_km1, (double *)c->P, c->n, c->ld, uu, c->pred_params, blocks, pr, ib),
+        hipLaunchKernelGGL(k_predict<float>, dim3(nb), dim3(256), 0, c->stream, c->x_kk, c->x_km1, (float *)c->P, c->n, c->ld, uu, c->pred_params, blocks, pr, ib));
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }
@@ -848,17 +807,10 @@ int launch_update_x(pre3_ctx *c, int which_prior, int r)
 }
 
 
-// The per-step inbox [meas | ic | hyp | z]: pinned host memory, read over PCIe by the device itself (16 bytes per lane, ONE workgroup so
-// that its last act can be to publish `seq` in the pinned mailbox: the host may overwrite the inbox once it reads that number back).
-__global__ __launch_bounds__(1024) void k_inbox_pull(const int4 *__restrict__ src, int4 *__restrict__ dst, size_t n16, int32_t *__restrict__ mail, int32_t seq)
-{
-    for (size_t i = threadIdx.x; i < n16; i += 1024) dst[i] = src[i];
-    __syncthreads();
-    if (threadIdx.x == 0) { __threadfence_system(); __hip_atomic_store(mail + 10, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-}
+__global__ __launch_bounds__(1024) void k_inbox_pull(InboxRide ib) { inbox_pull_block(ib); }
 int launch_inbox_pull(pre3_ctx *c, const void *src_host_mapped, void *dst_dev, size_t n16, int32_t seq)
 {
-    hipLaunchKernelGGL(k_inbox_pull, dim3(1), dim3(1024), 0, c->stream, (const int4 *)src_host_mapped, (int4 *)dst_dev, n16, c->mail_dev, seq);
+    hipLaunchKernelGGL(k_inbox_pull, dim3(1), dim3(1024), 0, c->stream, InboxRide{ (const int4 *)src_host_mapped, (int4 *)dst_dev, (int)n16, c->mail_dev, seq });
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }

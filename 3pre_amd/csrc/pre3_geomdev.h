@@ -192,6 +192,77 @@ __device__ __forceinline__ void proj_ride_block(const ProjRide &pr, int blk)
     if (threadIdx.x < 64 && i < pr.N) project_one(i, pr.lm_type, pr.lm_off, pr.x, pr.cam, pr.clear_first, pr.h, pr.has_h, pr.Hc, pr.Hl);
 }
 
+// ---- S_i = H_i P H_i' (+ I) per landmark (search_IC_matches.m:36; mode 1: the chi2 gate of rescue_hi_inliers.m:35-46).  Shared by k_innovation
+// (pre3_geom.hip) and by the rider blocks of k_ell_HP_build (pre3_update.hip: inside pre3_step the S_i pass has no launch of its own).
+template <typename T>
+__device__ __forceinline__ void innovation_body(int N, const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
+                                                const T *__restrict__ P, int ld, const double *Hc, const double *Hl,
+                                                const int32_t *has_h, int mode, double chi2,
+                                                const double *h, const double *__restrict__ z,
+                                                const int32_t *__restrict__ ic, const int32_t *__restrict__ li, int32_t *__restrict__ hi,
+                                                double *__restrict__ S, int32_t *__restrict__ has_S, const int gt /* global lane: 16 per landmark */)
+{
+    // 16 lanes per landmark: lane b < 13 owns column b of the gathered 13x13 block of P (7 pose + 6 landmark
+    // entries; P is symmetric, so the column is read as a row: two contiguous runs), then a 16-lane shuffle sum.
+    const int i = gt >> 4, b = gt & 15;
+    const bool valid = i < N;
+    const int ii = valid ? i : 0;
+    bool active = valid;
+    if (mode == 0) active = active && has_h[ii];
+    else active = active && (ic[ii] == 1 && li[ii] == 0);
+    const int d = lm_type[ii] == PRE3_INVDEPTH ? 6 : 3;
+    const int off = lm_off[ii];
+    const int nn = 7 + d;
+    double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+    if (active && b < nn) {
+        const int ib = b < 7 ? b : off + b - 7;
+        const T *prow = P + (size_t)ib * ld;
+        double hp0 = 0, hp1 = 0;
+#pragma unroll
+        for (int a = 0; a < 7; ++a) { double p = (double)prow[a]; hp0 += Hc[14 * ii + a] * p; hp1 += Hc[14 * ii + 7 + a] * p; }
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+            if (a < d) { double p = (double)prow[off + a]; hp0 += Hl[12 * ii + a] * p; hp1 += Hl[12 * ii + 6 + a] * p; }
+        const double h0b = b < 7 ? Hc[14 * ii + b] : Hl[12 * ii + b - 7];
+        const double h1b = b < 7 ? Hc[14 * ii + 7 + b] : Hl[12 * ii + 6 + b - 7];
+        s00 = hp0 * h0b; s01 = hp0 * h1b; s10 = hp1 * h0b; s11 = hp1 * h1b;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        s00 += __shfl_xor(s00, o, 16); s01 += __shfl_xor(s01, o, 16);
+        s10 += __shfl_xor(s10, o, 16); s11 += __shfl_xor(s11, o, 16);
+    }
+    if (!valid || b != 0) return;
+    if (mode == 0) {
+        if (!active) { has_S[i] = 0; return; }
+        S[4 * i + 0] = s00 + 1; S[4 * i + 1] = s01; S[4 * i + 2] = s10; S[4 * i + 3] = s11 + 1;
+        has_S[i] = 1;
+    } else {
+        if (!active) return;
+        double det = s00 * s11 - s01 * s10;
+        double i00 = s11 / det, i01 = -s01 / det, i10 = -s10 / det, i11 = s00 / det;
+        double n0 = z[2 * i] - h[2 * i], n1 = z[2 * i + 1] - h[2 * i + 1];
+        double t0 = n0 * i00 + n1 * i10, t1 = n0 * i01 + n1 * i11;
+        double d2 = t0 * n0 + t1 * n1;
+        hi[i] = d2 < chi2 ? 1 : 0;
+    }
+}
+
+struct InnovRide {                       // mode-0 innovation riding in another launch; n_blocks == 0: none
+    int n_blocks, N, ld, n_clear;
+    const int32_t *lm_type, *lm_off, *has_h;
+    const void *P; const double *Hc, *Hl;
+    double *S; int32_t *has_S, *clear;
+};
+template <typename T>
+__device__ __forceinline__ void innov_ride_block(const InnovRide &ir, int blk)
+{
+    const int gt = blk * blockDim.x + threadIdx.x;
+    for (int t = gt; t < ir.n_clear; t += ir.n_blocks * blockDim.x) ir.clear[t] = 0;
+    innovation_body<T>(ir.N, ir.lm_type, ir.lm_off, static_cast<const T *>(ir.P), ir.ld, ir.Hc, ir.Hl, ir.has_h, 0, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       ir.S, ir.has_S, gt);
+}
+
 ProjRide make_proj_ride(pre3_ctx *c, int which, int clear_first, int slot, int n_producers);   // pre3_geom.hip
 
 }  // namespace pre3

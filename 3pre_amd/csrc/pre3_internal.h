@@ -128,6 +128,7 @@ struct pre3_ctx {
     // per-step inbox: [meas | ic | hyp | z] contiguous on the device, mirrored in pinned host memory -> ONE H2D copy
     void *inbox_dev = nullptr; unsigned char *inbox_host = nullptr; void *inbox_host_dev = nullptr;   // pinned + device-mapped: the device address of inbox_host
     size_t inbox_bytes = 0, off_meas = 0, off_ic = 0, off_hyp = 0, off_z = 0, off_flags = 0, flags_bytes = 0;
+    bool ride_innovation = false;                 // pre3_step: the S_i pass goes out with the next k_ell_HP_build launch instead of its own
     int32_t seq_inbox = 0;                        // sequence number of the last inbox pull (published by the kernel in mailbox word 10)
     bool inbox_pending = false;
     // map management (allocated on first use)

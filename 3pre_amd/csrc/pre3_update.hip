@@ -60,8 +60,12 @@ __global__ __launch_bounds__(256) void k_ell_HP_build(int m, int r_pad, const in
                                                       const int32_t *__restrict__ lm_off, const double *__restrict__ Hc,
                                                       const double *__restrict__ Hl, const double *__restrict__ z, const double *__restrict__ h,
                                                       int32_t *__restrict__ row_col, T *__restrict__ row_val, double *__restrict__ row_nu,
-                                                      const T *__restrict__ P, int ld, T *__restrict__ dst, int ldw, const int32_t *__restrict__ need = nullptr, int need_tag = 0)
+                                                      const T *__restrict__ P, int ld, T *__restrict__ dst, int ldw, const int32_t *__restrict__ need, int need_tag,
+                                                      int ny_build, InnovRide ir)
 {
+    // rows of blocks beyond the build's own: the S_i pass of search_IC_matches.m:33-44 rides here (pre3_step; it only needs what the
+    // prediction's launch left behind, like this kernel)
+    if ((int)blockIdx.y >= ny_build) { innov_ride_block<T>(ir, ((int)blockIdx.y - ny_build) * gridDim.x + blockIdx.x); return; }
     // need != nullptr (a rank's slice of a sharded RANSAC round): only the measurements that slice's hypotheses draw (need[s] == tag of
     // this round: no clearing between rounds) are multiplied out
     if (need != nullptr && (int)blockIdx.y < m && need[blockIdx.y] != need_tag) return;
@@ -1712,13 +1716,21 @@ int launch_ell_HP(pre3_ctx *c, int r, void *dst, bool with_nu)
 int launch_ell_HP_build(pre3_ctx *c, void *dst, const int32_t *need, int need_tag)
 {
     const int r_pad = round_up(2 * c->m, NB);
-    dim3 g(ceil_div(c->ldw / 4, 256), r_pad / 2), b(256);
+    const int gx = ceil_div(c->ldw / 4, 256), ny = r_pad / 2;
+    InnovRide ir{};
+    if (c->ride_innovation && c->N > 0) {            // pre3_step: S_i of every predicted landmark (+ the clearing of last frame's inlier flags) in this launch
+        const int nb = ceil_div(c->N * 16, 256), rows = ceil_div(nb, gx);
+        ir = InnovRide{ rows * gx, c->N, c->ld, (int)(c->flags_bytes / sizeof(int32_t)), c->lm.type, c->lm.off, c->lm.has_h, c->P, c->lm.Hc, c->lm.Hl,
+                        c->lm.S, c->lm.has_S, (int32_t *)((unsigned char *)c->inbox_dev + c->off_flags) };
+    }
+    dim3 g(gx, ny + (ir.n_blocks ? ir.n_blocks / gx : 0)), b(256);
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_ell_HP_build<double>, g, b, 0, c->stream, c->m, r_pad, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl, c->lm.z, c->lm.h,
-                           c->row_col, (double *)c->row_val, c->row_nu, (const double *)c->P, c->ld, (double *)dst, c->ldw, need, need_tag),
+                           c->row_col, (double *)c->row_val, c->row_nu, (const double *)c->P, c->ld, (double *)dst, c->ldw, need, need_tag, ny, ir),
         hipLaunchKernelGGL(k_ell_HP_build<float>, g, b, 0, c->stream, c->m, r_pad, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl, c->lm.z, c->lm.h,
-                           c->row_col, (float *)c->row_val, c->row_nu, (const float *)c->P, c->ld, (float *)dst, c->ldw, need, need_tag));
+                           c->row_col, (float *)c->row_val, c->row_nu, (const float *)c->P, c->ld, (float *)dst, c->ldw, need, need_tag, ny, ir));
     PRE3_HIP(hipGetLastError());
+    if (ir.n_blocks) { c->ride_innovation = false; c->innovated = true; }
     return PRE3_OK;
 }
 
