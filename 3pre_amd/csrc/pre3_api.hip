@@ -758,8 +758,16 @@ int pre3_ransac(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, double thres
     PRE3_TRY(check_ctx(c));
     PRE3_TRY(ransac_prepare(c, n_draw, k, hyp));
     int words = ceil_div(c->m, 32);
-    // one launch: every hypothesis scored, the last workgroup to finish replays the reference's loop and picks the winner
-    PRE3_TRY(launch_ransac_score_impl(c, k, threshold, 0, n_draw, round_up(2 * c->m, NB), c->support, c->masks, words, n_draw, early_exit));
+    // Scoring, then the selection stage (the reference's loop replayed on the supports) as a launch of its own.  The selection can also ride
+    // in the scoring launch's last workgroup (PRE3_SELECT_FUSE=1, round 1's form), but measured at N=500 / 200 hypotheses that launch then
+    // takes 21.2 us against 10.0 + 6.7 us for the two (tools/score_split.py): every workgroup pays a device-scope release (an L2 write-back)
+    // and a ticket before it may finish, and the last one starts the selection behind an L2 invalidate.
+    static const int fuse_env = getenv("PRE3_SELECT_FUSE") ? atoi(getenv("PRE3_SELECT_FUSE")) : 0;
+    if (fuse_env) PRE3_TRY(launch_ransac_score_impl(c, k, threshold, 0, n_draw, round_up(2 * c->m, NB), c->support, c->masks, words, n_draw, early_exit));
+    else {
+        PRE3_TRY(launch_ransac_score_impl(c, k, threshold, 0, n_draw, round_up(2 * c->m, NB), c->support, c->masks, words, 0, 0));
+        PRE3_TRY(launch_ransac_select_impl(c, n_draw, k, early_exit, c->support, c->masks, words));
+    }
     return ransac_results(c, n_draw, support, li_mask, stats);
 }
 

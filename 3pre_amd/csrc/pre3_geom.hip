@@ -325,16 +325,57 @@ __global__ __launch_bounds__(512) void k_ransac_score(int hyp_begin, const int32
     constexpr int R = 2 * K;                // compile-time so that every small array stays in registers
     extern __shared__ double s_res[];       // [m] residuals, then mask words
     __shared__ double s_w[R];
-    __shared__ int s_rows[R];
     __shared__ double s_red[8];
     __shared__ int s_cnt[8];
     const int hidx = hyp_begin + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid < 64) {
-        // wave 0: lane (a, b) gathers one entry of the augmented system [S_h | nu_h]; lane 0 then eliminates
-        int rows[R];
+    // Everything that does not depend on the solution of the hypothesis' 2k x 2k system is requested BEFORE the barrier behind that
+    // solve: the rows of H*P the hypothesis draws (pose columns: uniform; this lane's landmark columns), the landmark's state and pixel.
+    // Three dependent load levels (meas -> type / off -> H*P) used to start only after the solve; now they fly beside it.
+    int rows[R];
 #pragma unroll
-        for (int s = 0; s < K; ++s) { int j = hyp[hidx * K + s]; rows[2 * s] = 2 * j; rows[2 * s + 1] = 2 * j + 1; }
+    for (int s = 0; s < K; ++s) { const int j = hyp[hidx * K + s]; rows[2 * s] = 2 * j; rows[2 * s + 1] = 2 * j + 1; }
+    const T *hp[R];
+#pragma unroll
+    for (int b = 0; b < R; ++b) hp[b] = HP + (size_t)rows[b] * ldw;
+    constexpr bool PRE_POSE = R * sizeof(T) <= 48;                // (fp64 with k = 4 would spill: its pose columns are read after the barrier)
+    T hpc[R][7];                                                   // pose columns of the drawn rows (the same for every lane)
+    double xp[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+        xp[c] = x[c];
+        if (PRE_POSE) {
+#pragma unroll
+            for (int b = 0; b < R; ++b) hpc[b][c] = hp[b][c];
+        }
+    }
+    const bool have0 = PRE_POSE && tid < m;                        // this lane's first measurement (all of them when m <= 512)
+    int i0 = 0, type0 = PRE3_INVDEPTH;
+    T hpl[R][6];
+    double xl[6], z0 = 0, z1 = 0;
+    if (have0) {
+        i0 = meas[tid];
+        type0 = lm_type[i0];
+        const int off = lm_off[i0];
+        // six consecutive columns per row as ONE access each (element-aligned only: off = 13 + 6 i), instead of six strided dword loads:
+        // a wave's 36 + 6 load instructions become 6 + 1 wide ones and the texture path sees a third of the requests.  A Cartesian
+        // landmark's last three columns belong to its neighbour (or to the padding of the row: ldw >= n + 64) and are zeroed after the load.
+        struct __attribute__((packed, aligned(sizeof(T)))) Row6 { T v[6]; };
+        struct __attribute__((packed, aligned(8))) X6 { double v[6]; };
+        const X6 xv = *reinterpret_cast<const X6 *>(x + off);
+#pragma unroll
+        for (int b = 0; b < R; ++b) {
+            const Row6 rv = *reinterpret_cast<const Row6 *>(hp[b] + off);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) hpl[b][c] = (c < 3 || type0 == PRE3_INVDEPTH) ? rv.v[c] : (T)0;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) xl[c] = (c < 3 || type0 == PRE3_INVDEPTH) ? xv.v[c] : 0.0;
+        z0 = z[2 * i0]; z1 = z[2 * i0 + 1];
+    }
+    const int solver = (int)(blockDim.x >> 6) - 1;                 // the last wave: it has the fewest (at m <= 448: no) measurements of its own
+    if (wv == solver) {
+        // lane (a, b) gathers one entry of the augmented system [S_h | nu_h]; lane 0 then eliminates
         double A[R][R + 1];
 #pragma unroll
         for (int a = 0; a < R; ++a) {
@@ -345,7 +386,7 @@ __global__ __launch_bounds__(512) void k_ransac_score(int hyp_begin, const int32
             }
             A[a][R] = row_nu[rows[a]];
         }
-        if (tid == 0) {
+        if (lane == 0) {
             // Gaussian elimination with partial pivoting (MATLAB's inv(S)*nu up to rounding), fully unrolled
 #pragma unroll
             for (int c = 0; c < R; ++c) {
@@ -375,37 +416,37 @@ __global__ __launch_bounds__(512) void k_ransac_score(int hyp_begin, const int32
                 w[a] = s / A[a][a];
             }
 #pragma unroll
-            for (int a = 0; a < R; ++a) { s_w[a] = w[a]; s_rows[a] = rows[a]; }
+            for (int a = 0; a < R; ++a) s_w[a] = w[a];
         }
     }
     __syncthreads();
     double w[R];
-    const T *hp[R];
 #pragma unroll
-    for (int b = 0; b < R; ++b) { w[b] = s_w[b]; hp[b] = HP + (size_t)s_rows[b] * ldw; }
-    // pose part of x_i (every lane redundantly: 7 x 2k broadcast loads)
+    for (int b = 0; b < R; ++b) w[b] = s_w[b];
+    // pose part of x_i (every lane redundantly)
     double xc[7];
 #pragma unroll
     for (int c = 0; c < 7; ++c) {
         double s = 0;
 #pragma unroll
-        for (int b = 0; b < R; ++b) s += w[b] * (double)hp[b][c];
-        xc[c] = x[c] + s;
+        for (int b = 0; b < R; ++b) s += w[b] * (double)(PRE_POSE ? hpc[b][c] : hp[b][c]);
+        xc[c] = xp[c] + s;
     }
     double rot[9];
     d_q2r(xc + 3, rot);                   // un-normalised quaternion (quirk Q4)
     double lmin = INFINITY;
     for (int j = tid; j < m; j += blockDim.x) {
-        const int i = meas[j];
-        const int type = lm_type[i], off = lm_off[i];
+        const bool pre = PRE_POSE && j == tid;                     // the first measurement of the lane came with the prefetch
+        const int i = pre ? i0 : meas[j];
+        const int type = pre ? type0 : lm_type[i], off = pre ? 0 : lm_off[i];
         double y[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             double s = 0;
             if (c < 3 || type == PRE3_INVDEPTH) {
 #pragma unroll
-                for (int b = 0; b < R; ++b) s += w[b] * (double)hp[b][off + c];
-                s += x[off + c];
+                for (int b = 0; b < R; ++b) s += w[b] * (double)(pre ? hpl[b][c] : hp[b][off + c]);
+                s += pre ? xl[c] : x[off + c];
             }
             y[c] = s;
         }
@@ -415,7 +456,7 @@ __global__ __launch_bounds__(512) void k_ransac_score(int hyp_begin, const int32
         for (int c = 0; c < 3; ++c) hc[c] = rot[0 * 3 + c] * v[0] + rot[1 * 3 + c] * v[1] + rot[2 * 3 + c] * v[2];
         double uvd[2];
         d_pinhole_distort(hc, cam, uvd);
-        const double n0 = z[2 * i] - uvd[0], n1 = z[2 * i + 1] - uvd[1];
+        const double n0 = (pre ? z0 : z[2 * i]) - uvd[0], n1 = (pre ? z1 : z[2 * i + 1]) - uvd[1];
         const double res = sqrt(n0 * n0 + n1 * n1);
         s_res[j] = res;
         if (type == PRE3_INVDEPTH) lmin = fmin(lmin, res);
@@ -605,6 +646,23 @@ __device__ __forceinline__ void collect_hi_body(int m, const int32_t *__restrict
 }
 
 
+// the HI collection as a launch of its own (one wave), behind the rescue gate's launch
+__global__ __launch_bounds__(64) void k_collect_hi(int m, const int32_t *__restrict__ meas, const int32_t *__restrict__ lm_ic, const int32_t *__restrict__ lm_li,
+                                                   const int32_t *lm_hi, int32_t *__restrict__ hi_meas, int32_t *__restrict__ sel_rows,
+                                                   int32_t *__restrict__ stats, int32_t *mail, int seq)
+{
+    collect_hi_body(m, meas, lm_ic, lm_li, lm_hi, hi_meas, sel_rows, stats, mail, seq);
+}
+// The collection can ride in the gate's last workgroup (PRE3_HI_FUSE=1, round 1's form) or follow as its own launch (default): like the
+// RANSAC selection (pre3_api.hip, pre3_ransac), the in-launch form makes every workgroup pay a device-scope release and a ticket.
+static bool hi_fuse() { static const int e = getenv("PRE3_HI_FUSE") ? atoi(getenv("PRE3_HI_FUSE")) : 0; return e != 0; }
+static int launch_collect_hi(pre3_ctx *c, const HiArgs &ha)
+{
+    hipLaunchKernelGGL(k_collect_hi, dim3(1), dim3(64), 0, c->stream, ha.m, ha.meas, c->lm.ic, c->lm.li, c->lm.hi, ha.hi_meas, ha.sel_rows, ha.stats, ha.mail, ha.seq);
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
 // x_out = x_prior + W' y  (update.m:36), then Jn at the un-normalised quaternion (update.m:42) -> params,
 // then normalise (update.m:48).  W: r_pad x ldw, y = column `ld` of W.
 template <typename T>
@@ -700,7 +758,7 @@ int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode,
     int32_t *clr = (int32_t *)((unsigned char *)c->inbox_dev + c->off_flags);
     const int n_clr = mode == 0 ? (int)(c->flags_bytes / sizeof(int32_t)) : 0;
     HiArgs ha{};
-    if (mode == 1) ha = HiArgs{ 1, c->m, ++c->seq_collect, c->meas, c->hi_meas, c->sel_rows, c->stats, c->mail_dev, c->chol_arrive + 2 };
+    if (mode == 1) ha = HiArgs{ hi_fuse() ? 1 : 0, c->m, ++c->seq_collect, c->meas, c->hi_meas, c->sel_rows, c->stats, c->mail_dev, c->chol_arrive + 2 };
     dim3 g(ceil_div(c->N * 16, 256)), b(256);
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_project_innovation<double>, g, b, 0, c->stream, c->N, c->lm.type, c->lm.off, x, to_camd(c->cam), clear_first,
@@ -710,6 +768,7 @@ int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode,
                            (const float *)c->P, c->ld, c->lm.Hc, c->lm.Hl, c->lm.has_h, mode, chi2, c->lm.h, c->lm.z, c->lm.ic, c->lm.li,
                            c->lm.hi, c->lm.S, c->lm.has_S, clr, n_clr, ha));
     PRE3_HIP(hipGetLastError());
+    if (mode == 1 && !ha.fuse) PRE3_TRY(launch_collect_hi(c, ha));
     return PRE3_OK;
 }
 
@@ -718,7 +777,7 @@ int launch_innovation(pre3_ctx *c, int mode, double chi2, bool clear_flags)
     int32_t *clr = (int32_t *)((unsigned char *)c->inbox_dev + c->off_flags);
     const int n_clr = clear_flags ? (int)(c->flags_bytes / sizeof(int32_t)) : 0;
     HiArgs ha{};
-    if (mode == 1) ha = HiArgs{ 1, c->m, ++c->seq_collect, c->meas, c->hi_meas, c->sel_rows, c->stats, c->mail_dev, c->chol_arrive + 2 };
+    if (mode == 1) ha = HiArgs{ hi_fuse() ? 1 : 0, c->m, ++c->seq_collect, c->meas, c->hi_meas, c->sel_rows, c->stats, c->mail_dev, c->chol_arrive + 2 };
     dim3 g(ceil_div(c->N * 16, 256)), b(256);
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_innovation<double>, g, b, 0, c->stream, c->N, c->lm.type, c->lm.off, (const double *)c->P, c->ld, c->lm.Hc,
@@ -726,6 +785,7 @@ int launch_innovation(pre3_ctx *c, int mode, double chi2, bool clear_flags)
         hipLaunchKernelGGL(k_innovation<float>, g, b, 0, c->stream, c->N, c->lm.type, c->lm.off, (const float *)c->P, c->ld, c->lm.Hc,
                            c->lm.Hl, c->lm.has_h, mode, chi2, c->lm.h, c->lm.z, c->lm.ic, c->lm.li, c->lm.hi, c->lm.S, c->lm.has_S, clr, n_clr, ha));
     PRE3_HIP(hipGetLastError());
+    if (mode == 1 && !ha.fuse) PRE3_TRY(launch_collect_hi(c, ha));
     return PRE3_OK;
 }
 
