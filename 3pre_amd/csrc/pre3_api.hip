@@ -892,9 +892,11 @@ int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, co
     // mono_slam.m:153 + search_IC_matches.m:31-32: prediction, with the projection of every landmark at x_k_km1 riding in the
     // same launch; then search_IC_matches.m:33-44 (S_i), which also clears the previous frame's inlier flags
     {
-        const int rc_p = launch_predict_impl(c, u, true, (inbox_bytes + 15) / 16, ++c->seq_inbox);
+        static const int ride_proj = getenv("PRE3_RIDE_PROJ") ? atoi(getenv("PRE3_RIDE_PROJ")) : 1;      // 0: the projection as its own launch (A/B)
+        const int rc_p = launch_predict_impl(c, u, ride_proj != 0, (inbox_bytes + 15) / 16, ++c->seq_inbox);
         c->inbox_pending = rc_p == PRE3_OK;
         if (rc_p != PRE3_OK) { c->measurements_set = false; return rc_p; }
+        if (!ride_proj && c->N) PRE3_TRY(launch_project(c, PRE3_X_K_KM1, 1));
     }
     c->x_valid[PRE3_X_K_KM1] = true; c->p_which = PRE3_X_K_KM1; c->hp_all_valid = false;
     c->projected = true;
