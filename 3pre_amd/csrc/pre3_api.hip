@@ -35,7 +35,7 @@ int match_bench_info(void *h, int32_t info[3]);
 int match_bench_run(void *h, int reps, double *ms_per);
 int match_bench_fetch(void *h, double *best, double *second, int32_t *arg);
 void match_bench_destroy(void *h);
-void *match_shard_create(int device, int ND, int K1, const uint8_t *L1, int K2, const uint8_t *L2, int k2_offset);
+void *match_shard_create(int device, int cls, int ND, int K1, const void *L1, int K2, const void *L2, int k2_offset);
 int match_shard_run(void *h, void **partial_dev, int *n_doubles);
 int match_shard_merge(void *h, int G, const void *gathered_dev, double thresh, double *pairs_out, double *score_out, int *M_out);
 void match_shard_destroy(void *h);
@@ -1194,15 +1194,19 @@ int pre3_bench_downdate(pre3_ctx *c, int r, int reps, double *ms_per_launch_out)
 }
 
 // ---- device-resident database shard of the sharded matcher (uint8 class; DESIGN.md "multi-GPU", C2)
-int pre3_match_shard_create(pre3_match_shard **out, int device, int ND, int K1, const uint8_t *L1, int K2_local, const uint8_t *L2_local, int k2_offset)
+int pre3_match_shard_create_cls(pre3_match_shard **out, int device, int cls, int ND, int K1, const void *L1, int K2_local, const void *L2_local, int k2_offset)
 {
     PRE3_CHECK(out != nullptr, PRE3_E_ARG, "pre3_match_shard_create: null output");
     int nd = 0;
     if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) { set_error("no HIP device available (libpre3 has no CPU fallback)"); return PRE3_E_NODEVICE; }
-    void *h = match_shard_create(device, ND, K1, L1, K2_local, L2_local, k2_offset);
+    void *h = match_shard_create(device, cls, ND, K1, L1, K2_local, L2_local, k2_offset);
     if (!h) return PRE3_E_ARG;
     *out = (pre3_match_shard *)h;
     return PRE3_OK;
+}
+int pre3_match_shard_create(pre3_match_shard **out, int device, int ND, int K1, const uint8_t *L1, int K2_local, const uint8_t *L2_local, int k2_offset)
+{
+    return pre3_match_shard_create_cls(out, device, 2, ND, K1, L1, K2_local, L2_local, k2_offset);
 }
 int pre3_match_shard_run(pre3_match_shard *s, void **partial_dev, int *n_doubles) { return s ? match_shard_run(s, partial_dev, n_doubles) : PRE3_E_ARG; }
 int pre3_match_shard_merge(pre3_match_shard *s, int G, const void *gathered_dev, double thresh, double *pairs_out, double *score_out, int *M_out)

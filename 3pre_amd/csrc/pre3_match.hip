@@ -1377,7 +1377,9 @@ int knn_run(int device, int D, int N, const double *data, int M, const double *q
 // caller on DEVICE memory: RCCL), and the merge + Lowe's test + ordered compaction on the device.  Only the final pair list crosses PCIe.
 // ------------------------------------------------------------------------------------------------
 struct MatchShard {
-    I8Match m; int device = 0, k2_offset = 0;
+    I8Match m; RankMatch r; int cls = 2;    // cls 2: uint8 operands in m; 0 / 1: double / float descriptors in r (its outputs are r.m.ob / os / oa)
+    int device = 0, k2_offset = 0;
+    I8Match &out() { return cls == 2 ? m : r.m; }
     DevBuf part;            // double [3][K1]: best | second | arg (as double) -- the all-gather payload
     DevBuf res;             // double [1 + 3 K1]: count | pairs (2 K1) | scores (K1)
 };
@@ -1409,7 +1411,7 @@ __global__ __launch_bounds__(1024) void k_shard_merge(int G, int K1, const doubl
                 if (ob < B || (ob == B && oa < K)) { S2 = os < B ? os : B; B = ob; K = oa; }
                 else { S2 = ob < S2 ? ob : S2; }
             }
-            if (K >= 0) ok = thresh * (float)(int)B <= (float)(int)S2;
+            if (K >= 0) ok = thresh * (float)B <= (float)S2;           // siftmatch.c:122 (integer classes: the doubles hold the int distances exactly)
         }
         const unsigned long long bal = __ballot(ok);
         if (lane == 0) s_cnt[wv] = __popcll(bal);
@@ -1428,28 +1430,40 @@ __global__ __launch_bounds__(1024) void k_shard_merge(int G, int K1, const doubl
     if (tid == 0) res[0] = (double)s_base;
 }
 
-void *match_shard_create(int device, int ND, int K1, const uint8_t *L1, int K2, const uint8_t *L2, int k2_offset)
+void *match_shard_create(int device, int cls, int ND, int K1, const void *L1, int K2, const void *L2, int k2_offset)
 {
-    if (ND <= 0 || K1 <= 0 || K2 < 0 || !L1 || (K2 && !L2)) { set_error("match shard: bad arguments"); return nullptr; }
+    if (ND <= 0 || K1 <= 0 || K2 < 0 || !L1 || (K2 && !L2) || cls < 0 || cls > 2) { set_error("match shard: bad arguments"); return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { set_error("no HIP device %d", device); return nullptr; }
     MatchShard *sh = new MatchShard();
-    sh->device = device; sh->k2_offset = k2_offset;
-    if (i8_prepare(sh->m, ND, K1, L1, K2, L2, 128) != PRE3_OK || sh->part.alloc(sizeof(double) * 3 * (size_t)K1) != PRE3_OK ||
-        sh->res.alloc(sizeof(double) * (1 + 3 * (size_t)K1)) != PRE3_OK) { delete sh; return nullptr; }
+    sh->device = device; sh->k2_offset = k2_offset; sh->cls = cls;
+    int rc = PRE3_OK;
+    if (cls == 2) rc = i8_prepare(sh->m, ND, K1, (const uint8_t *)L1, K2, (const uint8_t *)L2, 128);
+    else {
+        // double / float descriptors (what matching_sift_based.m:104-118 passes): the matrix-core routes of the float classes, resident
+        const bool ok = K2 > 0 && (cls == 0 ? rank_applies<double>(ND, K1, K2) : rank_applies<float>(ND, K1, K2));
+        if (!ok) { set_error("match shard: this shape is not on a matrix-core path for class %d (ND <= 128, K1 * K2_local >= 65536): use the host-array form", cls); rc = PRE3_E_ARG; }
+        else rc = cls == 0 ? rank_prepare<double>(sh->r, ND, K1, (const double *)L1, K2, (const double *)L2) : rank_prepare<float>(sh->r, ND, K1, (const float *)L1, K2, (const float *)L2);
+        if (rc == PRE3_OK && sh->r.route == 0) { set_error("match shard: descriptors outside the ranked path's bounds (NaN / Inf / magnitude): use the host-array form"); rc = PRE3_E_ARG; }
+    }
+    if (rc != PRE3_OK || sh->part.alloc(sizeof(double) * 3 * (size_t)K1) != PRE3_OK || sh->res.alloc(sizeof(double) * (1 + 3 * (size_t)K1)) != PRE3_OK) { delete sh; return nullptr; }
     return sh;
 }
 int match_shard_run(void *h, void **partial_dev, int *n_doubles)
 {
     MatchShard *sh = (MatchShard *)h;
     PRE3_HIP(hipSetDevice(sh->device));
-    if (sh->m.K2 > 0) PRE3_TRY(i8_run(sh->m, sh->k2_offset, 0));
-    else { PRE3_HIP(hipMemsetAsync(sh->m.oa.p, 0xff, sizeof(int32_t) * sh->m.K1, 0)); }                      // empty slice: arg = -1 everywhere
-    hipLaunchKernelGGL(k_shard_pack, dim3(ceil_div(sh->m.K1, 256)), dim3(256), 0, 0, sh->m.K1, (const double *)sh->m.ob.p, (const double *)sh->m.os.p,
-                       (const int32_t *)sh->m.oa.p, (double *)sh->part.p);
+    I8Match &o = sh->out();
+    if (o.K2 > 0) {
+        if (sh->cls == 2) PRE3_TRY(i8_run(sh->m, sh->k2_offset, 0));
+        else if (sh->cls == 0) PRE3_TRY(rank_run<double>(sh->r, sh->k2_offset, 0));
+        else PRE3_TRY(rank_run<float>(sh->r, sh->k2_offset, 0));
+    } else { PRE3_HIP(hipMemsetAsync(o.oa.p, 0xff, sizeof(int32_t) * o.K1, 0)); }                                   // empty slice: arg = -1 everywhere
+    hipLaunchKernelGGL(k_shard_pack, dim3(ceil_div(o.K1, 256)), dim3(256), 0, 0, o.K1, (const double *)o.ob.p, (const double *)o.os.p,
+                       (const int32_t *)o.oa.p, (double *)sh->part.p);
     PRE3_HIP(hipGetLastError());
     PRE3_HIP(hipStreamSynchronize(0));              // the caller's collective runs on another stream
     if (partial_dev) *partial_dev = sh->part.p;
-    if (n_doubles) *n_doubles = 3 * sh->m.K1;
+    if (n_doubles) *n_doubles = 3 * o.K1;
     return PRE3_OK;
 }
 int match_shard_merge(void *h, int G, const void *gathered_dev, double thresh, double *pairs_out, double *score_out, int *M_out)
@@ -1457,7 +1471,7 @@ int match_shard_merge(void *h, int G, const void *gathered_dev, double thresh, d
     MatchShard *sh = (MatchShard *)h;
     PRE3_CHECK(G >= 1 && gathered_dev && pairs_out && M_out, PRE3_E_ARG, "match shard merge: bad arguments");
     PRE3_HIP(hipSetDevice(sh->device));
-    const int K1 = sh->m.K1;
+    const int K1 = sh->out().K1;
     hipLaunchKernelGGL(k_shard_merge, dim3(1), dim3(1024), 0, 0, G, K1, (const double *)gathered_dev, (float)thresh, (double *)sh->res.p);
     PRE3_HIP(hipGetLastError());
     double cnt = 0;

@@ -91,19 +91,20 @@ def kNearestNeighbors(dataMatrix, queryMatrix, k, device=0):
 
 
 class MatchShard:
-    """Device-resident database shard of the sharded matcher (pre3_match_shard_*): uint8 descriptors, L1 (128 x K1) replicated, L2_local
+    """Device-resident database shard of the sharded matcher (pre3_match_shard_*): uint8 / double / single descriptors, L1 (128 x K1) replicated, L2_local
     (128 x K2_local) = this rank's columns [k2_offset, ...) of the database.  run() leaves the per-query partials on the device and returns
     (device pointer, number of doubles) for the caller's all-gather; merge() takes the DEVICE address of the gathered double[G][3][K1]."""
 
     def __init__(self, L1, L2_local, k2_offset, device=0):
         L1, L2 = np.asarray(L1), np.asarray(L2_local)
-        if L1.dtype != np.uint8 or L2.dtype != np.uint8:
-            raise Pre3Error(-1, "MatchShard: uint8 descriptors (the class of BASELINE.json configs[3])")
+        cls = {np.dtype(np.float64): 0, np.dtype(np.float32): 1, np.dtype(np.uint8): 2}.get(L1.dtype)
+        if cls is None or L2.dtype != L1.dtype:
+            raise Pre3Error(-1, "MatchShard: uint8 (BASELINE.json configs[3]), double (what matching_sift_based.m passes) or single descriptors, both of one class")
         a, b = np.asfortranarray(L1), np.asfortranarray(L2)          # one descriptor per column, contiguous (MATLAB's layout)
         self.K1, self.ND = int(L1.shape[1]), int(L1.shape[0])
         self._h = C.c_void_p()
-        check(lib.pre3_match_shard_create(C.byref(self._h), int(device), self.ND, self.K1, a.ctypes.data_as(C.c_void_p), int(L2.shape[1]),
-                                     b.ctypes.data_as(C.c_void_p) if L2.shape[1] else None, int(k2_offset)))
+        check(lib.pre3_match_shard_create_cls(C.byref(self._h), int(device), cls, self.ND, self.K1, a.ctypes.data_as(C.c_void_p), int(L2.shape[1]),
+                                         b.ctypes.data_as(C.c_void_p) if L2.shape[1] else None, int(k2_offset)))
 
     def run(self):
         p, n = C.c_void_p(), C.c_int(0)

@@ -291,6 +291,9 @@ PRE3_API int pre3_siftmatch_merge(int cls, int G, int K1, const double *best, co
  * whole database for any number of shards. */
 typedef struct pre3_match_shard pre3_match_shard;
 PRE3_API int pre3_match_shard_create(pre3_match_shard **out, int device, int ND, int K1, const uint8_t *L1, int K2_local, const uint8_t *L2_local, int k2_offset);
+/* the same for any class the matrix cores serve: cls 0 double (what matching_sift_based.m:104-118 passes), 1 float, 2 uint8.  double / float
+ * need ND <= 128 and K1 * K2_local >= 65536 (else PRE3_E_ARG: use pre3_siftmatch_partial); the ratio test is siftmatch.c:122's for every class */
+PRE3_API int pre3_match_shard_create_cls(pre3_match_shard **out, int device, int cls, int ND, int K1, const void *L1, int K2_local, const void *L2_local, int k2_offset);
 PRE3_API int pre3_match_shard_run(pre3_match_shard *s, void **partial_dev, int *n_doubles);
 PRE3_API int pre3_match_shard_merge(pre3_match_shard *s, int G, const void *gathered_dev, double thresh, double *pairs_out, double *score_out, int *M_out);
 PRE3_API int pre3_match_shard_destroy(pre3_match_shard *s);

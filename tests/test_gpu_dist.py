@@ -88,18 +88,28 @@ def test_resident_matcher_shards_equal_the_unsharded_match(orc=None):
     L2 = rng.integers(0, 255, (128, 700)).astype(np.uint8)
     L2[:, 50:250] = L1[:, :200]
     L2[:, 600] = L1[:, 3]                                       # a duplicate of a matched column: ties -> lowest index, ratio test fails
-    mr, dr = oracle.siftmatch(L1, L2, 1.5)
-    for G in (1, 2, 3, 5):
-        parts, shards = [], []
-        for g in range(G):
-            lo, hi = pd.shard_range(L2.shape[1], g, G)
-            sh = mt.MatchShard(L1, L2[:, lo:hi], lo)
-            ptr, n = sh.run()
-            parts.append(pd.dev_tensor(ptr, n, "<f8").clone())
-            shards.append(sh)
-        allp = torch.cat(parts)
-        torch.cuda.synchronize()
-        m, d = shards[0].merge(G, allp.data_ptr(), 1.5, return_scores=True)
-        assert np.array_equal(m, mr) and np.array_equal(d, dr), G
-        for sh in shards:
-            sh.close()
+    # uint8; the same descriptors as doubles (what matching_sift_based.m:104-118 passes: integer-valued -> the int8 route inside the shard);
+    # real-valued doubles and singles (bf16 rank + exact re-evaluation inside the shard)
+    real1, real2 = L1 + rng.random(L1.shape), L2 + rng.random(L2.shape)
+    real2[:, 600] = real1[:, 3]; real2[:, 53] = real1[:, 3]
+    for A, B, Gs in ((L1, L2, (1, 2, 3, 5)), (L1.astype(np.float64), L2.astype(np.float64), (1, 3)), (real1, real2, (1, 2, 3)),
+                     (real1.astype(np.float32), real2.astype(np.float32), (2,))):
+        mr, dr = oracle.siftmatch(A, B, 1.5)
+        for G in Gs:
+            parts, shards = [], []
+            for g in range(G):
+                lo, hi = pd.shard_range(B.shape[1], g, G)
+                sh = mt.MatchShard(A, B[:, lo:hi], lo)
+                ptr, n = sh.run()
+                parts.append(pd.dev_tensor(ptr, n, "<f8").clone())
+                shards.append(sh)
+            allp = torch.cat(parts)
+            torch.cuda.synchronize()
+            m, d = shards[0].merge(G, allp.data_ptr(), 1.5, return_scores=True)
+            assert np.array_equal(m, mr) and np.array_equal(d, dr), (A.dtype, G)
+            for sh in shards:
+                sh.close()
+    # a slice too small for the matrix-core paths of the float classes is refused (the host-array form serves it)
+    import pytest
+    with pytest.raises(Exception):
+        mt.MatchShard(real1[:, :10], real2[:, :20], 0)
