@@ -47,7 +47,14 @@ __device__ inline void d_process_noise(double *Pn)
 struct InboxRide { const int4 *src; int4 *dst; int n16; int32_t *mail; int32_t seq; };        // n16 == 0: no pull in this launch
 __device__ __forceinline__ void inbox_pull_block(const InboxRide &ib)
 {
-    for (int i = threadIdx.x; i < ib.n16; i += blockDim.x) ib.dst[i] = ib.src[i];
+    // four PCIe reads in flight per lane (a read is ~1.5 us; one after the other they made this block the long pole of k_predict)
+    for (int i0 = threadIdx.x; i0 < ib.n16; i0 += 4 * blockDim.x) {
+        int4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * blockDim.x; v[u] = i < ib.n16 ? ib.src[i] : int4{ 0, 0, 0, 0 }; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * blockDim.x; if (i < ib.n16) ib.dst[i] = v[u]; }
+    }
     __syncthreads();
     if (threadIdx.x == 0) { __threadfence_system(); __hip_atomic_store(ib.mail + 10, ib.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }
@@ -102,7 +109,9 @@ __global__ __launch_bounds__(256) void k_predict(const double *__restrict__ x_in
             for (int i = 7; i < 13; ++i) x_out[i] = 0;
         }
     }
-    if (pr.n_blocks) ride_signal(pr.ctr);              // this block's share of x_out is written (includes the barrier)
+    // the projection riders read the landmarks from x_in (the prediction copies them unchanged) and only the POSE from x_out: block 0's
+    // signal is the only one they wait for (every block signalling cost each of them a device-scope release)
+    if (pr.n_blocks && blockIdx.x == 0) ride_signal(pr.ctr);       // (includes the barrier)
     else __syncthreads();
     if (j >= 7 && j < n) {
         double a[4], b[4];
@@ -721,7 +730,7 @@ int launch_predict_impl(pre3_ctx *c, const double u[7], bool with_projection, si
     U7 uu; for (int i = 0; i < 7; ++i) uu.v[i] = u[i];
     int blocks = ceil_div(c->n, 256);
     ProjRide pr{};
-    if (with_projection && c->N > 0) pr = make_proj_ride(c, PRE3_X_K_KM1, 1, 0, blocks);
+    if (with_projection && c->N > 0) { pr = make_proj_ride(c, PRE3_X_K_KM1, 1, 0, 1); pr.x_lm = c->x_kk; }      // one producer: block 0 (the pose)
     InboxRide ib{ (const int4 *)c->inbox_host_dev, (int4 *)c->inbox_dev, (int)inbox_n16, c->mail_dev, inbox_seq };     // one more block when inbox_n16 > 0
     const int nb = blocks + pr.n_blocks + (inbox_n16 ? 1 : 0);
     DISPATCH_T(c,

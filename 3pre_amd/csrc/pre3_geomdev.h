@@ -71,10 +71,11 @@ __device__ inline void d_ray(int type, const double *y, const double *t, double 
 // ------------------------------------------------------------------------------------------------
 __device__ inline void project_one(const int i, const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
                             const double *__restrict__ x, const CamD &cam, int clear_first,
-                            double *__restrict__ h, int32_t *__restrict__ has_h, double *__restrict__ Hc, double *__restrict__ Hl)
+                            double *__restrict__ h, int32_t *__restrict__ has_h, double *__restrict__ Hc, double *__restrict__ Hl,
+                            const double *__restrict__ x_lm = nullptr /* the landmark part of the state, if it lives in another vector */)
 {
     int type = lm_type[i];
-    const double *y = x + lm_off[i];
+    const double *y = (x_lm ? x_lm : x) + lm_off[i];
     double Rwc[9];
     d_q2r(x + 3, Rwc);
     double v[3], hrl[3];
@@ -158,7 +159,7 @@ __device__ inline void project_one(const int i, const int32_t *__restrict__ lm_t
 struct ProjRide {
     int n_blocks;                       // 0: no rider in this launch
     int N, clear_first;
-    const int32_t *lm_type, *lm_off; const double *x; CamD cam;
+    const int32_t *lm_type, *lm_off; const double *x; const double *x_lm /* landmark entries (null: x) */; CamD cam;
     double *h; int32_t *has_h; double *Hc, *Hl;
     unsigned int *ctr; unsigned int target;
     int32_t *guard;                     // device error word (stats[7]): set when a wait gives up
@@ -189,7 +190,7 @@ __device__ __forceinline__ void proj_ride_block(const ProjRide &pr, int blk)
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const int i = blk * 64 + threadIdx.x;
-    if (threadIdx.x < 64 && i < pr.N) project_one(i, pr.lm_type, pr.lm_off, pr.x, pr.cam, pr.clear_first, pr.h, pr.has_h, pr.Hc, pr.Hl);
+    if (threadIdx.x < 64 && i < pr.N) project_one(i, pr.lm_type, pr.lm_off, pr.x, pr.cam, pr.clear_first, pr.h, pr.has_h, pr.Hc, pr.Hl, pr.x_lm);
 }
 
 // ---- S_i = H_i P H_i' (+ I) per landmark (search_IC_matches.m:36; mode 1: the chi2 gate of rescue_hi_inliers.m:35-46).  Shared by k_innovation
