@@ -1148,9 +1148,12 @@ static int rank_prepare(RankMatch &r, int ND, int K1, const T *L1, int K2, const
     PRE3_TRY(r.fl.alloc(sizeof(int) * 4));
     // tiled form: K1p / 64 query groups x nsl database slices ~ one workgroup per CU (and at least 8 blocks of 16 columns per wave-round)
     {
-        int ncu = 256;
-        hipDeviceProp_t prop; int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+        static int ncu_of[64];                            // CUs per device, asked once (hipGetDeviceProperties is slow)
+        int ncu = 256, dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            if (ncu_of[dev] == 0) { int v = 0; ncu_of[dev] = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0 ? v : 256; }
+            ncu = ncu_of[dev];
+        }
         const int groups = r.K1p / RT_Q, nblk = r.K2p / 16;
         r.nsl = std::max(1, std::min(std::min(ceil_div(ncu, groups), nblk / RT_WAVES), 64));
     }
