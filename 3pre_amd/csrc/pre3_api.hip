@@ -919,7 +919,8 @@ int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, co
         ran = true;
     }
     if (trace) t2 = now();
-    c->ride_rescue_projection = true;                               // the rescue's projection rides in the LI update's K9 launch
+    static const int ride_rescue = getenv("PRE3_RIDE_RESCUE") ? atoi(getenv("PRE3_RIDE_RESCUE")) : 1;      // 0: projection + gate as one launch of their own (A/B)
+    c->ride_rescue_projection = ride_rescue != 0;                   // the rescue's projection rides in the LI update's K9 launch
     {
         const int rc_li = pre3_update_li(c);                        // mono_slam.m:181
         c->ride_rescue_projection = false;                          // (also on failure: a later K9 launch must not carry the riders)
