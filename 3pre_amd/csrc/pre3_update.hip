@@ -473,7 +473,7 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
         if (PRO && planes) {
             // operands as bf16 planes (written by the store epilogues of launch J-1), this wave's fragments straight into registers.
             // A operand: rows w0.. of B = M(J, J-1).  B operand: D tile -> rows w1.. of B;  X tile -> the own block's rows / columns w1..
-            if (tile_live) {
+            if (tile_live && J > 0) {                    // (panel 0 has no pending update: pacc stays 0)
                 const frag_t *Bp = static_cast<const frag_t *>(Sp) + ((size_t)J * sp_stride + (J - 1)) * B3_SGRAN + lane;
                 const frag_t *Op; int ostage, oplane;
                 if (!xside) { Op = Bp + fb * 64; ostage = 384; oplane = 128; }
@@ -484,7 +484,7 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) { fA[q][pl] = Bp[q * 384 + pl * 128 + fa * 64]; fB[q][pl] = Op[q * ostage + pl * oplane]; }
             }
-        } else if (PRO) {
+        } else if (PRO && J > 0) {
             // operands of the pending update through LDS: D workers bring B = M(J, J-1), X workers the workgroup's own M(b, J-1)
             if (!xside) {
 #pragma unroll
@@ -512,7 +512,7 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
                 for (int t = 0; t < 16; ++t) Xs[lr + 4 * t][lc] = g[t];        // W strip: (a = lr+4t, i = lc)
             }
         }
-        if (PRO && !planes) {
+        if (PRO && !planes && J > 0) {
             if (!xside) {
 #pragma unroll
                 for (int t = 0; t < 16; ++t) sm.Bs[lr + 4 * t][lc] = gp[t];                      // Bs[j][a]
@@ -538,8 +538,10 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
 #pragma unroll
                 for (int e = 0; e < 16; ++e) pacc[e] = 0.f;
 #define PRO_MMA(px, py) pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fA[q][px]), __builtin_bit_cast(bf16x8_t, fB[q][py]), pacc, 0, 0, 0)
+                if (J > 0) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { PRO_MMA(0, 0); PRO_MMA(0, 1); PRO_MMA(1, 0); PRO_MMA(1, 1); PRO_MMA(0, 2); PRO_MMA(2, 0); }
+                    for (int q = 0; q < 4; ++q) { PRO_MMA(0, 0); PRO_MMA(0, 1); PRO_MMA(1, 0); PRO_MMA(1, 1); PRO_MMA(0, 2); PRO_MMA(2, 0); }
+                }
 #undef PRO_MMA
                 const int lrow = 4 * (lane >> 5), lcol = lane & 31;
 #pragma unroll
@@ -564,7 +566,7 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
             // tile(r, c) -= sum_k A[r][k] B[c][k]: A = rows w0.. of Bs (= M(J, J-1));  B = rows w1.. of Bs (D tile), of As[i][k] (S block: the
             // own block's rows) or the columns of As[k][i] (W strip)
 #pragma unroll 4
-            for (int k0 = 0; k0 < NB; k0 += M::KS) {
+            for (int k0 = 0; k0 < (J > 0 ? NB : 0); k0 += M::KS) {
                 const int kx = k0 + M::kk(lane);
                 T av[NBLK], bv[NBLK];
 #pragma unroll
@@ -1003,10 +1005,27 @@ __device__ __forceinline__ void chol_trail_body(T (&As)[NB][NB + 1], T (&Bs)[NB]
 template <typename T>
 __global__ __launch_bounds__(CH_NTH) void k_chol_step(T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb, int nW,
                                                    int nP, int32_t *__restrict__ status, unsigned int *__restrict__ arrive, unsigned int target,
-                                                   int nPT, void *__restrict__ Wp, int nst_total, int ncb, int ld_split, void *__restrict__ Sp, int sp_stride)
+                                                   int nPT, void *__restrict__ Wp, int nst_total, int ncb, int ld_split, void *__restrict__ Sp, int sp_stride,
+                                                   const int32_t *__restrict__ n_dev, int nS_max)
 {
     __shared__ ChSmem<T> sm;
-    const int b = blockIdx.x;
+    int b = blockIdx.x;
+    if (n_dev != nullptr) {
+        // Panel 0 launched BEFORE the host knows the number of rows (LI update of a step: the count is still on its way through the mailbox):
+        // the grid is sized for all measurements (nS_max S row blocks), the row count is read on the device (as k_gather_li in front of it
+        // does), and the workgroups of S row blocks that do not exist arrive and leave.  The host polls the count while this launch runs and
+        // sizes the launches of the panels >= 1 exactly; without it the stream sat idle for the mailbox round trip + a launch between the
+        // gather and the first panel.  (Same kernel, same code as every other panel: the chain's ~35 KB of instructions are fetched cold once.)
+        const int n = *n_dev;
+        nrb = (2 * n + NB - 1) / NB; lds = nrb * NB;
+        const int nS = nrb - 1;
+        if (n <= 0 || (b > nS && b <= nS_max)) {      // no update at all / a row block beyond the selected rows: keep the arrival count the host assumed
+            if (b != 0 && threadIdx.x == 0) atomicAdd(arrive, 1u);
+            return;
+        }
+        if (b > nS_max) b -= nS_max - nS;             // the W strips follow the S row blocks that exist
+        nP = nPT = 1 + nS + nW;
+    }
 #ifdef PRE3_PROBE
     // wall-clock (100 MHz) begin / end of every workgroup of the launch of panel 2: which workgroups are the launch's long pole
     struct RtStamp { int b, on; __device__ RtStamp(int b_, int on_) : b(b_), on(on_) { stamp(0); }
@@ -1023,33 +1042,12 @@ __global__ __launch_bounds__(CH_NTH) void k_chol_step(T *__restrict__ S, int lds
         return;
     }
     if (b < nP) {
-        if (J == 0) chol_panel_body<T, false>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target, Wp, nst_total, ld_split, Sp, sp_stride);
-        else chol_panel_body<T, true>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target, Wp, nst_total, ld_split, Sp, sp_stride);
+        chol_panel_body<T, true>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target, Wp, nst_total, ld_split, Sp, sp_stride);     // (J == 0: no pending update, skipped at run time)
     } else {
         chol_trail_body<T>(sm.As, sm.Bs, S, lds, W, ldw, J - 1, J + 1, nrb, nW, b - nP, Wp, nst_total, Sp, sp_stride);
     }
 }
 
-// Panel 0 launched BEFORE the host knows the number of rows (LI update of a step: the count is still on its way through the mailbox):
-// the grid is sized for all measurements, the row count is read on the device (as k_gather_li in front of it does), and the workgroups of
-// S row blocks that do not exist arrive and leave.  The host polls the count while this launch runs and sizes the launches of the
-// panels >= 1 exactly; without it the stream sat idle for the mailbox round trip + a launch (~6 us) between the gather and the first panel.
-template <typename T>
-__global__ __launch_bounds__(CH_NTH) void k_chol_step0_spec(T *__restrict__ S, T *__restrict__ W, int ldw, int nS_max, const int32_t *__restrict__ n_dev,
-                                                            int32_t *__restrict__ status, unsigned int *__restrict__ arrive, unsigned int target,
-                                                            void *__restrict__ Wp, int nst_total, int ld_split, void *__restrict__ Sp, int sp_stride)
-{
-    __shared__ ChSmem<T> sm;
-    const int n = *n_dev;
-    const int nrb = (2 * n + NB - 1) / NB, nS = nrb - 1;
-    int b = blockIdx.x;
-    if (n <= 0 || (b > nS && b <= nS_max)) {          // no update at all / a row block beyond the selected rows: keep the arrival count the host assumed
-        if (b != 0 && threadIdx.x == 0) atomicAdd(arrive, 1u);
-        return;
-    }
-    if (b > nS_max) b -= nS_max - nS;                 // the W strips follow the S row blocks that exist
-    chol_panel_body<T, false>(sm, S, nrb * NB, W, ldw, 0, nrb, status, b, arrive, target, Wp, nst_total, ld_split, Sp, sp_stride);
-}
 
 // K' = L^-T W  (so that K = W' L^-1 ... = P H' inv(S)); slow back substitution, one lane per state row.
 // Only the stateless drop-in returns K (no caller in the reference uses it).  Kt: r_pad x ldw.
@@ -1783,9 +1781,9 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad, bool first_done = false)
             c->chol_target += (unsigned)(nP - 1);                           // every non-diagonal workgroup of the panel arrives once
             DISPATCH_T(c,
                 hipLaunchKernelGGL(k_chol_step<double>, g, bP, 0, c->stream, (double *)c->Smat, r_pad, (double *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
-                                   nP + nT_in, nullptr, 0, 0, 0, nullptr, 0),
+                                   nP + nT_in, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0),
                 hipLaunchKernelGGL(k_chol_step<float>, g, bP, 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
-                                   nP + nT_in, split ? c->Wp : nullptr, c->rcap / B3_BK, ncb, c->ld, pro_planes ? c->Sp : nullptr, c->rcap / NB));
+                                   nP + nT_in, split ? c->Wp : nullptr, c->rcap / B3_BK, ncb, c->ld, pro_planes ? c->Sp : nullptr, c->rcap / NB, nullptr, 0));
         }
         if (split) c->split_rows = nrb * NB;
         PRE3_HIP(hipGetLastError());
@@ -1933,10 +1931,10 @@ int launch_chol_first_spec(pre3_ctx *c, int nsel_max)
     const int nP = 1 + nS_max + nW;
     c->chol_target += (unsigned)(nP - 1);
     DISPATCH_T(c,
-        hipLaunchKernelGGL(k_chol_step0_spec<double>, dim3(nP), dim3(CH_NTH), 0, c->stream, (double *)c->Smat, (double *)c->W, c->ldw, nS_max, c->stats + 4, c->stats + 6,
-                           c->chol_arrive, c->chol_target, nullptr, 0, 0, nullptr, 0),
-        hipLaunchKernelGGL(k_chol_step0_spec<float>, dim3(nP), dim3(CH_NTH), 0, c->stream, (float *)c->Smat, (float *)c->W, c->ldw, nS_max, c->stats + 4, c->stats + 6,
-                           c->chol_arrive, c->chol_target, split ? c->Wp : nullptr, c->rcap / B3_BK, c->ld, pro_planes ? c->Sp : nullptr, c->rcap / NB));
+        hipLaunchKernelGGL(k_chol_step<double>, dim3(nP), dim3(CH_NTH), 0, c->stream, (double *)c->Smat, 0, (double *)c->W, c->ldw, 0, 0, nW, nP, c->stats + 6,
+                           c->chol_arrive, c->chol_target, nP, nullptr, 0, 0, 0, nullptr, 0, c->stats + 4, nS_max),
+        hipLaunchKernelGGL(k_chol_step<float>, dim3(nP), dim3(CH_NTH), 0, c->stream, (float *)c->Smat, 0, (float *)c->W, c->ldw, 0, 0, nW, nP, c->stats + 6,
+                           c->chol_arrive, c->chol_target, nP, split ? c->Wp : nullptr, c->rcap / B3_BK, 0, c->ld, pro_planes ? c->Sp : nullptr, c->rcap / NB, c->stats + 4, nS_max));
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }
