@@ -31,6 +31,9 @@ if ROOT not in sys.path:
 PEAK = {"f32": 157.3, "f64": 78.6, "bf16": 2500.0, "i8": 5000.0}       # dense MFMA TFLOP/s, MI355X_MICROARCH.md "Chip-level parameters" / "Matrix cores"
 
 
+COLL_DEV = "cuda"        # device of the small tensors the bench all-reduces (rehearsal over gloo: "cpu")
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -97,7 +100,7 @@ def all_ranks_ok(dist, ok):
     if dist is None:
         return ok
     import torch
-    t = torch.tensor([1 if ok else 0], device="cuda", dtype=torch.int32)
+    t = torch.tensor([1 if ok else 0], device=COLL_DEV, dtype=torch.int32)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return bool(t.item())
 
@@ -128,7 +131,7 @@ def matcher_shard_leg(pre3, dist, rank, world, local_rank=0, K=4096, reps=20):
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([el], device="cuda", dtype=torch.float64)
+            t = torch.tensor([el], device=COLL_DEV, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
     finally:
@@ -175,7 +178,7 @@ def ransac_shard_leg(pre3, synth, dist, rank, world, local_rank, N=2000, n_hyp=1
         el = time.perf_counter() - t0
         if dist is not None:
             dist.barrier()
-            t = torch.tensor([el], device="cuda", dtype=torch.float64)
+            t = torch.tensor([el], device=COLL_DEV, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return {"workload": "configs[4]: N=%d (n=%d), %d hypotheses (k=3), m=%d measured, f32; per round: H*P and H*P*H' gathers, "
@@ -322,6 +325,12 @@ def main():
         sys.exit(self_launch(args))                 # nothing in this process has touched the GPU yet
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # PRE3_BENCH_REHEARSAL=gloo: every rank on cuda:0 with the gloo backend -- rehearses the whole multi-rank flow (self-launch, the
+    # sharded legs' host-staged branches, the agreement exchanges, max-over-ranks timing) on a one-GPU box; the numbers mean nothing
+    global COLL_DEV
+    rehearsal = os.environ.get("PRE3_BENCH_REHEARSAL") == "gloo"
+    if rehearsal:
+        local_rank, COLL_DEV = 0, "cpu"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s); refusing to print a line that would claim the wrong n_gpus\n" % (args.gpus, world))
@@ -333,7 +342,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=180))
+        if rehearsal:
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=180))
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=180))
     pre3 = importlib.import_module("3pre_amd")
     synth = importlib.import_module("3pre_amd.synth")
     if pre3.device_count() < 1:
@@ -366,7 +378,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device=COLL_DEV, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kt = f.kernel_timing_read()
