@@ -342,10 +342,23 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        if rehearsal:
-            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=180))
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=180))
+        # RCCL prints a version banner on STDOUT when its communicator comes up: keep the contract's "ONE JSON line" by sending fd 1 to
+        # stderr while the process group is created and its first collective runs
+        sys.stdout.flush()
+        saved_out = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if rehearsal:
+                dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=180))
+            else:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=180))
+            dist.barrier()
+            if not rehearsal:
+                torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_out, 1)
+            os.close(saved_out)
     pre3 = importlib.import_module("3pre_amd")
     synth = importlib.import_module("3pre_amd.synth")
     if pre3.device_count() < 1:
