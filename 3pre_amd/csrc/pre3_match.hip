@@ -1210,7 +1210,7 @@ static int partial_float(int ND, int K1, const T *L1, int K2, const T *L2, int k
     PRE3_HIP(hipMemcpy(best, r.m.ob.p, sizeof(double) * K1, hipMemcpyDeviceToHost));
     PRE3_HIP(hipMemcpy(second, r.m.os.p, sizeof(double) * K1, hipMemcpyDeviceToHost));
     PRE3_HIP(hipMemcpy(arg, r.m.oa.p, sizeof(int32_t) * K1, hipMemcpyDeviceToHost));
-    if (r.route == 1 && sizeof(T) == 4) {}                        // (int-valued sums < 2^24: the float class's own sums are the same integers)
+    // (route 1, single class: int-valued sums < 2^24, so the float class's own bin-by-bin sums are the same integers)
     return PRE3_OK;
 }
 
