@@ -1,0 +1,33 @@
+"""The launch structure of pre3_step has switches (what rides in which launch, which tails are launches of their own,
+the speculative first panel).  They change WHERE work runs, never what is computed: every variant must give bit-identical states,
+flags and statistics."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+VARIANTS = [
+    {},
+    {"PRE3_SELECT_FUSE": "1", "PRE3_HI_FUSE": "1"},
+    {"PRE3_RIDE_INNOV": "0", "PRE3_RIDE_PROJ": "0", "PRE3_RIDE_RESCUE": "0"},
+    {"PRE3_CHOL_SPEC0": "0"},
+]      # (not here: PRE3_CHOL_PRO_B3 / PRE3_K9_B3 change the ARITHMETIC of the fp32 path -- f32 MFMA instead of the bf16 split -- not just the launches)
+
+
+def _digest(env_extra):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_worker.py")], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("DIGEST ")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return lines[0].split()[1]
+
+
+def test_launch_structure_variants_are_bit_identical():
+    ref = _digest(VARIANTS[0])
+    for v in VARIANTS[1:]:
+        assert _digest(v) == ref, v

@@ -1,0 +1,37 @@
+"""Worker of tests/test_gpu_variants.py: a short filter sequence in the launch structure the environment selects; prints a digest of the
+final state and of every step's statistics."""
+import hashlib
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    pre3 = importlib.import_module("3pre_amd")
+    synth = importlib.import_module("3pre_amd.synth")
+    h = hashlib.sha256()
+    for N, n_hyp, dtype, steps in ((120, 60, "f32", 12), (120, 60, "f64", 6), (9, 8, "f32", 6)):
+        seq = synth.make_sequence(N, steps, n_hyp, seed=4242 + N)
+        f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype=dtype, max_hyp=n_hyp, std_z=1.0)
+        f.set_x_p_k_k(seq["x0"], seq["P0"])
+        f.defer_hi_update(True)
+        for t, s in enumerate(seq["steps"]):
+            z = s["z"]
+            if t == 3:                                    # a frame whose measurements are all gross outliers: RANSAC runs, (almost) nothing is selected
+                z = z + 300.0
+            st = f.step(s["u"], s["meas_idx"], z, s["hyp"], threshold=1.0, early_exit=bool(t % 2))
+            h.update(repr(sorted(st.items())).encode())
+        li, hi = f.get_flags()
+        h.update(li.tobytes()); h.update(hi.tobytes())
+        h.update(f.get_x_k_k().tobytes()); h.update(f.get_p_k_k().tobytes())
+        f.close()
+    print("DIGEST", h.hexdigest())
+
+
+if __name__ == "__main__":
+    main()
