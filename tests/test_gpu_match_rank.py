@@ -11,19 +11,19 @@ pytestmark = pytest.mark.gpu
 
 
 class _Form:
-    """PRE3_MATCH_FLOAT_FORM for the duration of a block (0: exact kernels only, 2: never the int8 route; read by the library per call)"""
-    def __init__(self, v):
-        self.v = v
+    """PRE3_MATCH_FLOAT_FORM (or another switch the library reads per call) for the duration of a block (0: exact kernels only, 2: never the int8 route)"""
+    def __init__(self, v, name="PRE3_MATCH_FLOAT_FORM"):
+        self.v, self.name = v, name
 
     def __enter__(self):
-        self.old = os.environ.get("PRE3_MATCH_FLOAT_FORM")
-        os.environ["PRE3_MATCH_FLOAT_FORM"] = str(self.v)
+        self.old = os.environ.get(self.name)
+        os.environ[self.name] = str(self.v)
 
     def __exit__(self, *a):
         if self.old is None:
-            del os.environ["PRE3_MATCH_FLOAT_FORM"]
+            del os.environ[self.name]
         else:
-            os.environ["PRE3_MATCH_FLOAT_FORM"] = self.old
+            os.environ[self.name] = self.old
 
 
 def _route(pre3, L1, L2):
@@ -141,3 +141,19 @@ def test_full_size_double_class(pre3):
     info, got = _route(pre3, L1f, L2f)
     ref = _exact_partial(pre3, L1f, L2f)
     assert info[0] == 2 and all(np.array_equal(g, r) for g, r in zip(got, ref))
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_one_launch_and_tiled_forms_agree(pre3, orc, dt):
+    """PRE3_MATCH_RANK_FORM: the tiled form (three launches, default) and the one-launch form rank with differently packed planes and
+    different reduction trees -- the exact re-evaluation makes both land on the oracle's bits"""
+    rng = np.random.default_rng(6)
+    L1 = (rng.standard_normal((128, 333)) * 7).astype(dt)
+    L2 = (rng.standard_normal((128, 901)) * 7).astype(dt)
+    L2[:, 100:300] = L1[:, :200] + (0.05 * rng.standard_normal((128, 200))).astype(dt)
+    L2[:, 900] = L2[:, 100]
+    mr, dr = orc.siftmatch(L1, L2, 1.4)
+    for form in (1, 0):
+        with _Form(form, "PRE3_MATCH_RANK_FORM"):
+            m, d = pre3.siftmatch(L1, L2, 1.4, return_scores=True)
+        assert np.array_equal(m, mr) and np.array_equal(d, dr), form
