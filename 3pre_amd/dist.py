@@ -59,10 +59,11 @@ def _agree_zero_copy(ok_here):
     return _ZERO_COPY[key]
 
 
-def ransac_sharded(f, hyp, threshold, early_exit=True, device=None, timing=None):
+def ransac_sharded(f, hyp, threshold, early_exit=True, device=None, timing=None, fetch=True):
     """f: EkfFilter with projection + measurements installed (identical on every rank).
     Scores this rank's slice on the GPU, all-reduces supports and masks, selects.  Returns the same dict as
-    EkfFilter.ransac_hypotheses on every rank.  timing: optional dict that receives the round's split (compute / collective / select, s)."""
+    EkfFilter.ransac_hypotheses on every rank.  timing: optional dict that receives the round's split (compute / collective / select, s).
+    fetch=False: only the statistics are returned (no D2H of the supports and the winner's mask: they stay on the device for the update)."""
     import time
     rank, world = _world()
     hyp = np.ascontiguousarray(hyp, np.int32)
@@ -105,7 +106,7 @@ def ransac_sharded(f, hyp, threshold, early_exit=True, device=None, timing=None)
             torch.cuda.synchronize()
             f.ransac_import(n_draw, sup.data_ptr(), msk.data_ptr())
     t2 = time.perf_counter()
-    out = f.ransac_select(n_draw, k, early_exit)
+    out = f.ransac_select(n_draw, k, early_exit, fetch=fetch)
     if timing is not None:
         t3 = time.perf_counter()
         timing["compute"] = timing.get("compute", 0.0) + (t1 - t0)

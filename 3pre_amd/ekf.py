@@ -217,10 +217,15 @@ class EkfFilter:
                                     C.byref(sp), C.byref(mp), C.byref(mw)))
         return sp.value, mp.value, mw.value
 
-    def ransac_select(self, n_draw, k, early_exit=True):
+    def ransac_select(self, n_draw, k, early_exit=True, fetch=True):
+        """fetch=False: only the four statistics come back (through the mailbox: no stream sync, no D2H of the supports / the mask); the
+        winner's flags stay on the device for ekf_update_li_inliers"""
+        st = np.zeros(4, np.int32)
+        if not fetch:
+            check(lib.pre3_ransac_select(self._ctx, int(n_draw), int(k), int(bool(early_exit)), None, None, dptr(st)))
+            return dict(best=int(st[0]), iters=int(st[1]), n_hyp=int(st[2]), max_support=int(st[3]))
         sup = np.zeros(n_draw, np.int32)
         li = np.zeros(max(self.m, 1), np.int32)
-        st = np.zeros(4, np.int32)
         check(lib.pre3_ransac_select(self._ctx, int(n_draw), int(k), int(bool(early_exit)), dptr(sup), dptr(li), dptr(st)))
         return dict(support=sup, li_mask=li[:self.m], best=int(st[0]), iters=int(st[1]), n_hyp=int(st[2]), max_support=int(st[3]))
 

@@ -164,7 +164,7 @@ def ransac_shard_leg(pre3, synth, dist, rank, world, local_rank, N=2000, n_hyp=1
         raise RuntimeError("sharded-RANSAC leg skipped: set-up failed on a rank (%r)" % (err,))
     try:
         for _ in range(2):
-            out = pd.ransac_sharded(f, s["hyp"], 1.0, early_exit=False)
+            out = pd.ransac_sharded(f, s["hyp"], 1.0, early_exit=False, fetch=False)
         f.sync()
         torch.cuda.synchronize()
         if dist is not None:
@@ -172,7 +172,7 @@ def ransac_shard_leg(pre3, synth, dist, rank, world, local_rank, N=2000, n_hyp=1
         split = {}
         t0 = time.perf_counter()
         for _ in range(reps):
-            out = pd.ransac_sharded(f, s["hyp"], 1.0, early_exit=False, timing=split)
+            out = pd.ransac_sharded(f, s["hyp"], 1.0, early_exit=False, timing=split, fetch=False)
         f.sync()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
