@@ -10,6 +10,7 @@
 //   * uint8 / int8 classes: distances are integers; d2 = |a|^2 + |b|^2 - 2 a.b is evaluated exactly in
 //     int32 on the matrix cores (v_mfma_i32_32x32x32_i8; uint8 is re-centred by -128, which leaves a-b
 //     unchanged) with the best/second-best scan fused into the epilogue.
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -1385,6 +1386,7 @@ struct MatchShard {
     I8Match &out() { return cls == 2 ? m : r.m; }
     DevBuf part;            // double [3][K1]: best | second | arg (as double) -- the all-gather payload
     DevBuf res;             // double [1 + 3 K1]: count | pairs (2 K1) | scores (K1)
+    std::vector<double> host_res;
 };
 
 __global__ void k_shard_pack(int K1, const double *__restrict__ b, const double *__restrict__ s2, const int32_t *__restrict__ a, double *__restrict__ out)
@@ -1477,12 +1479,14 @@ int match_shard_merge(void *h, int G, const void *gathered_dev, double thresh, d
     const int K1 = sh->out().K1;
     hipLaunchKernelGGL(k_shard_merge, dim3(1), dim3(1024), 0, 0, G, K1, (const double *)gathered_dev, (float)thresh, (double *)sh->res.p);
     PRE3_HIP(hipGetLastError());
-    double cnt = 0;
-    PRE3_HIP(hipMemcpy(&cnt, sh->res.p, sizeof(double), hipMemcpyDeviceToHost));
-    const int M = (int)cnt;
+    // ONE copy of the whole result block [count | pairs (2 K1) | scores (K1)] (98 KB at K1 = 4096): three dependent copies cost three PCIe
+    // round trips and the count is not known before the first
+    sh->host_res.resize(1 + 3 * (size_t)K1);
+    PRE3_HIP(hipMemcpy(sh->host_res.data(), sh->res.p, sizeof(double) * sh->host_res.size(), hipMemcpyDeviceToHost));
+    const int M = (int)sh->host_res[0];
     if (M > 0) {
-        PRE3_HIP(hipMemcpy(pairs_out, (const double *)sh->res.p + 1, sizeof(double) * 2 * M, hipMemcpyDeviceToHost));
-        if (score_out) PRE3_HIP(hipMemcpy(score_out, (const double *)sh->res.p + 1 + 2 * (size_t)K1, sizeof(double) * M, hipMemcpyDeviceToHost));
+        memcpy(pairs_out, sh->host_res.data() + 1, sizeof(double) * 2 * M);
+        if (score_out) memcpy(score_out, sh->host_res.data() + 1 + 2 * (size_t)K1, sizeof(double) * M);
     }
     *M_out = M;
     return PRE3_OK;
