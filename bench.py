@@ -268,14 +268,21 @@ def self_launch(args):
 
 def legs_agree(dist, err, name):
     """Collective-safe error hand-off after a leg's collectives: if the leg failed on ANY rank, every rank learns it here (one MIN
-    all-reduce) and the job stops with a non-zero exit instead of walking into further collectives with a rank missing."""
+    all-reduce) and no rank walks into further collectives with a rank missing.  Returns True (every rank fine), False (a rank failed:
+    the caller skips the remaining legs) or None (the exchange itself failed: the communicator is unusable, nothing collective may follow).
+    The headline was measured before the legs and is still printed in every case -- an auxiliary leg must not cost the line."""
     if dist is None:
-        return                                  # one process: the leg's error is recorded in the line, nothing can be left waiting
-    ok = all_ranks_ok(dist, err is None)
-    if not ok:
-        sys.stderr.write("bench.py: leg %r failed on a rank (%r) -- aborting, no further collectives\n" % (name, err))
+        return err is None                      # one process: the leg's error is recorded in the line, nothing can be left waiting
+    try:
+        ok = all_ranks_ok(dist, err is None)
+    except Exception as e:                      # pragma: no cover  (a collective that timed out takes the communicator with it)
+        sys.stderr.write("bench.py: the agreement exchange after leg %r failed (%r): no further collectives\n" % (name, e))
         sys.stderr.flush()
-        os._exit(3)
+        return None
+    if not ok:
+        sys.stderr.write("bench.py: leg %r failed on a rank (%r) -- the remaining legs are skipped\n" % (name, err))
+        sys.stderr.flush()
+    return ok
 
 
 def check_step(pre3, f, seq, s, thr, dtype):
@@ -466,7 +473,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(seq, thr, args.cpu_budget)
     f.close()
     # secondary legs: sharded RANSAC and sharded matcher at every N, kernel-only matcher and VO RANSAC at N=1.  A leg that fails on any
-    # rank stops the job (legs_agree): the other ranks must not be left inside a collective.
+    # rank is recorded and ends the legs (legs_agree): no rank may be left inside a collective, and the headline is printed regardless.
+    comm_broken = False
     if not args.no_extra_legs:
         for name, fn in (("ransac_shard", lambda: ransac_shard_leg(pre3, synth, dist, rank, world, local_rank)),
                          ("matcher_shard", lambda: matcher_shard_leg(pre3, dist, rank, world, local_rank))):
@@ -475,20 +483,31 @@ def main():
                 leg = fn()
             except Exception as e:                              # pragma: no cover
                 err = e
-            legs_agree(dist, err, name)
+            agreed = legs_agree(dist, err, name)
             if rank == 0:
-                out[name] = leg if err is None else {"error": repr(err)[:300]}
+                out[name] = leg if (err is None and agreed) else {"error": repr(err)[:300] if err is not None else "failed on another rank"}
+            if agreed is None:
+                comm_broken = True
+            if not agreed:
+                break                                           # no further collectives after a failed leg
         if world == 1:
             for name, fn in (("matcher", lambda: matcher_leg(pre3)), ("vo_ransac", lambda: vo_leg(pre3))):
                 try:
                     out[name] = fn()
                 except Exception as e:                          # pragma: no cover
                     out[name] = {"error": repr(e)[:300]}
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if dist is not None and not comm_broken:
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:                                  # pragma: no cover
+            sys.stderr.write("bench.py: final barrier failed (%r)\n" % (e,))
+            comm_broken = True
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
+    if comm_broken:
+        os._exit(0)                                             # (skips the teardown of a communicator that no longer answers)
 
 
 if __name__ == "__main__":
