@@ -356,9 +356,9 @@ def main():
         os.dup2(2, 1)
         try:
             if rehearsal:
-                dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=180))
+                dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=90))
             else:
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=180))
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=90))
             dist.barrier()
             if not rehearsal:
                 torch.cuda.synchronize()
@@ -480,6 +480,8 @@ def main():
                          ("matcher_shard", lambda: matcher_shard_leg(pre3, dist, rank, world, local_rank))):
             leg, err = None, None
             try:
+                if os.environ.get("PRE3_BENCH_FAIL_LEG") == name and rank == world - 1:
+                    raise RuntimeError("injected failure (PRE3_BENCH_FAIL_LEG): rehearses the error hand-off")
                 leg = fn()
             except Exception as e:                              # pragma: no cover
                 err = e
