@@ -7,6 +7,7 @@
 #include <new>
 
 #include "pre3_internal.h"
+#include "pre3_cholp.h"
 
 namespace pre3 {
 
@@ -225,6 +226,9 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
         // on XCD b % 8, so a super-tile's 8 column blocks of planes stay in one L2)
         A(dmalloc_bytes(&c->Wp, (size_t)(c->ld + 128) * c->rcap * 6));       // + one column block for the nu strip's planes
         A(dmalloc_bytes(&c->Sp, (size_t)(c->rcap / NB) * (c->rcap / NB) * 1536 * 16));
+        // persistent factorisation (pre3_cholp.hip): flag words (zero: every launch brings its own epoch), one plane block per row for the hand-over to crit
+        { void *f = nullptr; A(dmalloc_bytes(&f, cholp_flag_bytes())); c->cholp_flags = (unsigned int *)f; }
+        A(dmalloc_bytes(&c->cholp_tp, (size_t)(c->rcap / NB) * 1536 * 16));
         const int nt = c->ld / 128, ns = ceil_div(nt, 4);
         std::vector<std::vector<int2>> lists(8);
         for (int SI = 0; SI < ns; ++SI)
@@ -290,7 +294,7 @@ int pre3_destroy(pre3_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
                      c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
-                     c->sel_rows, c->support, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128, c->need };
+                     c->sel_rows, c->support, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128, c->need, c->cholp_flags, c->cholp_tp };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->pinned_stats) (void)hipHostFree(c->pinned_stats);
     if (c->inbox_host) (void)hipHostFree(c->inbox_host);
@@ -309,6 +313,7 @@ int pre3_set_option(pre3_ctx *c, int option, int value)
     switch (option) {
     case PRE3_OPT_DEFER_HI: c->defer_hi = value != 0; return PRE3_OK;
     case PRE3_OPT_K9_BF16X3: c->k9_b3 = value != 0 && c->dtype == PRE3_F32 && c->Wp != nullptr; return PRE3_OK;
+    case PRE3_OPT_CHOL_PERSIST: c->chol_persist = value != 0; return PRE3_OK;
     default: set_error("pre3_set_option: unknown option %d", option); return PRE3_E_ARG;
     }
 }
@@ -319,6 +324,7 @@ int pre3_get_option(pre3_ctx *c, int option, int *value_out)
     switch (option) {
     case PRE3_OPT_DEFER_HI: *value_out = c->defer_hi ? 1 : 0; return PRE3_OK;
     case PRE3_OPT_K9_BF16X3: *value_out = c->k9_b3 ? 1 : 0; return PRE3_OK;
+    case PRE3_OPT_CHOL_PERSIST: *value_out = cholp_usable(c, 1) ? 1 : 0; return PRE3_OK;
     default: set_error("pre3_get_option: unknown option %d", option); return PRE3_E_ARG;
     }
 }
@@ -801,7 +807,12 @@ int pre3_update_li(pre3_ctx *c)
             gathered = true;
             // ... and so does the first panel of the factorisation (row count read on the device, grid sized for all measurements)
             static const int spec_env = getenv("PRE3_CHOL_SPEC0") ? atoi(getenv("PRE3_CHOL_SPEC0")) : 1;
-            if (spec_env && round_up(2 * c->m, NB) <= c->rcap) { PRE3_TRY(launch_chol_first_spec(c, c->m)); first_done = true; }
+            if (spec_env && round_up(2 * c->m, NB) <= c->rcap) {
+                // fp32: the whole factorisation + solve is ONE launch that reads the row count on the device (pre3_cholp.hip)
+                if (cholp_usable(c, round_up(2 * c->m, NB) / NB)) { PRE3_TRY(launch_cholp(c, -1, round_up(2 * c->m, NB) / NB)); c->cholp_done = true; }
+                else PRE3_TRY(launch_chol_first_spec(c, c->m));
+                first_done = true;
+            }
         }
         PRE3_TRY(wait_mail(c, 8, c->seq_select)); n_li = c->mail_host[4];
     }

@@ -1,0 +1,16 @@
+// pre3_cholp.h -- the persistent factorisation + triangular solve (pre3_cholp.hip): host entry points
+#pragma once
+#include "pre3_internal.h"
+
+namespace pre3 {
+
+constexpr int CP_NTH = 768;          // crit: ten chain waves + two side waves; rows and strips use the first four waves
+constexpr int CP_MAX_NRB = 13;       // panels of 64 rows: the strips keep nrb - 1 blocks of W as bf16 planes in LDS (12 KB each) + 12 KB of scratch
+
+size_t cholp_flag_bytes();
+bool cholp_usable(const pre3_ctx *c, int nrb_max);
+// S (c->Smat, stride nrb * 64) and [HP | nu] (c->W) in place -> L and W = L^-1 [HP | nu], W's bf16 planes (c->Wp) included.
+// nrb < 0: the number of rows is read on the device (stats[4] measurements, as k_gather_li does); nrb_max bounds grid and LDS.
+int launch_cholp(pre3_ctx *c, int nrb, int nrb_max);
+
+}  // namespace pre3

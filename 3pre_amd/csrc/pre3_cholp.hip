@@ -1,0 +1,945 @@
+// pre3_cholp.hip -- update.m:32-33 (S = L L', W = L^-1 [HP | nu]) as ONE persistent launch (fp32 contexts, r <= 13 panels of 64).
+//
+// The launch-per-panel form (k_chol_step, pre3_update.hip) carries all W strips through every panel launch in lock-step with the
+// r x r factorisation and pays a launch boundary, a cold reload and a ramp per panel.  Here the r x r factorisation is a task graph
+// whose critical path never leaves ONE workgroup, and W is a blocked triangular solve on the matrix cores that trails it:
+//
+//   crit   (block 0, 12 waves)   for J = 0 .. nrb-1:  chain on the diagonal block D_J (chol_chain, pre3_chain.h) with X := I, so that
+//          M_J = inv(L_JJ) falls out of the same lock-step solve;  then, on the bf16 matrix cores from planes in LDS,
+//          L(J+1,J) = A(J+1,J) M_J' and D_{J+1} = A(J+1,J+1) - L(J+1,J) L(J+1,J)'.  Nothing on this path waits for another workgroup:
+//          the two tiles of row J+1 it needs (updated through panel J-1) are fetched by its two side waves WHILE the chain of panel J
+//          runs, and M_J / L(J+1,J) leave as bf16 planes through the same side waves.
+//   row i  (blocks 1.., i >= 2, 4 waves)  for J = 0 .. i-2:  L(i,J) = A(i,J) M_J' once M_J is published, then A(i,k) -= L(i,J) L(k,J)'
+//          for k = J+1 .. i.  After panel i-2 the row's two leading tiles go to crit (A(i,i-1) as planes, A(i,i) as f32).
+//   strip s (32 columns of [HP | nu], 4 waves)  for J = 0 .. nrb-1:  W_J = M_J (HP_J - sum_{K<J} L(J,K) W_K), the W_K as bf16 planes in
+//          LDS; epilogue: W in f32 and as the bf16 planes k_downdate_b3 reads.
+//
+// Every hand-off is: payload by 16-byte sc1 (write-through) stores, each storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier,
+// ONE lane stores the flag (agent scope); consumer: one lane polls the flag (sc1), workgroup barrier, then every load of the payload
+// is an sc1 buffer load (crit, rows) or a plain load behind ONE agent-scope acquire (strips: they are not latency critical and
+// share the planes through their XCD's L2).  Flags are monotonic words tagged with a per-launch epoch; every wait is bounded
+// (guard word stats[7], as in pre3_geomdev.h) and no access depends on a value that a give-up would leave undefined.
+#include <algorithm>
+#include <cstdlib>
+
+#include "pre3_internal.h"
+#include "pre3_geomdev.h"
+#include "pre3_chain.h"
+#include "pre3_cholp.h"
+
+namespace pre3 {
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef int frag_t __attribute__((ext_vector_type(4)));      // 8 bf16
+typedef float f4v_t __attribute__((ext_vector_type(4)));
+
+#ifdef PRE3_PROBE
+// wall-clock stamps (s_memrealtime, 100 MHz, chip-wide) of the last launch: [role 0 crit main, 1 crit side, 2..15 rows, 16 strip 0, 17 last strip][panel 16][slot 8]
+static __device__ unsigned long long g_cp[20 * 16 * 8];
+#define CP_CLK(role, J, slot) do { if ((threadIdx.x & 63) == 0) { unsigned long long t_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_cp[((role) * 16 + (J)) * 8 + (slot)] = t_; } } while (0)
+#define CP_STAMP(role, J, slot) do { if ((threadIdx.x & 63) == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_cp[((role) * 16 + (J)) * 8 + (slot)] = t_; } } while (0)
+#else
+#define CP_STAMP(role, J, slot)
+#define CP_CLK(role, J, slot)
+#endif
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cp_rsrc(const void *p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7fffffff, 0x00020000);
+}
+// 16-byte sc1 load / store at a byte offset (aux 16 = sc1: bypasses this CU's L1 / writes through)
+__device__ __forceinline__ u32x4_t ld16_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16); }
+__device__ __forceinline__ void st16_sc1(u32x4_t v, __amdgpu_buffer_rsrc_t r, unsigned off) { __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16); }
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ unsigned cf_load(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cf_store(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool cf_reached(unsigned v, unsigned target) { return (int)(v - target) >= 0; }
+// one lane: bounded poll (the same budget as bounded_wait)
+__device__ __forceinline__ void cf_wait(const unsigned *p, unsigned target, int32_t *guard)
+{
+    for (int spin = 0; spin < SPIN_LIMIT; ++spin) {
+        if (cf_reached(cf_load(p), target)) return;
+        // another wait of this launch has already given up: what it was waiting for will not come either, let the launch drain
+        if ((spin & 1023) == 1023 && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    atomicExch(guard, 1);
+}
+// the whole workgroup waits for a flag: lane 0 polls, everybody meets at the barrier
+__device__ __forceinline__ void wg_wait(const unsigned *p, unsigned target, int32_t *guard)
+{
+    if (threadIdx.x == 0) cf_wait(p, target, guard);
+    __syncthreads();
+}
+
+// x[0..7] -> the three bf16 planes' granules (as b3_split_store, values returned)
+__device__ __forceinline__ void b3_split3(const float (&x)[8], u32x4_t &a, u32x4_t &b, u32x4_t &c)
+{
+    bf16x8_t pa, pb, pc;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 ha = (__bf16)x[j];
+        const float r1 = x[j] - (float)ha;
+        const __bf16 hb = (__bf16)r1;
+        const float r2 = r1 - (float)hb;
+        pa[j] = ha; pb[j] = hb; pc[j] = (__bf16)r2;
+    }
+    a = __builtin_bit_cast(u32x4_t, pa); b = __builtin_bit_cast(u32x4_t, pb); c = __builtin_bit_cast(u32x4_t, pc);
+}
+
+// 64 x 64 x 64 on the bf16 matrix cores, six products per f32 product: acc(row, col) += sum_k A(row, k) B(col, k) for this wave's
+// 32 x 32 tile; fA[q][pl] / fB[q][pl]: the wave's fragments of k-step q, plane pl
+__device__ __forceinline__ void mma6(const frag_t (&fA)[4][3], const frag_t (&fB)[4][3], f32x16_t &acc, int q0 = 0, int q1 = 4)
+{
+#define CP_MMA(px, py) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fA[q][px]), __builtin_bit_cast(bf16x8_t, fB[q][py]), acc, 0, 0, 0)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (q >= q0 && q < q1) { CP_MMA(0, 0); CP_MMA(0, 1); CP_MMA(1, 0); CP_MMA(1, 1); CP_MMA(0, 2); CP_MMA(2, 0); }
+#undef CP_MMA
+}
+// the same with the A fragments read from an LDS plane block k-step by k-step (12 registers instead of 48)
+__device__ __forceinline__ void mma6_alds(const frag_t *Ablk, int half, int lane, const frag_t (&fB)[4][3], f32x16_t &acc)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const frag_t a0 = Ablk[q * 384 + half * 64 + lane], a1 = Ablk[q * 384 + 128 + half * 64 + lane], a2 = Ablk[q * 384 + 256 + half * 64 + lane];
+#define CP_MMA(ax, py) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ax), __builtin_bit_cast(bf16x8_t, fB[q][py]), acc, 0, 0, 0)
+        CP_MMA(a0, 0); CP_MMA(a0, 1); CP_MMA(a1, 0); CP_MMA(a1, 1); CP_MMA(a0, 2); CP_MMA(a2, 0);
+#undef CP_MMA
+    }
+}
+// fragments of one 64 x 64 plane block ([q 4][plane 3][half 2][lane 64] granules) from LDS / from global memory (sc1)
+__device__ __forceinline__ void frags_lds(const frag_t *blk, int half, int lane, frag_t (&f)[4][3])
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) f[q][pl] = blk[q * 384 + pl * 128 + half * 64 + lane];
+}
+// one granule of a plane block in global memory: the lane's part of the address in a VGPR, the block / k-step / plane part in an SGPR
+__device__ __forceinline__ frag_t ld_granule(__amdgpu_buffer_rsrc_t r, unsigned lane_off /* (half * 64 + lane) * 16 */, unsigned granule /* uniform */, int aux)
+{
+    return __builtin_bit_cast(frag_t, aux ? __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, granule * 16u, 16) : __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, granule * 16u, 0));
+}
+__device__ __forceinline__ void frags_sc1(__amdgpu_buffer_rsrc_t r, unsigned blk_granule, int half, int lane, frag_t (&f)[4][3])
+{
+    const unsigned lo = (unsigned)(half * 64 + lane) * 16u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) f[q][pl] = ld_granule(r, lo, blk_granule + q * 384 + pl * 128, 1);
+}
+__device__ __forceinline__ void frags_plain(const frag_t *blk, int half, int lane, frag_t (&f)[4][3])
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) f[q][pl] = blk[q * 384 + pl * 128 + half * 64 + lane];
+}
+
+// one f32 of a 32 x 32 accumulator tile in a row-major matrix: the lane's part of the address in a VGPR (voff), the register's part
+// (its row) and the tile's origin in an SGPR (soff) -- sixteen 64-bit addresses per tile would cost 32 registers
+__device__ __forceinline__ unsigned acc_voff(int lane, int ldm) { return (unsigned)((4 * (lane >> 5)) * ldm + (lane & 31)) * 4u; }
+__device__ __forceinline__ unsigned acc_soff(int e, int ldm) { return (unsigned)(((e & 3) + 8 * (e >> 2)) * ldm) * 4u; }
+__device__ __forceinline__ float ld_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); }
+__device__ __forceinline__ void st_f32(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0); }
+
+constexpr int CP_YS = NB + 1;                       // row stride of the f32 transposition buffers
+// accumulator layout of a 32 x 32 tile: register e of lane l holds (row (e&3) + 8 (e>>2) + 4 (l>>5), column l & 31)
+__device__ __forceinline__ int acc_row(int e, int lane) { return (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); }
+
+// Y (f32 [64][CP_YS], rows x k) -> plane block: granule job g in [0, 512): (q, half, lane) -> Y[32 half + r][16 q + 8 h + 0..7]
+__device__ __forceinline__ void y_granule(const float *Y, int g, u32x4_t &a, u32x4_t &b, u32x4_t &c, int &gi)
+{
+    const int q = g >> 7, half = (g >> 6) & 1, l = g & 63, r = l & 31, h = l >> 5;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = Y[(32 * half + r) * CP_YS + 16 * q + 8 * h + j];
+    b3_split3(x, a, b, c);
+    gi = q * 384 + half * 64 + l;                 // plane 0; planes are 128 granules apart
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// crit
+// ------------------------------------------------------------------------------------------------------------------------------
+struct CpArgs {
+    float *S; float *W; int ldw; int ld;
+    void *Sp; int sp_stride;             // plane blocks of S: block (rb, J) at (rb * sp_stride + J) * 1536 granules
+    void *Tp;                            // per row: the planes of A(i, i-1) handed to crit, 1536 granules each
+    void *Wp; int nst_total;             // k_downdate_b3's planes of W
+    unsigned *cf; unsigned base;         // flags, epoch
+    int32_t *status;                     // stats[6] (not positive definite), stats[7] (a wait gave up)
+    const int32_t *n_dev; int nrb; int nrb_max; int n_strips;
+};
+// A call passes its arguments in VGPRs: the callee makes the (wave-uniform) launch arguments scalar again, word by word
+__device__ __forceinline__ CpArgs cp_uniform(const CpArgs &v)
+{
+    CpArgs a;
+    const unsigned *src = reinterpret_cast<const unsigned *>(&v);
+    unsigned *dst = reinterpret_cast<unsigned *>(&a);
+#pragma unroll
+    for (unsigned w = 0; w < sizeof(CpArgs) / 4; ++w) dst[w] = (unsigned)__builtin_amdgcn_readfirstlane((int)src[w]);
+    return a;
+}
+constexpr int CF_MP = 0, CF_ROWL = 32, CF_ROWA = 32 * 65, CF_WORDS = 32 * 130;     // one 128-byte line per flag
+__device__ __forceinline__ unsigned *cf_rowL(unsigned *cf, int i) { return cf + CF_ROWL + 32 * i; }
+__device__ __forceinline__ unsigned *cf_rowA(unsigned *cf, int i) { return cf + CF_ROWA + 32 * i; }
+
+struct CritSmem {
+    ChSmem<float> ch;                                            // Ls, Xs, As | pipe, Bs
+    __attribute__((aligned(16))) frag_t MPl[B3_SGRAN];           // planes of M_J (built while the chain runs)
+    __attribute__((aligned(16))) frag_t T1p[B3_SGRAN];           // planes of A(J+1, J); after B1: the planes of L(J+1, J)
+};
+
+// panel 0: the raw blocks straight from S (written by the launch in front); all twelve waves
+__device__ __forceinline__ void crit_prologue(const CpArgs &a, int nrb, CritSmem &sm)
+{
+    auto &Ls = sm.ch.Ls; auto &Xs = sm.ch.Xs;
+    float *T2 = &sm.ch.Bs[0][0];
+    const int tid = threadIdx.x, lds = nrb * NB;
+    for (int idx = tid; idx < NB * NB; idx += blockDim.x) {
+        const int i = idx >> 6, c = idx & 63;
+        Ls[i][c] = a.S[(size_t)i * lds + c];
+        Xs[i][c] = i == c ? 1.f : 0.f;
+        if (nrb > 1) T2[i * NB + c] = a.S[(size_t)(NB + i) * lds + NB + c];
+    }
+    if (nrb > 1 && tid < 512) {                                   // planes of A(1, 0): 8 consecutive k of one row per job
+        const int q = tid >> 7, half = (tid >> 6) & 1, l = tid & 63, r = l & 31, h = l >> 5;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = a.S[(size_t)(NB + 32 * half + r) * lds + 16 * q + 8 * h + j];
+        u32x4_t p0, p1, p2;
+        b3_split3(x, p0, p1, p2);
+        frag_t *d = sm.T1p + q * 384 + half * 64 + l;
+        d[0] = __builtin_bit_cast(frag_t, p0); d[128] = __builtin_bit_cast(frag_t, p1); d[256] = __builtin_bit_cast(frag_t, p2);
+    }
+    __syncthreads();
+}
+
+// waves 0-9: the chain and the two products.  Barriers per panel: the chain's ten, then b0..b3 (crit_side keeps the same count).
+__device__ __forceinline__ void crit_main(const CpArgs &a, int nrb, CritSmem &sm)
+{
+    auto &Ls = sm.ch.Ls; auto &Xs = sm.ch.Xs;
+    float *Y = &sm.ch.As[0][0];                                  // B1's output (f32), alias of the chain's hand-off buffers
+    const float *T2 = &sm.ch.Bs[0][0];                           // A(J+1, J+1), f32 [64][64]
+    const int tid0 = threadIdx.x;
+    if ((tid0 >> 6) == 8) __builtin_amdgcn_s_setprio(3);
+    else if ((tid0 >> 6) == 9) __builtin_amdgcn_s_setprio(2);
+    bool bad = false;
+    for (int J = 0; J < nrb; ++J) {
+        if (tid0 == 0) { CP_STAMP(0, J, 0); CP_CLK(19, J, 0); }
+        {
+            typename ChW<float>::acc_t acc[ChW<float>::NBLK][ChW<float>::NBLK];
+            chol_chain<float, true>(sm.ch, acc, false, true, bad, [](int) {});
+        }
+        if (tid0 == 0) { CP_STAMP(0, J, 1); CP_CLK(19, J, 1); }
+        // Ls = L_JJ, Xs = M_J
+        // (the products' address arithmetic hangs off a value defined HERE: hoisted out of the panel loop it would live through
+        //  the chain, whose code already takes every register, and come back as scratch traffic inside the chain)
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        if (J + 1 >= nrb) break;
+        __syncthreads();                                                            // b0: MPl complete, T1p / T2 landed
+        if (tid0 == 0) CP_STAMP(0, J, 2);
+        const int wave = tid >> 6, lane = tid & 63, fa = (wave >> 1) & 1, fb = wave & 1;
+        if (wave < 4) {
+            // B1: L(J+1, J)(i, a) = sum_c A(J+1, J)(i, c) M_J(a, c)
+            frag_t fB[4][3];
+            frags_lds(sm.MPl, fb, lane, fB);
+            f32x16_t c1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) c1[e] = 0.f;
+            mma6_alds(sm.T1p, fa, lane, fB, c1);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Y[(32 * fa + acc_row(e, lane)) * CP_YS + 32 * fb + (lane & 31)] = c1[e];
+            if (tid0 == 0) CP_STAMP(0, J, 7);
+        } else if (wave < 8) {
+            // next chain's X block: the identity (M_J's f32 image is dead: its planes are complete)
+            for (int idx = tid - 256; idx < NB * NB; idx += 256) Xs[idx >> 6][idx & 63] = (idx >> 6) == (idx & 63) ? 1.f : 0.f;
+        }
+        __syncthreads();                                                            // b1: Y = L(J+1, J)
+        if (tid0 == 0) CP_STAMP(0, J, 4);
+        if (tid < 512) {
+            u32x4_t p0, p1, p2; int gi;
+            y_granule(Y, tid, p0, p1, p2, gi);
+            sm.T1p[gi] = __builtin_bit_cast(frag_t, p0); sm.T1p[gi + 128] = __builtin_bit_cast(frag_t, p1); sm.T1p[gi + 256] = __builtin_bit_cast(frag_t, p2);
+        }
+        __syncthreads();                                                            // b2: T1p = planes of L(J+1, J)
+        if (tid0 == 0) CP_STAMP(0, J, 5);
+        if (wave < 4) {
+            if (wave != 1) {
+                // B2: D_{J+1} = A(J+1, J+1) - L(J+1, J) L(J+1, J)'   (the tile above the diagonal is never read)
+                frag_t fB[4][3];
+                frags_lds(sm.T1p, fb, lane, fB);
+                float t2[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) t2[e] = T2[(32 * fa + acc_row(e, lane)) * NB + 32 * fb + (lane & 31)];
+                f32x16_t c2;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) c2[e] = 0.f;
+                mma6_alds(sm.T1p, fa, lane, fB, c2);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) Ls[32 * fa + acc_row(e, lane)][32 * fb + (lane & 31)] = t2[e] - c2[e];
+                if (tid0 == 0) CP_STAMP(0, J, 6);
+            }
+        } else {
+            // L(J+1, J) in f32 as part of the final factor: waves 4-9
+#pragma unroll 3
+            for (int idx = tid - 256; idx < NB * NB / 4; idx += 384) {
+                const float *yp = Y + (idx >> 4) * CP_YS + (idx & 15) * 4;
+                *reinterpret_cast<f4v_t *>(a.S + (size_t)((J + 1) * NB + (idx >> 4)) * (nrb * NB) + J * NB + (idx & 15) * 4) = f4v_t{ yp[0], yp[1], yp[2], yp[3] };
+            }
+        }
+        __syncthreads();                                                            // b3: Ls = D_{J+1}, Xs = I
+        if (tid0 == 0) CP_STAMP(0, J, 3);
+    }
+    if (bad && tid0 == 512) atomicExch(a.status, 1);
+}
+
+// waves 10, 11: M_J and L(J+1, J) leave through wave 10; both fetch the tiles of row J+1 while the chain of panel J runs
+__device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm)
+{
+    auto &Ls = sm.ch.Ls; auto &Xs = sm.ch.Xs;
+    float *T2 = &sm.ch.Bs[0][0];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lds = nrb * NB;
+    const __amdgpu_buffer_rsrc_t rSp = cp_rsrc(a.Sp);
+    int32_t *guard = a.status + 1;
+    // Fetch of the two tiles of row J+1 (published by its row workgroup: A(J+1, J+1) in f32, then A(J+1, J) as planes; flag = base + 2 once
+    // both are out) by LDS-DMA: no registers are held while the bytes travel.  State: 0 poll -> 1 test, issue the DMAs -> 2 wait for them
+    // -> 5 done.  Whatever is issued in one pipeline step of the chain is consumed `cool` steps later (an sc1 access takes 1-1.4 us, a step
+    // 0.6), and the loop's barriers are raw s_barriers: the chain's barriers are never held for memory.  (Each of these lines is read once
+    // per launch by this CU, so there is no older copy for its L1 to hold; the loads carry sc1 all the same.)
+    int fst = 5, cool = 0;
+    unsigned pv = 0;
+    for (int J = 0; J < nrb; ++J) {
+        const bool more = J + 1 < nrb;
+        const int fr = J + 1;                                     // the row whose tiles this panel's products need
+        const unsigned *fflag = cf_rowA(a.cf, fr < 64 ? fr : 63);
+        fst = (more && J > 0) ? 0 : 5;                            // (panel 0's tiles came with the prologue)
+        cool = 0;
+        auto fetch_step = [&](bool blocking) {
+            if (!blocking && cool > 0) { --cool; return; }
+            if (fst == 0) { pv = cf_load(fflag); fst = 1; cool = 2; }
+            else if (fst == 1) {
+                if (cf_reached(pv, a.base + 2)) {
+                    const frag_t *src1 = static_cast<const frag_t *>(a.Tp) + (size_t)fr * B3_SGRAN + lane;
+#pragma unroll
+                    for (int t = 0; t < 24; ++t)
+                        __builtin_amdgcn_global_load_lds(src1 + t * 64, (__attribute__((address_space(3))) void *)(sm.T1p + t * 64), 16, 0, 16);
+                    // A(fr, fr): 1024 granules of 4 floats; granule g = t * 64 + lane -> row g >> 4, columns 4 (g & 15); LDS image [64][64]
+                    const float *src2 = a.S + (size_t)(fr * NB + (lane >> 4)) * lds + fr * NB + (lane & 15) * 4;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t)
+                        __builtin_amdgcn_global_load_lds(src2 + (size_t)(4 * t) * lds, (__attribute__((address_space(3))) void *)(T2 + (t * 64) * 4), 16, 0, 16);
+                    fst = 2; cool = 2;
+                    CP_STAMP(1, J, 0);
+                } else { pv = cf_load(fflag); cool = 2; }
+            } else if (fst == 2) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                fst = 5;
+                CP_STAMP(1, J, 3);
+            }
+        };
+        // rows 8 sp .. 8 sp + 7 of M_J (final once the z wave has passed them) -> planes in LDS and in Sp(J, J)
+        auto publish_m_rows = [&](int sp) {
+            const int arow = 8 * sp + (lane >> 3), cg = lane & 7;                   // 8 consecutive c of one row per lane
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = Xs[arow][8 * cg + j];
+            u32x4_t p0, p1, p2;
+            b3_split3(x, p0, p1, p2);
+            const int q = cg >> 1, h = cg & 1, half = arow >> 5, r = arow & 31;
+            const int gi = q * 384 + half * 64 + 32 * h + r;
+            sm.MPl[gi] = __builtin_bit_cast(frag_t, p0); sm.MPl[gi + 128] = __builtin_bit_cast(frag_t, p1); sm.MPl[gi + 256] = __builtin_bit_cast(frag_t, p2);
+            const unsigned gb = ((unsigned)(J * a.sp_stride + J) * B3_SGRAN + gi) * 16u;
+            st16_sc1(p0, rSp, gb); st16_sc1(p1, rSp, gb + 128 * 16); st16_sc1(p2, rSp, gb + 256 * 16);
+        };
+        // columns 8 sp .. 8 sp + 7 of L_JJ (final once the factor wave has passed them; zero above the diagonal) to S -- part of the final
+        // factor (k_gain; not read again in this launch): wave 11, lane = row
+        auto publish_l_cols = [&](int sp) {
+            const int i = lane, C = 8 * sp;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int c4 = C + 4 * u;
+                f4v_t w = *reinterpret_cast<const f4v_t *>(&Ls[i][c4]);
+                w.x = c4 <= i ? w.x : 0.f; w.y = c4 + 1 <= i ? w.y : 0.f; w.z = c4 + 2 <= i ? w.z : 0.f; w.w = c4 + 3 <= i ? w.w : 0.f;
+                *reinterpret_cast<f4v_t *>(a.S + (size_t)(J * NB + i) * lds + J * NB + c4) = w;
+            }
+        };
+#pragma unroll 1
+        for (int k = -1; k <= CH_NSP; ++k) {                     // one barrier per pipeline step of the chain
+            // the fetch first: it is the only thing here that waits on memory (the compiler's wait covers every older operation of the
+            // wave, so this step's stores must come after it -- a store's write-through acknowledge takes about as long as a step)
+            if (wave == 11) fetch_step(false);                    // (no LDS access of its own in this loop: nothing for the compiler to order behind the DMAs)
+            if (wave == 10) {
+                if (k == -1 && J > 0) {      // L(J, J-1)'s planes (stored during the last products) have drained: publish
+                    drain_stores();
+                    if (lane == 0) cf_store(cf_rowL(a.cf, J), a.base + (unsigned)J);
+                    CP_STAMP(1, J, 5);
+                }
+                if (k >= 1) publish_l_cols(k - 1);
+                if (k >= 2) publish_m_rows(k - 2);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): this step's LDS writes have landed
+            __builtin_amdgcn_s_barrier();                        // (raw: __syncthreads() would also wait for every LDS-DMA in flight)
+        }
+        // chain done: Ls = L_JJ, Xs = M_J (rows 56..63 not yet in planes)
+        if (wave == 10) {
+            // M_J is out as soon as the last rows' stores have drained: the rows' (and with them the next panel's) clock starts at this flag
+            publish_m_rows(7);
+            drain_stores();
+            if (lane == 0) cf_store(a.cf + CF_MP, a.base + (unsigned)J + 1);
+            CP_STAMP(1, J, 4);
+        }
+        if (!more) break;
+        {   // the fetch must be complete before the products (normally it is: the tiles arrive mid-chain)
+            int spin = 0;
+            while (wave == 11 && fst < 5 && spin < SPIN_LIMIT) {
+                const int before = fst;
+                fetch_step(true);
+                if (fst == before) {
+                    __builtin_amdgcn_s_sleep(1); ++spin;
+                    if ((spin & 1023) == 1023 && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                }
+            }
+            if (wave == 11 && fst < 5 && lane == 0) atomicExch(guard, 1);
+        }
+        CP_STAMP(wave == 10 ? 1 : 18, J, wave == 10 ? 7 : 2);                         // arrival at b0
+        __syncthreads();                                                            // b0
+        __syncthreads();                                                            // b1
+        __syncthreads();                                                            // b2: T1p = planes of L(J+1, J), Y = its f32 image
+        if (wave == 10) {
+            // L(J+1, J) leaves as planes: 24 granules per lane in three batches (the LDS reads of a batch first); the flag follows at the first
+            // step of the next chain, once these stores have drained (the rows need it only after their own L(i, J))
+#pragma unroll
+            for (int b8 = 0; b8 < 3; ++b8) {
+                frag_t g8[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) g8[t] = sm.T1p[(b8 * 8 + t) * 64 + lane];
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    st16_sc1(__builtin_bit_cast(u32x4_t, g8[t]), rSp, ((unsigned)((J + 1) * a.sp_stride + J) * B3_SGRAN + (b8 * 8 + t) * 64 + lane) * 16u);
+            }
+            CP_STAMP(1, J, 6);
+        }
+        __syncthreads();                                                            // b3
+    }
+}
+
+__device__ __forceinline__ void crit_body(const CpArgs &a, int nrb, unsigned char *smem_raw)
+{
+    CritSmem &sm = *reinterpret_cast<CritSmem *>(smem_raw);
+    crit_prologue(a, nrb, sm);
+    if (threadIdx.x < 640) crit_main(a, nrb, sm);
+    else crit_side(a, nrb, sm);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// row i >= 2
+// ------------------------------------------------------------------------------------------------------------------------------
+struct RowSmem {
+    __attribute__((aligned(16))) frag_t OL[B3_SGRAN];            // planes of the row's own L(i, J)
+    __attribute__((aligned(16))) frag_t NA[B3_SGRAN];            // planes of A(i, J): the operand of the next L(i, J)
+    float patch[12][32 * 33];                                    // wave-private transposition patches
+    unsigned cnt[4];                                             // arrivals of the four waves behind a hand-over to crit; [2]: bulk release
+    unsigned tick[16];                                           // per panel: the next bulk item
+};
+
+// all lanes of a wave poll one flag (one request); bounded
+__device__ __forceinline__ void wave_wait(const unsigned *p, unsigned target, int32_t *guard)
+{
+    for (int spin = 0; spin < SPIN_LIMIT; ++spin) {
+        if (cf_reached(cf_load(p), target)) return;
+        if ((spin & 1023) == 1023 && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if ((threadIdx.x & 63) == 0) atomicExch(guard, 1);
+}
+// lane l < n polls the flag of row k0 + l: ONE wait for every operand of a panel's bulk tiles
+__device__ __forceinline__ void wave_wait_rows(unsigned *cf, int k0, int n, unsigned target, int lane, int32_t *guard)
+{
+    const unsigned *p = cf_rowL(cf, k0 + (lane < n ? lane : 0));
+    for (int spin = 0; spin < SPIN_LIMIT; ++spin) {
+        const bool ok = lane >= n || cf_reached(cf_load(p), target);
+        if (__all(ok)) return;
+        if ((spin & 1023) == 1023 && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (lane == 0) atomicExch(guard, 1);
+}
+__device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }
+
+// a wave's 32 x 32 tile (accumulator layout, quadrant (fa, fb) of a 64 x 64 block, rows x k) -> its 128 granules of the block's planes:
+// through the wave's private patch; fn(gi, p0, p1, p2) receives plane 0's granule index (planes are 128 granules apart)
+template <typename F>
+__device__ __forceinline__ void wave_tile_granules(float *patch, const float (&v)[16], int fa, int fb, int lane, F &&fn)
+{
+#pragma unroll
+    for (int e = 0; e < 16; ++e) patch[acc_row(e, lane) * 33 + (lane & 31)] = v[e];
+    wave_lds_sync();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int g = lane + 64 * u, r = g & 31, cg = g >> 5;            // row r, columns 8 cg .. 8 cg + 7 of the quadrant
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = patch[r * 33 + 8 * cg + j];
+        u32x4_t p0, p1, p2;
+        b3_split3(x, p0, p1, p2);
+        fn((2 * fb + (cg >> 1)) * 384 + fa * 64 + 32 * (cg & 1) + r, p0, p1, p2);
+    }
+    wave_lds_sync();
+}
+
+// Row i: twelve waves.  Waves 0-3 are the row's critical path -- L(i, J) as soon as M_J is out, then the tile the next panel (or crit)
+// needs; waves 4-11 work through the other tiles of the panel, one quadrant per item, with no workgroup barrier between items.
+__device__ __attribute__((noinline)) void row_body(CpArgs a_v, int nrb_v, int i_v)
+{
+    const CpArgs a = cp_uniform(a_v);
+    const int nrb = __builtin_amdgcn_readfirstlane(nrb_v), i = __builtin_amdgcn_readfirstlane(i_v);
+    extern __shared__ __attribute__((aligned(16))) unsigned char cp_smem[];
+    RowSmem &sm = *reinterpret_cast<RowSmem *>(cp_smem);
+    const int tid = threadIdx.x, wave = tid >> 6, lane_in = tid & 63;
+    const int lds = nrb * NB;
+    const __amdgpu_buffer_rsrc_t rS = cp_rsrc(a.S), rSp = cp_rsrc(a.Sp), rTp = cp_rsrc(a.Tp);
+    int32_t *guard = a.status + 1;
+    float *patch = sm.patch[wave];
+    auto tile_soff = [&](int k) { return (unsigned)((i * NB) * lds + k * NB) * 4u; };
+    // NA <- planes of the raw A(i, 0)
+    if (tid < 512) {
+        const int q = tid >> 7, half = (tid >> 6) & 1, l = tid & 63, r = l & 31, h = l >> 5;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = a.S[(size_t)(i * NB + 32 * half + r) * lds + 16 * q + 8 * h + j];
+        u32x4_t p0, p1, p2;
+        b3_split3(x, p0, p1, p2);
+        frag_t *d = sm.NA + q * 384 + half * 64 + l;
+        d[0] = __builtin_bit_cast(frag_t, p0); d[128] = __builtin_bit_cast(frag_t, p1); d[256] = __builtin_bit_cast(frag_t, p2);
+    }
+    if (tid < 4) sm.cnt[tid] = 0;
+    if (tid < 16) sm.tick[tid] = 0;
+    __syncthreads();
+    const int lane0 = lane_in;
+    for (int J = 0; J + 2 <= i; ++J) {
+        const bool last = J + 2 == i;                           // after this panel the row's leading tiles go to crit
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));                          // (address arithmetic is redone per panel instead of living in registers across panels)
+        auto quad_voff = [&](int fa, int fb) { return acc_voff(lane, lds) + (unsigned)((32 * fa) * lds + 32 * fb) * 4u; };
+        if (wave < 4) {
+            // ---- L(i, J) = A(i, J) M_J'
+            const int fa = (wave >> 1) & 1, fb = wave & 1;
+            wave_wait(a.cf + CF_MP, a.base + (unsigned)J + 1, guard);
+            if (lane == 0 && wave == 0 && i < 16) CP_STAMP(i, J, 0);
+            frag_t fB[4][3];
+            frags_sc1(rSp, (unsigned)(J * a.sp_stride + J) * B3_SGRAN, fb, lane, fB);
+            f32x16_t c1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) c1[e] = 0.f;
+            mma6_alds(sm.NA, fa, lane, fB, c1);
+            float v[16];
+            const unsigned tv = quad_voff(fa, fb);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { v[e] = c1[e]; st_f32(c1[e], rS, tv, tile_soff(J) + acc_soff(e, lds)); }      // the final factor (not read again here)
+            wave_tile_granules(patch, v, fa, fb, lane, [&](int gi, u32x4_t p0, u32x4_t p1, u32x4_t p2) {
+                sm.OL[gi] = __builtin_bit_cast(frag_t, p0); sm.OL[gi + 128] = __builtin_bit_cast(frag_t, p1); sm.OL[gi + 256] = __builtin_bit_cast(frag_t, p2);
+                const unsigned gb = ((unsigned)(i * a.sp_stride + J) * B3_SGRAN + gi) * 16u;
+                st16_sc1(p0, rSp, gb); st16_sc1(p1, rSp, gb + 128 * 16); st16_sc1(p2, rSp, gb + 256 * 16);
+            });
+            drain_stores();
+        }
+        __syncthreads();                                        // OL complete and drained; every tile store of the previous panel is ordered
+        if (tid == 0) { cf_store(cf_rowL(a.cf, i), a.base + (unsigned)J + 1); if (i < 16) CP_STAMP(i, J, 1); }
+        if (wave < 4) {
+            // ---- the tile the next panel starts from: A(i, J+1) -= L(i, J) L(J+1, J)'
+            const int fa = (wave >> 1) & 1, fb = wave & 1;
+            const unsigned tv = quad_voff(fa, fb);
+            frag_t fB[4][3];
+            float v[16];
+            f32x16_t c2;
+            if (last) {
+                // the diagonal tile A(i, i) -= L(i, J) L(i, J)' needs nothing from outside: it goes to crit (in f32) while L(J+1, J) is on its way
+                frags_lds(sm.OL, fb, lane, fB);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = ld_f32(rS, tv, tile_soff(i) + acc_soff(e, lds));
+#pragma unroll
+                for (int e = 0; e < 16; ++e) c2[e] = 0.f;
+                mma6_alds(sm.OL, fa, lane, fB, c2);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) patch[acc_row(e, lane) * 33 + (lane & 31)] = v[e] - c2[e];
+                wave_lds_sync();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {                    // 32 rows x 8 pieces of 16 bytes
+                    const int g = lane + 64 * u, r = g >> 3, c4 = (g & 7) * 4;
+                    const float *y = patch + r * 33 + c4;
+                    st16_sc1(__builtin_bit_cast(u32x4_t, f4v_t{ y[0], y[1], y[2], y[3] }), rS, (unsigned)(((size_t)(i * NB + 32 * fa + r) * lds + i * NB + 32 * fb + c4) * 4));
+                }
+                wave_lds_sync();
+                if (lane == 0 && wave == 0 && i < 16) CP_STAMP(i, J, 3);
+            }
+            wave_wait(cf_rowL(a.cf, J + 1), a.base + (unsigned)J + 1, guard);
+            if (lane == 0 && wave == 0 && i < 16) CP_STAMP(i, J, 2);
+            frags_sc1(rSp, (unsigned)((J + 1) * a.sp_stride + J) * B3_SGRAN, fb, lane, fB);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = ld_f32(rS, tv, tile_soff(J + 1) + acc_soff(e, lds));
+#pragma unroll
+            for (int e = 0; e < 16; ++e) c2[e] = 0.f;
+            mma6_alds(sm.OL, fa, lane, fB, c2);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] -= c2[e];
+            if (!last) {
+                wave_tile_granules(patch, v, fa, fb, lane, [&](int gi, u32x4_t p0, u32x4_t p1, u32x4_t p2) {
+                    sm.NA[gi] = __builtin_bit_cast(frag_t, p0); sm.NA[gi + 128] = __builtin_bit_cast(frag_t, p1); sm.NA[gi + 256] = __builtin_bit_cast(frag_t, p2);
+                });
+            } else {
+                // to crit, as planes; the flag's second stage: both tiles are out
+                wave_tile_granules(patch, v, fa, fb, lane, [&](int gi, u32x4_t p0, u32x4_t p1, u32x4_t p2) {
+                    const unsigned gb = ((unsigned)i * B3_SGRAN + gi) * 16u;
+                    st16_sc1(p0, rTp, gb); st16_sc1(p1, rTp, gb + 128 * 16); st16_sc1(p2, rTp, gb + 256 * 16);
+                });
+                drain_stores();
+                if (lane == 0 && atomicAdd(&sm.cnt[0], 1u) == 3u) { cf_store(cf_rowA(a.cf, i), a.base + 2u); if (i < 16) CP_STAMP(i, J, 4); }
+            }
+        }
+        if (!last) {
+            // ---- the other tiles, A(i, k) -= L(i, J) L(k, J)' for k = J+2 .. i: item = (tile, quadrant).  Every wave draws items from a ticket
+            //      counter in LDS -- waves 4-11 from the start of the panel, waves 0-3 once the leading tile is done -- with no workgroup barrier
+            //      between items.
+            const int n_items = 4 * (i - J - 1);
+            // Rows J+2 .. i-1 have published L(k, J): wave 4 waits for all of them with ONE poll loop, issues ONE agent-scope acquire for the
+            // workgroup and, once its invalidate has completed, releases the other waves through a word in LDS -- their operand loads are then
+            // plain loads, served by the XCD's L2 (the same block is wanted by every row below it; the rows share crit's XCD, see k_cholp)
+            if (wave == 4) {
+                if (i - J - 2 > 0) {
+                    wave_wait_rows(a.cf, J + 2, i - J - 2, a.base + (unsigned)J + 1, lane, guard);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (lane == 0) __hip_atomic_store(&sm.cnt[2], (unsigned)J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                for (int spin = 0; spin < SPIN_LIMIT; ++spin) {
+                    if (__hip_atomic_load(&sm.cnt[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= (unsigned)J + 1) break;
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            auto ticket = [&]() { return __builtin_amdgcn_readfirstlane(lane == 0 ? (int)atomicAdd(&sm.tick[J], 1u) : 0); };
+            int t = ticket();
+            if (t < n_items) {
+                // the B fragments of the NEXT item are requested k-step by k-step into the registers the current item has just multiplied from
+                frag_t fB[4][3];
+                auto load_bq = [&](int tt, int q, frag_t (&d)[4][3]) {
+                    const int k = J + 2 + (tt >> 2), fb = tt & 1;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        d[q][pl] = k < i ? ld_granule(rSp, (unsigned)(fb * 64 + lane) * 16u, (unsigned)(k * a.sp_stride + J) * B3_SGRAN + q * 384 + pl * 128, 0)
+                                         : sm.OL[q * 384 + pl * 128 + fb * 64 + lane];
+                };
+#pragma unroll
+                for (int q = 0; q < 4; ++q) load_bq(t, q, fB);
+                while (t < n_items) {
+                    const int tn = ticket();                     // the next item (its operands are requested during this one)
+                    const int k = J + 2 + (t >> 2), fa = (t >> 1) & 1, fb = t & 1;
+                    const unsigned tv = quad_voff(fa, fb);
+                    const bool nx = tn < n_items;
+                    float v[16];
+                    f32x16_t c2;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) c2[e] = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const frag_t *ap = sm.OL + q * 384 + fa * 64 + lane;
+                        const frag_t a0 = ap[0], a1 = ap[128], a2 = ap[256];
+#define RW_MMA(ax, py) c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ax), __builtin_bit_cast(bf16x8_t, fB[q][py]), c2, 0, 0, 0)
+                        RW_MMA(a0, 0); RW_MMA(a0, 1); RW_MMA(a1, 0); RW_MMA(a1, 1); RW_MMA(a0, 2); RW_MMA(a2, 0);
+#undef RW_MMA
+                        if (q == 0) {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) v[e] = ld_f32(rS, tv, tile_soff(k) + acc_soff(e, lds));
+                        }
+                        if (nx) load_bq(tn, q, fB);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) st_f32(v[e] - c2[e], rS, tv, tile_soff(k) + acc_soff(e, lds));
+                    t = tn;
+                }
+            }
+        }
+        __syncthreads();                                        // the panel's tiles are stored; NA complete
+        if (tid == 0 && i < 16) CP_STAMP(i, J, 5);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// strip s: 32 columns of [HP | nu]
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr int CP_WS = 32 + 1;                        // row stride of the strip's f32 transposition buffer
+constexpr int CP_WGRAN = 4 * 3 * 64;                 // granules of one 64 x 32 block of W as B-operand planes: [q 4][plane 3][lane 64]
+
+__device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int s_v)
+{
+    const CpArgs a = cp_uniform(a_v);
+    const int nrb = __builtin_amdgcn_readfirstlane(nrb_v), s = __builtin_amdgcn_readfirstlane(s_v);
+    extern __shared__ __attribute__((aligned(16))) unsigned char cp_smem[];
+    // Eight waves: wave (fa, par) owns row half fa of the 64 x 32 block and every fourth operand block (or k-step) par; the four shares meet
+    // through two f32 buffers.  LDS: [nrb - 1] blocks of W as B-operand planes | CP (the current right-hand side's planes; Yw aliases it) |
+    // Yw2 aliases the LAST plane slot, which is written at the end of step nrb - 2 and not read after that step's last term.
+    frag_t *WPl = reinterpret_cast<frag_t *>(cp_smem);                  // [nrb - 1][CP_WGRAN]
+    frag_t *CP = WPl + (size_t)(nrb > 1 ? nrb - 1 : 0) * CP_WGRAN;      // [CP_WGRAN]
+    float *Yw = reinterpret_cast<float *>(CP);                          // f32 [64][CP_WS] (8.4 KB), alias of CP: used strictly before / after it
+    float *Yw2 = nrb > 1 ? reinterpret_cast<float *>(WPl + (size_t)(nrb - 2) * CP_WGRAN) : reinterpret_cast<float *>(CP + CP_WGRAN);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int fa = wave & 1, par = wave >> 1;
+    const int c0 = s * 32, lcol = lane & 31;
+    int32_t *guard = a.status + 1;
+    frag_t *Wp = static_cast<frag_t *>(a.Wp);
+    const __amdgpu_buffer_rsrc_t rW = cp_rsrc(a.W), rSp = cp_rsrc(a.Sp);
+    const unsigned wvoff = acc_voff(lane, a.ldw) + (unsigned)((32 * fa) * a.ldw + c0) * 4u;
+    const unsigned plo = (unsigned)(fa * 64 + lane) * 16u;               // this lane's place in a plane block's row half
+    float *yrow = Yw + (32 * fa) * CP_WS + lcol, *yrow2 = Yw2 + (32 * fa) * CP_WS + lcol;
+    // the four shares of a 64 x 32 tile -> their sum in the par == 0 waves (three barriers; Yw / Yw2 must be free on entry)
+    auto reduce4 = [&](f32x16_t &v) {
+        if (par == 1) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) yrow[acc_row(e, lane) * CP_WS] = v[e];
+        } else if (par == 3) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) yrow2[acc_row(e, lane) * CP_WS] = v[e];
+        }
+        __syncthreads();
+        if (par == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] += yrow[acc_row(e, lane) * CP_WS];
+        } else if (par == 2) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] += yrow2[acc_row(e, lane) * CP_WS];
+        }
+        __syncthreads();
+        if (par == 2) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) yrow[acc_row(e, lane) * CP_WS] = v[e];
+        }
+        __syncthreads();
+        if (par == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] += yrow[acc_row(e, lane) * CP_WS];
+        }
+    };
+    // f32 [64][32] tile in Yw -> B-operand planes; 256 jobs (q, lane), every thread joins the barrier
+    auto tile_to_planes = [&](int J, bool keep, bool to_wp) {
+        const int q = (tid >> 6) & 3, l = tid & 63, col = l & 31, h = l >> 5;
+        u32x4_t p0, p1, p2;
+        if (tid < 256) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = Yw[(16 * q + 8 * h + j) * CP_WS + col];
+            b3_split3(x, p0, p1, p2);
+        }
+        __syncthreads();                                                 // every read of Yw is done: CP (its alias) may be written
+        if (tid < 256) {
+            if (!keep && !to_wp) {
+                CP[q * 192 + l] = __builtin_bit_cast(frag_t, p0); CP[q * 192 + 64 + l] = __builtin_bit_cast(frag_t, p1); CP[q * 192 + 128 + l] = __builtin_bit_cast(frag_t, p2);
+            }
+            if (keep) {
+                frag_t *d = WPl + (size_t)J * CP_WGRAN + q * 192 + l;
+                d[0] = __builtin_bit_cast(frag_t, p0); d[64] = __builtin_bit_cast(frag_t, p1); d[128] = __builtin_bit_cast(frag_t, p2);
+            }
+            if (to_wp) {
+                // k_downdate_b3's image: block (column block of 128, stage of 16 k) = [plane 3][fragment 4][lane 64]
+                frag_t *d = Wp + ((size_t)(c0 >> 7) * a.nst_total + 4 * J + q) * B3_GRAN + ((c0 >> 5) & 3) * 64 + l;
+                d[0] = __builtin_bit_cast(frag_t, p0); d[256] = __builtin_bit_cast(frag_t, p1); d[512] = __builtin_bit_cast(frag_t, p2);
+            }
+        }
+    };
+#define ST_MMA(fa_, bb) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa_), __builtin_bit_cast(bf16x8_t, bb), acc, 0, 0, 0)
+    // acc of wave (fa, par): this wave's share of  sum_K L(J, K) W_K - HP_J  for the step about to be solved (-HP_J rides with par 0; blocks
+    // K = par (mod 4); the newest block K = J-1 is split by k-steps instead).  It is accumulated AHEAD of need: the terms K <= J-2 of step J
+    // while the strip waits for M_{J-1}, the last term as soon as W_{J-1} exists -- when M_J arrives only one product and the epilogue are left.
+    f32x16_t acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = par == 0 ? -ld_f32(rW, wvoff, acc_soff(e, a.ldw)) : 0.f;
+    // HP_{J+1} (raw, cold in HBM) is requested one step ahead by the par == 0 waves: nothing later in a step waits for it
+    float hp[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) hp[e] = (par == 0 && nrb > 1) ? ld_f32(rW, wvoff, (unsigned)(NB * a.ldw) * 4u + acc_soff(e, a.ldw)) : 0.f;
+    for (int J = 0; J < nrb; ++J) {
+        // (1) right-hand side C_J = HP_J - sum: the shares meet in the par == 0 waves, then C_J as B-operand planes (CP)
+        reduce4(acc);
+        __syncthreads();
+        if (par == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) yrow[acc_row(e, lane) * CP_WS] = -acc[e];
+        }
+        __syncthreads();
+        tile_to_planes(J, false, false);                                 // -> CP
+        if (tid == 0 && (s == 0 || s == a.n_strips - 1)) CP_STAMP(s == 0 ? 16 : 17, J, 3);
+        // (2) while M_J is on its way: the terms K <= J-1 of step J+1
+        const bool more = J + 1 < nrb;
+        if (more) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = -hp[e];
+            if (J + 2 < nrb) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) hp[e] = par == 0 ? ld_f32(rW, wvoff, (unsigned)((J + 2) * NB * a.ldw) * 4u + acc_soff(e, a.ldw)) : 0.f;
+            }
+            if (J >= 1) {
+                // L(J+1, K), K <= J-1, were published during panel J-1; plain loads (shared through the XCD's L2) behind the acquire thread 0
+                // issued in the previous step's (4) -- its invalidate has run in the shadow of that term and of (1)
+                if (tid == 448) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0 && (s == 0 || s == a.n_strips - 1)) CP_STAMP(s == 0 ? 16 : 17, J, 0);
+                // blocks K_u = par + 4 u: the fragments of the next block are requested, k-step by k-step, into the registers the current block
+                // has just multiplied from
+                const int nb = par <= J - 1 ? (J - 1 - par) / 4 + 1 : 0;
+                const unsigned row0 = (unsigned)((J + 1) * a.sp_stride + par) * B3_SGRAN;
+                frag_t f0[4][3];
+                auto loadq = [&](int u, int q) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) f0[q][pl] = ld_granule(rSp, plo, row0 + (unsigned)(4 * u) * B3_SGRAN + q * 384 + pl * 128, 0);
+                };
+                if (nb > 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) loadq(0, q);
+                }
+                for (int u = 0; u < nb; ++u) {
+                    const frag_t *wb = WPl + (size_t)(par + 4 * u) * CP_WGRAN + lane;
+                    const bool nx = u + 1 < nb;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const frag_t b0 = wb[q * 192], b1 = wb[q * 192 + 64], b2 = wb[q * 192 + 128];
+                        ST_MMA(f0[q][0], b0); ST_MMA(f0[q][0], b1); ST_MMA(f0[q][1], b0); ST_MMA(f0[q][1], b1); ST_MMA(f0[q][0], b2); ST_MMA(f0[q][2], b0);
+                        if (nx) loadq(u + 1, q);
+                    }
+                }
+            }
+        }
+        // (3) W_J = M_J C_J: wave (fa, par) multiplies k-step par; M_J by sc1 loads (one lane polls, barrier, then every wave loads)
+        if (tid == 0 && (s == 0 || s == a.n_strips - 1)) CP_STAMP(s == 0 ? 16 : 17, J, 4);
+        wg_wait(a.cf + CF_MP, a.base + (unsigned)J + 1, guard);
+        if (tid == 0 && (s == 0 || s == a.n_strips - 1)) CP_STAMP(s == 0 ? 16 : 17, J, 1);
+        f32x16_t wacc;
+        {
+            frag_t fM[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) fM[pl] = ld_granule(rSp, plo, (unsigned)(J * a.sp_stride + J) * B3_SGRAN + par * 384 + pl * 128, 1);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) wacc[e] = 0.f;
+            const frag_t b0 = CP[par * 192 + lane], b1 = CP[par * 192 + 64 + lane], b2 = CP[par * 192 + 128 + lane];
+#define SM_MMA(px, bb) wacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fM[px]), __builtin_bit_cast(bf16x8_t, bb), wacc, 0, 0, 0)
+            SM_MMA(0, b0); SM_MMA(0, b1); SM_MMA(1, b0); SM_MMA(1, b1); SM_MMA(0, b2); SM_MMA(2, b0);
+        }
+        __syncthreads();                                                 // CP's reads are done (Yw aliases it)
+        reduce4(wacc);
+        __syncthreads();
+        if (tid == 0 && (s == 0 || s == a.n_strips - 1)) CP_STAMP(s == 0 ? 16 : 17, J, 5);
+        if (par == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                yrow[acc_row(e, lane) * CP_WS] = wacc[e];
+                st_f32(wacc[e], rW, wvoff, (unsigned)(J * NB * a.ldw) * 4u + acc_soff(e, a.ldw));
+            }
+        }
+        __syncthreads();
+        tile_to_planes(J, more, c0 < a.ld + NB);
+        __syncthreads();
+        if (tid == 0 && (s == 0 || s == a.n_strips - 1)) CP_STAMP(s == 0 ? 16 : 17, J, 2);
+        // (4) the newest term of step J+1: L(J+1, J) W_J, one k-step per wave; L(J+1, J) is published about now (sc1 loads)
+        if (more) {
+            // the next step's (2) reads L(J+2, K), K <= J, by plain loads: once row J+2 has published them, thread 0 issues the acquire for those
+            // loads; its invalidate runs in the shadow of this term and of the next step's (1)
+            if (wave == 7) {
+                // rows J+1 and (if it exists) J+2 have published their L(., J): one poll loop for both flags (lane 0 / lane 1)
+                wave_wait_rows(a.cf, J + 1, J + 2 < nrb ? 2 : 1, a.base + (unsigned)J + 1, lane, guard);
+                if (J + 2 < nrb) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            if (tid == 0 && (s == 0 || s == a.n_strips - 1)) CP_STAMP(s == 0 ? 16 : 17, J, 6);
+            const frag_t *wb = WPl + (size_t)J * CP_WGRAN + lane;
+            frag_t fL[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) fL[pl] = ld_granule(rSp, plo, (unsigned)((J + 1) * a.sp_stride + J) * B3_SGRAN + par * 384 + pl * 128, 1);
+            const frag_t b0 = wb[par * 192], b1 = wb[par * 192 + 64], b2 = wb[par * 192 + 128];
+            ST_MMA(fL[0], b0); ST_MMA(fL[0], b1); ST_MMA(fL[1], b0); ST_MMA(fL[1], b1); ST_MMA(fL[0], b2); ST_MMA(fL[2], b0);
+            if (tid == 0 && (s == 0 || s == a.n_strips - 1)) CP_STAMP(s == 0 ? 16 : 17, J, 7);
+        }
+    }
+#undef ST_MMA
+#undef SM_MMA
+}
+
+__global__ __launch_bounds__(CP_NTH) void k_cholp(CpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char cp_smem[];
+    int nrb = a.nrb;
+    if (a.n_dev != nullptr) {                                   // the row count is still on its way to the host (LI update of a step)
+        const int n = *a.n_dev;
+        nrb = (2 * n + NB - 1) / NB;
+        if (nrb > a.nrb_max) nrb = a.nrb_max;
+    }
+    if (nrb <= 0) return;
+    // Blocks 0, 8, 16, .. 8 nH are crit and the rows: blocks are dealt round-robin over the eight XCDs, so these share one XCD's L2 -- the rows'
+    // bulk operands (each L(k, J) is wanted by every row below k) and the hand-offs with crit are then served by that L2.  Placement is a
+    // speed assumption only: every hand-off is valid for any placement.  Every other block is a strip.
+    const int b = blockIdx.x, nH = a.nrb_max > 2 ? a.nrb_max - 2 : 0;
+#ifndef CP_TEST_ROLE
+#define CP_TEST_ROLE 7
+#endif
+    if ((b & 7) == 0 && (b >> 3) <= nH) {
+        const int r = b >> 3;
+        if (r == 0) { if (CP_TEST_ROLE & 1) crit_body(a, nrb, cp_smem); return; }
+        const int i = r + 1;
+        if ((CP_TEST_ROLE & 2) && i < nrb) row_body(a, nrb, i);
+        return;
+    }
+    if (threadIdx.x >= 512) return;                             // strips are eight waves
+    const int sidx = b - ((b >> 3) < nH ? (b >> 3) + 1 : nH + 1);
+    if ((CP_TEST_ROLE & 4) && sidx < a.n_strips) strip_body(a, nrb, sidx);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------------------
+size_t cholp_flag_bytes() { return sizeof(unsigned) * CF_WORDS; }
+
+bool cholp_usable(const pre3_ctx *c, int nrb_max)
+{
+    static const int form = getenv("PRE3_CHOL_FORM") ? atoi(getenv("PRE3_CHOL_FORM")) : 1;
+    if (form == 0 || !c->chol_persist) return false;
+    return c->dtype == PRE3_F32 && c->k9_b3 && c->Wp != nullptr && c->Sp != nullptr && c->cholp_flags != nullptr && c->cholp_tp != nullptr &&
+           nrb_max >= 1 && nrb_max <= CP_MAX_NRB && nrb_max <= c->rcap / NB;
+}
+
+// nrb < 0: the row count is read on the device (stats[4]); nrb_max bounds the grid and the LDS
+int launch_cholp(pre3_ctx *c, int nrb, int nrb_max)
+{
+    const int n_strips = c->ldw / 32;
+    const int nH = nrb_max > 2 ? nrb_max - 2 : 0;
+    const size_t lds_crit = sizeof(CritSmem), lds_row = sizeof(RowSmem);
+    const size_t lds_strip = (size_t)(nrb_max > 1 ? nrb_max - 1 : 1) * CP_WGRAN * 16 + (size_t)CP_WGRAN * 16;     // (one panel: Yw2 takes the place of a plane slot)
+    const size_t lds = std::max(lds_crit, std::max(lds_row, lds_strip));
+    static bool attr_set = false;
+    if (!attr_set) {
+        PRE3_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cholp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    PRE3_CHECK(lds <= 160 * 1024, PRE3_E_ARG, "launch_cholp: %d panels do not fit the strips' LDS", nrb_max);
+    c->cholp_epoch += 64;
+    CpArgs a{};
+    a.S = (float *)c->Smat; a.W = (float *)c->W; a.ldw = c->ldw; a.ld = c->ld;
+    a.Sp = c->Sp; a.sp_stride = c->rcap / NB; a.Tp = c->cholp_tp; a.Wp = c->Wp; a.nst_total = c->rcap / B3_BK;
+    a.cf = c->cholp_flags; a.base = c->cholp_epoch; a.status = c->stats + 6;
+    a.n_dev = nrb < 0 ? c->stats + 4 : nullptr; a.nrb = nrb < 0 ? nrb_max : nrb; a.nrb_max = nrb_max; a.n_strips = n_strips;
+    hipLaunchKernelGGL(k_cholp, dim3(std::max(1 + nH + n_strips, 8 * nH + 1)), dim3(CP_NTH), lds, c->stream, a);
+    PRE3_HIP(hipGetLastError());
+    c->split_rows = (nrb < 0 ? nrb_max : nrb) * NB;             // the strips' epilogues have written every plane k_downdate_b3 reads
+    return PRE3_OK;
+}
+
+#ifdef PRE3_PROBE
+extern "C" __attribute__((visibility("default"))) int pre3_debug_cholp(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cp), sizeof(unsigned long long) * 20 * 16 * 8) == hipSuccess ? 0 : -3;
+}
+#endif
+
+}  // namespace pre3

@@ -103,6 +103,15 @@ class EkfFilter:
         check(lib.pre3_get_option(self._ctx, 2, C.byref(v)))
         return bool(v.value)
 
+    def chol_persist(self, on=None):
+        """PRE3_OPT_CHOL_PERSIST (fp32 contexts): update.m:32-33 -- the factorisation of S and W = L^-1 [HP | nu] -- as one persistent launch
+        (default) or, off, one launch per 64-column panel.  Returns whether the persistent form is in effect."""
+        if on is not None:
+            check(lib.pre3_set_option(self._ctx, 3, int(bool(on))))
+        v = C.c_int(0)
+        check(lib.pre3_get_option(self._ctx, 3, C.byref(v)))
+        return bool(v.value)
+
     # ---- map management between steps (map_management.m:27-79); the policy stays with the caller
     def _refresh_map(self):
         self.N = int(lib.pre3_get_map(self._ctx, None))

@@ -188,6 +188,10 @@ PRE3_API int pre3_update_ell(int device, int dtype, int n, int r, const double *
  * the nine partial products are accumulated in f32 (the dropped ones are below f32 rounding), 16/6 of the f32 matrix rate at
  * f32 accuracy.  0: plain f32 MFMA (bitwise an fmaf chain).  No effect on fp64 contexts. */
 #define PRE3_OPT_K9_BF16X3 2
+/* PRE3_OPT_CHOL_PERSIST (fp32 contexts with PRE3_OPT_K9_BF16X3; default 1, or the environment's PRE3_CHOL_FORM): update.m:32-33 -- the
+ * factorisation of S and W = L^-1 [HP | nu] -- as ONE persistent launch (pre3_cholp.hip) for updates of up to 13 x 64 rows;
+ * 0: one launch per 64-column panel (the form every fp64 context and every larger update uses).  get: whether the form is in effect. */
+#define PRE3_OPT_CHOL_PERSIST 3
 PRE3_API int pre3_set_option(pre3_ctx *ctx, int option, int value);
 PRE3_API int pre3_get_option(pre3_ctx *ctx, int option, int *value_out);
 

@@ -1,0 +1,53 @@
+"""Timeline of ONE persistent factorisation + solve launch (pre3_cholp.hip) from its device-side wall-clock stamps (probe build).
+usage (GPU box): PRE3_LIB=3pre_amd/lib/libpre3_probe.so python tools/probe_cholp.py [N] [warm steps]"""
+import ctypes as C, importlib, os, sys
+import numpy as np
+sys.path.insert(0, ".")
+os.environ.setdefault("PRE3_LIB", "3pre_amd/lib/libpre3_probe.so")
+pre3 = importlib.import_module("3pre_amd")
+synth = importlib.import_module("3pre_amd.synth")
+lib = importlib.import_module("3pre_amd._lib").lib
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+warm = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+seq = synth.make_sequence(N, warm + 1, 200)
+f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", max_hyp=200, std_z=1.0)
+f.set_x_p_k_k(seq["x0"], seq["P0"])
+for s in seq["steps"][:warm]:
+    f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=1.0, early_exit=False)
+s = seq["steps"][warm]
+for rep in range(3):           # the same LI update three times (state restored): the last one is read
+    xs, Ps = f.get_x_k_k(), f.get_p_k_k()
+    f.ekf_prediction(s["u"]); f.search_IC_matches(); f.set_measurements(s["meas_idx"], s["z"])
+    r = f.ransac_hypotheses(s["hyp"], threshold=1.0, early_exit=False)
+    f.ekf_update_li_inliers(); f.sync()
+    if rep < 2: f.set_x_p_k_k(xs, Ps)
+buf = np.zeros(20 * 16 * 8, np.uint64)
+fn = lib.pre3_debug_cholp; fn.restype = C.c_int
+assert fn(buf.ctypes.data_as(C.c_void_p)) == 0
+raw = buf.reshape(20, 16, 8).astype(np.int64)
+t = buf.reshape(20, 16, 8).astype(np.float64) / 100.0      # us
+n_li = int(r["li_mask"].sum()); nrb = (2 * n_li + 63) // 64
+t0 = t[0, 0, 0]
+def rel(x): return "%7.2f" % (x - t0) if x > 0 else "      -"
+print("n_li %d -> %d panels; all times in us after crit's first chain start" % (n_li, nrb))
+print("crit main   J: chain start, chain end, b0 passed, b3 passed | side: T1 issued, T1 landed, T2 issued, T2 landed, M_J flag, rowL[J] flag")
+for J in range(nrb):
+    print("  J=%2d  %s %s %s %s | %s %s %s %s %s %s   chain %.2f  products %.2f" % ((J,) + tuple(rel(t[0, J, k]) for k in range(4)) + tuple(rel(t[1, J, k]) for k in range(6)) +
+          (t[0, J, 1] - t[0, J, 0], (t[0, J, 3] - t[0, J, 1]) if t[0, J, 3] > 0 else 0.0)) + "  chain cycles %d (%.2f GHz)" % (raw[19, J, 1] - raw[19, J, 0], (raw[19, J, 1] - raw[19, J, 0]) / max(t[0, J, 1] - t[0, J, 0], 1e-9) / 1e3))
+print("products, per J (us after the chain's end): side waves at b0 (w10, w11) | b0 | B1 done | w11 L_JJ stored, w10 M flag | b1 | b2 | B2 done | w10 planes out, w11 f32 out | b3")
+for J in range(nrb - 1):
+    e = t[0, J, 1]
+    r2 = lambda x: "%5.2f" % (x - e) if x > 0 else "    -"
+    print("  J=%2d  %s %s | %s | %s | %s %s | %s | %s | %s | %s %s | %s" % (J, r2(t[1, J, 7]), r2(t[18, J, 2]), r2(t[0, J, 2]), r2(t[0, J, 7]), r2(t[18, J, 0]), r2(t[1, J, 4]), r2(t[0, J, 4]), r2(t[0, J, 5]), r2(t[0, J, 6]), r2(t[1, J, 6]), r2(t[18, J, 1]), r2(t[0, J, 3])))
+print("rows  (i, J): M_J seen, L(i,J) flagged, L(J+1,J) seen, T1 flagged, T2 flagged, panel done")
+for i in range(2, min(nrb, 16)):
+    for J in range(0, i - 1):
+        print("  i=%2d J=%2d  %s" % (i, J, " ".join(rel(t[i, J, k]) for k in range(6))))
+print("row 9, wave 5, panel 1 bulk: enter %s | wave 4: rows seen %s acquire done %s | wave 5 released %s" % (rel(t[12,1,0]), rel(t[12,1,1]), rel(t[12,1,2]), rel(t[12,1,3])))
+for u in range(4):
+    print("   item %d: start %s  after k-step 0..3 %s  stored %s" % (u, rel(t[12+u,0,0]), " ".join(rel(t[12+u,0,1+q]) for q in range(4)), rel(t[12+u,0,5])))
+print("strip 0 / last strip, per J: (1) rhs planes done, (2) acquire done, (2) sum done, M_J seen, product reduced, stored + planes done, L(J+1,J) seen, its term done")
+for J in range(nrb):
+    order = (3, 0, 4, 1, 5, 2, 6, 7)
+    print("  J=%2d  %s | %s" % (J, " ".join(rel(t[16, J, k]) for k in order), " ".join(rel(t[17, J, k]) for k in order)))
