@@ -387,11 +387,8 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
         }
         // chain done: Ls = L_JJ, Xs = M_J (rows 56..63 not yet in planes)
         if (wave == 10) {
-            // M_J is out as soon as the last rows' stores have drained: the rows' (and with them the next panel's) clock starts at this flag
             publish_m_rows(7);
-            drain_stores();
-            if (lane == 0) cf_store(a.cf + CF_MP, a.base + (unsigned)J + 1);
-            CP_STAMP(1, J, 4);
+            if (!more) { drain_stores(); if (lane == 0) cf_store(a.cf + CF_MP, a.base + (unsigned)J + 1); CP_STAMP(1, J, 4); }
         }
         if (!more) break;
         {   // the fetch must be complete before the products (normally it is: the tiles arrive mid-chain)
@@ -408,6 +405,9 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
         }
         CP_STAMP(wave == 10 ? 1 : 18, J, wave == 10 ? 7 : 2);                         // arrival at b0
         __syncthreads();                                                            // b0
+        // M_J is out once wave 10's stores have drained -- in the shadow of the first product, not in front of it (the tiles of row J+1
+        // arrive before the chain ends, so b0 waits for nothing else)
+        if (wave == 10) { drain_stores(); if (lane == 0) cf_store(a.cf + CF_MP, a.base + (unsigned)J + 1); CP_STAMP(1, J, 4); }
         __syncthreads();                                                            // b1
         __syncthreads();                                                            // b2: T1p = planes of L(J+1, J), Y = its f32 image
         if (wave == 10) {
