@@ -229,6 +229,7 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
         // persistent factorisation (pre3_cholp.hip): flag words (zero: every launch brings its own epoch), one plane block per row for the hand-over to crit
         { void *f = nullptr; A(dmalloc_bytes(&f, cholp_flag_bytes())); c->cholp_flags = (unsigned int *)f; }
         A(dmalloc_bytes(&c->cholp_tp, (size_t)(c->rcap / NB) * 1536 * 16));
+        if (rc == PRE3_OK) { cholp_context_count(c->device, +1); c->cholp_counted = true; }
         const int nt = c->ld / 128, ns = ceil_div(nt, 4);
         std::vector<std::vector<int2>> lists(8);
         for (int SI = 0; SI < ns; ++SI)
@@ -292,6 +293,7 @@ int pre3_destroy(pre3_ctx *c)
     if (!c) return PRE3_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->cholp_counted) { cholp_context_count(c->device, -1); c->cholp_counted = false; }
     void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
                      c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
                      c->sel_rows, c->support, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128, c->need, c->cholp_flags, c->cholp_tp };

@@ -9,6 +9,7 @@ constexpr int CP_MAX_NRB = 13;       // panels of 64 rows: the strips keep nrb -
 
 size_t cholp_flag_bytes();
 bool cholp_usable(const pre3_ctx *c, int nrb_max);
+void cholp_context_count(int device, int delta);      // a context with the persistent form's buffers was created (+1) / destroyed (-1)
 // S (c->Smat, stride nrb * 64) and [HP | nu] (c->W) in place -> L and W = L^-1 [HP | nu], W's bf16 planes (c->Wp) included.
 // nrb < 0: the number of rows is read on the device (stats[4] measurements, as k_gather_li does); nrb_max bounds grid and LDS.
 int launch_cholp(pre3_ctx *c, int nrb, int nrb_max);

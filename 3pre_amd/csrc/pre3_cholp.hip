@@ -20,6 +20,7 @@
 // share the planes through their XCD's L2).  Flags are monotonic words tagged with a per-launch epoch; every wait is bounded
 // (guard word stats[7], as in pre3_geomdev.h) and no access depends on a value that a give-up would leave undefined.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include "pre3_internal.h"
@@ -901,10 +902,19 @@ __global__ __launch_bounds__(CP_NTH) void k_cholp(CpArgs a)
 // ------------------------------------------------------------------------------------------------------------------------------
 size_t cholp_flag_bytes() { return sizeof(unsigned) * CF_WORDS; }
 
+// Contexts of this process that can launch k_cholp, per device.  A launch is a set of workgroups that wait for one another and each fills a
+// CU (LDS): two launches fit the chip side by side (2 x 110 workgroups at N = 500), a third one's workgroups could interleave with theirs at
+// dispatch so that none of the three is complete.  With more than two such contexts alive on a device the launch-per-panel form is used
+// (PRE3_CHOL_FORM=2 overrides; several PROCESSES sharing one GPU are not seen here: run those with PRE3_CHOL_FORM=0).  A wait that never
+// ends is bounded in any case (stats[7] -> PRE3_E_HIP).
+static std::atomic<int> g_cholp_live[64];
+void cholp_context_count(int device, int delta) { if (device >= 0 && device < 64) g_cholp_live[device].fetch_add(delta); }
+
 bool cholp_usable(const pre3_ctx *c, int nrb_max)
 {
     static const int form = getenv("PRE3_CHOL_FORM") ? atoi(getenv("PRE3_CHOL_FORM")) : 1;
     if (form == 0 || !c->chol_persist) return false;
+    if (form != 2 && c->device >= 0 && c->device < 64 && g_cholp_live[c->device].load() > 2) return false;
     return c->dtype == PRE3_F32 && c->k9_b3 && c->Wp != nullptr && c->Sp != nullptr && c->cholp_flags != nullptr && c->cholp_tp != nullptr &&
            nrb_max >= 1 && nrb_max <= CP_MAX_NRB && nrb_max <= c->rcap / NB;
 }

@@ -148,6 +148,7 @@ struct pre3_ctx {
     int32_t *need = nullptr; int need_tag = 0;    // [capm] sharded RANSAC: need[s] == need_tag where this rank's hypothesis slice draws measurement s
     // persistent factorisation (pre3_cholp.hip)
     unsigned int *cholp_flags = nullptr; void *cholp_tp = nullptr; unsigned int cholp_epoch = 0; bool chol_persist = true;
+    bool cholp_counted = false;                   // this context is in pre3_cholp.hip's per-device count
     bool cholp_done = false;                      // the speculative launch of an LI update has already factored and solved
     bool hp_all_valid = false;                    // HP / G hold H*P, H*P*H' of ALL measured rows at the current prior (ransac_prepare)
 };

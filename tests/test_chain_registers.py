@@ -1,0 +1,41 @@
+"""CPU (cross-compile only): the persistent factorisation kernel (3pre_amd/csrc/pre3_cholp.hip) must keep its dependent chain free of scratch
+traffic.  The chain's unrolled code takes every vector register a 768-thread workgroup may have; one more value living across it comes back
+as a scratch reload in every pipeline step of the worker waves (seen during development: +30 % chain time).  The check reads the compiler's
+own assembly: no scratch instruction between the first and the last v_mfma_f32_32x32x2_f32 of k_cholp (only the chain uses that
+instruction), and no vector-register spill in the kernel itself."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "3pre_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_the_chain_of_k_cholp_has_no_scratch_traffic():
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=on", "-mllvm", "-pragma-unroll-threshold=200000"]      # the Makefile's
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    for f in ("-O3", "-std=c++17", "-ffp-contract=on", "-pragma-unroll-threshold=200000"):
+        assert f in mk, "the Makefile's flags changed: keep this test's in step (%s)" % f
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "cholp.s")
+        r = subprocess.run([HIPCC] + flags + ["-S", "--cuda-device-only", "-I", CSRC, "-Rpass-analysis=kernel-resource-usage", "-o", out,
+                            os.path.join(CSRC, "pre3_cholp.hip")], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        asm = open(out).read().split("\n")
+    start = [i for i, l in enumerate(asm) if l.startswith("_ZN4pre37k_cholp")]
+    assert start, "k_cholp not found in the assembly"
+    kern = asm[start[0]:]
+    mf = [i for i, l in enumerate(kern) if "v_mfma_f32_32x32x2_f32" in l]
+    assert len(mf) > 100, "the chain's f32 MFMAs are gone?"
+    inside = [l.strip() for l in kern[mf[0]:mf[-1]] if "scratch_" in l]
+    assert not inside, "scratch traffic inside the chain of k_cholp:\n" + "\n".join(inside[:8])
+    m = re.findall(r"Function Name: (\S+).*?VGPRs Spill: (\d+)", r.stderr, re.S)
+    spills = {n: int(v) for n, v in m}
+    k = [v for n, v in spills.items() if "k_cholp" in n]
+    assert k and k[0] <= 4, spills

@@ -1,0 +1,142 @@
+"""GPU: update.m:32-33 (S = L L', W = L^-1 [HP | nu]) as ONE persistent launch (3pre_amd/csrc/pre3_cholp.hip, fp32 contexts, <= 13 panels of
+64 rows) against the launch-per-panel form on the same inputs, and against the oracle where a test says so.  The two forms factor and solve
+with different operation orders (blocked inverse-of-diagonal-block solve vs lock-step substitution), so they agree to fp32 rounding of the
+update, not bit for bit: tolerances are written at each assert; inlier sets must be identical."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+synth = importlib.import_module("3pre_amd.synth")
+
+
+def _pair(pre3, seq, N, n_hyp):
+    fs = []
+    for on in (False, True):
+        f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", max_hyp=n_hyp, std_z=1.0)
+        f.chol_persist(on)
+        assert f.chol_persist() == on
+        f.set_x_p_k_k(seq["x0"], seq["P0"])
+        fs.append(f)
+    return fs
+
+
+@pytest.mark.parametrize("N,n_hyp,steps", [(50, 40, 3), (120, 60, 3), (500, 200, 3)])
+def test_whole_steps_agree_between_the_two_forms(pre3, N, n_hyp, steps):
+    """LI update (1 .. 10 panels), rescue, HI update (one panel) through pre3_step: same inlier sets, x / P to fp32 rounding of one update"""
+    seq = synth.make_sequence(N, steps, n_hyp)
+    fs = _pair(pre3, seq, N, n_hyp)
+    for s in seq["steps"]:
+        out = []
+        for f in fs:
+            st = f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=1.0, early_exit=False)
+            li, hi = f.get_flags()
+            out.append((st, li, hi, f.get_x_k_k(), f.get_p_k_k()))
+        (s0, li0, hi0, x0, P0), (s1, li1, hi1, x1, P1) = out
+        assert np.array_equal(li0, li1) and np.array_equal(hi0, hi1)
+        assert (s0["best"], s0["n_li"], s0["n_hi"]) == (s1["best"], s1["n_li"], s1["n_hi"])
+        scale = np.abs(P0).max()
+        assert np.isfinite(P1).all()
+        assert np.abs(P1 - P0).max() < 1e-4 * scale, np.abs(P1 - P0).max() / scale       # (the fp32-vs-fp64 tolerance of the suite is 3e-4)
+        assert np.abs(x1 - x0).max() < 1e-5
+        A = np.abs(P1 - P1.T); A[3:7, :] = 0; A[:, 3:7] = 0
+        assert A.max() == 0.0                                                            # still exactly symmetric outside the Jnorm rows
+        fs[1].set_x_p_k_k(x0, P0)                                                        # each step compares ONE update
+    for f in fs:
+        f.close()
+
+
+@pytest.mark.parametrize("n_rows_meas", [1, 31, 32, 33, 97, 400, 416])
+def test_update_sizes_from_one_row_pair_to_thirteen_panels(pre3, orc, n_rows_meas):
+    """ekf_update_li_inliers with a forced inlier set: r = 2 .. 832 rows (1 .. 13 panels; padding rows when r is not a multiple of 64),
+    persistent form vs the C oracle's update.m restatement (fp64) and vs the launch-per-panel form"""
+    N, n_hyp = 500, 8
+    seq = synth.make_sequence(N, 1, n_hyp)
+    s = seq["steps"][0]
+    types, off, n = orc.landmark_table(np.zeros(N, int))
+    m = min(n_rows_meas, len(s["meas_idx"]))
+    if m < n_rows_meas:
+        # more measurements than the sequence provides: measure further landmarks at their predicted pixels (innovation 0)
+        extra = np.setdiff1d(np.arange(N), s["meas_idx"])[: n_rows_meas - m]
+        meas = np.sort(np.concatenate([s["meas_idx"], extra])).astype(np.int32)
+    else:
+        meas = np.asarray(s["meas_idx"][:m], np.int32)
+    res = []
+    for on in (True, False):
+        f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", max_hyp=n_hyp, std_z=1.0)
+        f.chol_persist(on)
+        f.set_x_p_k_k(seq["x0"], seq["P0"])
+        f.ekf_prediction(s["u"])
+        f.search_IC_matches()
+        h = f.landmark_fields()["h"]
+        zmap = {int(i): zz for i, zz in zip(s["meas_idx"], s["z"])}
+        z = np.array([zmap.get(int(i), h[int(i)]) for i in meas])
+        f.set_measurements(meas, z)
+        f.set_flags(li=np.ones(len(meas), np.int32))
+        f.ekf_update_li_inliers()
+        res.append((f.get_x_k_k(), f.get_p_k_k(), f.get_x_k_km1() if False else None, meas, z))
+        f.close()
+    (xp, Pp, _, meas, z), (xl, Pl, _, _, _) = res
+    scale = np.abs(Pl).max()
+    assert np.isfinite(Pp).all()
+    assert np.abs(Pp - Pl).max() < 1e-4 * scale, (n_rows_meas, np.abs(Pp - Pl).max() / scale)
+    assert np.abs(xp - xl).max() < 1e-5
+    # ... and against update.m's restatement in fp64 (the numpy twin: explicit inv(S), K S K', 0.5 (P + P'), Jnorm rebuild)
+    from oracle import np_twin as tw
+    xr, Pr = tw.predict(seq["x0"], seq["P0"], s["u"])
+    hh, has = tw.project(types, off, xr, seq["cam"])
+    Hc, Hl = tw.jacobian(types, off, xr, seq["cam"], hh, has)
+    zfull = np.zeros((N, 2)); zfull[meas] = z
+    xo, Po = tw.update_landmarks(types, off, meas, xr, Pr, Hc, Hl, zfull, hh)
+    assert np.abs(Pp - Po).max() < 3e-4 * np.abs(Po).max(), np.abs(Pp - Po).max() / np.abs(Po).max()
+    assert np.abs(xp - xo).max() < 2e-5
+
+
+def test_an_update_beyond_thirteen_panels_takes_the_other_form(pre3):
+    """r = 900 rows = 15 panels: more than the strips' LDS holds; the launch-per-panel form serves it, same call, same result class"""
+    N = 500
+    seq = synth.make_sequence(N, 1, 8)
+    s = seq["steps"][0]
+    f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", max_hyp=8, std_z=1.0)
+    assert f.chol_persist()
+    f.set_x_p_k_k(seq["x0"], seq["P0"])
+    f.ekf_prediction(s["u"])
+    f.search_IC_matches()
+    meas = np.arange(450, dtype=np.int32)
+    f.set_measurements(meas, f.landmark_fields()["h"][:450] + 0.25)
+    f.set_flags(li=np.ones(450, np.int32))
+    f.ekf_update_li_inliers()
+    P = f.get_p_k_k()
+    assert np.isfinite(P).all() and np.abs(P - P.T).max() < 1e-12 * np.abs(P).max() + 1e-30
+    assert (np.diag(P)[7:] > 0).all()
+    f.close()
+
+
+def test_not_positive_definite_is_reported_by_the_persistent_form(pre3):
+    seq = synth.make_sequence(60, 1, 8)
+    s = seq["steps"][0]
+    f = pre3.EkfFilter(seq["cam"], np.zeros(60, np.int32), dtype="f32", max_hyp=8, std_z=1.0)
+    assert f.chol_persist()
+    f.set_x_p_k_km1(seq["x0"], -np.eye(seq["n"]) * 10.0)
+    f.search_IC_matches()
+    f.set_measurements(s["meas_idx"], s["z"])
+    f.ekf_update_all()
+    with pytest.raises(pre3.Pre3Error) as e:
+        f.get_p_k_k()
+    assert e.value.code == -5
+    f.close()
+
+
+def test_more_than_two_capable_contexts_fall_back(pre3):
+    """a launch of the persistent form is a set of workgroups that wait for one another; two launches fit the chip side by side, a third
+    context on the device switches every context's NEXT updates to the launch-per-panel form (3pre_amd/csrc/pre3_cholp.hip, cholp_usable)"""
+    seq = synth.make_sequence(30, 1, 8)
+    fs = [pre3.EkfFilter(seq["cam"], np.zeros(30, np.int32), dtype="f32", max_hyp=8) for _ in range(2)]
+    assert all(f.chol_persist() for f in fs)
+    f3 = pre3.EkfFilter(seq["cam"], np.zeros(30, np.int32), dtype="f32", max_hyp=8)
+    assert not f3.chol_persist() and not fs[0].chol_persist()
+    f3.close()
+    assert fs[0].chol_persist()
+    for f in fs:
+        f.close()
