@@ -57,8 +57,34 @@ with open(os.path.join(P, "%s_pmc_k9.json" % tag), "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps(out["counters_KB"], indent=1), out["k9_trace_durations_us"], out["hbm_bytes_per_li_launch"])
 
-# ---- the factorisation (k_chol_step): per-launch durations by panel and the SQ counters of its launches
+# ---- the factorisation + solve as one persistent launch (k_cholp, round 3): durations of the LI launches (r ~ 640: ten panels) and of the HI
+#      launches (one panel), and the SQ counters of its launches
 import collections
+cp = [((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in csv.DictReader(open(find("%s_trace" % tag, "%s_kernel_trace.csv" % tag))) if "k_cholp" in r["Kernel_Name"]]
+if cp:
+    big_ = sorted(d for d in cp if d > 0.5 * max(cp)); small_ = sorted(d for d in cp if d <= 0.5 * max(cp))
+    cl = ["# k_cholp (K8, round 3: S = L L' and W = L^-1 [HP | nu] in ONE persistent launch) in `bench.py --steps 40` (N=500, n=3013), rocprofv3 --kernel-trace",
+          "# LI updates (r ~ 640 rows, ten 64-row panels): %d launches, median %.2f us, mean %.2f us, min %.2f us" % (len(big_), big_[len(big_) // 2], sum(big_) / len(big_), big_[0])]
+    if small_:
+        cl.append("# HI updates (r <= 64 rows, one panel): %d launches, median %.2f us, mean %.2f us" % (len(small_), small_[len(small_) // 2], sum(small_) / len(small_)))
+    sqd = os.path.join(G, "%s_pmc_sq" % tag)
+    if os.path.isdir(sqd):
+        cl.append("# SQ counters per launch (separate --pmc passes, means over the k_cholp launches above the median of 10 steps: the LI updates)")
+        for dp, _, fs_ in sorted(os.walk(sqd)):
+            for fn in fs_:
+                if fn.endswith("counter_collection.csv"):
+                    acc = collections.defaultdict(list)
+                    for r in csv.DictReader(open(os.path.join(dp, fn))):
+                        if "k_cholp" in r["Kernel_Name"]:
+                            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    for k_, v in sorted(acc.items()):
+                        top = sorted(v)[len(v) // 2:]
+                        cl.append("%-28s %12.5g  (%d launches)" % (k_, sum(top) / len(top), len(top)))
+    with open(os.path.join(P, "%s_cholp_launches.txt" % tag), "w") as fh:
+        fh.write("\n".join(cl) + "\n")
+    print("\n".join(cl))
+
+# ---- the factorisation (k_chol_step): per-launch durations by panel and the SQ counters of its launches
 by = collections.defaultdict(list)
 for r in csv.DictReader(open(find("%s_trace" % tag, "%s_kernel_trace.csv" % tag))):
     if "k_chol_step" in r["Kernel_Name"]:
@@ -84,9 +110,10 @@ if os.path.isdir(sq):
                         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 for k_, v in sorted(acc.items()):
                     lines.append("%-28s %12.5g  (%d launches)" % (k_, sum(v) / len(v), len(v)))
-with open(os.path.join(P, "%s_chol_launches.txt" % tag), "w") as fh:
-    fh.write("\n".join(lines) + "\n")
-print("\n".join(lines[-14:]))
+if by:
+    with open(os.path.join(P, "%s_chol_launches.txt" % tag), "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    print("\n".join(lines[-14:]))
 
 # ---- the matcher (k_match_i8_q)
 try:
