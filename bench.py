@@ -411,7 +411,7 @@ def main():
         n_hi = float(np.mean([s["n_hi"] for s in stats]))
         achieved = kt["flops"] / (kt["total_ms"] * 1e-3) / 1e12 if kt["total_ms"] > 0 else 0.0
         traffic, traffic_src = None, None
-        for tag in ("r2", "r1"):    # HBM bytes per LI launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
+        for tag in ("r3", "r2", "r1"):    # HBM bytes per LI launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
             try:
                 with open(os.path.join(ROOT, "profiles", "%s_pmc_k9.json" % tag)) as fh:
                     pj = json.load(fh)
