@@ -84,4 +84,5 @@ EXPORTS = [
     "pre3_siftmatch_i8", "pre3_siftmatch_partial", "pre3_siftmatch_merge", "pre3_match_shard_create", "pre3_match_shard_create_cls", "pre3_match_shard_run", "pre3_match_shard_merge",
     "pre3_match_shard_destroy", "pre3_release_scratch", "pre3_knn_f64", "pre3_timer_start",
     "pre3_timer_stop", "pre3_kernel_timing", "pre3_kernel_timing_read", "pre3_bench_downdate",
+    "pre3_match_bench_create", "pre3_match_bench_create_cls", "pre3_match_bench_info", "pre3_match_bench_run", "pre3_match_bench_fetch", "pre3_match_bench_destroy",
 ]

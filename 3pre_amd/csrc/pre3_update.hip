@@ -1357,7 +1357,8 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad, bool first_done = false)
         return PRE3_OK;
     }
     c->cholp_done = false;
-    if (!first_done && cholp_usable(c, nrb)) return launch_cholp(c, nrb, nrb);
+    // (one panel is one launch in either form, and the lock-step form has no hand-off in it: 12.5 us against 17)
+    if (!first_done && nrb >= 2 && cholp_usable(c, nrb)) return launch_cholp(c, nrb, nrb);
     {
         const bool split = c->k9_b3 && c->dtype == PRE3_F32 && c->Wp != nullptr;
         static const int pro_env = getenv("PRE3_CHOL_PRO_B3") ? atoi(getenv("PRE3_CHOL_PRO_B3")) : 1;

@@ -86,6 +86,17 @@ def make_map(N, seed=None):
     return x0, P0, x_true
 
 
+def draw_hypotheses(rng, m, n_hyp, k=3):
+    """RANSAC draws for m individually compatible measurements: k distinct positions per hypothesis when more than k are there, ONE
+    otherwise (select_random_match.m:47-51 takes 3 landmarks if #IC > 3, else 1); with no measurement at all the table still has one
+    column (of zeros: pre3_step wants n_draw >= 1, k >= 1 and then skips RANSAC because m < k).  A long synthetic sequence walks away
+    from its map and ends up here -- a table with fewer than one column is what pre3_step rejects as "bad hypothesis table"."""
+    kk = k if m > k else 1
+    if m == 0:
+        return np.zeros((n_hyp, 1), np.int32)
+    return np.stack([rng.permutation(m)[:kk] for _ in range(n_hyp)]).astype(np.int32)
+
+
 def make_sequence(N, steps, n_hyp, k=3, meas_frac=0.8, outlier_frac=0.2, sigma_z=0.25, seed=None):
     """A whole input sequence: per step the odometry u, the measured landmark list, their pixels and the
     RANSAC draws.  The truth moves by u_true = u + noise; pixels come from the truth."""
@@ -117,7 +128,6 @@ def make_sequence(N, steps, n_hyp, k=3, meas_frac=0.8, outlier_frac=0.2, sigma_z
         n_out = int(round(outlier_frac * len(pick)))
         out_pos = rng.choice(len(pick), size=n_out, replace=False)
         z[out_pos] = np.stack([rng.uniform(1, 175, n_out), rng.uniform(1, 143, n_out)], 1)
-        m = len(pick)
-        hyp = np.stack([rngh.permutation(m)[:k] for _ in range(n_hyp)]).astype(np.int32)
+        hyp = draw_hypotheses(rngh, len(pick), n_hyp, k)
         seq.append(dict(u=u, meas_idx=pick, z=z, hyp=hyp, outliers=np.sort(out_pos)))
     return dict(N=N, n=13 + 6 * N, cam=CAM.copy(), x0=x0, P0=P0, x_true0=x_true, steps=seq)

@@ -119,6 +119,7 @@ def matcher_shard_leg(pre3, dist, rank, world, local_rank=0, K=4096, reps=20):
     L1c, L2c = np.asfortranarray(L1.T), np.asfortranarray(L2.T)      # 128 x K, column-major like the reference
     lo, hi = pd.shard_range(K, rank, world)
     sh = mt.MatchShard(L1c, L2c[:, lo:hi], lo, device=local_rank)
+    yield None                                          # set-up done: nothing collective has been issued yet (run_leg agrees on it)
     try:
         for _ in range(3):
             m = pd.siftmatch_sharded_resident(sh, 1.5)
@@ -136,7 +137,7 @@ def matcher_shard_leg(pre3, dist, rank, world, local_rank=0, K=4096, reps=20):
             el = float(t.item())
     finally:
         sh.close()
-    return {"workload": "configs[3]: 4096x4096x128 uint8, database columns sharded over %d GPU(s), operands resident in HBM, partials "
+    yield {"workload": "configs[3]: 4096x4096x128 uint8, database columns sharded over %d GPU(s), operands resident in HBM, partials "
                         "all-gathered as device tensors, merge on the device" % world,
             "ms_per_match": 1e3 * el / reps, "pairs_per_s": reps * K * K / el, "matches": int(np.asarray(m).shape[1]), "n_gpus": world, "scaling": "strong"}
 
@@ -147,22 +148,16 @@ def ransac_shard_leg(pre3, synth, dist, rank, world, local_rank, N=2000, n_hyp=1
     hypotheses/s at this number of GPUs (the all-reduce and the replay are inside the timed region)."""
     import torch
     pd = importlib.import_module("3pre_amd.dist")
-    f, err = None, None
+    seq = synth.make_sequence(N, 1, n_hyp)              # same seed on every rank: identical replicas
+    s = seq["steps"][0]
+    f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", device=local_rank, max_hyp=n_hyp)
     try:
-        seq = synth.make_sequence(N, 1, n_hyp)          # same seed on every rank: identical replicas
-        s = seq["steps"][0]
-        f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", device=local_rank, max_hyp=n_hyp)
         f.set_x_p_k_k(seq["x0"], seq["P0"])
         f.ekf_prediction(s["u"])
         f.search_IC_matches()
         f.set_measurements(s["meas_idx"], s["z"])
-    except Exception as e:                              # pragma: no cover
-        err = e
-    if not all_ranks_ok(dist, err is None):             # nobody enters the collectives unless everybody can
-        if f is not None:
-            f.close()
-        raise RuntimeError("sharded-RANSAC leg skipped: set-up failed on a rank (%r)" % (err,))
-    try:
+        yield None                                      # set-up done: nobody enters the collectives unless everybody can (run_leg agrees on it)
+
         for _ in range(2):
             out = pd.ransac_sharded(f, s["hyp"], 1.0, early_exit=False, fetch=False)
         f.sync()
@@ -181,7 +176,7 @@ def ransac_shard_leg(pre3, synth, dist, rank, world, local_rank, N=2000, n_hyp=1
             t = torch.tensor([el], device=COLL_DEV, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        return {"workload": "configs[4]: N=%d (n=%d), %d hypotheses (k=3), m=%d measured, f32; per round: H*P and H*P*H' gathers, "
+        yield {"workload": "configs[4]: N=%d (n=%d), %d hypotheses (k=3), m=%d measured, f32; per round: H*P and H*P*H' gathers, "
                             "sharded scoring, all-reduce, replay" % (N, seq["n"], n_hyp, len(s["meas_idx"])),
                 "value": reps * n_hyp / el, "unit": "hypotheses/s", "n_gpus": world, "ms_per_round": 1e3 * el / reps,
                 "max_support": int(out["max_support"]), "scaling": "strong",
@@ -262,8 +257,38 @@ def self_launch(args):
         port = so.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    return subprocess.call(cmd, env=env)
+    import tempfile
+    fd, side = tempfile.mkstemp(prefix="pre3_bench_", suffix=".json")
+    os.close(fd)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), PRE3_BENCH_SIDEFILE=side)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    seen = False
+    for line in proc.stdout:                            # pass the ranks' output through; remember whether the line came
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        if line.lstrip().startswith("{") and '"metric"' in line:
+            seen = True
+    rc = proc.wait()
+    try:
+        if not seen and os.path.getsize(side) > 0:
+            # rank 0 measured the headline but never got to print (e.g. aborted inside a later collective): print what it left
+            with open(side) as fh:
+                line = fh.readline().strip()
+            try:
+                rec = json.loads(line)
+                rec["communicator"] = "rank 0 ended (exit code %d) before printing; this is the headline it had measured before the auxiliary legs" % rc
+                line = json.dumps(rec)
+            except ValueError:
+                pass
+            print(line)
+            sys.stdout.flush()
+            rc = rc or 3
+    finally:
+        try:
+            os.unlink(side)
+        except OSError:
+            pass
+    return rc
 
 
 def legs_agree(dist, err, name):
@@ -283,6 +308,34 @@ def legs_agree(dist, err, name):
         sys.stderr.write("bench.py: leg %r failed on a rank (%r) -- the remaining legs are skipped\n" % (name, err))
         sys.stderr.flush()
     return ok
+
+
+def run_leg(dist, name, gen_fn, inject):
+    """A sharded leg is a generator: everything up to its first `yield` is set-up (no collective), the rest is the measured run (its own
+    collectives) and yields the result.  Every rank takes the same path through here and issues the same collectives in the same order:
+    set-up -> ONE agreement -> run -> ONE agreement.  A rank whose set-up fails (or is made to, `inject`) therefore cannot be left one
+    collective apart from the others.  Returns (result | None, error | None, agreed) with agreed = True / False / None (communicator broken)."""
+    gen, err, res = None, None, None
+    try:
+        if inject:
+            raise RuntimeError("injected failure (PRE3_BENCH_FAIL_LEG): rehearses the error hand-off")
+        gen = gen_fn()
+        next(gen)
+    except Exception as e:                              # pragma: no cover
+        err = e
+    agreed = legs_agree(dist, err, name + " (set-up)")
+    if agreed:
+        try:
+            res = next(gen)
+        except Exception as e:                          # pragma: no cover
+            err = e
+        agreed = legs_agree(dist, err, name)
+    if gen is not None:
+        try:
+            gen.close()                                 # runs the generator's `finally` (closes filters / shards)
+        except Exception:                               # pragma: no cover
+            pass
+    return res, err, agreed
 
 
 def check_step(pre3, f, seq, s, thr, dtype):
@@ -321,6 +374,11 @@ def main():
     ap.add_argument("--kt-every", type=int, default=4, help="bracket one K9 launch in N with HIP events (an event pair costs ~11 us of stream time); 1 = every launch")
     ap.add_argument("--sync-hi", action="store_true", help="complete every step's HI update inside the step call (default: deferred to the next call)")
     ap.add_argument("--k9-f32", action="store_true", help="fp32 path: K9 on the f32 MFMA instead of the three-way bf16 split (PRE3_OPT_K9_BF16X3 = 0)")
+    ap.add_argument("--threshold", type=float, default=0.45, help="RANSAC threshold in pixels (ransac_hypotheses.m:33, threshold = std_z); 0.45 = 1.8 sigma of "
+                    "the synthetic pixel noise: some true inliers then miss the low-innovation set and about ten of them come back through the chi2 "
+                    "rescue (whose gate, sqrt(5.99 H P H'), is ~0.7 px on the converged map), so that every step carries a real HI update of ~20 rows; "
+                    "1.0 is the reference's own constant (the `no_hi` leg)")
+    ap.add_argument("--no-hi-steps", type=int, default=60, help="steps of the second leg (threshold 1.0: the rescue finds next to nothing); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of host work per CPU-baseline leg (three legs)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity check of one step behind the timed region")
@@ -373,8 +431,9 @@ def main():
     torch.cuda.set_device(local_rank)
 
     N, K, W = args.landmarks, args.steps, args.warmup
-    thr = 1.0
-    seq = synth.make_sequence(N, K + W + 1, args.hyp, seed=None if rank == 0 else 10_000 * rank + N)     # + 1: the checked step
+    thr = args.threshold
+    K2 = max(0, args.no_hi_steps)
+    seq = synth.make_sequence(N, K + W + 1 + (K2 + 3 if K2 else 0), args.hyp, seed=None if rank == 0 else 10_000 * rank + N)     # + 1: the checked step; + the `no_hi` leg
     f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype=args.dtype, device=local_rank, max_hyp=args.hyp, std_z=thr)
     b3 = f.k9_bf16x3(False if args.k9_f32 else None) if args.dtype == "f32" else False
     f.set_x_p_k_k(seq["x0"], seq["P0"])
@@ -403,6 +462,41 @@ def main():
         elapsed = float(t.item())
     kt = f.kernel_timing_read()
     f.kernel_timing(False)
+    # parity of what was timed: the NEXT step of the same sequence, GPU vs the numpy twin (outside the timed region)
+    chk = None
+    if rank == 0 and not args.no_check:
+        try:
+            chk = check_step(pre3, f, seq, seq["steps"][W + K], thr, args.dtype)
+        except Exception as e:                                  # pragma: no cover
+            chk = {"checked": False, "check_error": repr(e)[:300]}
+        if not args.sync_hi:
+            f.defer_hi_update(True)
+    # second leg, same filter, the reference's own threshold (1.0 px): the workload of rounds 1-2, where the rescue finds next to nothing
+    no_hi = None
+    if K2:
+        st2 = []
+        s2 = seq["steps"][W + K + 1:]
+        for s in s2[:3]:
+            f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=1.0, early_exit=False)
+        f.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t2 = time.perf_counter()
+        for s in s2[3:3 + K2]:
+            st2.append(f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=1.0, early_exit=False))
+        f.sync()
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t2
+        if dist is not None:
+            dist.barrier()
+            t = torch.tensor([el2], device=COLL_DEV, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el2 = float(t.item())
+        no_hi = {"value": world * K2 / el2, "unit": "steps/s", "steps": K2, "ms_per_step": 1e3 * el2 / K2, "threshold_px": 1.0,
+                 "mean_li_rows": 2 * float(np.mean([s_["n_li"] for s_ in st2])), "mean_hi_rows": 2 * float(np.mean([s_["n_hi"] for s_ in st2])),
+                 "note": "the same filter continued with the reference's own RANSAC threshold (ransac_hypotheses.m:33 with mono_slam.m:78's "
+                         "sigma_image_noise = 1): the headline workload of rounds 1 and 2"}
 
     out = None
     if rank == 0:
@@ -457,35 +551,34 @@ def main():
             "config": {"workload": "configs[2]: N=%d inverse-depth landmarks (n=%d), %d RANSAC hypotheses (k=3, all evaluated), "
                                    "%s covariance path, full 1PRE step" % (N, n, args.hyp, args.dtype),
                        "measured_per_step": int(np.mean([len(s["meas_idx"]) for s in seq["steps"][W:W + K]])),
-                       "mean_li_rows": 2 * n_li, "mean_hi_rows": 2 * n_hi, "parallelism": "replicas x%d" % world,
+                       "mean_li_rows": 2 * n_li, "mean_hi_rows": 2 * n_hi, "ransac_threshold_px": thr, "parallelism": "replicas x%d" % world,
                        "hip_event_ms_per_step": ev_ms / K},
             "roofline": roofline,
+            "no_hi": no_hi,
             "step_ideal": {"ideal_us": ideal_us, "achieved_us": 1e3 * ms_step, "step_ideal_frac": ideal_us / (1e3 * ms_step),
                            "note": "SURVEY 8(d): algorithmic flops of the LI + HI updates at the %s MFMA peak, no latency" % args.dtype},
         }
-    # parity of what was timed: one more step of the same sequence, GPU vs the numpy twin (outside the timed region)
-    if rank == 0 and not args.no_check:
-        try:
-            out.update(check_step(pre3, f, seq, seq["steps"][W + K], thr, args.dtype))
-        except Exception as e:                                  # pragma: no cover
-            out.update({"checked": False, "check_error": repr(e)[:300]})
+    if rank == 0 and chk is not None:
+        out.update(chk)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(seq, thr, args.cpu_budget)
     f.close()
     # secondary legs: sharded RANSAC and sharded matcher at every N, kernel-only matcher and VO RANSAC at N=1.  A leg that fails on any
     # rank is recorded and ends the legs (legs_agree): no rank may be left inside a collective, and the headline is printed regardless.
     comm_broken = False
+    side = os.environ.get("PRE3_BENCH_SIDEFILE")
+    if rank == 0 and side:
+        # the headline alone, before any auxiliary collective: the self-launch parent (which never touches the GPU) prints this line if
+        # this process should die inside a collective (an RCCL watchdog abort leaves no chance to print)
+        try:
+            with open(side, "w") as fh:
+                fh.write(json.dumps(out) + "\n")
+        except OSError:                                         # pragma: no cover
+            pass
     if not args.no_extra_legs:
         for name, fn in (("ransac_shard", lambda: ransac_shard_leg(pre3, synth, dist, rank, world, local_rank)),
                          ("matcher_shard", lambda: matcher_shard_leg(pre3, dist, rank, world, local_rank))):
-            leg, err = None, None
-            try:
-                if os.environ.get("PRE3_BENCH_FAIL_LEG") == name and rank == world - 1:
-                    raise RuntimeError("injected failure (PRE3_BENCH_FAIL_LEG): rehearses the error hand-off")
-                leg = fn()
-            except Exception as e:                              # pragma: no cover
-                err = e
-            agreed = legs_agree(dist, err, name)
+            leg, err, agreed = run_leg(dist, name, fn, os.environ.get("PRE3_BENCH_FAIL_LEG") == name and rank == world - 1)
             if rank == 0:
                 out[name] = leg if (err is None and agreed) else {"error": repr(err)[:300] if err is not None else "failed on another rank"}
             if agreed is None:
@@ -498,6 +591,12 @@ def main():
                     out[name] = fn()
                 except Exception as e:                          # pragma: no cover
                     out[name] = {"error": repr(e)[:300]}
+    # the line goes out BEFORE the final barrier and the teardown: a collective whose partner is gone does not raise on RCCL, it aborts
+    if rank == 0:
+        if comm_broken:
+            out["communicator"] = "broken during an auxiliary leg (exit code 3); the headline was measured before the legs"
+        print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None and not comm_broken:
         try:
             dist.barrier()
@@ -505,11 +604,9 @@ def main():
         except Exception as e:                                  # pragma: no cover
             sys.stderr.write("bench.py: final barrier failed (%r)\n" % (e,))
             comm_broken = True
-    if rank == 0:
-        print(json.dumps(out))
-        sys.stdout.flush()
     if comm_broken:
-        os._exit(0)                                             # (skips the teardown of a communicator that no longer answers)
+        sys.stderr.flush()
+        os._exit(3)                                             # non-zero: a collective broke (and skip the teardown of a communicator that no longer answers)
 
 
 if __name__ == "__main__":

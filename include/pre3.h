@@ -320,6 +320,18 @@ PRE3_API int pre3_kernel_timing_read(pre3_ctx *ctx, int *launches_out, double *t
                                      double *bytes_out);                /* synchronises, then resets */
 /* run only the K9 down-date P <- P - W'W with a synthetic W of r rows `reps` times (roofline probe) */
 PRE3_API int pre3_bench_downdate(pre3_ctx *ctx, int r, int reps, double *ms_per_launch_out);
+/* Matcher probe (bench.py's `matcher` object, tests/test_gpu_match_rank.py): descriptors uploaded and packed ONCE, then `reps` back-to-back
+ * launches of the distance + best/second-best stage bracketed by HIP events -- the kernel time of siftmatch.c:91-129's loop without the
+ * per-call upload, packing and result copy of pre3_siftmatch_*.  cls: 0 double, 1 float, 2 uint8 (pre3_match_bench_create: uint8).
+ * info[3] = { route taken (0 exact kernels, 1 int8 matrix cores, 2 bf16 rank + exact re-evaluation), queries the ranked route had to scan
+ * in full, candidates it listed over all queries }; fetch: per query best / second-best squared distance and 0-based argument,
+ * as siftmatch.c:110-116 leaves them.  Handles are independent of any pre3_ctx; NULL on failure (pre3_last_error). */
+PRE3_API void *pre3_match_bench_create(int device, int ND, int K1, const uint8_t *L1, int K2, const uint8_t *L2);
+PRE3_API void *pre3_match_bench_create_cls(int device, int cls, int ND, int K1, const void *L1, int K2, const void *L2);
+PRE3_API int pre3_match_bench_info(void *h, int32_t info[3]);
+PRE3_API int pre3_match_bench_run(void *h, int reps, double *ms_per_launch_out);
+PRE3_API int pre3_match_bench_fetch(void *h, double *best, double *second, int32_t *arg);
+PRE3_API void pre3_match_bench_destroy(void *h);
 
 #ifdef __cplusplus
 }
