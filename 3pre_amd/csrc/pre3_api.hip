@@ -294,6 +294,7 @@ int pre3_destroy(pre3_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->cholp_counted) { cholp_context_count(c->device, -1); c->cholp_counted = false; }
+    ic_rank_free(c);
     void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
                      c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
                      c->sel_rows, c->support, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128, c->need, c->cholp_flags, c->cholp_tp };
@@ -327,6 +328,7 @@ int pre3_get_option(pre3_ctx *c, int option, int *value_out)
     case PRE3_OPT_DEFER_HI: *value_out = c->defer_hi ? 1 : 0; return PRE3_OK;
     case PRE3_OPT_K9_BF16X3: *value_out = c->k9_b3 ? 1 : 0; return PRE3_OK;
     case PRE3_OPT_CHOL_PERSIST: *value_out = cholp_usable(c, 1) ? 1 : 0; return PRE3_OK;
+    case PRE3_OPT_IC_RANKED: *value_out = c->ic_last_ranked ? 1 : 0; return PRE3_OK;
     default: set_error("pre3_get_option: unknown option %d", option); return PRE3_E_ARG;
     }
 }
@@ -574,7 +576,7 @@ int pre3_set_descriptors(pre3_ctx *c, int first, int count, const double *desc)
     PRE3_HIP(hipStreamSynchronize(c->stream));
     if (count) PRE3_HIP(hipMemcpy(c->bank + (size_t)first * DESC_DIM, desc, sizeof(double) * (size_t)count * DESC_DIM, hipMemcpyHostToDevice));
     c->bank_set = true;
-    return PRE3_OK;
+    return ic_rank_check_bank(c, first, count);
 }
 
 int pre3_get_descriptors(pre3_ctx *c, int first, int count, double *desc)
@@ -610,7 +612,7 @@ int pre3_set_scan(pre3_ctx *c, int K2, const double *descriptor_raw, const doubl
         PRE3_HIP(hipMemcpy(c->scan_pos, scale_orient_pos_raw, sizeof(double) * (size_t)K2 * 4, hipMemcpyHostToDevice));
     }
     c->scan_K2 = K2;
-    return PRE3_OK;
+    return ic_rank_set_scan(c);
 }
 
 int pre3_ic_search(pre3_ctx *c, double thresh, int strict_reference, int32_t *n_matches_out, int32_t *m_out, int32_t *meas_idx_out,

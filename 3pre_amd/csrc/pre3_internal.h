@@ -140,6 +140,8 @@ struct pre3_ctx {
     double *scan_desc = nullptr, *scan_pos = nullptr; int scan_K2 = 0, scan_cap = 0;
     int32_t *ic_pred = nullptr, *ic_counts = nullptr, *ic_arg = nullptr, *ic_pairs = nullptr, *ic_newk2 = nullptr; double *ic_best = nullptr, *ic_second = nullptr;
     int32_t *bank_src = nullptr;
+    bool ic_last_ranked = false;                  // the last pre3_ic_search matched on the matrix cores (PRE3_OPT_IC_RANKED)
+    void *ic_rank = nullptr; bool bank_ok = false;   // the scan packed for the matrix-core matcher (pre3_match.hip: IcRank); every bank descriptor inside its bounds
     double *ic_pb = nullptr, *ic_ps = nullptr; int32_t *ic_pa = nullptr;     // per (column tile, landmark) partials of the tiled matcher [scan_cap/64][capN]
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -173,6 +175,9 @@ void scratch_release(int slot, void *p);
 // ---- IC search (pre3_match.hip)
 int launch_ic_search(pre3_ctx *c, double thresh, int strict);
 int launch_bank_gather(pre3_ctx *c, int N_new, const int32_t *src_host);
+int ic_rank_set_scan(pre3_ctx *c);
+int ic_rank_check_bank(pre3_ctx *c, int first, int count);
+void ic_rank_free(pre3_ctx *c);
 constexpr int DESC_DIM = 128;
 
 // ---- geometry / RANSAC kernels (pre3_geom.hip)

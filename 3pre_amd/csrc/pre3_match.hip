@@ -496,8 +496,9 @@ static void launch_pack_i8(int ND, int NDp, int K, int Kp, const T *L, int cente
 //           accumulation order and arithmetic (bin 0..ND-1, subtract, multiply, add, contraction off) and merges them with merge3: the
 //           outputs are bit-identical to k_match_exact's.  A query with more than 64 candidates is scanned in full by its wave.
 // Data the bounds do not cover (NaN / Inf, |x| > 2^60, 0 < |x| < 2^-40: squares or planes leaving the f32 range) set a flag in the pack
-// kernel and the host takes the exact kernels; descriptors that are integers in [0, 255] in every bin (what vl_sift produces, cast to
-// double) set another and go to the int8 kernel, whose integer distances are exactly the reference's double / float sums.
+// kernel and the host takes the exact kernels; descriptors that are integers in [0, 255] in every bin (Lowe-format descriptor files such as
+// sift/data/box.sift read into doubles; NOT what matching_sift_based.m:104-118 passes -- those are siftdescriptor.c:125-141's unit-norm real
+// values and take the ranked route above) set another and go to the int8 kernel, whose integer distances are exactly the reference's sums.
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -1325,11 +1326,123 @@ __global__ void k_bank_gather(const int32_t *__restrict__ src, const double *__r
     out[(size_t)blockIdx.x * DESC_DIM + threadIdx.x] = s >= 0 ? bank[(size_t)s * DESC_DIM + threadIdx.x] : 0.0;
 }
 
+// ---- the matcher of matching_sift_based.m:118 on the matrix cores inside the IC search (round 3).  The scan's descriptors are packed into
+// bf16 planes when they arrive (pre3_set_scan), the stacked query matrix des1 (matching_sift_based.m:108-114: the predicted landmarks'
+// descriptors in map order) is gathered from the bank through the device-side list and packed per call; k_rank_tiled<0/1> + k_rank_tail then
+// give (best, second, arg) bit-identical to the exact kernel's (tests/test_gpu_icsearch.py runs both).  Descriptors outside the ranked
+// route's bounds (NaN / Inf, |x| > 2^60, 0 < |x| < 2^-40), small problems and PRE3_IC_RANK=0 keep the exact VALU kernel.
+struct IcRank { RankMatch r; int K1cap = 0, K2 = -1; bool scan_ok = false; };
+
+__global__ void k_desc_check(size_t count, const double *__restrict__ d, int *__restrict__ flags)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const double ax = fabs(d[i]);
+    if (!(ax <= 0x1p60) || (ax != 0.0 && ax < 0x1p-40)) atomicOr(flags, 1);
+}
+// des1[q] = bank[pred[q]] (rows beyond the device-side count repeat older list entries: in range, never read back)
+__global__ __launch_bounds__(DESC_DIM) void k_ic_gather_q(const int32_t *__restrict__ pred, const double *__restrict__ bank, double *__restrict__ des1)
+{
+    des1[(size_t)blockIdx.x * DESC_DIM + threadIdx.x] = bank[(size_t)pred[blockIdx.x] * DESC_DIM + threadIdx.x];
+}
+
+static int desc_in_bounds(const double *dev, size_t count, bool *ok)      // synchronous (the callers are: descriptor / scan uploads)
+{
+    DevBuf fl;
+    PRE3_TRY(fl.alloc(sizeof(int)));
+    PRE3_HIP(hipMemset(fl.p, 0, sizeof(int)));
+    if (count) hipLaunchKernelGGL(k_desc_check, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, count, dev, (int *)fl.p);
+    int f = 0;
+    PRE3_HIP(hipMemcpy(&f, fl.p, sizeof(int), hipMemcpyDeviceToHost));
+    *ok = f == 0;
+    return PRE3_OK;
+}
+
+void ic_rank_free(pre3_ctx *c) { delete static_cast<IcRank *>(c->ic_rank); c->ic_rank = nullptr; }
+
+int ic_rank_check_bank(pre3_ctx *c, int first, int count)
+{
+    bool ok = true;
+    PRE3_TRY(desc_in_bounds(c->bank + (size_t)first * DESC_DIM, (size_t)count * DESC_DIM, &ok));
+    if (!ok) c->bank_ok = false;            // (sticky until the whole bank is rewritten: a bad descriptor may stay in the map)
+    else if (first == 0 && count >= c->N) c->bank_ok = true;
+    return PRE3_OK;
+}
+
+// the scan has just been uploaded: pack it for the ranked route (or note that it cannot take it)
+int ic_rank_set_scan(pre3_ctx *c)
+{
+    const int K2 = c->scan_K2, K1 = c->capN;
+    IcRank *ic = static_cast<IcRank *>(c->ic_rank);
+    if (ic) ic->scan_ok = false;
+    if (K2 <= 0 || K1 <= 0) return PRE3_OK;
+    if (!ic || ic->K1cap < K1 || round_up(K2, 128) > ic->r.K2p) {
+        ic_rank_free(c);
+        ic = new (std::nothrow) IcRank();
+        PRE3_CHECK(ic != nullptr, PRE3_E_NOMEM, "out of host memory");
+        c->ic_rank = ic;
+        RankMatch &r = ic->r;
+        r.ND = DESC_DIM; r.K1p = round_up(K1, 128); r.K2p = round_up(c->scan_cap > K2 ? c->scan_cap : K2, 128);
+        ic->K1cap = K1;
+        PRE3_TRY(r.L1.alloc(sizeof(double) * (size_t)DESC_DIM * r.K1p));
+        PRE3_TRY(r.qh.alloc((size_t)r.K1p * 256)); PRE3_TRY(r.ql.alloc((size_t)r.K1p * 256)); PRE3_TRY(r.dh.alloc((size_t)r.K2p * 256)); PRE3_TRY(r.dl.alloc((size_t)r.K2p * 256));
+        PRE3_TRY(r.nq.alloc(sizeof(float) * r.K1p)); PRE3_TRY(r.nqU.alloc(sizeof(float) * r.K1p)); PRE3_TRY(r.nqL.alloc(sizeof(float) * r.K1p));
+        PRE3_TRY(r.nU.alloc(sizeof(float) * r.K2p)); PRE3_TRY(r.nL.alloc(sizeof(float) * r.K2p)); PRE3_TRY(r.nd.alloc(sizeof(float) * r.K2p));
+        PRE3_TRY(r.fl.alloc(sizeof(int) * 4));
+        PRE3_TRY(r.pb.alloc(sizeof(float) * (size_t)64 * r.K1p)); PRE3_TRY(r.ps.alloc(sizeof(float) * (size_t)64 * r.K1p));
+        PRE3_TRY(r.gcnt.alloc(sizeof(int) * r.K1p)); PRE3_TRY(r.gcand.alloc(sizeof(int) * (size_t)r.K1p * RK_CAP));
+        PRE3_TRY(r.m.A.alloc((size_t)r.K1p * 128)); PRE3_TRY(r.m.B.alloc((size_t)r.K2p * 128));
+        PRE3_TRY(r.m.na.alloc(sizeof(int) * r.K1p)); PRE3_TRY(r.m.nb.alloc(sizeof(int) * r.K2p));
+        PRE3_TRY(r.m.ob.alloc(sizeof(double) * r.K1p)); PRE3_TRY(r.m.os.alloc(sizeof(double) * r.K1p)); PRE3_TRY(r.m.oa.alloc(sizeof(int32_t) * r.K1p));
+    }
+    RankMatch &r = ic->r;
+    const int K2p = round_up(K2, 128);
+    PRE3_HIP(hipMemset(r.fl.p, 0, sizeof(int) * 4));
+    hipLaunchKernelGGL((k_rank_pack<double>), dim3(K2p * 8 / 256), dim3(256), 0, 0, DESC_DIM, K2, K2p, (const double *)c->scan_desc, (v4i *)r.dh.p, (v4i *)r.dl.p,
+                       (float *)r.nU.p, (float *)r.nL.p, (float *)r.nd.p, (int8_t *)r.m.B.p, (int *)r.m.nb.p, (int *)r.fl.p);
+    PRE3_HIP(hipGetLastError());
+    int fl = 0;
+    PRE3_HIP(hipMemcpy(&fl, r.fl.p, sizeof(int), hipMemcpyDeviceToHost));
+    ic->K2 = K2;
+    ic->scan_ok = (fl & 1) == 0;
+    return PRE3_OK;
+}
+
+static bool ic_rank_usable(const pre3_ctx *c)
+{
+    const char *e = getenv("PRE3_IC_RANK");                    // 0: the exact VALU kernel (A/B, tests); read per call
+    if (e && atoi(e) == 0) return false;
+    const IcRank *ic = static_cast<const IcRank *>(c->ic_rank);
+    return ic && ic->scan_ok && ic->K2 == c->scan_K2 && c->bank_ok && c->N <= ic->K1cap && rank_applies<double>(DESC_DIM, c->N, c->scan_K2);
+}
+
 int launch_ic_search(pre3_ctx *c, double thresh, int strict)
 {
     const int N = c->N;
     hipLaunchKernelGGL(k_ic_stack, dim3(1), dim3(64), 0, c->stream, N, c->lm.has_h, c->ic_pred, c->ic_counts, c->ic_newk2);
     if (c->scan_K2 > 0) {
+        const double *best = c->ic_best, *second = c->ic_second;
+        const int32_t *arg = c->ic_arg;
+        c->ic_last_ranked = ic_rank_usable(c);
+        if (c->ic_last_ranked) {
+            RankMatch &r = static_cast<IcRank *>(c->ic_rank)->r;
+            const int K2 = c->scan_K2;
+            r.K1 = N; r.K2 = K2; r.K1p = round_up(N, 128); r.K2p = round_up(K2, 128); r.route = 2;
+            r.m.K1 = N; r.m.K2 = K2; r.m.K1p = r.K1p; r.m.K2p = r.K2p;
+            {   // the tiled form's database slices: about one workgroup per CU (as rank_prepare)
+                const int groups = r.K1p / RT_Q, nblk = r.K2p / 16;
+                r.nsl = std::max(1, std::min(std::min(ceil_div(c->num_cus, groups), nblk / RT_WAVES), 64));
+            }
+            hipLaunchKernelGGL(k_ic_gather_q, dim3(N), dim3(DESC_DIM), 0, c->stream, (const int32_t *)c->ic_pred, (const double *)c->bank, (double *)r.L1.p);
+            hipLaunchKernelGGL((k_rank_pack<double>), dim3(r.K1p * 8 / 256), dim3(256), 0, c->stream, DESC_DIM, N, r.K1p, (const double *)r.L1.p, (v4i *)r.qh.p, (v4i *)r.ql.p,
+                               (float *)r.nqU.p, (float *)r.nqL.p, (float *)r.nq.p, (int8_t *)r.m.A.p, (int *)r.m.na.p, (int *)r.fl.p + 1);
+            // (the tail re-evaluates from the original descriptors: des1 and the scan as the caller gave them)
+            const void *saveL2 = r.L2.p; r.L2.p = c->scan_desc;
+            const int rc = rank_run<double>(r, 0, c->stream);
+            r.L2.p = const_cast<void *>(saveL2);
+            PRE3_TRY(rc);
+            best = (const double *)r.m.ob.p; second = (const double *)r.m.os.p; arg = (const int32_t *)r.m.oa.p;
+        } else {
         const int ntn = ceil_div(c->scan_K2, 64);
         hipLaunchKernelGGL((k_match_exact_tiled<double>), dim3(ntn, ceil_div(N, 64)), dim3(256), 0, c->stream, DESC_DIM, N, c->scan_K2,
                            (const double *)c->bank, (const double *)c->scan_desc, c->ic_pb, c->ic_ps, c->ic_pa, ntn,
@@ -1337,10 +1450,14 @@ int launch_ic_search(pre3_ctx *c, double thresh, int strict)
         // rows >= the device-side query count hold stale partials; k_ic_gate only reads the first counts[0] results
         hipLaunchKernelGGL((k_match_reduce_f<double>), dim3(ceil_div(16 * N, 256)), dim3(256), 0, c->stream, N, ntn, (const double *)c->ic_pb,
                            (const double *)c->ic_ps, (const int32_t *)c->ic_pa, 0, c->ic_best, c->ic_second, c->ic_arg);
-        hipLaunchKernelGGL(k_ic_gate, dim3(1), dim3(512), 0, c->stream, c->ic_pred, c->ic_best, c->ic_second, c->ic_arg,
+        }
+        hipLaunchKernelGGL(k_ic_gate, dim3(1), dim3(512), 0, c->stream, c->ic_pred, best, second, arg,
                            (float)thresh, strict, c->scan_pos, c->lm.h, c->lm.S, c->lm.has_S, c->lm.z, c->lm.ic, c->ic_pairs, c->ic_newk2,
                            c->ic_counts, c->ic_counts + 4, (double *)(c->ic_counts + 4 + 4 * (size_t)c->capN));
         hipLaunchKernelGGL(k_ic_refresh, dim3(N), dim3(DESC_DIM), 0, c->stream, c->ic_newk2, c->scan_desc, c->bank);
+        // (accepted landmarks take the scan's descriptors: a scan outside the ranked route's bounds takes the bank with it)
+        const IcRank *ic = static_cast<const IcRank *>(c->ic_rank);
+        if (!(ic && ic->scan_ok && ic->K2 == c->scan_K2)) c->bank_ok = false;
     }
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;

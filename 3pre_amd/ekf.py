@@ -103,6 +103,12 @@ class EkfFilter:
         check(lib.pre3_get_option(self._ctx, 2, C.byref(v)))
         return bool(v.value)
 
+    def ic_search_was_ranked(self):
+        """PRE3_OPT_IC_RANKED: whether the last matching_sift_based() matched on the matrix cores"""
+        v = C.c_int(0)
+        check(lib.pre3_get_option(self._ctx, 4, C.byref(v)))
+        return bool(v.value)
+
     def chol_persist(self, on=None):
         """PRE3_OPT_CHOL_PERSIST (fp32 contexts): update.m:32-33 -- the factorisation of S and W = L^-1 [HP | nu] -- as one persistent launch
         (default) or, off, one launch per 64-column panel.  Returns whether the persistent form is in effect."""

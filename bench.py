@@ -203,13 +203,22 @@ def matcher_leg(pre3, reps=20):
     if rc != 0:
         return None
     tops = 2.0 * K * K * 128 / (ms.value * 1e-3) / 1e12
-    # the class matching_sift_based.m:104-118 actually passes (double): the same descriptors as doubles (integer-valued: int8 route) and a
-    # real-valued set (bf16 distance GEMM ranks, guard-band candidates re-evaluated exactly); pre3_match.hip "float / double classes"
+    # The class matching_sift_based.m:104-118 actually passes is DOUBLE holding siftdescriptor.c:125-141's unit-norm real values (normalise,
+    # clip at 0.2, renormalise): `double_unit_norm` is that distribution (bf16 distance GEMM ranks, guard-band candidates re-evaluated exactly;
+    # pre3_match.hip "float / double classes").  Beside it: doubles that hold integers (Lowe-format files: int8 route) and a real-valued set
+    # at the uint8 scale.
     fl = {}
     real1 = np.abs(rng.standard_normal((K, 128))) * 40
     real2 = real1[rng.permutation(K)] + rng.uniform(-2, 2, (K, 128))
-    for name, A, B in (("double_integer_valued", L1.astype(np.float64), L2.astype(np.float64)), ("double_real_valued", real1, real2),
-                       ("float_real_valued", real1.astype(np.float32), real2.astype(np.float32))):
+
+    def sift_like(X):
+        X = np.abs(X); X = X / np.linalg.norm(X, axis=1, keepdims=True)
+        X = np.minimum(X, 0.2)
+        return X / np.linalg.norm(X, axis=1, keepdims=True)
+    unit1 = sift_like(rng.standard_normal((K, 128)))
+    unit2 = sift_like(unit1[rng.permutation(K)] + 0.02 * np.abs(rng.standard_normal((K, 128))))
+    for name, A, B in (("double_unit_norm", unit1, unit2), ("double_integer_valued", L1.astype(np.float64), L2.astype(np.float64)),
+                       ("double_real_valued", real1, real2), ("float_real_valued", real1.astype(np.float32), real2.astype(np.float32))):
         hf = lib.pre3_match_bench_create_cls(0, 0 if A.dtype == np.float64 else 1, 128, K, A.ctypes.data_as(C.c_void_p), K, B.ctypes.data_as(C.c_void_p))
         if not hf:
             continue

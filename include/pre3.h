@@ -192,6 +192,10 @@ PRE3_API int pre3_update_ell(int device, int dtype, int n, int r, const double *
  * factorisation of S and W = L^-1 [HP | nu] -- as ONE persistent launch (pre3_cholp.hip) for updates of up to 13 x 64 rows;
  * 0: one launch per 64-column panel (the form every fp64 context and every larger update uses).  get: whether the form is in effect. */
 #define PRE3_OPT_CHOL_PERSIST 3
+/* PRE3_OPT_IC_RANKED (read only): 1 if the last pre3_ic_search ran matching_sift_based.m:118's siftmatch on the matrix cores (bf16 distance
+ * GEMM ranks + exact re-evaluation; N * K2 >= 65536 and every descriptor inside the route's bounds), 0 if it took the exact VALU kernel.
+ * The environment's PRE3_IC_RANK=0 forces the latter.  Results are bit-identical either way. */
+#define PRE3_OPT_IC_RANKED 4
 PRE3_API int pre3_set_option(pre3_ctx *ctx, int option, int value);
 PRE3_API int pre3_get_option(pre3_ctx *ctx, int option, int *value_out);
 

@@ -36,6 +36,39 @@ def _scan(rng, h, has_h, bank, n_clutter, frac_seen=0.8, px_sigma=1.5, n_far=4):
     return np.array(desc).T[:, perm].copy(), np.array(pos).T[:, perm].copy()
 
 
+@pytest.mark.parametrize("rank_env", ["1", "0"])
+def test_ic_search_on_the_matrix_cores_matches_oracle(pre3, orc, rank_env, monkeypatch):
+    """N = 300 landmarks against ~300 keypoints (N * K2 >= 65536): matching_sift_based.m:118's siftmatch runs as the bf16 distance GEMM +
+    exact re-evaluation inside pre3_ic_search (PRE3_IC_RANK=0: the exact VALU kernel); match list, scores-dependent ratio test, gate,
+    measurement list, z and the refreshed bank are the oracle's bit for bit on both routes"""
+    monkeypatch.setenv("PRE3_IC_RANK", rank_env)
+    N = 300
+    rng, seq, bank = _scene(N, 31)
+    s = seq["steps"][0]
+    types, off, n = orc.landmark_table(np.zeros(N, int))
+    f = pre3.EkfFilter(seq["cam"], types, dtype="f64", max_hyp=8)
+    f.set_x_p_k_k(seq["x0"], seq["P0"])
+    f.set_descriptors(bank)
+    for frame in range(2):                                     # second frame: the bank holds refreshed (scan) descriptors
+        f.ekf_prediction(s["u"])
+        x1, P1 = f.get_x_k_km1(), f.get_p_k_km1()
+        h, has_h = orc.project(types, off, x1, seq["cam"])
+        sd, sp = _scan(rng, h, has_h, bank, 90, px_sigma=4.0)
+        sd[:, 5] = sd[:, 17]                                   # two identical keypoints: a tie for best / second best
+        f.load_scan(sd, sp)
+        bank_before = f.get_descriptors()
+        out = f.matching_sift_based(1.5, strict_reference=True)
+        assert f.ic_search_was_ranked() == (rank_env == "1") and N * sd.shape[1] >= 65536
+        ref = orc.ic_search(types, off, x1, P1, seq["cam"], bank_before, sd, sp, 1.5, True)
+        assert ref["match_idx"].shape[1] > 100
+        assert np.array_equal(out["match_idx"], ref["match_idx"]) and np.array_equal(out["accepted"], ref["accepted"])
+        assert np.array_equal(out["meas_idx"], ref["meas_idx"]) and np.array_equal(out["z"], ref["z"])
+        assert np.array_equal(f.get_descriptors(), ref["bank"])
+        f.set_x_p_k_k(x1, P1)
+        bank = ref["bank"]
+    f.close()
+
+
 @pytest.mark.parametrize("dtype,strict", [("f64", True), ("f64", False), ("f32", True)])
 def test_ic_search_matches_oracle(pre3, orc, dtype, strict):
     N = 60

@@ -58,7 +58,7 @@ def test_routes(pre3, dt):
     assert info[0] == 2 and info[1] == 0 and 2 * 256 <= info[2] <= 8 * 256          # bf16 rank; a handful of candidates per query
     ref = _exact_partial(pre3, L1, L2)
     assert all(np.array_equal(g, r) for g, r in zip(got, ref))
-    Li1, Li2 = np.floor(L1 * 256).astype(dt), np.floor(L2 * 256).astype(dt)        # what vl_sift hands matching_sift_based.m:104-118, as doubles
+    Li1, Li2 = np.floor(L1 * 256).astype(dt), np.floor(L2 * 256).astype(dt)        # integer-valued doubles (Lowe-format files such as sift/data/box.sift)
     info, got = _route(pre3, Li1, Li2)
     assert info[0] == 1                                                              # integers in [0, 255]: the int8 kernel is exact
     ref = _exact_partial(pre3, Li1, Li2)
@@ -121,6 +121,39 @@ def test_scales_and_forced_rank(pre3, orc, dt):
     assert np.array_equal(m, mr) and np.array_equal(d, dr)
     m1, d1 = pre3.siftmatch(Li1, Li2, 1.5, return_scores=True)                                   # the int8 route
     assert np.array_equal(m1, mr) and np.array_equal(d1, dr)
+
+
+def test_the_reference_s_own_descriptors_through_the_ranked_route(pre3, orc, sr4000):
+    """What matching_sift_based.m:104-118 really hands siftmatch: siftdescriptor.c:125-141's UNIT-NORM real-valued descriptors as doubles (the
+    185 landmark descriptors of the SR4000 snapshot: max bin 0.48, norm 1) against a scan made of their perturbed, permuted copies plus
+    clutter.  The guard band E (n_q + n_b) = 3.6e-4 is then small against match distances of 0.01-0.3 -- few candidates per query -- and the
+    result must be the oracle's bit for bit, scores included.  PRE3_MATCH_FLOAT_FORM=2 keeps the problem (185 x 700, below the size cut-off
+    of the matrix-core route) on that route."""
+    rng = np.random.default_rng(11)
+    D = np.ascontiguousarray(sr4000["descriptor"].reshape(-1, 128).T)              # 128 x 185, column = descriptor
+    assert D.shape == (128, 185) and np.allclose(np.linalg.norm(D, axis=0), 1.0, atol=1e-6) and D.max() < 0.6
+
+    def sift_like(X):                                                               # siftdescriptor.c:125-141: normalise, clip at 0.2, renormalise
+        X = np.abs(X)
+        X = X / np.linalg.norm(X, axis=0)
+        X = np.minimum(X, 0.2)
+        return X / np.linalg.norm(X, axis=0)
+
+    perm = rng.permutation(185)
+    scan = np.concatenate([sift_like(D[:, perm] + 0.02 * np.abs(rng.standard_normal((128, 185)))),      # the landmarks seen again, perturbed
+                           sift_like(rng.standard_normal((128, 515)))], axis=1)                        # clutter keypoints
+    scan[:, 300] = scan[:, 7]                                                       # an exact duplicate in the scan: a tie for the best
+    for dt in (np.float64, np.float32):
+        L1, L2 = D.astype(dt), scan.astype(dt)
+        mr, dr = orc.siftmatch(L1, L2, 1.5)
+        with _Form(2):
+            m, d = pre3.siftmatch(L1, L2, 1.5, return_scores=True)
+            info, got = _route(pre3, L1, L2)
+        assert np.array_equal(m, mr) and np.array_equal(d, dr), dt
+        assert mr.shape[1] > 100                                                    # most landmarks find their perturbed copy
+        assert info[0] == 2 and info[1] == 0 and info[2] <= 8 * 185, info           # ranked route, nobody scanned in full, a few candidates each
+        ref = _exact_partial(pre3, L1, L2)
+        assert all(np.array_equal(g, r) for g, r in zip(got, ref))
 
 
 def test_full_size_double_class(pre3):
