@@ -890,7 +890,16 @@ int pre3_set_flags(pre3_ctx *c, const int32_t *li, const int32_t *hi)
 int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, const double *z, int n_draw, int k, const int32_t *hyp,
               double threshold, int early_exit, double chi2, int32_t stats[8])
 {
-    PRE3_TRY(check_ctx(c));
+    // the previous step's deferred HI update is completed here; its rows/cols 3..6 <- Jn pass (update.m:42-46) is left to the prediction's
+    // launch below (one launch less per step; PRE3_FUSE_JN=0: as its own launch).  Any return before that launch flushes it.
+    static const int fuse_jn_env = getenv("PRE3_FUSE_JN") ? atoi(getenv("PRE3_FUSE_JN")) : 1;
+    if (c) c->leave_jn_to_predict = fuse_jn_env && c->hi_pending;
+    {
+        const int rc0 = check_ctx(c);
+        if (c) c->leave_jn_to_predict = false;
+        if (rc0 != PRE3_OK) { if (c && c->jn_pending) { c->jn_pending = false; (void)launch_jnorm(c, 0); } return rc0; }
+    }
+    struct JnFlush { pre3_ctx *c; ~JnFlush() { if (c->jn_pending) { c->jn_pending = false; (void)launch_jnorm(c, 0); } } } jn_flush{ c };
     static const bool trace = getenv("PRE3_STEP_TRACE") != nullptr;     // host-side stage clock (debug): where the host spends a step
     static double acc[8], t_prev_end = 0; static int nacc = 0;
     auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; };

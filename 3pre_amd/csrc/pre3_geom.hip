@@ -41,7 +41,14 @@ __device__ inline void d_process_noise(double *Pn)
         }
 }
 
-// pred_params layout: [0..15] A4 = Qq1, [16..31] Jn, [32..80] Q7 = G Pn G' (7x7)
+// pred_params layout: [0..15] A4 = Qq1, [16..31] Jn, [32..80] Q7 = G Pn G' (7x7), [96..111] Jn of the last update (a copy the prediction's
+// launch does not overwrite: k_predict reads it when it carries that update's update.m:42-46 pass, fuse_jn)
+// One row of the 4x4 normalisation Jacobian applied to a 4-vector, with the contraction spelled out: k_jnorm_P and the prediction launch
+// that carries the same pass (fuse_jn) must round identically (tests/test_gpu_synth.py: deferred == immediate HI update, bit for bit).
+__device__ __forceinline__ double jn_row(const double *J, int i, const double v[4])
+{
+    return fma(J[i * 4 + 3], v[3], fma(J[i * 4 + 2], v[2], fma(J[i * 4 + 1], v[1], J[i * 4] * v[0])));
+}
 // The per-step inbox [meas | ic | hyp | z]: pinned host memory, read over PCIe by the device itself (16 bytes per lane).  ONE workgroup, so
 // that its last act can be to publish `seq` in the pinned mailbox: the host may overwrite the inbox once it reads that number back.
 struct InboxRide { const int4 *src; int4 *dst; int n16; int32_t *mail; int32_t seq; };        // n16 == 0: no pull in this launch
@@ -64,12 +71,15 @@ __device__ __forceinline__ void inbox_pull_block(const InboxRide &ib)
 // reading them from a previous kernel; block 0 additionally owns x_out[0:13], the process noise and the 7x7 pose block.
 template <typename T>
 __global__ __launch_bounds__(256) void k_predict(const double *__restrict__ x_in, double *x_out, T *__restrict__ P, int n, int ld, U7 u,
-                                                 double *__restrict__ params, int n_pred_blocks, ProjRide pr, InboxRide ib)
+                                                 double *__restrict__ params, int n_pred_blocks, ProjRide pr, InboxRide ib, int fuse_jn)
 {
     if ((int)blockIdx.x >= n_pred_blocks + pr.n_blocks) { inbox_pull_block(ib); return; }               // the step's inbox crosses PCIe beside the prediction
     if ((int)blockIdx.x >= n_pred_blocks) { proj_ride_block(pr, blockIdx.x - n_pred_blocks); return; }   // IC-search projection rides along
-    __shared__ double sQq1[16], sJn[16], sQ[49], sG[49], sPn[49], sGP[49];
+    __shared__ double sQq1[16], sJn[16], sQ[49], sG[49], sPn[49], sGP[49], sJu[16];
     __shared__ double corner[49];      // old P[0:7,0:7]
+    // fuse_jn: the previous update's rows/cols 3..6 <- Jn pass (update.m:42-46, k_jnorm_P) is applied here first, value for value as
+    // that kernel would have stored it (rounded to T), so the launch in front of this one is saved (pre3_step with PRE3_OPT_DEFER_HI)
+    if (fuse_jn && threadIdx.x >= 64 && threadIdx.x < 80) sJu[threadIdx.x - 64] = params[96 + threadIdx.x - 64];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     // landmarks copied (predict_state_and_covariance.m:79)
     for (int i = 13 + j; i < n; i += n_pred_blocks * blockDim.x) x_out[i] = x_in[i];
@@ -113,6 +123,27 @@ __global__ __launch_bounds__(256) void k_predict(const double *__restrict__ x_in
     // signal is the only one they wait for (every block signalling cost each of them a device-scope release)
     if (pr.n_blocks && blockIdx.x == 0) ride_signal(pr.ctr);       // (includes the barrier)
     else __syncthreads();
+    double cfix = 0; int cpos = -1;
+    if (fuse_jn) {
+        if (j >= 7 && j < n) { double w[4]; for (int i = 0; i < 4; ++i) w[i] = (double)(T)jn_row(sJu, i, v); for (int i = 0; i < 4; ++i) v[i] = w[i]; }
+        if (blockIdx.x == 0 && threadIdx.x < 28) {
+            // the 7x7 corner: columns 0..2 of rows 3..6 (and their mirror), then the 4x4 block J C J'
+            const int t = threadIdx.x;
+            if (t < 12) {
+                const int jc = t >> 2, i = t & 3;
+                const double w[4] = { corner[3 * 7 + jc], corner[4 * 7 + jc], corner[5 * 7 + jc], corner[6 * 7 + jc] };
+                cfix = (double)(T)jn_row(sJu, i, w); cpos = (3 + i) * 7 + jc;
+            } else {
+                const int i = (t - 12) >> 2, k = (t - 12) & 3;
+                double T1[4];
+                for (int c2 = 0; c2 < 4; ++c2) { const double w[4] = { corner[3 * 7 + 3 + c2], corner[4 * 7 + 3 + c2], corner[5 * 7 + 3 + c2], corner[6 * 7 + 3 + c2] }; T1[c2] = jn_row(sJu, i, w); }
+                cfix = (double)(T)jn_row(sJu, k, T1); cpos = (3 + i) * 7 + 3 + k;
+            }
+        }
+        __syncthreads();
+        if (cpos >= 0) { corner[cpos] = cfix; if (threadIdx.x < 12) corner[(cpos % 7) * 7 + cpos / 7] = cfix; }
+        // (block 0 reads the corner behind the barriers of its pose-block section below)
+    }
     if (j >= 7 && j < n) {
         double a[4], b[4];
         for (int i = 0; i < 4; ++i) a[i] = sQq1[i * 4] * v[0] + sQq1[i * 4 + 1] * v[1] + sQq1[i * 4 + 2] * v[2] + sQq1[i * 4 + 3] * v[3];
@@ -159,14 +190,14 @@ __global__ void k_jnorm_P(T *__restrict__ P, int n, int ld, const double *__rest
     __syncthreads();
     if (strip) {
         for (int i = 0; i < 4; ++i) {
-            double b = sJn[i * 4] * v[0] + sJn[i * 4 + 1] * v[1] + sJn[i * 4 + 2] * v[2] + sJn[i * 4 + 3] * v[3];
+            const double b = jn_row(sJn, i, v);
             P[(3 + i) * ld + j] = (T)b; P[j * ld + 3 + i] = (T)b;
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         double T1[16];
-        for (int i = 0; i < 4; ++i) for (int k = 0; k < 4; ++k) { double s = 0; for (int t = 0; t < 4; ++t) s += sJn[i * 4 + t] * corner[t * 4 + k]; T1[i * 4 + k] = s; }
-        for (int i = 0; i < 4; ++i) for (int k = 0; k < 4; ++k) { double s = 0; for (int t = 0; t < 4; ++t) s += T1[i * 4 + t] * sJn[k * 4 + t]; P[(3 + i) * ld + 3 + k] = (T)s; }
+        for (int i = 0; i < 4; ++i) for (int k = 0; k < 4; ++k) { const double w[4] = { corner[k], corner[4 + k], corner[8 + k], corner[12 + k] }; T1[i * 4 + k] = jn_row(sJn, i, w); }
+        for (int i = 0; i < 4; ++i) for (int k = 0; k < 4; ++k) P[(3 + i) * ld + 3 + k] = (T)jn_row(sJn, k, &T1[i * 4]);
     }
 }
 
@@ -698,7 +729,7 @@ __global__ __launch_bounds__(1024) void k_update_x(int n, int r, const T *__rest
     if (blockIdx.x == 0) {          // block-uniform branch: every thread of block 0 reaches the barrier
         if (rg == 0 && i >= 3 && i < 7) q[i - 3] = s;
         __syncthreads();
-        if (rg == 0 && i == 0) { double Jn[16]; d_normjac(q, Jn); for (int t = 0; t < 16; ++t) params[16 + t] = Jn[t]; }
+        if (rg == 0 && i == 0) { double Jn[16]; d_normjac(q, Jn); for (int t = 0; t < 16; ++t) { params[16 + t] = Jn[t]; params[96 + t] = Jn[t]; } }
         if (rg == 0 && i >= 3 && i < 7) s = s / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     }
     if (rg == 0 && i < n) x_out[i] = s;
@@ -733,10 +764,12 @@ int launch_predict_impl(pre3_ctx *c, const double u[7], bool with_projection, si
     if (with_projection && c->N > 0) { pr = make_proj_ride(c, PRE3_X_K_KM1, 1, 0, 1); pr.x_lm = c->x_kk; }      // one producer: block 0 (the pose)
     InboxRide ib{ (const int4 *)c->inbox_host_dev, (int4 *)c->inbox_dev, (int)inbox_n16, c->mail_dev, inbox_seq };     // one more block when inbox_n16 > 0
     const int nb = blocks + pr.n_blocks + (inbox_n16 ? 1 : 0);
+    const int fuse_jn = c->jn_pending ? 1 : 0;          // the pending update.m:42-46 pass of the update in front (run_update left it to this launch)
     DISPATCH_T(c,
-        hipLaunchKernelGGL(k_predict<double>, dim3(nb), dim3(256), 0, c->stream, c->x_kk, c->x_km1, (double *)c->P, c->n, c->ld, uu, c->pred_params, blocks, pr, ib),
-        hipLaunchKernelGGL(k_predict<float>, dim3(nb), dim3(256), 0, c->stream, c->x_kk, c->x_km1, (float *)c->P, c->n, c->ld, uu, c->pred_params, blocks, pr, ib));
+        hipLaunchKernelGGL(k_predict<double>, dim3(nb), dim3(256), 0, c->stream, c->x_kk, c->x_km1, (double *)c->P, c->n, c->ld, uu, c->pred_params, blocks, pr, ib, fuse_jn),
+        hipLaunchKernelGGL(k_predict<float>, dim3(nb), dim3(256), 0, c->stream, c->x_kk, c->x_km1, (float *)c->P, c->n, c->ld, uu, c->pred_params, blocks, pr, ib, fuse_jn));
     PRE3_HIP(hipGetLastError());
+    c->jn_pending = false;
     return PRE3_OK;
 }
 

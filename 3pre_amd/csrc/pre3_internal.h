@@ -88,6 +88,7 @@ struct pre3_ctx {
     void *tiles128 = nullptr; int n_tiles128 = 0; // int2[n_tiles128]: 128x128 upper-triangle tiles of k_downdate_b3, XCD-interleaved
     unsigned int *chol_arrive = nullptr; unsigned int chol_target = 0;   // [0] panel arrivals, [1] scoring done, [2] rescue done, [3],[4] rider producers
     unsigned int ride_target[2] = { 0, 0 };
+    bool leave_jn_to_predict = false, jn_pending = false;          // the deferred HI update's rows/cols 3..6 <- Jn pass rides in the next k_predict
     bool defer_hi = false, hi_pending = false; int last_n_hi = 0;   // PRE3_OPT_DEFER_HI (pre3_set_option)
     bool ride_rescue_projection = false;          // request: the next K9 launch also projects at x_k_k (pre3_step sets it before the LI update)
     bool rescue_projected = false;                // h / H at the current x_k_k are on the device (set by that launch, consumed by pre3_rescue)

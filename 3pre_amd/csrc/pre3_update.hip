@@ -889,7 +889,7 @@ __device__ __forceinline__ void update_x_block(int blk, int n, int r, const T *_
     if (blk == 0) {                 // block-uniform branch: every thread of the block reaches the barrier
         if (rg == 0 && i >= 3 && i < 7) q[i - 3] = s;
         __syncthreads();
-        if (rg == 0 && i == 0) { double Jn[16]; d_normjac(q, Jn); for (int t = 0; t < 16; ++t) params[16 + t] = Jn[t]; }
+        if (rg == 0 && i == 0) { double Jn[16]; d_normjac(q, Jn); for (int t = 0; t < 16; ++t) { params[16 + t] = Jn[t]; params[96 + t] = Jn[t]; } }
         if (rg == 0 && i >= 3 && i < 7) s = s / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     }
     if (rg == 0 && i < n) x_out[i] = s;
@@ -1347,7 +1347,7 @@ int launch_ell_G_hyp(pre3_ctx *c, int k, int lo, int hi, int ldg)
     return PRE3_OK;
 }
 
-static int launch_chol_solve(pre3_ctx *c, int r_pad, bool first_done = false)
+static int launch_chol_solve(pre3_ctx *c, int r_pad, bool first_done = false, bool predicted_prior = false)
 {
     int nrb = r_pad / NB, nW = c->ldw / NB;
     c->split_rows = 0;
@@ -1357,8 +1357,10 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad, bool first_done = false)
         return PRE3_OK;
     }
     c->cholp_done = false;
-    // (one panel is one launch in either form, and the lock-step form has no hand-off in it: 12.5 us against 17)
-    if (!first_done && nrb >= 2 && cholp_usable(c, nrb)) return launch_cholp(c, nrb, nrb);
+    // (one panel is one launch in either form, and the lock-step form has no hand-off in it: 12.5 us against 17 -- taken for the rescue
+    // stage's small updates; an update of the PREDICTED state keeps the persistent form at any size, because pre3_update_li's speculative
+    // launch -- row count still on the device -- cannot choose, and the two ways into that update must compute the same thing)
+    if (!first_done && (nrb >= 2 || predicted_prior) && cholp_usable(c, nrb)) return launch_cholp(c, nrb, nrb);
     {
         const bool split = c->k9_b3 && c->dtype == PRE3_F32 && c->Wp != nullptr;
         static const int pro_env = getenv("PRE3_CHOL_PRO_B3") ? atoi(getenv("PRE3_CHOL_PRO_B3")) : 1;
@@ -1551,9 +1553,11 @@ int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_d
         PRE3_TRY(launch_ell_HP(c, r, c->W, true));
         PRE3_TRY(launch_ell_G(c, r, c->W, c->Smat, r_pad, 1, dense_R ? c->Rdense : nullptr));
     }
-    PRE3_TRY(launch_chol_solve(c, r_pad, first_done));
+    PRE3_TRY(launch_chol_solve(c, r_pad, first_done, which_prior == PRE3_X_K_KM1));
     PRE3_TRY(launch_downdate(c, r, c->W, which_prior));
-    PRE3_TRY(launch_jnorm(c, 0));
+    // update.m:42-46.  leave_jn_to_predict (pre3_step completing the previous step's HI update): the prediction's launch that follows carries it
+    if (c->leave_jn_to_predict && !Kt_out_dev) c->jn_pending = true;
+    else PRE3_TRY(launch_jnorm(c, 0));
     if (Kt_out_dev) {
         dim3 g(ceil_div(c->n, 256)), b(256);
         DISPATCH_T(c,
