@@ -40,6 +40,8 @@ void *match_shard_create(int device, int cls, int ND, int K1, const void *L1, in
 int match_shard_run(void *h, void **partial_dev, int *n_doubles);
 int match_shard_merge(void *h, int G, const void *gathered_dev, double thresh, double *pairs_out, double *score_out, int *M_out);
 void match_shard_destroy(void *h);
+int match_shard_set_comm(void *h, void *comm);
+int match_shard_match(void *h, double thresh, double *pairs_out, double *score_out, int *M_out);
 
 template <typename T> static int dmalloc(T **p, size_t count)
 {
@@ -78,6 +80,7 @@ static int wait_mail(pre3_ctx *c, int slot, int32_t seq)
     for (long spin = 0; spin < 20000000L; ++spin) {
         if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == seq) return PRE3_OK;
         if ((spin & 1023) == 1023 && hipStreamQuery(c->stream) == hipSuccess) break;
+        if (c->comm && (spin & 0xfffff) == 0xfffff) PRE3_TRY(comm_poll_error(c->comm));     // a collective in front of the awaited kernel whose peer died
     }
     PRE3_HIP(hipStreamSynchronize(c->stream));
     PRE3_CHECK(__atomic_load_n(w, __ATOMIC_ACQUIRE) == seq, PRE3_E_STATE, "mailbox: the producing kernel has not been launched");
@@ -295,6 +298,8 @@ int pre3_destroy(pre3_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->cholp_counted) { cholp_context_count(c->device, -1); c->cholp_counted = false; }
     ic_rank_free(c);
+    if (c->comm && c->comm_owned) (void)pre3_comm_destroy((pre3_comm *)c->comm);
+    c->comm = nullptr;
     void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
                      c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
                      c->sel_rows, c->support, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128, c->need, c->cholp_flags, c->cholp_tp };
@@ -662,7 +667,7 @@ __global__ void k_mark_needed(const int32_t *__restrict__ hyp, int k, int lo, in
     if (t < (hi - lo) * k) need[hyp[lo * k + t]] = tag;
 }
 
-static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, int lo = 0, int hi = -1)
+static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, int lo = 0, int hi = -1, bool slice_form = false)
 {
     PRE3_CHECK(c->measurements_set && c->projected, PRE3_E_STATE, "ransac: needs pre3_project and measurements");
     PRE3_CHECK(c->p_which == PRE3_X_K_KM1, PRE3_E_STATE, "ransac: needs the predicted estimate (call pre3_predict or set x_k_km1)");
@@ -681,7 +686,7 @@ static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, in
     c->scored_n_draw = n_draw; c->scored_k = k;         // the mask offset depends on n_draw: select / export / import must use the same
     int r = 2 * c->m, r_pad = round_up(r, NB);
     if (hi < 0) hi = n_draw;
-    if (lo > 0 || hi < n_draw) {
+    if (lo > 0 || hi < n_draw || slice_form) {
         // a rank's slice of a sharded round: H*P and H*P*H' only for the measurements its hypotheses draw (the scorer of hypothesis h
         // reads the 2k rows of its own landmarks and the entries of G among them, nothing else) -- the part of the round that
         // shrinks with the number of ranks.  The LI update must not gather from these partial products: hp_all_valid stays false.
@@ -760,6 +765,52 @@ int pre3_ransac_import(pre3_ctx *c, int n_draw, const void *support_src_dev, con
     if (mask_src_dev) PRE3_HIP(hipMemcpyAsync(c->masks, mask_src_dev, sizeof(uint32_t) * (size_t)n_draw * words, hipMemcpyDeviceToDevice, c->stream));
     PRE3_HIP(hipStreamSynchronize(c->stream));
     return PRE3_OK;
+}
+
+// ---- RCCL communicator on the context (pre3_comm.hip) ------------------------------------------------
+int pre3_set_comm(pre3_ctx *c, pre3_comm *comm)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(comm == nullptr || comm_device(comm) == c->device, PRE3_E_ARG, "pre3_set_comm: the communicator lives on device %d, the context on %d", comm ? comm_device(comm) : -1, c->device);
+    if (c->comm && c->comm_owned && c->comm != (void *)comm) { PRE3_HIP(hipStreamSynchronize(c->stream)); (void)pre3_comm_destroy((pre3_comm *)c->comm); }
+    c->comm = comm; c->comm_owned = false;
+    return PRE3_OK;
+}
+
+int pre3_comm_init(pre3_ctx *c, const void *id, int rank, int world)
+{
+    PRE3_TRY(check_ctx(c));
+    pre3_comm *cm = nullptr;
+    PRE3_TRY(pre3_comm_create(&cm, c->device, id, rank, world));
+    const int rc = pre3_set_comm(c, cm);
+    if (rc != PRE3_OK) { (void)pre3_comm_destroy(cm); return rc; }
+    c->comm_owned = true;
+    return PRE3_OK;
+}
+
+// One sharded RANSAC round with everything on the context's stream: [H*P | H*P*H' of this rank's measurements] -> scoring of hypotheses
+// [lo, hi) -> ncclAllReduce(sum) of [supports | masks], in place (the slices are disjoint and the buffer is cleared first: the integer sum
+// is the union) -> selection.  The host waits once, on the selection's mailbox word.
+int pre3_ransac_sharded(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, double threshold, int early_exit, int32_t *support, int32_t *li_mask,
+                        int32_t stats[4])
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(c->comm != nullptr, PRE3_E_STATE, "pre3_ransac_sharded: no communicator (pre3_comm_init / pre3_set_comm)");
+    PRE3_CHECK(n_draw >= 1 && n_draw <= c->caph, PRE3_E_ARG, "ransac: n_draw=%d exceeds capacity %d", n_draw, c->caph);
+    int rank = 0, world = 1;
+    comm_rank_world(c->comm, &rank, &world);
+    const int base = n_draw / world, rem = n_draw % world;
+    const int lo = rank * base + std::min(rank, rem), hi = lo + base + (rank < rem ? 1 : 0);
+    const int words = ceil_div(c->m, 32);
+    const size_t count = (size_t)round_up(n_draw, 4) + (size_t)n_draw * words;
+    PRE3_HIP(hipMemsetAsync(c->support, 0, sizeof(int32_t) * count, c->stream));
+    // (the slice form at any number of ranks, one included: H*P only of the measurements this rank's hypotheses draw, H*P*H' only among each
+    // hypothesis' own rows -- the round's cost then falls with the number of ranks from the same code path)
+    PRE3_TRY(ransac_prepare(c, n_draw, k, hyp, lo, hi, true));
+    if (hi > lo) PRE3_TRY(launch_ransac_score_impl(c, k, threshold, lo, hi, round_up(2 * c->m, NB), c->support, c->masks, words));
+    PRE3_TRY(comm_all_reduce_i32(c->comm, c->support, count, c->stream));
+    PRE3_TRY(launch_ransac_select_impl(c, n_draw, k, early_exit, c->support, c->masks, words));
+    return ransac_results(c, n_draw, support, li_mask, stats);
 }
 
 int pre3_ransac(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, double threshold, int early_exit, int32_t *support, int32_t *li_mask,
@@ -1237,6 +1288,11 @@ int pre3_match_shard_run(pre3_match_shard *s, void **partial_dev, int *n_doubles
 int pre3_match_shard_merge(pre3_match_shard *s, int G, const void *gathered_dev, double thresh, double *pairs_out, double *score_out, int *M_out)
 {
     return s ? match_shard_merge(s, G, gathered_dev, thresh, pairs_out, score_out, M_out) : PRE3_E_ARG;
+}
+int pre3_match_shard_set_comm(pre3_match_shard *s, pre3_comm *comm) { return s ? match_shard_set_comm(s, comm) : PRE3_E_ARG; }
+int pre3_match_shard_match(pre3_match_shard *s, double thresh, double *pairs_out, double *score_out, int *M_out)
+{
+    return s ? match_shard_match(s, thresh, pairs_out, score_out, M_out) : PRE3_E_ARG;
 }
 int pre3_match_shard_destroy(pre3_match_shard *s) { if (s) match_shard_destroy(s); return PRE3_OK; }
 

@@ -88,6 +88,7 @@ struct pre3_ctx {
     void *tiles128 = nullptr; int n_tiles128 = 0; // int2[n_tiles128]: 128x128 upper-triangle tiles of k_downdate_b3, XCD-interleaved
     unsigned int *chol_arrive = nullptr; unsigned int chol_target = 0;   // [0] panel arrivals, [1] scoring done, [2] rescue done, [3],[4] rider producers
     unsigned int ride_target[2] = { 0, 0 };
+    void *comm = nullptr; bool comm_owned = false;                 // RCCL communicator (pre3_comm.hip): pre3_comm_init / pre3_set_comm
     bool leave_jn_to_predict = false, jn_pending = false;          // the deferred HI update's rows/cols 3..6 <- Jn pass rides in the next k_predict
     bool defer_hi = false, hi_pending = false; int last_n_hi = 0;   // PRE3_OPT_DEFER_HI (pre3_set_option)
     bool ride_rescue_projection = false;          // request: the next K9 launch also projects at x_k_k (pre3_step sets it before the LI update)
@@ -172,6 +173,13 @@ __device__ inline void d_normjac(const double *q, double *J)
 // ---- pooled device scratch of the stateless entry points (pre3_match.hip)
 int scratch_acquire(size_t bytes, void **p_out, int *slot_out);
 void scratch_release(int slot, void *p);
+
+// ---- RCCL communicator (pre3_comm.hip): collectives on the caller's stream
+int comm_all_reduce_i32(void *comm, void *buf, size_t count, hipStream_t st);                       /* in place, sum */
+int comm_all_gather_f64(void *comm, const void *src, void *dst, size_t count_per_rank, hipStream_t st);
+int comm_poll_error(void *comm);                                                                    /* PRE3_E_COMM once the communicator has failed (and is aborted) */
+void comm_rank_world(void *comm, int *rank, int *world);
+int comm_device(void *comm);
 
 // ---- IC search (pre3_match.hip)
 int launch_ic_search(pre3_ctx *c, double thresh, int strict);

@@ -1025,8 +1025,10 @@ void scratch_release(int slot, void *p)
 struct DevBuf {
     void *p = nullptr;
     int slot = -1;
-    ~DevBuf() { scratch_release(slot, p); }
+    bool borrowed = false;                                   // p points into another DevBuf's allocation
+    ~DevBuf() { if (!borrowed) scratch_release(slot, p); }
     int alloc(size_t bytes) { return scratch_acquire(bytes, &p, &slot); }
+    void borrow(void *q) { if (!borrowed) scratch_release(slot, p); p = q; slot = -1; borrowed = true; }
 };
 
 void release_scratch() { std::lock_guard<std::mutex> lk(g_scratch_mu); g_scratch.release(); }
@@ -1504,6 +1506,14 @@ struct MatchShard {
     DevBuf part;            // double [3][K1]: best | second | arg (as double) -- the all-gather payload
     DevBuf res;             // double [1 + 3 K1]: count | pairs (2 K1) | scores (K1)
     std::vector<double> host_res;
+    // pre3_match_shard_match: the whole match on one stream of the shard's own, result block written to pinned host memory by the merge kernel
+    void *comm = nullptr;   // borrowed (pre3_match_shard_set_comm)
+    hipStream_t st = nullptr;
+    DevBuf raw; int raw_stride = 0;                           // [best | second | arg] of the slice, the distance kernel's outputs live here
+    DevBuf gathered; int gathered_world = 0;
+    double *res_host = nullptr, *res_host_dev = nullptr;      // [1 + 3 K1] + one int32 sequence word behind it
+    int32_t seq = 0;
+    ~MatchShard() { if (st) (void)hipStreamDestroy(st); if (res_host) (void)hipHostFree(res_host); }
 };
 
 __global__ void k_shard_pack(int K1, const double *__restrict__ b, const double *__restrict__ s2, const int32_t *__restrict__ a, double *__restrict__ out)
@@ -1514,42 +1524,73 @@ __global__ void k_shard_pack(int K1, const double *__restrict__ b, const double 
 
 // pre3_siftmatch_merge on the device for the integer classes: per query the G partials are merged (ties -> lowest global index), the ratio
 // test is done in float on int-valued distances (siftmatch.c:122), and the matches are compacted in increasing k1 (one workgroup, ballots).
-__global__ __launch_bounds__(1024) void k_shard_merge(int G, int K1, const double *__restrict__ gathered, float thresh, double *__restrict__ res)
+// raw_stride > 0 (pre3_match_shard_match): a rank's block is the distance kernel's own output, [best f64 | second f64 | arg int32] with
+// `raw_stride` entries per array (no packing launch in front of the all-gather); 0: double[3][K1] with the arg as a double (pre3_match_shard_run)
+__global__ __launch_bounds__(1024) void k_shard_merge(int G, int K1, const double *__restrict__ gathered, float thresh, double *__restrict__ res,
+                                                      int32_t *mail = nullptr, int32_t seq = 0, int raw_stride = 0)
 {
-    __shared__ int s_cnt[16];
+    // four blocks of 1024 queries per pass, every load of the pass issued before the first use (the loop of one block per pass was four
+    // dependent rounds of load latency + three barriers each: 12 us at K1 = 4096)
+    __shared__ int s_cnt[4][16];
     __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) s_base = 0;
     __syncthreads();
-    for (int k0 = 0; k0 < K1; k0 += 1024) {
-        const int k1 = k0 + tid;
-        int ok = 0, K = -1; double B = 0, S2 = 0;
-        if (k1 < K1) {
-            for (int g = 0; g < G; ++g) {
-                const double *p = gathered + (size_t)g * 3 * K1;
-                const double ob = p[k1], os = p[K1 + k1]; const int oa = (int)p[2 * K1 + k1];
-                if (oa < 0) continue;
-                if (K < 0) { B = ob; S2 = os; K = oa; continue; }
-                if (ob < B || (ob == B && oa < K)) { S2 = os < B ? os : B; B = ob; K = oa; }
-                else { S2 = ob < S2 ? ob : S2; }
-            }
-            if (K >= 0) ok = thresh * (float)B <= (float)S2;           // siftmatch.c:122 (integer classes: the doubles hold the int distances exactly)
-        }
-        const unsigned long long bal = __ballot(ok);
-        if (lane == 0) s_cnt[wv] = __popcll(bal);
-        __syncthreads();
-        int off = s_base, tot = 0;
+    const int st = raw_stride ? raw_stride : K1;
+    for (int k0 = 0; k0 < K1; k0 += 4096) {
+        int ok[4], Kq[4]; double Bq[4];
+        unsigned long long bal[4];
 #pragma unroll
-        for (int w = 0; w < 16; ++w) { const int c = s_cnt[w]; if (w < wv) off += c; tot += c; }
-        if (ok) {
-            const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
-            res[1 + 2 * pos] = k1 + 1; res[2 + 2 * pos] = K + 1; res[1 + 2 * (size_t)K1 + pos] = B;
+        for (int q = 0; q < 4; ++q) {
+            const int k1 = k0 + q * 1024 + tid;
+            int K = -1; double B = 0, S2 = 0;
+            ok[q] = 0;
+            if (k1 < K1) {
+                for (int g = 0; g < G; ++g) {
+                    const double *p = gathered + (size_t)g * 3 * st;
+                    const double ob = p[k1], os = p[st + k1];
+                    const int oa = raw_stride ? reinterpret_cast<const int32_t *>(p + 2 * (size_t)st)[k1] : (int)p[2 * K1 + k1];
+                    if (oa < 0) continue;
+                    if (K < 0) { B = ob; S2 = os; K = oa; continue; }
+                    if (ob < B || (ob == B && oa < K)) { S2 = os < B ? os : B; B = ob; K = oa; }
+                    else { S2 = ob < S2 ? ob : S2; }
+                }
+                if (K >= 0) ok[q] = thresh * (float)B <= (float)S2;    // siftmatch.c:122 (integer classes: the doubles hold the int distances exactly)
+            }
+            Kq[q] = K; Bq[q] = B;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { bal[q] = __ballot(ok[q]); if (lane == 0) s_cnt[q][wv] = __popcll(bal[q]); }
+        __syncthreads();
+        int run = s_base;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int off = run, tot = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) { const int c = s_cnt[q][w]; if (w < wv) off += c; tot += c; }
+            if (ok[q]) {
+                const int k1 = k0 + q * 1024 + tid;
+                const int pos = off + __popcll(bal[q] & ((1ull << lane) - 1ull));
+                if (mail) {         // pinned host memory: [pairs | scores | count], a pair is ONE 16-byte store (a wave's pairs fill whole PCIe writes)
+                    typedef double d2_t __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<d2_t *>(res + 2 * (size_t)pos) = d2_t{ (double)(k1 + 1), (double)(Kq[q] + 1) };
+                    res[2 * (size_t)K1 + pos] = Bq[q];
+                } else { res[1 + 2 * pos] = k1 + 1; res[2 + 2 * pos] = Kq[q] + 1; res[1 + 2 * (size_t)K1 + pos] = Bq[q]; }
+            }
+            run += tot;
         }
         __syncthreads();
-        if (tid == 0) s_base += tot;
+        if (tid == 0) s_base = run;
         __syncthreads();
     }
-    if (tid == 0) res[0] = (double)s_base;
+    if (mail) {             // res is pinned host memory (uncached: the stores go straight out): every wave's stores have been acknowledged
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // before the word the host polls is written (a system-scope fence per wave
+        __syncthreads();                                      // would also write the L2 back, once per wave)
+    }
+    if (tid == 0) {
+        res[mail ? 3 * (size_t)K1 : 0] = (double)s_base;
+        if (mail) { __threadfence_system(); __hip_atomic_store(mail, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+    }
 }
 
 void *match_shard_create(int device, int cls, int ND, int K1, const void *L1, int K2, const void *L2, int k2_offset)
@@ -1568,6 +1609,12 @@ void *match_shard_create(int device, int cls, int ND, int K1, const void *L1, in
         if (rc == PRE3_OK && sh->r.route == 0) { set_error("match shard: descriptors outside the ranked path's bounds (NaN / Inf / magnitude): use the host-array form"); rc = PRE3_E_ARG; }
     }
     if (rc != PRE3_OK || sh->part.alloc(sizeof(double) * 3 * (size_t)K1) != PRE3_OK || sh->res.alloc(sizeof(double) * (1 + 3 * (size_t)K1)) != PRE3_OK) { delete sh; return nullptr; }
+    // the kernels' three output arrays become one allocation: it is the all-gather's payload as it stands (pre3_match_shard_match)
+    sh->raw_stride = round_up(K1, 128);
+    if (sh->raw.alloc(sizeof(double) * 3 * (size_t)sh->raw_stride) != PRE3_OK) { delete sh; return nullptr; }
+    if (hipMemset(sh->raw.p, 0, sizeof(double) * 3 * (size_t)sh->raw_stride) != hipSuccess) { set_error("hipMemset failed"); delete sh; return nullptr; }
+    I8Match &o = sh->out();
+    o.ob.borrow(sh->raw.p); o.os.borrow((double *)sh->raw.p + sh->raw_stride); o.oa.borrow((double *)sh->raw.p + 2 * (size_t)sh->raw_stride);
     return sh;
 }
 int match_shard_run(void *h, void **partial_dev, int *n_doubles)
@@ -1604,6 +1651,62 @@ int match_shard_merge(void *h, int G, const void *gathered_dev, double thresh, d
     if (M > 0) {
         memcpy(pairs_out, sh->host_res.data() + 1, sizeof(double) * 2 * M);
         if (score_out) memcpy(score_out, sh->host_res.data() + 1 + 2 * (size_t)K1, sizeof(double) * M);
+    }
+    *M_out = M;
+    return PRE3_OK;
+}
+int match_shard_set_comm(void *h, void *comm)
+{
+    MatchShard *sh = (MatchShard *)h;
+    PRE3_CHECK(comm == nullptr || comm_device(comm) == sh->device, PRE3_E_ARG, "match shard: the communicator lives on device %d, the shard on %d", comm ? comm_device(comm) : -1, sh->device);
+    sh->comm = comm;
+    return PRE3_OK;
+}
+// run + all-gather + merge on the shard's stream; the host waits once, on the word the merge kernel writes behind its result block
+int match_shard_match(void *h, double thresh, double *pairs_out, double *score_out, int *M_out)
+{
+    MatchShard *sh = (MatchShard *)h;
+    PRE3_CHECK(pairs_out && M_out, PRE3_E_ARG, "match shard: null outputs");
+    PRE3_HIP(hipSetDevice(sh->device));
+    I8Match &o = sh->out();
+    const int K1 = o.K1;
+    const size_t nres = 1 + 3 * (size_t)K1;
+    if (!sh->st) PRE3_HIP(hipStreamCreateWithFlags(&sh->st, hipStreamNonBlocking));
+    if (!sh->res_host) {
+        PRE3_HIP(hipHostMalloc((void **)&sh->res_host, sizeof(double) * nres + 64, hipHostMallocMapped));
+        memset(sh->res_host, 0, sizeof(double) * nres + 64);
+        PRE3_HIP(hipHostGetDevicePointer((void **)&sh->res_host_dev, sh->res_host, 0));
+    }
+    int rank = 0, world = 1;
+    if (sh->comm) comm_rank_world(sh->comm, &rank, &world);
+    const size_t nraw = 3 * (size_t)sh->raw_stride;
+    if (sh->comm && sh->gathered_world != world) { PRE3_TRY(sh->gathered.alloc(sizeof(double) * nraw * world)); sh->gathered_world = world; }
+    if (o.K2 > 0) {
+        if (sh->cls == 2) PRE3_TRY(i8_run(sh->m, sh->k2_offset, sh->st));
+        else if (sh->cls == 0) PRE3_TRY(rank_run<double>(sh->r, sh->k2_offset, sh->st));
+        else PRE3_TRY(rank_run<float>(sh->r, sh->k2_offset, sh->st));
+    } else { PRE3_HIP(hipMemsetAsync(o.oa.p, 0xff, sizeof(int32_t) * K1, sh->st)); }
+    const void *src = sh->raw.p;
+    if (sh->comm) { PRE3_TRY(comm_all_gather_f64(sh->comm, sh->raw.p, sh->gathered.p, nraw, sh->st)); src = sh->gathered.p; }
+    int32_t *mail_host = reinterpret_cast<int32_t *>(sh->res_host + nres), *mail_dev = reinterpret_cast<int32_t *>(sh->res_host_dev + nres);
+    const int32_t seq = ++sh->seq;
+    hipLaunchKernelGGL(k_shard_merge, dim3(1), dim3(1024), 0, sh->st, world, K1, (const double *)src, (float)thresh, sh->res_host_dev, mail_dev, seq, sh->raw_stride);
+    PRE3_HIP(hipGetLastError());
+    bool arrived = false;
+    for (long spin = 0; spin < 2000000000L && !arrived; ++spin) {
+        if (__atomic_load_n(mail_host, __ATOMIC_ACQUIRE) == seq) { arrived = true; break; }
+        if ((spin & 0xfffff) == 0xfffff) {
+            if (sh->comm) PRE3_TRY(comm_poll_error(sh->comm));
+            const hipError_t q = hipStreamQuery(sh->st);
+            if (q == hipSuccess) { arrived = __atomic_load_n(mail_host, __ATOMIC_ACQUIRE) == seq; break; }
+            if (q != hipErrorNotReady) { set_error("match shard: stream failed: %s", hipGetErrorString(q)); return PRE3_E_HIP; }
+        }
+    }
+    if (!arrived) { PRE3_HIP(hipStreamSynchronize(sh->st)); PRE3_CHECK(__atomic_load_n(mail_host, __ATOMIC_ACQUIRE) == seq, PRE3_E_HIP, "match shard: the merge kernel did not publish its result"); }
+    const int M = (int)sh->res_host[3 * (size_t)K1];
+    if (M > 0) {
+        memcpy(pairs_out, sh->res_host, sizeof(double) * 2 * M);
+        if (score_out) memcpy(score_out, sh->res_host + 2 * (size_t)K1, sizeof(double) * M);
     }
     *M_out = M;
     return PRE3_OK;

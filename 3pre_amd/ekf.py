@@ -244,6 +244,25 @@ class EkfFilter:
         check(lib.pre3_ransac_select(self._ctx, int(n_draw), int(k), int(bool(early_exit)), dptr(sup), dptr(li), dptr(st)))
         return dict(support=sup, li_mask=li[:self.m], best=int(st[0]), iters=int(st[1]), n_hyp=int(st[2]), max_support=int(st[3]))
 
+    def set_comm(self, comm):
+        """attach a comm.Comm (None detaches): ransac_sharded_stream then runs its all-reduce on this filter's stream"""
+        check(lib.pre3_set_comm(self._ctx, comm._h if comm is not None else None))
+        self._comm = comm                                   # keeps the communicator alive as long as the filter borrows it
+
+    def ransac_sharded_stream(self, hyp, threshold, early_exit=True, fetch=True):
+        """pre3_ransac_sharded: ransac_hypotheses with the draws dealt to the communicator's ranks -- scoring, ncclAllReduce and selection
+        on the library's stream, one wait; same dict as ransac_hypotheses, identical on every rank"""
+        hyp = i32(hyp)
+        n_draw, k = hyp.shape
+        st = np.zeros(4, np.int32)
+        if not fetch:
+            check(lib.pre3_ransac_sharded(self._ctx, n_draw, k, dptr(hyp), C.c_double(float(threshold)), int(bool(early_exit)), None, None, dptr(st)))
+            return dict(best=int(st[0]), iters=int(st[1]), n_hyp=int(st[2]), max_support=int(st[3]))
+        sup = np.zeros(n_draw, np.int32)
+        li = np.zeros(max(self.m, 1), np.int32)
+        check(lib.pre3_ransac_sharded(self._ctx, n_draw, k, dptr(hyp), C.c_double(float(threshold)), int(bool(early_exit)), dptr(sup), dptr(li), dptr(st)))
+        return dict(support=sup, li_mask=li[:self.m], best=int(st[0]), iters=int(st[1]), n_hyp=int(st[2]), max_support=int(st[3]))
+
     def ransac_export(self, n_draw, support_ptr, mask_ptr):
         check(lib.pre3_ransac_export(self._ctx, int(n_draw), C.c_void_p(support_ptr), C.c_void_p(mask_ptr)))
 

@@ -117,6 +117,21 @@ class MatchShard:
         m = pairs[:M.value].T.copy()
         return (m, sc[:M.value].copy()) if return_scores else m
 
+    def set_comm(self, comm):
+        check(lib.pre3_match_shard_set_comm(self._h, comm._h if comm is not None else None))
+        self._comm = comm
+
+    def match(self, thresh=1.5, return_scores=False):
+        """pre3_match_shard_match: distance kernel on the slice, ncclAllGather of the partials, merge + ratio test + compaction on the
+        shard's own stream; the merge kernel writes the list to pinned host memory -- one wait, no copy call"""
+        if getattr(self, "_out", None) is None:                  # the wrapper's time is GPU idle time: outputs allocated once
+            self._out = (np.zeros((self.K1, 2)), np.zeros(self.K1), C.c_int(0))
+            self._out_p = (dptr(self._out[0]), dptr(self._out[1]), C.byref(self._out[2]))
+        pairs, sc, M = self._out
+        check(lib.pre3_match_shard_match(self._h, C.c_double(float(thresh)), self._out_p[0], self._out_p[1], self._out_p[2]))
+        m = pairs[:M.value].T.copy()
+        return (m, sc[:M.value].copy()) if return_scores else m
+
     def close(self):
         if getattr(self, "_h", None):
             lib.pre3_match_shard_destroy(self._h)

@@ -105,7 +105,20 @@ def all_ranks_ok(dist, ok):
     return bool(t.item())
 
 
-def matcher_shard_leg(pre3, dist, rank, world, local_rank=0, K=4096, reps=20):
+COLLECTIVE_BY = {True: "%s enqueued by libpre3 on its own stream (pre3_comm_create: RCCL bound at run time), one host wait per round",
+                 False: "torch.distributed between host synchronisations (3pre_amd/dist.py; the %s of the RCCL build is not used in this run)"}
+
+
+def comm_leg(dist, local_rank, holder):
+    """libpre3's own RCCL communicator, as a leg of its own: binding the library is local (set-up), creating the communicator is collective"""
+    cm = importlib.import_module("3pre_amd.comm")
+    cm.unique_id()                                      # binds librccl.so in this process; raises if it cannot
+    yield None
+    holder["comm"] = cm.Comm.from_torch_distributed(local_rank)
+    yield holder["comm"].info()
+
+
+def matcher_shard_leg(pre3, dist, rank, world, local_rank=0, K=4096, reps=100, comm=None):
     """BASELINE.json configs[3] over the ranks, device resident: the queries are replicated and every rank keeps its slice of the
     database packed in HBM (matcher.MatchShard); a match = int8-MFMA distance kernel on the slice, ONE all-gather of the per-query
     partials as device tensors (RCCL over xGMI), merge + ratio test + compaction on the device; only the match list crosses PCIe.
@@ -119,16 +132,20 @@ def matcher_shard_leg(pre3, dist, rank, world, local_rank=0, K=4096, reps=20):
     L1c, L2c = np.asfortranarray(L1.T), np.asfortranarray(L2.T)      # 128 x K, column-major like the reference
     lo, hi = pd.shard_range(K, rank, world)
     sh = mt.MatchShard(L1c, L2c[:, lo:hi], lo, device=local_rank)
+    # with libpre3's own communicator the whole match (kernel, ncclAllGather, merge) is enqueued on the shard's stream and waited for once
+    one_match = (lambda: sh.match(1.5)) if comm is not None else (lambda: pd.siftmatch_sharded_resident(sh, 1.5))
+    if comm is not None:
+        sh.set_comm(comm)
     yield None                                          # set-up done: nothing collective has been issued yet (run_leg agrees on it)
     try:
         for _ in range(3):
-            m = pd.siftmatch_sharded_resident(sh, 1.5)
+            m = one_match()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
         for _ in range(reps):
-            m = pd.siftmatch_sharded_resident(sh, 1.5)
+            m = one_match()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         if dist is not None:
@@ -139,10 +156,11 @@ def matcher_shard_leg(pre3, dist, rank, world, local_rank=0, K=4096, reps=20):
         sh.close()
     yield {"workload": "configs[3]: 4096x4096x128 uint8, database columns sharded over %d GPU(s), operands resident in HBM, partials "
                         "all-gathered as device tensors, merge on the device" % world,
-            "ms_per_match": 1e3 * el / reps, "pairs_per_s": reps * K * K / el, "matches": int(np.asarray(m).shape[1]), "n_gpus": world, "scaling": "strong"}
+            "ms_per_match": 1e3 * el / reps, "pairs_per_s": reps * K * K / el, "matches": int(np.asarray(m).shape[1]), "n_gpus": world, "scaling": "strong",
+            "collective": COLLECTIVE_BY[comm is not None] % "ncclAllGather"}
 
 
-def ransac_shard_leg(pre3, synth, dist, rank, world, local_rank, N=2000, n_hyp=1000, reps=10):
+def ransac_shard_leg(pre3, synth, dist, rank, world, local_rank, N=2000, n_hyp=1000, reps=10, comm=None):
     """BASELINE.json configs[4]: N=2000 landmarks (n=12013), 1000 hypotheses sharded over the ranks with an RCCL
     all-reduce of supports + inlier masks (3pre_amd/dist.ransac_sharded); state replicated.  Whole-job
     hypotheses/s at this number of GPUs (the all-reduce and the replay are inside the timed region)."""
@@ -156,18 +174,23 @@ def ransac_shard_leg(pre3, synth, dist, rank, world, local_rank, N=2000, n_hyp=1
         f.ekf_prediction(s["u"])
         f.search_IC_matches()
         f.set_measurements(s["meas_idx"], s["z"])
+        split = {}
+        if comm is not None:                            # pre3_ransac_sharded: scoring, ncclAllReduce, selection on the filter's stream, one wait
+            f.set_comm(comm)
+            one_round = lambda timing=None: f.ransac_sharded_stream(s["hyp"], 1.0, early_exit=False, fetch=False)
+        else:
+            one_round = lambda timing=None: pd.ransac_sharded(f, s["hyp"], 1.0, early_exit=False, timing=timing, fetch=False)
         yield None                                      # set-up done: nobody enters the collectives unless everybody can (run_leg agrees on it)
 
         for _ in range(2):
-            out = pd.ransac_sharded(f, s["hyp"], 1.0, early_exit=False, fetch=False)
+            out = one_round()
         f.sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        split = {}
         t0 = time.perf_counter()
         for _ in range(reps):
-            out = pd.ransac_sharded(f, s["hyp"], 1.0, early_exit=False, timing=split, fetch=False)
+            out = one_round(split)
         f.sync()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
@@ -179,8 +202,8 @@ def ransac_shard_leg(pre3, synth, dist, rank, world, local_rank, N=2000, n_hyp=1
         yield {"workload": "configs[4]: N=%d (n=%d), %d hypotheses (k=3), m=%d measured, f32; per round: H*P and H*P*H' gathers, "
                             "sharded scoring, all-reduce, replay" % (N, seq["n"], n_hyp, len(s["meas_idx"])),
                 "value": reps * n_hyp / el, "unit": "hypotheses/s", "n_gpus": world, "ms_per_round": 1e3 * el / reps,
-                "max_support": int(out["max_support"]), "scaling": "strong",
-                "ms_split_rank0": {k_: 1e3 * v / reps for k_, v in split.items()}}
+                "max_support": int(out["max_support"]), "scaling": "strong", "collective": COLLECTIVE_BY[comm is not None] % "ncclAllReduce",
+                "ms_split_rank0": {k_: 1e3 * v / reps for k_, v in split.items()} if split else None}
     finally:
         f.close()
 
@@ -584,16 +607,25 @@ def main():
                 fh.write(json.dumps(out) + "\n")
         except OSError:                                         # pragma: no cover
             pass
+    holder = {}
     if not args.no_extra_legs:
-        for name, fn in (("ransac_shard", lambda: ransac_shard_leg(pre3, synth, dist, rank, world, local_rank)),
-                         ("matcher_shard", lambda: matcher_shard_leg(pre3, dist, rank, world, local_rank))):
+        legs = [("ransac_shard", lambda: ransac_shard_leg(pre3, synth, dist, rank, world, local_rank, comm=holder.get("comm"))),
+                ("matcher_shard", lambda: matcher_shard_leg(pre3, dist, rank, world, local_rank, comm=holder.get("comm")))]
+        if not rehearsal and os.environ.get("PRE3_BENCH_COMM", "1") != "0":     # (gloo rehearsal: several ranks share one GPU, which RCCL refuses)
+            legs.insert(0, ("rccl", lambda: comm_leg(dist, local_rank, holder)))
+        for name, fn in legs:
             leg, err, agreed = run_leg(dist, name, fn, os.environ.get("PRE3_BENCH_FAIL_LEG") == name and rank == world - 1)
             if rank == 0:
                 out[name] = leg if (err is None and agreed) else {"error": repr(err)[:300] if err is not None else "failed on another rank"}
             if agreed is None:
                 comm_broken = True
+            if not agreed and name == "rccl" and agreed is not None:
+                holder.pop("comm", None)                        # no communicator of libpre3's own: the legs go through torch.distributed
+                continue
             if not agreed:
                 break                                           # no further collectives after a failed leg
+        if holder.get("comm") is not None and not comm_broken:
+            holder.pop("comm").close()
         if world == 1:
             for name, fn in (("matcher", lambda: matcher_leg(pre3)), ("vo_ransac", lambda: vo_leg(pre3))):
                 try:

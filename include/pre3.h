@@ -43,7 +43,8 @@ typedef enum {
     PRE3_E_HIP = -3,        /* a HIP call or kernel failed */
     PRE3_E_STATE = -4,      /* call order violated (e.g. update before predict/project) */
     PRE3_E_NUMERIC = -5,    /* S not positive definite */
-    PRE3_E_NOMEM = -6
+    PRE3_E_NOMEM = -6,
+    PRE3_E_COMM = -7        /* RCCL: library not found, communicator creation failed, or a collective reported an error */
 } pre3_status;
 
 enum { PRE3_F64 = 0, PRE3_F32 = 1 };
@@ -305,6 +306,39 @@ PRE3_API int pre3_match_shard_create_cls(pre3_match_shard **out, int device, int
 PRE3_API int pre3_match_shard_run(pre3_match_shard *s, void **partial_dev, int *n_doubles);
 PRE3_API int pre3_match_shard_merge(pre3_match_shard *s, int G, const void *gathered_dev, double thresh, double *pairs_out, double *score_out, int *M_out);
 PRE3_API int pre3_match_shard_destroy(pre3_match_shard *s);
+
+/* ---- the RCCL communicator: collectives enqueued by the library on its own stream ------------------------------------------------------
+ * SURVEY section 8(e) / BASELINE.json north_star ("RCCL all-reduce of inlier counts over xGMI"): the two stages that shard exchange data once
+ * per round.  With a communicator attached, the library itself enqueues that collective between its kernels, on the stream they run on:
+ *   pre3_ransac_sharded    H*P / H*P*H' of the slice's measurements, scoring of hypotheses [lo, hi) of this rank, ncclAllReduce (int32 sum, in
+ *                          place, supports + inlier bitmasks in ONE call), the selection kernel (ransac_hypotheses.m:41-62 replayed on the
+ *                          reduced buffers) -- one host wait (the pinned mailbox) per round;
+ *   pre3_match_shard_match distance kernel on the resident slice, ncclAllGather of the per-query partials, merge + Lowe's test + compaction,
+ *                          result block written to pinned host memory by the merge kernel -- one host wait per match.
+ * One process per GPU.  Rank 0 makes the 128-byte id (pre3_comm_unique_id) and the host program hands it to the other ranks by any means
+ * (3pre_amd/comm.py: torch.distributed broadcast; INTEGRATION.md: MPI_Bcast / a file); every rank then calls pre3_comm_create (collective:
+ * it returns when all `world` ranks have called it).  world == 1 is allowed (the collectives run, over one rank).
+ * RCCL is bound at run time: librccl.so.1 as already loaded in the process (e.g. PyTorch's copy), else from the loader path, else
+ * /opt/rocm/lib; the environment's PRE3_RCCL_LIB overrides.  Without it these calls return PRE3_E_COMM; nothing else in libpre3 needs it.
+ * A collective whose peer has died never completes: the wait of pre3_ransac_sharded / pre3_match_shard_match polls ncclCommGetAsyncError,
+ * aborts the communicator when it reports one and returns PRE3_E_COMM; a peer that merely stalls is the host program's time-out to set. */
+#define PRE3_COMM_ID_BYTES 128
+typedef struct pre3_comm pre3_comm;
+PRE3_API int pre3_comm_unique_id(void *id_out /* PRE3_COMM_ID_BYTES */);
+PRE3_API int pre3_comm_create(pre3_comm **out, int device, const void *id, int rank, int world);
+PRE3_API int pre3_comm_destroy(pre3_comm *comm);
+PRE3_API int pre3_comm_info(pre3_comm *comm, int *rank, int *world, int *rccl_version, char *lib_path, int lib_path_len);
+/* attach: the context / the shard borrows `comm` (must be on the same device; NULL detaches).  pre3_comm_init = create + attach, owned by the
+ * context and destroyed with it. */
+PRE3_API int pre3_set_comm(pre3_ctx *ctx, pre3_comm *comm);
+PRE3_API int pre3_comm_init(pre3_ctx *ctx, const void *id, int rank, int world);
+PRE3_API int pre3_match_shard_set_comm(pre3_match_shard *s, pre3_comm *comm);
+/* pre3_ransac with the hypotheses dealt to the communicator's ranks (contiguous slices, sizes differing by at most one): same arguments, same
+ * outputs on every rank, bit-identical to pre3_ransac for any number of ranks.  Every rank must hold the same state, measurements and draws. */
+PRE3_API int pre3_ransac_sharded(pre3_ctx *ctx, int n_draw, int k, const int32_t *hyp, double threshold, int early_exit,
+                                 int32_t *support, int32_t *li_mask, int32_t stats[4]);
+/* one whole sharded match (run + all-gather + merge); outputs as pre3_match_shard_merge.  Without a communicator: the slice alone (G = 1). */
+PRE3_API int pre3_match_shard_match(pre3_match_shard *s, double thresh, double *pairs_out, double *score_out, int *M_out);
 
 /* ---- a11: kNearestNeighbors.m:29-39 ------------------------------------------------------------- */
 /* data: N x D, query: M x D, MATLAB column-major.  ids_out (M x k, column-major, 1-based doubles),

@@ -23,6 +23,11 @@ def main():
     pre3 = importlib.import_module("3pre_amd")
     pd = importlib.import_module("3pre_amd.dist")
     synth = importlib.import_module("3pre_amd.synth")
+    # libpre3's own RCCL communicator (3pre_amd/comm.py): one GPU per rank only -- RCCL refuses two ranks on one device
+    comm = None
+    if backend == "nccl":
+        comm = importlib.import_module("3pre_amd.comm").Comm.from_torch_distributed(dev)
+        assert comm.info()["world"] == world
     N, n_draw = 60, 45
     seq = synth.make_sequence(N, 1, n_draw, seed=8)
     s = seq["steps"][0]
@@ -38,6 +43,13 @@ def main():
         for key in ("best", "iters", "n_hyp", "max_support"):
             assert got[key] == ref[key], (key, got[key], ref[key])
         assert np.array_equal(got["li_mask"], ref["li_mask"]) and np.array_equal(got["support"], ref["support"])
+        if comm is not None:
+            # the same round with the collective enqueued by libpre3 itself on the filter's stream (pre3_ransac_sharded)
+            f.set_comm(comm)
+            got2 = f.ransac_sharded_stream(s["hyp"], 1.0, early_exit=True)
+            for key in ("best", "iters", "n_hyp", "max_support"):
+                assert got2[key] == ref[key], (key, got2[key], ref[key])
+            assert np.array_equal(got2["li_mask"], ref["li_mask"]) and np.array_equal(got2["support"], ref["support"])
         # and the LI update that follows uses the reduced winner on every rank
         f.ekf_update_li_inliers()
         P = f.get_p_k_k()
@@ -63,7 +75,15 @@ def main():
         m, d = pd.siftmatch_sharded_resident(sh, thr, return_scores=True)
         mr, dr = orc.siftmatch(L1, L2, thr)
         assert np.array_equal(m, mr) and np.array_equal(d, dr), "resident sharded matcher differs from the oracle"
+    if comm is not None:
+        sh.set_comm(comm)
+        for thr in (1.5, 1.1):
+            m, d = sh.match(thr, return_scores=True)               # run + ncclAllGather + merge on the shard's stream
+            mr, dr = orc.siftmatch(L1, L2, thr)
+            assert np.array_equal(m, mr) and np.array_equal(d, dr), "on-stream sharded matcher differs from the oracle"
     sh.close()
+    if comm is not None:
+        comm.close()
     dist.barrier()
     dist.destroy_process_group()
     print("rank %d/%d OK" % (rank, world))

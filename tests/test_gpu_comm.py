@@ -1,0 +1,76 @@
+"""GPU: libpre3's own RCCL communicator (include/pre3.h "the RCCL communicator", 3pre_amd/comm.py) with ONE rank -- all a one-GPU box can
+hold (RCCL refuses two ranks on one device; tests/test_gpu_dist.py runs the 2-rank form where there are two GPUs).  The collectives really
+run (ncclAllReduce / ncclAllGather over one rank, enqueued by the library on its own stream), so everything but the wire is exercised:
+binding librccl at run time, communicator creation, the on-stream round and its single wait."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+synth = importlib.import_module("3pre_amd.synth")
+
+
+@pytest.fixture(scope="module")
+def comm(pre3):
+    cm = importlib.import_module("3pre_amd.comm")
+    c = cm.Comm(0, cm.unique_id(), 0, 1)
+    yield c
+    c.close()
+
+
+def test_communicator_binds_rccl_at_run_time(comm):
+    info = comm.info()
+    assert info["rank"] == 0 and info["world"] == 1
+    assert info["rccl_version"] >= 20000 and "rccl" in info["library"]
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_on_stream_sharded_round_equals_the_unsharded_round(pre3, comm, dtype):
+    N, n_draw = 120, 70
+    seq = synth.make_sequence(N, 2, n_draw, seed=21)
+    f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype=dtype, max_hyp=n_draw)
+    f.set_x_p_k_k(seq["x0"], seq["P0"])
+    with pytest.raises(pre3.Pre3Error) as e:                      # no communicator yet
+        f.ekf_prediction(seq["steps"][0]["u"]); f.search_IC_matches(); f.set_measurements(seq["steps"][0]["meas_idx"], seq["steps"][0]["z"])
+        f.ransac_sharded_stream(seq["steps"][0]["hyp"], 1.0)
+    assert e.value.code == -4
+    f.set_x_p_k_k(seq["x0"], seq["P0"])
+    f.set_comm(comm)
+    for s in seq["steps"]:
+        for early in (True, False):
+            f.ekf_prediction(s["u"]); f.search_IC_matches(); f.set_measurements(s["meas_idx"], s["z"])
+            ref = f.ransac_hypotheses(s["hyp"], threshold=1.0, early_exit=early)
+            x_ref = None
+            got = f.ransac_sharded_stream(s["hyp"], 1.0, early_exit=early)
+            for key in ("best", "iters", "n_hyp", "max_support"):
+                assert got[key] == ref[key], key
+            assert np.array_equal(got["support"], ref["support"]) and np.array_equal(got["li_mask"], ref["li_mask"])
+            st = f.ransac_sharded_stream(s["hyp"], 1.0, early_exit=early, fetch=False)       # statistics through the mailbox only
+            assert st["best"] == ref["best"] and st["max_support"] == ref["max_support"]
+            # the update that follows takes the winner left on the device
+            f.ekf_update_li_inliers()
+            assert np.isfinite(f.get_p_k_k()).all()
+            f.set_x_p_k_k(f.get_x_k_k(), f.get_p_k_k())
+    f.set_comm(None)
+    f.close()
+
+
+def test_on_stream_shard_match_equals_the_oracle(pre3, orc, comm):
+    mt = importlib.import_module("3pre_amd.matcher")
+    rng = np.random.default_rng(5)
+    L1 = rng.integers(0, 255, (128, 333)).astype(np.uint8)
+    L2 = rng.integers(0, 255, (128, 700)).astype(np.uint8)
+    L2[:, 50:250] = L1[:, :200]
+    L2[:, 600] = L1[:, 3]
+    real1, real2 = L1 + rng.random(L1.shape), L2 + rng.random(L2.shape)
+    for A, B in ((L1, L2), (real1, real2)):
+        sh = mt.MatchShard(A, B, 0)
+        for with_comm in (False, True):
+            sh.set_comm(comm if with_comm else None)
+            for thr in (1.5, 1.1, 1.5):
+                m, d = sh.match(thr, return_scores=True)
+                mr, dr = orc.siftmatch(A, B, thr)
+                assert np.array_equal(m, mr) and np.array_equal(d, dr), (A.dtype, with_comm, thr)
+        sh.close()
