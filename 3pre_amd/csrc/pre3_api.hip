@@ -7,6 +7,7 @@
 #include <new>
 
 #include "pre3_internal.h"
+#include <mutex>
 #include "pre3_cholp.h"
 
 namespace pre3 {
@@ -1124,12 +1125,32 @@ int pre3_hypothesis_support(int device, int n, const double *xi, const pre3_cam 
 
 // Stateless drop-in for `[X_km1_k, P_km1_k] = predict_state_and_covariance(X_k, P_k, type, SD_A, SD_alpha)`
 // (predict_state_and_covariance.m:27, caller @ekf_filter/ekf_prediction.m:29) with the odometry increment made explicit.
+struct DenseCtx { pre3_ctx *c = nullptr; int device = 0, dtype = 0, capL = 0; };
+static DenseCtx g_dense[4];
+static std::mutex g_dense_mu;
+
 int pre3_predict_dense(int device, int dtype, int n, const double *x, const double *P, const double u[7], double *x_out, double *P_out)
 {
     PRE3_CHECK(n >= 13 && (n - 13) % 3 == 0 && x && P && u && x_out && P_out, PRE3_E_ARG, "pre3_predict_dense: bad arguments (n = 13 + 6 N_id + 3 N_euc)");
     int capL = std::max((n - 13 + 5) / 6, 1);
-    pre3_ctx *c = nullptr;
-    PRE3_TRY(pre3_create(&c, device, dtype, capL, 1));
+    // ekf_prediction.m reaches this entry every frame: the context (P at capacity, the update's work buffers, pinned inbox / mailbox -- more
+    // than a GB allocated and cleared at n = 12013) is kept between calls, one per (device, dtype), grown when a larger state arrives and
+    // released by pre3_release_scratch().  Calls are serialised on it.
+    std::lock_guard<std::mutex> lk(g_dense_mu);
+    DenseCtx *slot = nullptr;
+    for (DenseCtx &d : g_dense) if (d.c && d.device == device && d.dtype == dtype) slot = &d;
+    if (slot && slot->capL < capL) { pre3_destroy(slot->c); slot->c = nullptr; slot = nullptr; }
+    if (!slot) {
+        for (DenseCtx &d : g_dense) if (!d.c) { slot = &d; break; }
+        if (!slot) { slot = &g_dense[0]; pre3_destroy(slot->c); slot->c = nullptr; }
+        const int cap = capL + capL / 8;                                     // a little headroom: the map grows by a few landmarks per frame
+        PRE3_TRY(pre3_create(&slot->c, device, dtype, cap, 1));
+        slot->device = device; slot->dtype = dtype; slot->capL = cap;
+        // (this context never factorises: it must not count against the two persistent-factorisation contexts a device serves, pre3_cholp.hip)
+        slot->c->chol_persist = false;
+        if (slot->c->cholp_counted) { cholp_context_count(device, -1); slot->c->cholp_counted = false; }
+    }
+    pre3_ctx *c = slot->c;
     int rc = PRE3_OK;
     do {
         c->n = n; c->N = 0;                       // the prediction touches the 13 camera entries and rows/columns 1:13 only: no landmark table needed
@@ -1137,11 +1158,17 @@ int pre3_predict_dense(int device, int dtype, int n, const double *x, const doub
         if ((rc = pre3_predict(c, u)) != PRE3_OK) break;
         rc = pre3_get_state(c, PRE3_X_K_KM1, n, x_out, P_out);
     } while (0);
-    pre3_destroy(c);
+    if (rc != PRE3_OK) { pre3_destroy(slot->c); slot->c = nullptr; }         // never reuse a context that failed half-way
     return rc;
 }
 
-int pre3_release_scratch(void) { release_scratch(); return PRE3_OK; }
+int pre3_release_scratch(void)
+{
+    release_scratch();
+    std::lock_guard<std::mutex> lk(g_dense_mu);
+    for (DenseCtx &d : g_dense) if (d.c) { pre3_destroy(d.c); d.c = nullptr; }
+    return PRE3_OK;
+}
 
 int pre3_siftmatch_merge(int cls, int G, int K1, const double *best, const double *second, const int32_t *arg, double thresh_d,
                          double *pairs_out, double *score_out, int *M_out)

@@ -45,13 +45,19 @@ def _world():
 # ---------------------------------------------------------------------------------------------------
 # C1: sharded RANSAC scoring
 # ---------------------------------------------------------------------------------------------------
-_ZERO_COPY = {}         # (backend, world) -> bool: the path every rank agreed on (decided ONCE, collectively)
+_ZERO_COPY = {}         # (backend, world, n_draw, words) -> bool: the path every rank agreed on for rounds of THAT shape (decided collectively)
 
 
-def _agree_zero_copy(ok_here):
+def _agree_zero_copy(ok_here, n_draw, words):
     """All ranks must issue the same collectives: the zero-copy in-place all-reduce is used only if it works on EVERY rank (one MIN
-    all-reduce, the first time; a rank-local choice could leave ranks in collectives of different count and size)."""
-    key = (dist.get_backend(), dist.get_world_size())
+    all-reduce per round shape; a rank-local choice could leave ranks in collectives of different count and size).  The decision is
+    cached per (backend, world, n_draw, words): whether the view can be built depends on the buffer layout of that shape (the same on
+    every rank -- state and draws are replicated), so a cached True cannot meet a local failure that the other ranks do not share; should
+    it happen anyway, the cached decision is dropped and agreed again by every rank's next call, and this call raises on this rank alone --
+    after the agreement, not inside a collective the others never entered."""
+    key = (dist.get_backend(), dist.get_world_size(), int(n_draw), int(words))
+    if key in _ZERO_COPY and _ZERO_COPY[key] and not ok_here:
+        del _ZERO_COPY[key]
     if key not in _ZERO_COPY:
         t = torch.tensor([1 if ok_here else 0], dtype=torch.int32, device="cuda" if key[0] == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -84,7 +90,7 @@ def ransac_sharded(f, hyp, threshold, early_exit=True, device=None, timing=None,
                     both = dev_tensor(sup_ptr, gap + n_draw * max(words, 1), "<i4", dev)
                 except Exception:                           # a torch build that cannot import __cuda_array_interface__ objects
                     both = None
-            if _agree_zero_copy(both is not None):
+            if _agree_zero_copy(both is not None, n_draw, words):
                 dist.all_reduce(both, op=dist.ReduceOp.SUM)  # ONE collective, in place; slices are disjoint: integer sum == bitwise or
                 torch.cuda.synchronize()
             else:                                           # stage through copies (every rank takes this branch together)

@@ -85,7 +85,9 @@ PRE3_API int pre3_predict(pre3_ctx *ctx, const double u[7]);
  * SD_alpha_component_filter)` (predict_state_and_covariance.m:27, caller @ekf_filter/ekf_prediction.m:29): host in, host out.
  * `type` is 'constant_velocity' in every call of the reference and the two standard deviations are unused by this fork (:98-102 hard-
  * code Pn); the increment u = [dX; dq] the .m file reads from disk through fv.m:47 is an explicit argument (the MEX gateway resolves it,
- * INTEGRATION.md).  n = 13 + 6 N_id + 3 N_euc; P, P_out: n x n. */
+ * INTEGRATION.md).  n = 13 + 6 N_id + 3 N_euc; P, P_out: n x n.
+ * The device context behind this entry (P at capacity and the work buffers) is kept between calls, one per (device, dtype), grown when a larger
+ * state arrives; calls are serialised on it; pre3_release_scratch() frees it. */
 PRE3_API int pre3_predict_dense(int device, int dtype, int n, const double *x, const double *P, const double u[7], double *x_out, double *P_out);
 
 /* ---- a3/a4: predict_camera_measurements.m:27-68 + calculate_derivatives.m:27-60 ------------------ */
@@ -343,7 +345,7 @@ PRE3_API int pre3_match_shard_match(pre3_match_shard *s, double thresh, double *
 /* ---- a11: kNearestNeighbors.m:29-39 ------------------------------------------------------------- */
 /* data: N x D, query: M x D, MATLAB column-major.  ids_out (M x k, column-major, 1-based doubles),
  * dist_out (M x k, Euclidean).  Ties: lowest index first (MATLAB's stable sort). */
-/* the stateless matcher / kNN calls keep their device scratch in a small per-thread pool between calls; this frees the idle part */
+/* the stateless matcher / kNN calls keep their device scratch in a small pool between calls, pre3_predict_dense its context; this frees the idle part */
 PRE3_API int pre3_release_scratch(void);
 PRE3_API int pre3_knn_f64(int device, int D, int N, const double *data, int M, const double *query, int k,
                           double *ids_out, double *dist_out);

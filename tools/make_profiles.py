@@ -8,7 +8,7 @@ usage: python tools/make_profiles.py [tag]      (tag defaults to r1)"""
 import csv, json, os, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 K9 = "k_downdate_b3"
@@ -24,8 +24,8 @@ shutil.copy(find("%s_trace" % tag, "%s_kernel_stats.csv" % tag), os.path.join(P,
 tl = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_timeline.py"), find("%s_trace" % tag, "%s_kernel_trace.csv" % tag), "3"],
                     capture_output=True, text=True, check=True).stdout
 with open(os.path.join(P, "%s_bench_one_step_timeline.txt" % tag), "w") as fh:
-    fh.write("# one filter step (N=500, n=3013, 200 hypotheses, f32) from rocprofv3 --kernel-trace of `python3 bench.py --steps 40 --warmup 5 "
-             "--no-cpu-baseline --no-extra-legs`\n# (the profiler adds ~10 % to the step; unprofiled numbers are in DESIGN.md section 8)\n" + tl)
+    fh.write("# one filter step (N=500, n=3013, 200 hypotheses, f32, RANSAC threshold 0.45 px: LI update ~500 rows + HI update ~20 rows) from rocprofv3 "
+             "--kernel-trace of `python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extra-legs --no-check --no-hi-steps 0`\n# (the profiler adds ~10 % to the step; unprofiled numbers are in DESIGN.md section 8)\n" + tl)
 
 
 def counter(dirname, prefix, name):
@@ -53,6 +53,25 @@ out = {
     "hbm_bytes_per_li_launch": {"raw": 1024.0 * (fs["li_launch_avg_KB"] + ws["li_launch_avg_KB"]),
                                 "fetch_doubled": 1024.0 * (2 * fs["li_launch_avg_KB"] + ws["li_launch_avg_KB"])},
 }
+# SQ counters of the K9 launches (the LI updates: the upper half by SQ_BUSY_CYCLES-independent ranking on each counter), from the separate --pmc passes
+sqk = {}
+sqd0 = os.path.join(G, "%s_pmc_sq" % tag)
+if os.path.isdir(sqd0):
+    for dp, _, fs_ in sorted(os.walk(sqd0)):
+        for fn in fs_:
+            if fn.endswith("counter_collection.csv"):
+                acc = {}
+                for r in csv.DictReader(open(os.path.join(dp, fn))):
+                    if K9 in r["Kernel_Name"]:
+                        acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                for k_, v in acc.items():
+                    top = [x for x in v if x > 0.6 * max(v)] if max(v) > 0 else v
+                    sqk[k_] = {"li_launch_avg": sum(top) / len(top), "launches": len(top)}
+if sqk:
+    out["sq_counters_per_li_launch"] = sqk
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in sqk and "GRBM_GUI_ACTIVE" in sqk:
+        out["mfma_busy_fraction_of_chip"] = sqk["SQ_VALU_MFMA_BUSY_CYCLES"]["li_launch_avg"] / (sqk["GRBM_GUI_ACTIVE"]["li_launch_avg"] * 1024.0)
+        out["notes"].append("mfma_busy_fraction_of_chip = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs): the share of the chip's matrix-pipe cycles the launch kept busy")
 with open(os.path.join(P, "%s_pmc_k9.json" % tag), "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps(out["counters_KB"], indent=1), out["k9_trace_durations_us"], out["hbm_bytes_per_li_launch"])
