@@ -70,8 +70,14 @@ if os.path.isdir(sqd0):
 if sqk:
     out["sq_counters_per_li_launch"] = sqk
     if "SQ_VALU_MFMA_BUSY_CYCLES" in sqk and "GRBM_GUI_ACTIVE" in sqk:
-        out["mfma_busy_fraction_of_chip"] = sqk["SQ_VALU_MFMA_BUSY_CYCLES"]["li_launch_avg"] / (sqk["GRBM_GUI_ACTIVE"]["li_launch_avg"] * 1024.0)
-        out["notes"].append("mfma_busy_fraction_of_chip = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs): the share of the chip's matrix-pipe cycles the launch kept busy")
+        # GRBM_GUI_ACTIVE comes back accumulated over the 8 XCDs (its value is ~8 x launch duration x shader clock: check below), so the
+        # chip's matrix-pipe capacity during the launch is (GRBM / 8) cycles x 1024 SIMDs
+        cyc = sqk["GRBM_GUI_ACTIVE"]["li_launch_avg"] / 8.0
+        out["mfma_busy_fraction_of_chip"] = sqk["SQ_VALU_MFMA_BUSY_CYCLES"]["li_launch_avg"] / (cyc * 1024.0)
+        out["implied_clock_GHz"] = cyc / (out["k9_trace_durations_us"]["li_launch_avg"] * 1e3)
+        out["notes"].append("mfma_busy_fraction_of_chip = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8 XCDs) x 1024 SIMDs): the share of the chip's "
+                            "matrix-pipe cycles the LI launch kept busy; SQ_VALU_MFMA_BUSY_CYCLES = 32 x SQ_INSTS_MFMA (v_mfma_f32_32x32x16_bf16: 8 passes); "
+                            "implied_clock_GHz = (GRBM_GUI_ACTIVE / 8) / launch duration -- the clock the chip held under this launch")
 with open(os.path.join(P, "%s_pmc_k9.json" % tag), "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps(out["counters_KB"], indent=1), out["k9_trace_durations_us"], out["hbm_bytes_per_li_launch"])
@@ -83,9 +89,9 @@ cp = [((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in csv
 if cp:
     big_ = sorted(d for d in cp if d > 0.5 * max(cp)); small_ = sorted(d for d in cp if d <= 0.5 * max(cp))
     cl = ["# k_cholp (K8, round 3: S = L L' and W = L^-1 [HP | nu] in ONE persistent launch) in `bench.py --steps 40` (N=500, n=3013), rocprofv3 --kernel-trace",
-          "# LI updates (r ~ 640 rows, ten 64-row panels): %d launches, median %.2f us, mean %.2f us, min %.2f us" % (len(big_), big_[len(big_) // 2], sum(big_) / len(big_), big_[0])]
+          "# LI updates (r ~ 500 rows at the bench's default RANSAC threshold of 0.45 px: eight 64-row panels; ten at r ~ 640): %d launches, median %.2f us, mean %.2f us, min %.2f us" % (len(big_), big_[len(big_) // 2], sum(big_) / len(big_), big_[0])]
     if small_:
-        cl.append("# HI updates (r <= 64 rows, one panel): %d launches, median %.2f us, mean %.2f us" % (len(small_), small_[len(small_) // 2], sum(small_) / len(small_)))
+        cl.append("# HI updates of two and more panels (one-panel updates take k_chol_step: one launch in either form): %d launches, median %.2f us, mean %.2f us" % (len(small_), small_[len(small_) // 2], sum(small_) / len(small_)))
     sqd = os.path.join(G, "%s_pmc_sq" % tag)
     if os.path.isdir(sqd):
         cl.append("# SQ counters per launch (separate --pmc passes, means over the k_cholp launches above the median of 10 steps: the LI updates)")
