@@ -514,12 +514,15 @@ def main():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
+        f.kernel_timing(max(1, args.kt_every))
         t2 = time.perf_counter()
         for s in s2[3:3 + K2]:
             st2.append(f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=1.0, early_exit=False))
         f.sync()
         torch.cuda.synchronize()
         el2 = time.perf_counter() - t2
+        kt2 = f.kernel_timing_read()
+        f.kernel_timing(False)
         if dist is not None:
             dist.barrier()
             t = torch.tensor([el2], device=COLL_DEV, dtype=torch.float64)
@@ -529,6 +532,13 @@ def main():
                  "mean_li_rows": 2 * float(np.mean([s_["n_li"] for s_ in st2])), "mean_hi_rows": 2 * float(np.mean([s_["n_hi"] for s_ in st2])),
                  "note": "the same filter continued with the reference's own RANSAC threshold (ransac_hypotheses.m:33 with mono_slam.m:78's "
                          "sigma_image_noise = 1): the headline workload of rounds 1 and 2"}
+        if kt2["total_ms"] > 0 and kt2["launches"] > 0:
+            # K9 of this leg's LI updates (r ~ 640), priced like `roofline` (the headline's LI updates have r ~ 500: the same kernel with 8 instead of 10 k-panels)
+            ach2 = kt2["flops"] / (kt2["total_ms"] * 1e-3) / 1e12
+            six = 6.0 if (args.dtype == "f32" and b3) else 1.0
+            no_hi["k9"] = {"achieved": six * ach2, "unit": "TFLOP/s", "peak": PEAK["bf16"] if six > 1 else PEAK[args.dtype],
+                           "frac": six * ach2 / (PEAK["bf16"] if six > 1 else PEAK[args.dtype]), "launches": kt2["launches"],
+                           "avg_launch_us": 1e3 * kt2["total_ms"] / kt2["launches"], "f32_equivalent_ratio": ach2 / PEAK["f32"] if args.dtype == "f32" else None}
 
     out = None
     if rank == 0:
