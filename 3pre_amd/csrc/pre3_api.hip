@@ -840,9 +840,15 @@ static int update_selected(pre3_ctx *c, int which_prior, int nsel, const int32_t
     int r = 2 * nsel;
     // rows of the predicted-state update that RANSAC already multiplied out: gather instead of recomputing
     const bool reuse = r > 0 && which_prior == PRE3_X_K_KM1 && c->hp_all_valid && sel_dev != nullptr;
+    bool hp_built = false;
     if (reuse) { if (!gathered) PRE3_TRY(launch_gather_li(c, nsel, nsel, sel_dev, round_up(2 * c->m, NB))); }
-    else if (r > 0) PRE3_TRY(launch_build_rows_impl(c, nsel, sel_dev, round_up(r, NB)));
-    PRE3_TRY(run_update(c, which_prior, r, false, nullptr, reuse, first_done && reuse));
+    else if (r > 0) {
+        // rows built on the fly inside the H*P launch (one launch instead of k_build_rows + k_ell_HP; PRE3_FUSE_ROWS=0: the two)
+        static const int fuse_rows = getenv("PRE3_FUSE_ROWS") ? atoi(getenv("PRE3_FUSE_ROWS")) : 1;
+        if (fuse_rows && round_up(r, NB) <= c->rcap) { PRE3_TRY(launch_ell_HP_build_sel(c, nsel, sel_dev, c->W)); hp_built = true; }
+        else PRE3_TRY(launch_build_rows_impl(c, nsel, sel_dev, round_up(r, NB)));
+    }
+    PRE3_TRY(run_update(c, which_prior, r, false, nullptr, reuse, first_done && reuse, hp_built));
     c->hp_all_valid = false;                 // P changed
     c->x_valid[PRE3_X_K_K] = true; c->p_which = PRE3_X_K_K;
     return PRE3_OK;

@@ -202,7 +202,9 @@ int run_hypothesis_support(int n, const double *xi, const pre3_cam &cam, int n_i
 // ---- dense update kernels (pre3_update.hip)
 // rows: ELL rows [r] in c->row_col/row_val with nu in c->row_nu; computes W = H*P (+ nu column),
 // S = H*P*H' + R, Cholesky, W = L^-1 [HP | nu], x += W' y, P -= W'W, Jnorm + normalise.
-int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_dev /*nullable, r_pad x ldw T*/, bool prebuilt = false, bool first_done = false);
+int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_dev /*nullable, r_pad x ldw T*/, bool prebuilt = false, bool first_done = false,
+               bool hp_built = false /* rows and W = H*P are in place (launch_ell_HP_build_sel), S is not */);
+int launch_ell_HP_build_sel(pre3_ctx *c, int nsel, const int32_t *sel_dev /* nullable: the first nsel measurements */, void *dst);
 int launch_chol_first_spec(pre3_ctx *c, int nsel_max);
 int launch_ell_HP_build(pre3_ctx *c, void *dst, const int32_t *need = nullptr, int need_tag = 0 /* sharded RANSAC: only the measurements with need[s] == need_tag */);
 int launch_ell_G_hyp(pre3_ctx *c, int k, int lo, int hi, int ldg);                 /* H*P*H' entries among each hypothesis' own rows, hypotheses [lo, hi) */

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_ell_HP_build(int m, int r_pad, const in
                                                       const double *__restrict__ Hl, const double *__restrict__ z, const double *__restrict__ h,
                                                       int32_t *__restrict__ row_col, T *__restrict__ row_val, double *__restrict__ row_nu,
                                                       const T *__restrict__ P, int ld, T *__restrict__ dst, int ldw, const int32_t *__restrict__ need, int need_tag,
-                                                      int ny_build, InnovRide ir)
+                                                      int ny_build, InnovRide ir, const int32_t *__restrict__ sel = nullptr)
 {
     // rows of blocks beyond the build's own: the S_i pass of search_IC_matches.m:33-44 rides here (pre3_step; it only needs what the
     // prediction's launch left behind, like this kernel)
@@ -79,7 +79,9 @@ __global__ __launch_bounds__(256) void k_ell_HP_build(int m, int r_pad, const in
     if (2 * sIdx >= r_pad) return;
     v4_t out0 = { (T)0, (T)0, (T)0, (T)0 }, out1 = out0;
     if (sIdx < m) {
-        const int i = meas[sIdx];
+        // sel != nullptr (an update of a subset -- the rescue stage's HI inliers, an LI update after a sliced RANSAC round): row pair sIdx is
+        // measurement sel[sIdx], m is the subset's size (launch_ell_HP_build_sel: k_build_rows + k_ell_HP in one launch)
+        const int i = meas[sel ? sel[sIdx] : sIdx];
         const int d = lm_type[i] == PRE3_INVDEPTH ? 6 : 3, off = lm_off[i];
         T v0[13], v1[13]; int cc[13];
 #pragma unroll
@@ -1301,6 +1303,23 @@ int launch_ell_HP(pre3_ctx *c, int r, void *dst, bool with_nu)
     return PRE3_OK;
 }
 
+// the same for a subset: row pair a = measurement sel[a] (sel == nullptr: a), a < nsel; the padding up to r_pad is zero rows
+int launch_ell_HP_build_sel(pre3_ctx *c, int nsel, const int32_t *sel_dev, void *dst)
+{
+    const int r_pad = round_up(2 * nsel, NB);
+    if (r_pad == 0) return PRE3_OK;
+    const int gx = ceil_div(c->ldw / 4, 256), ny = r_pad / 2;
+    InnovRide ir{};
+    dim3 g(gx, ny), b(256);
+    DISPATCH_T(c,
+        hipLaunchKernelGGL(k_ell_HP_build<double>, g, b, 0, c->stream, nsel, r_pad, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl, c->lm.z, c->lm.h,
+                           c->row_col, (double *)c->row_val, c->row_nu, (const double *)c->P, c->ld, (double *)dst, c->ldw, (const int32_t *)nullptr, 0, ny, ir, sel_dev),
+        hipLaunchKernelGGL(k_ell_HP_build<float>, g, b, 0, c->stream, nsel, r_pad, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl, c->lm.z, c->lm.h,
+                           c->row_col, (float *)c->row_val, c->row_nu, (const float *)c->P, c->ld, (float *)dst, c->ldw, (const int32_t *)nullptr, 0, ny, ir, sel_dev));
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
 // rows of all m measurements built and multiplied in one launch (replaces launch_build_rows_impl + launch_ell_HP)
 int launch_ell_HP_build(pre3_ctx *c, void *dst, const int32_t *need, int need_tag)
 {
@@ -1541,7 +1560,7 @@ int launch_chol_first_spec(pre3_ctx *c, int nsel_max)
 }
 
 // prebuilt: W (H*P with the nu column) and Smat (S) are already in place (launch_gather_li); first_done: so is panel 0 (launch_chol_first_spec)
-int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_dev, bool prebuilt, bool first_done)
+int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_dev, bool prebuilt, bool first_done, bool hp_built)
 {
     if (r == 0) {   // update.m:50-55: x_k_k = x_km1_k, p_k_k = p_km1_k
         if (which_prior == PRE3_X_K_KM1) PRE3_HIP(hipMemcpyAsync(c->x_kk, c->x_km1, sizeof(double) * c->n, hipMemcpyDeviceToDevice, c->stream));
@@ -1550,7 +1569,7 @@ int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_d
     int r_pad = round_up(r, NB);
     PRE3_CHECK(r_pad <= c->rcap, PRE3_E_ARG, "update with %d rows exceeds the context capacity %d", r, c->rcap);
     if (!prebuilt) {
-        PRE3_TRY(launch_ell_HP(c, r, c->W, true));
+        if (!hp_built) PRE3_TRY(launch_ell_HP(c, r, c->W, true));           // (hp_built: launch_ell_HP_build_sel made the rows and W = H*P in one launch)
         PRE3_TRY(launch_ell_G(c, r, c->W, c->Smat, r_pad, 1, dense_R ? c->Rdense : nullptr));
     }
     PRE3_TRY(launch_chol_solve(c, r_pad, first_done, which_prior == PRE3_X_K_KM1));
