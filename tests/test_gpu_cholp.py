@@ -140,3 +140,66 @@ def test_more_than_two_capable_contexts_fall_back(pre3):
     assert fs[0].chol_persist()
     for f in fs:
         f.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("n_hi", [1, 5, 16, 17])
+def test_small_hi_updates_against_the_twin(pre3, orc, dtype, n_hi):
+    """ekf_update_hi_inliers with 1 .. 17 rescued measurements after an LI update (one panel with 2 .. 34 real rows: the lock-step kernel,
+    rows built inside the H*P launch) against update.m's restatement in fp64 (numpy twin) applied twice -- LI set at x_k_km1, HI set with
+    h / H re-evaluated at x_k_k (rescue_hi_inliers.m:29-47)"""
+    from oracle import np_twin as tw
+    N, n_hyp = 500, 8
+    seq = synth.make_sequence(N, 1, n_hyp)
+    s = seq["steps"][0]
+    types, off, n = orc.landmark_table(np.zeros(N, int))
+    meas, z = np.asarray(s["meas_idx"], np.int32), np.asarray(s["z"])
+    inl = np.setdiff1d(np.arange(len(meas)), s["outliers"])
+    li_pos, hi_pos = inl[:100], inl[100:100 + n_hi]
+    f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype=dtype, max_hyp=n_hyp, std_z=1.0)
+    f.set_x_p_k_k(seq["x0"], seq["P0"])
+    f.ekf_prediction(s["u"])
+    f.search_IC_matches()
+    f.set_measurements(meas, z)
+    li = np.zeros(len(meas), np.int32); li[li_pos] = 1
+    f.set_flags(li=li)
+    f.ekf_update_li_inliers()
+    f.rescue_hi_inliers()                                            # h / H at x_k_k (its own gate result is overwritten below)
+    hi = np.zeros(len(meas), np.int32); hi[hi_pos] = 1
+    f.set_flags(hi=hi)
+    f.ekf_update_hi_inliers()
+    xg, Pg = f.get_x_k_k(), f.get_p_k_k()
+    f.close()
+    xr, Pr = tw.predict(seq["x0"], seq["P0"], s["u"])
+    hh, has = tw.project(types, off, xr, seq["cam"])
+    Hc, Hl = tw.jacobian(types, off, xr, seq["cam"], hh, has)
+    zfull = np.zeros((N, 2)); zfull[meas] = z
+    x1, P1 = tw.update_landmarks(types, off, meas[li_pos], xr, Pr, Hc, Hl, zfull, hh)
+    h1, has1 = tw.project(types, off, x1, seq["cam"])
+    Hc1, Hl1 = tw.jacobian(types, off, x1, seq["cam"], h1, has1)
+    x2, P2 = tw.update_landmarks(types, off, meas[hi_pos], x1, P1, Hc1, Hl1, zfull, h1)
+    tolP, tolx = (3e-4, 2e-5) if dtype == "f32" else (1e-9, 1e-9)
+    assert np.isfinite(Pg).all()
+    assert np.abs(Pg - P2).max() < tolP * np.abs(P2).max(), np.abs(Pg - P2).max() / np.abs(P2).max()
+    assert np.abs(xg - x2).max() < tolx, np.abs(xg - x2).max()
+    assert np.abs(P2 - P1).max() > 1e-6 * np.abs(P1).max()           # the HI update did something
+
+
+def test_not_positive_definite_is_reported_by_a_one_panel_update(pre3):
+    seq = synth.make_sequence(60, 1, 8)
+    s = seq["steps"][0]
+    for dtype in ("f32", "f64"):
+        f = pre3.EkfFilter(seq["cam"], np.zeros(60, np.int32), dtype=dtype, max_hyp=8, std_z=1.0)
+        f.set_x_p_k_k(seq["x0"], seq["P0"])
+        f.ekf_prediction(s["u"]); f.search_IC_matches(); f.set_measurements(s["meas_idx"], s["z"])
+        f.set_flags(li=np.zeros(len(s["meas_idx"]), np.int32))
+        f.ekf_update_li_inliers()                                     # no inliers: x_k_k = x_k_km1
+        f.rescue_hi_inliers()
+        f.set_x_p_k_k(f.get_x_k_k(), -np.eye(seq["n"]) * 10.0)       # S = H P H' + R not positive definite
+        hi = np.zeros(len(s["meas_idx"]), np.int32); hi[:6] = 1
+        f.set_flags(hi=hi)
+        f.ekf_update_hi_inliers()
+        with pytest.raises(pre3.Pre3Error) as e:
+            f.get_p_k_k()
+        assert e.value.code == -5
+        f.close()
