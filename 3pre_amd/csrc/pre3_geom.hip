@@ -96,14 +96,24 @@ __global__ __launch_bounds__(256) void k_predict(const double *__restrict__ x_in
         xo[4] = a * x + b * w + c * z - d * y;
         xo[5] = a * y - b * z + c * w + d * x;
         xo[6] = a * z + b * y - c * x + d * w;
+        double R[9];
+        if (blockIdx.x == 0) {
+            // the predicted pose first, and the riders' signal right behind it: they read nothing else of this launch, and the rest of this
+            // lane's serial work (normalisation Jacobian, G, process noise: a few hundred dependent fp64 operations) need not stand in front
+            // of the 500 projections
+            d_q2R_sola(q, R);
+            for (int i = 0; i < 3; ++i) xo[i] = x_in[i] + (R[i * 3] * u.v[0] + R[i * 3 + 1] * u.v[1] + R[i * 3 + 2] * u.v[2]);
+            const double nq = sqrt(xo[3] * xo[3] + xo[4] * xo[4] + xo[5] * xo[5] + xo[6] * xo[6]);
+            for (int i = 0; i < 3; ++i) x_out[i] = xo[i];
+            for (int i = 0; i < 4; ++i) x_out[3 + i] = xo[3 + i] / nq;
+            for (int i = 7; i < 13; ++i) x_out[i] = 0;
+            if (pr.n_blocks) { __threadfence(); __hip_atomic_fetch_add(pr.ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+        }
         const double Qq1[16] = { w, -x, -y, -z,  x, w, z, -y,  y, -z, w, x,  z, y, -x, w };
         double Jn[16];
         d_normjac(xo + 3, Jn);     // at the un-normalised q (predict_state_and_covariance.m:137)
         for (int i = 0; i < 16; ++i) { sQq1[i] = Qq1[i]; sJn[i] = Jn[i]; }
         if (blockIdx.x == 0) {
-            double R[9];
-            d_q2R_sola(q, R);
-            for (int i = 0; i < 3; ++i) xo[i] = x_in[i] + (R[i * 3] * u.v[0] + R[i * 3 + 1] * u.v[1] + R[i * 3 + 2] * u.v[2]);
             const double Qq2[16] = { a, -b, -c, -d,  b, a, -d, c,  c, d, a, -b,  d, -c, b, a };
             // G = [R 0; 0 Qq2] (7x7 non-zero part) and the process noise go to LDS; Q7 = G Pn G' is formed by 49 lanes below
             double Pn[49];
@@ -113,16 +123,11 @@ __global__ __launch_bounds__(256) void k_predict(const double *__restrict__ x_in
             d_process_noise(Pn);
             for (int i = 0; i < 49; ++i) sPn[i] = Pn[i];
             for (int i = 0; i < 16; ++i) { params[i] = Qq1[i]; params[16 + i] = Jn[i]; }
-            const double nq = sqrt(xo[3] * xo[3] + xo[4] * xo[4] + xo[5] * xo[5] + xo[6] * xo[6]);
-            for (int i = 0; i < 3; ++i) x_out[i] = xo[i];
-            for (int i = 0; i < 4; ++i) x_out[3 + i] = xo[3 + i] / nq;
-            for (int i = 7; i < 13; ++i) x_out[i] = 0;
         }
     }
     // the projection riders read the landmarks from x_in (the prediction copies them unchanged) and only the POSE from x_out: block 0's
     // signal is the only one they wait for (every block signalling cost each of them a device-scope release)
-    if (pr.n_blocks && blockIdx.x == 0) ride_signal(pr.ctr);       // (includes the barrier)
-    else __syncthreads();
+    __syncthreads();                                               // (block 0's lane 0 has signalled the riders already, behind the pose)
     double cfix = 0; int cpos = -1;
     if (fuse_jn) {
         if (j >= 7 && j < n) { double w[4]; for (int i = 0; i < 4; ++i) w[i] = (double)(T)jn_row(sJu, i, v); for (int i = 0; i < 4; ++i) v[i] = w[i]; }
