@@ -1430,9 +1430,10 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
         c->tile_ctr_clean = false;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    // only launches in the matrix-bound regime are bracketed (r_pad >= 128: the LI updates); an HI update's r <= 64 launch is a
-    // read-modify-write of P at HBM speed and would only dilute the figure -- and with 'one in N' it would alias with the LI/HI alternation
-    const bool timed = c->kt.enabled && r_pad >= 2 * NB && (c->kt.seen++ % c->kt.every) == 0;
+    // only launches in the matrix-bound regime are bracketed: the updates of the PREDICTED state (the LI updates, r_pad >= 128; and
+    // pre3_bench_downdate).  The rescue stage's HI update -- a few dozen rows, at most a couple of panels early in a sequence -- is a
+    // read-modify-write of P at HBM speed and would only dilute the figure, and with 'one in N' it would alias with the LI/HI alternation
+    const bool timed = c->kt.enabled && r_pad >= 2 * NB && which_prior != PRE3_X_K_K && (c->kt.seen++ % c->kt.every) == 0;
     if (timed) {
         if ((size_t)c->kt.used + 2 > c->kt.ev.size()) {
             for (int i = 0; i < 2; ++i) { hipEvent_t e; PRE3_HIP(hipEventCreate(&e)); c->kt.ev.push_back(e); }
@@ -1442,7 +1443,9 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
         PRE3_HIP(hipEventRecord(e0, c->stream));
     }
     if (use_b3) {
-        const int nst = r_pad / B3_BK, nst_total = c->rcap / B3_BK;
+        // k-stages of 16 rows: rows r .. r_pad-1 of W are zero (identity padding of S against zero rows of H*P), so the stages that hold nothing
+        // else are skipped -- the tile loop wants an even count of at least four (r = 518: 34 stages instead of 36)
+        const int nst = std::min(r_pad / B3_BK, std::max(4, 2 * ceil_div(r, 2 * B3_BK))), nst_total = c->rcap / B3_BK;
         const int st0 = c->split_rows / B3_BK;                         // row blocks the factorisation's riders have already split
         c->split_rows = 0;
         if (st0 < nst) {

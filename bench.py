@@ -406,10 +406,10 @@ def main():
     ap.add_argument("--kt-every", type=int, default=4, help="bracket one K9 launch in N with HIP events (an event pair costs ~11 us of stream time); 1 = every launch")
     ap.add_argument("--sync-hi", action="store_true", help="complete every step's HI update inside the step call (default: deferred to the next call)")
     ap.add_argument("--k9-f32", action="store_true", help="fp32 path: K9 on the f32 MFMA instead of the three-way bf16 split (PRE3_OPT_K9_BF16X3 = 0)")
-    ap.add_argument("--threshold", type=float, default=0.45, help="RANSAC threshold in pixels (ransac_hypotheses.m:33, threshold = std_z); 0.45 = 1.8 sigma of "
-                    "the synthetic pixel noise: some true inliers then miss the low-innovation set and about ten of them come back through the chi2 "
-                    "rescue (whose gate, sqrt(5.99 H P H'), is ~0.7 px on the converged map), so that every step carries a real HI update of ~20 rows; "
-                    "1.0 is the reference's own constant (the `no_hi` leg)")
+    ap.add_argument("--threshold", type=float, default=0.5, help="RANSAC threshold in pixels (ransac_hypotheses.m:33, threshold = std_z); 0.5 = 2 sigma of "
+                    "the synthetic pixel noise: some true inliers then miss the low-innovation set and come back through the chi2 rescue (whose gate, "
+                    "sqrt(5.99 H P H'), is ~0.7 px on the converged map), so that every step carries a real HI update: ~40 rows in steps 5..25 of the "
+                    "sequence (the window of `--steps 20 --warmup 5`), ~12 rows averaged over 200 steps; 1.0 is the reference's own constant (the `no_hi` leg)")
     ap.add_argument("--no-hi-steps", type=int, default=60, help="steps of the second leg (threshold 1.0: the rescue finds next to nothing); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of host work per CPU-baseline leg (three legs)")

@@ -24,7 +24,7 @@ shutil.copy(find("%s_trace" % tag, "%s_kernel_stats.csv" % tag), os.path.join(P,
 tl = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_timeline.py"), find("%s_trace" % tag, "%s_kernel_trace.csv" % tag), "3"],
                     capture_output=True, text=True, check=True).stdout
 with open(os.path.join(P, "%s_bench_one_step_timeline.txt" % tag), "w") as fh:
-    fh.write("# one filter step (N=500, n=3013, 200 hypotheses, f32, RANSAC threshold 0.45 px: LI update ~500 rows + HI update ~20 rows) from rocprofv3 "
+    fh.write("# one filter step (N=500, n=3013, 200 hypotheses, f32, RANSAC threshold 0.5 px: LI update ~540 rows + HI update ~12 rows at this point of the sequence) from rocprofv3 "
              "--kernel-trace of `python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extra-legs --no-check --no-hi-steps 0`\n# (the profiler adds ~10 % to the step; unprofiled numbers are in DESIGN.md section 8)\n" + tl)
 
 
@@ -89,7 +89,7 @@ cp = [((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in csv
 if cp:
     big_ = sorted(d for d in cp if d > 0.5 * max(cp)); small_ = sorted(d for d in cp if d <= 0.5 * max(cp))
     cl = ["# k_cholp (K8, round 3: S = L L' and W = L^-1 [HP | nu] in ONE persistent launch) in `bench.py --steps 40` (N=500, n=3013), rocprofv3 --kernel-trace",
-          "# LI updates (r ~ 500 rows at the bench's default RANSAC threshold of 0.45 px: eight 64-row panels; ten at r ~ 640): %d launches, median %.2f us, mean %.2f us, min %.2f us" % (len(big_), big_[len(big_) // 2], sum(big_) / len(big_), big_[0])]
+          "# LI updates (r ~ 540 rows at the bench's default RANSAC threshold of 0.5 px: nine 64-row panels; ten at r ~ 640): %d launches, median %.2f us, mean %.2f us, min %.2f us" % (len(big_), big_[len(big_) // 2], sum(big_) / len(big_), big_[0])]
     if small_:
         cl.append("# HI updates of two and more panels (one-panel updates take k_chol_step: one launch in either form): %d launches, median %.2f us, mean %.2f us" % (len(small_), small_[len(small_) // 2], sum(small_) / len(small_)))
     sqd = os.path.join(G, "%s_pmc_sq" % tag)
