@@ -109,12 +109,28 @@ COLLECTIVE_BY = {True: "%s enqueued by libpre3 on its own stream (pre3_comm_crea
                  False: "torch.distributed between host synchronisations (3pre_amd/dist.py; the %s of the RCCL build is not used in this run)"}
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on STDOUT (from C) when the first communicator of a process comes up: fd 1 goes to stderr meanwhile, so
+    that the contract's ONE JSON line stays the only thing on stdout"""
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def comm_leg(dist, local_rank, holder):
     """libpre3's own RCCL communicator, as a leg of its own: binding the library is local (set-up), creating the communicator is collective"""
     cm = importlib.import_module("3pre_amd.comm")
-    cm.unique_id()                                      # binds librccl.so in this process; raises if it cannot
+    with _StdoutToStderr():
+        cm.unique_id()                                  # binds librccl.so in this process; raises if it cannot
     yield None
-    holder["comm"] = cm.Comm.from_torch_distributed(local_rank)
+    with _StdoutToStderr():
+        holder["comm"] = cm.Comm.from_torch_distributed(local_rank)
     yield holder["comm"].info()
 
 
