@@ -358,7 +358,7 @@ def legs_agree(dist, err, name):
     return ok
 
 
-def run_leg(dist, name, gen_fn, inject):
+def run_leg(dist, name, gen_fn, inject, hang=False):
     """A sharded leg is a generator: everything up to its first `yield` is set-up (no collective), the rest is the measured run (its own
     collectives) and yields the result.  Every rank takes the same path through here and issues the same collectives in the same order:
     set-up -> ONE agreement -> run -> ONE agreement.  A rank whose set-up fails (or is made to, `inject`) therefore cannot be left one
@@ -374,6 +374,8 @@ def run_leg(dist, name, gen_fn, inject):
     agreed = legs_agree(dist, err, name + " (set-up)")
     if agreed:
         try:
+            if hang:                                    # PRE3_BENCH_HANG_LEG: stands in for a collective whose partner never arrives (rehearses the watchdog)
+                time.sleep(10 ** 6)
             res = next(gen)
         except Exception as e:                          # pragma: no cover
             err = e
@@ -633,6 +635,28 @@ def main():
                 fh.write(json.dumps(out) + "\n")
         except OSError:                                         # pragma: no cover
             pass
+    # A collective of an auxiliary leg whose partner never arrives does not return (libpre3's own communicator has no time-out; torch's
+    # aborts the process after its 90 s): under an external launcher nobody would print the headline then.  A watchdog thread does: if the
+    # legs are not through after PRE3_BENCH_LEG_TIMEOUT seconds (default 150), rank 0 prints the headline it already has -- with the
+    # legs marked as timed out -- and every rank leaves with exit code 3.
+    import threading
+    printed = threading.Lock()
+    def _watchdog():
+        if not printed.acquire(blocking=False):
+            return                                              # the main thread is printing / has printed
+        if rank == 0:
+            o = dict(out) if out is not None else {}
+            o["legs"] = "timed out inside an auxiliary leg's collective (exit code 3); the headline was measured before the legs"
+            sys.stdout.write(json.dumps(o) + "\n")
+            sys.stdout.flush()
+        sys.stderr.write("bench.py: rank %d: the auxiliary legs did not finish in time -- leaving\n" % rank)
+        sys.stderr.flush()
+        os._exit(3)
+    wd = None
+    if not args.no_extra_legs and (dist is not None or os.environ.get("PRE3_BENCH_COMM", "1") != "0"):
+        wd = threading.Timer(float(os.environ.get("PRE3_BENCH_LEG_TIMEOUT", "150")) + (0.0 if rank == 0 else 5.0), _watchdog)
+        wd.daemon = True
+        wd.start()
     holder = {}
     if not args.no_extra_legs:
         legs = [("ransac_shard", lambda: ransac_shard_leg(pre3, synth, dist, rank, world, local_rank, comm=holder.get("comm"))),
@@ -640,7 +664,8 @@ def main():
         if not rehearsal and os.environ.get("PRE3_BENCH_COMM", "1") != "0":     # (gloo rehearsal: several ranks share one GPU, which RCCL refuses)
             legs.insert(0, ("rccl", lambda: comm_leg(dist, local_rank, holder)))
         for name, fn in legs:
-            leg, err, agreed = run_leg(dist, name, fn, os.environ.get("PRE3_BENCH_FAIL_LEG") == name and rank == world - 1)
+            leg, err, agreed = run_leg(dist, name, fn, os.environ.get("PRE3_BENCH_FAIL_LEG") == name and rank == world - 1,
+                                       hang=os.environ.get("PRE3_BENCH_HANG_LEG") == name and rank == world - 1)
             if rank == 0:
                 out[name] = leg if (err is None and agreed) else {"error": repr(err)[:300] if err is not None else "failed on another rank"}
             if agreed is None:
@@ -659,6 +684,11 @@ def main():
                 except Exception as e:                          # pragma: no cover
                     out[name] = {"error": repr(e)[:300]}
     # the line goes out BEFORE the final barrier and the teardown: a collective whose partner is gone does not raise on RCCL, it aborts
+    if not printed.acquire(blocking=False):
+        time.sleep(30)                                          # the watchdog is printing and leaving: nothing more to do here
+        os._exit(3)
+    if wd is not None:
+        wd.cancel()
     if rank == 0:
         if comm_broken:
             out["communicator"] = "broken during an auxiliary leg (exit code 3); the headline was measured before the legs"
