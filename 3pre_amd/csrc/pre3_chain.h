@@ -263,9 +263,13 @@ __device__ __forceinline__ void ch_worker_step(const int k, ChSmem<T> &sm, typen
 // worker waves already carry their tiles in `acc` (acc_loaded: the fused prologue of k_chol_step); on exit Ls holds L_JJ and
 // Xs[a][i] the solved block L_JJ^-1 X.  Waves 0-7 workers, 8 factor wave, 9 z wave; any further wave of the workgroup (the
 // persistent kernel's publisher / fetcher waves) runs side_step(k) once per pipeline step and joins the step's barrier.
-template <typename T, bool RELAX = false, typename SideStep>
+// EARLY: the panel's last `NSP - nsp_eff` sub-panels are padding (identity rows and columns of S against zero rows of the right-hand side: the
+// last panel of an update whose row count is not a multiple of 64).  Their steps change nothing -- L keeps its identity columns, the
+// right-hand side its rows -- so the steps behind the one in which sub-panel nsp_eff-1 passes the z wave (k = nsp_eff) are skipped: an update of 20 rows
+// runs 5 of the 10 steps.  nsp_eff is workgroup-uniform.
+template <typename T, bool RELAX = false, bool EARLY = false, typename SideStep>
 __device__ __forceinline__ void chol_chain(ChSmem<T> &sm, typename ChW<T>::acc_t (&acc)[ChW<T>::NBLK][ChW<T>::NBLK], const bool acc_loaded,
-                                           const bool hasX, bool &bad, SideStep &&side_step)
+                                           const bool hasX, bool &bad, SideStep &&side_step, const int nsp_eff = CH_NSP)
 {
     constexpr int MB = CH_MB, NSP = CH_NSP;
     typedef T v4_t __attribute__((ext_vector_type(4), aligned(16)));
@@ -302,6 +306,7 @@ __device__ __forceinline__ void chol_chain(ChSmem<T> &sm, typename ChW<T>::acc_t
 #define LDS_GROUP() do { if constexpr (sizeof(T) == 4) __builtin_amdgcn_sched_barrier(0); } while (0)      // (fp64: the register budget does not allow it)
 #pragma unroll
     for (int k = -1; k <= NSP; ++k) {
+        if constexpr (EARLY) { if (k > nsp_eff) continue; }       // (not `break`: a second loop exit keeps the optimizer from unrolling, and every index below is a constant only unrolled)
         PROBE_STEP(k, 0);
         if (worker) {
             if (xside) {

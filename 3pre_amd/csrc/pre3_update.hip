@@ -181,7 +181,8 @@ __global__ __launch_bounds__(256) void k_ell_G_hyp(const int32_t *__restrict__ h
 template <typename T, bool PRO>
 __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb,
                                                 int32_t *__restrict__ status, const int b, unsigned int *__restrict__ arrive, unsigned int target,
-                                                void *__restrict__ Wp = nullptr, int nst_total = 0, int ld = 0, void *__restrict__ Sp = nullptr, int sp_stride = 0)
+                                                void *__restrict__ Wp = nullptr, int nst_total = 0, int ld = 0, void *__restrict__ Sp = nullptr, int sp_stride = 0,
+                                                int rows_last = 0 /* > 0: real rows of the LAST panel (the rest of it is padding) */)
 {
     PROBE_STAMP(0);
     auto &Ls = sm.Ls; auto &Xs = sm.Xs;
@@ -347,7 +348,9 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
     }
     PROBE_STAMP(1);
     bool bad = false;
-    chol_chain<T>(sm, acc, acc_loaded, hasX, bad, [](int) {});
+    // (the last panel of an update whose row count is not a multiple of 64 stops behind its last real sub-panel; PRE3_CHOL_EARLY=0 at the host: never)
+    const int nsp_eff = (rows_last > 0 && J == nrb - 1) ? (rows_last + CH_MB - 1) / CH_MB : CH_NSP;
+    chol_chain<T, false, true>(sm, acc, acc_loaded, hasX, bad, [](int) {}, __builtin_amdgcn_readfirstlane(nsp_eff));
     PROBE_STAMP(2);
     if (bad && role == 0 && (tid & 63) == 0 && b == 0) atomicExch(status, 1);
     if (b == 0) {
@@ -599,7 +602,7 @@ template <typename T>
 __global__ __launch_bounds__(CH_NTH) void k_chol_step(T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb, int nW,
                                                    int nP, int32_t *__restrict__ status, unsigned int *__restrict__ arrive, unsigned int target,
                                                    int nPT, void *__restrict__ Wp, int nst_total, int ncb, int ld_split, void *__restrict__ Sp, int sp_stride,
-                                                   const int32_t *__restrict__ n_dev, int nS_max)
+                                                   const int32_t *__restrict__ n_dev, int nS_max, int rows_last = 0)
 {
     __shared__ ChSmem<T> sm;
     int b = blockIdx.x;
@@ -635,7 +638,7 @@ __global__ __launch_bounds__(CH_NTH) void k_chol_step(T *__restrict__ S, int lds
         return;
     }
     if (b < nP) {
-        chol_panel_body<T, true>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target, Wp, nst_total, ld_split, Sp, sp_stride);     // (J == 0: no pending update, skipped at run time)
+        chol_panel_body<T, true>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target, Wp, nst_total, ld_split, Sp, sp_stride, rows_last);     // (J == 0: no pending update, skipped at run time)
     } else {
         chol_trail_body<T>(sm.As, sm.Bs, S, lds, W, ldw, J - 1, J + 1, nrb, nW, b - nP, Wp, nst_total, Sp, sp_stride);
     }
@@ -1366,7 +1369,7 @@ int launch_ell_G_hyp(pre3_ctx *c, int k, int lo, int hi, int ldg)
     return PRE3_OK;
 }
 
-static int launch_chol_solve(pre3_ctx *c, int r_pad, bool first_done = false, bool predicted_prior = false)
+static int launch_chol_solve(pre3_ctx *c, int r_pad, bool first_done = false, bool predicted_prior = false, int r = -1 /* real rows, if known */)
 {
     int nrb = r_pad / NB, nW = c->ldw / NB;
     c->split_rows = 0;
@@ -1384,6 +1387,8 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad, bool first_done = false, bo
         const bool split = c->k9_b3 && c->dtype == PRE3_F32 && c->Wp != nullptr;
         static const int pro_env = getenv("PRE3_CHOL_PRO_B3") ? atoi(getenv("PRE3_CHOL_PRO_B3")) : 1;
         const bool pro_planes = split && pro_env && c->Sp != nullptr;       // pending updates on the bf16 MFMA as well
+        static const int early_env = getenv("PRE3_CHOL_EARLY") ? atoi(getenv("PRE3_CHOL_EARLY")) : 1;
+        const int rows_last = (early_env && r > 0 && r <= r_pad && r > r_pad - NB) ? r - (r_pad - NB) : 0;      // real rows of the last panel (0: unknown / switched off)
         for (int J = first_done ? 1 : 0; J < nrb; ++J) {
             const int nS = nrb - J - 1, nP = 1 + nS + nW;
             const int nK = J >= 1 ? nrb - J - 1 : 0;                        // column blocks >= J+1 of panel J-1's update
@@ -1401,9 +1406,9 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad, bool first_done = false, bo
             c->chol_target += (unsigned)(nP - 1);                           // every non-diagonal workgroup of the panel arrives once
             DISPATCH_T(c,
                 hipLaunchKernelGGL(k_chol_step<double>, g, bP, 0, c->stream, (double *)c->Smat, r_pad, (double *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
-                                   nP + nT_in, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0),
+                                   nP + nT_in, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, rows_last),
                 hipLaunchKernelGGL(k_chol_step<float>, g, bP, 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
-                                   nP + nT_in, split ? c->Wp : nullptr, c->rcap / B3_BK, ncb, c->ld, pro_planes ? c->Sp : nullptr, c->rcap / NB, nullptr, 0));
+                                   nP + nT_in, split ? c->Wp : nullptr, c->rcap / B3_BK, ncb, c->ld, pro_planes ? c->Sp : nullptr, c->rcap / NB, nullptr, 0, rows_last));
         }
         if (split) c->split_rows = nrb * NB;
         PRE3_HIP(hipGetLastError());
@@ -1575,7 +1580,7 @@ int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_d
         if (!hp_built) PRE3_TRY(launch_ell_HP(c, r, c->W, true));           // (hp_built: launch_ell_HP_build_sel made the rows and W = H*P in one launch)
         PRE3_TRY(launch_ell_G(c, r, c->W, c->Smat, r_pad, 1, dense_R ? c->Rdense : nullptr));
     }
-    PRE3_TRY(launch_chol_solve(c, r_pad, first_done, which_prior == PRE3_X_K_KM1));
+    PRE3_TRY(launch_chol_solve(c, r_pad, first_done, which_prior == PRE3_X_K_KM1, r));
     PRE3_TRY(launch_downdate(c, r, c->W, which_prior));
     // update.m:42-46.  leave_jn_to_predict (pre3_step completing the previous step's HI update): the prediction's launch that follows carries it
     if (c->leave_jn_to_predict && !Kt_out_dev) c->jn_pending = true;
