@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_ell_G_hyp(const int32_t *__restrict__ h
 
 // PRO: the workgroup first applies the update of panel J-1 to its own blocks (diagonal block and X), i.e. the K = J
 // column of the trailing update, so that the launch of panel J does not have to wait for a separate trail kernel.
-template <typename T, bool PRO>
+template <typename T, bool PRO, bool EARLY = false>
 __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb,
                                                 int32_t *__restrict__ status, const int b, unsigned int *__restrict__ arrive, unsigned int target,
                                                 void *__restrict__ Wp = nullptr, int nst_total = 0, int ld = 0, void *__restrict__ Sp = nullptr, int sp_stride = 0,
@@ -350,7 +350,10 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
     bool bad = false;
     // (the last panel of an update whose row count is not a multiple of 64 stops behind its last real sub-panel; PRE3_CHOL_EARLY=0 at the host: never)
     const int nsp_eff = (rows_last > 0 && J == nrb - 1) ? (rows_last + CH_MB - 1) / CH_MB : CH_NSP;
-    chol_chain<T, false, true>(sm, acc, acc_loaded, hasX, bad, [](int) {}, __builtin_amdgcn_readfirstlane(nsp_eff));
+    // (EARLY is a KERNEL variant: the step-skipping form's uniform branches cost a full chain ~6 % -- measured in the persistent kernel, 14.35 k ->
+    // 15.3 k cycles per panel -- and both forms in one kernel spill; the host launches it for a last panel that really has padding)
+    if constexpr (EARLY) chol_chain<T, false, true>(sm, acc, acc_loaded, hasX, bad, [](int) {}, __builtin_amdgcn_readfirstlane(nsp_eff));
+    else chol_chain<T, false, false>(sm, acc, acc_loaded, hasX, bad, [](int) {});
     PROBE_STAMP(2);
     if (bad && role == 0 && (tid & 63) == 0 && b == 0) atomicExch(status, 1);
     if (b == 0) {
@@ -598,7 +601,7 @@ __device__ __forceinline__ void chol_trail_body(T (&As)[NB][NB + 1], T (&Bs)[NB]
 // J-1's trailing update to their own blocks (PRO) -- while workgroups [nP, ...) apply the rest of panel J-1's trailing
 // update (column blocks >= J+1), which nothing in this launch reads.  The dependent chain is then 1 launch per panel
 // instead of 2, and the wide update runs in the shadow of the (latency-bound) panel.
-template <typename T>
+template <typename T, bool EARLY = false>
 __global__ __launch_bounds__(CH_NTH) void k_chol_step(T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb, int nW,
                                                    int nP, int32_t *__restrict__ status, unsigned int *__restrict__ arrive, unsigned int target,
                                                    int nPT, void *__restrict__ Wp, int nst_total, int ncb, int ld_split, void *__restrict__ Sp, int sp_stride,
@@ -638,7 +641,7 @@ __global__ __launch_bounds__(CH_NTH) void k_chol_step(T *__restrict__ S, int lds
         return;
     }
     if (b < nP) {
-        chol_panel_body<T, true>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target, Wp, nst_total, ld_split, Sp, sp_stride, rows_last);     // (J == 0: no pending update, skipped at run time)
+        chol_panel_body<T, true, EARLY>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target, Wp, nst_total, ld_split, Sp, sp_stride, rows_last);     // (J == 0: no pending update, skipped at run time)
     } else {
         chol_trail_body<T>(sm.As, sm.Bs, S, lds, W, ldw, J - 1, J + 1, nrb, nW, b - nP, Wp, nst_total, Sp, sp_stride);
     }
@@ -1404,11 +1407,20 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad, bool first_done = false, bo
             const int nT_in = own_trail ? 0 : nT;
             dim3 g(nP + nT_in + 4 * ncb), bP(CH_NTH);
             c->chol_target += (unsigned)(nP - 1);                           // every non-diagonal workgroup of the panel arrives once
+            const bool early = rows_last > 0 && rows_last <= NB - 8 && J == nrb - 1;       // at least one padded sub-panel in the last panel
+            if (early) {
+                DISPATCH_T(c,
+                    hipLaunchKernelGGL((k_chol_step<double, true>), g, bP, 0, c->stream, (double *)c->Smat, r_pad, (double *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
+                                       nP + nT_in, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, rows_last),
+                    hipLaunchKernelGGL((k_chol_step<float, true>), g, bP, 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
+                                       nP + nT_in, split ? c->Wp : nullptr, c->rcap / B3_BK, ncb, c->ld, pro_planes ? c->Sp : nullptr, c->rcap / NB, nullptr, 0, rows_last));
+            } else {
             DISPATCH_T(c,
                 hipLaunchKernelGGL(k_chol_step<double>, g, bP, 0, c->stream, (double *)c->Smat, r_pad, (double *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
-                                   nP + nT_in, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, rows_last),
+                                   nP + nT_in, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, 0),
                 hipLaunchKernelGGL(k_chol_step<float>, g, bP, 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
-                                   nP + nT_in, split ? c->Wp : nullptr, c->rcap / B3_BK, ncb, c->ld, pro_planes ? c->Sp : nullptr, c->rcap / NB, nullptr, 0, rows_last));
+                                   nP + nT_in, split ? c->Wp : nullptr, c->rcap / B3_BK, ncb, c->ld, pro_planes ? c->Sp : nullptr, c->rcap / NB, nullptr, 0, 0));
+            }
         }
         if (split) c->split_rows = nrb * NB;
         PRE3_HIP(hipGetLastError());
