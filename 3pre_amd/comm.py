@@ -53,7 +53,7 @@ class Comm:
         return dict(rank=r.value, world=w.value, rccl_version=v.value, library=path.value.decode(errors="replace"))
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:          # (lib is None while the interpreter shuts down)
             lib.pre3_comm_destroy(self._h)
             self._h = None
 

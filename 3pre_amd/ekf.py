@@ -53,7 +53,7 @@ class EkfFilter:
         self._st_addr = self._st.ctypes.data
 
     def close(self):
-        if getattr(self, "_ctx", None):
+        if getattr(self, "_ctx", None) and lib is not None:        # (lib is None while the interpreter shuts down)
             lib.pre3_destroy(self._ctx)
             self._ctx = None
 

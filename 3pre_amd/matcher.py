@@ -133,7 +133,7 @@ class MatchShard:
         return (m, sc[:M.value].copy()) if return_scores else m
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:          # (lib is None while the interpreter shuts down)
             lib.pre3_match_shard_destroy(self._h)
             self._h = None
 
