@@ -231,7 +231,16 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
         A(dmalloc_bytes(&c->Wp, (size_t)(c->ld + 128) * c->rcap * 6));       // + one column block for the nu strip's planes
         A(dmalloc_bytes(&c->Sp, (size_t)(c->rcap / NB) * (c->rcap / NB) * 1536 * 16));
         // persistent factorisation (pre3_cholp.hip): flag words (zero: every launch brings its own epoch), one plane block per row for the hand-over to crit
-        { void *f = nullptr; A(dmalloc_bytes(&f, cholp_flag_bytes())); c->cholp_flags = (unsigned int *)f; }
+        { void *f = nullptr; A(dmalloc_bytes(&f, cholp_flag_bytes(c->ldw / 32))); c->cholp_flags = (unsigned int *)f; }
+        {   // the down-date consumers' schedule (pre3_cholp.hip)
+            std::vector<int32_t> rec; std::vector<int2> t64;
+            dd_build_groups(c->ld / 64, rec, t64, c->dd_tile_off);
+            c->dd_n_groups = (int)c->dd_tile_off.size() - 1;
+            { void *f = nullptr; A(dmalloc_bytes(&f, sizeof(int32_t) * rec.size())); c->dd_groups = (int32_t *)f; }
+            A(dmalloc_bytes(&c->dd_tiles, sizeof(int2) * t64.size()));
+            if (rc == PRE3_OK && (hipMemcpy(c->dd_groups, rec.data(), sizeof(int32_t) * rec.size(), hipMemcpyHostToDevice) != hipSuccess ||
+                                  hipMemcpy(c->dd_tiles, t64.data(), sizeof(int2) * t64.size(), hipMemcpyHostToDevice) != hipSuccess)) { set_error("consumer table upload failed"); rc = PRE3_E_HIP; }
+        }
         A(dmalloc_bytes(&c->cholp_tp, (size_t)(c->rcap / NB) * 1536 * 16));
         if (rc == PRE3_OK) { cholp_context_count(c->device, +1); c->cholp_counted = true; }
         const int nt = c->ld / 128, ns = ceil_div(nt, 4);
@@ -303,7 +312,7 @@ int pre3_destroy(pre3_ctx *c)
     c->comm = nullptr;
     void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
                      c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
-                     c->sel_rows, c->support, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128, c->need, c->cholp_flags, c->cholp_tp };
+                     c->sel_rows, c->support, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128, c->need, c->cholp_flags, c->cholp_tp, c->dd_groups, c->dd_tiles };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->pinned_stats) (void)hipHostFree(c->pinned_stats);
     if (c->inbox_host) (void)hipHostFree(c->inbox_host);
@@ -323,6 +332,7 @@ int pre3_set_option(pre3_ctx *c, int option, int value)
     case PRE3_OPT_DEFER_HI: c->defer_hi = value != 0; return PRE3_OK;
     case PRE3_OPT_K9_BF16X3: c->k9_b3 = value != 0 && c->dtype == PRE3_F32 && c->Wp != nullptr; return PRE3_OK;
     case PRE3_OPT_CHOL_PERSIST: c->chol_persist = value != 0; return PRE3_OK;
+    case PRE3_OPT_K9_OVERLAP: c->k9_overlap = value != 0; return PRE3_OK;
     default: set_error("pre3_set_option: unknown option %d", option); return PRE3_E_ARG;
     }
 }
@@ -335,6 +345,7 @@ int pre3_get_option(pre3_ctx *c, int option, int *value_out)
     case PRE3_OPT_K9_BF16X3: *value_out = c->k9_b3 ? 1 : 0; return PRE3_OK;
     case PRE3_OPT_CHOL_PERSIST: *value_out = cholp_usable(c, 1) ? 1 : 0; return PRE3_OK;
     case PRE3_OPT_IC_RANKED: *value_out = c->ic_last_ranked ? 1 : 0; return PRE3_OK;
+    case PRE3_OPT_K9_OVERLAP: *value_out = c->k9_overlap ? 1 : 0; return PRE3_OK;
     default: set_error("pre3_get_option: unknown option %d", option); return PRE3_E_ARG;
     }
 }

@@ -12,7 +12,11 @@
 //   row i  (blocks 1.., i >= 2, 4 waves)  for J = 0 .. i-2:  L(i,J) = A(i,J) M_J' once M_J is published, then A(i,k) -= L(i,J) L(k,J)'
 //          for k = J+1 .. i.  After panel i-2 the row's two leading tiles go to crit (A(i,i-1) as planes, A(i,i) as f32).
 //   strip s (32 columns of [HP | nu], 4 waves)  for J = 0 .. nrb-1:  W_J = M_J (HP_J - sum_{K<J} L(J,K) W_K), the W_K as bf16 planes in
-//          LDS; epilogue: W in f32 and as the bf16 planes k_downdate_b3 reads.
+//          LDS; epilogue: W in f32 and as the bf16 planes k_downdate_b3 reads (sc1 stores, then the strip's flag for panel J).
+//   down-date consumer g (the CUs the factorisation leaves idle; round 4)  up to twelve 64 x 64 tiles of P's upper triangle, one per wave,
+//          accumulators resident for the whole launch: for J = 0 .. nrb-1, as soon as the strips that own the group's column blocks have
+//          published W_J, the panel's planes come in by LDS-DMA and acc += W_J' W_J (update.m:37 is a sum over panels); P is read, down-dated
+//          and written (with its mirror image) once, behind the last panel.  Same products in the same order as k_downdate_b3: bit-identical.
 //
 // Every hand-off is: payload by 16-byte sc1 (write-through) stores, each storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier,
 // ONE lane stores the flag (agent scope); consumer: one lane polls the flag (sc1), workgroup barrier, then every load of the payload
@@ -35,8 +39,8 @@ typedef int frag_t __attribute__((ext_vector_type(4)));      // 8 bf16
 typedef float f4v_t __attribute__((ext_vector_type(4)));
 
 #ifdef PRE3_PROBE
-// wall-clock stamps (s_memrealtime, 100 MHz, chip-wide) of the last launch: [role 0 crit main, 1 crit side, 2..15 rows, 16 strip 0, 17 last strip][panel 16][slot 8]
-static __device__ unsigned long long g_cp[20 * 16 * 8];
+// wall-clock stamps (s_memrealtime, 100 MHz, chip-wide) of the last launch: [role 0 crit main, 1 crit side, 2..15 rows, 16 strip 0, 17 last strip, 20 consumer 0, 21 last consumer][panel 16][slot 8]
+static __device__ unsigned long long g_cp[24 * 16 * 8];
 #define CP_CLK(role, J, slot) do { if ((threadIdx.x & 63) == 0) { unsigned long long t_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_cp[((role) * 16 + (J)) * 8 + (slot)] = t_; } } while (0)
 #define CP_STAMP(role, J, slot) do { if ((threadIdx.x & 63) == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_cp[((role) * 16 + (J)) * 8 + (slot)] = t_; } } while (0)
 #else
@@ -172,6 +176,7 @@ struct CpArgs {
     unsigned *cf; unsigned base;         // flags, epoch
     int32_t *status;                     // stats[6] (not positive definite), stats[7] (a wait gave up)
     const int32_t *n_dev; int nrb; int nrb_max; int n_strips;
+    float *P; const int32_t *dd; int n_dd; int rows;      // down-date consumers: group table (DG_WORDS each), groups in this launch, rows if host-known
 };
 // A call passes its arguments in VGPRs: the callee makes the (wave-uniform) launch arguments scalar again, word by word
 __device__ __forceinline__ CpArgs cp_uniform(const CpArgs &v)
@@ -183,9 +188,10 @@ __device__ __forceinline__ CpArgs cp_uniform(const CpArgs &v)
     for (unsigned w = 0; w < sizeof(CpArgs) / 4; ++w) dst[w] = (unsigned)__builtin_amdgcn_readfirstlane((int)src[w]);
     return a;
 }
-constexpr int CF_MP = 0, CF_ROWL = 32, CF_ROWA = 32 * 65, CF_WORDS = 32 * 130;     // one 128-byte line per flag
+constexpr int CF_MP = 0, CF_ROWL = 32, CF_ROWA = 32 * 65, CF_STRIP = 32 * 130;     // one 128-byte line per flag; the strips' flags follow
 __device__ __forceinline__ unsigned *cf_rowL(unsigned *cf, int i) { return cf + CF_ROWL + 32 * i; }
 __device__ __forceinline__ unsigned *cf_rowA(unsigned *cf, int i) { return cf + CF_ROWA + 32 * i; }
+__device__ __forceinline__ unsigned *cf_strip(unsigned *cf, int s) { return cf + CF_STRIP + 32 * s; }
 
 struct CritSmem {
     ChSmem<float> ch;                                            // Ls, Xs, As | pipe, Bs
@@ -674,6 +680,7 @@ __device__ __attribute__((noinline)) void row_body(CpArgs a_v, int nrb_v, int i_
 // ------------------------------------------------------------------------------------------------------------------------------
 // strip s: 32 columns of [HP | nu]
 // ------------------------------------------------------------------------------------------------------------------------------
+constexpr int DG_SLOTS = 6, DG_TASKS = 12, DG_WORDS = 16, DG_SLOT_GRAN = 3 * 2 * 64;     // down-date consumers (dd_body)
 constexpr int CP_WS = 32 + 1;                        // row stride of the strip's f32 transposition buffer
 constexpr int CP_WGRAN = 4 * 3 * 64;                 // granules of one 64 x 32 block of W as B-operand planes: [q 4][plane 3][lane 64]
 
@@ -693,8 +700,7 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
     const int fa = wave & 1, par = wave >> 1;
     const int c0 = s * 32, lcol = lane & 31;
     int32_t *guard = a.status + 1;
-    frag_t *Wp = static_cast<frag_t *>(a.Wp);
-    const __amdgpu_buffer_rsrc_t rW = cp_rsrc(a.W), rSp = cp_rsrc(a.Sp);
+    const __amdgpu_buffer_rsrc_t rW = cp_rsrc(a.W), rSp = cp_rsrc(a.Sp), rWp = cp_rsrc(a.Wp);
     const unsigned wvoff = acc_voff(lane, a.ldw) + (unsigned)((32 * fa) * a.ldw + c0) * 4u;
     const unsigned plo = (unsigned)(fa * 64 + lane) * 16u;               // this lane's place in a plane block's row half
     float *yrow = Yw + (32 * fa) * CP_WS + lcol, *yrow2 = Yw2 + (32 * fa) * CP_WS + lcol;
@@ -746,9 +752,11 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
                 d[0] = __builtin_bit_cast(frag_t, p0); d[64] = __builtin_bit_cast(frag_t, p1); d[128] = __builtin_bit_cast(frag_t, p2);
             }
             if (to_wp) {
-                // k_downdate_b3's image: block (column block of 128, stage of 16 k) = [plane 3][fragment 4][lane 64]
-                frag_t *d = Wp + ((size_t)(c0 >> 7) * a.nst_total + 4 * J + q) * B3_GRAN + ((c0 >> 5) & 3) * 64 + l;
-                d[0] = __builtin_bit_cast(frag_t, p0); d[256] = __builtin_bit_cast(frag_t, p1); d[512] = __builtin_bit_cast(frag_t, p2);
+                // k_downdate_b3's image: block (column block of 128, stage of 16 k) = [plane 3][fragment 4][lane 64].  Write-through stores:
+                // the down-date consumers of THIS launch read the panel as soon as the strip's flag is up.
+                const unsigned gb = (unsigned)((((size_t)(c0 >> 7) * a.nst_total + 4 * J + q) * B3_GRAN + ((c0 >> 5) & 3) * 64 + l) * 16u);
+                st16_sc1(p0, rWp, gb); st16_sc1(p1, rWp, gb + 256 * 16); st16_sc1(p2, rWp, gb + 512 * 16);
+                if (a.n_dd > 0) drain_stores();
             }
         }
     };
@@ -843,6 +851,8 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
         __syncthreads();
         tile_to_planes(J, more, c0 < a.ld + NB);
         __syncthreads();
+        // W_J's planes of these 32 columns are out (every storing thread has drained): the consumers' flag
+        if (tid == 0 && a.n_dd > 0) cf_store(cf_strip(a.cf, s), a.base + (unsigned)J + 1);
         if (tid == 0 && (s == 0 || s == a.n_strips - 1)) CP_STAMP(s == 0 ? 16 : 17, J, 2);
         // (4) the newest term of step J+1: L(J+1, J) W_J, one k-step per wave; L(J+1, J) is published about now (sc1 loads)
         if (more) {
@@ -868,22 +878,176 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
 #undef SM_MMA
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// down-date consumer g: up to twelve 64 x 64 tiles of P's upper triangle (update.m:37-38), one per wave
+// ------------------------------------------------------------------------------------------------------------------------------
+// Group record (DG_WORDS int32, built by dd_build_groups): [0] = tasks | slots << 8; [1..6] = the 64-column block of W each LDS slot holds;
+// [7..9] = one byte per task: slot of the tile's row block | slot of its column block << 4.  LDS: [stage 4][slot 6][plane 3][fragment 2][lane 64]
+// granules = 144 KB -- one whole panel of the group's operands; the epilogue's wave-private patches alias it.
+template <int N> __device__ __forceinline__ void dd_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wait until at most n of this wave's vector-memory operations are outstanding (a smaller immediate than n is only stricter)
+__device__ __forceinline__ void dd_vmwait_le(int n)
+{
+    switch (n) {
+    case 0: dd_vmwait<0>(); break;   case 1: dd_vmwait<1>(); break;   case 2: dd_vmwait<2>(); break;   case 3: dd_vmwait<3>(); break;
+    case 4: dd_vmwait<4>(); break;   case 5: dd_vmwait<5>(); break;   case 6: dd_vmwait<6>(); break;   case 7: dd_vmwait<6>(); break;
+    case 8: dd_vmwait<8>(); break;   case 9: dd_vmwait<9>(); break;   case 10: dd_vmwait<10>(); break; case 11: dd_vmwait<10>(); break;
+    case 12: dd_vmwait<12>(); break; case 13: dd_vmwait<12>(); break; case 14: dd_vmwait<12>(); break; default: dd_vmwait<15>(); break;
+    }
+}
+
+__device__ __attribute__((noinline)) void dd_body(CpArgs a_v, int nrb_v, int rows_v, int g_v)
+{
+    const CpArgs a = cp_uniform(a_v);
+    const int nrb = __builtin_amdgcn_readfirstlane(nrb_v), rows = __builtin_amdgcn_readfirstlane(rows_v), g = __builtin_amdgcn_readfirstlane(g_v);
+    extern __shared__ __attribute__((aligned(16))) unsigned char cp_smem[];
+    frag_t *ops = reinterpret_cast<frag_t *>(cp_smem);
+    const int32_t *rec = a.dd + (size_t)g * DG_WORDS;
+    const int hdr = rec[0], ntasks = hdr & 0xff, nslots = (hdr >> 8) & 0xff;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    if (wave >= ntasks) return;                                  // (an ended wave is not waited for by the barriers below)
+    const int tb = (rec[7 + (wave >> 2)] >> (8 * (wave & 3))) & 0xff, sa = tb & 15, sb = tb >> 4;
+    const int bi = rec[1 + sa], bj = rec[1 + sb];
+    const bool diag = bi == bj;
+    int32_t *guard = a.status + 1;
+    const int nst_real = (rows + B3_BK - 1) / B3_BK;              // k-stages that hold real rows (the rest of the last panel is zero padding)
+    // this wave's share of a stage's LDS-DMA instructions: idx = wave, wave + ntasks, .. < 6 nslots; idx -> (slot, plane, fragment)
+    const int n_inst = 6 * nslots, c_w = (n_inst - wave + ntasks - 1) / ntasks;
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const frag_t *Wp = static_cast<const frag_t *>(a.Wp);
+    for (int J = 0; J < nrb; ++J) {
+        int ns = nst_real - 4 * J;
+        ns = ns > 4 ? 4 : ns;
+        if (ns <= 0) break;
+        // the strips that own the group's column blocks (two per 64-column block) have published W_J
+        if (wave == 0) {
+            const int nfl = 2 * nslots;
+            const int blk = rec[1 + ((lane < nfl ? lane : 0) >> 1)];
+            const unsigned *fp = cf_strip(a.cf, 2 * blk + (lane & 1));
+            bool gave_up = true;
+            for (int spin = 0; spin < SPIN_LIMIT; ++spin) {
+                const bool ok = lane >= nfl || cf_reached(cf_load(fp), a.base + (unsigned)J + 1);
+                if (__all(ok)) { gave_up = false; break; }
+                if ((spin & 1023) == 1023 && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { gave_up = false; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (gave_up && lane == 0) atomicExch(guard, 1);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                      // (this wave's reads of the previous panel are in registers)
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0 && (g == 0 || g == a.n_dd - 1)) CP_STAMP(g == 0 ? 20 : 21, J, 0);
+        for (int st = 0; st < ns; ++st)
+            for (int idx = wave; idx < n_inst; idx += ntasks) {
+                const int slot = idx / 6, pf = idx - 6 * slot, pl = pf >> 1, f = pf & 1;
+                const int blk = rec[1 + slot];
+                const frag_t *src = Wp + ((size_t)(blk >> 1) * a.nst_total + 4 * J + st) * B3_GRAN + pl * 256 + (2 * (blk & 1) + f) * 64 + lane;
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(ops + (st * DG_SLOTS + slot) * DG_SLOT_GRAN + (2 * pl + f) * 64), 16, 0, 16);
+            }
+        for (int st = 0; st < ns; ++st) {
+            dd_vmwait_le(c_w * (ns - 1 - st));
+            __builtin_amdgcn_s_barrier();                        // every wave's share of stage st has landed
+            const frag_t *sA = ops + (st * DG_SLOTS + sa) * DG_SLOT_GRAN + lane, *sB = ops + (st * DG_SLOTS + sb) * DG_SLOT_GRAN + lane;
+            frag_t A[3][2], B[3][2];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { A[pl][i] = sA[(2 * pl + i) * 64]; B[pl][i] = sB[(2 * pl + i) * 64]; }
+#define DD_MMA(pa, pb) \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+                    if (!(diag && i > j)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, A[pa][i]), __builtin_bit_cast(bf16x8_t, B[pb][j]), acc[i][j], 0, 0, 0)
+            // (the six products of k_downdate_b3, in its order)
+            DD_MMA(0, 0); DD_MMA(0, 1); DD_MMA(1, 0); DD_MMA(1, 1); DD_MMA(0, 2); DD_MMA(2, 0);
+#undef DD_MMA
+        }
+        if (tid == 0 && (g == 0 || g == a.n_dd - 1)) CP_STAMP(g == 0 ? 20 : 21, J, 1);
+    }
+    // ---- P tile <- P tile - acc, and its mirror image (as k_downdate_b3's epilogue; blocks below the diagonal of a diagonal tile are skipped)
+    if (tid == 0 && (g == 0 || g == a.n_dd - 1)) CP_STAMP(g == 0 ? 20 : 21, 15, 0);
+    float *P = a.P;
+    const int ld = a.ld, R0 = bi * 64, C0 = bj * 64;
+    const int lrow = 4 * (lane >> 5), lcol = lane & 31;
+    float pv[2][2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (!(diag && i > j)) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) pv[i][j][e] = P[(size_t)(R0 + i * 32 + (e & 3) + 8 * (e >> 2) + lrow) * ld + C0 + j * 32 + lcol];
+            }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();                                // the patches alias the operand slots
+    float (*patch)[36] = reinterpret_cast<float (*)[36]>(reinterpret_cast<float *>(cp_smem) + wave * (2 * 32 * 36));
+    float (*patchT)[36] = patch + 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (diag && i > j) continue;
+            const bool dblk = diag && i == j;
+            const int r0 = R0 + i * 32, c0 = C0 + j * 32;
+            if (dblk) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int lr = (e & 3) + 8 * (e >> 2) + lrow;
+                    const float v = pv[i][j][e] - acc[i][j][e];
+                    if (lr <= lcol) P[(size_t)(r0 + lr) * ld + c0 + lcol] = v;
+                    patch[lr][lcol] = v;
+                }
+                wave_lds_sync();
+                const int rr = lane & 31, half = lane >> 5;
+#pragma unroll
+                for (int cc = 0; cc < 32; cc += 2) {
+                    const int c = cc + half;
+                    if (rr < c) P[(size_t)(c0 + c) * ld + r0 + rr] = patch[rr][c];
+                }
+            } else {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f4v_t v;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { v[t] = pv[i][j][4 * g4 + t] - acc[i][j][4 * g4 + t]; patch[8 * g4 + lrow + t][lcol] = v[t]; }
+                    *reinterpret_cast<f4v_t *>(&patchT[lcol][8 * g4 + lrow]) = v;
+                }
+                wave_lds_sync();
+                const int rr = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = rr + 8 * it;
+                    *reinterpret_cast<f4v_t *>(P + (size_t)(r0 + row) * ld + c0 + c4) = *reinterpret_cast<const f4v_t *>(&patch[row][c4]);
+                    *reinterpret_cast<f4v_t *>(P + (size_t)(c0 + row) * ld + r0 + c4) = *reinterpret_cast<const f4v_t *>(&patchT[row][c4]);
+                }
+            }
+            wave_lds_sync();
+        }
+    if (tid == 0 && (g == 0 || g == a.n_dd - 1)) CP_STAMP(g == 0 ? 20 : 21, 15, 1);
+}
+
 __global__ __launch_bounds__(CP_NTH) void k_cholp(CpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char cp_smem[];
-    int nrb = a.nrb;
+    int nrb = a.nrb, rows = a.rows;
     if (a.n_dev != nullptr) {                                   // the row count is still on its way to the host (LI update of a step)
         const int n = *a.n_dev;
-        nrb = (2 * n + NB - 1) / NB;
+        rows = 2 * n;
+        nrb = (rows + NB - 1) / NB;
         if (nrb > a.nrb_max) nrb = a.nrb_max;
     }
+    if (rows > nrb * NB) rows = nrb * NB;
     if (nrb <= 0) return;
     // Blocks 0, 8, 16, .. 8 nH are crit and the rows: blocks are dealt round-robin over the eight XCDs, so these share one XCD's L2 -- the rows'
     // bulk operands (each L(k, J) is wanted by every row below k) and the hand-offs with crit are then served by that L2.  Placement is a
     // speed assumption only: every hand-off is valid for any placement.  Every other block is a strip.
     const int b = blockIdx.x, nH = a.nrb_max > 2 ? a.nrb_max - 2 : 0;
 #ifndef CP_TEST_ROLE
-#define CP_TEST_ROLE 7
+#define CP_TEST_ROLE 15
 #endif
     if ((b & 7) == 0 && (b >> 3) <= nH) {
         const int r = b >> 3;
@@ -892,15 +1056,19 @@ __global__ __launch_bounds__(CP_NTH) void k_cholp(CpArgs a)
         if ((CP_TEST_ROLE & 2) && i < nrb) row_body(a, nrb, i);
         return;
     }
-    if (threadIdx.x >= 512) return;                             // strips are eight waves
     const int sidx = b - ((b >> 3) < nH ? (b >> 3) + 1 : nH + 1);
-    if ((CP_TEST_ROLE & 4) && sidx < a.n_strips) strip_body(a, nrb, sidx);
+    if (sidx < a.n_strips) {
+        if (threadIdx.x >= 512) return;                         // strips are eight waves
+        if (CP_TEST_ROLE & 4) strip_body(a, nrb, sidx);
+    } else if (sidx - a.n_strips < a.n_dd) {
+        if (CP_TEST_ROLE & 8) dd_body(a, nrb, rows, sidx - a.n_strips);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------------------
-size_t cholp_flag_bytes() { return sizeof(unsigned) * CF_WORDS; }
+size_t cholp_flag_bytes(int n_strips) { return sizeof(unsigned) * ((size_t)CF_STRIP + 32 * (size_t)(n_strips > 0 ? n_strips : 1)); }
 
 // Contexts of this process that can launch k_cholp, per device.  A launch is a set of workgroups that wait for one another and each fills a
 // CU (LDS): two launches fit the chip side by side (2 x 110 workgroups at N = 500), a third one's workgroups could interleave with theirs at
@@ -915,40 +1083,107 @@ bool cholp_usable(const pre3_ctx *c, int nrb_max)
     static const int form = getenv("PRE3_CHOL_FORM") ? atoi(getenv("PRE3_CHOL_FORM")) : 1;
     if (form == 0 || !c->chol_persist) return false;
     if (form != 2 && c->device >= 0 && c->device < 64 && g_cholp_live[c->device].load() > 2) return false;
+    // crit and the rows wait for one another: blocks 0, 8, .. 8 nH must be resident together, each on a CU of its own (the strips only wait
+    // for them, so strips beyond the chip's capacity simply start later)
+    const int nH = nrb_max > 2 ? nrb_max - 2 : 0;
+    if (8 * nH + 1 > c->num_cus) return false;
     return c->dtype == PRE3_F32 && c->k9_b3 && c->Wp != nullptr && c->Sp != nullptr && c->cholp_flags != nullptr && c->cholp_tp != nullptr &&
            nrb_max >= 1 && nrb_max <= CP_MAX_NRB && nrb_max <= c->rcap / NB;
 }
 
-// nrb < 0: the row count is read on the device (stats[4]); nrb_max bounds the grid and the LDS
-int launch_cholp(pre3_ctx *c, int nrb, int nrb_max)
+// The down-date consumers' schedule: P's upper triangle in 64-column blocks, 4 x 4 super-blocks.  A diagonal super-block is ONE group (its 10 tiles
+// read 4 column blocks of W); an off-diagonal one is two groups of 4 x 2 tiles (4 + 2 column blocks).  tiles64 lists every tile in group order
+// (what k_downdate_b3 takes over when a launch cannot hold all groups), tile_off[g] the first tile of group g.
+void dd_build_groups(int nb, std::vector<int32_t> &rec, std::vector<int2> &tiles64, std::vector<int> &tile_off)
+{
+    rec.clear(); tiles64.clear(); tile_off.clear();
+    const int ns = (nb + 3) / 4;
+    auto emit = [&](const std::vector<int> &slots, const std::vector<std::pair<int, int>> &tasks) {
+        if (tasks.empty()) return;
+        int32_t r[DG_WORDS] = { 0 };
+        r[0] = (int)tasks.size() | ((int)slots.size() << 8);
+        for (size_t k = 0; k < slots.size(); ++k) r[1 + k] = slots[k];
+        tile_off.push_back((int)tiles64.size());
+        for (size_t t = 0; t < tasks.size(); ++t) {
+            r[7 + (t >> 2)] |= (tasks[t].first | (tasks[t].second << 4)) << (8 * (t & 3));
+            tiles64.push_back(make_int2(slots[tasks[t].first], slots[tasks[t].second]));
+        }
+        rec.insert(rec.end(), r, r + DG_WORDS);
+    };
+    for (int SI = 0; SI < ns; ++SI)
+        for (int SJ = SI; SJ < ns; ++SJ) {
+            const int r0 = 4 * SI, r1 = std::min(nb, r0 + 4), c0 = 4 * SJ, c1 = std::min(nb, c0 + 4);
+            if (SI == SJ) {
+                std::vector<int> slots; std::vector<std::pair<int, int>> tasks;
+                for (int i = r0; i < r1; ++i) slots.push_back(i);
+                for (int i = r0; i < r1; ++i) for (int j = i; j < r1; ++j) tasks.push_back({ i - r0, j - r0 });
+                emit(slots, tasks);
+            } else {
+                for (int h = c0; h < c1; h += 2) {
+                    std::vector<int> slots; std::vector<std::pair<int, int>> tasks;
+                    for (int i = r0; i < r1; ++i) slots.push_back(i);
+                    const int nr = r1 - r0;
+                    for (int j = h; j < std::min(c1, h + 2); ++j) slots.push_back(j);
+                    for (int i = r0; i < r1; ++i) for (int j = h; j < std::min(c1, h + 2); ++j) tasks.push_back({ i - r0, nr + j - h });
+                    emit(slots, tasks);
+                }
+            }
+        }
+    tile_off.push_back((int)tiles64.size());
+}
+
+// nrb < 0: the row count is read on the device (stats[4]); nrb_max bounds the grid and the LDS.  rows: the real row count when nrb >= 0.
+int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows)
 {
     const int n_strips = c->ldw / 32;
     const int nH = nrb_max > 2 ? nrb_max - 2 : 0;
     const size_t lds_crit = sizeof(CritSmem), lds_row = sizeof(RowSmem);
     const size_t lds_strip = (size_t)(nrb_max > 1 ? nrb_max - 1 : 1) * CP_WGRAN * 16 + (size_t)CP_WGRAN * 16;     // (one panel: Yw2 takes the place of a plane slot)
-    const size_t lds = std::max(lds_crit, std::max(lds_row, lds_strip));
-    static bool attr_set = false;
-    if (!attr_set) {
+    size_t lds = std::max(lds_crit, std::max(lds_row, lds_strip));
+    // Down-date consumers (P -= W_J' W_J behind the strips, update.m:37): as many groups as there are CUs left.  Every workgroup of the launch
+    // declares the same LDS (more than half a CU's), so there is one per CU, and the grid never exceeds the CU count: all of them are resident
+    // together whatever the dispatch order -- a consumer can never hold the CU a strip, a row or crit is waiting for.
+    static const int ov_env = getenv("PRE3_K9_OVERLAP") ? atoi(getenv("PRE3_K9_OVERLAP")) : 1;
+    int n_dd = 0;
+    // (with the consumers a launch fills the chip: it must be the only such launch in flight -- one live fp32 context on the device; with two,
+    //  the launches run without consumers, 2 x 110 workgroups side by side as before)
+    static const int form = getenv("PRE3_CHOL_FORM") ? atoi(getenv("PRE3_CHOL_FORM")) : 1;
+    const bool alone = form == 2 || !(c->device >= 0 && c->device < 64) || g_cholp_live[c->device].load() <= 1;
+    if (ov_env && alone && c->k9_overlap && c->dd_groups != nullptr && c->dd_n_groups > 0) {
+        n_dd = std::min(c->dd_n_groups, c->num_cus - (1 + nH + n_strips));
+        if (n_dd < 0 || std::max(1 + nH + n_strips + n_dd, 8 * nH + 1) > c->num_cus) n_dd = 0;
+    }
+    if (n_dd > 0) lds = std::max(lds, (size_t)4 * DG_SLOTS * DG_SLOT_GRAN * 16);
+    static std::atomic<unsigned long long> attr_set{ 0 };        // one bit per device
+    if (c->device >= 0 && c->device < 64 && !((attr_set.load() >> c->device) & 1ull)) {
         PRE3_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cholp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set.fetch_or(1ull << c->device);
     }
     PRE3_CHECK(lds <= 160 * 1024, PRE3_E_ARG, "launch_cholp: %d panels do not fit the strips' LDS", nrb_max);
+    // flag words are never cleared within an epoch range: values are epoch + step, compared as signed differences.  Long before a word that has
+    // not been written for 2^31 / 64 launches could read as "reached", the block is cleared and the epoch restarts.
+    if (c->cholp_epoch >= (1u << 28)) {
+        PRE3_HIP(hipMemsetAsync(c->cholp_flags, 0, cholp_flag_bytes(n_strips), c->stream));
+        c->cholp_epoch = 0;
+    }
     c->cholp_epoch += 64;
     CpArgs a{};
     a.S = (float *)c->Smat; a.W = (float *)c->W; a.ldw = c->ldw; a.ld = c->ld;
     a.Sp = c->Sp; a.sp_stride = c->rcap / NB; a.Tp = c->cholp_tp; a.Wp = c->Wp; a.nst_total = c->rcap / B3_BK;
     a.cf = c->cholp_flags; a.base = c->cholp_epoch; a.status = c->stats + 6;
     a.n_dev = nrb < 0 ? c->stats + 4 : nullptr; a.nrb = nrb < 0 ? nrb_max : nrb; a.nrb_max = nrb_max; a.n_strips = n_strips;
-    hipLaunchKernelGGL(k_cholp, dim3(std::max(1 + nH + n_strips, 8 * nH + 1)), dim3(CP_NTH), lds, c->stream, a);
+    a.P = (float *)c->P; a.dd = c->dd_groups; a.n_dd = n_dd; a.rows = nrb < 0 ? nrb_max * NB : (rows > 0 && rows <= nrb * NB ? rows : nrb * NB);
+    hipLaunchKernelGGL(k_cholp, dim3(std::max(1 + nH + n_strips + n_dd, 8 * nH + 1)), dim3(CP_NTH), lds, c->stream, a);
     PRE3_HIP(hipGetLastError());
     c->split_rows = (nrb < 0 ? nrb_max : nrb) * NB;             // the strips' epilogues have written every plane k_downdate_b3 reads
+    c->dd_done = n_dd;                                          // the next launch_downdate only covers the groups behind these
     return PRE3_OK;
 }
 
 #ifdef PRE3_PROBE
 extern "C" __attribute__((visibility("default"))) int pre3_debug_cholp(unsigned long long *out)
 {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cp), sizeof(unsigned long long) * 20 * 16 * 8) == hipSuccess ? 0 : -3;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cp), sizeof(unsigned long long) * 24 * 16 * 8) == hipSuccess ? 0 : -3;
 }
 #endif
 

@@ -154,6 +154,10 @@ struct pre3_ctx {
     unsigned int *cholp_flags = nullptr; void *cholp_tp = nullptr; unsigned int cholp_epoch = 0; bool chol_persist = true;
     bool cholp_counted = false;                   // this context is in pre3_cholp.hip's per-device count
     bool cholp_done = false;                      // the speculative launch of an LI update has already factored and solved
+    // down-date consumers inside the persistent factorisation (pre3_cholp.hip): group records, all tiles in group order, first tile per group
+    int32_t *dd_groups = nullptr; int dd_n_groups = 0; void *dd_tiles = nullptr; std::vector<int> dd_tile_off;
+    bool k9_overlap = true;                       // PRE3_OPT_K9_OVERLAP
+    int dd_done = 0;                              // groups the last k_cholp launch has down-dated (consumed by the next launch_downdate)
     bool hp_all_valid = false;                    // HP / G hold H*P, H*P*H' of ALL measured rows at the current prior (ransac_prepare)
 };
 

@@ -1378,14 +1378,14 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad, bool first_done = false, bo
     c->split_rows = 0;
     if (first_done && c->cholp_done) {             // pre3_update_li's speculative launch was the persistent form: everything is done
         c->cholp_done = false;
-        c->split_rows = nrb * NB;
+        c->split_rows = nrb * NB;                  // (c->dd_done: the groups its consumers have down-dated already)
         return PRE3_OK;
     }
-    c->cholp_done = false;
+    c->cholp_done = false; c->dd_done = 0;
     // (one panel is one launch in either form, and the lock-step form has no hand-off in it: 12.5 us against 17 -- taken for the rescue
     // stage's small updates; an update of the PREDICTED state keeps the persistent form at any size, because pre3_update_li's speculative
     // launch -- row count still on the device -- cannot choose, and the two ways into that update must compute the same thing)
-    if (!first_done && (nrb >= 2 || predicted_prior) && cholp_usable(c, nrb)) return launch_cholp(c, nrb, nrb);
+    if (!first_done && (nrb >= 2 || predicted_prior) && cholp_usable(c, nrb)) return launch_cholp(c, nrb, nrb, r);
     {
         const bool split = c->k9_b3 && c->dtype == PRE3_F32 && c->Wp != nullptr;
         static const int pro_env = getenv("PRE3_CHOL_PRO_B3") ? atoi(getenv("PRE3_CHOL_PRO_B3")) : 1;
@@ -1469,16 +1469,28 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
             dim3 gs(c->ld / B3_T, nst - st0);
             hipLaunchKernelGGL(k_split_w, gs, b, 0, c->stream, (const float *)W, c->ldw, (bf16x8_t *)c->Wp, nst_total, st0);
         }
-        XUpd xu{ c->n_tiles128, c->n, r, which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1, c->x_kk, c->pred_params };
+        // the persistent factorisation's consumers have down-dated the tiles of groups [0, dd_done) already (pre3_cholp.hip): what is left
+        // -- nothing at N = 500 -- goes out as 64 x 64 tiles; the x-update and the rescue's projection ride in this launch either way
+        const int2 *tiles = (const int2 *)c->tiles128;
+        int n_tiles_launch = c->n_tiles128;
+        if (c->dd_done > 0) {
+            const int t0 = c->dd_tile_off[c->dd_done];
+            tiles = (const int2 *)c->dd_tiles + t0;
+            n_tiles_launch = c->dd_tile_off.back() - t0;
+        }
+        c->dd_done = 0;
+        XUpd xu{ n_tiles_launch, c->n, r, which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1, c->x_kk, c->pred_params };
         const int nx = which_prior >= 0 ? ceil_div(c->n, 64) : 0;
         ProjRide pr{};
         if (nx > 0 && c->ride_rescue_projection && c->N > 0) {
             pr = make_proj_ride(c, PRE3_X_K_K, 0, 1, nx);
             c->ride_rescue_projection = false; c->rescue_projected = true;
         }
-        dim3 g1(c->n_tiles128 + nx + pr.n_blocks);
-        hipLaunchKernelGGL(k_downdate_b3, g1, b, 0, c->stream, (float *)c->P, c->ld, (const bf16x8_t *)c->Wp, nst_total, nst, (const float *)W, c->ldw,
-                           (const int2 *)c->tiles128, xu, pr);
+        dim3 g1(n_tiles_launch + nx + pr.n_blocks);
+        if (g1.x > 0) {
+            hipLaunchKernelGGL(k_downdate_b3, g1, b, 0, c->stream, (float *)c->P, c->ld, (const bf16x8_t *)c->Wp, nst_total, nst, (const float *)W, c->ldw,
+                               tiles, xu, pr);
+        }
     } else if (one_tile) {
         XUpd xu{ c->n_tiles, c->n, r, which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1, c->x_kk, c->pred_params };
         const int nx = which_prior >= 0 ? ceil_div(c->n, 64) : 0;
@@ -1583,6 +1595,7 @@ int launch_chol_first_spec(pre3_ctx *c, int nsel_max)
 int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_dev, bool prebuilt, bool first_done, bool hp_built)
 {
     if (r == 0) {   // update.m:50-55: x_k_k = x_km1_k, p_k_k = p_km1_k
+        c->dd_done = 0; c->cholp_done = false;      // (a speculative persistent launch found no rows on the device either)
         if (which_prior == PRE3_X_K_KM1) PRE3_HIP(hipMemcpyAsync(c->x_kk, c->x_km1, sizeof(double) * c->n, hipMemcpyDeviceToDevice, c->stream));
         return PRE3_OK;
     }

@@ -118,6 +118,16 @@ class EkfFilter:
         check(lib.pre3_get_option(self._ctx, 3, C.byref(v)))
         return bool(v.value)
 
+    def k9_overlap(self, on=None):
+        """PRE3_OPT_K9_OVERLAP (fp32 contexts with the persistent factorisation): update.m:37's P - K*S*K' = P - sum_J W_J'W_J accumulated panel by
+        panel inside the factorisation's launch, on the CUs it leaves idle (default); off: the down-date starts when the factorisation has
+        finished.  Bit-identical results.  Returns the setting in force."""
+        if on is not None:
+            check(lib.pre3_set_option(self._ctx, 5, int(bool(on))))
+        v = C.c_int(0)
+        check(lib.pre3_get_option(self._ctx, 5, C.byref(v)))
+        return bool(v.value)
+
     # ---- map management between steps (map_management.m:27-79); the policy stays with the caller
     def _refresh_map(self):
         self.N = int(lib.pre3_get_map(self._ctx, None))

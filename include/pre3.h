@@ -199,6 +199,11 @@ PRE3_API int pre3_update_ell(int device, int dtype, int n, int r, const double *
  * GEMM ranks + exact re-evaluation; N * K2 >= 65536 and every descriptor inside the route's bounds), 0 if it took the exact VALU kernel.
  * The environment's PRE3_IC_RANK=0 forces the latter.  Results are bit-identical either way. */
 #define PRE3_OPT_IC_RANKED 4
+/* PRE3_OPT_K9_OVERLAP (fp32 contexts with PRE3_OPT_CHOL_PERSIST; default 1, or the environment's PRE3_K9_OVERLAP): update.m:37's
+ * P - K*S*K' = P - sum_J W_J'W_J is accumulated panel by panel INSIDE the persistent factorisation's launch, by workgroups on the CUs that
+ * launch leaves idle (as many tile groups as there are CUs left; the rest, if any, in the launch that follows).  0: the down-date only
+ * starts when the factorisation has finished.  Results are bit-identical either way. */
+#define PRE3_OPT_K9_OVERLAP 5
 PRE3_API int pre3_set_option(pre3_ctx *ctx, int option, int value);
 PRE3_API int pre3_get_option(pre3_ctx *ctx, int option, int *value_out);
 

@@ -203,3 +203,29 @@ def test_not_positive_definite_is_reported_by_a_one_panel_update(pre3):
             f.get_p_k_k()
         assert e.value.code == -5
         f.close()
+
+
+@pytest.mark.parametrize("N,n_hyp,steps", [(30, 16, 3), (120, 60, 4), (500, 200, 4), (560, 100, 2)])
+def test_downdate_consumers_inside_the_factorisation_are_bit_identical(pre3, N, n_hyp, steps):
+    """update.m:37 accumulated panel by panel by consumer workgroups of k_cholp (PRE3_OPT_K9_OVERLAP, default) against the down-date as a
+    launch of its own behind the factorisation: the same six bf16 products per k-stage in the same order, so x, P and the flags must agree
+    bit for bit -- LI updates of 1 .. 10 panels, HI updates, deferred and not.  N = 560: more tile groups than idle CUs, the rest of the
+    tiles goes through k_downdate_b3."""
+    seq = synth.make_sequence(N, steps, n_hyp, seed=31 + N)
+    res = []
+    for on in (False, True):              # one filter at a time: with two fp32 contexts alive on the device the launches carry no consumers
+        f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", max_hyp=n_hyp, std_z=1.0)
+        f.k9_overlap(on)
+        assert f.k9_overlap() == on and f.chol_persist()
+        f.set_x_p_k_k(seq["x0"], seq["P0"])
+        f.defer_hi_update(bool(N % 2 == 0))
+        sts = [f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=1.0 if t % 2 == 0 else 0.5, early_exit=False) for t, s in enumerate(seq["steps"])]
+        li, hi = f.get_flags()
+        res.append((sts, li, hi, f.get_x_k_k(), f.get_p_k_k()))
+        f.close()
+    (st0, li0, hi0, x0, P0), (st1, li1, hi1, x1, P1) = res
+    assert st0 == st1, (st0, st1)
+    assert np.array_equal(li0, li1) and np.array_equal(hi0, hi1)
+    assert np.array_equal(x0, x1)
+    assert np.array_equal(P0, P1), np.abs(P0 - P1).max()
+    assert np.isfinite(P1).all() and np.abs(P1).max() > 0
