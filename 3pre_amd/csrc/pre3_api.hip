@@ -882,7 +882,7 @@ int pre3_update_li(pre3_ctx *c)
             static const int spec_env = getenv("PRE3_CHOL_SPEC0") ? atoi(getenv("PRE3_CHOL_SPEC0")) : 1;
             if (spec_env && round_up(2 * c->m, NB) <= c->rcap) {
                 // fp32: the whole factorisation + solve is ONE launch that reads the row count on the device (pre3_cholp.hip)
-                if (cholp_usable(c, round_up(2 * c->m, NB) / NB)) { PRE3_TRY(launch_cholp(c, -1, round_up(2 * c->m, NB) / NB)); c->cholp_done = true; }
+                if (cholp_usable(c, round_up(2 * c->m, NB) / NB)) { PRE3_TRY(launch_cholp(c, -1, round_up(2 * c->m, NB) / NB, -1, PRE3_X_K_KM1)); c->cholp_done = true; }
                 else PRE3_TRY(launch_chol_first_spec(c, c->m));
                 first_done = true;
             }

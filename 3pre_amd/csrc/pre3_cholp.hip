@@ -148,6 +148,8 @@ __device__ __forceinline__ void frags_plain(const frag_t *blk, int half, int lan
 __device__ __forceinline__ unsigned acc_voff(int lane, int ldm) { return (unsigned)((4 * (lane >> 5)) * ldm + (lane & 31)) * 4u; }
 __device__ __forceinline__ unsigned acc_soff(int e, int ldm) { return (unsigned)(((e & 3) + 8 * (e >> 2)) * ldm) * 4u; }
 __device__ __forceinline__ float ld_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); }
+__device__ __forceinline__ void st_f32_sc1(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 16); }
+__device__ __forceinline__ float ld_f32_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 16)); }
 __device__ __forceinline__ void st_f32(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0); }
 
 constexpr int CP_YS = NB + 1;                       // row stride of the f32 transposition buffers
@@ -176,7 +178,8 @@ struct CpArgs {
     unsigned *cf; unsigned base;         // flags, epoch
     int32_t *status;                     // stats[6] (not positive definite), stats[7] (a wait gave up)
     const int32_t *n_dev; int nrb; int nrb_max; int n_strips;
-    float *P; const int32_t *dd; int n_dd; int rows;      // down-date consumers: group table (DG_WORDS each), groups in this launch, rows if host-known
+    int n; const double *x_prior; double *x_out; double *params; int xu;      // xu: the strips finish with x_out = x_prior + W'(L^-1 nu) (update.m:36,42,48)
+    float *P; const int32_t *dd; int n_dd; int rows; int dd_mode;      // down-date consumers: group table (DG_WORDS each), groups in this launch, rows if host-known
 };
 // A call passes its arguments in VGPRs: the callee makes the (wave-uniform) launch arguments scalar again, word by word
 __device__ __forceinline__ CpArgs cp_uniform(const CpArgs &v)
@@ -680,11 +683,11 @@ __device__ __attribute__((noinline)) void row_body(CpArgs a_v, int nrb_v, int i_
 // ------------------------------------------------------------------------------------------------------------------------------
 // strip s: 32 columns of [HP | nu]
 // ------------------------------------------------------------------------------------------------------------------------------
-constexpr int DG_SLOTS = 6, DG_TASKS = 12, DG_WORDS = 16, DG_SLOT_GRAN = 3 * 2 * 64;     // down-date consumers (dd_body)
+constexpr int DG_SLOTS = 6, DG_KMAX = 12, DG_WORDS = 16, DG_SLOT_GRAN = 3 * 2 * 64;     // down-date consumers (dd_body)
 constexpr int CP_WS = 32 + 1;                        // row stride of the strip's f32 transposition buffer
 constexpr int CP_WGRAN = 4 * 3 * 64;                 // granules of one 64 x 32 block of W as B-operand planes: [q 4][plane 3][lane 64]
 
-__device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int s_v)
+__device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int rows_v, int s_v)
 {
     const CpArgs a = cp_uniform(a_v);
     const int nrb = __builtin_amdgcn_readfirstlane(nrb_v), s = __builtin_amdgcn_readfirstlane(s_v);
@@ -699,6 +702,7 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int fa = wave & 1, par = wave >> 1;
     const int c0 = s * 32, lcol = lane & 31;
+    const bool nu_strip = c0 == a.ld, publish = a.n_dd > 0 || a.xu != 0;
     int32_t *guard = a.status + 1;
     const __amdgpu_buffer_rsrc_t rW = cp_rsrc(a.W), rSp = cp_rsrc(a.Sp), rWp = cp_rsrc(a.Wp);
     const unsigned wvoff = acc_voff(lane, a.ldw) + (unsigned)((32 * fa) * a.ldw + c0) * 4u;
@@ -756,7 +760,7 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
                 // the down-date consumers of THIS launch read the panel as soon as the strip's flag is up.
                 const unsigned gb = (unsigned)((((size_t)(c0 >> 7) * a.nst_total + 4 * J + q) * B3_GRAN + ((c0 >> 5) & 3) * 64 + l) * 16u);
                 st16_sc1(p0, rWp, gb); st16_sc1(p1, rWp, gb + 256 * 16); st16_sc1(p2, rWp, gb + 512 * 16);
-                if (a.n_dd > 0) drain_stores();
+                if (publish) drain_stores();
             }
         }
     };
@@ -845,14 +849,16 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 yrow[acc_row(e, lane) * CP_WS] = wacc[e];
-                st_f32(wacc[e], rW, wvoff, (unsigned)(J * NB * a.ldw) * 4u + acc_soff(e, a.ldw));
+                // (the strip that owns column ld = L^-1 nu writes through: every strip reads that column for its x-update)
+                if (nu_strip) st_f32_sc1(wacc[e], rW, wvoff, (unsigned)(J * NB * a.ldw) * 4u + acc_soff(e, a.ldw));
+                else st_f32(wacc[e], rW, wvoff, (unsigned)(J * NB * a.ldw) * 4u + acc_soff(e, a.ldw));
             }
         }
         __syncthreads();
         tile_to_planes(J, more, c0 < a.ld + NB);
         __syncthreads();
         // W_J's planes of these 32 columns are out (every storing thread has drained): the consumers' flag
-        if (tid == 0 && a.n_dd > 0) cf_store(cf_strip(a.cf, s), a.base + (unsigned)J + 1);
+        if (tid == 0 && publish) cf_store(cf_strip(a.cf, s), a.base + (unsigned)J + 1);
         if (tid == 0 && (s == 0 || s == a.n_strips - 1)) CP_STAMP(s == 0 ? 16 : 17, J, 2);
         // (4) the newest term of step J+1: L(J+1, J) W_J, one k-step per wave; L(J+1, J) is published about now (sc1 loads)
         if (more) {
@@ -876,6 +882,40 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
     }
 #undef ST_MMA
 #undef SM_MMA
+    // ---- update.m:36,42,48 for this strip's 32 states: x_out = x_prior + W'(L^-1 nu), the normalisation Jacobian at the un-normalised quaternion
+    //      -> params, the quaternion normalised.  Sixteen chains (chain g: rows a = g mod 16, in order), summed 0 .. 15, x_prior last -- term for
+    //      term the sums of update_x_block / k_update_x, so x_k_k is the same bits whichever of them ran.  W is this strip's own (its stores have
+    //      drained); c = L^-1 nu is the nu strip's column, written through and read here behind that strip's last flag.
+    if (a.xu && c0 < a.ld) {
+        const int rows = __builtin_amdgcn_readfirstlane(rows_v);
+        float *cs = reinterpret_cast<float *>(cp_smem);                              // [nrb * 64]
+        double *red = reinterpret_cast<double *>(cp_smem + 4096);                    // [16][32]
+        double *qs = red + 16 * 32;
+        __syncthreads();                                                             // (the plane slots are dead)
+        wg_wait(cf_strip(a.cf, a.ld / 32), a.base + (unsigned)nrb, guard);
+        for (int k = tid; k < rows; k += 512) cs[k] = ld_f32_sc1(rW, (unsigned)(k * a.ldw + a.ld) * 4u, 0);
+        __syncthreads();
+        const int ci = tid & 31, rg = tid >> 5, i = c0 + ci;
+        const float *Wc = a.W + i;
+        double sx = 0;
+#pragma unroll 8
+        for (int k = rg; k < rows; k += 16) sx = fma((double)Wc[(size_t)k * a.ldw], (double)cs[k], sx);
+        red[rg * 32 + ci] = sx;
+        __syncthreads();
+        sx = 0;
+        if (rg == 0) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) sx += red[g * 32 + ci];
+            if (i < a.n) sx += a.x_prior[i];
+        }
+        if (s == 0) {                                                                // (strip-uniform: every thread reaches the barrier)
+            if (rg == 0 && i >= 3 && i < 7) qs[i - 3] = sx;
+            __syncthreads();
+            if (rg == 0 && i == 0) { double Jn[16]; d_normjac(qs, Jn); for (int t = 0; t < 16; ++t) { a.params[16 + t] = Jn[t]; a.params[96 + t] = Jn[t]; } }
+            if (rg == 0 && i >= 3 && i < 7) sx = sx / sqrt(qs[0] * qs[0] + qs[1] * qs[1] + qs[2] * qs[2] + qs[3] * qs[3]);
+        }
+        if (rg == 0 && i < a.n) a.x_out[i] = sx;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -903,16 +943,32 @@ __device__ __attribute__((noinline)) void dd_body(CpArgs a_v, int nrb_v, int row
     extern __shared__ __attribute__((aligned(16))) unsigned char cp_smem[];
     frag_t *ops = reinterpret_cast<frag_t *>(cp_smem);
     const int32_t *rec = a.dd + (size_t)g * DG_WORDS;
-    const int hdr = rec[0], ntasks = hdr & 0xff, nslots = (hdr >> 8) & 0xff;
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    // (everything read from the record is made scalar explicitly: left to itself the compiler kept the slot table in vector registers and
+    //  put a load + s_waitcnt vmcnt(0) between two LDS-DMA instructions -- 9.9 us per panel instead of 3)
+    auto U = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    const int hdr = U(rec[0]), ntasks = hdr & 0xff, nslots = (hdr >> 8) & 0xff;
+    const int tid = threadIdx.x, wave = U(tid >> 6), lane = tid & 63;
     if (wave >= ntasks) return;                                  // (an ended wave is not waited for by the barriers below)
-    const int tb = (rec[7 + (wave >> 2)] >> (8 * (wave & 3))) & 0xff, sa = tb & 15, sb = tb >> 4;
-    const int bi = rec[1 + sa], bj = rec[1 + sb];
+    const int tb = (U(rec[7 + (wave >> 2)]) >> (8 * (wave & 3))) & 0xff, sa = tb & 15, sb = tb >> 4;
+    const int bi = U(rec[1 + sa]), bj = U(rec[1 + sb]);
     const bool diag = bi == bj;
     int32_t *guard = a.status + 1;
     const int nst_real = (rows + B3_BK - 1) / B3_BK;              // k-stages that hold real rows (the rest of the last panel is zero padding)
-    // this wave's share of a stage's LDS-DMA instructions: idx = wave, wave + ntasks, .. < 6 nslots; idx -> (slot, plane, fragment)
-    const int n_inst = 6 * nslots, c_w = (n_inst - wave + ntasks - 1) / ntasks;
+    // This wave's share of a stage's LDS-DMA instructions: idx = wave, wave + ntasks, .. < 6 nslots; idx -> (slot, plane, fragment).  The
+    // descriptors (source / LDS offsets in granules) are worked out once and live in scalar registers: the issue loop has no load in it.
+    const int n_inst = 6 * nslots, c_w = U((n_inst - wave + ntasks - 1) / ntasks);
+    unsigned src_off[DG_KMAX]; int lds_off[DG_KMAX];
+#pragma unroll
+    for (int k = 0; k < DG_KMAX; ++k) {
+        const int idx = wave + k * ntasks, idc = idx < n_inst ? idx : 0;
+        const int slot = U(idc / 6), pf = idc - 6 * slot, pl = pf >> 1, f = pf & 1;
+        const int blk = U(rec[1 + slot]);
+        src_off[k] = (unsigned)U((blk >> 1) * a.nst_total * B3_GRAN + pl * 256 + (2 * (blk & 1) + f) * 64);
+        lds_off[k] = U(slot * DG_SLOT_GRAN + (2 * pl + f) * 64);
+    }
+    // wave 0, lane l < 2 nslots: the flag of strip 2 blk + (l & 1) of slot l >> 1
+    const unsigned *fp = a.cf;
+    if (wave == 0) fp = cf_strip(a.cf, 2 * rec[1 + ((lane < 2 * nslots ? lane : 0) >> 1)] + (lane & 1));
     f32x16_t acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -928,8 +984,6 @@ __device__ __attribute__((noinline)) void dd_body(CpArgs a_v, int nrb_v, int row
         // the strips that own the group's column blocks (two per 64-column block) have published W_J
         if (wave == 0) {
             const int nfl = 2 * nslots;
-            const int blk = rec[1 + ((lane < nfl ? lane : 0) >> 1)];
-            const unsigned *fp = cf_strip(a.cf, 2 * blk + (lane & 1));
             bool gave_up = true;
             for (int spin = 0; spin < SPIN_LIMIT; ++spin) {
                 const bool ok = lane >= nfl || cf_reached(cf_load(fp), a.base + (unsigned)J + 1);
@@ -938,17 +992,27 @@ __device__ __attribute__((noinline)) void dd_body(CpArgs a_v, int nrb_v, int row
                 __builtin_amdgcn_s_sleep(4);
             }
             if (gave_up && lane == 0) atomicExch(guard, 1);
+            // ONE agent-scope acquire for the workgroup, its invalidate complete before anybody loads: the panel then comes in by PLAIN LDS-DMA
+            // loads, served by the XCD's L2 (every block of W_J is wanted by some twenty groups).  With sc1 loads instead every group fetched
+            // its 144 KB from the fabric: 9.9 us per panel instead of 3 (measured, tools/probe_cholp.py).
+            if (a.dd_mode & 2) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                      // (this wave's reads of the previous panel are in registers)
         __builtin_amdgcn_s_barrier();
         if (tid == 0 && (g == 0 || g == a.n_dd - 1)) CP_STAMP(g == 0 ? 20 : 21, J, 0);
-        for (int st = 0; st < ns; ++st)
-            for (int idx = wave; idx < n_inst; idx += ntasks) {
-                const int slot = idx / 6, pf = idx - 6 * slot, pl = pf >> 1, f = pf & 1;
-                const int blk = rec[1 + slot];
-                const frag_t *src = Wp + ((size_t)(blk >> 1) * a.nst_total + 4 * J + st) * B3_GRAN + pl * 256 + (2 * (blk & 1) + f) * 64 + lane;
-                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(ops + (st * DG_SLOTS + slot) * DG_SLOT_GRAN + (2 * pl + f) * 64), 16, 0, 16);
-            }
+        for (int st = 0; st < ns; ++st) {
+            const frag_t *src = Wp + (size_t)(4 * J + st) * B3_GRAN + lane;
+            frag_t *dst = ops + st * (DG_SLOTS * DG_SLOT_GRAN);
+#pragma unroll
+            for (int k = 0; k < DG_KMAX; ++k)
+                if (k < c_w) {
+                    if (a.dd_mode & 1) __builtin_amdgcn_global_load_lds(src + src_off[k], (__attribute__((address_space(3))) void *)(dst + lds_off[k]), 16, 0, 16);
+                    else __builtin_amdgcn_global_load_lds(src + src_off[k], (__attribute__((address_space(3))) void *)(dst + lds_off[k]), 16, 0, 0);
+                }
+        }
         for (int st = 0; st < ns; ++st) {
             dd_vmwait_le(c_w * (ns - 1 - st));
             __builtin_amdgcn_s_barrier();                        // every wave's share of stage st has landed
@@ -961,7 +1025,7 @@ __device__ __attribute__((noinline)) void dd_body(CpArgs a_v, int nrb_v, int row
 #define DD_MMA(pa, pb) \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j) \
-                    if (!(diag && i > j)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, A[pa][i]), __builtin_bit_cast(bf16x8_t, B[pb][j]), acc[i][j], 0, 0, 0)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, A[pa][i]), __builtin_bit_cast(bf16x8_t, B[pb][j]), acc[i][j], 0, 0, 0)
             // (the six products of k_downdate_b3, in its order)
             DD_MMA(0, 0); DD_MMA(0, 1); DD_MMA(1, 0); DD_MMA(1, 1); DD_MMA(0, 2); DD_MMA(2, 0);
 #undef DD_MMA
@@ -1059,7 +1123,7 @@ __global__ __launch_bounds__(CP_NTH) void k_cholp(CpArgs a)
     const int sidx = b - ((b >> 3) < nH ? (b >> 3) + 1 : nH + 1);
     if (sidx < a.n_strips) {
         if (threadIdx.x >= 512) return;                         // strips are eight waves
-        if (CP_TEST_ROLE & 4) strip_body(a, nrb, sidx);
+        if (CP_TEST_ROLE & 4) strip_body(a, nrb, rows, sidx);
     } else if (sidx - a.n_strips < a.n_dd) {
         if (CP_TEST_ROLE & 8) dd_body(a, nrb, rows, sidx - a.n_strips);
     }
@@ -1133,7 +1197,7 @@ void dd_build_groups(int nb, std::vector<int32_t> &rec, std::vector<int2> &tiles
 }
 
 // nrb < 0: the row count is read on the device (stats[4]); nrb_max bounds the grid and the LDS.  rows: the real row count when nrb >= 0.
-int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows)
+int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior)
 {
     const int n_strips = c->ldw / 32;
     const int nH = nrb_max > 2 ? nrb_max - 2 : 0;
@@ -1172,10 +1236,18 @@ int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows)
     a.Sp = c->Sp; a.sp_stride = c->rcap / NB; a.Tp = c->cholp_tp; a.Wp = c->Wp; a.nst_total = c->rcap / B3_BK;
     a.cf = c->cholp_flags; a.base = c->cholp_epoch; a.status = c->stats + 6;
     a.n_dev = nrb < 0 ? c->stats + 4 : nullptr; a.nrb = nrb < 0 ? nrb_max : nrb; a.nrb_max = nrb_max; a.n_strips = n_strips;
+    static const int dd_mode = getenv("PRE3_DD_MODE") ? atoi(getenv("PRE3_DD_MODE")) : 1;
+    a.dd_mode = dd_mode;
+    // with the consumers in the launch the strips also finish the state: x_k_k = x_prior + W'(L^-1 nu) (the K9 launch that used to carry the
+    // x-update as riders has nothing left to do at N = 500)
+    static const int xu_env = getenv("PRE3_CHOLP_XU") ? atoi(getenv("PRE3_CHOLP_XU")) : 1;
+    a.xu = (xu_env && n_dd > 0 && which_prior >= 0) ? 1 : 0;
+    a.n = c->n; a.x_prior = which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1; a.x_out = c->x_kk; a.params = c->pred_params;
     a.P = (float *)c->P; a.dd = c->dd_groups; a.n_dd = n_dd; a.rows = nrb < 0 ? nrb_max * NB : (rows > 0 && rows <= nrb * NB ? rows : nrb * NB);
     hipLaunchKernelGGL(k_cholp, dim3(std::max(1 + nH + n_strips + n_dd, 8 * nH + 1)), dim3(CP_NTH), lds, c->stream, a);
     PRE3_HIP(hipGetLastError());
     c->split_rows = (nrb < 0 ? nrb_max : nrb) * NB;             // the strips' epilogues have written every plane k_downdate_b3 reads
+    c->x_done = a.xu != 0;
     c->dd_done = n_dd;                                          // the next launch_downdate only covers the groups behind these
     return PRE3_OK;
 }

@@ -182,8 +182,11 @@ __global__ __launch_bounds__(256) void k_predict(const double *__restrict__ x_in
 
 // rows/cols 3..6 <- Jn (update.m:42-46).  params[16..31] = Jn.
 template <typename T>
-__global__ void k_jnorm_P(T *__restrict__ P, int n, int ld, const double *__restrict__ params)
+__global__ void k_jnorm_P(T *__restrict__ P, int n, int ld, const double *__restrict__ params, int n_jn_blocks, ProjRide pr)
 {
+    // the rescue's projection at x_k_k (rescue_hi_inliers.m:31-32) rides along when the update's x came out of the launch in front
+    // (persistent factorisation with its own x-update): it needs nothing of this launch
+    if ((int)blockIdx.x >= n_jn_blocks) { proj_ride_block(pr, blockIdx.x - n_jn_blocks); return; }
     __shared__ double sJn[16];
     __shared__ double corner[16];
     if (threadIdx.x < 16) sJn[threadIdx.x] = params[16 + threadIdx.x];
@@ -722,7 +725,7 @@ __global__ __launch_bounds__(1024) void k_update_x(int n, int r, const T *__rest
     const int i = blockIdx.x * 64 + ci;            // i < ldw always (ldw >= ld + 64 > n rounded up)
     double s = 0;
 #pragma unroll 8
-    for (int a = rg; a < r; a += 16) s += (double)W[(size_t)a * ldw + i] * (double)W[(size_t)a * ldw + ld];
+    for (int a = rg; a < r; a += 16) s = fma((double)W[(size_t)a * ldw + i], (double)W[(size_t)a * ldw + ld], s);      // (chain g = rows g mod 16: update_x_block's order)
     red[rg][ci] = s;
     __syncthreads();
     if (rg == 0) {
@@ -781,9 +784,15 @@ int launch_predict_impl(pre3_ctx *c, const double u[7], bool with_projection, si
 int launch_jnorm(pre3_ctx *c, int)
 {
     int blocks = ceil_div(c->n, 256);
+    ProjRide pr{};
+    if (c->proj_with_jnorm && c->N > 0) {        // (no producer to wait for: x_k_k is complete)
+        pr = make_proj_ride(c, PRE3_X_K_K, 0, 1, 0);
+        c->rescue_projected = true;
+    }
+    c->proj_with_jnorm = false;
     DISPATCH_T(c,
-        hipLaunchKernelGGL(k_jnorm_P<double>, dim3(blocks), dim3(256), 0, c->stream, (double *)c->P, c->n, c->ld, c->pred_params),
-        hipLaunchKernelGGL(k_jnorm_P<float>, dim3(blocks), dim3(256), 0, c->stream, (float *)c->P, c->n, c->ld, c->pred_params));
+        hipLaunchKernelGGL(k_jnorm_P<double>, dim3(blocks + pr.n_blocks), dim3(256), 0, c->stream, (double *)c->P, c->n, c->ld, c->pred_params, blocks, pr),
+        hipLaunchKernelGGL(k_jnorm_P<float>, dim3(blocks + pr.n_blocks), dim3(256), 0, c->stream, (float *)c->P, c->n, c->ld, c->pred_params, blocks, pr));
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }

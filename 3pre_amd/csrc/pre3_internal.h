@@ -157,6 +157,8 @@ struct pre3_ctx {
     // down-date consumers inside the persistent factorisation (pre3_cholp.hip): group records, all tiles in group order, first tile per group
     int32_t *dd_groups = nullptr; int dd_n_groups = 0; void *dd_tiles = nullptr; std::vector<int> dd_tile_off;
     bool k9_overlap = true;                       // PRE3_OPT_K9_OVERLAP
+    bool x_done = false;                          // ... and its strips have computed x_k_k = x_prior + W'(L^-1 nu) as well (update.m:36,42,48)
+    bool proj_with_jnorm = false;                 // the rescue's projection rides in the next k_jnorm_P launch (no K9 launch to carry it)
     int dd_done = 0;                              // groups the last k_cholp launch has down-dated (consumed by the next launch_downdate)
     bool hp_all_valid = false;                    // HP / G hold H*P, H*P*H' of ALL measured rows at the current prior (ransac_prepare)
 };

@@ -879,19 +879,27 @@ __device__ __forceinline__ void lds_dma_stage(const T *__restrict__ W, int ldw, 
 template <typename T>
 __device__ __forceinline__ void update_x_block(int blk, int n, int r, const T *__restrict__ W, int ldw, int ld,
                                                const double *__restrict__ x_prior, double *__restrict__ x_out, double *__restrict__ params,
-                                               double *scratch /* >= 4*64+4 doubles of LDS: the tile path's staging buffer, no extra allocation */)
+                                               double *scratch /* >= 16*64+4 doubles of LDS: the tile path's staging buffer, no extra allocation */)
 {
+    // Sixteen chains, chain g summing the rows a = g (mod 16) in increasing order, then the chains in order 0 .. 15 and x_prior last: the same
+    // sums, term for term, as k_update_x (pre3_geom.hip) and as the strips of the persistent factorisation (pre3_cholp.hip, x-update at their
+    // end), so that x_k_k does not depend on which of the three computed it.  Four chains per thread here.
     double (*red)[64] = reinterpret_cast<double (*)[64]>(scratch);
-    double *q = scratch + 4 * 64;
+    double *q = scratch + 16 * 64;
     const int ci = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int i = blk * 64 + ci;                   // i < ldw always (ldw >= ld + 64 > n rounded up)
-    double s = 0;
+#pragma unroll 1
+    for (int u = 0; u < 4; ++u) {                  // chain rg + 4 u
+        double sc = 0;
 #pragma unroll 8
-    for (int a = rg; a < r; a += 4) s += (double)W[(size_t)a * ldw + i] * (double)W[(size_t)a * ldw + ld];
-    red[rg][ci] = s;
+        for (int a = rg + 4 * u; a < r; a += 16) sc = fma((double)W[(size_t)a * ldw + i], (double)W[(size_t)a * ldw + ld], sc);
+        red[rg + 4 * u][ci] = sc;
+    }
     __syncthreads();
+    double s = 0;
     if (rg == 0) {
-        s = red[0][ci] + red[1][ci] + red[2][ci] + red[3][ci];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s += red[g][ci];
         if (i < n) s += x_prior[i];
     }
     if (blk == 0) {                 // block-uniform branch: every thread of the block reaches the barrier
@@ -925,7 +933,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
     constexpr int PS = sizeof(T) == 4 ? 33 : 32;
     constexpr int SMEM = 4 * STG > 4 * 32 * PS ? 4 * STG : 4 * 32 * PS;     // staging buffers, reused by the 4 epilogue patches
     __shared__ __attribute__((aligned(16))) T smem[SMEM];                   // [A0 | A1 | B0 | B1], each [BK][64]
-    static_assert(sizeof(T) * SMEM >= sizeof(double) * (4 * 64 + 4), "the riders borrow the staging buffer");
+    static_assert(sizeof(T) * SMEM >= sizeof(double) * (16 * 64 + 4), "the riders borrow the staging buffer");
     if ((int)blockIdx.x >= xu.n_tiles) {            // riders (launch_downdate adds these workgroups)
         __builtin_amdgcn_s_setprio(3);              // short dependent chains: must not starve behind the MFMA waves sharing their SIMD
         const int nx = (xu.n + 63) / 64, rb = blockIdx.x - xu.n_tiles;
@@ -1251,7 +1259,7 @@ __global__ __launch_bounds__(256) void k_downdate_b3(float *__restrict__ P, int 
                                                       const float *__restrict__ W, int ldw, const int2 *__restrict__ tiles, XUpd xu, ProjRide pr)
 {
     __shared__ __attribute__((aligned(16))) bf16x8_t smem[B3_NBUF * 2 * B3_GRAN];       // 24 KB per ring slot: [slot][A | B][plane][fragment][lane]
-    static_assert(sizeof(smem) >= 4 * 32 * 33 * sizeof(float) && sizeof(smem) >= sizeof(double) * (4 * 64 + 4), "patches and riders borrow the ring");
+    static_assert(sizeof(smem) >= 4 * 32 * 33 * sizeof(float) && sizeof(smem) >= sizeof(double) * (16 * 64 + 4), "patches and riders borrow the ring");
     if ((int)blockIdx.x >= xu.n_tiles) {            // riders, as in k_downdate_1t
         __builtin_amdgcn_s_setprio(3);
         const int nx = (xu.n + 63) / 64, rb = blockIdx.x - xu.n_tiles;
@@ -1372,7 +1380,7 @@ int launch_ell_G_hyp(pre3_ctx *c, int k, int lo, int hi, int ldg)
     return PRE3_OK;
 }
 
-static int launch_chol_solve(pre3_ctx *c, int r_pad, bool first_done = false, bool predicted_prior = false, int r = -1 /* real rows, if known */)
+static int launch_chol_solve(pre3_ctx *c, int r_pad, bool first_done = false, bool predicted_prior = false, int r = -1 /* real rows, if known */, int which_prior = -1)
 {
     int nrb = r_pad / NB, nW = c->ldw / NB;
     c->split_rows = 0;
@@ -1381,11 +1389,11 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad, bool first_done = false, bo
         c->split_rows = nrb * NB;                  // (c->dd_done: the groups its consumers have down-dated already)
         return PRE3_OK;
     }
-    c->cholp_done = false; c->dd_done = 0;
+    c->cholp_done = false; c->dd_done = 0; c->x_done = false;
     // (one panel is one launch in either form, and the lock-step form has no hand-off in it: 12.5 us against 17 -- taken for the rescue
     // stage's small updates; an update of the PREDICTED state keeps the persistent form at any size, because pre3_update_li's speculative
     // launch -- row count still on the device -- cannot choose, and the two ways into that update must compute the same thing)
-    if (!first_done && (nrb >= 2 || predicted_prior) && cholp_usable(c, nrb)) return launch_cholp(c, nrb, nrb, r);
+    if (!first_done && (nrb >= 2 || predicted_prior) && cholp_usable(c, nrb)) return launch_cholp(c, nrb, nrb, r, which_prior);
     {
         const bool split = c->k9_b3 && c->dtype == PRE3_F32 && c->Wp != nullptr;
         static const int pro_env = getenv("PRE3_CHOL_PRO_B3") ? atoi(getenv("PRE3_CHOL_PRO_B3")) : 1;
@@ -1480,11 +1488,18 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
         }
         c->dd_done = 0;
         XUpd xu{ n_tiles_launch, c->n, r, which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1, c->x_kk, c->pred_params };
-        const int nx = which_prior >= 0 ? ceil_div(c->n, 64) : 0;
+        const bool x_done = c->x_done && which_prior >= 0;            // the factorisation's strips have computed x_k_k already
+        c->x_done = false;
+        const int nx = (which_prior >= 0 && !x_done) ? ceil_div(c->n, 64) : 0;
         ProjRide pr{};
-        if (nx > 0 && c->ride_rescue_projection && c->N > 0) {
-            pr = make_proj_ride(c, PRE3_X_K_K, 0, 1, nx);
-            c->ride_rescue_projection = false; c->rescue_projected = true;
+        if (which_prior >= 0 && c->ride_rescue_projection && c->N > 0) {
+            if (n_tiles_launch + nx == 0) {                           // nothing left for this launch: the projection rides with the Jnorm pass
+                c->proj_with_jnorm = true;
+            } else {
+                pr = make_proj_ride(c, PRE3_X_K_K, 0, 1, nx);
+                c->rescue_projected = true;
+            }
+            c->ride_rescue_projection = false;
         }
         dim3 g1(n_tiles_launch + nx + pr.n_blocks);
         if (g1.x > 0) {
@@ -1595,7 +1610,7 @@ int launch_chol_first_spec(pre3_ctx *c, int nsel_max)
 int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_dev, bool prebuilt, bool first_done, bool hp_built)
 {
     if (r == 0) {   // update.m:50-55: x_k_k = x_km1_k, p_k_k = p_km1_k
-        c->dd_done = 0; c->cholp_done = false;      // (a speculative persistent launch found no rows on the device either)
+        c->dd_done = 0; c->x_done = false; c->cholp_done = false;      // (a speculative persistent launch found no rows on the device either)
         if (which_prior == PRE3_X_K_KM1) PRE3_HIP(hipMemcpyAsync(c->x_kk, c->x_km1, sizeof(double) * c->n, hipMemcpyDeviceToDevice, c->stream));
         return PRE3_OK;
     }
@@ -1605,10 +1620,11 @@ int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_d
         if (!hp_built) PRE3_TRY(launch_ell_HP(c, r, c->W, true));           // (hp_built: launch_ell_HP_build_sel made the rows and W = H*P in one launch)
         PRE3_TRY(launch_ell_G(c, r, c->W, c->Smat, r_pad, 1, dense_R ? c->Rdense : nullptr));
     }
-    PRE3_TRY(launch_chol_solve(c, r_pad, first_done, which_prior == PRE3_X_K_KM1, r));
+    // (a stateless update that wants K' back keeps the x-update where it was)
+    PRE3_TRY(launch_chol_solve(c, r_pad, first_done, which_prior == PRE3_X_K_KM1, r, which_prior));
     PRE3_TRY(launch_downdate(c, r, c->W, which_prior));
     // update.m:42-46.  leave_jn_to_predict (pre3_step completing the previous step's HI update): the prediction's launch that follows carries it
-    if (c->leave_jn_to_predict && !Kt_out_dev) c->jn_pending = true;
+    if (c->leave_jn_to_predict && !Kt_out_dev && !c->proj_with_jnorm) c->jn_pending = true;
     else PRE3_TRY(launch_jnorm(c, 0));
     if (Kt_out_dev) {
         dim3 g(ceil_div(c->n, 256)), b(256);

@@ -22,11 +22,11 @@ for rep in range(3):           # the same LI update three times (state restored)
     r = f.ransac_hypotheses(s["hyp"], threshold=1.0, early_exit=False)
     f.ekf_update_li_inliers(); f.sync()
     if rep < 2: f.set_x_p_k_k(xs, Ps)
-buf = np.zeros(20 * 16 * 8, np.uint64)
+buf = np.zeros(24 * 16 * 8, np.uint64)
 fn = lib.pre3_debug_cholp; fn.restype = C.c_int
 assert fn(buf.ctypes.data_as(C.c_void_p)) == 0
-raw = buf.reshape(20, 16, 8).astype(np.int64)
-t = buf.reshape(20, 16, 8).astype(np.float64) / 100.0      # us
+raw = buf.reshape(24, 16, 8).astype(np.int64)
+t = buf.reshape(24, 16, 8).astype(np.float64) / 100.0      # us
 n_li = int(r["li_mask"].sum()); nrb = (2 * n_li + 63) // 64
 t0 = t[0, 0, 0]
 def rel(x): return "%7.2f" % (x - t0) if x > 0 else "      -"
@@ -51,3 +51,7 @@ print("strip 0 / last strip, per J: (1) rhs planes done, (2) acquire done, (2) s
 for J in range(nrb):
     order = (3, 0, 4, 1, 5, 2, 6, 7)
     print("  J=%2d  %s | %s" % (J, " ".join(rel(t[16, J, k]) for k in order), " ".join(rel(t[17, J, k]) for k in order)))
+print("down-date consumers (first / last group), per J: flags seen, panel's MFMAs done")
+for J in range(nrb):
+    print("  J=%2d  %s %s | %s %s" % (J, rel(t[20, J, 0]), rel(t[20, J, 1]), rel(t[21, J, 0]), rel(t[21, J, 1])))
+print("  epilogue start / end: %s %s | %s %s" % (rel(t[20, 15, 0]), rel(t[20, 15, 1]), rel(t[21, 15, 0]), rel(t[21, 15, 1])))
