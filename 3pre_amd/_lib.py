@@ -83,7 +83,7 @@ EXPORTS = [
     "pre3_set_flags", "pre3_step", "pre3_set_option", "pre3_get_option", "pre3_map_delete", "pre3_map_add_inverse_depth", "pre3_map_inversedepth_2_cartesian", "pre3_get_map", "pre3_set_descriptors", "pre3_get_descriptors", "pre3_set_scan", "pre3_ic_search", "pre3_vo_ransac", "pre3_vo_ransac_frames", "pre3_vo_bench", "pre3_update_ell", "pre3_siftmatch_f64", "pre3_siftmatch_f32", "pre3_siftmatch_u8",
     "pre3_siftmatch_i8", "pre3_siftmatch_partial", "pre3_siftmatch_merge", "pre3_match_shard_create", "pre3_match_shard_create_cls", "pre3_match_shard_run", "pre3_match_shard_merge",
     "pre3_match_shard_destroy", "pre3_release_scratch", "pre3_knn_f64", "pre3_timer_start",
-    "pre3_timer_stop", "pre3_kernel_timing", "pre3_kernel_timing_read", "pre3_bench_downdate",
+    "pre3_timer_stop", "pre3_kernel_timing", "pre3_kernel_timing_read", "pre3_kernel_timing_info", "pre3_bench_downdate",
     "pre3_match_bench_create", "pre3_match_bench_create_cls", "pre3_match_bench_info", "pre3_match_bench_run", "pre3_match_bench_fetch", "pre3_match_bench_destroy",
     "pre3_comm_unique_id", "pre3_comm_create", "pre3_comm_destroy", "pre3_comm_info", "pre3_set_comm", "pre3_comm_init", "pre3_match_shard_set_comm",
     "pre3_ransac_sharded", "pre3_match_shard_match",

@@ -1277,6 +1277,7 @@ int pre3_kernel_timing(pre3_ctx *c, int enable)
 {
     PRE3_TRY(check_ctx(c));
     c->kt.enabled = enable != 0; c->kt.every = enable > 1 ? enable : 1; c->kt.seen = 0; c->kt.used = 0; c->kt.flops = 0; c->kt.bytes = 0;
+    c->kt.fused = 0; c->kt.fact_flops = 0; c->kt.pending = false;
     return PRE3_OK;
 }
 
@@ -1291,6 +1292,15 @@ int pre3_kernel_timing_read(pre3_ctx *c, int *launches_out, double *total_ms_out
     if (flops_out) *flops_out = c->kt.flops;
     if (bytes_out) *bytes_out = c->kt.bytes;
     c->kt.used = 0; c->kt.flops = 0; c->kt.bytes = 0;
+    return PRE3_OK;
+}
+
+int pre3_kernel_timing_info(pre3_ctx *c, int *fused_launches_out, double *fact_flops_out)
+{
+    PRE3_TRY(check_ctx(c));
+    if (fused_launches_out) *fused_launches_out = c->kt.fused;
+    if (fact_flops_out) *fact_flops_out = c->kt.fact_flops;
+    c->kt.fused = 0; c->kt.fact_flops = 0;
     return PRE3_OK;
 }
 

@@ -14,6 +14,7 @@ bool cholp_usable(const pre3_ctx *c, int nrb_max);
 void cholp_context_count(int device, int delta);      // a context with the persistent form's buffers was created (+1) / destroyed (-1)
 // S (c->Smat, stride nrb * 64) and [HP | nu] (c->W) in place -> L and W = L^-1 [HP | nu], W's bf16 planes (c->Wp) included.
 // nrb < 0: the number of rows is read on the device (stats[4] measurements, as k_gather_li does); nrb_max bounds grid and LDS.
+void cholp_timing_rows(pre3_ctx *c, int r);             // pre3_kernel_timing: the rows of a bracketed speculative launch have reached the host
 int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows = -1, int which_prior = -1 /* >= 0: the launch may also compute x_k_k from that prior */);
 
 }  // namespace pre3

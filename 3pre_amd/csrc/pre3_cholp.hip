@@ -1196,6 +1196,15 @@ void dd_build_groups(int nb, std::vector<int32_t> &rec, std::vector<int2> &tiles
     tile_off.push_back((int)tiles64.size());
 }
 
+// algorithmic work of a bracketed fused launch once its row count is known: SYRK n(n+1)r (the graded down-date), r^3/3 + n r^2 (factorisation + solve)
+void cholp_timing_rows(pre3_ctx *c, int r)
+{
+    c->kt.pending = false;
+    c->kt.flops += (double)c->n * ((double)c->n + 1.0) * r;
+    c->kt.fact_flops += (double)r * r * r / 3.0 + (double)c->n * r * (double)r;
+    c->kt.bytes += 1.5 * c->n * (double)c->n * c->esz + (double)c->n * (double)r * c->esz;
+}
+
 // nrb < 0: the row count is read on the device (stats[4]); nrb_max bounds the grid and the LDS.  rows: the real row count when nrb >= 0.
 int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior)
 {
@@ -1244,7 +1253,24 @@ int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior)
     a.xu = (xu_env && n_dd > 0 && which_prior >= 0) ? 1 : 0;
     a.n = c->n; a.x_prior = which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1; a.x_out = c->x_kk; a.params = c->pred_params;
     a.P = (float *)c->P; a.dd = c->dd_groups; a.n_dd = n_dd; a.rows = nrb < 0 ? nrb_max * NB : (rows > 0 && rows <= nrb * NB ? rows : nrb * NB);
+    // roofline bracket (pre3_kernel_timing): the launches that carry a matrix-bound down-date -- updates of the predicted state
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool timed = c->kt.enabled && n_dd > 0 && which_prior == PRE3_X_K_KM1 && (nrb < 0 || nrb >= 2) && (c->kt.seen++ % c->kt.every) == 0;
+    if (timed) {
+        if ((size_t)c->kt.used + 2 > c->kt.ev.size()) {
+            for (int i = 0; i < 2; ++i) { hipEvent_t e; PRE3_HIP(hipEventCreate(&e)); c->kt.ev.push_back(e); }
+        }
+        e0 = c->kt.ev[c->kt.used]; e1 = c->kt.ev[c->kt.used + 1];
+        c->kt.used += 2;
+        PRE3_HIP(hipEventRecord(e0, c->stream));
+    }
     hipLaunchKernelGGL(k_cholp, dim3(std::max(1 + nH + n_strips + n_dd, 8 * nH + 1)), dim3(CP_NTH), lds, c->stream, a);
+    if (timed) {
+        PRE3_HIP(hipEventRecord(e1, c->stream));
+        c->kt.fused += 1;
+        if (nrb < 0) c->kt.pending = true;                      // the row count arrives with the mailbox: cholp_timing_rows()
+        else cholp_timing_rows(c, a.rows);
+    }
     PRE3_HIP(hipGetLastError());
     c->split_rows = (nrb < 0 ? nrb_max : nrb) * NB;             // the strips' epilogues have written every plane k_downdate_b3 reads
     c->x_done = a.xu != 0;

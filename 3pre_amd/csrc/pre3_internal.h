@@ -56,6 +56,9 @@ struct KernelTiming {
     std::vector<hipEvent_t> ev;     // pairs
     int used = 0;
     double flops = 0, bytes = 0;
+    // launches of the persistent factorisation that carry the down-date (pre3_cholp.hip) are bracketed instead of the K9 launch they replace:
+    // `flops` keeps the SYRK count of those updates, `fact_flops` the factorisation + solve the same launch executes (r^3/3 + n r^2)
+    int fused = 0; double fact_flops = 0; bool pending = false;     // pending: a bracketed launch whose row count the host does not know yet
 };
 
 }  // namespace pre3

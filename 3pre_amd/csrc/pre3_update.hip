@@ -1387,6 +1387,7 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad, bool first_done = false, bo
     if (first_done && c->cholp_done) {             // pre3_update_li's speculative launch was the persistent form: everything is done
         c->cholp_done = false;
         c->split_rows = nrb * NB;                  // (c->dd_done: the groups its consumers have down-dated already)
+        if (c->kt.pending) cholp_timing_rows(c, r > 0 ? r : r_pad);
         return PRE3_OK;
     }
     c->cholp_done = false; c->dd_done = 0; c->x_done = false;
@@ -1458,7 +1459,7 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
     // only launches in the matrix-bound regime are bracketed: the updates of the PREDICTED state (the LI updates, r_pad >= 128; and
     // pre3_bench_downdate).  The rescue stage's HI update -- a few dozen rows, at most a couple of panels early in a sequence -- is a
     // read-modify-write of P at HBM speed and would only dilute the figure, and with 'one in N' it would alias with the LI/HI alternation
-    const bool timed = c->kt.enabled && r_pad >= 2 * NB && which_prior != PRE3_X_K_K && (c->kt.seen++ % c->kt.every) == 0;
+    const bool timed = c->kt.enabled && c->dd_done == 0 && r_pad >= 2 * NB && which_prior != PRE3_X_K_K && (c->kt.seen++ % c->kt.every) == 0;
     if (timed) {
         if ((size_t)c->kt.used + 2 > c->kt.ev.size()) {
             for (int i = 0; i < 2; ++i) { hipEvent_t e; PRE3_HIP(hipEventCreate(&e)); c->kt.ev.push_back(e); }
@@ -1611,6 +1612,7 @@ int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_d
 {
     if (r == 0) {   // update.m:50-55: x_k_k = x_km1_k, p_k_k = p_km1_k
         c->dd_done = 0; c->x_done = false; c->cholp_done = false;      // (a speculative persistent launch found no rows on the device either)
+        if (c->kt.pending) cholp_timing_rows(c, 0);
         if (which_prior == PRE3_X_K_KM1) PRE3_HIP(hipMemcpyAsync(c->x_kk, c->x_km1, sizeof(double) * c->n, hipMemcpyDeviceToDevice, c->stream));
         return PRE3_OK;
     }

@@ -330,9 +330,13 @@ class EkfFilter:
         check(lib.pre3_kernel_timing(self._ctx, int(enable)))
 
     def kernel_timing_read(self):
+        """launches / total_ms / flops (SYRK count n(n+1)r) / bytes of the bracketed launches; fused = how many of them were launches of the
+        persistent factorisation with the down-date inside, fact_flops = the factorisation + solve flops those also executed"""
+        fu, ff = C.c_int(0), C.c_double(0)
+        check(lib.pre3_kernel_timing_info(self._ctx, C.byref(fu), C.byref(ff)))
         n, ms, fl, by = C.c_int(0), C.c_double(0), C.c_double(0), C.c_double(0)
         check(lib.pre3_kernel_timing_read(self._ctx, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
-        return dict(launches=n.value, total_ms=ms.value, flops=fl.value, bytes=by.value)
+        return dict(launches=n.value, total_ms=ms.value, flops=fl.value, bytes=by.value, fused=fu.value, fact_flops=ff.value)
 
     def bench_downdate(self, r, reps):
         ms = C.c_double(0)

@@ -275,6 +275,151 @@ def matcher_leg(pre3, reps=20):
                                         "streaming the database through L2, not by the matrix pipe (DESIGN.md section 4, K11)"}}
 
 
+def fp64_n200_leg(pre3, synth, steps=40, warm=4):
+    """BASELINE.json configs[1] / BASELINE.md section 3: N=200 landmarks (n=1213), fp64, predict + update only (no RANSAC: every measured
+    landmark is updated, r = 2 * 0.8 * 200 = 320 rows, SURVEY 8(d)'s example): the K9 launch (P <- P - W'W on v_mfma_f64_16x16x4_f64) timed with
+    HIP events on the library's stream, its fraction of the f64 MFMA peak, and the max abs error of one predict + update against the C oracle
+    (oracle/pre3_oracle.c: explicit inv(S), K*S*K' -- checker code, used here as the checker)."""
+    import oracle as orc
+    orc.build()
+    N = 200
+    seq = synth.make_sequence(N, steps + warm + 1, 8, outlier_frac=0.0)
+    types, off, n = orc.landmark_table(np.zeros(N, int))
+    f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f64", max_hyp=8, std_z=1.0)
+    try:
+        f.set_x_p_k_k(seq["x0"], seq["P0"])
+
+        def one(s):
+            f.ekf_prediction(s["u"])
+            f.search_IC_matches()
+            f.set_measurements(s["meas_idx"], s["z"])
+            f.ekf_update_all()
+        # parity of one predict + update against the C oracle, from the same state
+        s = seq["steps"][0]
+        x1, P1 = orc.predict(seq["x0"], seq["P0"], s["u"])
+        h, has_h = orc.project(types, off, x1, seq["cam"])
+        Hc, Hl = orc.jacobian(types, off, x1, seq["cam"], h, has_h)
+        zfull = np.zeros((N, 2))
+        zfull[s["meas_idx"]] = s["z"]
+        xr, Pr = orc.update_landmarks(types, off, np.asarray(s["meas_idx"], np.int32), x1, P1, Hc, Hl, zfull, h)
+        one(s)
+        xg, Pg = f.get_x_k_k(), f.get_p_k_k()
+        err_x, err_P = float(np.abs(xg - xr).max()), float(np.abs(Pg - Pr).max())
+        for s in seq["steps"][1:1 + warm]:
+            one(s)
+        f.sync()
+        f.kernel_timing(1)
+        f.timer_start()
+        for s in seq["steps"][1 + warm:1 + warm + steps]:
+            one(s)
+        ev = f.timer_stop()
+        kt = f.kernel_timing_read()
+        f.kernel_timing(False)
+    finally:
+        f.close()
+    r = 2 * int(np.mean([len(s_["meas_idx"]) for s_ in seq["steps"][1 + warm:1 + warm + steps]]))
+    t_s = kt["total_ms"] * 1e-3
+    ach = kt["flops"] / t_s / 1e12 if t_s > 0 else 0.0
+    return {"workload": "configs[1]: N=200 inverse-depth landmarks (n=%d), fp64, predict + update of all %d measured landmarks (r = %d rows), no RANSAC" % (n, r // 2, r),
+            "updates_per_s": steps / (ev * 1e-3), "ms_per_predict_update": ev / steps,
+            "k9": {"kernel": "k_downdate_1t<double> (v_mfma_f64_16x16x4_f64)", "launches": kt["launches"], "avg_launch_us": 1e3 * kt["total_ms"] / max(kt["launches"], 1),
+                   "achieved": ach, "unit": "TFLOP/s", "peak": PEAK["f64"], "frac": ach / PEAK["f64"], "algorithmic": "SYRK n(n+1)r per launch"},
+            "max_abs_err_vs_c_oracle": {"x": err_x, "P": err_P, "P_scale": float(np.abs(Pr).max()),
+                                        "how": "one predict + update from the same state: GPU (Cholesky solve, symmetric down-date) vs oracle/pre3_oracle.c (explicit inv(S), K*S*K')"}}
+
+
+def frame_leg(pre3, synth, N=500, K2=600, frames=40, warm=4, n_hyp=200):
+    """One reference FRAME, not just the inner step (mono_slam.m:113-264): map_management (one delete_a_feature + one add_features_inverse_depth,
+    map_management.m:27-79), ekf_prediction, search_IC_matches + matching_sift_based on the frame's SIFT set (K2 = 600 keypoints, SIFT_extract_save.m:68-89:
+    descriptors are unit-norm doubles), RANSAC, LI update, rescue, HI update.  Frames/s with the scan crossing PCIe inside the timed region, and the
+    per-stage split from a second pass with a stream synchronisation behind every stage."""
+    rng = np.random.default_rng(7000)
+    seq = synth.make_sequence(N, frames + warm, n_hyp, **{k: v for k, v in synth.HEADLINE.items() if k == "motion_noise"})
+    thr = synth.HEADLINE["threshold"]
+
+    def sift_like(X):
+        X = np.abs(X); X = X / np.linalg.norm(X, axis=0, keepdims=True)
+        X = np.minimum(X, 0.2)
+        return X / np.linalg.norm(X, axis=0, keepdims=True)
+    bank = sift_like(rng.standard_normal((128, N)))
+    scans = []
+    for s in seq["steps"]:                                   # the frame's SIFT set: the measured landmarks' descriptors (perturbed) at their pixels + distractors
+        m = len(s["meas_idx"])
+        d = sift_like(bank[:, s["meas_idx"]] + 0.01 * rng.standard_normal((128, m)))
+        nd = max(0, K2 - m)
+        d = np.concatenate([d, sift_like(rng.standard_normal((128, nd)))], 1)
+        pos = np.concatenate([s["z"].T, np.stack([rng.uniform(1, 175, nd), rng.uniform(1, 143, nd)])], 1)
+        pos = np.concatenate([pos, np.full((1, m + nd), 2.0), np.zeros((1, m + nd))], 0)
+        perm = rng.permutation(m + nd)
+        scans.append((np.asfortranarray(d[:, perm]), np.asfortranarray(pos[:, perm])))
+    f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", max_hyp=n_hyp, max_landmarks=N + 2, std_z=thr)
+    try:
+        f.set_x_p_k_k(seq["x0"], seq["P0"])
+        f.set_descriptors(bank)
+        new_desc = sift_like(rng.standard_normal((128, frames + warm + 1)))
+
+        def draws(m):                                        # select_random_match.m:47-51: 3 distinct measurements per hypothesis (vectorised; duplicates redrawn)
+            if m <= 3:
+                return synth.draw_hypotheses(rng, m, n_hyp)
+            h = rng.integers(0, m, (n_hyp, 3))
+            bad = (h[:, 0] == h[:, 1]) | (h[:, 0] == h[:, 2]) | (h[:, 1] == h[:, 2])
+            while bad.any():
+                h[bad] = rng.integers(0, m, (int(bad.sum()), 3))
+                bad = (h[:, 0] == h[:, 1]) | (h[:, 0] == h[:, 2]) | (h[:, 1] == h[:, 2])
+            return h.astype(np.int32)
+
+        stage = {k: 0.0 for k in ("map_management", "prediction", "scan_upload", "ic_search", "ransac", "li_update", "rescue_hi_update")}
+
+        def frame(k, split):
+            t = [time.perf_counter()]
+
+            def mark(name):
+                if split:
+                    f.sync()
+                    t.append(time.perf_counter())
+                    stage[name] += t[-1] - t[-2]
+            s = seq["steps"][k]
+            # map_management.m:27-79: the landmark added last frame goes (frame 0: the last one of the map), a new one comes in
+            f.delete_features([f.N - 1])
+            f.add_features_inverse_depth(np.array([[rng.uniform(30, 140), rng.uniform(30, 110)]]), 1.0, 0.5)
+            f.set_descriptors(new_desc[:, k:k + 1], first=f.N - 1)
+            mark("map_management")
+            f.ekf_prediction(s["u"])
+            mark("prediction")
+            f.load_scan(*scans[k])
+            mark("scan_upload")
+            ic = f.matching_sift_based(1.5, strict_reference=True)
+            mark("ic_search")
+            m = len(ic["meas_idx"])
+            if m >= 3:
+                f.ransac_hypotheses(draws(m), threshold=thr, early_exit=False)
+            mark("ransac")
+            f.ekf_update_li_inliers()
+            mark("li_update")
+            f.rescue_hi_inliers()
+            f.ekf_update_hi_inliers()
+            mark("rescue_hi_update")
+            return m
+        for k in range(warm):
+            frame(k, False)
+        f.sync()
+        t0 = time.perf_counter()
+        ms = [frame(k, False) for k in range(warm, warm + frames // 2)]
+        f.sync()
+        el = time.perf_counter() - t0
+        for k in range(warm + frames // 2, warm + frames):
+            frame(k, True)
+        n_split = frames - frames // 2
+    finally:
+        f.close()
+    return {"workload": "one mono_slam.m frame at N=%d (n=%d): map_management (1 delete + 1 add), prediction, IC search on a %d-keypoint SIFT set (unit-norm doubles, "
+                        "uploaded per frame), RANSAC (%d hypotheses), LI update, rescue, HI update; f32 covariance path; threshold / motion noise as the headline" % (N, seq["n"], K2, n_hyp),
+            "frames_per_s": len(ms) / el, "ms_per_frame": 1e3 * el / len(ms), "mean_ic_matches": float(np.mean(ms)),
+            "stage_us_synchronised": {k_: 1e6 * v / n_split for k_, v in stage.items()},
+            "note": "frames_per_s: no synchronisation inside a frame except what the calls themselves need (the IC search returns its match list, the RANSAC "
+                    "statistics and the row counts are polled); stage_us: a second pass with a stream synchronisation behind every stage, so its sum exceeds ms_per_frame"}
+
+
 def vo_leg(pre3, pnum=500, n_hyp=700, reps=50):
     """the VO front end's 4-point RANSAC (vodometry_dr_ye.m:171-236), 700 hypotheses over pnum matched 3-D points,
     inputs resident (pre3_vo_bench: the dist / score / final kernels, HIP events)."""
@@ -424,15 +569,17 @@ def main():
     ap.add_argument("--kt-every", type=int, default=4, help="bracket one K9 launch in N with HIP events (an event pair costs ~11 us of stream time); 1 = every launch")
     ap.add_argument("--sync-hi", action="store_true", help="complete every step's HI update inside the step call (default: deferred to the next call)")
     ap.add_argument("--k9-f32", action="store_true", help="fp32 path: K9 on the f32 MFMA instead of the three-way bf16 split (PRE3_OPT_K9_BF16X3 = 0)")
-    ap.add_argument("--threshold", type=float, default=0.5, help="RANSAC threshold in pixels (ransac_hypotheses.m:33, threshold = std_z); 0.5 = 2 sigma of "
-                    "the synthetic pixel noise: some true inliers then miss the low-innovation set and come back through the chi2 rescue (whose gate, "
-                    "sqrt(5.99 H P H'), is ~0.7 px on the converged map), so that every step carries a real HI update: ~40 rows in steps 5..25 of the "
-                    "sequence (the window of `--steps 20 --warmup 5`), ~12 rows averaged over 200 steps; 1.0 is the reference's own constant (the `no_hi` leg)")
-    ap.add_argument("--no-hi-steps", type=int, default=60, help="steps of the second leg (threshold 1.0: the rescue finds next to nothing); 0 = skip")
+    ap.add_argument("--threshold", type=float, default=None, help="RANSAC threshold in pixels; default: the reference's own constant, 1.0 "
+                    "(ransac_hypotheses.m:33 with mono_slam.m:78's sigma_image_noise = 1)")
+    ap.add_argument("--motion-noise", type=float, default=None, help="how far the synthetic truth leaves the odometry, in units of the process noise the "
+                    "filter assumes (3pre_amd/synth.py HEADLINE: 2.5 -- the 3-point hypothesis states are then off by a pixel or so and the chi2 rescue "
+                    "has work in every step: ~36 HI rows in steps 5..25, ~31 over 60 steps, LI ~550 rows; 0.5 = the sequences of rounds 1-3)")
+    ap.add_argument("--legacy-steps", type=int, default=60, help="steps of each of the two legs on the rounds-1-3 sequence (motion noise 0.5): `thr05` "
+                    "(threshold 0.5 px, round 3's headline; it runs the headline's --steps / --warmup window) and `no_hi` (threshold 1.0, rounds 1-2); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of host work per CPU-baseline leg (three legs)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity check of one step behind the timed region")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip the sharded-RANSAC and matcher legs")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the sharded-RANSAC, matcher, fp64 and frame legs")
     args = ap.parse_args()
 
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
@@ -481,37 +628,42 @@ def main():
     torch.cuda.set_device(local_rank)
 
     N, K, W = args.landmarks, args.steps, args.warmup
-    thr = args.threshold
-    K2 = max(0, args.no_hi_steps)
-    seq = synth.make_sequence(N, K + W + 1 + (K2 + 3 if K2 else 0), args.hyp, seed=None if rank == 0 else 10_000 * rank + N)     # + 1: the checked step; + the `no_hi` leg
+    thr = synth.HEADLINE["threshold"] if args.threshold is None else args.threshold
+    motion = synth.HEADLINE["motion_noise"] if args.motion_noise is None else args.motion_noise
+    K2 = max(0, args.legacy_steps)
+
+    def timed_steps(f, steps, th):
+        """the contract's timed region: barrier + synchronize on both sides, max over ranks; K9 / fused-launch brackets collected meanwhile"""
+        f.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        f.kernel_timing(max(1, args.kt_every))
+        f.timer_start()
+        t0 = time.perf_counter()
+        st = [f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=th, early_exit=False) for s in steps]
+        ev = f.timer_stop()                      # HIP events on the stream the kernels run on (synchronises; flushes a deferred HI update)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+            t = torch.tensor([el], device=COLL_DEV, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        k = f.kernel_timing_read()
+        f.kernel_timing(False)
+        return el, st, k, ev
+
+    seq = synth.make_sequence(N, K + W + 1, args.hyp, seed=None if rank == 0 else 10_000 * rank + N, motion_noise=motion)     # + 1: the checked step
     f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype=args.dtype, device=local_rank, max_hyp=args.hyp, std_z=thr)
     b3 = f.k9_bf16x3(False if args.k9_f32 else None) if args.dtype == "f32" else False
     f.set_x_p_k_k(seq["x0"], seq["P0"])
-    stats = []
     for s in seq["steps"][:W]:
         f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=thr, early_exit=False)
-    f.sync()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    f.kernel_timing(max(1, args.kt_every))
     if not args.sync_hi:
         f.defer_hi_update(True)                    # PRE3_OPT_DEFER_HI: the HI update of step k is completed by the call of step k+1 (same results;
                                                    # the caller's time between steps overlaps the rescue stage); the final timer_stop() flushes the last one
-    f.timer_start()
-    t0 = time.perf_counter()
-    for s in seq["steps"][W:W + K]:
-        stats.append(f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=thr, early_exit=False))
-    ev_ms = f.timer_stop()                       # HIP events on the stream the kernels run on (synchronises)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        dist.barrier()
-        t = torch.tensor([elapsed], device=COLL_DEV, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kt = f.kernel_timing_read()
-    f.kernel_timing(False)
+    elapsed, stats, kt, ev_ms = timed_steps(f, seq["steps"][W:W + K], thr)
     # parity of what was timed: the NEXT step of the same sequence, GPU vs the numpy twin (outside the timed region)
     chk = None
     if rank == 0 and not args.no_check:
@@ -519,84 +671,117 @@ def main():
             chk = check_step(pre3, f, seq, seq["steps"][W + K], thr, args.dtype)
         except Exception as e:                                  # pragma: no cover
             chk = {"checked": False, "check_error": repr(e)[:300]}
-        if not args.sync_hi:
-            f.defer_hi_update(True)
-    # second leg, same filter, the reference's own threshold (1.0 px): the workload of rounds 1-2, where the rescue finds next to nothing
-    no_hi = None
+    f.close()
+
+    def k9_rate(ktx):
+        """the bracketed launches of a leg, priced like `roofline`"""
+        if not (ktx["total_ms"] > 0 and ktx["launches"] > 0):
+            return None
+        six = 6.0 if (args.dtype == "f32" and b3) else 1.0
+        fused = ktx["fused"] == ktx["launches"]
+        work = ktx["flops"] + (ktx["fact_flops"] if fused else 0.0)
+        ach = work / (ktx["total_ms"] * 1e-3) / 1e12
+        pk = PEAK["bf16"] if six > 1 else PEAK[args.dtype]
+        return {"kernel": "k_cholp (factorisation + solve + down-date in one launch)" if fused else "k_downdate_b3 / k_downdate_1t", "achieved": six * ach,
+                "unit": "TFLOP/s", "peak": pk, "frac": six * ach / pk, "launches": ktx["launches"], "avg_launch_us": 1e3 * ktx["total_ms"] / ktx["launches"],
+                "f32_equivalent_ratio": ach / PEAK["f32"] if args.dtype == "f32" else None}
+
+    # Two legs on the sequence of rounds 1-3 (motion noise 0.5), a fresh filter: `thr05` = round 3's headline (threshold 0.5 px: ~260 LI inliers, the
+    # rest of the true inliers come back through the rescue) over the same --steps / --warmup window, then `no_hi` = the same filter continued at the
+    # reference's 1.0 px (rounds 1-2: the rescue finds next to nothing) -- so that the rounds stay comparable.
+    thr05, no_hi = None, None
     if K2:
-        st2 = []
-        s2 = seq["steps"][W + K + 1:]
+        seq2 = synth.make_sequence(N, W + K + 3 + K2, args.hyp, seed=None if rank == 0 else 10_000 * rank + N)
+        f2 = pre3.EkfFilter(seq2["cam"], np.zeros(N, np.int32), dtype=args.dtype, device=local_rank, max_hyp=args.hyp, std_z=0.5)
+        if args.dtype == "f32":
+            f2.k9_bf16x3(False if args.k9_f32 else None)
+        f2.set_x_p_k_k(seq2["x0"], seq2["P0"])
+        for s in seq2["steps"][:W]:
+            f2.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=0.5, early_exit=False)
+        if not args.sync_hi:
+            f2.defer_hi_update(True)
+        el5, st5, kt5, _ = timed_steps(f2, seq2["steps"][W:W + K], 0.5)
+        thr05 = {"value": world * K / el5, "unit": "steps/s", "steps": K, "warmup": W, "ms_per_step": 1e3 * el5 / K, "threshold_px": 0.5, "motion_noise": 0.5,
+                 "mean_li_rows": 2 * float(np.mean([s_["n_li"] for s_ in st5])), "mean_hi_rows": 2 * float(np.mean([s_["n_hi"] for s_ in st5])),
+                 "dominant_launch": k9_rate(kt5),
+                 "note": "round 3's headline workload: threshold 0.5 px on the motion-noise-0.5 sequence, same --steps / --warmup window"}
+        s2 = seq2["steps"][W + K:]
         for s in s2[:3]:
-            f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=1.0, early_exit=False)
-        f.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        f.kernel_timing(max(1, args.kt_every))
-        t2 = time.perf_counter()
-        for s in s2[3:3 + K2]:
-            st2.append(f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=1.0, early_exit=False))
-        f.sync()
-        torch.cuda.synchronize()
-        el2 = time.perf_counter() - t2
-        kt2 = f.kernel_timing_read()
-        f.kernel_timing(False)
-        if dist is not None:
-            dist.barrier()
-            t = torch.tensor([el2], device=COLL_DEV, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el2 = float(t.item())
-        no_hi = {"value": world * K2 / el2, "unit": "steps/s", "steps": K2, "ms_per_step": 1e3 * el2 / K2, "threshold_px": 1.0,
+            f2.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=1.0, early_exit=False)
+        el2, st2, kt2, _ = timed_steps(f2, s2[3:3 + K2], 1.0)
+        no_hi = {"value": world * K2 / el2, "unit": "steps/s", "steps": K2, "ms_per_step": 1e3 * el2 / K2, "threshold_px": 1.0, "motion_noise": 0.5,
                  "mean_li_rows": 2 * float(np.mean([s_["n_li"] for s_ in st2])), "mean_hi_rows": 2 * float(np.mean([s_["n_hi"] for s_ in st2])),
-                 "note": "the same filter continued with the reference's own RANSAC threshold (ransac_hypotheses.m:33 with mono_slam.m:78's "
-                         "sigma_image_noise = 1): the headline workload of rounds 1 and 2"}
-        if kt2["total_ms"] > 0 and kt2["launches"] > 0:
-            # K9 of this leg's LI updates (r ~ 640), priced like `roofline` (the headline's LI updates have r ~ 500: the same kernel with 8 instead of 10 k-panels)
-            ach2 = kt2["flops"] / (kt2["total_ms"] * 1e-3) / 1e12
-            six = 6.0 if (args.dtype == "f32" and b3) else 1.0
-            no_hi["k9"] = {"achieved": six * ach2, "unit": "TFLOP/s", "peak": PEAK["bf16"] if six > 1 else PEAK[args.dtype],
-                           "frac": six * ach2 / (PEAK["bf16"] if six > 1 else PEAK[args.dtype]), "launches": kt2["launches"],
-                           "avg_launch_us": 1e3 * kt2["total_ms"] / kt2["launches"], "f32_equivalent_ratio": ach2 / PEAK["f32"] if args.dtype == "f32" else None}
+                 "dominant_launch": k9_rate(kt2),
+                 "note": "the same filter continued with the reference's own RANSAC threshold on the motion-noise-0.5 sequence: the headline "
+                         "workload of rounds 1 and 2 (the rescue finds next to nothing)"}
+        f2.close()
 
     out = None
     if rank == 0:
         n = seq["n"]
         n_li = float(np.mean([s["n_li"] for s in stats]))
         n_hi = float(np.mean([s["n_hi"] for s in stats]))
-        achieved = kt["flops"] / (kt["total_ms"] * 1e-3) / 1e12 if kt["total_ms"] > 0 else 0.0
+        t_s = kt["total_ms"] * 1e-3
+        achieved = kt["flops"] / t_s / 1e12 if t_s > 0 else 0.0                      # the SYRK count n(n+1)r alone
+        fused = kt["launches"] > 0 and kt["fused"] == kt["launches"]                  # every bracketed launch was k_cholp with the down-date inside
+        mean_r = (kt["flops"] / max(kt["launches"], 1)) / (n * (n + 1.0))
         traffic, traffic_src = None, None
-        for tag in ("r3", "r2", "r1"):    # HBM bytes per LI launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
-            try:
-                with open(os.path.join(ROOT, "profiles", "%s_pmc_k9.json" % tag)) as fh:
+        for tag, key in (("r4", "pmc_cholp"), ("r3", "pmc_k9")) if fused else (("r3", "pmc_k9"), ("r2", "pmc_k9"), ("r1", "pmc_k9")):
+            try:     # HBM bytes per LI launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
+                with open(os.path.join(ROOT, "profiles", "%s_%s.json" % (tag, key))) as fh:
                     pj = json.load(fh)
                 traffic = pj["hbm_bytes_per_li_launch"]["fetch_doubled"]
-                traffic_src = ("profiles/%s_pmc_k9.json (WRITE_SIZE + 2 x FETCH_SIZE of the r=640 launches: gfx950 reports half the bytes of 16 B/lane "
-                               "reads, MI355X_MICROARCH.md; raw sum %.1f MB)" % (tag, pj["hbm_bytes_per_li_launch"]["raw"] / 1e6))
+                traffic_src = ("profiles/%s_%s.json (WRITE_SIZE + 2 x FETCH_SIZE of the LI launches, mean r = %s: gfx950 reports half the bytes of 16 B/lane "
+                               "reads, MI355X_MICROARCH.md; raw sum %.1f MB)" % (tag, key, pj.get("mean_rows", "?"), pj["hbm_bytes_per_li_launch"]["raw"] / 1e6))
+                if not (fused and key == "pmc_k9"):
+                    break
+                traffic_src += " -- measured on the stand-alone K9 launch of round 3; no PMC pass of the fused launch is committed yet"
                 break
             except Exception:
                 pass
-        algo = ("symmetric rank-r down-date (SYRK): n(n+1)r flop per launch, r = rows of that update, averaged over the K9 launches of "
-                "the timed region that were bracketed with HIP events: one in --kt-every of the launches with >= 128 rows, i.e. the LI "
-                "updates (r ~ 640); the HI updates' launches (r <= 64) are HBM-bound read-modify-writes of P and are not priced against the "
-                "matrix roofline; SURVEY 8(d)'s un-halved convention 2n^2r gives twice this figure")
-        common = {"unit": "TFLOP/s", "traffic": traffic, "traffic_source": traffic_src, "launches": kt["launches"],
-                  "avg_launch_us": 1e3 * kt["total_ms"] / max(kt["launches"], 1), "algorithmic": algo,
-                  "survey_2n2r_equivalent": 2.0 * achieved * n / (n + 1.0)}
-        if b3:
-            # the launch executes six bf16 products per f32 product (three-way split of W): priced against the
-            # bf16 dense peak on the flops it executes; the f32-equivalent rate is reported next to it
-            roofline = dict(kernel="k_downdate_b3 (K9: P <- P - W'W; W split exactly into three bf16 planes, six bf16 MFMA products with "
-                                   "f32 accumulation per f32 product; 128x128 + 64x64 tiles; the x-update and rescue-projection riders "
-                                   "share the launch)",
-                            bound="mfma", dtype="bf16 operands (3-way split of f32), f32 accumulate", achieved=6.0 * achieved, peak=PEAK["bf16"],
-                            frac=6.0 * achieved / PEAK["bf16"],
-                            f32_equivalent={"achieved": achieved, "f32_mfma_peak": PEAK["f32"], "ratio": achieved / PEAK["f32"],
-                                            "note": "the same launches priced as the f32 SYRK they replace: n(n+1)r flop / time; BASELINE.json's "
-                                                    "north star asks for the P-update at >= 60 % of the fp32 MFMA roofline -- this ratio is that figure"}, **common)
+        if fused:
+            # The dominant launch is now k_cholp: update.m:32-38 of an LI update in ONE launch -- factorisation of S (a latency chain on one
+            # workgroup), blocked triangular solve, x-update, and P - W'W accumulated panel by panel by consumer workgroups on the other CUs.
+            # Every product of the launch except the 64-column diagonal chains runs as six bf16 products with f32 accumulation.
+            work = kt["flops"] + kt["fact_flops"]
+            algo = ("per launch: SYRK n(n+1)r (the graded down-date, update.m:37) + r^3/3 + n r^2 (factorisation of S and W = L^-1 [HP | nu], update.m:32-33), "
+                    "r = rows of that update; averaged over the launches of the timed region bracketed with HIP events on the library's stream "
+                    "(one LI update in --kt-every); executed = 6 x that (three-way bf16 split); SURVEY 8(d)'s un-halved 2n^2r convention doubles the SYRK part")
+            roofline = dict(kernel="k_cholp (persistent factorisation + solve + x-update with the K9 down-date inside: crit / row / strip workgroups and, on the CUs "
+                                   "they leave idle, consumer workgroups holding 64x64 tiles of P as accumulators; six bf16 MFMA products per f32 product)",
+                            bound="mfma", dtype="bf16 operands (3-way split of f32), f32 accumulate", unit="TFLOP/s", achieved=6.0 * work / t_s / 1e12, peak=PEAK["bf16"],
+                            frac=6.0 * work / t_s / 1e12 / PEAK["bf16"], launches=kt["launches"], avg_launch_us=1e3 * kt["total_ms"] / kt["launches"], mean_rows=mean_r,
+                            traffic=traffic, traffic_source=traffic_src, algorithmic=algo,
+                            f32_equivalent={"achieved": work / t_s / 1e12, "f32_mfma_peak": PEAK["f32"], "ratio": work / t_s / 1e12 / PEAK["f32"],
+                                            "note": "the launch priced as the f32 work it replaces (SYRK + factorisation + solve) / its whole duration"},
+                            downdate_only={"syrk_TFLOPs_f32_equivalent": achieved, "ratio_of_f32_mfma_peak": achieved / PEAK["f32"],
+                                           "executed_bf16_frac_of_peak": 6.0 * achieved / PEAK["bf16"],
+                                           "note": "the SYRK count alone over the SAME duration (the launch also holds the factorisation's 60-us dependent chain): "
+                                                   "what north_star's 'P-update >= 60 % of the fp32 MFMA roofline' would read if the whole launch were charged to K9; "
+                                                   "the consumers' own matrix-pipe occupancy is in profiles/r4_pmc_cholp.json"})
         else:
-            roofline = dict(kernel="k_downdate_1t / k_downdate (K9: P <- P - W'W on the %s MFMA; the x-update and rescue-projection riders "
-                                   "share the one-tile launch)" % args.dtype,
-                            bound="mfma", dtype=args.dtype, achieved=achieved, peak=PEAK[args.dtype], frac=achieved / PEAK[args.dtype], **common)
+            algo = ("symmetric rank-r down-date (SYRK): n(n+1)r flop per launch, r = rows of that update, averaged over the K9 launches of "
+                    "the timed region that were bracketed with HIP events: one in --kt-every of the launches with >= 128 rows, i.e. the LI "
+                    "updates; the HI updates' launches (r <= 64) are HBM-bound read-modify-writes of P and are not priced against the "
+                    "matrix roofline; SURVEY 8(d)'s un-halved convention 2n^2r gives twice this figure")
+            common = {"unit": "TFLOP/s", "traffic": traffic, "traffic_source": traffic_src, "launches": kt["launches"],
+                      "avg_launch_us": 1e3 * kt["total_ms"] / max(kt["launches"], 1), "mean_rows": mean_r, "algorithmic": algo,
+                      "survey_2n2r_equivalent": 2.0 * achieved * n / (n + 1.0)}
+            if b3:
+                # the launch executes six bf16 products per f32 product (three-way split of W, DESIGN.md section 6): priced against the
+                # bf16 dense peak on the flops it executes; the f32-equivalent rate is reported next to it
+                roofline = dict(kernel="k_downdate_b3 (K9: P <- P - W'W; W split exactly into three bf16 planes, six bf16 MFMA products with "
+                                       "f32 accumulation per f32 product; 128x128 + 64x64 tiles; the x-update and rescue-projection riders "
+                                       "share the launch)",
+                                bound="mfma", dtype="bf16 operands (3-way split of f32), f32 accumulate", achieved=6.0 * achieved, peak=PEAK["bf16"],
+                                frac=6.0 * achieved / PEAK["bf16"],
+                                f32_equivalent={"achieved": achieved, "f32_mfma_peak": PEAK["f32"], "ratio": achieved / PEAK["f32"],
+                                                "note": "the same launches priced as the f32 SYRK they replace: n(n+1)r flop / time; BASELINE.json's "
+                                                        "north star asks for the P-update at >= 60 % of the fp32 MFMA roofline -- this ratio is that figure"}, **common)
+            else:
+                roofline = dict(kernel="k_downdate_1t / k_downdate (K9: P <- P - W'W on the %s MFMA; the x-update and rescue-projection riders "
+                                       "share the one-tile launch)" % args.dtype,
+                                bound="mfma", dtype=args.dtype, achieved=achieved, peak=PEAK[args.dtype], frac=achieved / PEAK[args.dtype], **common)
         ms_step = 1e3 * elapsed / K
         # SURVEY 8(d): the step's ideal = its algorithmic flops at the MFMA peak of the dtype, no latency: F_upd(r) = 2*19*n*r + 2*19*r^2 + r^3/3
         # + 2*n*r^2 + 2*n^2*r + 2*n*r for the LI and the HI update (r = measured mean rows)
@@ -611,9 +796,13 @@ def main():
             "config": {"workload": "configs[2]: N=%d inverse-depth landmarks (n=%d), %d RANSAC hypotheses (k=3, all evaluated), "
                                    "%s covariance path, full 1PRE step" % (N, n, args.hyp, args.dtype),
                        "measured_per_step": int(np.mean([len(s["meas_idx"]) for s in seq["steps"][W:W + K]])),
-                       "mean_li_rows": 2 * n_li, "mean_hi_rows": 2 * n_hi, "ransac_threshold_px": thr, "parallelism": "replicas x%d" % world,
+                       "mean_li_rows": 2 * n_li, "mean_hi_rows": 2 * n_hi, "ransac_threshold_px": thr, "motion_noise": motion,
+                       "sequence": "3pre_amd/synth.py HEADLINE: SURVEY 8(d)'s measurement spec (0.8 N measured, 20 % gross outliers, threshold 1.0 px); the truth "
+                                   "leaves the odometry by motion_noise x the filter's process noise, which is what gives rescue_hi_inliers.m work in every step",
+                       "parallelism": "replicas x%d" % world,
                        "hip_event_ms_per_step": ev_ms / K},
             "roofline": roofline,
+            "thr05": thr05,
             "no_hi": no_hi,
             "step_ideal": {"ideal_us": ideal_us, "achieved_us": 1e3 * ms_step, "step_ideal_frac": ideal_us / (1e3 * ms_step),
                            "note": "SURVEY 8(d): algorithmic flops of the LI + HI updates at the %s MFMA peak, no latency" % args.dtype},
@@ -622,7 +811,6 @@ def main():
         out.update(chk)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(seq, thr, args.cpu_budget)
-    f.close()
     # secondary legs: sharded RANSAC and sharded matcher at every N, kernel-only matcher and VO RANSAC at N=1.  A leg that fails on any
     # rank is recorded and ends the legs (legs_agree): no rank may be left inside a collective, and the headline is printed regardless.
     comm_broken = False
@@ -678,7 +866,8 @@ def main():
         if holder.get("comm") is not None and not comm_broken:
             holder.pop("comm").close()
         if world == 1:
-            for name, fn in (("matcher", lambda: matcher_leg(pre3)), ("vo_ransac", lambda: vo_leg(pre3))):
+            for name, fn in (("matcher", lambda: matcher_leg(pre3)), ("vo_ransac", lambda: vo_leg(pre3)), ("fp64_n200", lambda: fp64_n200_leg(pre3, synth)),
+                             ("frame", lambda: frame_leg(pre3, synth))):
                 try:
                     out[name] = fn()
                 except Exception as e:                          # pragma: no cover

@@ -363,6 +363,11 @@ PRE3_API int pre3_timer_stop(pre3_ctx *ctx, double *ms_out);             /* sync
 PRE3_API int pre3_kernel_timing(pre3_ctx *ctx, int enable);             /* 1: bracket every K9 launch of >= 128 rows (the matrix-bound ones) with events; N > 1: one such launch in N; 0: off */
 PRE3_API int pre3_kernel_timing_read(pre3_ctx *ctx, int *launches_out, double *total_ms_out, double *flops_out,
                                      double *bytes_out);                /* synchronises, then resets */
+/* Of the launches pre3_kernel_timing_read reports: how many were launches of the persistent factorisation that carry the down-date inside
+ * (PRE3_OPT_K9_OVERLAP: the bracket then spans update.m:32-38 -- factorisation, solve, x-update and P - W'W -- of an update of the predicted
+ * state), and the factorisation + solve flops (r^3/3 + n r^2) those launches executed besides the SYRK count.  Call it BEFORE
+ * pre3_kernel_timing_read (both reset their sums). */
+PRE3_API int pre3_kernel_timing_info(pre3_ctx *ctx, int *fused_launches_out, double *fact_flops_out);
 /* run only the K9 down-date P <- P - W'W with a synthetic W of r rows `reps` times (roofline probe) */
 PRE3_API int pre3_bench_downdate(pre3_ctx *ctx, int r, int reps, double *ms_per_launch_out);
 /* Matcher probe (bench.py's `matcher` object, tests/test_gpu_match_rank.py): descriptors uploaded and packed ONCE, then `reps` back-to-back

@@ -332,7 +332,12 @@ def rescue(types, off, P, Hc, Hl, h, z, ic, li, chi2=5.9915):   # @ekf_filter/re
             Hi = _rows(n, types, off, [i], Hc, Hl)[:, c]
             Si = Hi @ P[np.ix_(c, c)] @ Hi.T
             nui = z[i] - h[i]
-            hi[i] = 1 if nui @ np.linalg.inv(Si) @ nui < chi2 else 0
+            try:
+                hi[i] = 1 if nui @ np.linalg.inv(Si) @ nui < chi2 else 0
+            except np.linalg.LinAlgError:
+                # a measured landmark the projection skipped has H = 0, so Si = 0: MATLAB's inv warns and returns Inf, the quadratic form is
+                # Inf or NaN and `< chi2` is false (the C oracle's inv2 and the device's 1/det behave the same way)
+                hi[i] = 0
     return hi
 
 

@@ -34,7 +34,12 @@ def test_one_json_line_with_the_contract_s_keys():
         assert k in rf, k
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert d["checked"] is True and d["li_set_equal"] and d["hi_set_equal"]
-    assert d["config"]["mean_hi_rows"] > 0 and "no_hi" in d and d["no_hi"]["mean_hi_rows"] < d["config"]["mean_hi_rows"]
+    # the headline is SURVEY 8(d)'s step: the reference's threshold, an HI update in (nearly) every step; the two legs keep rounds 1-3 comparable
+    assert d["config"]["ransac_threshold_px"] == 1.0 and d["config"]["mean_hi_rows"] > 0
+    assert d["thr05"]["threshold_px"] == 0.5 and d["thr05"]["mean_hi_rows"] > 0 and d["no_hi"]["threshold_px"] == 1.0
+    assert "cholp" in rf["kernel"] and rf["launches"] >= 1 and rf["avg_launch_us"] > 0          # the fused launch is what the bracket times
+    assert d["fp64_n200"]["k9"]["frac"] > 0 and d["fp64_n200"]["max_abs_err_vs_c_oracle"]["P"] < 1e-10 * d["fp64_n200"]["max_abs_err_vs_c_oracle"]["P_scale"] + 1e-18
+    assert d["frame"]["frames_per_s"] > 0 and d["frame"]["mean_ic_matches"] > 100
     # the auxiliary legs, through libpre3's own communicator (one rank)
     assert d["rccl"]["world"] == 1 and "ncclAllReduce enqueued by libpre3" in d["ransac_shard"]["collective"]
     assert d["ransac_shard"]["value"] > 0 and d["matcher_shard"]["matches"] > 0 and d["matcher"]["ms_per_match"] > 0

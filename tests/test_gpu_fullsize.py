@@ -44,6 +44,41 @@ def test_config3_full_step_at_N500_matches_the_twin(pre3, dtype, tol_P, tol_x):
     f.close()
 
 
+@pytest.mark.parametrize("dtype,tol_P,tol_x", [("f64", 1e-10, 1e-9), ("f32", 1e-3, 1e-4)])
+def test_the_headline_workload_three_chained_steps_match_the_twin(pre3, dtype, tol_P, tol_x):
+    """bench.py's headline at its own parameters (3pre_amd/synth.py HEADLINE: the reference's threshold 1.0 px, motion noise 2.5, N = 500, 200
+    hypotheses): three CHAINED steps -- the filter keeps its own state, the twin its own -- after a warm-up that brings the LI update to its
+    full size.  Every step must find a non-empty HI set, LI / HI sets and the RANSAC winner identical; x and P after the third step within
+    the tolerance of three accumulated updates (fp64 1e-10 of P's scale; fp32 1e-3 -- one update is inside 3e-4, test above)."""
+    from oracle import np_twin as tw
+    import oracle as orc
+    N, n_hyp, warm = 500, 200, 2
+    seq = synth.make_sequence(N, warm + 3, n_hyp, motion_noise=synth.HEADLINE["motion_noise"])       # bench.py's sequence (same seeds)
+    thr = synth.HEADLINE["threshold"]
+    types, off, n = orc.landmark_table(np.zeros(N, int))
+    x, P = seq["x0"], seq["P0"]
+    for s in seq["steps"][:warm]:                          # warm-up on the twin only; the filter starts from the twin's state
+        ref = tw.step(types, off, seq["cam"], x, P, s["u"], s["meas_idx"], s["z"], s["hyp"], thr, early_exit=False)
+        x, P = ref["x_kk"], ref["P_kk"]
+    f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype=dtype, max_hyp=n_hyp, std_z=thr)
+    f.set_x_p_k_k(x, P)
+    f.defer_hi_update(True)                                # as bench.py runs it
+    for s in seq["steps"][warm:]:
+        ref = tw.step(types, off, seq["cam"], x, P, s["u"], s["meas_idx"], s["z"], s["hyp"], thr, early_exit=False)
+        x, P = ref["x_kk"], ref["P_kk"]
+        st = f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=thr, early_exit=False)
+        li, hi = f.get_flags()                             # (completes the deferred HI update)
+        r = ref["ransac"]
+        assert (st["best"], st["max_support"]) == (r["best"], r["max_support"])
+        assert np.array_equal(li, ref["li"]) and np.array_equal(hi, ref["hi"]), "inlier sets differ from the twin on the headline workload"
+        assert int(ref["hi"].sum()) > 0, "the headline workload must exercise ekf_update_hi_inliers in every step"
+    xg, Pg = f.get_x_k_k(), f.get_p_k_k()
+    scale = np.abs(P).max()
+    assert np.abs(Pg - P).max() < tol_P * scale, np.abs(Pg - P).max() / scale
+    assert np.abs(xg - x).max() < tol_x, np.abs(xg - x).max()
+    f.close()
+
+
 def test_config2_N200_fp64_matches_the_c_oracle(pre3, orc):
     N, n_hyp = 200, 100
     seq = synth.make_sequence(N, 2, n_hyp)

@@ -4,7 +4,7 @@
 # factorisation launches).  Then: python tools/make_profiles.py <tag>
 tag=${1:-r3}
 R=$GRAFT_REPO_ROOT
-B="python3 $R/bench.py --no-cpu-baseline --no-extra-legs --no-check --no-hi-steps 0"
+B="python3 $R/bench.py --no-cpu-baseline --no-extra-legs --no-check --legacy-steps 0"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_trace -o $tag -- $B --steps 40 --warmup 5 > $R/gpurun_out/${tag}_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${tag}_pmc_fetch -o f -- $B --steps 10 --warmup 2 > $R/gpurun_out/${tag}_pmc_fetch.log 2>&1

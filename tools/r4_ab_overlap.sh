@@ -13,7 +13,7 @@ for l in sys.stdin:
 done; done
 cd /tmp && export TMPDIR=/tmp
 for x in 1 0; do
-  PRE3_K9_OVERLAP=$x rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r4_ov${x}_trace -o t -- python3 $R/bench.py --no-cpu-baseline --no-extra-legs --no-check --no-hi-steps 0 --steps 40 --warmup 5 > $R/gpurun_out/r4_ov${x}_trace.log 2>&1
+  PRE3_K9_OVERLAP=$x rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r4_ov${x}_trace -o t -- python3 $R/bench.py --no-cpu-baseline --no-extra-legs --no-check --legacy-steps 0 --steps 40 --warmup 5 > $R/gpurun_out/r4_ov${x}_trace.log 2>&1
 done
 cd $R
 for x in 1 0; do
