@@ -2,7 +2,7 @@
 # On the GPU box: the rocprofv3 passes behind profiles/<tag>_* (kernel trace + stats of bench.py, the two HBM-byte PMC passes of the
 # same command -- separate passes, counters only with --kernel-trace --, the matcher's kernel trace, and the SQ counters of the
 # factorisation launches).  Then: python tools/make_profiles.py <tag>
-tag=${1:-r3}
+tag=${1:-r4}
 R=$GRAFT_REPO_ROOT
 B="python3 $R/bench.py --no-cpu-baseline --no-extra-legs --no-check --legacy-steps 0"
 cd /tmp && export TMPDIR=/tmp

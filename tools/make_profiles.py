@@ -8,10 +8,11 @@ usage: python tools/make_profiles.py [tag]      (tag defaults to r1)"""
 import csv, json, os, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 K9 = "k_downdate_b3"
+FUSED = "k_cholp"      # round 4: the LI update's down-date runs inside the persistent factorisation's launch (pre3_cholp.hip)
 
 def find(d, name):
     for dp, _, fs in os.walk(os.path.join(G, d)):
@@ -24,8 +25,8 @@ shutil.copy(find("%s_trace" % tag, "%s_kernel_stats.csv" % tag), os.path.join(P,
 tl = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_timeline.py"), find("%s_trace" % tag, "%s_kernel_trace.csv" % tag), "3"],
                     capture_output=True, text=True, check=True).stdout
 with open(os.path.join(P, "%s_bench_one_step_timeline.txt" % tag), "w") as fh:
-    fh.write("# one filter step (N=500, n=3013, 200 hypotheses, f32, RANSAC threshold 0.5 px: LI update ~540 rows + HI update ~12 rows at this point of the sequence) from rocprofv3 "
-             "--kernel-trace of `python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extra-legs --no-check --no-hi-steps 0`\n# (the profiler adds ~10 % to the step; unprofiled numbers are in DESIGN.md section 8)\n" + tl)
+    fh.write("# one filter step of the headline workload (N=500, n=3013, 200 hypotheses, f32, RANSAC threshold 1.0 px, motion noise 2.5: LI update ~550 rows + an HI update) from rocprofv3 "
+             "--kernel-trace of `python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extra-legs --no-check --legacy-steps 0`\n# (the profiler adds ~10 % to the step; unprofiled numbers are in DESIGN.md section 8)\n" + tl)
 
 
 def counter(dirname, prefix, name):
@@ -35,7 +36,7 @@ def counter(dirname, prefix, name):
     return dict(launches=len(v), avg_KB=sum(v) / len(v), max_KB=max(v), li_launch_avg_KB=sum(big) / len(big))
 
 
-fs, ws = counter("%s_pmc_fetch" % tag, "f", "FETCH_SIZE"), counter("%s_pmc_write" % tag, "w", "WRITE_SIZE")
+fs, ws = counter("%s_pmc_fetch" % tag, "f", "FETCH_SIZE"), counter("%s_pmc_write" % tag, "w", "WRITE_SIZE")      # (round 4: the K9 launches left are the HI updates')
 tr = [r for r in csv.DictReader(open(find("%s_trace" % tag, "%s_kernel_trace.csv" % tag))) if K9 in r["Kernel_Name"]]
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
 big = [d for d in dur if d > 0.6 * max(dur)]
@@ -81,6 +82,50 @@ if sqk:
 with open(os.path.join(P, "%s_pmc_k9.json" % tag), "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps(out["counters_KB"], indent=1), out["k9_trace_durations_us"], out["hbm_bytes_per_li_launch"])
+
+# ---- round 4: the fused launch (k_cholp with the down-date consumers inside): HBM bytes and SQ counters of its LI launches
+def counter_k(dirname, prefix, name, kern):
+    rows = [r for r in csv.DictReader(open(find(dirname, "%s_counter_collection.csv" % prefix))) if kern in r["Kernel_Name"] and r["Counter_Name"] == name]
+    v = [float(r["Counter_Value"]) for r in rows]
+    big = [x for x in v if x > 0.6 * max(v)]
+    return dict(launches=len(v), li_launches=len(big), li_launch_avg_KB=sum(big) / len(big))
+try:
+    ff, wf = counter_k("%s_pmc_fetch" % tag, "f", "FETCH_SIZE", FUSED), counter_k("%s_pmc_write" % tag, "w", "WRITE_SIZE", FUSED)
+    trf = [r for r in csv.DictReader(open(find("%s_trace" % tag, "%s_kernel_trace.csv" % tag))) if FUSED in r["Kernel_Name"]]
+    durf = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in trf]
+    bigf = [d for d in durf if d > 0.6 * max(durf)]
+    fo = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE|<SQ sets> --kernel-trace --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra-legs --no-check --legacy-steps 0 (separate passes)",
+          "kernel": "k_cholp with the down-date consumers inside (update.m:32-38 of an LI update in one launch)",
+          "counters_KB": {"FETCH_SIZE": ff, "WRITE_SIZE": wf},
+          "trace_durations_us": {"launches": len(durf), "li_launches": len(bigf), "li_launch_avg": sum(bigf) / len(bigf), "li_launch_median": sorted(bigf)[len(bigf) // 2]},
+          "mean_rows": "~550 (headline workload, 9 panels)",
+          "hbm_bytes_per_li_launch": {"raw": 1024.0 * (ff["li_launch_avg_KB"] + wf["li_launch_avg_KB"]), "fetch_doubled": 1024.0 * (2 * ff["li_launch_avg_KB"] + wf["li_launch_avg_KB"])},
+          "notes": ["algorithmic per LI launch (r ~ 550, n = 3013): P upper triangle read 18.2 MB + P written 36.3 MB (tile + mirror) + W (f32) written 6.6 MB + its bf16 planes written 10 MB and read by the consumers + S / HP read 7.8 MB",
+                    "FETCH_SIZE on gfx950 reports half the bytes of 16 B/lane streams (MI355X_MICROARCH.md): the read side lies between the raw figure and twice it"]}
+    sqf = {}
+    sqd1 = os.path.join(G, "%s_pmc_sq" % tag)
+    if os.path.isdir(sqd1):
+        for dp, _, fs_ in sorted(os.walk(sqd1)):
+            for fn in fs_:
+                if fn.endswith("counter_collection.csv"):
+                    acc = {}
+                    for r in csv.DictReader(open(os.path.join(dp, fn))):
+                        if FUSED in r["Kernel_Name"]:
+                            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                    for k_, v in acc.items():
+                        top = [x for x in v if x > 0.6 * max(v)] if max(v) > 0 else v
+                        sqf[k_] = {"li_launch_avg": sum(top) / len(top), "launches": len(top)}
+    if sqf:
+        fo["sq_counters_per_li_launch"] = sqf
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in sqf and "GRBM_GUI_ACTIVE" in sqf:
+            cyc = sqf["GRBM_GUI_ACTIVE"]["li_launch_avg"] / 8.0
+            fo["mfma_busy_fraction_of_chip"] = sqf["SQ_VALU_MFMA_BUSY_CYCLES"]["li_launch_avg"] / (cyc * 1024.0)
+            fo["implied_clock_GHz"] = cyc / (fo["trace_durations_us"]["li_launch_avg"] * 1e3)
+    with open(os.path.join(P, "%s_pmc_cholp.json" % tag), "w") as fh:
+        json.dump(fo, fh, indent=1)
+    print("fused launch:", json.dumps(fo["trace_durations_us"]), fo["hbm_bytes_per_li_launch"], fo.get("mfma_busy_fraction_of_chip"))
+except Exception as e:
+    print("no fused-launch PMC summary:", repr(e))
 
 # ---- the factorisation + solve as one persistent launch (k_cholp, round 3): durations of the LI launches (r ~ 640: ten panels) and of the HI
 #      launches (one panel), and the SQ counters of its launches
