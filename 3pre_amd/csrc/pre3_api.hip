@@ -915,6 +915,19 @@ int pre3_update_hi(pre3_ctx *c)
     int n_hi = 0;
     if (c->hi_from_host >= 0) n_hi = c->hi_from_host;
     else if (c->hi_kernel) { PRE3_TRY(wait_mail(c, 9, c->seq_collect)); n_hi = c->mail_host[5]; }
+    if (c->hi_fused) {
+        // pre3_step sent the collection and the update out as one device-driven pair of launches (k_hi_fused + its down-date): up to 32
+        // landmarks are done, only the Jnorm pass of update.m:42-46 is left; more than that take the general path now
+        c->hi_fused = false;
+        if (c->hi_from_host < 0 && n_hi <= 32) {
+            if (n_hi > 0) {
+                c->hp_all_valid = false;
+                if (c->leave_jn_to_predict) c->jn_pending = true;
+                else PRE3_TRY(launch_jnorm(c, 0));
+            }
+            return PRE3_OK;
+        }
+    }
     return update_selected(c, PRE3_X_K_K, n_hi, c->sel_rows);
 }
 
@@ -1021,6 +1034,17 @@ int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, co
     }
     if (ran) for (int i = 0; i < 4; ++i) st[i] = c->mail_host[i];
     if (trace) t3 = now();
+    if (hi_fused_usable(c)) {
+        // mono_slam.m:184 + :187 without the host in between: the chi2 gate, then the collection and the HI update of up to 32 landmarks as ONE
+        // launch that reads the count on the device, and its down-date behind it (pre3_update.hip, k_hi_fused)
+        PRE3_CHECK(c->p_which == PRE3_X_K_K && c->x_valid[PRE3_X_K_K], PRE3_E_STATE, "pre3_step: the LI update did not leave (x_k_k, p_k_k)");
+        if (c->rescue_projected) PRE3_TRY(launch_innovation(c, 1, chi2, false, false));
+        else PRE3_TRY(launch_project_innovation(c, PRE3_X_K_K, 0, 1, chi2, false));
+        c->rescue_projected = false;
+        c->hi_from_host = -1; c->hi_kernel = true;
+        PRE3_TRY(launch_hi_fused(c, ++c->seq_collect));
+        c->hi_fused = true;
+    } else
     PRE3_TRY(pre3_rescue(c, chi2, nullptr));                        // mono_slam.m:184
     if (trace) t4 = now();
     if (c->defer_hi) c->hi_pending = true;                          // mono_slam.m:187, completed at the next call on this context

@@ -808,13 +808,13 @@ int launch_project(pre3_ctx *c, int which, int clear_first)
 
 
 // project + innovation (+ the HI collection in mode 1) with one kernel boundary less
-int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode, double chi2)
+int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode, double chi2, bool collect)
 {
     const double *x = which == PRE3_X_K_K ? c->x_kk : c->x_km1;
     int32_t *clr = (int32_t *)((unsigned char *)c->inbox_dev + c->off_flags);
     const int n_clr = mode == 0 ? (int)(c->flags_bytes / sizeof(int32_t)) : 0;
     HiArgs ha{};
-    if (mode == 1) ha = HiArgs{ hi_fuse() ? 1 : 0, c->m, ++c->seq_collect, c->meas, c->hi_meas, c->sel_rows, c->stats, c->mail_dev, c->chol_arrive + 2 };
+    if (mode == 1 && collect) ha = HiArgs{ hi_fuse() ? 1 : 0, c->m, ++c->seq_collect, c->meas, c->hi_meas, c->sel_rows, c->stats, c->mail_dev, c->chol_arrive + 2 };
     dim3 g(ceil_div(c->N * 16, 256)), b(256);
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_project_innovation<double>, g, b, 0, c->stream, c->N, c->lm.type, c->lm.off, x, to_camd(c->cam), clear_first,
@@ -824,16 +824,16 @@ int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode,
                            (const float *)c->P, c->ld, c->lm.Hc, c->lm.Hl, c->lm.has_h, mode, chi2, c->lm.h, c->lm.z, c->lm.ic, c->lm.li,
                            c->lm.hi, c->lm.S, c->lm.has_S, clr, n_clr, ha));
     PRE3_HIP(hipGetLastError());
-    if (mode == 1 && !ha.fuse) PRE3_TRY(launch_collect_hi(c, ha));
+    if (mode == 1 && collect && !ha.fuse) PRE3_TRY(launch_collect_hi(c, ha));
     return PRE3_OK;
 }
 
-int launch_innovation(pre3_ctx *c, int mode, double chi2, bool clear_flags)
+int launch_innovation(pre3_ctx *c, int mode, double chi2, bool clear_flags, bool collect)
 {
     int32_t *clr = (int32_t *)((unsigned char *)c->inbox_dev + c->off_flags);
     const int n_clr = clear_flags ? (int)(c->flags_bytes / sizeof(int32_t)) : 0;
     HiArgs ha{};
-    if (mode == 1) ha = HiArgs{ hi_fuse() ? 1 : 0, c->m, ++c->seq_collect, c->meas, c->hi_meas, c->sel_rows, c->stats, c->mail_dev, c->chol_arrive + 2 };
+    if (mode == 1 && collect) ha = HiArgs{ hi_fuse() ? 1 : 0, c->m, ++c->seq_collect, c->meas, c->hi_meas, c->sel_rows, c->stats, c->mail_dev, c->chol_arrive + 2 };
     dim3 g(ceil_div(c->N * 16, 256)), b(256);
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_innovation<double>, g, b, 0, c->stream, c->N, c->lm.type, c->lm.off, (const double *)c->P, c->ld, c->lm.Hc,
@@ -841,7 +841,7 @@ int launch_innovation(pre3_ctx *c, int mode, double chi2, bool clear_flags)
         hipLaunchKernelGGL(k_innovation<float>, g, b, 0, c->stream, c->N, c->lm.type, c->lm.off, (const float *)c->P, c->ld, c->lm.Hc,
                            c->lm.Hl, c->lm.has_h, mode, chi2, c->lm.h, c->lm.z, c->lm.ic, c->lm.li, c->lm.hi, c->lm.S, c->lm.has_S, clr, n_clr, ha));
     PRE3_HIP(hipGetLastError());
-    if (mode == 1 && !ha.fuse) PRE3_TRY(launch_collect_hi(c, ha));
+    if (mode == 1 && collect && !ha.fuse) PRE3_TRY(launch_collect_hi(c, ha));
     return PRE3_OK;
 }
 

@@ -160,6 +160,7 @@ struct pre3_ctx {
     // down-date consumers inside the persistent factorisation (pre3_cholp.hip): group records, all tiles in group order, first tile per group
     int32_t *dd_groups = nullptr; int dd_n_groups = 0; void *dd_tiles = nullptr; std::vector<int> dd_tile_off;
     bool k9_overlap = true;                       // PRE3_OPT_K9_OVERLAP
+    bool hi_fused = false;                        // the rescue stage's collection + HI update went out as k_hi_fused (pre3_step): pre3_update_hi only has the count to read
     bool x_done = false;                          // ... and its strips have computed x_k_k = x_prior + W'(L^-1 nu) as well (update.m:36,42,48)
     bool proj_with_jnorm = false;                 // the rescue's projection rides in the next k_jnorm_P launch (no K9 launch to carry it)
     int dd_done = 0;                              // groups the last k_cholp launch has down-dated (consumed by the next launch_downdate)
@@ -200,8 +201,8 @@ constexpr int DESC_DIM = 128;
 
 // ---- geometry / RANSAC kernels (pre3_geom.hip)
 int launch_project(pre3_ctx *c, int which, int clear_first);
-int launch_innovation(pre3_ctx *c, int mode /*0: S=HPH'+I for predicted; 1: rescue gate + HI list*/, double chi2, bool clear_flags = false);
-int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode, double chi2);
+int launch_innovation(pre3_ctx *c, int mode /*0: S=HPH'+I for predicted; 1: rescue gate + HI list*/, double chi2, bool clear_flags = false, bool collect = true /* mode 1: the HI list follows (k_collect_hi) */);
+int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode, double chi2, bool collect = true);
 int launch_update_x(pre3_ctx *c, int which_prior, int r);
 int launch_jnorm(pre3_ctx *c, int which);
 
@@ -221,5 +222,7 @@ int launch_gather_li(pre3_ctx *c, int nsel /* < 0: count read on the device */, 
 int launch_ell_HP(pre3_ctx *c, int r, void *dst /*r_pad x ldw*/, bool with_nu);
 int launch_ell_G(pre3_ctx *c, int r, const void *HPsrc, void *dst, int ldg, int add_identity, const void *Rdense, bool lower_only = false);
 int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior = -1 /* >= 0: also x <- x_prior + W'y (update.m:36) */);
+bool hi_fused_usable(const pre3_ctx *c);
+int launch_hi_fused(pre3_ctx *c, int32_t seq);        /* the HI collection + update of up to 32 landmarks without the host (k_hi_fused + its down-date) */
 
 }  // namespace pre3

@@ -178,7 +178,9 @@ __global__ __launch_bounds__(256) void k_ell_G_hyp(const int32_t *__restrict__ h
 
 // PRO: the workgroup first applies the update of panel J-1 to its own blocks (diagonal block and X), i.e. the K = J
 // column of the trailing update, so that the launch of panel J does not have to wait for a separate trail kernel.
-template <typename T, bool PRO, bool EARLY = false>
+// PREBUILT: the raw diagonal block (Ls) and the workgroup's X block (Xs) are already in LDS (k_hi_fused computes them there): no global loads,
+// and nobody reads the raw diagonal block from global memory, so workgroup 0 need not wait before it stores L_JJ over it.
+template <typename T, bool PRO, bool EARLY = false, bool PREBUILT = false>
 __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb,
                                                 int32_t *__restrict__ status, const int b, unsigned int *__restrict__ arrive, unsigned int target,
                                                 void *__restrict__ Wp = nullptr, int nst_total = 0, int ld = 0, void *__restrict__ Sp = nullptr, int sp_stride = 0,
@@ -206,7 +208,7 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
     frag_t fA[4][3], fB[4][3];                                 // pending update of this wave's tile: A operand (rows) and B operand (columns)
     const int w0 = (wv >> 1) * 32, w1 = (wv & 1) * 32, fa = wv >> 1, fb = wv & 1;
     const bool tile_live = worker && (xside ? hasX : wv != 1);  // (the D tile above the diagonal is never read)
-    if (worker) {
+    if (!PREBUILT && worker) {
         // every global load of the wave is issued before its first LDS store: the raw 64x64 block (D workers: the diagonal block,
         // X workers: the workgroup's own block) and, for the pending update of panel J-1, the operands of THIS wave's tile
         T g[16], gp[16];
@@ -280,7 +282,7 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
     PROBE_STAMP(4);
     // every workgroup reads the raw diagonal block; workgroup 0 overwrites it with L_JJ at the end and must not do so
     // before all of them have it (they normally start together, but nothing guarantees that for very large grids)
-    if (tid == 0 && b != 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!PREBUILT && tid == 0 && b != 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     typename ChW<T>::acc_t acc[ChW<T>::NBLK][ChW<T>::NBLK];        // this worker wave's tile of D or X, in MFMA accumulator layout
     bool acc_loaded = false;
     if (PRO && planes) {
@@ -357,7 +359,7 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
     PROBE_STAMP(2);
     if (bad && role == 0 && (tid & 63) == 0 && b == 0) atomicExch(status, 1);
     if (b == 0) {
-        if (tid == 0) {
+        if (!PREBUILT && tid == 0) {
             bounded_wait(arrive, target, status + 1);        // status + 1 = stats[7], the wait guard (a give-up is reported as PRE3_E_HIP)
         }
         __syncthreads();
@@ -648,6 +650,141 @@ __global__ __launch_bounds__(CH_NTH) void k_chol_step(T *__restrict__ S, int lds
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// rescue_hi_inliers.m:44-47 + ekf_update_hi_inliers.m:45-58 up to the down-date, for at most 32 rescued landmarks (64 rows), in ONE launch
+// that reads nothing from the host: every workgroup (0: the diagonal block; 1..: the 64-column strips of [HP | nu]) collects the HI list from
+// the gate's flags, builds the measurement rows, multiplies out its own block of H*P and the whole of S = H*P*H' + I in LDS, and runs the
+// one-panel chain on them (chol_panel_body, PREBUILT).  Replaces k_collect_hi -> [host poll] -> k_ell_HP_build -> k_ell_G -> k_chol_step.
+// The arithmetic is theirs term for term (H*P: the 13-term fma chain of k_ell_HP_build; S: k_ell_G's sum over a row's non-zeros of H*P at
+// those columns), so the factor, W and its planes are the same bits.  Workgroup 0 also does k_collect_hi's bookkeeping (hi_meas, sel_rows,
+// stats[5], the mailbox) and the rows for later readers.  stats[8] <- 1 iff the update was done here (1 <= count <= 32): the speculative
+// down-date behind this launch runs on that word; count == 0: nothing to do, the next prediction's Jnorm pass gets the identity;
+// count > 32: the host takes the general path once it has polled the count.
+// ------------------------------------------------------------------------------------------------
+constexpr int HF_MAXL = 32, HF_NU = 7 + 6 * HF_MAXL, HF_TS = HF_NU + 2;
+struct HiFused {
+    int m; const int32_t *meas, *lm_ic, *lm_li, *lm_hi, *lm_type, *lm_off; const double *Hc, *Hl, *z, *h;
+    int32_t *hi_meas, *sel_rows, *stats, *mail; int seq;
+    int32_t *row_col; float *row_val; double *row_nu;
+    const float *P; int ld; float *S; float *W; int ldw; void *Wp; int nst_total; void *Sp; int sp_stride;
+    double *params;
+};
+struct HfSmem {
+    int list[HF_MAXL]; int cnt;
+    int rc[NB][13]; float rv[NB][13]; float nu[NB];
+    int ucol[HF_NU];
+    float T[NB][HF_TS];                           // T[a][k] = (H*P)(a, ucol[k]): the columns S needs
+};
+
+__global__ __launch_bounds__(CH_NTH) void k_hi_fused(HiFused a)
+{
+    __shared__ ChSmem<float> sm;
+    __shared__ HfSmem hf;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    // ---- the HI list (rescue_hi_inliers.m:44-46: ic && !li && hi), in measurement order: one wave, ballots
+    if (tid < 64) {
+        int cnt = 0;
+        for (int base = 0; base < a.m; base += 64) {
+            const int j = base + tid;
+            int in = 0;
+            if (j < a.m) { const int i = a.meas[j]; in = (a.lm_ic[i] == 1 && a.lm_li[i] == 0) ? a.lm_hi[i] : 0; }
+            if (b == 0 && j < a.m) a.hi_meas[j] = in;
+            const unsigned long long mask = __ballot(in);
+            const int pos = cnt + __popcll(mask & ((1ull << tid) - 1ull));
+            if (in && pos < HF_MAXL) hf.list[pos] = j;
+            if (in && b == 0) a.sel_rows[pos] = j;
+            cnt += __popcll(mask);
+        }
+        if (tid == 0) hf.cnt = cnt;
+    }
+    __syncthreads();
+    const int cnt = hf.cnt, r = 2 * cnt;
+    const bool here = cnt >= 1 && cnt <= HF_MAXL;
+    if (b == 0 && tid == 0) {
+        a.stats[5] = cnt; a.stats[8] = here ? 1 : 0;
+        if (cnt == 0) for (int t = 0; t < 16; ++t) a.params[96 + t] = (t % 5 == 0) ? 1.0 : 0.0;      // no update: the pending Jnorm pass is the identity
+        a.mail[5] = cnt;
+        __threadfence_system();
+        __hip_atomic_store(&a.mail[9], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (!here) return;
+    // ---- the rows (k_build_rows / k_ell_HP_build): row 2s+c of HI measurement s = [Hc(c,:) | Hl(c,:)] at columns [0..6 | off..off+d-1], nu = z - h
+    if (tid < NB) {
+        const int row = tid;
+        if (row < r) {
+            const int i = a.meas[hf.list[row >> 1]], c = row & 1;
+            const int d = a.lm_type[i] == PRE3_INVDEPTH ? 6 : 3, off = a.lm_off[i];
+#pragma unroll
+            for (int t = 0; t < 7; ++t) { hf.rc[row][t] = t; hf.rv[row][t] = (float)a.Hc[14 * i + 7 * c + t]; }
+#pragma unroll
+            for (int t = 0; t < 6; ++t) { hf.rc[row][7 + t] = t < d ? off + t : 0; hf.rv[row][7 + t] = t < d ? (float)a.Hl[12 * i + 6 * c + t] : 0.f; }
+            const double nu = a.z[2 * i + c] - a.h[2 * i + c];
+            hf.nu[row] = (float)nu;
+            if (c == 0) {
+#pragma unroll
+                for (int t = 0; t < 6; ++t) hf.ucol[7 + 6 * (row >> 1) + t] = t < d ? off + t : 0;
+            }
+            if (b == 0) a.row_nu[row] = nu;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 13; ++t) { hf.rc[row][t] = 0; hf.rv[row][t] = 0.f; }
+            hf.nu[row] = 0.f;
+            if (b == 0) a.row_nu[row] = 0;
+        }
+        if (row < 7) hf.ucol[row] = row;
+    }
+    __syncthreads();
+    if (b == 0) {                                  // the rows in their ELL form for whoever reads them after this launch
+        for (int idx = tid; idx < NB * ELLW; idx += CH_NTH) {
+            const int row = idx >> 4, t = idx & 15;
+            a.row_col[idx] = t < 13 ? hf.rc[row][t] : 0; a.row_val[idx] = t < 13 ? hf.rv[row][t] : 0.f;
+        }
+    }
+    const int nU = 7 + 6 * cnt;
+    // ---- T = (H*P) at the columns of the selected rows, and this workgroup's own block of [H*P | nu]
+    for (int idx = tid; idx < r * nU; idx += CH_NTH) {
+        const int row = idx / nU, k = idx - row * nU;
+        const float *pc = a.P + hf.ucol[k];
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 13; ++t) s = fmaf(hf.rv[row][t], pc[(size_t)hf.rc[row][t] * a.ld], s);
+        hf.T[row][k] = s;
+    }
+    if (b >= 1) {
+        const int c0 = (b - 1) * NB;
+        for (int idx = tid; idx < NB * NB; idx += CH_NTH) {
+            const int row = idx >> 6, i = idx & 63, j = c0 + i;
+            float s = 0.f;
+            if (row < r) {
+                if (j < a.ld) {
+                    const float *pc = a.P + j;
+#pragma unroll
+                    for (int t = 0; t < 13; ++t) s = fmaf(hf.rv[row][t], pc[(size_t)hf.rc[row][t] * a.ld], s);
+                } else if (j == a.ld) s = hf.nu[row];
+            }
+            sm.Xs[row][i] = s;
+        }
+    }
+    __syncthreads();
+    // ---- S = H*P*H' + I on and below the diagonal (k_ell_G: sum over the non-zeros of row b of H*P(a, .) there), identity padding
+    for (int idx = tid; idx < NB * NB; idx += CH_NTH) {
+        const int ra = idx >> 6, rb = idx & 63;
+        float s = 0.f;
+        if (rb <= ra) {
+            if (ra < r) {
+                const int kb = 7 + 6 * (rb >> 1);
+#pragma unroll
+                for (int t = 0; t < 13; ++t) s = fmaf(hf.rv[rb][t], hf.T[ra][t < 7 ? t : kb + t - 7], s);
+                if (ra == rb) s += 1.f;
+            } else s = ra == rb ? 1.f : 0.f;
+        }
+        sm.Ls[ra][rb] = s;
+    }
+    __syncthreads();
+    chol_panel_body<float, false, true, true>(sm, a.S, NB, a.W, a.ldw, 0, 1, a.stats + 6, b, nullptr, 0u, a.Wp, a.nst_total, a.ld, a.Sp, a.sp_stride, r);
+}
+
+
 // K' = L^-T W  (so that K = W' L^-1 ... = P H' inv(S)); slow back substitution, one lane per state row.
 // Only the stateless drop-in returns K (no caller in the reference uses it).  Kt: r_pad x ldw.
 template <typename T>
@@ -911,7 +1048,8 @@ __device__ __forceinline__ void update_x_block(int blk, int n, int r, const T *_
     if (rg == 0 && i < n) x_out[i] = s;
 }
 
-struct XUpd { int n_tiles, n, r; const double *x_prior; double *x_out; double *params; };
+struct XUpd { int n_tiles, n, r; const double *x_prior; double *x_out; double *params;
+              const int32_t *gate; };   // gate != nullptr (the speculative down-date behind k_hi_fused): run only if gate[8] == 1, with r = 2 * gate[5] rows
 
 // waves_per_eu: the riders' fp64 geometry must not raise the register count of the tile path (5 workgroups per CU in fp32,
 // 4 in fp64 -- every tile resident at once); if anything spills, it is the riders.
@@ -1260,11 +1398,12 @@ __global__ __launch_bounds__(256) void k_downdate_b3(float *__restrict__ P, int 
 {
     __shared__ __attribute__((aligned(16))) bf16x8_t smem[B3_NBUF * 2 * B3_GRAN];       // 24 KB per ring slot: [slot][A | B][plane][fragment][lane]
     static_assert(sizeof(smem) >= 4 * 32 * 33 * sizeof(float) && sizeof(smem) >= sizeof(double) * (16 * 64 + 4), "patches and riders borrow the ring");
+    if (xu.gate != nullptr && xu.gate[8] != 1) return;          // the fused HI update in front found nothing to do (or too much: the host follows up)
     if ((int)blockIdx.x >= xu.n_tiles) {            // riders, as in k_downdate_1t
         __builtin_amdgcn_s_setprio(3);
         const int nx = (xu.n + 63) / 64, rb = blockIdx.x - xu.n_tiles;
         if (rb < nx) {
-            update_x_block<float>(rb, xu.n, xu.r, W, ldw, ld, xu.x_prior, xu.x_out, xu.params, reinterpret_cast<double *>(smem));
+            update_x_block<float>(rb, xu.n, xu.gate != nullptr ? 2 * xu.gate[5] : xu.r, W, ldw, ld, xu.x_prior, xu.x_out, xu.params, reinterpret_cast<double *>(smem));
             if (pr.n_blocks) ride_signal(pr.ctr);
         } else {
             proj_ride_block(pr, rb - nx);
@@ -1488,7 +1627,7 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
             n_tiles_launch = c->dd_tile_off.back() - t0;
         }
         c->dd_done = 0;
-        XUpd xu{ n_tiles_launch, c->n, r, which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1, c->x_kk, c->pred_params };
+        XUpd xu{ n_tiles_launch, c->n, r, which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1, c->x_kk, c->pred_params, nullptr };
         const bool x_done = c->x_done && which_prior >= 0;            // the factorisation's strips have computed x_k_k already
         c->x_done = false;
         const int nx = (which_prior >= 0 && !x_done) ? ceil_div(c->n, 64) : 0;
@@ -1508,7 +1647,7 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
                                tiles, xu, pr);
         }
     } else if (one_tile) {
-        XUpd xu{ c->n_tiles, c->n, r, which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1, c->x_kk, c->pred_params };
+        XUpd xu{ c->n_tiles, c->n, r, which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1, c->x_kk, c->pred_params, nullptr };
         const int nx = which_prior >= 0 ? ceil_div(c->n, 64) : 0;
         ProjRide pr{};
         if (nx > 0 && c->ride_rescue_projection && c->N > 0) {      // the rescue's projection (stale h kept: clear_first = 0) rides along
@@ -1529,6 +1668,36 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
         c->kt.bytes += 1.5 * c->n * (double)c->n * c->esz + (double)c->n * (double)r * c->esz;
     }
     PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
+// rescue_hi_inliers.m:44-47 + ekf_update_hi_inliers.m:45-58 without the host: k_hi_fused (collection, rows, H*P, S, one-panel factorisation and
+// solve for up to 32 rescued landmarks) and, right behind it, the down-date of that update, which runs only if k_hi_fused says it did the update
+// (stats[8]) and takes its row count from the device.  seq: the mailbox sequence number the collection publishes.
+bool hi_fused_usable(const pre3_ctx *c)
+{
+    static const int env = getenv("PRE3_HI_FUSED") ? atoi(getenv("PRE3_HI_FUSED")) : 1;
+    return env != 0 && c->dtype == PRE3_F32 && c->k9_b3 && c->Wp != nullptr && c->Sp != nullptr && c->m > 0 && c->rcap >= NB && c->N > 0;
+}
+
+int launch_hi_fused(pre3_ctx *c, int32_t seq)
+{
+    HiFused a{};
+    a.m = c->m; a.meas = c->meas; a.lm_ic = c->lm.ic; a.lm_li = c->lm.li; a.lm_hi = c->lm.hi; a.lm_type = c->lm.type; a.lm_off = c->lm.off;
+    a.Hc = c->lm.Hc; a.Hl = c->lm.Hl; a.z = c->lm.z; a.h = c->lm.h;
+    a.hi_meas = c->hi_meas; a.sel_rows = c->sel_rows; a.stats = c->stats; a.mail = c->mail_dev; a.seq = seq;
+    a.row_col = c->row_col; a.row_val = (float *)c->row_val; a.row_nu = c->row_nu;
+    a.P = (const float *)c->P; a.ld = c->ld; a.S = (float *)c->Smat; a.W = (float *)c->W; a.ldw = c->ldw;
+    a.Wp = c->Wp; a.nst_total = c->rcap / B3_BK; a.Sp = c->Sp; a.sp_stride = c->rcap / NB; a.params = c->pred_params;
+    hipLaunchKernelGGL(k_hi_fused, dim3(1 + c->ldw / NB), dim3(CH_NTH), 0, c->stream, a);
+    // the down-date of that update (one panel: four k-stages), the x-update riding along; every workgroup leaves at once unless stats[8] == 1
+    XUpd xu{ c->n_tiles128, c->n, 0, c->x_kk, c->x_kk, c->pred_params, c->stats };
+    const int nx = ceil_div(c->n, 64);
+    ProjRide pr{};
+    hipLaunchKernelGGL(k_downdate_b3, dim3(c->n_tiles128 + nx), dim3(256), 0, c->stream, (float *)c->P, c->ld, (const bf16x8_t *)c->Wp, c->rcap / B3_BK, 4,
+                       (const float *)c->W, c->ldw, (const int2 *)c->tiles128, xu, pr);
+    PRE3_HIP(hipGetLastError());
+    c->split_rows = 0; c->dd_done = 0; c->x_done = false; c->cholp_done = false;
     return PRE3_OK;
 }
 
