@@ -681,14 +681,22 @@ __global__ __launch_bounds__(CH_NTH) void k_hi_fused(HiFused a)
     __shared__ ChSmem<float> sm;
     __shared__ HfSmem hf;
     const int tid = threadIdx.x, b = blockIdx.x;
-    // ---- the HI list (rescue_hi_inliers.m:44-46: ic && !li && hi), in measurement order: one wave, ballots
+    // ---- the HI list (rescue_hi_inliers.m:44-46: ic && !li && hi), in measurement order.  The flags of all measurements are fetched by the
+    //      whole workgroup at once (two dependent load levels, paid once: a single wave walking the list chunk by chunk took 9 us), then one
+    //      wave compacts them from LDS with ballots.
+    unsigned char *flg = reinterpret_cast<unsigned char *>(&sm.Bs[0][0]);          // [m] (Bs is free until the chain; m <= 16 K)
+    for (int j = tid; j < a.m; j += CH_NTH) {
+        const int i = a.meas[j];
+        const int in = (a.lm_ic[i] == 1 && a.lm_li[i] == 0) ? a.lm_hi[i] : 0;
+        flg[j] = (unsigned char)(in != 0);
+        if (b == 0) a.hi_meas[j] = in;
+    }
+    __syncthreads();
     if (tid < 64) {
         int cnt = 0;
         for (int base = 0; base < a.m; base += 64) {
             const int j = base + tid;
-            int in = 0;
-            if (j < a.m) { const int i = a.meas[j]; in = (a.lm_ic[i] == 1 && a.lm_li[i] == 0) ? a.lm_hi[i] : 0; }
-            if (b == 0 && j < a.m) a.hi_meas[j] = in;
+            const int in = j < a.m ? flg[j] : 0;
             const unsigned long long mask = __ballot(in);
             const int pos = cnt + __popcll(mask & ((1ull << tid) - 1ull));
             if (in && pos < HF_MAXL) hf.list[pos] = j;
@@ -1677,7 +1685,7 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
 bool hi_fused_usable(const pre3_ctx *c)
 {
     static const int env = getenv("PRE3_HI_FUSED") ? atoi(getenv("PRE3_HI_FUSED")) : 1;
-    return env != 0 && c->dtype == PRE3_F32 && c->k9_b3 && c->Wp != nullptr && c->Sp != nullptr && c->m > 0 && c->rcap >= NB && c->N > 0;
+    return env != 0 && c->dtype == PRE3_F32 && c->k9_b3 && c->Wp != nullptr && c->Sp != nullptr && c->m > 0 && c->m <= 16384 && c->rcap >= NB && c->N > 0;
 }
 
 int launch_hi_fused(pre3_ctx *c, int32_t seq)
