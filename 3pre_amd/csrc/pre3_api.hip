@@ -914,7 +914,12 @@ int pre3_update_hi(pre3_ctx *c)
     PRE3_TRY(check_ctx(c));
     int n_hi = 0;
     if (c->hi_from_host >= 0) n_hi = c->hi_from_host;
-    else if (c->hi_kernel) { PRE3_TRY(wait_mail(c, 9, c->seq_collect)); n_hi = c->mail_host[5]; }
+    else if (c->hi_kernel) {
+        PRE3_TRY(wait_mail(c, 9, c->seq_collect)); n_hi = c->mail_host[5];
+        // the collection stage also brings the device's error words: what went wrong in this step's launches fails THIS call
+        PRE3_CHECK(c->mail_host[7] == 0, PRE3_E_HIP, "a device-side wait on another workgroup gave up (counter never arrived): results are invalid");
+        PRE3_CHECK(c->mail_host[6] == 0, PRE3_E_NUMERIC, "innovation covariance S is not positive definite");
+    }
     if (c->hi_fused) {
         // pre3_step sent the collection and the update out as one device-driven pair of launches (k_hi_fused + its down-date): up to 32
         // landmarks are done, only the Jnorm pass of update.m:42-46 is left; more than that take the general path now

@@ -688,6 +688,9 @@ __device__ __forceinline__ void collect_hi_body(int m, const int32_t *__restrict
     if (tid == 0) {
         stats[5] = cnt;
         mail[5] = cnt;
+        // the device's error words ride along: a wait that gave up (stats[7]) or a factorisation that met a non-positive pivot (stats[6]) in the
+        // launches in front of this one -- the step's own LI update -- fails the call that reads this count, not some later pre3_get_state
+        mail[6] = stats[6]; mail[7] = stats[7];
         __threadfence_system();
         __hip_atomic_store(&mail[9], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

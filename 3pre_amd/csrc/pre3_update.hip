@@ -712,6 +712,7 @@ __global__ __launch_bounds__(CH_NTH) void k_hi_fused(HiFused a)
         a.stats[5] = cnt; a.stats[8] = here ? 1 : 0;
         if (cnt == 0) for (int t = 0; t < 16; ++t) a.params[96 + t] = (t % 5 == 0) ? 1.0 : 0.0;      // no update: the pending Jnorm pass is the identity
         a.mail[5] = cnt;
+        a.mail[6] = a.stats[6]; a.mail[7] = a.stats[7];       // (the device's error words, as k_collect_hi publishes them)
         __threadfence_system();
         __hip_atomic_store(&a.mail[9], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

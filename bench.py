@@ -593,6 +593,7 @@ def main():
     rehearsal = os.environ.get("PRE3_BENCH_REHEARSAL") == "gloo"
     if rehearsal:
         local_rank, COLL_DEV = 0, "cpu"
+        os.environ["PRE3_CHOL_FORM"] = "0"          # several processes on one device: their persistent launches could interleave
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s); refusing to print a line that would claim the wrong n_gpus\n" % (args.gpus, world))

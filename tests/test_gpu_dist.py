@@ -17,7 +17,8 @@ def _run_two_ranks(backend):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1", PRE3_TEST_BACKEND=backend,
-               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               PRE3_CHOL_FORM="0")      # two processes on ONE device: no persistent launches (they could interleave)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_gpu.py")]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
@@ -88,7 +89,7 @@ def test_resident_matcher_shards_equal_the_unsharded_match(orc=None):
     L2 = rng.integers(0, 255, (128, 700)).astype(np.uint8)
     L2[:, 50:250] = L1[:, :200]
     L2[:, 600] = L1[:, 3]                                       # a duplicate of a matched column: ties -> lowest index, ratio test fails
-    # uint8; the same descriptors as doubles (what matching_sift_based.m:104-118 passes: integer-valued -> the int8 route inside the shard);
+    # uint8; the same descriptors as doubles (what Lowe-format SIFT files such as box.sift hold (matching_sift_based.m:104-118 itself passes unit-norm real-valued doubles): integer-valued -> the int8 route inside the shard);
     # real-valued doubles and singles (bf16 rank + exact re-evaluation inside the shard)
     real1, real2 = L1 + rng.random(L1.shape), L2 + rng.random(L2.shape)
     real2[:, 600] = real1[:, 3]; real2[:, 53] = real1[:, 3]
