@@ -328,6 +328,43 @@ def fp64_n200_leg(pre3, synth, steps=40, warm=4):
                                         "how": "one predict + update from the same state: GPU (Cholesky solve, symmetric down-date) vs oracle/pre3_oracle.c (explicit inv(S), K*S*K')"}}
 
 
+def n2000_step_leg(pre3, synth, N=2000, n_hyp=1000, steps=6, warm=2):
+    """BASELINE.json configs[4]'s state size on ONE GPU, the whole step ("the scaling axis is state dimension n"): N=2000
+    landmarks (n=12013, P = 579 MB in fp32), 1000 hypotheses, ~1600 measured, LI update of ~2550 rows = 40 panels.  Steps/s, and the K9 launches
+    of the LI updates priced like `roofline` (HIP events on the library's stream).  At 40 panels the factorisation takes the launch-per-panel form
+    (the persistent launch keeps W's planes in LDS: 13 panels), so the down-date is a launch of its own here."""
+    seq = synth.make_sequence(N, steps + warm, n_hyp)
+    f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", max_hyp=n_hyp, std_z=1.0)
+    try:
+        f.set_x_p_k_k(seq["x0"], seq["P0"])
+        f.defer_hi_update(True)
+        for s in seq["steps"][:warm]:
+            f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=1.0, early_exit=False)
+        f.sync()
+        f.kernel_timing(1)
+        f.timer_start()
+        t0 = time.perf_counter()
+        st = [f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=1.0, early_exit=False) for s in seq["steps"][warm:warm + steps]]
+        ev = f.timer_stop()
+        el = time.perf_counter() - t0
+        kt = f.kernel_timing_read()
+        f.kernel_timing(False)
+        persistent = f.chol_persist()
+    finally:
+        f.close()
+    n = seq["n"]
+    t_s = kt["total_ms"] * 1e-3
+    fused = kt["launches"] > 0 and kt["fused"] == kt["launches"]
+    ach = (kt["flops"] + (kt["fact_flops"] if fused else 0.0)) / t_s / 1e12 if t_s > 0 else 0.0
+    return {"workload": "configs[4] size on one GPU: N=%d (n=%d), %d hypotheses (k=3, all evaluated), %d measured, f32 covariance path, full 1PRE step" % (N, n, n_hyp, len(seq["steps"][0]["meas_idx"])),
+            "value": steps / el, "unit": "steps/s", "ms_per_step": 1e3 * el / steps, "hip_event_ms_per_step": ev / steps,
+            "mean_li_rows": 2 * float(np.mean([s_["n_li"] for s_ in st])), "mean_hi_rows": 2 * float(np.mean([s_["n_hi"] for s_ in st])),
+            "factorisation": "one persistent launch with the down-date inside (k_cholp)" if fused else "launch per 64-row panel (k_chol_step; the persistent form holds <= 13 panels)",
+            "persistent_form_available": bool(persistent),
+            "k9": {"launches": kt["launches"], "avg_launch_us": 1e3 * kt["total_ms"] / max(kt["launches"], 1), "achieved": 6.0 * ach, "unit": "TFLOP/s", "peak": PEAK["bf16"],
+                   "frac": 6.0 * ach / PEAK["bf16"], "f32_equivalent_ratio": ach / PEAK["f32"], "algorithmic": "SYRK n(n+1)r per LI launch, x6 executed (three-way bf16 split)"}}
+
+
 def frame_leg(pre3, synth, N=500, K2=600, frames=40, warm=4, n_hyp=200):
     """One reference FRAME, not just the inner step (mono_slam.m:113-264): map_management (one delete_a_feature + one add_features_inverse_depth,
     map_management.m:27-79), ekf_prediction, search_IC_matches + matching_sift_based on the frame's SIFT set (K2 = 600 keypoints, SIFT_extract_save.m:68-89:
@@ -868,7 +905,7 @@ def main():
             holder.pop("comm").close()
         if world == 1:
             for name, fn in (("matcher", lambda: matcher_leg(pre3)), ("vo_ransac", lambda: vo_leg(pre3)), ("fp64_n200", lambda: fp64_n200_leg(pre3, synth)),
-                             ("frame", lambda: frame_leg(pre3, synth))):
+                             ("frame", lambda: frame_leg(pre3, synth)), ("n2000_step", lambda: n2000_step_leg(pre3, synth))):
                 try:
                     out[name] = fn()
                 except Exception as e:                          # pragma: no cover

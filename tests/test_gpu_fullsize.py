@@ -134,3 +134,30 @@ def test_config5_ransac_round_at_N2000_matches_the_twin(pre3):
             assert np.abs(out["support"].astype(int) - ref["support"]).max() <= 2
         assert (out["best"], out["max_support"]) == (ref["best"], ref["max_support"])
         assert np.array_equal(out["li_mask"], ref["li_mask"])
+
+
+def test_config5_size_one_full_step_at_N2000_matches_the_twin(pre3):
+    """the scaling axis is the state dimension.  One WHOLE step at BASELINE configs[4]'s size on one GPU -- N=2000 (n=12013),
+    1000 hypotheses, ~1600 measured, an LI update of ~2500 rows (40 panels of the factorisation), rescue, HI update -- fp32 covariance path
+    against the numpy twin (fp64): inlier sets and the RANSAC winner exact, P within 3e-4 of its scale and x within 2e-5 (the f32 tolerances of
+    the N=500 test above; the twin takes about a minute on the host)."""
+    from oracle import np_twin as tw
+    import oracle as orc
+    N, n_hyp = 2000, 1000
+    seq = synth.make_sequence(N, 1, n_hyp)
+    s = seq["steps"][0]
+    types, off, n = orc.landmark_table(np.zeros(N, int))
+    f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", max_hyp=n_hyp, std_z=1.0)
+    f.set_x_p_k_k(seq["x0"], seq["P0"])
+    st = f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=1.0, early_exit=False)
+    li, hi = f.get_flags()
+    xg, Pg = f.get_x_k_k(), f.get_p_k_k()
+    f.close()
+    ref = tw.step(types, off, seq["cam"], seq["x0"], seq["P0"], s["u"], s["meas_idx"], s["z"], s["hyp"], 1.0, early_exit=False)
+    r = ref["ransac"]
+    assert (st["best"], st["max_support"]) == (r["best"], r["max_support"])
+    assert np.array_equal(li, ref["li"]) and np.array_equal(hi, ref["hi"])
+    assert st["n_li"] + st["n_hi"] > 1000                                   # the update really has the 2000+ rows of the configuration
+    scale = np.abs(ref["P_kk"]).max()
+    assert np.abs(Pg - ref["P_kk"]).max() < 3e-4 * scale, np.abs(Pg - ref["P_kk"]).max() / scale
+    assert np.abs(xg - ref["x_kk"]).max() < 2e-5, np.abs(xg - ref["x_kk"]).max()
