@@ -5,7 +5,13 @@
 namespace pre3 {
 
 constexpr int CP_NTH = 768;          // crit: ten chain waves + two side waves; rows and strips use the first four waves
-constexpr int CP_MAX_NRB = 13;       // panels of 64 rows: the strips keep nrb - 1 blocks of W as bf16 planes in LDS (12 KB each) + 12 KB of scratch
+// Panels of 64 rows the one-launch form takes.  The strips keep the last 11 blocks of W as bf16 planes in LDS (a ring) and re-read older ones
+// from the planes they wrote, so the form WORKS for any count up to the 64 flag slots -- config 5's 40 panels included (round 4; correct, tested
+// at 15 and 16 panels) -- but it only PAYS while the strips' per-panel sum stays in the shadow of the chain: at 40 panels (N = 2000) the launch took
+// 1.69-1.82 ms against 1.73 ms for the launch-per-panel form (rocprofv3, gpurun_out/r4_n2000b): the strips' block loop is latency-bound (~2 us per
+// 64x32x64 block: its operands are requested one block ahead), 378 strips need two dispatch rounds on 256 CUs (the second one starts at 0.92 ms),
+// and the 38 row workgroups' tile traffic delays crit's next tiles from panel 10 on.  So updates beyond 16 panels keep the launch-per-panel form.
+constexpr int CP_MAX_NRB = 16;
 
 size_t cholp_flag_bytes(int n_strips);
 // the down-date consumers' group table for nb 64-column blocks (device records, the tiles in group order, first tile of each group)

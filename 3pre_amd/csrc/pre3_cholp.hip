@@ -41,8 +41,8 @@ typedef float f4v_t __attribute__((ext_vector_type(4)));
 #ifdef PRE3_PROBE
 // wall-clock stamps (s_memrealtime, 100 MHz, chip-wide) of the last launch: [role 0 crit main, 1 crit side, 2..15 rows, 16 strip 0, 17 last strip, 20 consumer 0, 21 last consumer][panel 16][slot 8]
 static __device__ unsigned long long g_cp[24 * 16 * 8];
-#define CP_CLK(role, J, slot) do { if ((threadIdx.x & 63) == 0) { unsigned long long t_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_cp[((role) * 16 + (J)) * 8 + (slot)] = t_; } } while (0)
-#define CP_STAMP(role, J, slot) do { if ((threadIdx.x & 63) == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_cp[((role) * 16 + (J)) * 8 + (slot)] = t_; } } while (0)
+#define CP_CLK(role, J, slot) do { if ((threadIdx.x & 63) == 0 && (J) < 16) { unsigned long long t_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_cp[((role) * 16 + (J)) * 8 + (slot)] = t_; } } while (0)
+#define CP_STAMP(role, J, slot) do { if ((threadIdx.x & 63) == 0 && (J) < 16) { unsigned long long t_; asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_cp[((role) * 16 + (J)) * 8 + (slot)] = t_; } } while (0)
 #else
 #define CP_STAMP(role, J, slot)
 #define CP_CLK(role, J, slot)
@@ -178,6 +178,8 @@ struct CpArgs {
     unsigned *cf; unsigned base;         // flags, epoch
     int32_t *status;                     // stats[6] (not positive definite), stats[7] (a wait gave up)
     const int32_t *n_dev; int nrb; int nrb_max; int n_strips;
+    int win;                             // strips: blocks of W kept in LDS (a ring: block K in slot K % win); older blocks are re-read from Wp
+    int stride;                          // crit and the rows are blocks 0, stride, 2 stride, ..
     int n; const double *x_prior; double *x_out; double *params; int xu;      // xu: the strips finish with x_out = x_prior + W'(L^-1 nu) (update.m:36,42,48)
     float *P; const int32_t *dd; int n_dd; int rows; int dd_mode;      // down-date consumers: group table (DG_WORDS each), groups in this launch, rows if host-known
 };
@@ -455,7 +457,7 @@ struct RowSmem {
     __attribute__((aligned(16))) frag_t NA[B3_SGRAN];            // planes of A(i, J): the operand of the next L(i, J)
     float patch[12][32 * 33];                                    // wave-private transposition patches
     unsigned cnt[4];                                             // arrivals of the four waves behind a hand-over to crit; [2]: bulk release
-    unsigned tick[16];                                           // per panel: the next bulk item
+    unsigned tick[64];                                           // per panel: the next bulk item
 };
 
 // all lanes of a wave poll one flag (one request); bounded
@@ -529,7 +531,7 @@ __device__ __attribute__((noinline)) void row_body(CpArgs a_v, int nrb_v, int i_
         d[0] = __builtin_bit_cast(frag_t, p0); d[128] = __builtin_bit_cast(frag_t, p1); d[256] = __builtin_bit_cast(frag_t, p2);
     }
     if (tid < 4) sm.cnt[tid] = 0;
-    if (tid < 16) sm.tick[tid] = 0;
+    if (tid < 64) sm.tick[tid] = 0;
     __syncthreads();
     const int lane0 = lane_in;
     for (int J = 0; J + 2 <= i; ++J) {
@@ -693,12 +695,14 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
     const int nrb = __builtin_amdgcn_readfirstlane(nrb_v), s = __builtin_amdgcn_readfirstlane(s_v);
     extern __shared__ __attribute__((aligned(16))) unsigned char cp_smem[];
     // Eight waves: wave (fa, par) owns row half fa of the 64 x 32 block and every fourth operand block (or k-step) par; the four shares meet
-    // through two f32 buffers.  LDS: [nrb - 1] blocks of W as B-operand planes | CP (the current right-hand side's planes; Yw aliases it) |
-    // Yw2 aliases the LAST plane slot, which is written at the end of step nrb - 2 and not read after that step's last term.
-    frag_t *WPl = reinterpret_cast<frag_t *>(cp_smem);                  // [nrb - 1][CP_WGRAN]
-    frag_t *CP = WPl + (size_t)(nrb > 1 ? nrb - 1 : 0) * CP_WGRAN;      // [CP_WGRAN]
+    // through two f32 buffers.  LDS: [win] blocks of W as B-operand planes | CP (the current right-hand side's planes; Yw aliases it) | Yw2.
+    // (round 4: the plane blocks are a RING of a.win slots, block K in slot K % win; an update with more panels than slots re-reads the older
+    //  blocks from Wp, where the strip has written them anyway -- config 5's 40 panels take the one-launch form; Yw2 has a buffer of its own)
+    const int win = a.win;
+    frag_t *WPl = reinterpret_cast<frag_t *>(cp_smem);                  // [win][CP_WGRAN]
+    frag_t *CP = WPl + (size_t)win * CP_WGRAN;                          // [CP_WGRAN]
     float *Yw = reinterpret_cast<float *>(CP);                          // f32 [64][CP_WS] (8.4 KB), alias of CP: used strictly before / after it
-    float *Yw2 = nrb > 1 ? reinterpret_cast<float *>(WPl + (size_t)(nrb - 2) * CP_WGRAN) : reinterpret_cast<float *>(CP + CP_WGRAN);
+    float *Yw2 = reinterpret_cast<float *>(CP + CP_WGRAN);              // f32 [64][CP_WS]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int fa = wave & 1, par = wave >> 1;
     const int c0 = s * 32, lcol = lane & 31;
@@ -752,7 +756,7 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
                 CP[q * 192 + l] = __builtin_bit_cast(frag_t, p0); CP[q * 192 + 64 + l] = __builtin_bit_cast(frag_t, p1); CP[q * 192 + 128 + l] = __builtin_bit_cast(frag_t, p2);
             }
             if (keep) {
-                frag_t *d = WPl + (size_t)J * CP_WGRAN + q * 192 + l;
+                frag_t *d = WPl + (size_t)(J % win) * CP_WGRAN + q * 192 + l;
                 d[0] = __builtin_bit_cast(frag_t, p0); d[64] = __builtin_bit_cast(frag_t, p1); d[128] = __builtin_bit_cast(frag_t, p2);
             }
             if (to_wp) {
@@ -760,7 +764,7 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
                 // the down-date consumers of THIS launch read the panel as soon as the strip's flag is up.
                 const unsigned gb = (unsigned)((((size_t)(c0 >> 7) * a.nst_total + 4 * J + q) * B3_GRAN + ((c0 >> 5) & 3) * 64 + l) * 16u);
                 st16_sc1(p0, rWp, gb); st16_sc1(p1, rWp, gb + 256 * 16); st16_sc1(p2, rWp, gb + 512 * 16);
-                if (publish) drain_stores();
+                if (publish || a.nrb_max - 1 > win) drain_stores();        // (also when the strip itself re-reads these blocks later)
             }
         }
     };
@@ -814,8 +818,33 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) loadq(0, q);
                 }
-                for (int u = 0; u < nb; ++u) {
-                    const frag_t *wb = WPl + (size_t)(par + 4 * u) * CP_WGRAN + lane;
+                // blocks written so far: 0 .. J-1, the ring holds the last `win` of them; the older ones (K < J - win) come back from Wp (this
+                // strip's own write-through stores, drained steps ago), their fragments requested one block ahead like L's
+                const int n_old = J - win > par ? (J - win - par + 3) / 4 : 0;          // blocks K = par + 4 u < J - win
+                int u = 0;
+                if (n_old > 0) {
+                    const unsigned wlane = (unsigned)lane * 16u;
+                    const unsigned wbase = (unsigned)(((size_t)(c0 >> 7) * a.nst_total) * B3_GRAN + ((c0 >> 5) & 3) * 64);
+                    frag_t w0[4][3];
+                    auto loadw = [&](int uu, int q) {
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) w0[q][pl] = ld_granule(rWp, wlane, wbase + (unsigned)(4 * (par + 4 * uu) + q) * B3_GRAN + pl * 256, 1);
+                    };
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) loadw(0, q);
+                    for (; u < n_old; ++u) {
+                        const bool nx = u + 1 < nb, nw = u + 1 < n_old;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const frag_t b0 = w0[q][0], b1 = w0[q][1], b2 = w0[q][2];
+                            ST_MMA(f0[q][0], b0); ST_MMA(f0[q][0], b1); ST_MMA(f0[q][1], b0); ST_MMA(f0[q][1], b1); ST_MMA(f0[q][0], b2); ST_MMA(f0[q][2], b0);
+                            if (nx) loadq(u + 1, q);
+                            if (nw) loadw(u + 1, q);
+                        }
+                    }
+                }
+                for (; u < nb; ++u) {
+                    const frag_t *wb = WPl + (size_t)((par + 4 * u) % win) * CP_WGRAN + lane;
                     const bool nx = u + 1 < nb;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -871,7 +900,7 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
             }
             __syncthreads();
             if (tid == 0 && (s == 0 || s == a.n_strips - 1)) CP_STAMP(s == 0 ? 16 : 17, J, 6);
-            const frag_t *wb = WPl + (size_t)J * CP_WGRAN + lane;
+            const frag_t *wb = WPl + (size_t)(J % win) * CP_WGRAN + lane;
             frag_t fL[3];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) fL[pl] = ld_granule(rSp, plo, (unsigned)((J + 1) * a.sp_stride + J) * B3_SGRAN + par * 384 + pl * 128, 1);
@@ -977,10 +1006,21 @@ __device__ __attribute__((noinline)) void dd_body(CpArgs a_v, int nrb_v, int row
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const frag_t *Wp = static_cast<const frag_t *>(a.Wp);
+    const int j_last = (nst_real + 3) / 4 - 1;                  // the last panel that holds real rows
     for (int J = 0; J < nrb; ++J) {
         int ns = nst_real - 4 * J;
         ns = ns > 4 ? 4 : ns;
         if (ns <= 0) break;
+        if (J == j_last && (a.dd_mode & 4)) {
+            // While the strips finish the last panel: this wave's tile of P is pulled towards the XCD's L2 (sixteen LDS-DMA requests into a 1 KB
+            // scratch line behind the operand slots, contents ignored), so that the epilogue's read of P -- all consumers at once, behind the last
+            // MFMA -- is served by the L2 instead of HBM.
+            frag_t *sink = ops + 4 * DG_SLOTS * DG_SLOT_GRAN + wave * 64;
+            const float *pt = a.P + (size_t)(bi * 64 + (lane >> 4)) * a.ld + bj * 64 + (lane & 15) * 4;
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                __builtin_amdgcn_global_load_lds(pt + (size_t)(4 * t) * a.ld, (__attribute__((address_space(3))) void *)sink, 16, 0, 0);
+        }
         // the strips that own the group's column blocks (two per 64-column block) have published W_J
         if (wave == 0) {
             const int nfl = 2 * nslots;
@@ -1109,18 +1149,18 @@ __global__ __launch_bounds__(CP_NTH) void k_cholp(CpArgs a)
     // Blocks 0, 8, 16, .. 8 nH are crit and the rows: blocks are dealt round-robin over the eight XCDs, so these share one XCD's L2 -- the rows'
     // bulk operands (each L(k, J) is wanted by every row below k) and the hand-offs with crit are then served by that L2.  Placement is a
     // speed assumption only: every hand-off is valid for any placement.  Every other block is a strip.
-    const int b = blockIdx.x, nH = a.nrb_max > 2 ? a.nrb_max - 2 : 0;
+    const int b = blockIdx.x, nH = a.nrb_max > 2 ? a.nrb_max - 2 : 0, stride = a.stride;
 #ifndef CP_TEST_ROLE
 #define CP_TEST_ROLE 15
 #endif
-    if ((b & 7) == 0 && (b >> 3) <= nH) {
-        const int r = b >> 3;
+    if (b % stride == 0 && b / stride <= nH) {
+        const int r = b / stride;
         if (r == 0) { if (CP_TEST_ROLE & 1) crit_body(a, nrb, cp_smem); return; }
         const int i = r + 1;
         if ((CP_TEST_ROLE & 2) && i < nrb) row_body(a, nrb, i);
         return;
     }
-    const int sidx = b - ((b >> 3) < nH ? (b >> 3) + 1 : nH + 1);
+    const int sidx = b - (b / stride < nH ? b / stride + 1 : nH + 1);
     if (sidx < a.n_strips) {
         if (threadIdx.x >= 512) return;                         // strips are eight waves
         if (CP_TEST_ROLE & 4) strip_body(a, nrb, rows, sidx);
@@ -1142,6 +1182,18 @@ size_t cholp_flag_bytes(int n_strips) { return sizeof(unsigned) * ((size_t)CF_ST
 static std::atomic<int> g_cholp_live[64];
 void cholp_context_count(int device, int delta) { if (device >= 0 && device < 64) g_cholp_live[device].fetch_add(delta); }
 
+// crit and the rows are blocks 0, stride, 2 stride ..: they must all be in the first wave of the dispatch (one workgroup per CU), and with
+// stride 8 they share one XCD's L2; an update of many panels (config 5: 40) takes the largest stride that still fits them, 0 if none does
+static int cholp_stride(const pre3_ctx *c, int nH)
+{
+    if (8 * nH + 1 <= c->num_cus) return 8;        // up to 31 rows: crit and the rows on one XCD (their hand-offs stay in one L2)
+    // more rows than that (config 5: 38): an ODD stride deals them over all eight XCDs -- their bulk tiles read and write S at several TB/s,
+    // more than the one or two L2s an even stride would put them on can serve (measured: crit waited 5-10 us per panel for its next tiles)
+    for (int st = 7; st >= 1; st -= 2) if (st * nH + 1 <= c->num_cus) return st;
+    return 0;
+}
+constexpr int CP_WIN_MAX = 11;                     // plane blocks of W a strip keeps in LDS: 11 x 12 KB + CP (12 KB) + Yw2 (8.3 KB) = 152 KB
+
 bool cholp_usable(const pre3_ctx *c, int nrb_max)
 {
     static const int form = getenv("PRE3_CHOL_FORM") ? atoi(getenv("PRE3_CHOL_FORM")) : 1;
@@ -1150,7 +1202,7 @@ bool cholp_usable(const pre3_ctx *c, int nrb_max)
     // crit and the rows wait for one another: blocks 0, 8, .. 8 nH must be resident together, each on a CU of its own (the strips only wait
     // for them, so strips beyond the chip's capacity simply start later)
     const int nH = nrb_max > 2 ? nrb_max - 2 : 0;
-    if (8 * nH + 1 > c->num_cus) return false;
+    if (cholp_stride(c, nH) < 1) return false;
     return c->dtype == PRE3_F32 && c->k9_b3 && c->Wp != nullptr && c->Sp != nullptr && c->cholp_flags != nullptr && c->cholp_tp != nullptr &&
            nrb_max >= 1 && nrb_max <= CP_MAX_NRB && nrb_max <= c->rcap / NB;
 }
@@ -1211,7 +1263,9 @@ int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior)
     const int n_strips = c->ldw / 32;
     const int nH = nrb_max > 2 ? nrb_max - 2 : 0;
     const size_t lds_crit = sizeof(CritSmem), lds_row = sizeof(RowSmem);
-    const size_t lds_strip = (size_t)(nrb_max > 1 ? nrb_max - 1 : 1) * CP_WGRAN * 16 + (size_t)CP_WGRAN * 16;     // (one panel: Yw2 takes the place of a plane slot)
+    const int win = std::max(1, std::min(nrb_max - 1, CP_WIN_MAX)), stride = cholp_stride(c, nH);
+    PRE3_CHECK(stride >= 1, PRE3_E_ARG, "launch_cholp: %d panels need more CUs than the device has", nrb_max);
+    const size_t lds_strip = (size_t)win * CP_WGRAN * 16 + (size_t)CP_WGRAN * 16 + (size_t)NB * CP_WS * sizeof(float);     // ring | CP (Yw) | Yw2
     size_t lds = std::max(lds_crit, std::max(lds_row, lds_strip));
     // Down-date consumers (P -= W_J' W_J behind the strips, update.m:37): as many groups as there are CUs left.  Every workgroup of the launch
     // declares the same LDS (more than half a CU's), so there is one per CU, and the grid never exceeds the CU count: all of them are resident
@@ -1224,9 +1278,11 @@ int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior)
     const bool alone = form == 2 || !(c->device >= 0 && c->device < 64) || g_cholp_live[c->device].load() <= 1;
     if (ov_env && alone && c->k9_overlap && c->dd_groups != nullptr && c->dd_n_groups > 0) {
         n_dd = std::min(c->dd_n_groups, c->num_cus - (1 + nH + n_strips));
-        if (n_dd < 0 || std::max(1 + nH + n_strips + n_dd, 8 * nH + 1) > c->num_cus) n_dd = 0;
+        static const int dd_max = getenv("PRE3_DD_MAX") ? atoi(getenv("PRE3_DD_MAX")) : -1;      // (tests: fewer groups in the launch than would fit -- the rest goes to k_downdate_b3)
+        if (dd_max >= 0) n_dd = std::min(n_dd, dd_max);
+        if (n_dd < 0 || std::max(1 + nH + n_strips + n_dd, stride * nH + 1) > c->num_cus) n_dd = 0;
     }
-    if (n_dd > 0) lds = std::max(lds, (size_t)4 * DG_SLOTS * DG_SLOT_GRAN * 16);
+    if (n_dd > 0) lds = std::max(lds, (size_t)4 * DG_SLOTS * DG_SLOT_GRAN * 16 + 12 * 1024);      // operand slots + one scratch line per wave (P warm-up)
     static std::atomic<unsigned long long> attr_set{ 0 };        // one bit per device
     if (c->device >= 0 && c->device < 64 && !((attr_set.load() >> c->device) & 1ull)) {
         PRE3_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cholp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1245,7 +1301,8 @@ int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior)
     a.Sp = c->Sp; a.sp_stride = c->rcap / NB; a.Tp = c->cholp_tp; a.Wp = c->Wp; a.nst_total = c->rcap / B3_BK;
     a.cf = c->cholp_flags; a.base = c->cholp_epoch; a.status = c->stats + 6;
     a.n_dev = nrb < 0 ? c->stats + 4 : nullptr; a.nrb = nrb < 0 ? nrb_max : nrb; a.nrb_max = nrb_max; a.n_strips = n_strips;
-    static const int dd_mode = getenv("PRE3_DD_MODE") ? atoi(getenv("PRE3_DD_MODE")) : 1;
+    a.win = win; a.stride = stride;
+    static const int dd_mode = getenv("PRE3_DD_MODE") ? atoi(getenv("PRE3_DD_MODE")) : 1;      // bit 0: sc1 LDS-DMA of the planes; bit 1: an acquire per panel (experiment); bit 2: P warm-up
     a.dd_mode = dd_mode;
     // with the consumers in the launch the strips also finish the state: x_k_k = x_prior + W'(L^-1 nu) (the K9 launch that used to carry the
     // x-update as riders has nothing left to do at N = 500)
@@ -1264,7 +1321,7 @@ int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior)
         c->kt.used += 2;
         PRE3_HIP(hipEventRecord(e0, c->stream));
     }
-    hipLaunchKernelGGL(k_cholp, dim3(std::max(1 + nH + n_strips + n_dd, 8 * nH + 1)), dim3(CP_NTH), lds, c->stream, a);
+    hipLaunchKernelGGL(k_cholp, dim3(std::max(1 + nH + n_strips + n_dd, stride * nH + 1)), dim3(CP_NTH), lds, c->stream, a);
     if (timed) {
         PRE3_HIP(hipEventRecord(e1, c->stream));
         c->kt.fused += 1;

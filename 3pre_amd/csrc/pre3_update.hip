@@ -1058,7 +1058,8 @@ __device__ __forceinline__ void update_x_block(int blk, int n, int r, const T *_
 }
 
 struct XUpd { int n_tiles, n, r; const double *x_prior; double *x_out; double *params;
-              const int32_t *gate; };   // gate != nullptr (the speculative down-date behind k_hi_fused): run only if gate[8] == 1, with r = 2 * gate[5] rows
+              const int32_t *gate;
+              int nx; };                // x-update workgroups in the launch (0: the state has been updated elsewhere -- the riders behind the tiles are all projection blocks)   // gate != nullptr (the speculative down-date behind k_hi_fused): run only if gate[8] == 1, with r = 2 * gate[5] rows
 
 // waves_per_eu: the riders' fp64 geometry must not raise the register count of the tile path (5 workgroups per CU in fp32,
 // 4 in fp64 -- every tile resident at once); if anything spills, it is the riders.
@@ -1083,7 +1084,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
     static_assert(sizeof(T) * SMEM >= sizeof(double) * (16 * 64 + 4), "the riders borrow the staging buffer");
     if ((int)blockIdx.x >= xu.n_tiles) {            // riders (launch_downdate adds these workgroups)
         __builtin_amdgcn_s_setprio(3);              // short dependent chains: must not starve behind the MFMA waves sharing their SIMD
-        const int nx = (xu.n + 63) / 64, rb = blockIdx.x - xu.n_tiles;
+        const int nx = xu.nx, rb = blockIdx.x - xu.n_tiles;
         if (rb < nx) {                              // the state update
             update_x_block<T>(rb, xu.n, xu.r, W, ldw, ld, xu.x_prior, xu.x_out, xu.params, reinterpret_cast<double *>(smem));
             if (pr.n_blocks) ride_signal(pr.ctr);
@@ -1410,7 +1411,7 @@ __global__ __launch_bounds__(256) void k_downdate_b3(float *__restrict__ P, int 
     if (xu.gate != nullptr && xu.gate[8] != 1) return;          // the fused HI update in front found nothing to do (or too much: the host follows up)
     if ((int)blockIdx.x >= xu.n_tiles) {            // riders, as in k_downdate_1t
         __builtin_amdgcn_s_setprio(3);
-        const int nx = (xu.n + 63) / 64, rb = blockIdx.x - xu.n_tiles;
+        const int nx = xu.nx, rb = blockIdx.x - xu.n_tiles;
         if (rb < nx) {
             update_x_block<float>(rb, xu.n, xu.gate != nullptr ? 2 * xu.gate[5] : xu.r, W, ldw, ld, xu.x_prior, xu.x_out, xu.params, reinterpret_cast<double *>(smem));
             if (pr.n_blocks) ride_signal(pr.ctr);
@@ -1636,10 +1637,11 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
             n_tiles_launch = c->dd_tile_off.back() - t0;
         }
         c->dd_done = 0;
-        XUpd xu{ n_tiles_launch, c->n, r, which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1, c->x_kk, c->pred_params, nullptr };
+        XUpd xu{ n_tiles_launch, c->n, r, which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1, c->x_kk, c->pred_params, nullptr, 0 };
         const bool x_done = c->x_done && which_prior >= 0;            // the factorisation's strips have computed x_k_k already
         c->x_done = false;
         const int nx = (which_prior >= 0 && !x_done) ? ceil_div(c->n, 64) : 0;
+        xu.nx = nx;
         ProjRide pr{};
         if (which_prior >= 0 && c->ride_rescue_projection && c->N > 0) {
             if (n_tiles_launch + nx == 0) {                           // nothing left for this launch: the projection rides with the Jnorm pass
@@ -1656,8 +1658,9 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
                                tiles, xu, pr);
         }
     } else if (one_tile) {
-        XUpd xu{ c->n_tiles, c->n, r, which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1, c->x_kk, c->pred_params, nullptr };
+        XUpd xu{ c->n_tiles, c->n, r, which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1, c->x_kk, c->pred_params, nullptr, 0 };
         const int nx = which_prior >= 0 ? ceil_div(c->n, 64) : 0;
+        xu.nx = nx;
         ProjRide pr{};
         if (nx > 0 && c->ride_rescue_projection && c->N > 0) {      // the rescue's projection (stale h kept: clear_first = 0) rides along
             pr = make_proj_ride(c, PRE3_X_K_K, 0, 1, nx);
@@ -1700,8 +1703,8 @@ int launch_hi_fused(pre3_ctx *c, int32_t seq)
     a.Wp = c->Wp; a.nst_total = c->rcap / B3_BK; a.Sp = c->Sp; a.sp_stride = c->rcap / NB; a.params = c->pred_params;
     hipLaunchKernelGGL(k_hi_fused, dim3(1 + c->ldw / NB), dim3(CH_NTH), 0, c->stream, a);
     // the down-date of that update (one panel: four k-stages), the x-update riding along; every workgroup leaves at once unless stats[8] == 1
-    XUpd xu{ c->n_tiles128, c->n, 0, c->x_kk, c->x_kk, c->pred_params, c->stats };
     const int nx = ceil_div(c->n, 64);
+    XUpd xu{ c->n_tiles128, c->n, 0, c->x_kk, c->x_kk, c->pred_params, c->stats, nx };
     ProjRide pr{};
     hipLaunchKernelGGL(k_downdate_b3, dim3(c->n_tiles128 + nx), dim3(256), 0, c->stream, (float *)c->P, c->ld, (const bf16x8_t *)c->Wp, c->rcap / B3_BK, 4,
                        (const float *)c->W, c->ldw, (const int2 *)c->tiles128, xu, pr);

@@ -332,7 +332,7 @@ def n2000_step_leg(pre3, synth, N=2000, n_hyp=1000, steps=6, warm=2):
     """BASELINE.json configs[4]'s state size on ONE GPU, the whole step ("the scaling axis is state dimension n"): N=2000
     landmarks (n=12013, P = 579 MB in fp32), 1000 hypotheses, ~1600 measured, LI update of ~2550 rows = 40 panels.  Steps/s, and the K9 launches
     of the LI updates priced like `roofline` (HIP events on the library's stream).  At 40 panels the factorisation takes the launch-per-panel form
-    (the persistent launch keeps W's planes in LDS: 13 panels), so the down-date is a launch of its own here."""
+    (the persistent launch was extended beyond its LDS window in round 4 and measured at 40 panels: no faster than the per-panel form, pre3_cholp.h), so the down-date is a launch of its own here."""
     seq = synth.make_sequence(N, steps + warm, n_hyp)
     f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", max_hyp=n_hyp, std_z=1.0)
     try:
@@ -359,7 +359,7 @@ def n2000_step_leg(pre3, synth, N=2000, n_hyp=1000, steps=6, warm=2):
     return {"workload": "configs[4] size on one GPU: N=%d (n=%d), %d hypotheses (k=3, all evaluated), %d measured, f32 covariance path, full 1PRE step" % (N, n, n_hyp, len(seq["steps"][0]["meas_idx"])),
             "value": steps / el, "unit": "steps/s", "ms_per_step": 1e3 * el / steps, "hip_event_ms_per_step": ev / steps,
             "mean_li_rows": 2 * float(np.mean([s_["n_li"] for s_ in st])), "mean_hi_rows": 2 * float(np.mean([s_["n_hi"] for s_ in st])),
-            "factorisation": "one persistent launch with the down-date inside (k_cholp)" if fused else "launch per 64-row panel (k_chol_step; the persistent form holds <= 13 panels)",
+            "factorisation": "one persistent launch with the down-date inside (k_cholp)" if fused else "launch per 64-row panel (k_chol_step; the persistent form is used up to 16 panels)",
             "persistent_form_available": bool(persistent),
             "k9": {"launches": kt["launches"], "avg_launch_us": 1e3 * kt["total_ms"] / max(kt["launches"], 1), "achieved": 6.0 * ach, "unit": "TFLOP/s", "peak": PEAK["bf16"],
                    "frac": 6.0 * ach / PEAK["bf16"], "f32_equivalent_ratio": ach / PEAK["f32"], "algorithmic": "SYRK n(n+1)r per LI launch, x6 executed (three-way bf16 split)"}}

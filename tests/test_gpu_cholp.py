@@ -47,7 +47,7 @@ def test_whole_steps_agree_between_the_two_forms(pre3, N, n_hyp, steps):
         f.close()
 
 
-@pytest.mark.parametrize("n_rows_meas", [1, 31, 32, 33, 97, 400, 416])
+@pytest.mark.parametrize("n_rows_meas", [1, 31, 32, 33, 97, 400, 416, 500])
 def test_update_sizes_from_one_row_pair_to_thirteen_panels(pre3, orc, n_rows_meas):
     """ekf_update_li_inliers with a forced inlier set: r = 2 .. 832 rows (1 .. 13 panels; padding rows when r is not a multiple of 64),
     persistent form vs the C oracle's update.m restatement (fp64) and vs the launch-per-panel form"""
@@ -80,7 +80,8 @@ def test_update_sizes_from_one_row_pair_to_thirteen_panels(pre3, orc, n_rows_mea
     (xp, Pp, _, meas, z), (xl, Pl, _, _, _) = res
     scale = np.abs(Pl).max()
     assert np.isfinite(Pp).all()
-    assert np.abs(Pp - Pl).max() < 1e-4 * scale, (n_rows_meas, np.abs(Pp - Pl).max() / scale)
+    # (the two forms differ by fp32 rounding of the update: 1e-4 of P's scale up to 13 panels, 2e-4 for the 16 panels of 500 measured landmarks, outliers included)
+    assert np.abs(Pp - Pl).max() < (1e-4 if n_rows_meas <= 416 else 2e-4) * scale, (n_rows_meas, np.abs(Pp - Pl).max() / scale)
     assert np.abs(xp - xl).max() < 1e-5
     # ... and against update.m's restatement in fp64 (the numpy twin: explicit inv(S), K S K', 0.5 (P + P'), Jnorm rebuild)
     from oracle import np_twin as tw
@@ -93,24 +94,32 @@ def test_update_sizes_from_one_row_pair_to_thirteen_panels(pre3, orc, n_rows_mea
     assert np.abs(xp - xo).max() < 2e-5
 
 
-def test_an_update_beyond_thirteen_panels_takes_the_other_form(pre3):
-    """r = 900 rows = 15 panels: more than the strips' LDS holds; the launch-per-panel form serves it, same call, same result class"""
+def test_an_update_beyond_the_lds_window_streams_older_blocks(pre3):
+    """r = 900 rows = 15 panels: more blocks of W than a strip keeps in LDS (a ring of 11): the older ones are re-read from the planes the strip
+    wrote (round 4; rounds 1-3 took the launch-per-panel form here).  Against that form on the same input: fp32 rounding of one update."""
     N = 500
     seq = synth.make_sequence(N, 1, 8)
     s = seq["steps"][0]
-    f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", max_hyp=8, std_z=1.0)
-    assert f.chol_persist()
-    f.set_x_p_k_k(seq["x0"], seq["P0"])
-    f.ekf_prediction(s["u"])
-    f.search_IC_matches()
-    meas = np.arange(450, dtype=np.int32)
-    f.set_measurements(meas, f.landmark_fields()["h"][:450] + 0.25)
-    f.set_flags(li=np.ones(450, np.int32))
-    f.ekf_update_li_inliers()
-    P = f.get_p_k_k()
+    res = []
+    for on in (True, False):
+        f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", max_hyp=8, std_z=1.0)
+        f.chol_persist(on)
+        assert f.chol_persist() == on
+        f.set_x_p_k_k(seq["x0"], seq["P0"])
+        f.ekf_prediction(s["u"])
+        f.search_IC_matches()
+        meas = np.arange(450, dtype=np.int32)
+        f.set_measurements(meas, f.landmark_fields()["h"][:450] + 0.25)
+        f.set_flags(li=np.ones(450, np.int32))
+        f.ekf_update_li_inliers()
+        res.append((f.get_x_k_k(), f.get_p_k_k()))
+        f.close()
+    (xp, P), (xl, Pl) = res
     assert np.isfinite(P).all() and np.abs(P - P.T).max() < 1e-12 * np.abs(P).max() + 1e-30
     assert (np.diag(P)[7:] > 0).all()
-    f.close()
+    scale = np.abs(Pl).max()
+    assert np.abs(P - Pl).max() < 2e-4 * scale, np.abs(P - Pl).max() / scale        # (fp32 rounding of a 900-row update; 1e-4 up to 13 panels)
+    assert np.abs(xp - xl).max() < 1e-5
 
 
 def test_not_positive_definite_is_reported_by_the_persistent_form(pre3):

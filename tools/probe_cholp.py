@@ -10,8 +10,9 @@ lib = importlib.import_module("3pre_amd._lib").lib
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 warm = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-seq = synth.make_sequence(N, warm + 1, 200)
-f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", max_hyp=200, std_z=1.0)
+H = 200 if N <= 500 else 1000
+seq = synth.make_sequence(N, warm + 1, H)
+f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", max_hyp=H, std_z=1.0)
 f.set_x_p_k_k(seq["x0"], seq["P0"])
 for s in seq["steps"][:warm]:
     f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=1.0, early_exit=False)
@@ -32,11 +33,11 @@ t0 = t[0, 0, 0]
 def rel(x): return "%7.2f" % (x - t0) if x > 0 else "      -"
 print("n_li %d -> %d panels; all times in us after crit's first chain start" % (n_li, nrb))
 print("crit main   J: chain start, chain end, b0 passed, b3 passed | side: T1 issued, T1 landed, T2 issued, T2 landed, M_J flag, rowL[J] flag")
-for J in range(nrb):
+for J in range(min(nrb, 16)):
     print("  J=%2d  %s %s %s %s | %s %s %s %s %s %s   chain %.2f  products %.2f" % ((J,) + tuple(rel(t[0, J, k]) for k in range(4)) + tuple(rel(t[1, J, k]) for k in range(6)) +
           (t[0, J, 1] - t[0, J, 0], (t[0, J, 3] - t[0, J, 1]) if t[0, J, 3] > 0 else 0.0)) + "  chain cycles %d (%.2f GHz)" % (raw[19, J, 1] - raw[19, J, 0], (raw[19, J, 1] - raw[19, J, 0]) / max(t[0, J, 1] - t[0, J, 0], 1e-9) / 1e3))
 print("products, per J (us after the chain's end): side waves at b0 (w10, w11) | b0 | B1 done | w11 L_JJ stored, w10 M flag | b1 | b2 | B2 done | w10 planes out, w11 f32 out | b3")
-for J in range(nrb - 1):
+for J in range(min(nrb, 16) - 1):
     e = t[0, J, 1]
     r2 = lambda x: "%5.2f" % (x - e) if x > 0 else "    -"
     print("  J=%2d  %s %s | %s | %s | %s %s | %s | %s | %s | %s %s | %s" % (J, r2(t[1, J, 7]), r2(t[18, J, 2]), r2(t[0, J, 2]), r2(t[0, J, 7]), r2(t[18, J, 0]), r2(t[1, J, 4]), r2(t[0, J, 4]), r2(t[0, J, 5]), r2(t[0, J, 6]), r2(t[1, J, 6]), r2(t[18, J, 1]), r2(t[0, J, 3])))
@@ -48,10 +49,10 @@ print("row 9, wave 5, panel 1 bulk: enter %s | wave 4: rows seen %s acquire done
 for u in range(4):
     print("   item %d: start %s  after k-step 0..3 %s  stored %s" % (u, rel(t[12+u,0,0]), " ".join(rel(t[12+u,0,1+q]) for q in range(4)), rel(t[12+u,0,5])))
 print("strip 0 / last strip, per J: (1) rhs planes done, (2) acquire done, (2) sum done, M_J seen, product reduced, stored + planes done, L(J+1,J) seen, its term done")
-for J in range(nrb):
+for J in range(min(nrb, 16)):
     order = (3, 0, 4, 1, 5, 2, 6, 7)
     print("  J=%2d  %s | %s" % (J, " ".join(rel(t[16, J, k]) for k in order), " ".join(rel(t[17, J, k]) for k in order)))
 print("down-date consumers (first / last group), per J: flags seen, panel's MFMAs done")
-for J in range(nrb):
+for J in range(min(nrb, 16)):
     print("  J=%2d  %s %s | %s %s" % (J, rel(t[20, J, 0]), rel(t[20, J, 1]), rel(t[21, J, 0]), rel(t[21, J, 1])))
 print("  epilogue start / end: %s %s | %s %s" % (rel(t[20, 15, 0]), rel(t[20, 15, 1]), rel(t[21, 15, 0]), rel(t[21, 15, 1])))
