@@ -847,8 +847,6 @@ def main():
         }
     if rank == 0 and chk is not None:
         out.update(chk)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(seq, thr, args.cpu_budget)
     # secondary legs: sharded RANSAC and sharded matcher at every N, kernel-only matcher and VO RANSAC at N=1.  A leg that fails on any
     # rank is recorded and ends the legs (legs_agree): no rank may be left inside a collective, and the headline is printed regardless.
     comm_broken = False
@@ -916,6 +914,11 @@ def main():
         os._exit(3)
     if wd is not None:
         wd.cancel()
+    # the CPU baseline LAST (no collective in it: the watchdog is off): its thread pools (256 OpenMP threads of the C restatement, OpenBLAS under
+    # the numpy twin) keep spinning on the host cores for a while after each call and slowed every host-driven GPU leg that used to follow them
+    # (fp64_n200: 425 instead of 5700 updates/s)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(seq, thr, args.cpu_budget)
     if rank == 0:
         if comm_broken:
             out["communicator"] = "broken during an auxiliary leg (exit code 3); the headline was measured before the legs"
