@@ -141,7 +141,7 @@ void mexFunction(int nout, mxArray *out[], int nin, const mxArray *in[])
         }
         mxFree(meas); mxFree(pairs); mxFree(z); check(rc);
     }
-    else if (!strcmp(cmd, "set_option")) {        /* pre3_mex('set_option', option, value): PRE3_OPT_DEFER_HI = 1, PRE3_OPT_K9_BF16X3 = 2 (include/pre3.h) */
+    else if (!strcmp(cmd, "set_option")) {        /* pre3_mex('set_option', option, value): PRE3_OPT_DEFER_HI = 1, PRE3_OPT_K9_BF16X3 = 2, PRE3_OPT_CHOL_PERSIST = 3, PRE3_OPT_K9_OVERLAP = 5 (include/pre3.h) */
         check(pre3_set_option(g_ctx, (int)mxGetScalar(in[1]), (int)mxGetScalar(in[2])));
     }
     else if (!strcmp(cmd, "destroy")) { at_exit(); if (mexIsLocked()) mexUnlock(); }
