@@ -727,7 +727,7 @@ def main():
     # Two legs on the sequence of rounds 1-3 (motion noise 0.5), a fresh filter: `thr05` = round 3's headline (threshold 0.5 px: ~260 LI inliers, the
     # rest of the true inliers come back through the rescue) over the same --steps / --warmup window, then `no_hi` = the same filter continued at the
     # reference's 1.0 px (rounds 1-2: the rescue finds next to nothing) -- so that the rounds stay comparable.
-    thr05, no_hi = None, None
+    thr05, no_hi, k9_alone = None, None, None
     if K2:
         seq2 = synth.make_sequence(N, W + K + 3 + K2, args.hyp, seed=None if rank == 0 else 10_000 * rank + N)
         f2 = pre3.EkfFilter(seq2["cam"], np.zeros(N, np.int32), dtype=args.dtype, device=local_rank, max_hyp=args.hyp, std_z=0.5)
@@ -752,6 +752,20 @@ def main():
                  "dominant_launch": k9_rate(kt2),
                  "note": "the same filter continued with the reference's own RANSAC threshold on the motion-noise-0.5 sequence: the headline "
                          "workload of rounds 1 and 2 (the rescue finds next to nothing)"}
+        # the stand-alone K9 launch (k_downdate_b3 behind a finished factorisation: what rounds 1-3 priced as `roofline`) at the headline's row
+        # count, on this leg's filter, which is done (the synthetic W of pre3_bench_downdate overwrites its P): the kernel-quality figure that the
+        # fused launch's duration can no longer show
+        try:
+            r_k9 = int(round(2 * float(np.mean([s_["n_li"] for s_ in stats]))))
+            ms_k9 = f2.bench_downdate(r_k9, 30)
+            n_ = seq["n"]
+            six = 6.0 if (args.dtype == "f32" and b3) else 1.0
+            tf = n_ * (n_ + 1.0) * r_k9 / (ms_k9 * 1e-3) / 1e12
+            k9_alone = {"kernel": "k_downdate_b3 as a launch of its own (pre3_bench_downdate: back-to-back launches, synthetic W, planes already split)", "rows": r_k9,
+                        "avg_launch_us": 1e3 * ms_k9, "achieved": six * tf, "unit": "TFLOP/s", "peak": PEAK["bf16"] if six > 1 else PEAK[args.dtype],
+                        "frac": six * tf / (PEAK["bf16"] if six > 1 else PEAK[args.dtype]), "f32_equivalent_ratio": tf / PEAK["f32"] if args.dtype == "f32" else None}
+        except Exception as e:                                      # pragma: no cover
+            k9_alone = {"error": repr(e)[:200]}
         f2.close()
 
     out = None
@@ -840,6 +854,7 @@ def main():
                        "parallelism": "replicas x%d" % world,
                        "hip_event_ms_per_step": ev_ms / K},
             "roofline": roofline,
+            "k9_standalone": k9_alone,
             "thr05": thr05,
             "no_hi": no_hi,
             "step_ideal": {"ideal_us": ideal_us, "achieved_us": 1e3 * ms_step, "step_ideal_frac": ideal_us / (1e3 * ms_step),
