@@ -27,7 +27,7 @@ int launch_window_gate(pre3_ctx *c, int M, const int32_t *pred_idx_dev, const in
 int launch_build_rows_impl(pre3_ctx *c, int nsel, const int32_t *sel_dev, int r_pad);
 int launch_ransac_score_impl(pre3_ctx *c, int k, double threshold, int hyp_begin, int hyp_end, int ldg, int32_t *support_dev, uint32_t *mask_dev, int mask_words,
                              int select_n_draw = 0, int early_exit = 0);
-int launch_ransac_select_impl(pre3_ctx *c, int n_draw, int k, int early_exit, int32_t *support_dev, const uint32_t *mask_dev, int mask_words);
+int launch_ransac_select_impl(pre3_ctx *c, int n_draw, int k, int early_exit, int32_t *support_dev, const uint32_t *mask_dev, int mask_words, int err_idx = -1);
 int launch_fill_w(pre3_ctx *c, int r_pad);
 void release_scratch();
 int match_partial(int device, int cls, int ND, int K1, const void *L1, int K2, const void *L2, int k2_offset, double *best, double *second, int32_t *arg);
@@ -741,7 +741,11 @@ static int ransac_results(pre3_ctx *c, int n_draw, int32_t *support, int32_t *li
         if (support) PRE3_HIP(hipMemcpy(support, c->support, sizeof(int32_t) * n_draw, hipMemcpyDeviceToHost));
         if (li_mask && c->m) PRE3_HIP(hipMemcpy(li_mask, c->li_meas, sizeof(int32_t) * c->m, hipMemcpyDeviceToHost));
     }
-    if (stats) { PRE3_TRY(wait_mail(c, 8, c->seq_select)); for (int i = 0; i < 4; ++i) stats[i] = c->mail_host[i]; }
+    if (stats) {
+        PRE3_TRY(wait_mail(c, 8, c->seq_select));
+        PRE3_CHECK(!c->shard_round || c->mail_host[11] == 0, PRE3_E_COMM, "sharded RANSAC: a rank failed before the collective of this round (its slice is missing from the sums)");
+        for (int i = 0; i < 4; ++i) stats[i] = c->mail_host[i];
+    }
     return PRE3_OK;
 }
 
@@ -815,13 +819,23 @@ int pre3_ransac_sharded(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, doub
     const int lo = rank * base + std::min(rank, rem), hi = lo + base + (rank < rem ? 1 : 0);
     const int words = ceil_div(c->m, 32);
     const size_t count = (size_t)round_up(n_draw, 4) + (size_t)n_draw * words;
-    PRE3_HIP(hipMemsetAsync(c->support, 0, sizeof(int32_t) * count, c->stream));
+    // one word more than supports + masks travels through the all-reduce: the number of ranks whose slice is MISSING.  A rank-local failure
+    // between here and the collective (a bad table, a failed launch) must not leave the peers waiting in ncclAllReduce for a partner that has
+    // returned: this rank still enters the collective -- with its slice zero and that word set -- and every rank then fails the round.
+    PRE3_HIP(hipMemsetAsync(c->support, 0, sizeof(int32_t) * (count + 1), c->stream));
     // (the slice form at any number of ranks, one included: H*P only of the measurements this rank's hypotheses draw, H*P*H' only among each
     // hypothesis' own rows -- the round's cost then falls with the number of ranks from the same code path)
-    PRE3_TRY(ransac_prepare(c, n_draw, k, hyp, lo, hi, true));
-    if (hi > lo) PRE3_TRY(launch_ransac_score_impl(c, k, threshold, lo, hi, round_up(2 * c->m, NB), c->support, c->masks, words));
-    PRE3_TRY(comm_all_reduce_i32(c->comm, c->support, count, c->stream));
-    PRE3_TRY(launch_ransac_select_impl(c, n_draw, k, early_exit, c->support, c->masks, words));
+    int rc_local = ransac_prepare(c, n_draw, k, hyp, lo, hi, true);
+    if (rc_local == PRE3_OK && hi > lo) rc_local = launch_ransac_score_impl(c, k, threshold, lo, hi, round_up(2 * c->m, NB), c->support, c->masks, words);
+    if (rc_local != PRE3_OK) {
+        (void)hipMemsetAsync(c->support, 0, sizeof(int32_t) * count, c->stream);                      // whatever part of the slice got written does not count
+        (void)hipMemsetAsync(c->support + count, 1, sizeof(int32_t), c->stream);                       // (0x01010101: non-zero is all that matters)
+    }
+    const int rc_coll = comm_all_reduce_i32(c->comm, c->support, count + 1, c->stream);
+    if (rc_local != PRE3_OK) return rc_local;
+    PRE3_TRY(rc_coll);
+    PRE3_TRY(launch_ransac_select_impl(c, n_draw, k, early_exit, c->support, c->masks, words, (int)count));
+    c->shard_round = true;
     return ransac_results(c, n_draw, support, li_mask, stats);
 }
 
@@ -829,6 +843,7 @@ int pre3_ransac(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, double thres
                 int32_t stats[4])
 {
     PRE3_TRY(check_ctx(c));
+    c->shard_round = false;
     PRE3_TRY(ransac_prepare(c, n_draw, k, hyp));
     int words = ceil_div(c->m, 32);
     // Scoring, then the selection stage (the reference's loop replayed on the supports) as a launch of its own.  The selection can also ride
@@ -888,6 +903,7 @@ int pre3_update_li(pre3_ctx *c)
             }
         }
         PRE3_TRY(wait_mail(c, 8, c->seq_select)); n_li = c->mail_host[4];
+        PRE3_CHECK(!c->shard_round || c->mail_host[11] == 0, PRE3_E_COMM, "sharded RANSAC: a rank failed before the collective of the round this update follows");
     }
     return update_selected(c, PRE3_X_K_KM1, n_li, c->sel_rows, gathered, first_done);
 }

@@ -359,7 +359,7 @@ __device__ __forceinline__ void select_body(int n_draw, int k, int early_exit, i
                                             int32_t *support, const uint32_t *masks, int mask_words,
                                             int32_t *__restrict__ li_meas, int32_t *__restrict__ lm_li,
                                             int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats,
-                                            int32_t *mail, int seq);
+                                            int32_t *mail, int seq, int err_idx = -1);
 
 template <typename T, int K>
 __global__ __launch_bounds__(512) void k_ransac_score(int hyp_begin, const int32_t *__restrict__ hyp, int m,
@@ -572,7 +572,7 @@ __device__ __forceinline__ void select_body(int n_draw, int k, int early_exit, i
                                             int32_t *support, const uint32_t *masks, int mask_words,
                                             int32_t *__restrict__ li_meas, int32_t *__restrict__ lm_li,
                                             int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats,
-                                            int32_t *mail, int seq)
+                                            int32_t *mail, int seq, int err_idx)
 {
     __shared__ int s_best, s_iters, s_wcnt[4], s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -641,6 +641,8 @@ __device__ __forceinline__ void select_body(int n_draw, int k, int early_exit, i
         stats[4] = s_base;
         // host mailbox: payload, system-scope fence, then the sequence word the host polls
         mail[0] = stats[0]; mail[1] = stats[1]; mail[2] = stats[2]; mail[3] = stats[3]; mail[4] = s_base;
+        // a sharded round (pre3_ransac_sharded): the word behind the all-reduced supports and masks counts the ranks whose slice is missing
+        mail[11] = err_idx >= 0 ? support[err_idx] : 0;
         __threadfence_system();
         __hip_atomic_store(&mail[8], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -650,9 +652,9 @@ __global__ __launch_bounds__(256) void k_ransac_select(int n_draw, int k, int ea
                                                        int32_t *__restrict__ support, const uint32_t *__restrict__ masks, int mask_words,
                                                        int32_t *__restrict__ li_meas, int32_t *__restrict__ lm_li,
                                                        int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats,
-                                                       int32_t *mail, int seq)
+                                                       int32_t *mail, int seq, int err_idx)
 {
-    select_body(n_draw, k, early_exit, m, meas, support, masks, mask_words, li_meas, lm_li, sel_rows, stats, mail, seq);
+    select_body(n_draw, k, early_exit, m, meas, support, masks, mask_words, li_meas, lm_li, sel_rows, stats, mail, seq, err_idx);
 }
 
 // hi flags (landmark order, written by k_innovation mode 1) -> measurement order + compacted list
@@ -905,10 +907,10 @@ int launch_ransac_score_impl(pre3_ctx *c, int k, double threshold, int hyp_begin
     return PRE3_OK;
 }
 
-int launch_ransac_select_impl(pre3_ctx *c, int n_draw, int k, int early_exit, int32_t *support_dev, const uint32_t *mask_dev, int mask_words)
+int launch_ransac_select_impl(pre3_ctx *c, int n_draw, int k, int early_exit, int32_t *support_dev, const uint32_t *mask_dev, int mask_words, int err_idx)
 {
     hipLaunchKernelGGL(k_ransac_select, dim3(1), dim3(256), 0, c->stream, n_draw, k, early_exit, c->m, c->meas, support_dev, mask_dev,
-                       mask_words, c->li_meas, c->lm.li, c->sel_rows, c->stats, c->mail_dev, ++c->seq_select);
+                       mask_words, c->li_meas, c->lm.li, c->sel_rows, c->stats, c->mail_dev, ++c->seq_select, err_idx);
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }

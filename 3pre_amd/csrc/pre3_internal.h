@@ -160,6 +160,7 @@ struct pre3_ctx {
     // down-date consumers inside the persistent factorisation (pre3_cholp.hip): group records, all tiles in group order, first tile per group
     int32_t *dd_groups = nullptr; int dd_n_groups = 0; void *dd_tiles = nullptr; std::vector<int> dd_tile_off;
     bool k9_overlap = true;                       // PRE3_OPT_K9_OVERLAP
+    bool shard_round = false;                     // the last RANSAC round was pre3_ransac_sharded (its selection publishes the missing-slice word in mail[11])
     bool hi_fused = false;                        // the rescue stage's collection + HI update went out as k_hi_fused (pre3_step): pre3_update_hi only has the count to read
     bool x_done = false;                          // ... and its strips have computed x_k_k = x_prior + W'(L^-1 nu) as well (update.m:36,42,48)
     bool proj_with_jnorm = false;                 // the rescue's projection rides in the next k_jnorm_P launch (no K9 launch to carry it)

@@ -57,6 +57,29 @@ def test_on_stream_sharded_round_equals_the_unsharded_round(pre3, comm, dtype):
     f.close()
 
 
+def test_a_rank_local_failure_still_enters_the_collective(pre3, comm):
+    """pre3_ransac_sharded with a draw table this rank rejects (a position outside the IC list): the call fails with the rank-local error AFTER
+    the all-reduce has been enqueued -- its peers, who are in ncclAllReduce by then, are not left waiting -- and the word that counts missing slices
+    goes round with the sums; the context and the communicator stay usable, the next round is correct."""
+    N, n_draw = 60, 24
+    seq = synth.make_sequence(N, 1, n_draw, seed=33)
+    s = seq["steps"][0]
+    f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", max_hyp=n_draw)
+    f.set_x_p_k_k(seq["x0"], seq["P0"])
+    f.set_comm(comm)
+    f.ekf_prediction(s["u"]); f.search_IC_matches(); f.set_measurements(s["meas_idx"], s["z"])
+    bad = s["hyp"].copy(); bad[3, 1] = len(s["meas_idx"]) + 5
+    with pytest.raises(pre3.Pre3Error) as e:
+        f.ransac_sharded_stream(bad, 1.0)
+    assert e.value.code == -1
+    assert comm.info()["world"] == 1                               # the communicator was not aborted
+    ref = f.ransac_hypotheses(s["hyp"], threshold=1.0, early_exit=False)
+    got = f.ransac_sharded_stream(s["hyp"], 1.0, early_exit=False)
+    assert got["best"] == ref["best"] and np.array_equal(got["support"], ref["support"]) and np.array_equal(got["li_mask"], ref["li_mask"])
+    f.set_comm(None)
+    f.close()
+
+
 def test_on_stream_shard_match_equals_the_oracle(pre3, orc, comm):
     mt = importlib.import_module("3pre_amd.matcher")
     rng = np.random.default_rng(5)
