@@ -990,6 +990,51 @@ int pre3_set_flags(pre3_ctx *c, const int32_t *li, const int32_t *hi)
     return PRE3_OK;
 }
 
+// mono_slam.m:178-187 behind the prediction and the IC search: RANSAC, LI update, rescue, HI update, every launch sized on the device.
+// hyp: the draw table -- the inbox's own copy when it was shipped with the measurements (pre3_step), the caller's otherwise.
+static int step_back(pre3_ctx *c, int m, int n_draw, int k, const int32_t *hyp, double threshold, int early_exit, double chi2, int32_t stats[8])
+{
+    int32_t st[8] = { -1, 0, 0, 0, 0, 0, 0, 0 };
+    bool ran = false;
+    if (m >= k && m > 0) {
+        // mono_slam.m:178; the statistics are read after pre3_update_li's poll of the same mailbox
+        const int rc_r = pre3_ransac(c, n_draw, k, hyp, threshold, early_exit, nullptr, nullptr, nullptr);
+        if (c->ride_innovation) {                                   // the H*P launch did not go out (error before it): S_i on its own, flags cleared
+            c->ride_innovation = false;
+            PRE3_TRY(launch_innovation(c, 0, 0.0, true));
+        }
+        PRE3_TRY(rc_r);
+        ran = true;
+    }
+    static const int ride_rescue = getenv("PRE3_RIDE_RESCUE") ? atoi(getenv("PRE3_RIDE_RESCUE")) : 1;      // 0: projection + gate as one launch of their own (A/B)
+    c->ride_rescue_projection = ride_rescue != 0;                   // the rescue's projection rides in the LI update's K9 launch
+    {
+        const int rc_li = pre3_update_li(c);                        // mono_slam.m:181
+        c->ride_rescue_projection = false;                          // (also on failure: a later K9 launch must not carry the riders)
+        if (rc_li != PRE3_OK) { c->rescue_projected = false; return rc_li; }
+    }
+    if (ran) for (int i = 0; i < 4; ++i) st[i] = c->mail_host[i];
+    if (hi_fused_usable(c)) {
+        // mono_slam.m:184 + :187 without the host in between: the chi2 gate, then the collection and the HI update of up to 32 landmarks as ONE
+        // launch that reads the count on the device, and its down-date behind it (pre3_update.hip, k_hi_fused)
+        PRE3_CHECK(c->p_which == PRE3_X_K_K && c->x_valid[PRE3_X_K_K], PRE3_E_STATE, "pre3_step: the LI update did not leave (x_k_k, p_k_k)");
+        if (c->rescue_projected) PRE3_TRY(launch_innovation(c, 1, chi2, false, false));
+        else PRE3_TRY(launch_project_innovation(c, PRE3_X_K_K, 0, 1, chi2, false));
+        c->rescue_projected = false;
+        c->hi_from_host = -1; c->hi_kernel = true;
+        PRE3_TRY(launch_hi_fused(c, ++c->seq_collect));
+        c->hi_fused = true;
+    } else
+    PRE3_TRY(pre3_rescue(c, chi2, nullptr));                        // mono_slam.m:184
+    if (c->defer_hi) c->hi_pending = true;                          // mono_slam.m:187, completed at the next call on this context
+    else PRE3_TRY(pre3_update_hi(c));                               // mono_slam.m:187
+    st[4] = c->li_from_host >= 0 ? c->li_from_host : (c->li_kernel ? c->mail_host[4] : 0);
+    st[5] = c->defer_hi ? c->last_n_hi : (c->hi_from_host >= 0 ? c->hi_from_host : (c->hi_kernel ? c->mail_host[5] : 0));
+    st[7] = c->defer_hi ? 1 : 0;          // 1: st[5] is the HI count of the PREVIOUS step (this step's is still on the device)
+    if (stats) for (int i = 0; i < 8; ++i) stats[i] = st[i];
+    return PRE3_OK;
+}
+
 int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, const double *z, int n_draw, int k, const int32_t *hyp,
               double threshold, int early_exit, double chi2, int32_t stats[8])
 {
@@ -1006,7 +1051,7 @@ int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, co
     static const bool trace = getenv("PRE3_STEP_TRACE") != nullptr;     // host-side stage clock (debug): where the host spends a step
     static double acc[8], t_prev_end = 0; static int nacc = 0;
     auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; };
-    double t0 = trace ? now() : 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+    double t0 = trace ? now() : 0, t1 = 0, t5 = 0;
     PRE3_CHECK(u != nullptr, PRE3_E_ARG, "pre3_step: null u");
     PRE3_CHECK(c->have_cam, PRE3_E_STATE, "pre3_step: camera not set");
     PRE3_CHECK(c->x_valid[PRE3_X_K_K] && c->p_which == PRE3_X_K_K, PRE3_E_STATE, "pre3_step: needs (x_k_k, p_k_k) on the device");
@@ -1033,59 +1078,31 @@ int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, co
     if (c->N && !c->ride_innovation) PRE3_TRY(launch_innovation(c, 0, 0.0, true));
     c->innovated = true;
     if (trace) t1 = now();
-    int32_t st[8] = { -1, 0, 0, 0, 0, 0, 0, 0 };
-    bool ran = false;
-    if (m >= k && m > 0) {
-        // mono_slam.m:178; the statistics are read after pre3_update_li's poll of the same mailbox
-        const int rc_r = pre3_ransac(c, n_draw, k, (const int32_t *)(c->inbox_host + c->off_hyp), threshold, early_exit, nullptr, nullptr, nullptr);
-        if (c->ride_innovation) {                                   // the H*P launch did not go out (error before it): S_i on its own, flags cleared
-            c->ride_innovation = false;
-            PRE3_TRY(launch_innovation(c, 0, 0.0, true));
-        }
-        PRE3_TRY(rc_r);
-        ran = true;
-    }
-    if (trace) t2 = now();
-    static const int ride_rescue = getenv("PRE3_RIDE_RESCUE") ? atoi(getenv("PRE3_RIDE_RESCUE")) : 1;      // 0: projection + gate as one launch of their own (A/B)
-    c->ride_rescue_projection = ride_rescue != 0;                   // the rescue's projection rides in the LI update's K9 launch
-    {
-        const int rc_li = pre3_update_li(c);                        // mono_slam.m:181
-        c->ride_rescue_projection = false;                          // (also on failure: a later K9 launch must not carry the riders)
-        if (rc_li != PRE3_OK) { c->rescue_projected = false; return rc_li; }
-    }
-    if (ran) for (int i = 0; i < 4; ++i) st[i] = c->mail_host[i];
-    if (trace) t3 = now();
-    if (hi_fused_usable(c)) {
-        // mono_slam.m:184 + :187 without the host in between: the chi2 gate, then the collection and the HI update of up to 32 landmarks as ONE
-        // launch that reads the count on the device, and its down-date behind it (pre3_update.hip, k_hi_fused)
-        PRE3_CHECK(c->p_which == PRE3_X_K_K && c->x_valid[PRE3_X_K_K], PRE3_E_STATE, "pre3_step: the LI update did not leave (x_k_k, p_k_k)");
-        if (c->rescue_projected) PRE3_TRY(launch_innovation(c, 1, chi2, false, false));
-        else PRE3_TRY(launch_project_innovation(c, PRE3_X_K_K, 0, 1, chi2, false));
-        c->rescue_projected = false;
-        c->hi_from_host = -1; c->hi_kernel = true;
-        PRE3_TRY(launch_hi_fused(c, ++c->seq_collect));
-        c->hi_fused = true;
-    } else
-    PRE3_TRY(pre3_rescue(c, chi2, nullptr));                        // mono_slam.m:184
-    if (trace) t4 = now();
-    if (c->defer_hi) c->hi_pending = true;                          // mono_slam.m:187, completed at the next call on this context
-    else PRE3_TRY(pre3_update_hi(c));                               // mono_slam.m:187
+    const int rc_back = step_back(c, m, n_draw, k, (const int32_t *)(c->inbox_host + c->off_hyp), threshold, early_exit, chi2, stats);
     if (trace) {
         t5 = now();
-        acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += t4 - t3; acc[4] += t5 - t4;
+        acc[0] += t1 - t0; acc[1] += t5 - t1;
         if (t_prev_end > 0) acc[5] += t0 - t_prev_end;
         t_prev_end = t5;
         if (++nacc == 100) {
-            fprintf(stderr, "[pre3 step trace, us] predict+project+innov launches %.1f | install+ransac launches %.1f | update_li (poll+launches) %.1f | rescue launches %.1f | update_hi (poll) %.1f | caller between steps %.1f\n",
-                    acc[0] / nacc, acc[1] / nacc, acc[2] / nacc, acc[3] / nacc, acc[4] / nacc, acc[5] / nacc);
-            nacc = 0; for (double &a : acc) a = 0;
+            fprintf(stderr, "[pre3 step trace, us] predict+project+innov launches %.1f | ransac .. HI update (polls + launches) %.1f | caller between steps %.1f\n",
+                    acc[0] / nacc, acc[1] / nacc, acc[5] / nacc);
+            nacc = 0; for (double &a2 : acc) a2 = 0;
         }
     }
-    st[4] = c->li_from_host >= 0 ? c->li_from_host : (c->li_kernel ? c->mail_host[4] : 0);
-    st[5] = c->defer_hi ? c->last_n_hi : (c->hi_from_host >= 0 ? c->hi_from_host : (c->hi_kernel ? c->mail_host[5] : 0));
-    st[7] = c->defer_hi ? 1 : 0;          // 1: st[5] is the HI count of the PREVIOUS step (this step's is still on the device)
-    if (stats) for (int i = 0; i < 8; ++i) stats[i] = st[i];
-    return PRE3_OK;
+    return rc_back;
+}
+
+/* The same behind a prediction and an IC search the caller has already run (mono_slam.m:153 ekf_prediction, :159 search_IC_matches +
+ * matching_sift_based, e.g. pre3_predict + pre3_ic_search): the installed measurements are used. */
+int pre3_step_predicted(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, double threshold, int early_exit, double chi2, int32_t stats[8])
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(c->x_valid[PRE3_X_K_KM1] && c->p_which == PRE3_X_K_KM1, PRE3_E_STATE, "pre3_step_predicted: needs the predicted estimate (pre3_predict)");
+    PRE3_CHECK(c->measurements_set && c->projected && c->innovated, PRE3_E_STATE, "pre3_step_predicted: needs projection, S_i and measurements (pre3_ic_search, or pre3_project + pre3_innovation + pre3_set_measurements)");
+    PRE3_CHECK(n_draw >= 1 && n_draw <= c->caph && k >= 1 && k <= MAXK && hyp, PRE3_E_ARG, "pre3_step_predicted: bad hypothesis table");
+    c->ride_innovation = false;
+    return step_back(c, c->m, n_draw, k, hyp, threshold, early_exit, chi2, stats);
 }
 
 // ---- stateless update.m drop-in ---------------------------------------------------------------------

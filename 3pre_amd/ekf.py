@@ -316,6 +316,17 @@ class EkfFilter:
         s = st.tolist()
         return dict(best=s[0], iters=s[1], n_hyp=s[2], max_support=s[3], n_li=s[4], n_hi=s[5])
 
+    def step_predicted(self, hyp, threshold=None, early_exit=True, chi2=CHI2INV_2_95):
+        """mono_slam.m:178-187 (RANSAC, LI update, rescue, HI update) behind ekf_prediction() and matching_sift_based() (or search_IC_matches()
+        + set_measurements()): the installed measurements, pre3_step's device-driven launches."""
+        hyp = i32(hyp)
+        n_draw, k = hyp.shape
+        rc = lib.pre3_step_predicted(self._ctx, n_draw, k, addr(hyp), self.std_z if threshold is None else threshold, 1 if early_exit else 0, chi2, self._st_addr)
+        if rc:
+            check(rc)
+        s = self._st.tolist()
+        return dict(best=s[0], iters=s[1], n_hyp=s[2], max_support=s[3], n_li=s[4], n_hi=s[5])
+
     # ---- measurement hooks
     def timer_start(self):
         check(lib.pre3_timer_start(self._ctx))

@@ -393,6 +393,7 @@ def frame_leg(pre3, synth, N=500, K2=600, frames=40, warm=4, n_hyp=200):
     try:
         f.set_x_p_k_k(seq["x0"], seq["P0"])
         f.set_descriptors(bank)
+        f.defer_hi_update(True)
         new_desc = sift_like(rng.standard_normal((128, frames + warm + 1)))
 
         def draws(m):                                        # select_random_match.m:47-51: 3 distinct measurements per hypothesis (vectorised; duplicates redrawn)
@@ -405,7 +406,7 @@ def frame_leg(pre3, synth, N=500, K2=600, frames=40, warm=4, n_hyp=200):
                 bad = (h[:, 0] == h[:, 1]) | (h[:, 0] == h[:, 2]) | (h[:, 1] == h[:, 2])
             return h.astype(np.int32)
 
-        stage = {k: 0.0 for k in ("map_management", "prediction", "scan_upload", "ic_search", "ransac", "li_update", "rescue_hi_update")}
+        stage = {k: 0.0 for k in ("map_management", "prediction", "scan_upload", "ic_search", "ransac_updates")}
 
         def frame(k, split):
             t = [time.perf_counter()]
@@ -428,14 +429,8 @@ def frame_leg(pre3, synth, N=500, K2=600, frames=40, warm=4, n_hyp=200):
             ic = f.matching_sift_based(1.5, strict_reference=True)
             mark("ic_search")
             m = len(ic["meas_idx"])
-            if m >= 3:
-                f.ransac_hypotheses(draws(m), threshold=thr, early_exit=False)
-            mark("ransac")
-            f.ekf_update_li_inliers()
-            mark("li_update")
-            f.rescue_hi_inliers()
-            f.ekf_update_hi_inliers()
-            mark("rescue_hi_update")
+            f.step_predicted(draws(m), threshold=thr, early_exit=False)      # RANSAC, LI update, rescue, HI update: pre3_step's launches on the installed measurements
+            mark("ransac_updates")
             return m
         for k in range(warm):
             frame(k, False)

@@ -173,6 +173,13 @@ PRE3_API int pre3_step(pre3_ctx *ctx, const double u[7], int m, const int32_t *m
                        int n_draw, int k, const int32_t *hyp, double threshold, int early_exit, double chi2,
                        int32_t stats[8]);
 
+/* mono_slam.m:178-187 -- RANSAC, LI update, rescue, HI update -- behind a prediction and an IC search the caller has already run on the
+ * context (pre3_predict, then pre3_ic_search or pre3_project + pre3_innovation + pre3_set_measurements): the measurements are the installed
+ * ones, the launches are pre3_step's (the persistent factorisation with the down-date inside, the device-driven HI update), none of them
+ * sized by a host poll.  stats as pre3_step.  This is what a frame loop that matches on the device calls instead of pre3_step. */
+PRE3_API int pre3_step_predicted(pre3_ctx *ctx, int n_draw, int k, const int32_t *hyp, double threshold, int early_exit, double chi2,
+                                 int32_t stats[8]);
+
 /* Stateless drop-in for `[x,P,K] = update(x,P,H,R,z,h)` (update.m:27): host in, host out.
  * H is r x n given by rows in ELL form: row a has nnz[a] <= width entries (col[a*width+t], val[...]);
  * R is r x r dense or NULL for eye(r) (every caller in the reference passes eye).  K_out (n x r,

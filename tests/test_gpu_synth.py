@@ -229,3 +229,36 @@ def test_k9_bf16_split_matches_f32_mfma_and_fp64(pre3, orc):
     assert np.array_equal(res["b3"][1], res["b3"][1].T)
     sig = np.sqrt(np.diag(P64))
     assert (np.abs(res["b3"][0] - x64) / sig).max() < 5e-3
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_step_predicted_equals_the_call_by_call_sequence_and_the_whole_step(pre3, dtype):
+    """pre3_step_predicted (RANSAC .. HI update behind a prediction and installed measurements: what a frame loop with the IC search on the device
+    calls) against (a) the call-by-call sequence ransac_hypotheses / ekf_update_li_inliers / rescue_hi_inliers / ekf_update_hi_inliers and (b)
+    pre3_step on the same inputs: flags, statistics, x and P bit for bit -- they are the same launches' arithmetic."""
+    N, n_hyp = 120, 60
+    seq = synth.make_sequence(N, 4, n_hyp, seed=91, motion_noise=2.5)
+    outs = []
+    for mode in ("predicted", "calls", "step"):
+        f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype=dtype, max_hyp=n_hyp, std_z=1.0)
+        f.set_x_p_k_k(seq["x0"], seq["P0"])
+        st_all = []
+        for s in seq["steps"]:
+            if mode == "step":
+                st = f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=1.0, early_exit=False)
+            else:
+                f.ekf_prediction(s["u"]); f.search_IC_matches(); f.set_measurements(s["meas_idx"], s["z"])
+                if mode == "predicted":
+                    st = f.step_predicted(s["hyp"], threshold=1.0, early_exit=False)
+                else:
+                    r = f.ransac_hypotheses(s["hyp"], threshold=1.0, early_exit=False)
+                    f.ekf_update_li_inliers(); f.rescue_hi_inliers(); f.ekf_update_hi_inliers()
+                    st = dict(best=r["best"], max_support=r["max_support"])
+            li, hi = f.get_flags()
+            st_all.append((st["best"], st["max_support"], li.tobytes(), hi.tobytes()))
+        outs.append((st_all, f.get_x_k_k(), f.get_p_k_k()))
+        f.close()
+    for other in outs[1:]:
+        assert outs[0][0] == other[0]
+        assert np.array_equal(outs[0][1], other[1]) and np.array_equal(outs[0][2], other[2])
+    assert any(np.frombuffer(h, np.int32).sum() > 0 for _, _, _, h in outs[0][0])          # the rescue stage found work somewhere
