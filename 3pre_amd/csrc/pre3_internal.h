@@ -139,6 +139,8 @@ struct pre3_ctx {
     // map management (allocated on first use)
     void *P_alt = nullptr; double *x_alt = nullptr; int32_t *map_col = nullptr; void *map_val = nullptr; int32_t *map_desc = nullptr;
     double *map_feat = nullptr; int32_t *map_flags = nullptr;
+    void *map_stage[2] = { nullptr, nullptr }; hipEvent_t map_stage_ev[2] = { nullptr, nullptr }; bool map_stage_used[2] = { false, false };
+    int map_stage_next = 0; size_t map_stage_bytes = 0;   // pinned staging blocks of the map operations (pre3_map.hip)
     std::vector<int32_t> lm_type_host;
     // IC search (matching_sift_based.m): landmark descriptor bank [capN][128], the current scan's SIFT set, match scratch
     double *bank = nullptr, *bank_alt = nullptr; bool bank_set = false;

@@ -202,6 +202,23 @@ __global__ void k_map_add_noise(int n_feat, int first_off, const double *__restr
     P[o] = (T)((double)P[o] + feat[(size_t)f * FEATW + 14 + i * 6 + j]);
 }
 
+// Everything that follows the congruence in one launch (round 4; it was one copy, two uploads, three fills and the bank gather with two
+// stream synchronisations): the new state, the new landmark table, the per-landmark fields cleared (update_features_info.m:30-44), the
+// inbox cleared, and the descriptor bank re-laid-out (src[i] = old index of new landmark i, -1: a new landmark, zero descriptor).
+__global__ __launch_bounds__(256) void k_map_finish(int n_new, const double *__restrict__ x_alt, double *__restrict__ x_kk, int N, const int32_t *__restrict__ types_src,
+                                                   const int32_t *__restrict__ off_src, int32_t *__restrict__ lm_type, int32_t *__restrict__ lm_off, int capN,
+                                                   int32_t *__restrict__ has_h, int32_t *__restrict__ has_S, int32_t *__restrict__ inbox, int inbox_words,
+                                                   const int32_t *__restrict__ src, const double *__restrict__ bank, double *__restrict__ bank_out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    for (int i = t; i < n_new; i += nt) x_kk[i] = x_alt[i];
+    for (int i = t; i < N; i += nt) { lm_type[i] = types_src[i]; lm_off[i] = off_src[i]; }
+    for (int i = t; i < capN; i += nt) { has_h[i] = 0; has_S[i] = 0; }
+    for (int i = t; i < inbox_words; i += nt) inbox[i] = 0;
+    if (bank != nullptr)
+        for (int i = t; i < N * 128; i += nt) { const int sidx = src[i >> 7]; bank_out[i] = sidx >= 0 ? bank[(size_t)sidx * 128 + (i & 127)] : 0.0; }
+}
+
 #define DISPATCH_T(c, expr_f64, expr_f32) do { if ((c)->dtype == PRE3_F64) { expr_f64; } else { expr_f32; } } while (0)
 
 static int ensure_map_buffers(pre3_ctx *c)
@@ -210,20 +227,57 @@ static int ensure_map_buffers(pre3_ctx *c)
     auto bytes = [&](void **p, size_t b) { return hipMalloc(p, b ? b : 16) == hipSuccess; };
     bool ok = bytes(&c->P_alt, (size_t)c->ld * c->ld * c->esz) && bytes((void **)&c->x_alt, sizeof(double) * c->capn) &&
               bytes((void **)&c->map_col, sizeof(int32_t) * (size_t)c->capn * MAPW) && bytes(&c->map_val, c->esz * (size_t)c->capn * MAPW) &&
-              bytes((void **)&c->map_desc, sizeof(int32_t) * 3 * (size_t)c->capn) &&
+              bytes((void **)&c->map_desc, sizeof(int32_t) * (3 * (size_t)c->capn + 3 * (size_t)c->capN + 16) + sizeof(double) * 3 * (size_t)c->capN) &&
               bytes((void **)&c->map_feat, sizeof(double) * (size_t)c->capN * (FEATW > CONVW ? FEATW : CONVW)) &&
               bytes((void **)&c->map_flags, sizeof(int32_t) * c->capN);
     if (!ok) { set_error("map management: device allocation failed"); return PRE3_E_NOMEM; }
+    // two pinned staging blocks ([desc | types | off | src | uvd, rho]: ONE upload per call), used alternately: a block is written again only
+    // after the call before last has been consumed (its event), so a call does not end in a stream synchronisation
+    c->map_stage_bytes = sizeof(int32_t) * (3 * (size_t)c->capn + 3 * (size_t)c->capN + 16) + sizeof(double) * 3 * (size_t)c->capN;
+    for (int k = 0; k < 2; ++k) {
+        if (hipHostMalloc(&c->map_stage[k], c->map_stage_bytes) != hipSuccess || hipEventCreateWithFlags(&c->map_stage_ev[k], hipEventDisableTiming) != hipSuccess) {
+            set_error("map management: pinned staging allocation failed"); return PRE3_E_NOMEM;
+        }
+    }
     return PRE3_OK;
 }
 
-// apply the state map described by desc (3 ints per new row), then install the new landmark table
+// apply the state map described by desc (3 ints per new row), then install the new landmark table.  uvd_rho: 3 n_feat doubles ([u v] per new
+// feature, then rho0 per feature) for pre3_map_add_inverse_depth, staged with everything else.
 static int apply_map(pre3_ctx *c, const std::vector<int32_t> &desc, int n_new, const std::vector<int32_t> &new_types,
-                     int n_feat, int first_new_off, const std::vector<int32_t> &lm_src)
+                     int n_feat, int first_new_off, const std::vector<int32_t> &lm_src, const double *uvd = nullptr, const double *rho0 = nullptr,
+                     double std_pxl = 0.0)
 {
     PRE3_CHECK(n_new <= c->capn && (int)new_types.size() <= c->capN, PRE3_E_ARG, "map management: the new map (N=%zu, n=%d) exceeds the context capacity (N=%d, n=%d)",
                new_types.size(), n_new, c->capN, c->capn);
-    PRE3_HIP(hipMemcpyAsync(c->map_desc, desc.data(), sizeof(int32_t) * desc.size(), hipMemcpyHostToDevice, c->stream));
+    const int N = (int)new_types.size();
+    std::vector<int32_t> off(N ? N : 1);
+    int n = 13;
+    for (int i = 0; i < N; ++i) { off[i] = n; n += new_types[i] == PRE3_INVDEPTH ? 6 : 3; }
+    PRE3_CHECK(n == n_new, PRE3_E_STATE, "map management: internal size mismatch (%d vs %d)", n, n_new);
+    // ---- stage: [desc 3 n_new | types N | off N | src N | pad to 8 bytes | uvd 2 n_feat, rho n_feat]
+    const int k = c->map_stage_next; c->map_stage_next ^= 1;
+    if (c->map_stage_used[k]) PRE3_HIP(hipEventSynchronize(c->map_stage_ev[k]));
+    int32_t *st = static_cast<int32_t *>(c->map_stage[k]);
+    const size_t o_types = desc.size(), o_off = o_types + (size_t)N, o_src = o_off + (size_t)N, o_end = (o_src + (size_t)N + 1) & ~(size_t)1;
+    memcpy(st, desc.data(), sizeof(int32_t) * desc.size());
+    if (N) { memcpy(st + o_types, new_types.data(), sizeof(int32_t) * N); memcpy(st + o_off, off.data(), sizeof(int32_t) * N); memcpy(st + o_src, lm_src.data(), sizeof(int32_t) * N); }
+    size_t bytes = sizeof(int32_t) * o_end;
+    if (n_feat > 0) {
+        double *sd = reinterpret_cast<double *>(st + o_end);
+        memcpy(sd, uvd, sizeof(double) * 2 * n_feat); memcpy(sd + 2 * n_feat, rho0, sizeof(double) * n_feat);
+        bytes += sizeof(double) * 3 * (size_t)n_feat;
+    }
+    PRE3_CHECK(bytes <= c->map_stage_bytes, PRE3_E_ARG, "map management: staging block too small");
+    PRE3_HIP(hipMemcpyAsync(c->map_desc, st, bytes, hipMemcpyHostToDevice, c->stream));
+    PRE3_HIP(hipEventRecord(c->map_stage_ev[k], c->stream));
+    c->map_stage_used[k] = true;
+    const int32_t *d_types = c->map_desc + o_types, *d_off = c->map_desc + o_off, *d_src = c->map_desc + o_src;
+    if (n_feat > 0) {
+        const double *d_uvd = reinterpret_cast<const double *>(c->map_desc + o_end);
+        CamM cam{ c->cam.f, c->cam.Cx, c->cam.Cy, c->cam.k1, c->cam.k2 };
+        hipLaunchKernelGGL(k_map_new_features, dim3(ceil_div(n_feat, 64)), dim3(64), 0, c->stream, n_feat, d_uvd, d_uvd + 2 * n_feat, std_pxl, c->x_kk, cam, c->map_feat);
+    }
     const double *feat = c->map_feat;
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_map_fill<double>, dim3(ceil_div(n_new, 256)), dim3(256), 0, c->stream, n_new, c->map_desc, c->x_kk, feat, feat, c->lm.off, c->map_col, (double *)c->map_val, c->x_alt),
@@ -240,24 +294,13 @@ static int apply_map(pre3_ctx *c, const std::vector<int32_t> &desc, int n_new, c
             hipLaunchKernelGGL(k_map_add_noise<double>, dim3(ceil_div(n_feat * 36, 256)), dim3(256), 0, c->stream, n_feat, first_new_off, feat, (double *)c->P, c->ld),
             hipLaunchKernelGGL(k_map_add_noise<float>, dim3(ceil_div(n_feat * 36, 256)), dim3(256), 0, c->stream, n_feat, first_new_off, feat, (float *)c->P, c->ld));
     }
+    // new state, landmark table, cleared per-landmark fields and inbox, re-laid-out descriptor bank: one launch, no synchronisation
+    const bool with_bank = c->bank != nullptr && c->bank_alt != nullptr && N > 0;
+    const int work = std::max(std::max(n_new, (int)(c->inbox_bytes / 4)), with_bank ? N * 128 : 0);
+    hipLaunchKernelGGL(k_map_finish, dim3(std::min(1024, ceil_div(work, 256))), dim3(256), 0, c->stream, n_new, c->x_alt, c->x_kk, N, d_types, d_off, c->lm.type, c->lm.off,
+                       c->capN, c->lm.has_h, c->lm.has_S, (int32_t *)c->inbox_dev, (int)(c->inbox_bytes / 4), d_src, with_bank ? c->bank : nullptr, c->bank_alt);
     PRE3_HIP(hipGetLastError());
-    PRE3_HIP(hipMemcpyAsync(c->x_kk, c->x_alt, sizeof(double) * n_new, hipMemcpyDeviceToDevice, c->stream));
-    // new landmark table; per-landmark fields cleared (update_features_info.m:30-44)
-    const int N = (int)new_types.size();
-    std::vector<int32_t> off(N ? N : 1);
-    int n = 13;
-    for (int i = 0; i < N; ++i) { off[i] = n; n += new_types[i] == PRE3_INVDEPTH ? 6 : 3; }
-    PRE3_CHECK(n == n_new, PRE3_E_STATE, "map management: internal size mismatch (%d vs %d)", n, n_new);
-    // landmark table + cleared per-landmark fields, all on the stream; ONE synchronisation at the end (the host vectors are locals)
-    if (N) {
-        PRE3_HIP(hipMemcpyAsync(c->lm.type, new_types.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice, c->stream));
-        PRE3_HIP(hipMemcpyAsync(c->lm.off, off.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice, c->stream));
-    }
-    PRE3_HIP(hipMemsetAsync(c->lm.has_h, 0, sizeof(int32_t) * c->capN, c->stream));
-    PRE3_HIP(hipMemsetAsync(c->lm.has_S, 0, sizeof(int32_t) * c->capN, c->stream));
-    PRE3_HIP(hipMemsetAsync(c->inbox_dev, 0, c->inbox_bytes, c->stream));          // meas / ic / z and the inlier flags
-    PRE3_HIP(hipStreamSynchronize(c->stream));
-    PRE3_TRY(launch_bank_gather(c, N, lm_src.data()));
+    if (with_bank) std::swap(c->bank, c->bank_alt);
     c->N = N; c->n = n; c->lm_type_host = new_types;
     c->m = 0; c->meas_host.clear(); c->measurements_set = false; c->projected = false; c->innovated = false; c->hp_all_valid = false;
     c->li_from_host = c->hi_from_host = -1; c->li_kernel = c->hi_kernel = false;
@@ -313,14 +356,7 @@ int pre3_map_add_inverse_depth(pre3_ctx *c, int n_new, const double *uvd, double
     PRE3_CHECK(n_new >= 0 && (n_new == 0 || (uvd && initial_rho)), PRE3_E_ARG, "pre3_map_add_inverse_depth: bad arguments");
     if (n_new == 0) return PRE3_OK;
     PRE3_CHECK(c->N + n_new <= c->capN, PRE3_E_ARG, "pre3_map_add_inverse_depth: %d + %d landmarks exceed the capacity %d", c->N, n_new, c->capN);
-    // stage (uvd, rho0) behind the feature records of the scratch buffer
-    double *d_uvd = c->map_feat + (size_t)c->capN * FEATW - 3 * (size_t)n_new;      // tail of the buffer (capN*FEATW doubles)
-    PRE3_CHECK((size_t)n_new * FEATW + 3 * (size_t)n_new <= (size_t)c->capN * FEATW, PRE3_E_ARG, "pre3_map_add_inverse_depth: too many new features in one call");
-    PRE3_HIP(hipMemcpy(d_uvd, uvd, sizeof(double) * 2 * n_new, hipMemcpyHostToDevice));
-    PRE3_HIP(hipMemcpy(d_uvd + 2 * n_new, initial_rho, sizeof(double) * n_new, hipMemcpyHostToDevice));
-    CamM cam{ c->cam.f, c->cam.Cx, c->cam.Cy, c->cam.k1, c->cam.k2 };
-    hipLaunchKernelGGL(k_map_new_features, dim3(ceil_div(n_new, 64)), dim3(64), 0, c->stream, n_new, d_uvd, d_uvd + 2 * n_new, std_pxl, c->x_kk, cam, c->map_feat);
-    PRE3_HIP(hipGetLastError());
+    PRE3_CHECK((size_t)n_new * FEATW <= (size_t)c->capN * FEATW, PRE3_E_ARG, "pre3_map_add_inverse_depth: too many new features in one call");
     std::vector<int32_t> desc, types(c->lm_type_host), src;
     for (int i = 0; i < c->N; ++i) src.push_back(i);
     for (int i = 0; i < c->n; ++i) { desc.push_back(0); desc.push_back(i); desc.push_back(0); }
@@ -328,7 +364,7 @@ int pre3_map_add_inverse_depth(pre3_ctx *c, int n_new, const double *uvd, double
         for (int q = 0; q < 6; ++q) { desc.push_back(1); desc.push_back(f); desc.push_back(q); }
         types.push_back(PRE3_INVDEPTH); src.push_back(-1);
     }
-    return apply_map(c, desc, c->n + 6 * n_new, types, n_new, c->n, src);
+    return apply_map(c, desc, c->n + 6 * n_new, types, n_new, c->n, src, uvd, initial_rho, std_pxl);
 }
 
 int pre3_map_inversedepth_2_cartesian(pre3_ctx *c, double thr, int32_t *converted_out)
