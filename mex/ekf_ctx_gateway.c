@@ -99,6 +99,16 @@ void mexFunction(int nout, mxArray *out[], int nin, const mxArray *in[])
         if (nout > 1) { out[1] = mxCreateDoubleMatrix(1, 4, mxREAL); for (i = 0; i < 4; ++i) mxGetPr(out[1])[i] = st[i]; }
         mxFree(hyp); mxFree(li); check(rc);
     }
+    else if (!strcmp(cmd, "step_predicted")) {    /* stats = pre3_mex('step_predicted', hyp (n_draw x k, 0-based positions), thr, early_exit, chi2): mono_slam.m:178-187 in one call,
+                                                     behind pre3_mex('predict', u) and pre3_mex('ic_search', ...) (or 'set_measurements'); stats = [best iters n_hyp max_support n_li n_hi] */
+        int n_draw = (int)mxGetM(in[1]), k = (int)mxGetN(in[1]), i, j, rc;
+        int32_t *hyp = (int32_t *)mxMalloc(sizeof(int32_t) * n_draw * k), st[8];
+        for (i = 0; i < n_draw; ++i) for (j = 0; j < k; ++j) hyp[i * k + j] = (int32_t)mxGetPr(in[1])[(size_t)j * n_draw + i];
+        rc = pre3_step_predicted(g_ctx, n_draw, k, hyp, mxGetScalar(in[2]), (int)mxGetScalar(in[3]), nin > 4 ? mxGetScalar(in[4]) : 5.9915, st);
+        out[0] = mxCreateDoubleMatrix(1, 6, mxREAL);
+        for (i = 0; i < 6; ++i) mxGetPr(out[0])[i] = st[i];
+        mxFree(hyp); check(rc);
+    }
     else if (!strcmp(cmd, "rescue")) {            /* hi_mask = pre3_mex('rescue', chi2, m) */
         int m = nin > 2 ? (int)mxGetScalar(in[2]) : 4096, i, rc; int32_t *hi = (int32_t *)mxCalloc(m, sizeof(int32_t));
         rc = pre3_rescue(g_ctx, mxGetScalar(in[1]), hi);
