@@ -294,18 +294,9 @@ def fp64_n200_leg(pre3, synth, steps=40, warm=4):
             f.search_IC_matches()
             f.set_measurements(s["meas_idx"], s["z"])
             f.ekf_update_all()
-        # parity of one predict + update against the C oracle, from the same state
-        s = seq["steps"][0]
-        x1, P1 = orc.predict(seq["x0"], seq["P0"], s["u"])
-        h, has_h = orc.project(types, off, x1, seq["cam"])
-        Hc, Hl = orc.jacobian(types, off, x1, seq["cam"], h, has_h)
-        zfull = np.zeros((N, 2))
-        zfull[s["meas_idx"]] = s["z"]
-        xr, Pr = orc.update_landmarks(types, off, np.asarray(s["meas_idx"], np.int32), x1, P1, Hc, Hl, zfull, h)
-        one(s)
-        xg, Pg = f.get_x_k_k(), f.get_p_k_k()
-        err_x, err_P = float(np.abs(xg - xr).max()), float(np.abs(Pg - Pr).max())
-        for s in seq["steps"][1:1 + warm]:
+        # timed first, checked afterwards: the C oracle's OpenMP pool keeps spinning on the host cores for a while after a call, and this
+        # leg is host-driven (four calls per update): with the check in front the timed loop ran at 450 instead of 5700 updates/s
+        for s in seq["steps"][:1 + warm]:
             one(s)
         f.sync()
         f.kernel_timing(1)
@@ -315,6 +306,18 @@ def fp64_n200_leg(pre3, synth, steps=40, warm=4):
         ev = f.timer_stop()
         kt = f.kernel_timing_read()
         f.kernel_timing(False)
+        # parity of one predict + update against the C oracle, from the same state
+        s = seq["steps"][0]
+        f.set_x_p_k_k(seq["x0"], seq["P0"])
+        one(s)
+        xg, Pg = f.get_x_k_k(), f.get_p_k_k()
+        x1, P1 = orc.predict(seq["x0"], seq["P0"], s["u"])
+        h, has_h = orc.project(types, off, x1, seq["cam"])
+        Hc, Hl = orc.jacobian(types, off, x1, seq["cam"], h, has_h)
+        zfull = np.zeros((N, 2))
+        zfull[s["meas_idx"]] = s["z"]
+        xr, Pr = orc.update_landmarks(types, off, np.asarray(s["meas_idx"], np.int32), x1, P1, Hc, Hl, zfull, h)
+        err_x, err_P = float(np.abs(xg - xr).max()), float(np.abs(Pg - Pr).max())
     finally:
         f.close()
     r = 2 * int(np.mean([len(s_["meas_idx"]) for s_ in seq["steps"][1 + warm:1 + warm + steps]]))
