@@ -965,6 +965,20 @@ __device__ __forceinline__ void dd_vmwait_le(int n)
     }
 }
 
+// The consumers' stores of P are write-through (sc0 sc1): the 37 MB then drain to memory while the launch still runs.  As plain stores they
+// sat dirty in the eight L2s until the end-of-kernel release wrote them back -- a 6-us gap between this launch and the next one
+// (tools/ab_env2.sh PRE3_DD_MODE 1 17: +1.8 % steps/s).
+__device__ __forceinline__ void dd_store_wt(float *d, float v, bool wt)
+{
+    if (wt) asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(d), "v"(v) : "memory");
+    else *d = v;
+}
+__device__ __forceinline__ void dd_store_wt(f4v_t *d, f4v_t v, bool wt)
+{
+    if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(d), "v"(v) : "memory");
+    else *d = v;
+}
+
 __device__ __attribute__((noinline)) void dd_body(CpArgs a_v, int nrb_v, int rows_v, int g_v)
 {
     const CpArgs a = cp_uniform(a_v);
@@ -1075,6 +1089,7 @@ __device__ __attribute__((noinline)) void dd_body(CpArgs a_v, int nrb_v, int row
     // ---- P tile <- P tile - acc, and its mirror image (as k_downdate_b3's epilogue; blocks below the diagonal of a diagonal tile are skipped)
     if (tid == 0 && (g == 0 || g == a.n_dd - 1)) CP_STAMP(g == 0 ? 20 : 21, 15, 0);
     float *P = a.P;
+    const bool wt = (a.dd_mode & 16) != 0;
     const int ld = a.ld, R0 = bi * 64, C0 = bj * 64;
     const int lrow = 4 * (lane >> 5), lcol = lane & 31;
     float pv[2][2][16];
@@ -1102,7 +1117,7 @@ __device__ __attribute__((noinline)) void dd_body(CpArgs a_v, int nrb_v, int row
                 for (int e = 0; e < 16; ++e) {
                     const int lr = (e & 3) + 8 * (e >> 2) + lrow;
                     const float v = pv[i][j][e] - acc[i][j][e];
-                    if (lr <= lcol) P[(size_t)(r0 + lr) * ld + c0 + lcol] = v;
+                    if (lr <= lcol) dd_store_wt(P + (size_t)(r0 + lr) * ld + c0 + lcol, v, wt);
                     patch[lr][lcol] = v;
                 }
                 wave_lds_sync();
@@ -1110,7 +1125,7 @@ __device__ __attribute__((noinline)) void dd_body(CpArgs a_v, int nrb_v, int row
 #pragma unroll
                 for (int cc = 0; cc < 32; cc += 2) {
                     const int c = cc + half;
-                    if (rr < c) P[(size_t)(c0 + c) * ld + r0 + rr] = patch[rr][c];
+                    if (rr < c) dd_store_wt(P + (size_t)(c0 + c) * ld + r0 + rr, patch[rr][c], wt);
                 }
             } else {
 #pragma unroll
@@ -1125,8 +1140,9 @@ __device__ __attribute__((noinline)) void dd_body(CpArgs a_v, int nrb_v, int row
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int row = rr + 8 * it;
-                    *reinterpret_cast<f4v_t *>(P + (size_t)(r0 + row) * ld + c0 + c4) = *reinterpret_cast<const f4v_t *>(&patch[row][c4]);
-                    *reinterpret_cast<f4v_t *>(P + (size_t)(c0 + row) * ld + r0 + c4) = *reinterpret_cast<const f4v_t *>(&patchT[row][c4]);
+                    f4v_t *d0 = reinterpret_cast<f4v_t *>(P + (size_t)(r0 + row) * ld + c0 + c4), *d1 = reinterpret_cast<f4v_t *>(P + (size_t)(c0 + row) * ld + r0 + c4);
+                    const f4v_t v0 = *reinterpret_cast<const f4v_t *>(&patch[row][c4]), v1 = *reinterpret_cast<const f4v_t *>(&patchT[row][c4]);
+                    dd_store_wt(d0, v0, wt); dd_store_wt(d1, v1, wt);
                 }
             }
             wave_lds_sync();
@@ -1351,7 +1367,7 @@ int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior)
     a.cf = c->cholp_flags; a.base = c->cholp_epoch; a.status = c->stats + 6;
     a.n_dev = nrb < 0 ? c->stats + 4 : nullptr; a.nrb = nrb < 0 ? nrb_max : nrb; a.nrb_max = nrb_max; a.n_strips = n_strips;
     a.win = win; a.stride = stride;
-    static const int dd_mode = getenv("PRE3_DD_MODE") ? atoi(getenv("PRE3_DD_MODE")) : 1;      // bit 0: sc1 LDS-DMA of the planes; bit 1: an acquire per panel (experiment); bit 2: P warm-up
+    static const int dd_mode = getenv("PRE3_DD_MODE") ? atoi(getenv("PRE3_DD_MODE")) : 17;     // bit 0: sc1 LDS-DMA of the planes; bit 1: an acquire per panel (experiment); bit 2: P warm-up; bit 4: write-through stores of P
     a.dd_mode = dd_mode;
     // with the consumers in the launch the strips also finish the state: x_k_k = x_prior + W'(L^-1 nu) (the K9 launch that used to carry the
     // x-update as riders has nothing left to do at N = 500)

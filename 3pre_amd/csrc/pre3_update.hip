@@ -1057,9 +1057,10 @@ __device__ __forceinline__ void update_x_block(int blk, int n, int r, const T *_
     if (rg == 0 && i < n) x_out[i] = s;
 }
 
+static inline int k9_write_through() { static const int v = getenv("PRE3_K9_WT") ? atoi(getenv("PRE3_K9_WT")) : 1; return v; }
 struct XUpd { int n_tiles, n, r; const double *x_prior; double *x_out; double *params;
               const int32_t *gate;
-              int nx; };                // x-update workgroups in the launch (0: the state has been updated elsewhere -- the riders behind the tiles are all projection blocks)   // gate != nullptr (the speculative down-date behind k_hi_fused): run only if gate[8] == 1, with r = 2 * gate[5] rows
+              int nx, wt = 0; };        // (wt: P leaves as write-through stores, store_wt)  x-update workgroups in the launch (0: the state has been updated elsewhere -- the riders behind the tiles are all projection blocks)   // gate != nullptr (the speculative down-date behind k_hi_fused): run only if gate[8] == 1, with r = 2 * gate[5] rows
 
 // waves_per_eu: the riders' fp64 geometry must not raise the register count of the tile path (5 workgroups per CU in fp32,
 // 4 in fp64 -- every tile resident at once); if anything spills, it is the riders.
@@ -1239,9 +1240,23 @@ __device__ __forceinline__ void b3_wait(int wave)
 }
 
 // TM x TM tile at 64-column block (bi, bj): 4 waves x (TM/2 x TM/2), i.e. NB x NB accumulators of 32x32 per wave
+// Write-through (sc0 sc1) stores of the down-dated P: the tiles drain to memory while the launch still runs instead of sitting dirty in the
+// eight L2s until the end-of-kernel release writes them back (a ~6-us gap in front of the next launch at N = 500; pre3_cholp.hip: dd_store_wt).
+typedef float store_f4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_wt(float *d, float v, bool wt)
+{
+    if (wt) asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(d), "v"(v) : "memory");
+    else *d = v;
+}
+__device__ __forceinline__ void store_wt(store_f4_t *d, store_f4_t v, bool wt)
+{
+    if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(d), "v"(v) : "memory");
+    else *d = v;
+}
+
 template <int TM>
 __device__ __forceinline__ void b3_tile(float *__restrict__ P, int ld, const bf16x8_t *__restrict__ Wp, int nst_total, int nst, int bi, int bj,
-                                        bf16x8_t *smem /* ring: [3][2][768 granules] */)
+                                        bf16x8_t *smem /* ring: [3][2][768 granules] */, bool wt = false)
 {
     constexpr int NB = TM / 64, PL = (TM / 32) * 64;       // blocks per wave and dimension; granules per plane of an operand stage
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1367,7 +1382,7 @@ __device__ __forceinline__ void b3_tile(float *__restrict__ P, int ld, const bf1
                 for (int e = 0; e < 16; ++e) {
                     const int lr = (e & 3) + 8 * (e >> 2) + lrow;
                     const float v = pv[i][j][e] - acc[i][j][e];
-                    if (lr <= lcol) P[(size_t)(r0 + lr) * ld + c0 + lcol] = v;
+                    if (lr <= lcol) store_wt(P + (size_t)(r0 + lr) * ld + c0 + lcol, v, wt);
                     patch[lr][lcol] = v;
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -1376,7 +1391,7 @@ __device__ __forceinline__ void b3_tile(float *__restrict__ P, int ld, const bf1
 #pragma unroll
                 for (int cc = 0; cc < 32; cc += 2) {
                     const int c = cc + half;
-                    if (rr < c) P[(size_t)(c0 + c) * ld + r0 + rr] = patch[rr][c];
+                    if (rr < c) store_wt(P + (size_t)(c0 + c) * ld + r0 + rr, patch[rr][c], wt);
                 }
             } else {
 #pragma unroll
@@ -1392,8 +1407,8 @@ __device__ __forceinline__ void b3_tile(float *__restrict__ P, int ld, const bf1
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int row = rr + 8 * it;
-                    *reinterpret_cast<f4_t *>(P + (size_t)(r0 + row) * ld + c0 + c4) = *reinterpret_cast<const f4_t *>(&patch[row][c4]);
-                    *reinterpret_cast<f4_t *>(P + (size_t)(c0 + row) * ld + r0 + c4) = *reinterpret_cast<const f4_t *>(&patchT[row][c4]);
+                    store_wt(reinterpret_cast<f4_t *>(P + (size_t)(r0 + row) * ld + c0 + c4), *reinterpret_cast<const f4_t *>(&patch[row][c4]), wt);
+                    store_wt(reinterpret_cast<f4_t *>(P + (size_t)(c0 + row) * ld + r0 + c4), *reinterpret_cast<const f4_t *>(&patchT[row][c4]), wt);
                 }
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -1430,8 +1445,8 @@ __global__ __launch_bounds__(256) void k_downdate_b3(float *__restrict__ P, int 
         g_k9hw[blockIdx.x] = (hw & 0xffff) | ((xcc & 0xf) << 16) | ((unsigned)(t.x >> 16) << 24);
     }
 #endif
-    if (t.x >> 16) b3_tile<128>(P, ld, Wp, nst_total, nst, t.x & 0xffff, t.y, smem);
-    else b3_tile<64>(P, ld, Wp, nst_total, nst, t.x, t.y, smem);
+    if (t.x >> 16) b3_tile<128>(P, ld, Wp, nst_total, nst, t.x & 0xffff, t.y, smem, xu.wt != 0);
+    else b3_tile<64>(P, ld, Wp, nst_total, nst, t.x, t.y, smem, xu.wt != 0);
 #ifdef PRE3_PROBE
     if (threadIdx.x == 0 && blockIdx.x < 2048) g_k9rt[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1638,6 +1653,7 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
         }
         c->dd_done = 0;
         XUpd xu{ n_tiles_launch, c->n, r, which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1, c->x_kk, c->pred_params, nullptr, 0 };
+        xu.wt = k9_write_through();
         const bool x_done = c->x_done && which_prior >= 0;            // the factorisation's strips have computed x_k_k already
         c->x_done = false;
         const int nx = (which_prior >= 0 && !x_done) ? ceil_div(c->n, 64) : 0;
@@ -1659,6 +1675,7 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
         }
     } else if (one_tile) {
         XUpd xu{ c->n_tiles, c->n, r, which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1, c->x_kk, c->pred_params, nullptr, 0 };
+        xu.wt = k9_write_through();
         const int nx = which_prior >= 0 ? ceil_div(c->n, 64) : 0;
         xu.nx = nx;
         ProjRide pr{};
@@ -1705,6 +1722,7 @@ int launch_hi_fused(pre3_ctx *c, int32_t seq)
     // the down-date of that update (one panel: four k-stages), the x-update riding along; every workgroup leaves at once unless stats[8] == 1
     const int nx = ceil_div(c->n, 64);
     XUpd xu{ c->n_tiles128, c->n, 0, c->x_kk, c->x_kk, c->pred_params, c->stats, nx };
+    xu.wt = k9_write_through();
     ProjRide pr{};
     hipLaunchKernelGGL(k_downdate_b3, dim3(c->n_tiles128 + nx), dim3(256), 0, c->stream, (float *)c->P, c->ld, (const bf16x8_t *)c->Wp, c->rcap / B3_BK, 4,
                        (const float *)c->W, c->ldw, (const int2 *)c->tiles128, xu, pr);
