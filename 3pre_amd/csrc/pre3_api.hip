@@ -504,6 +504,7 @@ static int install_measurements(pre3_ctx *c, int m, const int32_t *meas_idx, con
     // a barrier packet into the stream -- and, unlike a stream sync, it does not wait for the kernels queued since)
     if (c->inbox_pending) { PRE3_TRY(wait_mail(c, 10, c->seq_inbox)); c->inbox_pending = false; }
     c->m = m; c->meas_host.assign(meas_idx, meas_idx + m);
+    c->select_pending = false;
     int32_t *hm = (int32_t *)(c->inbox_host + c->off_meas), *hic = (int32_t *)(c->inbox_host + c->off_ic);
     double *hz = (double *)(c->inbox_host + c->off_z);
     memset(hic, 0, sizeof(int32_t) * c->N);
@@ -698,6 +699,8 @@ static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, in
     c->masks = reinterpret_cast<uint32_t *>(c->support + round_up(n_draw, 4));
     c->scored_n_draw = n_draw; c->scored_k = k;         // the mask offset depends on n_draw: select / export / import must use the same
     int r = 2 * c->m, r_pad = round_up(r, NB);
+    static const int inline_g_env = getenv("PRE3_INLINE_G") ? atoi(getenv("PRE3_INLINE_G")) : 1;
+    const bool inline_g = inline_g_env != 0;
     if (hi < 0) hi = n_draw;
     if (lo > 0 || hi < n_draw || slice_form) {
         // a rank's slice of a sharded round: H*P and H*P*H' only for the measurements its hypotheses draw (the scorer of hypothesis h
@@ -706,12 +709,16 @@ static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, in
         ++c->need_tag;
         if (hi > lo) hipLaunchKernelGGL(k_mark_needed, dim3(ceil_div((hi - lo) * k, 256)), dim3(256), 0, c->stream, c->hyp, k, lo, hi, c->need, c->need_tag);
         PRE3_TRY(launch_ell_HP_build(c, c->HP, c->need, c->need_tag));
-        PRE3_TRY(launch_ell_G_hyp(c, k, lo, hi, r_pad));
+        if (!inline_g) PRE3_TRY(launch_ell_G_hyp(c, k, lo, hi, r_pad));
+        c->g_valid = !inline_g;
         c->hp_all_valid = false;
         return PRE3_OK;
     }
     PRE3_TRY(launch_ell_HP_build(c, c->HP));
-    PRE3_TRY(launch_ell_G(c, r, c->HP, c->G, r_pad, 0, nullptr, true));      // lower triangle: the scorer and the LI gather read (max, min)
+    // H*P*H' of all measured rows is no longer built (6.6 us of launch in front of the scoring, PRE3_INLINE_G=0 brings it back): the scorer
+    // computes the (2k)^2 entries among its hypothesis' rows and the LI gather the entries of S it needs, both with k_ell_G's sum
+    if (!inline_g) PRE3_TRY(launch_ell_G(c, r, c->HP, c->G, r_pad, 0, nullptr, true));      // lower triangle: the scorer and the LI gather read (max, min)
+    c->g_valid = !inline_g;
     c->hp_all_valid = true;
     return PRE3_OK;
 }
@@ -844,7 +851,7 @@ int pre3_ransac(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, double thres
                 int32_t stats[4])
 {
     PRE3_TRY(check_ctx(c));
-    c->shard_round = false;
+    c->shard_round = false; c->select_pending = false;
     PRE3_TRY(ransac_prepare(c, n_draw, k, hyp));
     int words = ceil_div(c->m, 32);
     // Scoring, then the selection stage (the reference's loop replayed on the supports) as a launch of its own.  The selection can also ride
@@ -855,6 +862,12 @@ int pre3_ransac(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, double thres
     if (fuse_env) PRE3_TRY(launch_ransac_score_impl(c, k, threshold, 0, n_draw, round_up(2 * c->m, NB), c->support, c->masks, words, n_draw, early_exit));
     else {
         PRE3_TRY(launch_ransac_score_impl(c, k, threshold, 0, n_draw, round_up(2 * c->m, NB), c->support, c->masks, words, 0, 0));
+        // pre3_step: the selection rides in the LI gather's launch (k_select_gather), which pre3_update_li sends next
+        if (c->defer_select && !support && !li_mask && !stats && select_gather_usable(c)) {
+            c->select_pending = true; c->sel_n_draw = n_draw; c->sel_k = k; c->sel_early_exit = early_exit;
+            c->li_from_host = -1; c->li_kernel = true;
+            return PRE3_OK;
+        }
         PRE3_TRY(launch_ransac_select_impl(c, n_draw, k, early_exit, c->support, c->masks, words));
     }
     return ransac_results(c, n_draw, support, li_mask, stats);
@@ -889,10 +902,14 @@ int pre3_update_li(pre3_ctx *c)
     bool gathered = false, first_done = false;
     if (c->li_from_host >= 0) n_li = c->li_from_host;
     else if (c->li_kernel) {
+        const bool fused_sel = c->select_pending && c->p_which == PRE3_X_K_KM1 && c->hp_all_valid && c->m > 0;
+        if (c->select_pending && !fused_sel) PRE3_TRY(launch_ransac_select_impl(c, c->sel_n_draw, c->sel_k, c->sel_early_exit, c->support, c->masks, ceil_div(c->m, 32)));
+        c->select_pending = false;
         // the gather of the LI rows does not need the count on the host: issue it first, with the grid sized for all
         // measurements, so that the GPU has work while the host polls the mailbox and launches the factorisation
         if (c->p_which == PRE3_X_K_KM1 && c->hp_all_valid && c->m > 0) {
-            PRE3_TRY(launch_gather_li(c, -1, c->m, c->sel_rows, round_up(2 * c->m, NB)));
+            if (fused_sel) PRE3_TRY(launch_select_gather(c, c->sel_n_draw, c->sel_k, c->sel_early_exit, ceil_div(c->m, 32)));
+            else PRE3_TRY(launch_gather_li(c, -1, c->m, c->sel_rows, round_up(2 * c->m, NB)));
             gathered = true;
             // ... and so does the first panel of the factorisation (row count read on the device, grid sized for all measurements)
             static const int spec_env = getenv("PRE3_CHOL_SPEC0") ? atoi(getenv("PRE3_CHOL_SPEC0")) : 1;
@@ -999,7 +1016,9 @@ static int step_back(pre3_ctx *c, int m, int n_draw, int k, const int32_t *hyp, 
     bool ran = false;
     if (m >= k && m > 0) {
         // mono_slam.m:178; the statistics are read after pre3_update_li's poll of the same mailbox
+        c->defer_select = true;                                     // the selection stage rides in the LI gather's launch (pre3_update_li below)
         const int rc_r = pre3_ransac(c, n_draw, k, hyp, threshold, early_exit, nullptr, nullptr, nullptr);
+        c->defer_select = false;
         if (c->ride_innovation) {                                   // the H*P launch did not go out (error before it): S_i on its own, flags cleared
             c->ride_innovation = false;
             PRE3_TRY(launch_innovation(c, 0, 0.0, true));

@@ -368,7 +368,8 @@ __global__ __launch_bounds__(512) void k_ransac_score(int hyp_begin, const int32
                                                       const T *__restrict__ HP, int ldw, const T *__restrict__ G, int ldg,
                                                       const double *__restrict__ row_nu, const double *__restrict__ z,
                                                       CamD cam, double threshold, int32_t *support,
-                                                      uint32_t *masks, int mask_words, SelArgs sel)
+                                                      uint32_t *masks, int mask_words, SelArgs sel,
+                                                      const int32_t *__restrict__ row_col, const T *__restrict__ row_val)
 {
     constexpr int R = 2 * K;                // compile-time so that every small array stays in registers
     extern __shared__ double s_res[];       // [m] residuals, then mask words
@@ -425,12 +426,39 @@ __global__ __launch_bounds__(512) void k_ransac_score(int hyp_begin, const int32
     if (wv == solver) {
         // lane (a, b) gathers one entry of the augmented system [S_h | nu_h]; lane 0 then eliminates
         double A[R][R + 1];
+        T gv = (T)0;
+        if (G == nullptr) {
+            // H*P*H' among the hypothesis' own rows, computed here: lane p < R(R+1)/2 takes pair p = (i >= j) and runs k_ell_G's sum for the
+            // entry (max row, min row) term for term (the values a full build of G would hold) -- no launch for G in front of the scoring
+            int pi = 0;
+            while ((pi + 1) * (pi + 2) / 2 <= lane) ++pi;
+            const int pj = lane - pi * (pi + 1) / 2;
+            if (pi < R) {
+                int ri = 0, rj = 0;
+#pragma unroll
+                for (int a = 0; a < R; ++a) { if (a == pi) ri = rows[a]; if (a == pj) rj = rows[a]; }
+                const int ra = ri > rj ? ri : rj, rb = ri > rj ? rj : ri;
+                T vv[ELLW]; int cc[ELLW];
+#pragma unroll
+                for (int t = 0; t < ELLW; ++t) { vv[t] = row_val[rb * ELLW + t]; cc[t] = row_col[rb * ELLW + t]; }
+                T hv[ELLW];
+#pragma unroll
+                for (int t = 0; t < ELLW; ++t) hv[t] = HP[(size_t)ra * ldw + cc[t]];
+#pragma unroll
+                for (int t = 0; t < ELLW; ++t) gv = ell_fma(vv[t], hv[t], gv);
+            }
+        }
 #pragma unroll
         for (int a = 0; a < R; ++a) {
 #pragma unroll
             for (int b = 0; b < R; ++b) {                      // G holds its lower triangle: entry (max, min)
-                const int ra = rows[a] > rows[b] ? rows[a] : rows[b], rb = rows[a] > rows[b] ? rows[b] : rows[a];
-                A[a][b] = (double)G[(size_t)ra * ldg + rb] + (a == b ? 1.0 : 0.0);
+                if (G != nullptr) {
+                    const int ra = rows[a] > rows[b] ? rows[a] : rows[b], rb = rows[a] > rows[b] ? rows[b] : rows[a];
+                    A[a][b] = (double)G[(size_t)ra * ldg + rb] + (a == b ? 1.0 : 0.0);
+                } else {
+                    const int hi_ = a > b ? a : b, lo_ = a > b ? b : a;
+                    A[a][b] = (double)__shfl(gv, hi_ * (hi_ + 1) / 2 + lo_, 64) + (a == b ? 1.0 : 0.0);
+                }
             }
             A[a][R] = row_nu[rows[a]];
         }
@@ -564,9 +592,56 @@ __device__ inline int ransac_n_hyp(int sup, int m)
     return (int)ceil(log(1 - 0.99) / log(1 - (1 - epsilon)));
 }
 
-// The reference's loop only changes state at "improvements" (support > running max), and its exit test
-// n_hyp <= k can only become true at an improvement, so the replay walks the improvements in order:
-// wave 0 finds them 64 supports at a time (prefix max by shuffles + ballot) and evaluates the few hits.
+// The reference's loop (ransac_hypotheses.m:40-80) only changes state at "improvements" (support > running max), and its exit test
+// n_hyp <= k can only become true at an improvement.  n_hyp falls as the support grows, so the FIRST index whose support passes the test is
+// an improvement (every earlier support failed it, hence is smaller) and is where the loop stops; the winner is the first maximum up to
+// there.  Both are reductions: every thread tests its own supports (the logarithms run side by side instead of one improvement after the
+// other), a min over the indices that pass, then a max over (support, -index).  Every thread of the workgroup calls this (barriers inside);
+// threads >= 256 only keep the barriers.
+struct SelBest { int best, iters, n_hyp, max_support; };
+__device__ __forceinline__ SelBest select_find_best(int n_draw, int k, int early_exit, int m, const int32_t *support)
+{
+    __shared__ int s_stop[4];
+    __shared__ unsigned long long s_key[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool act = tid < 256;
+    const int limit = early_exit ? (n_draw < 1000 ? n_draw : 1000) : n_draw;
+    int v4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int it = tid + 256 * q; v4[q] = (act && it < limit) ? support[it] : -1; }
+    int e = limit;                                              // the index the loop stops at (limit: it runs to the end)
+    if (early_exit) {
+        int mine = 0x7fffffff;
+#pragma unroll
+        for (int q = 3; q >= 0; --q) if (v4[q] >= 1 && ransac_n_hyp(v4[q], m) <= k) mine = tid + 256 * q;
+        for (int o = 32; o > 0; o >>= 1) mine = min(mine, __shfl_xor(mine, o, 64));
+        if (act && lane == 0) s_stop[wv] = mine;
+        __syncthreads();
+        const int first = min(min(s_stop[0], s_stop[1]), min(s_stop[2], s_stop[3]));
+        if (first < limit) e = first;
+    }
+    unsigned long long key = 0;                                 // (support, ~index): the maximum is the first largest support
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int it = tid + 256 * q;
+        if (it <= e && v4[q] >= 1) key = max(key, ((unsigned long long)v4[q] << 32) | (unsigned long long)(0xffffffffu - (unsigned)it));
+    }
+    for (int it = tid + 1024; act && it < limit; it += 256) {   // (only without the early exit: more than 1000 supports)
+        const int v = support[it];
+        if (v >= 1) key = max(key, ((unsigned long long)v << 32) | (unsigned long long)(0xffffffffu - (unsigned)it));
+    }
+    for (int o = 32; o > 0; o >>= 1) key = max(key, (unsigned long long)__shfl_xor((long long)key, o, 64));
+    if (act && lane == 0) s_key[wv] = key;
+    __syncthreads();
+    key = max(max(s_key[0], s_key[1]), max(s_key[2], s_key[3]));
+    SelBest r;
+    r.best = key ? (int)(0xffffffffu - (unsigned)(key & 0xffffffffull)) : -1;
+    r.max_support = (int)(key >> 32);
+    r.iters = e < limit ? e + 1 : limit;
+    r.n_hyp = r.best >= 0 ? ransac_n_hyp(r.max_support, m) : 1000;
+    return r;
+}
+
 // out[0..5]: written twice -- device stats (for later kernels) and the pinned host mirror (polled by the host).
 __device__ __forceinline__ void select_body(int n_draw, int k, int early_exit, int m, const int32_t *__restrict__ meas,
                                             int32_t *support, const uint32_t *masks, int mask_words,
@@ -574,49 +649,12 @@ __device__ __forceinline__ void select_body(int n_draw, int k, int early_exit, i
                                             int32_t *__restrict__ sel_rows, int32_t *__restrict__ stats,
                                             int32_t *mail, int seq, int err_idx)
 {
-    __shared__ int s_best, s_iters, s_wcnt[4], s_base;
+    __shared__ int s_wcnt[4], s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) s_base = 0;
-    if (wv == 0) {
-        const int limit = early_exit ? (n_draw < 1000 ? n_draw : 1000) : n_draw;
-        int n_hyp = 1000, max_support = 0, best = -1, iters = limit;
-        bool done = false;
-        for (int base0 = 0; base0 < limit && !done; base0 += 8 * 64) {
-            int v8[8];                                               // 8 chunks of supports in flight at once
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { const int it = base0 + q * 64 + lane; v8[q] = it < limit ? support[it] : -1; }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int base = base0 + q * 64;
-                if (base >= limit || done) continue;
-                const int v = v8[q];
-                int pm = v;                                          // inclusive prefix max over the chunk
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(pm, o, 64); if (lane >= o) pm = max(pm, t); }
-                int excl = __shfl_up(pm, 1, 64);
-                if (lane == 0) excl = -1;
-                excl = max(excl, max_support);
-                unsigned long long hits = __ballot(v > excl);        // improvements, in index order
-                while (hits) {
-                    const int l = __ffsll((long long)hits) - 1;
-                    hits &= hits - 1;
-                    const int sup = __shfl(v, l, 64);
-                    max_support = sup; best = base + l;
-                    if (early_exit) {
-                        n_hyp = ransac_n_hyp(sup, m);
-                        if (n_hyp <= k) { iters = base + l + 1; done = true; break; }
-                    }
-                }
-            }
-        }
-        if (!early_exit && best >= 0) n_hyp = ransac_n_hyp(max_support, m);
-        if (lane == 0) {
-            s_best = best; s_iters = iters;
-            stats[0] = best; stats[1] = iters; stats[2] = n_hyp; stats[3] = max_support;
-        }
-    }
-    __syncthreads();
-    const int best = s_best, iters = s_iters;
+    const SelBest sb = select_find_best(n_draw, k, early_exit, m, support);
+    if (tid == 0) { stats[0] = sb.best; stats[1] = sb.iters; stats[2] = sb.n_hyp; stats[3] = sb.max_support; }
+    const int best = sb.best, iters = sb.iters;
     const bool act = tid < 256;                                            // the launch may have more waves (k_ransac_score: 8): they only keep the barriers
     for (int it = iters + tid; act && it < n_draw; it += 256) support[it] = -1;   // never evaluated by the reference
     // winner's mask -> flags (set_as_most_supported_hypothesis.m:32-52) + ordered compaction of the LI rows
@@ -640,7 +678,7 @@ __device__ __forceinline__ void select_body(int n_draw, int k, int early_exit, i
     if (tid == 0) {
         stats[4] = s_base;
         // host mailbox: payload, system-scope fence, then the sequence word the host polls
-        mail[0] = stats[0]; mail[1] = stats[1]; mail[2] = stats[2]; mail[3] = stats[3]; mail[4] = s_base;
+        mail[0] = sb.best; mail[1] = sb.iters; mail[2] = sb.n_hyp; mail[3] = sb.max_support; mail[4] = s_base;
         // a sharded round (pre3_ransac_sharded): the word behind the all-reduced supports and masks counts the ranks whose slice is missing
         mail[11] = err_idx >= 0 ? support[err_idx] : 0;
         __threadfence_system();
@@ -655,6 +693,93 @@ __global__ __launch_bounds__(256) void k_ransac_select(int n_draw, int k, int ea
                                                        int32_t *mail, int seq, int err_idx)
 {
     select_body(n_draw, k, early_exit, m, meas, support, masks, mask_words, li_meas, lm_li, sel_rows, stats, mail, seq, err_idx);
+}
+
+// ---- selection + LI gather in ONE launch (pre3_step) --------------------------------------------------------------------------------
+// k_ransac_select -> k_gather_li was two dependent launches (7.5 + 7.1 us) for a few hundred integer operations and a copy.  Here every
+// workgroup of the gather replays the selection for itself -- the improvement walk of select_body with its early-exit test evaluated by all
+// improvement lanes of a chunk at once (the test only depends on the lane's own support; the first lane that passes it is where the
+// reference's loop stops), then the winner's mask -> ordered list of LI measurements in LDS -- and gathers its rows of H*P (-> W) or
+// computes its entries of S = H*P*H' + I from the ELL rows (k_ell_G's sum, term for term).  One more workgroup (blockIdx.y == ny) runs
+// select_body itself: the flags, the list, the counts and the mailbox for everything downstream (k_cholp reads the row count it leaves).
+constexpr int SG_RB = 8;                    // rows per workgroup
+constexpr int SG_MAXW = 64;                 // mask words a wave takes in one go (m <= 2048)
+template <typename T>
+__global__ __launch_bounds__(256) void k_select_gather(int n_draw, int k, int early_exit, int m, const int32_t *__restrict__ meas,
+                                                       int32_t *support, const uint32_t *masks, int mask_words,
+                                                       int32_t *__restrict__ li_meas, int32_t *__restrict__ lm_li, int32_t *__restrict__ sel_rows,
+                                                       int32_t *__restrict__ stats, int32_t *mail, int seq,
+                                                       int ny, int gxW, const T *__restrict__ HP, T *__restrict__ W, int ldw,
+                                                       const int32_t *__restrict__ row_col, const T *__restrict__ row_val, T *__restrict__ S, int dbg)
+{
+    if ((int)blockIdx.y == ny) {
+        if (blockIdx.x == 0 && !(dbg & 4)) select_body(n_draw, k, early_exit, m, meas, support, masks, mask_words, li_meas, lm_li, sel_rows, stats, mail, seq);
+        return;
+    }
+    if (dbg & 8) return;
+    __shared__ int s_sel[SG_MAXW * 32];
+    __shared__ int s_pre[SG_MAXW + 1];
+    __shared__ uint32_t s_word[SG_MAXW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int best = select_find_best(n_draw, k, early_exit, m, support).best;
+    if (wv == 0) {
+        // the winner's mask: one word per lane, exclusive prefix of the popcounts
+        uint32_t wd = (best >= 0 && lane < mask_words) ? masks[(size_t)best * mask_words + lane] : 0u;
+        if (lane == mask_words - 1 && (m & 31)) wd &= (1u << (m & 31)) - 1u;
+        int inc = __popc(wd);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        s_word[lane] = wd; s_pre[lane + 1] = inc;
+        if (lane == 0) s_pre[0] = 0;
+    }
+    __syncthreads();
+    for (int j = tid; j < m; j += 256) {
+        const uint32_t wd = s_word[j >> 5];
+        if ((wd >> (j & 31)) & 1u) s_sel[s_pre[j >> 5] + __popc(wd & ((1u << (j & 31)) - 1u))] = j;
+    }
+    __syncthreads();
+    const int r = 2 * s_pre[mask_words], r_pad = (r + NB - 1) / NB * NB;
+    const int a0 = blockIdx.y * SG_RB;
+    if (a0 >= r_pad) return;
+    if ((int)blockIdx.x < gxW) {
+        if (dbg & 2) return;
+        const int j = (blockIdx.x * 256 + tid) * 4;
+        if (j >= ldw) return;
+        typedef T v4_t __attribute__((ext_vector_type(4)));
+        v4_t v[SG_RB];
+#pragma unroll
+        for (int q = 0; q < SG_RB; ++q) {
+            const int a = a0 + q;
+            v[q] = v4_t{ (T)0, (T)0, (T)0, (T)0 };
+            if (a < r) v[q] = *reinterpret_cast<const v4_t *>(HP + (size_t)(2 * s_sel[a >> 1] + (a & 1)) * ldw + j);
+        }
+#pragma unroll
+        for (int q = 0; q < SG_RB; ++q) *reinterpret_cast<v4_t *>(W + (size_t)(a0 + q) * ldw + j) = v[q];      // (r_pad is a multiple of 64: all SG_RB rows are inside)
+    } else {
+        const int b = (blockIdx.x - gxW) * 256 + tid;
+        if (b >= r_pad) return;
+        // S holds its lower triangle (the factorisation never reads above the diagonal: 0 / 1 there); sel is ascending
+        const bool any = b < r && b <= a0 + SG_RB - 1 && !(dbg & 1);
+        T vv[ELLW]; int cc[ELLW];
+        if (any) {
+            const int rb = 2 * s_sel[b >> 1] + (b & 1);
+#pragma unroll
+            for (int t = 0; t < ELLW; ++t) { vv[t] = row_val[rb * ELLW + t]; cc[t] = row_col[rb * ELLW + t]; }
+        }
+#pragma unroll
+        for (int q = 0; q < SG_RB; ++q) {
+            const int a = a0 + q;
+            T out = (a == b) ? (T)1 : (T)0;
+            if (any && a < r && b <= a) {
+                const T *hp = HP + (size_t)(2 * s_sel[a >> 1] + (a & 1)) * ldw;
+                T g = (T)0;
+#pragma unroll
+                for (int t = 0; t < ELLW; ++t) g = ell_fma(vv[t], hp[cc[t]], g);
+                out += g;
+            }
+            S[(size_t)a * r_pad + b] = out;
+        }
+    }
 }
 
 // hi flags (landmark order, written by k_innovation mode 1) -> measurement order + compacted list
@@ -878,8 +1003,8 @@ template <typename T>
 static void launch_score_k(pre3_ctx *c, int k, int nb, size_t shm, int hyp_begin, double threshold, int ldg, int32_t *support_dev,
                            uint32_t *mask_dev, int mask_words, const SelArgs &sel)
 {
-#define SCORE_ARGS hyp_begin, c->hyp, c->m, c->meas, c->lm.type, c->lm.off, c->x_km1, (const T *)c->HP, c->ldw, (const T *)c->G, ldg, \
-                   c->row_nu, c->lm.z, to_camd(c->cam), threshold, support_dev, mask_dev, mask_words, sel
+#define SCORE_ARGS hyp_begin, c->hyp, c->m, c->meas, c->lm.type, c->lm.off, c->x_km1, (const T *)c->HP, c->ldw, c->g_valid ? (const T *)c->G : (const T *)nullptr, ldg, \
+                   c->row_nu, c->lm.z, to_camd(c->cam), threshold, support_dev, mask_dev, mask_words, sel, c->row_col, (const T *)c->row_val
     switch (k) {
     case 1: hipLaunchKernelGGL((k_ransac_score<T, 1>), dim3(nb), dim3(SCORE_THREADS), shm, c->stream, SCORE_ARGS); break;
     case 2: hipLaunchKernelGGL((k_ransac_score<T, 2>), dim3(nb), dim3(SCORE_THREADS), shm, c->stream, SCORE_ARGS); break;
@@ -911,6 +1036,30 @@ int launch_ransac_select_impl(pre3_ctx *c, int n_draw, int k, int early_exit, in
 {
     hipLaunchKernelGGL(k_ransac_select, dim3(1), dim3(256), 0, c->stream, n_draw, k, early_exit, c->m, c->meas, support_dev, mask_dev,
                        mask_words, c->li_meas, c->lm.li, c->sel_rows, c->stats, c->mail_dev, ++c->seq_select, err_idx);
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
+bool select_gather_usable(const pre3_ctx *c)
+{
+    static const int env = getenv("PRE3_SELECT_GATHER") ? atoi(getenv("PRE3_SELECT_GATHER")) : 1;
+    return env && c->m > 0 && ceil_div(c->m, 32) <= SG_MAXW;
+}
+
+int launch_select_gather(pre3_ctx *c, int n_draw, int k, int early_exit, int mask_words)
+{
+    const int r_pad_max = round_up(2 * c->m, NB), ny = r_pad_max / SG_RB;
+    const int gxW = ceil_div(c->ldw / 4, 256);
+    dim3 g(gxW + ceil_div(r_pad_max, 256), ny + 1), b(256);
+    const int seq = ++c->seq_select;
+    static const int dbg = getenv("PRE3_SG_DBG") ? atoi(getenv("PRE3_SG_DBG")) : 0;
+    DISPATCH_T(c,
+        hipLaunchKernelGGL(k_select_gather<double>, g, b, 0, c->stream, n_draw, k, early_exit, c->m, c->meas, c->support, c->masks, mask_words, c->li_meas, c->lm.li,
+                           c->sel_rows, c->stats, c->mail_dev, seq, ny, gxW, (const double *)c->HP, (double *)c->W, c->ldw, c->row_col,
+                           (const double *)c->row_val, (double *)c->Smat, dbg),
+        hipLaunchKernelGGL(k_select_gather<float>, g, b, 0, c->stream, n_draw, k, early_exit, c->m, c->meas, c->support, c->masks, mask_words, c->li_meas, c->lm.li,
+                           c->sel_rows, c->stats, c->mail_dev, seq, ny, gxW, (const float *)c->HP, (float *)c->W, c->ldw, c->row_col,
+                           (const float *)c->row_val, (float *)c->Smat, dbg));
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }

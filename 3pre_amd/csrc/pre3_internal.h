@@ -38,6 +38,13 @@ constexpr int NB = 64;          // Cholesky / triangular-solve panel width
 constexpr int ELLW = 16;        // ELL width of measurement rows (7 pose + 6 landmark = 13 used)
 constexpr int MAXK = 4;         // landmarks per RANSAC hypothesis (reference uses 3 or 1)
 
+// one term of an ELL row product (k_ell_G and everything that restates its sums entry by entry: the scorer, the LI gather): an explicit fma,
+// so that every kernel holding that sum rounds it the same way
+#ifdef __HIPCC__
+__device__ __forceinline__ float ell_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double ell_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+#endif
+
 // flags of the per-landmark table
 struct LmBuffers {
     int32_t *type = nullptr, *off = nullptr;          // [N]
@@ -128,6 +135,10 @@ struct pre3_ctx {
     // sequence word, so the host learns r for the next launches by polling instead of a copy + stream sync
     int32_t *mail_host = nullptr, *mail_dev = nullptr;
     int32_t seq_select = 0, seq_collect = 0;
+    bool g_valid = false;                         // c->G holds H*P*H' of all measured rows (PRE3_INLINE_G=0); otherwise the scorer and the LI gather compute their entries
+    // pre3_step: the selection stage of the RANSAC round is not launched by pre3_ransac but rides in the LI gather's launch (k_select_gather)
+    bool defer_select = false, select_pending = false;
+    int sel_n_draw = 0, sel_k = 0, sel_early_exit = 0;
     int li_from_host = -1, hi_from_host = -1;     // row counts forced through pre3_set_flags (-1: use the kernels' counts)
     bool li_kernel = false, hi_kernel = false;    // a select / collect kernel has run for the current measurement set
     // per-step inbox: [meas | ic | hyp | z] contiguous on the device, mirrored in pinned host memory -> ONE H2D copy
@@ -222,6 +233,8 @@ int launch_chol_first_spec(pre3_ctx *c, int nsel_max);
 int launch_ell_HP_build(pre3_ctx *c, void *dst, const int32_t *need = nullptr, int need_tag = 0 /* sharded RANSAC: only the measurements with need[s] == need_tag */);
 int launch_ell_G_hyp(pre3_ctx *c, int k, int lo, int hi, int ldg);                 /* H*P*H' entries among each hypothesis' own rows, hypotheses [lo, hi) */
 int launch_gather_li(pre3_ctx *c, int nsel /* < 0: count read on the device */, int nsel_max, const int32_t *sel_dev, int ldg);
+int launch_select_gather(pre3_ctx *c, int n_draw, int k, int early_exit, int mask_words);     // selection + LI gather in one launch (pre3_geom.hip)
+bool select_gather_usable(const pre3_ctx *c);
 int launch_ell_HP(pre3_ctx *c, int r, void *dst /*r_pad x ldw*/, bool with_nu);
 int launch_ell_G(pre3_ctx *c, int r, const void *HPsrc, void *dst, int ldg, int add_identity, const void *Rdense, bool lower_only = false);
 int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior = -1 /* >= 0: also x <- x_prior + W'y (update.m:36) */);

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64) void k_ell_G(int r, int r_pad, const int32_t *_
     } else if (a < r && b < r) {
         T s = (T)0;
 #pragma unroll
-        for (int t = 0; t < ELLW; ++t) s += row_val[b * ELLW + t] * HP[(size_t)a * ldw + row_col[b * ELLW + t]];
+        for (int t = 0; t < ELLW; ++t) s = ell_fma(row_val[b * ELLW + t], HP[(size_t)a * ldw + row_col[b * ELLW + t]], s);
         if (Rd) s += Rd[(size_t)a * r + b];
         else if (add_identity && a == b) s += (T)1;
         out = s;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_ell_G_hyp(const int32_t *__restrict__ h
     const int a = ri > rj ? ri : rj, b = ri > rj ? rj : ri;
     T s = (T)0;
 #pragma unroll
-    for (int t = 0; t < ELLW; ++t) s += row_val[b * ELLW + t] * HP[(size_t)a * ldw + row_col[b * ELLW + t]];
+    for (int t = 0; t < ELLW; ++t) s = ell_fma(row_val[b * ELLW + t], HP[(size_t)a * ldw + row_col[b * ELLW + t]], s);
     dst[(size_t)a * ldg + b] = s;
 }
 
@@ -1750,7 +1750,7 @@ int launch_fill_w(pre3_ctx *c, int r_pad)
 template <typename T>
 __global__ __launch_bounds__(256) void k_gather_li(int nsel, const int32_t *__restrict__ n_dev, int gxW, const int32_t *__restrict__ sel,
                                                    const T *__restrict__ HP, T *__restrict__ W, int ldw, const T *__restrict__ G, int ldg,
-                                                   T *__restrict__ S)
+                                                   T *__restrict__ S, const int32_t *__restrict__ row_col, const T *__restrict__ row_val)
 {
     const int r = 2 * (nsel >= 0 ? nsel : n_dev[0]);
     const int r_pad = (r + NB - 1) / NB * NB;
@@ -1769,7 +1769,16 @@ __global__ __launch_bounds__(256) void k_gather_li(int nsel, const int32_t *__re
         T out = (a == b) ? (T)1 : (T)0;
         // G holds its lower triangle (64-column granularity); sel is ascending, so b <= a maps to a lower entry; the factorisation
         // never reads S above the diagonal (kept at 0 / 1 there)
-        if (a < r && b < r && b <= a) out += G[(size_t)(2 * sel[a >> 1] + (a & 1)) * ldg + 2 * sel[b >> 1] + (b & 1)];
+        if (a < r && b < r && b <= a) {
+            const int ra = 2 * sel[a >> 1] + (a & 1), rb = 2 * sel[b >> 1] + (b & 1);
+            if (G != nullptr) out += G[(size_t)ra * ldg + rb];
+            else {                                              // k_ell_G's sum for this entry, here (no H*P*H' of all measured rows is built)
+                T g = (T)0;
+#pragma unroll
+                for (int t = 0; t < ELLW; ++t) g = ell_fma(row_val[rb * ELLW + t], HP[(size_t)ra * ldw + row_col[rb * ELLW + t]], g);
+                out += g;
+            }
+        }
         S[(size_t)a * r_pad + b] = out;
     }
 }
@@ -1781,8 +1790,8 @@ int launch_gather_li(pre3_ctx *c, int nsel, int nsel_max, const int32_t *sel_dev
     const int gxW = ceil_div(c->ldw / 4, 256);
     dim3 g(gxW + ceil_div(r_pad, 256), r_pad), b(256);
     DISPATCH_T(c,
-        hipLaunchKernelGGL(k_gather_li<double>, g, b, 0, c->stream, nsel, c->stats + 4, gxW, sel_dev, (const double *)c->HP, (double *)c->W, c->ldw, (const double *)c->G, ldg, (double *)c->Smat),
-        hipLaunchKernelGGL(k_gather_li<float>, g, b, 0, c->stream, nsel, c->stats + 4, gxW, sel_dev, (const float *)c->HP, (float *)c->W, c->ldw, (const float *)c->G, ldg, (float *)c->Smat));
+        hipLaunchKernelGGL(k_gather_li<double>, g, b, 0, c->stream, nsel, c->stats + 4, gxW, sel_dev, (const double *)c->HP, (double *)c->W, c->ldw, c->g_valid ? (const double *)c->G : nullptr, ldg, (double *)c->Smat, c->row_col, (const double *)c->row_val),
+        hipLaunchKernelGGL(k_gather_li<float>, g, b, 0, c->stream, nsel, c->stats + 4, gxW, sel_dev, (const float *)c->HP, (float *)c->W, c->ldw, c->g_valid ? (const float *)c->G : nullptr, ldg, (float *)c->Smat, c->row_col, (const float *)c->row_val));
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }

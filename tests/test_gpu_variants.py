@@ -19,6 +19,8 @@ VARIANTS = [
     {"PRE3_HI_FUSED": "0"},                                 # the rescue stage's collection + HI update as four launches sized by a host poll instead of k_hi_fused
     {"PRE3_DD_MAX": "3"},                                   # only three tile groups down-dated inside the persistent launch, the rest (and the rescue's projection) in the launch behind it
     {"PRE3_K9_OVERLAP": "0"},                               # the down-date as a launch behind the persistent factorisation instead of consumers inside it
+    {"PRE3_INLINE_G": "0"},                                 # H*P*H' of all measured rows built by a launch of its own instead of entry by entry in the scorer / the LI gather
+    {"PRE3_SELECT_GATHER": "0"},                            # the selection stage and the LI gather as two launches instead of k_select_gather
     {"PRE3_CHOL_EARLY": "0"},                               # the padded last panel runs all ten chain steps (the skipped ones change nothing)
 ]      # (not here: PRE3_CHOL_PRO_B3 / PRE3_K9_B3 change the ARITHMETIC of the fp32 path -- f32 MFMA instead of the bf16 split -- not just the launches)
 
