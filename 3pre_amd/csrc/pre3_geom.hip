@@ -704,20 +704,12 @@ __global__ __launch_bounds__(256) void k_ransac_select(int n_draw, int k, int ea
 // select_body itself: the flags, the list, the counts and the mailbox for everything downstream (k_cholp reads the row count it leaves).
 constexpr int SG_RB = 8;                    // rows per workgroup
 constexpr int SG_MAXW = 64;                 // mask words a wave takes in one go (m <= 2048)
-template <typename T>
-__global__ __launch_bounds__(256) void k_select_gather(int n_draw, int k, int early_exit, int m, const int32_t *__restrict__ meas,
-                                                       int32_t *support, const uint32_t *masks, int mask_words,
-                                                       int32_t *__restrict__ li_meas, int32_t *__restrict__ lm_li, int32_t *__restrict__ sel_rows,
-                                                       int32_t *__restrict__ stats, int32_t *mail, int seq,
-                                                       int ny, int gxW, const T *__restrict__ HP, T *__restrict__ W, int ldw,
-                                                       const int32_t *__restrict__ row_col, const T *__restrict__ row_val, T *__restrict__ S, int dbg)
+constexpr int SGL_RB = 4;                   // rows per workgroup of the staged form
+
+// The selection replayed by this workgroup: the ordered list of LI measurement positions into s_sel, their number returned.
+__device__ __forceinline__ int select_local_list(int n_draw, int k, int early_exit, int m, const int32_t *support, const uint32_t *masks, int mask_words,
+                                                 int *s_sel /* [SG_MAXW * 32] */)
 {
-    if ((int)blockIdx.y == ny) {
-        if (blockIdx.x == 0 && !(dbg & 4)) select_body(n_draw, k, early_exit, m, meas, support, masks, mask_words, li_meas, lm_li, sel_rows, stats, mail, seq);
-        return;
-    }
-    if (dbg & 8) return;
-    __shared__ int s_sel[SG_MAXW * 32];
     __shared__ int s_pre[SG_MAXW + 1];
     __shared__ uint32_t s_word[SG_MAXW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -738,11 +730,27 @@ __global__ __launch_bounds__(256) void k_select_gather(int n_draw, int k, int ea
         if ((wd >> (j & 31)) & 1u) s_sel[s_pre[j >> 5] + __popc(wd & ((1u << (j & 31)) - 1u))] = j;
     }
     __syncthreads();
-    const int r = 2 * s_pre[mask_words], r_pad = (r + NB - 1) / NB * NB;
+    return s_pre[mask_words];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_select_gather(int n_draw, int k, int early_exit, int m, const int32_t *__restrict__ meas,
+                                                       int32_t *support, const uint32_t *masks, int mask_words,
+                                                       int32_t *__restrict__ li_meas, int32_t *__restrict__ lm_li, int32_t *__restrict__ sel_rows,
+                                                       int32_t *__restrict__ stats, int32_t *mail, int seq,
+                                                       int ny, int gxW, const T *__restrict__ HP, T *__restrict__ W, int ldw,
+                                                       const int32_t *__restrict__ row_col, const T *__restrict__ row_val, T *__restrict__ S)
+{
+    if ((int)blockIdx.y == ny) {
+        if (blockIdx.x == 0) select_body(n_draw, k, early_exit, m, meas, support, masks, mask_words, li_meas, lm_li, sel_rows, stats, mail, seq);
+        return;
+    }
+    __shared__ int s_sel[SG_MAXW * 32];
+    const int tid = threadIdx.x;
+    const int r = 2 * select_local_list(n_draw, k, early_exit, m, support, masks, mask_words, s_sel), r_pad = (r + NB - 1) / NB * NB;
     const int a0 = blockIdx.y * SG_RB;
     if (a0 >= r_pad) return;
     if ((int)blockIdx.x < gxW) {
-        if (dbg & 2) return;
         const int j = (blockIdx.x * 256 + tid) * 4;
         if (j >= ldw) return;
         typedef T v4_t __attribute__((ext_vector_type(4)));
@@ -759,7 +767,7 @@ __global__ __launch_bounds__(256) void k_select_gather(int n_draw, int k, int ea
         const int b = (blockIdx.x - gxW) * 256 + tid;
         if (b >= r_pad) return;
         // S holds its lower triangle (the factorisation never reads above the diagonal: 0 / 1 there); sel is ascending
-        const bool any = b < r && b <= a0 + SG_RB - 1 && !(dbg & 1);
+        const bool any = b < r && b <= a0 + SG_RB - 1;
         T vv[ELLW]; int cc[ELLW];
         if (any) {
             const int rb = 2 * s_sel[b >> 1] + (b & 1);
@@ -772,6 +780,67 @@ __global__ __launch_bounds__(256) void k_select_gather(int n_draw, int k, int ea
             T out = (a == b) ? (T)1 : (T)0;
             if (any && a < r && b <= a) {
                 const T *hp = HP + (size_t)(2 * s_sel[a >> 1] + (a & 1)) * ldw;
+                T g = (T)0;
+#pragma unroll
+                for (int t = 0; t < ELLW; ++t) g = ell_fma(vv[t], hp[cc[t]], g);
+                out += g;
+            }
+            S[(size_t)a * r_pad + b] = out;
+        }
+    }
+}
+
+// The staged form (the SGL_RB rows of H*P fit in LDS: N = 500 in fp32): a workgroup reads its rows ONCE -- 16-byte loads, on their way to W
+// and into LDS -- and takes the entries of S out of LDS.  In the form above every row is read by the W copy and, entry by entry, by the S
+// workgroups, from an L2 that another XCD's k_ell_HP_build wrote (13.8 us against ~10).
+template <typename T>
+__global__ __launch_bounds__(256) void k_select_gather_lds(int n_draw, int k, int early_exit, int m, const int32_t *__restrict__ meas,
+                                                           int32_t *support, const uint32_t *masks, int mask_words,
+                                                           int32_t *__restrict__ li_meas, int32_t *__restrict__ lm_li, int32_t *__restrict__ sel_rows,
+                                                           int32_t *__restrict__ stats, int32_t *mail, int seq,
+                                                           int ny, const T *__restrict__ HP, T *__restrict__ W, int ldw,
+                                                           const int32_t *__restrict__ row_col, const T *__restrict__ row_val, T *__restrict__ S)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sg_smem[];
+    if ((int)blockIdx.x == ny) {
+        select_body(n_draw, k, early_exit, m, meas, support, masks, mask_words, li_meas, lm_li, sel_rows, stats, mail, seq);
+        return;
+    }
+    __shared__ int s_sel[SG_MAXW * 32];
+    const int tid = threadIdx.x;
+    const int r = 2 * select_local_list(n_draw, k, early_exit, m, support, masks, mask_words, s_sel), r_pad = (r + NB - 1) / NB * NB;
+    const int a0 = blockIdx.x * SGL_RB;
+    if (a0 >= r_pad) return;
+    T *rows = reinterpret_cast<T *>(sg_smem);
+    typedef T v4_t __attribute__((ext_vector_type(4)));
+    const T *src[SGL_RB];
+#pragma unroll
+    for (int q = 0; q < SGL_RB; ++q) { const int a = a0 + q; src[q] = a < r ? HP + (size_t)(2 * s_sel[a >> 1] + (a & 1)) * ldw : nullptr; }
+    for (int j = tid * 4; j < ldw; j += 1024) {
+        v4_t v[SGL_RB];
+#pragma unroll
+        for (int q = 0; q < SGL_RB; ++q) v[q] = src[q] ? *reinterpret_cast<const v4_t *>(src[q] + j) : v4_t{ (T)0, (T)0, (T)0, (T)0 };
+#pragma unroll
+        for (int q = 0; q < SGL_RB; ++q) {
+            *reinterpret_cast<v4_t *>(W + (size_t)(a0 + q) * ldw + j) = v[q];
+            *reinterpret_cast<v4_t *>(rows + (size_t)q * ldw + j) = v[q];
+        }
+    }
+    __syncthreads();
+    for (int b = tid; b < r_pad; b += 256) {
+        const bool any = b < r && b <= a0 + SGL_RB - 1;
+        T vv[ELLW]; int cc[ELLW];
+        if (any) {
+            const int rb = 2 * s_sel[b >> 1] + (b & 1);
+#pragma unroll
+            for (int t = 0; t < ELLW; ++t) { vv[t] = row_val[rb * ELLW + t]; cc[t] = row_col[rb * ELLW + t]; }
+        }
+#pragma unroll
+        for (int q = 0; q < SGL_RB; ++q) {
+            const int a = a0 + q;
+            T out = (a == b) ? (T)1 : (T)0;
+            if (any && a < r && b <= a) {
+                const T *hp = rows + (size_t)q * ldw;
                 T g = (T)0;
 #pragma unroll
                 for (int t = 0; t < ELLW; ++t) g = ell_fma(vv[t], hp[cc[t]], g);
@@ -1048,18 +1117,31 @@ bool select_gather_usable(const pre3_ctx *c)
 
 int launch_select_gather(pre3_ctx *c, int n_draw, int k, int early_exit, int mask_words)
 {
-    const int r_pad_max = round_up(2 * c->m, NB), ny = r_pad_max / SG_RB;
+    const int r_pad_max = round_up(2 * c->m, NB);
+    const int seq = ++c->seq_select;
+    static const int lds_env = getenv("PRE3_SELECT_GATHER_LDS") ? atoi(getenv("PRE3_SELECT_GATHER_LDS")) : 1;
+    const size_t stage = (size_t)SGL_RB * c->ldw * (c->dtype == PRE3_F64 ? 8 : 4);
+    if (lds_env && stage <= 56 * 1024) {
+        const int ny = r_pad_max / SGL_RB;
+        dim3 g(ny + 1), b(256);
+        DISPATCH_T(c,
+            hipLaunchKernelGGL(k_select_gather_lds<double>, g, b, stage, c->stream, n_draw, k, early_exit, c->m, c->meas, c->support, c->masks, mask_words, c->li_meas, c->lm.li,
+                               c->sel_rows, c->stats, c->mail_dev, seq, ny, (const double *)c->HP, (double *)c->W, c->ldw, c->row_col, (const double *)c->row_val, (double *)c->Smat),
+            hipLaunchKernelGGL(k_select_gather_lds<float>, g, b, stage, c->stream, n_draw, k, early_exit, c->m, c->meas, c->support, c->masks, mask_words, c->li_meas, c->lm.li,
+                               c->sel_rows, c->stats, c->mail_dev, seq, ny, (const float *)c->HP, (float *)c->W, c->ldw, c->row_col, (const float *)c->row_val, (float *)c->Smat));
+        PRE3_HIP(hipGetLastError());
+        return PRE3_OK;
+    }
+    const int ny = r_pad_max / SG_RB;
     const int gxW = ceil_div(c->ldw / 4, 256);
     dim3 g(gxW + ceil_div(r_pad_max, 256), ny + 1), b(256);
-    const int seq = ++c->seq_select;
-    static const int dbg = getenv("PRE3_SG_DBG") ? atoi(getenv("PRE3_SG_DBG")) : 0;
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_select_gather<double>, g, b, 0, c->stream, n_draw, k, early_exit, c->m, c->meas, c->support, c->masks, mask_words, c->li_meas, c->lm.li,
                            c->sel_rows, c->stats, c->mail_dev, seq, ny, gxW, (const double *)c->HP, (double *)c->W, c->ldw, c->row_col,
-                           (const double *)c->row_val, (double *)c->Smat, dbg),
+                           (const double *)c->row_val, (double *)c->Smat),
         hipLaunchKernelGGL(k_select_gather<float>, g, b, 0, c->stream, n_draw, k, early_exit, c->m, c->meas, c->support, c->masks, mask_words, c->li_meas, c->lm.li,
                            c->sel_rows, c->stats, c->mail_dev, seq, ny, gxW, (const float *)c->HP, (float *)c->W, c->ldw, c->row_col,
-                           (const float *)c->row_val, (float *)c->Smat, dbg));
+                           (const float *)c->row_val, (float *)c->Smat));
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }
