@@ -5,8 +5,10 @@
 //   add_a_feature_covariance_inverse_depth.m:83-90  A = [I ; dy_dxv], D = dy_dhd Padd dy_dhd' on the new 6x6 block
 //   inversedepth_2_cartesian.m:58-72                A = blkdiag(I, J(3x6), I)
 // A is built row by row on the device (k_map_fill: <= 6 non-zeros per row) from a host-made row descriptor list, then
-// applied by two gather passes through a second ld x ld buffer:  T = A P  (k_map_rows, coalesced along columns) and
-// P = T A'  (k_map_cols).  Rows that are plain copies (coefficient 1) reproduce their source bit for bit.
+// applied in ONE pass into a second ld x ld buffer that becomes P (k_map_one: out[a][b] = sum_t val[b][t] * T[a][col[b][t]] with
+// T[a][c] = sum_t val[a][t] * P[col[a][t]][c] formed on the fly and rounded as a stored T would be; almost every entry is a plain copy
+// P[src(a)][src(b)] -- 36 MB read + 36 MB written at N = 500 instead of the two gather passes T = A P, P = T A' of rounds 1-3, which moved
+// twice that at half the rate: 53 -> ~17 us per call).  Rows that are plain copies (coefficient 1) reproduce their source bit for bit.
 #include <algorithm>
 
 #include "pre3_internal.h"
@@ -131,11 +133,12 @@ __global__ void k_map_convert_flags(int N, const int32_t *__restrict__ lm_type, 
 template <typename T>
 __global__ void k_map_fill(int n_new, const int32_t *__restrict__ desc, const double *__restrict__ x_old, const double *__restrict__ feat,
                            const double *__restrict__ conv, const int32_t *__restrict__ lm_off_old, int32_t *__restrict__ col,
-                           T *__restrict__ val, double *__restrict__ x_new)
+                           T *__restrict__ val, double *__restrict__ x_new, int32_t *__restrict__ src0)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n_new) return;
     const int kind = desc[3 * a], p0 = desc[3 * a + 1], p1 = desc[3 * a + 2];
+    src0[a] = kind == 0 ? p0 : -1;                  // k_map_one: the old row / column a plain copy comes from
     int32_t *cc = col + a * MAPW;
     T *vv = val + a * MAPW;
     for (int t = 0; t < MAPW; ++t) { cc[t] = 0; vv[t] = (T)0; }
@@ -192,6 +195,107 @@ __global__ __launch_bounds__(256) void k_map_cols(int n_new, const int32_t *__re
     dst[(size_t)a * ld + b] = s;
 }
 
+// out = A P A' (+ D) in one pass: out[a][b] = sum_t val[b][t] * T[a][col[b][t]],  T[a][c] = sum_t val[a][t] * P[col[a][t]][c] -- the sums of
+// k_map_rows / k_map_cols term for term, T rounded to the storage type as the stored intermediate was.  A workgroup writes 8 rows x 1024
+// columns; where row and columns are plain copies (src0 >= 0: everything but the few new / converted rows) an entry is one load.
+// feat != nullptr: the new features' 6x6 noise blocks (add_a_feature_covariance_inverse_depth.m:88-90, k_map_add_noise) are added here.
+template <typename T>
+__device__ __forceinline__ T map_tm(const int32_t *__restrict__ col, const T *__restrict__ val, const T *__restrict__ P, int ld, int a, int ka, int c)
+{
+    if (ka == 0) return P[(size_t)col[a * MAPW] * ld + c];
+    T s = (T)0;
+#pragma unroll
+    for (int t = 0; t < MAPW; ++t) s = ell_fma(val[a * MAPW + t], P[(size_t)col[a * MAPW + t] * ld + c], s);
+    return s;
+}
+// an entry whose row AND column are computed (the new features' own blocks, a converted landmark's block: a few dozen entries per call)
+template <typename T>
+__device__ __attribute__((noinline)) T map_entry(int a, int b, const int32_t *__restrict__ desc, const int32_t *__restrict__ col, const T *__restrict__ val,
+                                                 const T *__restrict__ P, int ld, const double *__restrict__ feat)
+{
+    const int ka = desc[3 * a];
+    T tm[MAPW];                                     // (all 64 loads in flight: the few lanes that come here are the longest chain of the launch)
+#pragma unroll
+    for (int t = 0; t < MAPW; ++t) tm[t] = map_tm(col, val, P, ld, a, ka, col[b * MAPW + t]);
+    T s = (T)0;
+#pragma unroll
+    for (int t = 0; t < MAPW; ++t) s = ell_fma(val[b * MAPW + t], tm[t], s);
+    if (feat != nullptr && ka == 1 && desc[3 * b] == 1 && desc[3 * a + 1] == desc[3 * b + 1])
+        s = (T)((double)s + feat[(size_t)desc[3 * a + 1] * FEATW + 14 + desc[3 * a + 2] * 6 + desc[3 * b + 2]]);
+    return s;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_map_one(int n_new, const int32_t *__restrict__ desc, const int32_t *__restrict__ col, const T *__restrict__ val,
+                                                 const int32_t *__restrict__ src0, const T *__restrict__ P, int ld, T *__restrict__ dst,
+                                                 const double *__restrict__ feat)
+{
+    constexpr int RB = 8, CB = 4;                                                     // a workgroup writes RB rows x CB * 256 columns
+    // (ld is a multiple of 128: all RB rows exist.)  Last rows first: the computed rows of an add sit at the end of the state and take a dozen
+    // microseconds of dependent loads -- dispatched first they hide behind the copies, dispatched last they were the tail of the launch
+    const int a0 = ((int)gridDim.y - 1 - (int)blockIdx.y) * RB;
+    int cb[CB], sb[CB];                                                               // lane-consecutive columns: every access of a wave is one contiguous run
+#pragma unroll
+    for (int k = 0; k < CB; ++k) {
+        cb[k] = (blockIdx.x * CB + k) * 256 + threadIdx.x;
+        sb[k] = cb[k] < n_new ? src0[cb[k]] : -2;                                    // -1: a computed column, -2: beyond the new state (zero)
+    }
+    int sa[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) sa[r] = a0 + r < n_new ? src0[a0 + r] : -2;
+    bool rows_plain = true;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) rows_plain = rows_plain && sa[r] != -1;
+    if (rows_plain) {
+        // the common case (workgroup-uniform), free of branches between the loads of a column: copies P[src(a)][src(b)]; a computed column
+        // (a new feature's, a converted landmark's: a handful of lanes per call) takes its <= 8 terms for all RB rows at once
+        T o[RB][CB];
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            if (sb[k] != -1) {
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    const T v = P[(size_t)(sa[r] >= 0 ? sa[r] : 0) * ld + (sb[k] >= 0 ? sb[k] : 0)];
+                    o[r][k] = (sa[r] >= 0 && sb[k] >= 0) ? v : (T)0;
+                }
+            } else {
+                T vv[MAPW]; int cc[MAPW];
+#pragma unroll
+                for (int t = 0; t < MAPW; ++t) { vv[t] = val[cb[k] * MAPW + t]; cc[t] = col[cb[k] * MAPW + t]; }
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    T e = (T)0;
+#pragma unroll
+                    for (int t = 0; t < MAPW; ++t) e = ell_fma(vv[t], P[(size_t)(sa[r] >= 0 ? sa[r] : 0) * ld + cc[t]], e);
+                    o[r][k] = sa[r] >= 0 ? e : (T)0;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int k = 0; k < CB; ++k) if (cb[k] < ld) dst[(size_t)(a0 + r) * ld + cb[k]] = o[r][k];
+        return;
+    }
+#pragma unroll 1
+    for (int r = 0; r < RB; ++r) {
+        const int a = a0 + r;
+        const int ka = sa[r] == -1 ? desc[3 * a] : 0;
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            if (cb[k] >= ld) continue;
+            T e = (T)0;
+            if (sa[r] != -2 && sb[k] != -2) {
+                if (sb[k] >= 0) e = map_tm(col, val, P, ld, a, ka, sb[k]);           // (a copied row: one load; a computed row: its <= 8 terms, unrolled)
+                else if (sa[r] >= 0) {                                               // a computed column of a copied row
+#pragma unroll
+                    for (int t = 0; t < MAPW; ++t) e = ell_fma(val[cb[k] * MAPW + t], P[(size_t)sa[r] * ld + col[cb[k] * MAPW + t]], e);
+                } else e = map_entry(a, cb[k], desc, col, val, P, ld, feat);
+            }
+            dst[(size_t)a * ld + cb[k]] = e;
+        }
+    }
+}
+
 template <typename T>
 __global__ void k_map_add_noise(int n_feat, int first_off, const double *__restrict__ feat, T *__restrict__ P, int ld)
 {
@@ -229,7 +333,7 @@ static int ensure_map_buffers(pre3_ctx *c)
               bytes((void **)&c->map_col, sizeof(int32_t) * (size_t)c->capn * MAPW) && bytes(&c->map_val, c->esz * (size_t)c->capn * MAPW) &&
               bytes((void **)&c->map_desc, sizeof(int32_t) * (3 * (size_t)c->capn + 3 * (size_t)c->capN + 16) + sizeof(double) * 3 * (size_t)c->capN) &&
               bytes((void **)&c->map_feat, sizeof(double) * (size_t)c->capN * (FEATW > CONVW ? FEATW : CONVW)) &&
-              bytes((void **)&c->map_flags, sizeof(int32_t) * c->capN);
+              bytes((void **)&c->map_flags, sizeof(int32_t) * c->capN) && bytes((void **)&c->map_src0, sizeof(int32_t) * (size_t)c->ld);
     if (!ok) { set_error("map management: device allocation failed"); return PRE3_E_NOMEM; }
     // two pinned staging blocks ([desc | types | off | src | uvd, rho]: ONE upload per call), used alternately: a block is written again only
     // after the call before last has been consumed (its event), so a call does not end in a stream synchronisation
@@ -280,19 +384,30 @@ static int apply_map(pre3_ctx *c, const std::vector<int32_t> &desc, int n_new, c
     }
     const double *feat = c->map_feat;
     DISPATCH_T(c,
-        hipLaunchKernelGGL(k_map_fill<double>, dim3(ceil_div(n_new, 256)), dim3(256), 0, c->stream, n_new, c->map_desc, c->x_kk, feat, feat, c->lm.off, c->map_col, (double *)c->map_val, c->x_alt),
-        hipLaunchKernelGGL(k_map_fill<float>, dim3(ceil_div(n_new, 256)), dim3(256), 0, c->stream, n_new, c->map_desc, c->x_kk, feat, feat, c->lm.off, c->map_col, (float *)c->map_val, c->x_alt));
-    dim3 g(ceil_div(c->ld, 256), c->ld), b(256);
-    DISPATCH_T(c,
-        hipLaunchKernelGGL(k_map_rows<double>, g, b, 0, c->stream, n_new, c->map_desc, c->map_col, (const double *)c->map_val, (const double *)c->P, c->ld, (double *)c->P_alt),
-        hipLaunchKernelGGL(k_map_rows<float>, g, b, 0, c->stream, n_new, c->map_desc, c->map_col, (const float *)c->map_val, (const float *)c->P, c->ld, (float *)c->P_alt));
-    DISPATCH_T(c,
-        hipLaunchKernelGGL(k_map_cols<double>, g, b, 0, c->stream, n_new, c->map_desc, c->map_col, (const double *)c->map_val, (const double *)c->P_alt, c->ld, (double *)c->P),
-        hipLaunchKernelGGL(k_map_cols<float>, g, b, 0, c->stream, n_new, c->map_desc, c->map_col, (const float *)c->map_val, (const float *)c->P_alt, c->ld, (float *)c->P));
-    if (n_feat > 0) {
+        hipLaunchKernelGGL(k_map_fill<double>, dim3(ceil_div(n_new, 256)), dim3(256), 0, c->stream, n_new, c->map_desc, c->x_kk, feat, feat, c->lm.off, c->map_col, (double *)c->map_val, c->x_alt, c->map_src0),
+        hipLaunchKernelGGL(k_map_fill<float>, dim3(ceil_div(n_new, 256)), dim3(256), 0, c->stream, n_new, c->map_desc, c->x_kk, feat, feat, c->lm.off, c->map_col, (float *)c->map_val, c->x_alt, c->map_src0));
+    static const int one_pass = getenv("PRE3_MAP_ONE_PASS") ? atoi(getenv("PRE3_MAP_ONE_PASS")) : 1;
+    if (one_pass) {
+        // one pass into the second buffer, which becomes P
+        dim3 g1(ceil_div(c->ld, 1024), c->ld / 8), b(256);
+        const double *noise = n_feat > 0 ? feat : nullptr;
         DISPATCH_T(c,
-            hipLaunchKernelGGL(k_map_add_noise<double>, dim3(ceil_div(n_feat * 36, 256)), dim3(256), 0, c->stream, n_feat, first_new_off, feat, (double *)c->P, c->ld),
-            hipLaunchKernelGGL(k_map_add_noise<float>, dim3(ceil_div(n_feat * 36, 256)), dim3(256), 0, c->stream, n_feat, first_new_off, feat, (float *)c->P, c->ld));
+            hipLaunchKernelGGL(k_map_one<double>, g1, b, 0, c->stream, n_new, c->map_desc, c->map_col, (const double *)c->map_val, c->map_src0, (const double *)c->P, c->ld, (double *)c->P_alt, noise),
+            hipLaunchKernelGGL(k_map_one<float>, g1, b, 0, c->stream, n_new, c->map_desc, c->map_col, (const float *)c->map_val, c->map_src0, (const float *)c->P, c->ld, (float *)c->P_alt, noise));
+        std::swap(c->P, c->P_alt);
+    } else {
+        dim3 g(ceil_div(c->ld, 256), c->ld), b(256);
+        DISPATCH_T(c,
+            hipLaunchKernelGGL(k_map_rows<double>, g, b, 0, c->stream, n_new, c->map_desc, c->map_col, (const double *)c->map_val, (const double *)c->P, c->ld, (double *)c->P_alt),
+            hipLaunchKernelGGL(k_map_rows<float>, g, b, 0, c->stream, n_new, c->map_desc, c->map_col, (const float *)c->map_val, (const float *)c->P, c->ld, (float *)c->P_alt));
+        DISPATCH_T(c,
+            hipLaunchKernelGGL(k_map_cols<double>, g, b, 0, c->stream, n_new, c->map_desc, c->map_col, (const double *)c->map_val, (const double *)c->P_alt, c->ld, (double *)c->P),
+            hipLaunchKernelGGL(k_map_cols<float>, g, b, 0, c->stream, n_new, c->map_desc, c->map_col, (const float *)c->map_val, (const float *)c->P_alt, c->ld, (float *)c->P));
+        if (n_feat > 0) {
+            DISPATCH_T(c,
+                hipLaunchKernelGGL(k_map_add_noise<double>, dim3(ceil_div(n_feat * 36, 256)), dim3(256), 0, c->stream, n_feat, first_new_off, feat, (double *)c->P, c->ld),
+                hipLaunchKernelGGL(k_map_add_noise<float>, dim3(ceil_div(n_feat * 36, 256)), dim3(256), 0, c->stream, n_feat, first_new_off, feat, (float *)c->P, c->ld));
+        }
     }
     // new state, landmark table, cleared per-landmark fields and inbox, re-laid-out descriptor bank: one launch, no synchronisation
     const bool with_bank = c->bank != nullptr && c->bank_alt != nullptr && N > 0;

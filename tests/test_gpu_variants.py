@@ -21,7 +21,8 @@ VARIANTS = [
     {"PRE3_K9_OVERLAP": "0"},                               # the down-date as a launch behind the persistent factorisation instead of consumers inside it
     {"PRE3_INLINE_G": "0"},                                 # H*P*H' of all measured rows built by a launch of its own instead of entry by entry in the scorer / the LI gather
     {"PRE3_SELECT_GATHER": "0"},
-    {"PRE3_SELECT_GATHER_LDS": "0"},                        # k_select_gather reading H*P from global memory instead of staging its rows in LDS                            # the selection stage and the LI gather as two launches instead of k_select_gather
+    {"PRE3_SELECT_GATHER_LDS": "0"},
+    {"PRE3_MAP_ONE_PASS": "0"},                             # map management's congruence as two gather passes (T = A P, P = T A') instead of one                        # k_select_gather reading H*P from global memory instead of staging its rows in LDS                            # the selection stage and the LI gather as two launches instead of k_select_gather
     {"PRE3_CHOL_EARLY": "0"},                               # the padded last panel runs all ten chain steps (the skipped ones change nothing)
 ]      # (not here: PRE3_CHOL_PRO_B3 / PRE3_K9_B3 change the ARITHMETIC of the fp32 path -- f32 MFMA instead of the bf16 split -- not just the launches)
 

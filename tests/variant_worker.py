@@ -17,7 +17,7 @@ def main():
     h = hashlib.sha256()
     for N, n_hyp, dtype, steps in ((120, 60, "f32", 12), (120, 60, "f64", 6), (9, 8, "f32", 6)):
         seq = synth.make_sequence(N, steps, n_hyp, seed=4242 + N)
-        f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype=dtype, max_hyp=n_hyp, std_z=1.0)
+        f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype=dtype, max_hyp=n_hyp, max_landmarks=N + 4, std_z=1.0)
         f.set_x_p_k_k(seq["x0"], seq["P0"])
         f.defer_hi_update(True)
         for t, s in enumerate(seq["steps"]):
@@ -28,6 +28,15 @@ def main():
             h.update(repr(sorted(st.items())).encode())
         li, hi = f.get_flags()
         h.update(li.tobytes()); h.update(hi.tobytes())
+        h.update(f.get_x_k_k().tobytes()); h.update(f.get_p_k_k().tobytes())
+        # map management behind the steps (map_management.m:27-79): delete, add, convert -- the congruence in either of its forms
+        f.sync()
+        rng = np.random.default_rng(7 + N)
+        f.delete_features([1, N // 2])
+        uvd = np.stack([rng.uniform(5, 170, 3), rng.uniform(5, 140, 3)], 1)
+        f.add_features_inverse_depth(uvd, 1.0, rng.uniform(0.1, 1.0, 3))
+        conv = f.inversedepth_2_cartesian(1e6)              # (a threshold every inverse-depth landmark passes)
+        h.update(np.asarray(conv).tobytes())
         h.update(f.get_x_k_k().tobytes()); h.update(f.get_p_k_k().tobytes())
         f.close()
     print("DIGEST", h.hexdigest())
