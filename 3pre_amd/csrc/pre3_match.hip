@@ -1372,7 +1372,7 @@ int ic_rank_check_bank(pre3_ctx *c, int first, int count)
 }
 
 // the scan has just been uploaded: pack it for the ranked route (or note that it cannot take it)
-int ic_rank_set_scan(pre3_ctx *c)
+int ic_rank_set_scan(pre3_ctx *c, bool in_bounds)
 {
     const int K2 = c->scan_K2, K1 = c->capN;
     IcRank *ic = static_cast<IcRank *>(c->ic_rank);
@@ -1399,14 +1399,14 @@ int ic_rank_set_scan(pre3_ctx *c)
     }
     RankMatch &r = ic->r;
     const int K2p = round_up(K2, 128);
-    PRE3_HIP(hipMemset(r.fl.p, 0, sizeof(int) * 4));
-    hipLaunchKernelGGL((k_rank_pack<double>), dim3(K2p * 8 / 256), dim3(256), 0, 0, DESC_DIM, K2, K2p, (const double *)c->scan_desc, (v4i *)r.dh.p, (v4i *)r.dl.p,
+    // (on the context's stream, behind the upload; whether the scan is inside the ranked route's bounds is the caller's host-side check of
+    // the same descriptors -- k_rank_pack's own flag word is not read back)
+    PRE3_HIP(hipMemsetAsync(r.fl.p, 0, sizeof(int) * 4, c->stream));
+    hipLaunchKernelGGL((k_rank_pack<double>), dim3(K2p * 8 / 256), dim3(256), 0, c->stream, DESC_DIM, K2, K2p, (const double *)c->scan_desc, (v4i *)r.dh.p, (v4i *)r.dl.p,
                        (float *)r.nU.p, (float *)r.nL.p, (float *)r.nd.p, (int8_t *)r.m.B.p, (int *)r.m.nb.p, (int *)r.fl.p);
     PRE3_HIP(hipGetLastError());
-    int fl = 0;
-    PRE3_HIP(hipMemcpy(&fl, r.fl.p, sizeof(int), hipMemcpyDeviceToHost));
     ic->K2 = K2;
-    ic->scan_ok = (fl & 1) == 0;
+    ic->scan_ok = in_bounds;
     return PRE3_OK;
 }
 
