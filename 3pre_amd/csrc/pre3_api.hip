@@ -316,7 +316,7 @@ int pre3_destroy(pre3_ctx *c)
                      c->sel_rows, c->support, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_src0, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128, c->need, c->cholp_flags, c->cholp_tp, c->dd_groups, c->dd_tiles };
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (int k2 = 0; k2 < 2; ++k2) { if (c->map_stage[k2]) (void)hipHostFree(c->map_stage[k2]); if (c->map_stage_ev[k2]) (void)hipEventDestroy(c->map_stage_ev[k2]); }
-    for (int k2 = 0; k2 < 2; ++k2) { if (c->scan_stage[k2]) (void)hipHostFree(c->scan_stage[k2]); if (c->scan_stage_ev[k2]) (void)hipEventDestroy(c->scan_stage_ev[k2]); }
+    for (int k2 = 0; k2 < 2; ++k2) { if (c->up_stage[k2]) (void)hipHostFree(c->up_stage[k2]); if (c->up_stage_ev[k2]) (void)hipEventDestroy(c->up_stage_ev[k2]); }
     if (c->pinned_stats) (void)hipHostFree(c->pinned_stats);
     if (c->inbox_host) (void)hipHostFree(c->inbox_host);
     if (c->mail_host) (void)hipHostFree(c->mail_host);
@@ -589,15 +589,82 @@ static int ensure_ic_buffers(pre3_ctx *c)
     return PRE3_OK;
 }
 
+// the staged scan [descriptors | positions] out of pinned host memory into the two device arrays (n16_pos == 0: one array)
+__global__ __launch_bounds__(256) void k_scan_pull(const int4 *__restrict__ src, int n16_desc, int4 *__restrict__ desc, int n16_pos, int4 *__restrict__ pos)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16_desc) desc[i] = src[i];
+    else if (i < n16_desc + n16_pos) pos[i - n16_desc] = src[i];
+}
+
+// k_rank_pack's test of its input, on the host: every value finite with |x| <= 2^60 and no non-zero |x| < 2^-40 (an or-reduction of two
+// compares per value; the block has just been written, so it is read from the cache)
+static bool desc_in_bounds_host(const double *__restrict__ d, size_t count)
+{
+    int bad = 0;
+    for (size_t i = 0; i < count; ++i) {
+        const double ax = fabs(d[i]);
+        bad |= (int)!(ax <= 0x1p60);
+        bad |= (int)(ax != 0.0) & (int)(ax < 0x1p-40);
+    }
+    return bad == 0;
+}
+
+// A pinned block of the context for `bytes` of host data on their way to the device: two blocks, used alternately, grown on demand; a block is
+// written again only after the pull of its previous contents has run (its event).  The caller fills *host, enqueues the pull from *dev on the
+// context's stream and calls stage_release.
+static int stage_acquire(pre3_ctx *c, size_t bytes, void **host, void **dev, int *slot)
+{
+    if (c->up_stage_bytes < bytes) {
+        for (int k = 0; k < 2; ++k) {
+            if (c->up_stage_used[k]) PRE3_HIP(hipEventSynchronize(c->up_stage_ev[k]));
+            if (c->up_stage[k]) (void)hipHostFree(c->up_stage[k]);
+            c->up_stage[k] = nullptr; c->up_stage_used[k] = false;
+        }
+        c->up_stage_bytes = 0;
+        const size_t cap = (bytes + 65535) & ~(size_t)65535;
+        for (int k = 0; k < 2; ++k) {
+            PRE3_HIP(hipHostMalloc(&c->up_stage[k], cap));
+            if (!c->up_stage_ev[k]) PRE3_HIP(hipEventCreateWithFlags(&c->up_stage_ev[k], hipEventDisableTiming));
+        }
+        c->up_stage_bytes = cap;
+    }
+    const int k = c->up_stage_next; c->up_stage_next ^= 1;
+    if (c->up_stage_used[k]) PRE3_HIP(hipEventSynchronize(c->up_stage_ev[k]));
+    *host = c->up_stage[k]; *slot = k;
+    PRE3_HIP(hipHostGetDevicePointer(dev, c->up_stage[k], 0));
+    return PRE3_OK;
+}
+static int stage_release(pre3_ctx *c, int slot)
+{
+    PRE3_HIP(hipEventRecord(c->up_stage_ev[slot], c->stream));
+    c->up_stage_used[slot] = true;
+    return PRE3_OK;
+}
+
 int pre3_set_descriptors(pre3_ctx *c, int first, int count, const double *desc)
 {
     PRE3_TRY(check_ctx(c));
     PRE3_CHECK(first >= 0 && count >= 0 && first + count <= c->N && (count == 0 || desc), PRE3_E_ARG, "pre3_set_descriptors: range [%d, %d) outside the map (N=%d)", first, first + count, c->N);
     PRE3_TRY(ensure_ic_buffers(c));
-    PRE3_HIP(hipStreamSynchronize(c->stream));
-    if (count) PRE3_HIP(hipMemcpy(c->bank + (size_t)first * DESC_DIM, desc, sizeof(double) * (size_t)count * DESC_DIM, hipMemcpyHostToDevice));
+    bool ok = true;
+    if (count) {
+        // staged and pulled on the context's stream like the scan (pre3_set_scan): map management calls this once per frame for the new
+        // landmark -- it used to cost a stream synchronisation, a blocking copy and a device-side bounds check with a read-back
+        const size_t nd = (size_t)count * DESC_DIM;
+        void *st = nullptr, *st_dev = nullptr; int slot = 0;
+        PRE3_TRY(stage_acquire(c, sizeof(double) * nd, &st, &st_dev, &slot));
+        memcpy(st, desc, sizeof(double) * nd);
+        ok = desc_in_bounds_host(static_cast<const double *>(st), nd);
+        hipLaunchKernelGGL(k_scan_pull, dim3(ceil_div((int)(nd / 2), 256)), dim3(256), 0, c->stream, (const int4 *)st_dev, (int)(nd / 2),
+                           (int4 *)(c->bank + (size_t)first * DESC_DIM), 0, (int4 *)nullptr);
+        PRE3_HIP(hipGetLastError());
+        PRE3_TRY(stage_release(c, slot));
+    }
     c->bank_set = true;
-    return ic_rank_check_bank(c, first, count);
+    if (!ok) c->bank_ok = false;            // (sticky until the whole bank is rewritten: a bad descriptor may stay in the map)
+    else if (first == 0 && count >= c->N) c->bank_ok = true;
+    return PRE3_OK;
 }
 
 int pre3_get_descriptors(pre3_ctx *c, int first, int count, double *desc)
@@ -608,27 +675,6 @@ int pre3_get_descriptors(pre3_ctx *c, int first, int count, double *desc)
     PRE3_HIP(hipStreamSynchronize(c->stream));
     if (count) PRE3_HIP(hipMemcpy(desc, c->bank + (size_t)first * DESC_DIM, sizeof(double) * (size_t)count * DESC_DIM, hipMemcpyDeviceToHost));
     return PRE3_OK;
-}
-
-// the staged scan [descriptors | positions] out of pinned host memory into the two device arrays
-__global__ __launch_bounds__(256) void k_scan_pull(const int4 *__restrict__ src, int n16_desc, int4 *__restrict__ desc, int n16_pos, int4 *__restrict__ pos)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n16_desc) desc[i] = src[i];
-    else if (i < n16_desc + n16_pos) pos[i - n16_desc] = src[i];
-}
-
-// k_rank_pack's / k_desc_check's test on the host: every value finite with |x| <= 2^60 and no non-zero |x| < 2^-40 (an or-reduction of two
-// compares per value: the compiler vectorises it; the block has just been written, so it is read from the cache)
-static bool desc_in_bounds_host(const double *__restrict__ d, size_t count)
-{
-    int bad = 0;
-    for (size_t i = 0; i < count; ++i) {
-        const double ax = fabs(d[i]);
-        bad |= (int)!(ax <= 0x1p60);
-        bad |= (int)(ax != 0.0) & (int)(ax < 0x1p-40);
-    }
-    return bad == 0;
 }
 
 int pre3_set_scan(pre3_ctx *c, int K2, const double *descriptor_raw, const double *scale_orient_pos_raw)
@@ -654,22 +700,12 @@ int pre3_set_scan(pre3_ctx *c, int K2, const double *descriptor_raw, const doubl
         // The frame's scan crosses PCIe from a pinned block of the context's own, enqueued on its stream: the call neither waits for the queued
         // work nor ends in a read-back.  The bounds the ranked route needs of the descriptors (k_rank_pack's test: finite, |x| <= 2^60, no
         // non-zero |x| < 2^-40) are checked here, on the way into that block.
-        if (c->scan_stage_cap < c->scan_cap) {
-            for (int k = 0; k < 2; ++k) {
-                if (c->scan_stage_used[k]) PRE3_HIP(hipEventSynchronize(c->scan_stage_ev[k]));
-                if (c->scan_stage[k]) (void)hipHostFree(c->scan_stage[k]);
-                c->scan_stage[k] = nullptr; c->scan_stage_used[k] = false;
-                PRE3_HIP(hipHostMalloc(&c->scan_stage[k], sizeof(double) * (size_t)c->scan_cap * (DESC_DIM + 4)));
-                if (!c->scan_stage_ev[k]) PRE3_HIP(hipEventCreateWithFlags(&c->scan_stage_ev[k], hipEventDisableTiming));
-            }
-            c->scan_stage_cap = c->scan_cap;
-        }
         static const int trace = getenv("PRE3_SCAN_TRACE") ? atoi(getenv("PRE3_SCAN_TRACE")) : 0;
         const auto t0 = std::chrono::steady_clock::now();
-        const int k = c->scan_stage_next; c->scan_stage_next ^= 1;
-        if (c->scan_stage_used[k]) PRE3_HIP(hipEventSynchronize(c->scan_stage_ev[k]));
+        void *st_v = nullptr, *st_dev = nullptr; int k = 0;
+        PRE3_TRY(stage_acquire(c, sizeof(double) * (size_t)K2 * (DESC_DIM + 4), &st_v, &st_dev, &k));
         const auto t1 = std::chrono::steady_clock::now();
-        double *st = static_cast<double *>(c->scan_stage[k]);
+        double *st = static_cast<double *>(st_v);
         const size_t nd = (size_t)K2 * DESC_DIM;
         memcpy(st, descriptor_raw, sizeof(double) * nd);
         memcpy(st + nd, scale_orient_pos_raw, sizeof(double) * (size_t)K2 * 4);
@@ -678,13 +714,10 @@ int pre3_set_scan(pre3_ctx *c, int K2, const double *descriptor_raw, const doubl
         const auto t3 = std::chrono::steady_clock::now();
         // the device reads the block over PCIe itself (16 bytes per lane, every request in flight at once: ~20 us for 600 keypoints) instead of
         // two DMA-engine copies with their start-up latencies
-        void *st_dev = nullptr;
-        PRE3_HIP(hipHostGetDevicePointer(&st_dev, st, 0));
         const int n16_desc = (int)(nd / 2), n16_pos = K2 * 2;
         hipLaunchKernelGGL(k_scan_pull, dim3(ceil_div(n16_desc + n16_pos, 256)), dim3(256), 0, c->stream, (const int4 *)st_dev, n16_desc, (int4 *)c->scan_desc, n16_pos, (int4 *)c->scan_pos);
         PRE3_HIP(hipGetLastError());
-        PRE3_HIP(hipEventRecord(c->scan_stage_ev[k], c->stream));
-        c->scan_stage_used[k] = true;
+        PRE3_TRY(stage_release(c, k));
         if (trace) { const auto t4 = std::chrono::steady_clock::now(); auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
             fprintf(stderr, "[pre3 set_scan, us] event wait %.1f | memcpy %.1f | check %.1f | enqueue %.1f\n", us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4)); }
     }

@@ -156,10 +156,11 @@ struct pre3_ctx {
     // IC search (matching_sift_based.m): landmark descriptor bank [capN][128], the current scan's SIFT set, match scratch
     double *bank = nullptr, *bank_alt = nullptr; bool bank_set = false;
     double *scan_desc = nullptr, *scan_pos = nullptr; int scan_K2 = 0, scan_cap = 0;
-    // pinned staging of the per-frame scan ([descriptors | positions], two blocks used alternately, an event each): pre3_set_scan checks the
-    // descriptors' bounds while it copies them here and enqueues the upload on the context's stream -- no synchronisation, no read-back
-    void *scan_stage[2] = { nullptr, nullptr }; hipEvent_t scan_stage_ev[2] = { nullptr, nullptr }; bool scan_stage_used[2] = { false, false };
-    int scan_stage_next = 0; int scan_stage_cap = 0;
+    // pinned staging of host arrays on their way to the device (the per-frame scan, descriptors of new landmarks): two blocks used alternately,
+    // an event each; the caller's data is copied (and bounds-checked) into a block, the device pulls it over PCIe on the context's stream --
+    // no synchronisation, no read-back (pre3_api.hip: stage_acquire / stage_release)
+    void *up_stage[2] = { nullptr, nullptr }; hipEvent_t up_stage_ev[2] = { nullptr, nullptr }; bool up_stage_used[2] = { false, false };
+    int up_stage_next = 0; size_t up_stage_bytes = 0;
     int32_t *ic_pred = nullptr, *ic_counts = nullptr, *ic_arg = nullptr, *ic_pairs = nullptr, *ic_newk2 = nullptr; double *ic_best = nullptr, *ic_second = nullptr;
     int32_t *bank_src = nullptr;
     bool ic_last_ranked = false;                  // the last pre3_ic_search matched on the matrix cores (PRE3_OPT_IC_RANKED)
@@ -213,7 +214,6 @@ int comm_device(void *comm);
 int launch_ic_search(pre3_ctx *c, double thresh, int strict);
 int launch_bank_gather(pre3_ctx *c, int N_new, const int32_t *src_host);
 int ic_rank_set_scan(pre3_ctx *c, bool in_bounds);
-int ic_rank_check_bank(pre3_ctx *c, int first, int count);
 void ic_rank_free(pre3_ctx *c);
 constexpr int DESC_DIM = 128;
 

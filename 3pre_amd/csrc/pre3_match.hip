@@ -1335,41 +1335,13 @@ __global__ void k_bank_gather(const int32_t *__restrict__ src, const double *__r
 // route's bounds (NaN / Inf, |x| > 2^60, 0 < |x| < 2^-40), small problems and PRE3_IC_RANK=0 keep the exact VALU kernel.
 struct IcRank { RankMatch r; int K1cap = 0, K2 = -1; bool scan_ok = false; };
 
-__global__ void k_desc_check(size_t count, const double *__restrict__ d, int *__restrict__ flags)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const double ax = fabs(d[i]);
-    if (!(ax <= 0x1p60) || (ax != 0.0 && ax < 0x1p-40)) atomicOr(flags, 1);
-}
 // des1[q] = bank[pred[q]] (rows beyond the device-side count repeat older list entries: in range, never read back)
 __global__ __launch_bounds__(DESC_DIM) void k_ic_gather_q(const int32_t *__restrict__ pred, const double *__restrict__ bank, double *__restrict__ des1)
 {
     des1[(size_t)blockIdx.x * DESC_DIM + threadIdx.x] = bank[(size_t)pred[blockIdx.x] * DESC_DIM + threadIdx.x];
 }
 
-static int desc_in_bounds(const double *dev, size_t count, bool *ok)      // synchronous (the callers are: descriptor / scan uploads)
-{
-    DevBuf fl;
-    PRE3_TRY(fl.alloc(sizeof(int)));
-    PRE3_HIP(hipMemset(fl.p, 0, sizeof(int)));
-    if (count) hipLaunchKernelGGL(k_desc_check, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, count, dev, (int *)fl.p);
-    int f = 0;
-    PRE3_HIP(hipMemcpy(&f, fl.p, sizeof(int), hipMemcpyDeviceToHost));
-    *ok = f == 0;
-    return PRE3_OK;
-}
-
 void ic_rank_free(pre3_ctx *c) { delete static_cast<IcRank *>(c->ic_rank); c->ic_rank = nullptr; }
-
-int ic_rank_check_bank(pre3_ctx *c, int first, int count)
-{
-    bool ok = true;
-    PRE3_TRY(desc_in_bounds(c->bank + (size_t)first * DESC_DIM, (size_t)count * DESC_DIM, &ok));
-    if (!ok) c->bank_ok = false;            // (sticky until the whole bank is rewritten: a bad descriptor may stay in the map)
-    else if (first == 0 && count >= c->N) c->bank_ok = true;
-    return PRE3_OK;
-}
 
 // the scan has just been uploaded: pack it for the ranked route (or note that it cannot take it)
 int ic_rank_set_scan(pre3_ctx *c, bool in_bounds)
