@@ -98,6 +98,27 @@ static int fetch_stats(pre3_ctx *c)
     return PRE3_OK;
 }
 
+// the staged scan [descriptors | positions] out of pinned host memory into the two device arrays (n16_pos == 0: one array)
+__global__ __launch_bounds__(256) void k_scan_pull(const int4 *__restrict__ src, int n16_desc, int4 *__restrict__ desc, int n16_pos, int4 *__restrict__ pos)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16_desc) desc[i] = src[i];
+    else if (i < n16_desc + n16_pos) pos[i - n16_desc] = src[i];
+}
+
+// bytes of a pinned (device-mapped) host block -> device memory, read over PCIe by the device itself on the context's stream: no DMA engine,
+// whose copies start with ~10 us of latency each (and, once in a few hundred calls, with tens of milliseconds inside the runtime)
+int launch_pull(pre3_ctx *c, const void *pinned_host, void *dst_dev, size_t bytes)
+{
+    void *src_dev = nullptr;
+    PRE3_HIP(hipHostGetDevicePointer(&src_dev, const_cast<void *>(pinned_host), 0));
+    const int n16 = (int)((bytes + 15) / 16);
+    if (n16 == 0) return PRE3_OK;
+    hipLaunchKernelGGL(k_scan_pull, dim3(ceil_div(n16, 256)), dim3(256), 0, c->stream, (const int4 *)src_dev, n16, (int4 *)dst_dev, 0, (int4 *)nullptr);
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
 }  // namespace pre3
 
 using namespace pre3;
@@ -587,14 +608,6 @@ static int ensure_ic_buffers(pre3_ctx *c)
     PRE3_TRY(dmalloc(&c->ic_newk2, N)); PRE3_TRY(dmalloc(&c->ic_best, N)); PRE3_TRY(dmalloc(&c->ic_second, N)); PRE3_TRY(dmalloc(&c->bank_src, N));
     PRE3_HIP(hipMemset(c->bank, 0, sizeof(double) * N * DESC_DIM));
     return PRE3_OK;
-}
-
-// the staged scan [descriptors | positions] out of pinned host memory into the two device arrays (n16_pos == 0: one array)
-__global__ __launch_bounds__(256) void k_scan_pull(const int4 *__restrict__ src, int n16_desc, int4 *__restrict__ desc, int n16_pos, int4 *__restrict__ pos)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n16_desc) desc[i] = src[i];
-    else if (i < n16_desc + n16_pos) pos[i - n16_desc] = src[i];
 }
 
 // k_rank_pack's test of its input, on the host: every value finite with |x| <= 2^60 and no non-zero |x| < 2^-40 (an or-reduction of two

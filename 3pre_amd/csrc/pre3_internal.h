@@ -214,6 +214,7 @@ int comm_device(void *comm);
 int launch_ic_search(pre3_ctx *c, double thresh, int strict);
 int launch_bank_gather(pre3_ctx *c, int N_new, const int32_t *src_host);
 int ic_rank_set_scan(pre3_ctx *c, bool in_bounds);
+int launch_pull(pre3_ctx *c, const void *pinned_host, void *dst_dev, size_t bytes);      // pinned host block -> device, by a kernel (pre3_api.hip)
 void ic_rank_free(pre3_ctx *c);
 constexpr int DESC_DIM = 128;
 

@@ -331,13 +331,13 @@ static int ensure_map_buffers(pre3_ctx *c)
     auto bytes = [&](void **p, size_t b) { return hipMalloc(p, b ? b : 16) == hipSuccess; };
     bool ok = bytes(&c->P_alt, (size_t)c->ld * c->ld * c->esz) && bytes((void **)&c->x_alt, sizeof(double) * c->capn) &&
               bytes((void **)&c->map_col, sizeof(int32_t) * (size_t)c->capn * MAPW) && bytes(&c->map_val, c->esz * (size_t)c->capn * MAPW) &&
-              bytes((void **)&c->map_desc, sizeof(int32_t) * (3 * (size_t)c->capn + 3 * (size_t)c->capN + 16) + sizeof(double) * 3 * (size_t)c->capN) &&
+              bytes((void **)&c->map_desc, sizeof(int32_t) * (3 * (size_t)c->capn + 3 * (size_t)c->capN + 16) + sizeof(double) * 3 * (size_t)c->capN + 16) &&
               bytes((void **)&c->map_feat, sizeof(double) * (size_t)c->capN * (FEATW > CONVW ? FEATW : CONVW)) &&
               bytes((void **)&c->map_flags, sizeof(int32_t) * c->capN) && bytes((void **)&c->map_src0, sizeof(int32_t) * (size_t)c->ld);
     if (!ok) { set_error("map management: device allocation failed"); return PRE3_E_NOMEM; }
     // two pinned staging blocks ([desc | types | off | src | uvd, rho]: ONE upload per call), used alternately: a block is written again only
     // after the call before last has been consumed (its event), so a call does not end in a stream synchronisation
-    c->map_stage_bytes = sizeof(int32_t) * (3 * (size_t)c->capn + 3 * (size_t)c->capN + 16) + sizeof(double) * 3 * (size_t)c->capN;
+    c->map_stage_bytes = (sizeof(int32_t) * (3 * (size_t)c->capn + 3 * (size_t)c->capN + 16) + sizeof(double) * 3 * (size_t)c->capN + 15) & ~(size_t)15;
     for (int k = 0; k < 2; ++k) {
         if (hipHostMalloc(&c->map_stage[k], c->map_stage_bytes) != hipSuccess || hipEventCreateWithFlags(&c->map_stage_ev[k], hipEventDisableTiming) != hipSuccess) {
             set_error("map management: pinned staging allocation failed"); return PRE3_E_NOMEM;
@@ -373,7 +373,7 @@ static int apply_map(pre3_ctx *c, const std::vector<int32_t> &desc, int n_new, c
         bytes += sizeof(double) * 3 * (size_t)n_feat;
     }
     PRE3_CHECK(bytes <= c->map_stage_bytes, PRE3_E_ARG, "map management: staging block too small");
-    PRE3_HIP(hipMemcpyAsync(c->map_desc, st, bytes, hipMemcpyHostToDevice, c->stream));
+    PRE3_TRY(launch_pull(c, st, c->map_desc, bytes));        // (read over PCIe by the device: no DMA-engine copy)
     PRE3_HIP(hipEventRecord(c->map_stage_ev[k], c->stream));
     c->map_stage_used[k] = true;
     const int32_t *d_types = c->map_desc + o_types, *d_off = c->map_desc + o_off, *d_src = c->map_desc + o_src;
