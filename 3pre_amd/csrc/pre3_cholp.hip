@@ -202,6 +202,7 @@ struct CritSmem {
     ChSmem<float> ch;                                            // Ls, Xs, As | pipe, Bs
     __attribute__((aligned(16))) frag_t MPl[B3_SGRAN];           // planes of M_J (built while the chain runs)
     __attribute__((aligned(16))) frag_t T1p[B3_SGRAN];           // planes of A(J+1, J); after B1: the planes of L(J+1, J)
+    __attribute__((aligned(16))) unsigned fpoll[64];             // wave 11's view of row J+1's flag: filled by LDS-DMA, read without a memory wait
 };
 
 // panel 0: the raw blocks straight from S (written by the launch in front); all twelve waves
@@ -331,11 +332,18 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
         const unsigned *fflag = cf_rowA(a.cf, fr < 64 ? fr : 63);
         fst = (more && J > 0) ? 0 : 5;                            // (panel 0's tiles came with the prologue)
         cool = 0;
+        // The flag is polled at every step of the chain without ever waiting on memory: a 4-byte LDS-DMA of the flag word is sent off, and
+        // what the earlier ones have brought is read from LDS (a word that has not landed yet only reads as "not yet").  No poll of the
+        // previous panel is still in flight here: its tile fetch ended in vmcnt(0).
+        if (wave == 11 && fst == 0) sm.fpoll[lane] = a.base;
         auto fetch_step = [&](bool blocking) {
             if (!blocking && cool > 0) { --cool; return; }
-            if (fst == 0) { pv = cf_load(fflag); fst = 1; cool = 2; }
-            else if (fst == 1) {
-                if (cf_reached(pv, a.base + 2)) {
+            if (fst == 0) {
+                pv = *reinterpret_cast<volatile unsigned *>(&sm.fpoll[lane]);
+                if (!cf_reached(pv, a.base + 2)) {
+                    __builtin_amdgcn_global_load_lds(fflag, (__attribute__((address_space(3))) void *)sm.fpoll, 4, 0, 16);
+                    if (blocking) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else {
                     const frag_t *src1 = static_cast<const frag_t *>(a.Tp) + (size_t)fr * B3_SGRAN + lane;
 #pragma unroll
                     for (int t = 0; t < 24; ++t)
@@ -347,7 +355,7 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
                         __builtin_amdgcn_global_load_lds(src2 + (size_t)(4 * t) * lds, (__attribute__((address_space(3))) void *)(T2 + (t * 64) * 4), 16, 0, 16);
                     fst = 2; cool = 2;
                     CP_STAMP(1, J, 0);
-                } else { pv = cf_load(fflag); cool = 2; }
+                }
             } else if (fst == 2) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 fst = 5;
@@ -355,7 +363,8 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
             }
         };
         // rows 8 sp .. 8 sp + 7 of M_J (final once the z wave has passed them) -> planes in LDS and in Sp(J, J)
-        auto publish_m_rows = [&](int sp) {
+        u32x4_t mp0, mp1, mp2; unsigned mgb = 0;                                    // the last rows' planes on their way out (publish_m_rows(7, false))
+        auto publish_m_rows = [&](int sp, bool store = true) {
             const int arow = 8 * sp + (lane >> 3), cg = lane & 7;                   // 8 consecutive c of one row per lane
             float x[8];
 #pragma unroll
@@ -366,7 +375,8 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
             const int gi = q * 384 + half * 64 + 32 * h + r;
             sm.MPl[gi] = __builtin_bit_cast(frag_t, p0); sm.MPl[gi + 128] = __builtin_bit_cast(frag_t, p1); sm.MPl[gi + 256] = __builtin_bit_cast(frag_t, p2);
             const unsigned gb = ((unsigned)(J * a.sp_stride + J) * B3_SGRAN + gi) * 16u;
-            st16_sc1(p0, rSp, gb); st16_sc1(p1, rSp, gb + 128 * 16); st16_sc1(p2, rSp, gb + 256 * 16);
+            if (store) { st16_sc1(p0, rSp, gb); st16_sc1(p1, rSp, gb + 128 * 16); st16_sc1(p2, rSp, gb + 256 * 16); }
+            else { mp0 = p0; mp1 = p1; mp2 = p2; mgb = gb; }
         };
         // columns 8 sp .. 8 sp + 7 of L_JJ (final once the factor wave has passed them; zero above the diagonal) to S -- part of the final
         // factor (k_gain; not read again in this launch): wave 11, lane = row
@@ -398,8 +408,9 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
             __builtin_amdgcn_s_barrier();                        // (raw: __syncthreads() would also wait for every LDS-DMA in flight)
         }
         // chain done: Ls = L_JJ, Xs = M_J (rows 56..63 not yet in planes)
+        // (the products only need the last rows' planes in LDS: their copies for the other workgroups leave behind b0, in the products' shadow)
         if (wave == 10) {
-            publish_m_rows(7);
+            publish_m_rows(7, !more);
             if (!more) { drain_stores(); if (lane == 0) cf_store(a.cf + CF_MP, a.base + (unsigned)J + 1); CP_STAMP(1, J, 4); }
         }
         if (!more) break;
@@ -419,7 +430,10 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
         __syncthreads();                                                            // b0
         // M_J is out once wave 10's stores have drained -- in the shadow of the first product, not in front of it (the tiles of row J+1
         // arrive before the chain ends, so b0 waits for nothing else)
-        if (wave == 10) { drain_stores(); if (lane == 0) cf_store(a.cf + CF_MP, a.base + (unsigned)J + 1); CP_STAMP(1, J, 4); }
+        if (wave == 10) {
+            st16_sc1(mp0, rSp, mgb); st16_sc1(mp1, rSp, mgb + 128 * 16); st16_sc1(mp2, rSp, mgb + 256 * 16);
+            drain_stores(); if (lane == 0) cf_store(a.cf + CF_MP, a.base + (unsigned)J + 1); CP_STAMP(1, J, 4);
+        }
         __syncthreads();                                                            // b1
         __syncthreads();                                                            // b2: T1p = planes of L(J+1, J), Y = its f32 image
         if (wave == 10) {
