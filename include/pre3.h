@@ -235,11 +235,14 @@ PRE3_API int pre3_get_map(pre3_ctx *ctx, int32_t *lm_type_out);
 /* ---- the IC-search stage on the device (search_IC_matches.m:31-44 + matching_sift_based.m:104-149) ---- */
 /* features_info(i).Descriptor (128 x 1 double each, add_feature_to_info_vector_my_version_sift.m): desc is 128 x count
  * column-major for landmarks first .. first+count-1.  The bank follows the map through pre3_map_* (deleted landmarks
- * drop out, new ones start at zero until set). */
+ * drop out, new ones start at zero until set).  Asynchronous: the array is copied into pinned memory of the context's
+ * before the call returns (the caller may reuse it at once) and reaches the device on the context's stream. */
 PRE3_API int pre3_set_descriptors(pre3_ctx *ctx, int first, int count, const double *desc);
 PRE3_API int pre3_get_descriptors(pre3_ctx *ctx, int first, int count, double *desc);
 /* the frame's SIFT set as stored in SIFT_result%04d.mat (SIFT_extract_save.m:68-69): SCAN_SIFT.Descriptor_RAW (128 x K2)
- * and SCAN_SIFT.SCALE_ORIENT_POS_RAW (4 x K2; rows 1:2 = pixel u,v), both column-major doubles. */
+ * and SCAN_SIFT.SCALE_ORIENT_POS_RAW (4 x K2; rows 1:2 = pixel u,v), both column-major doubles.  Asynchronous like
+ * pre3_set_descriptors: copied (and checked against the matrix-core matcher's bounds) on the host, pulled over PCIe and
+ * packed on the context's stream; the call neither waits for queued work nor ends in a read-back. */
 PRE3_API int pre3_set_scan(pre3_ctx *ctx, int K2, const double *descriptor_raw, const double *scale_orient_pos_raw);
 /* One call = search_IC_matches.m:31-44 (h, H, S at the prediction) + matching_sift_based.m:104-149: stack the descriptors
  * of the predicted landmarks, siftmatch(des1', Descriptor_RAW) (double class, thresh 1.5 in the reference), window
