@@ -334,7 +334,7 @@ int pre3_destroy(pre3_ctx *c)
     c->comm = nullptr;
     void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
                      c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
-                     c->sel_rows, c->support, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_src0, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128, c->need, c->cholp_flags, c->cholp_tp, c->dd_groups, c->dd_tiles };
+                     c->sel_rows, c->support, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_src0, c->map_conv, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128, c->need, c->cholp_flags, c->cholp_tp, c->dd_groups, c->dd_tiles };
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (int k2 = 0; k2 < 2; ++k2) { if (c->map_stage[k2]) (void)hipHostFree(c->map_stage[k2]); if (c->map_stage_ev[k2]) (void)hipEventDestroy(c->map_stage_ev[k2]); }
     for (int k2 = 0; k2 < 2; ++k2) { if (c->up_stage[k2]) (void)hipHostFree(c->up_stage[k2]); if (c->up_stage_ev[k2]) (void)hipEventDestroy(c->up_stage_ev[k2]); }

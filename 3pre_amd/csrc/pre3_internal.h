@@ -148,7 +148,7 @@ struct pre3_ctx {
     int32_t seq_inbox = 0;                        // sequence number of the last inbox pull (published by the kernel in mailbox word 10)
     bool inbox_pending = false;
     // map management (allocated on first use)
-    void *P_alt = nullptr; double *x_alt = nullptr; int32_t *map_col = nullptr; void *map_val = nullptr; int32_t *map_desc = nullptr; int32_t *map_src0 = nullptr;
+    void *P_alt = nullptr; double *x_alt = nullptr; int32_t *map_col = nullptr; void *map_val = nullptr; int32_t *map_desc = nullptr; int32_t *map_src0 = nullptr; double *map_conv = nullptr;
     double *map_feat = nullptr; int32_t *map_flags = nullptr;
     void *map_stage[2] = { nullptr, nullptr }; hipEvent_t map_stage_ev[2] = { nullptr, nullptr }; bool map_stage_used[2] = { false, false };
     int map_stage_next = 0; size_t map_stage_bytes = 0;   // pinned staging blocks of the map operations (pre3_map.hip)

@@ -333,7 +333,8 @@ static int ensure_map_buffers(pre3_ctx *c)
               bytes((void **)&c->map_col, sizeof(int32_t) * (size_t)c->capn * MAPW) && bytes(&c->map_val, c->esz * (size_t)c->capn * MAPW) &&
               bytes((void **)&c->map_desc, sizeof(int32_t) * (3 * (size_t)c->capn + 3 * (size_t)c->capN + 16) + sizeof(double) * 3 * (size_t)c->capN + 16) &&
               bytes((void **)&c->map_feat, sizeof(double) * (size_t)c->capN * (FEATW > CONVW ? FEATW : CONVW)) &&
-              bytes((void **)&c->map_flags, sizeof(int32_t) * c->capN) && bytes((void **)&c->map_src0, sizeof(int32_t) * (size_t)c->ld);
+              bytes((void **)&c->map_flags, sizeof(int32_t) * c->capN) && bytes((void **)&c->map_src0, sizeof(int32_t) * (size_t)c->ld) &&
+              bytes((void **)&c->map_conv, sizeof(double) * (size_t)c->capN * CONVW);
     if (!ok) { set_error("map management: device allocation failed"); return PRE3_E_NOMEM; }
     // two pinned staging blocks ([desc | types | off | src | uvd, rho]: ONE upload per call), used alternately: a block is written again only
     // after the call before last has been consumed (its event), so a call does not end in a stream synchronisation
@@ -382,10 +383,10 @@ static int apply_map(pre3_ctx *c, const std::vector<int32_t> &desc, int n_new, c
         CamM cam{ c->cam.f, c->cam.Cx, c->cam.Cy, c->cam.k1, c->cam.k2 };
         hipLaunchKernelGGL(k_map_new_features, dim3(ceil_div(n_feat, 64)), dim3(64), 0, c->stream, n_feat, d_uvd, d_uvd + 2 * n_feat, std_pxl, c->x_kk, cam, c->map_feat);
     }
-    const double *feat = c->map_feat;
+    const double *feat = c->map_feat, *conv = c->map_conv;
     DISPATCH_T(c,
-        hipLaunchKernelGGL(k_map_fill<double>, dim3(ceil_div(n_new, 256)), dim3(256), 0, c->stream, n_new, c->map_desc, c->x_kk, feat, feat, c->lm.off, c->map_col, (double *)c->map_val, c->x_alt, c->map_src0),
-        hipLaunchKernelGGL(k_map_fill<float>, dim3(ceil_div(n_new, 256)), dim3(256), 0, c->stream, n_new, c->map_desc, c->x_kk, feat, feat, c->lm.off, c->map_col, (float *)c->map_val, c->x_alt, c->map_src0));
+        hipLaunchKernelGGL(k_map_fill<double>, dim3(ceil_div(n_new, 256)), dim3(256), 0, c->stream, n_new, c->map_desc, c->x_kk, feat, conv, c->lm.off, c->map_col, (double *)c->map_val, c->x_alt, c->map_src0),
+        hipLaunchKernelGGL(k_map_fill<float>, dim3(ceil_div(n_new, 256)), dim3(256), 0, c->stream, n_new, c->map_desc, c->x_kk, feat, conv, c->lm.off, c->map_col, (float *)c->map_val, c->x_alt, c->map_src0));
     static const int one_pass = getenv("PRE3_MAP_ONE_PASS") ? atoi(getenv("PRE3_MAP_ONE_PASS")) : 1;
     if (one_pass) {
         // one pass into the second buffer, which becomes P
@@ -488,8 +489,8 @@ int pre3_map_inversedepth_2_cartesian(pre3_ctx *c, double thr, int32_t *converte
     const int N = c->N;
     if (N == 0) return PRE3_OK;
     DISPATCH_T(c,
-        hipLaunchKernelGGL(k_map_convert_flags<double>, dim3(ceil_div(N, 64)), dim3(64), 0, c->stream, N, c->lm.type, c->lm.off, c->x_kk, (const double *)c->P, c->ld, thr, c->map_flags, c->map_feat),
-        hipLaunchKernelGGL(k_map_convert_flags<float>, dim3(ceil_div(N, 64)), dim3(64), 0, c->stream, N, c->lm.type, c->lm.off, c->x_kk, (const float *)c->P, c->ld, thr, c->map_flags, c->map_feat));
+        hipLaunchKernelGGL(k_map_convert_flags<double>, dim3(ceil_div(N, 64)), dim3(64), 0, c->stream, N, c->lm.type, c->lm.off, c->x_kk, (const double *)c->P, c->ld, thr, c->map_flags, c->map_conv),
+        hipLaunchKernelGGL(k_map_convert_flags<float>, dim3(ceil_div(N, 64)), dim3(64), 0, c->stream, N, c->lm.type, c->lm.off, c->x_kk, (const float *)c->P, c->ld, thr, c->map_flags, c->map_conv));
     PRE3_HIP(hipGetLastError());
     std::vector<int32_t> flags(N);
     PRE3_HIP(hipStreamSynchronize(c->stream));
@@ -514,6 +515,58 @@ int pre3_map_inversedepth_2_cartesian(pre3_ctx *c, double thr, int32_t *converte
         off += dim;
     }
     return apply_map(c, desc, (int)desc.size() / 3, types, 0, 0, src);
+}
+
+// map_management.m:27-79 as ONE call and ONE congruence: delete_features (:33), inversedepth_2_cartesian (:48, convert_threshold < 0: skipped),
+// initialize_features' add (:58-66).  All three only select / recombine rows of the OLD state (the new features' Jacobians read the camera
+// block, which neither a deletion nor a conversion touches), so their row maps compose into one descriptor list and P makes one pass
+// through k_map_one instead of up to three.  converted_out (may be null): per OLD landmark, 1 = converted (a deleted landmark reads 0).
+int pre3_map_management(pre3_ctx *c, int n_del, const int32_t *del_idx, double convert_threshold, int32_t *converted_out,
+                        int n_new, const double *uvd, double std_pxl, const double *initial_rho)
+{
+    PRE3_TRY(map_precheck(c, "pre3_map_management"));
+    PRE3_CHECK(n_del >= 0 && (n_del == 0 || del_idx), PRE3_E_ARG, "pre3_map_management: bad deletion list");
+    for (int d = 0; d < n_del; ++d)
+        PRE3_CHECK(del_idx[d] >= 0 && del_idx[d] < c->N && (d == 0 || del_idx[d] > del_idx[d - 1]), PRE3_E_ARG, "pre3_map_management: deletion indices must be ascending and in range");
+    PRE3_CHECK(n_new >= 0 && (n_new == 0 || (uvd && initial_rho)), PRE3_E_ARG, "pre3_map_management: bad new-feature arguments");
+    PRE3_CHECK(n_new == 0 || c->have_cam, PRE3_E_STATE, "pre3_map_management: camera not set");
+    PRE3_CHECK(c->N - n_del + n_new <= c->capN, PRE3_E_ARG, "pre3_map_management: %d - %d + %d landmarks exceed the capacity %d", c->N, n_del, n_new, c->capN);
+    const int N = c->N;
+    std::vector<int32_t> flags(N ? N : 1, 0);
+    if (convert_threshold >= 0 && N > 0) {
+        DISPATCH_T(c,
+            hipLaunchKernelGGL(k_map_convert_flags<double>, dim3(ceil_div(N, 64)), dim3(64), 0, c->stream, N, c->lm.type, c->lm.off, c->x_kk, (const double *)c->P, c->ld, convert_threshold, c->map_flags, c->map_conv),
+            hipLaunchKernelGGL(k_map_convert_flags<float>, dim3(ceil_div(N, 64)), dim3(64), 0, c->stream, N, c->lm.type, c->lm.off, c->x_kk, (const float *)c->P, c->ld, convert_threshold, c->map_flags, c->map_conv));
+        PRE3_HIP(hipGetLastError());
+        PRE3_HIP(hipStreamSynchronize(c->stream));
+        PRE3_HIP(hipMemcpy(flags.data(), c->map_flags, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+    }
+    std::vector<int32_t> desc, types, src;
+    desc.reserve(3 * (size_t)(c->n + 6 * n_new)); types.reserve(N + n_new); src.reserve(N + n_new);
+    for (int i = 0; i < 13; ++i) { desc.push_back(0); desc.push_back(i); desc.push_back(0); }
+    int d = 0, off = 13, n_out = 13;
+    bool any = n_del > 0 || n_new > 0;
+    for (int i = 0; i < N; ++i) {
+        const int dim = c->lm_type_host[i] == PRE3_INVDEPTH ? 6 : 3;
+        if (d < n_del && del_idx[d] == i) { ++d; off += dim; flags[i] = 0; continue; }
+        if (flags[i]) {
+            for (int q = 0; q < 3; ++q) { desc.push_back(2); desc.push_back(i); desc.push_back(q); }
+            types.push_back(PRE3_CARTESIAN); n_out += 3; any = true;
+        } else {
+            for (int q = 0; q < dim; ++q) { desc.push_back(0); desc.push_back(off + q); desc.push_back(0); }
+            types.push_back(c->lm_type_host[i]); n_out += dim;
+        }
+        src.push_back(i);
+        off += dim;
+    }
+    if (converted_out) for (int i = 0; i < N; ++i) converted_out[i] = flags[i];
+    if (!any) return PRE3_OK;
+    const int first_new_off = n_out;
+    for (int f = 0; f < n_new; ++f) {
+        for (int q = 0; q < 6; ++q) { desc.push_back(1); desc.push_back(f); desc.push_back(q); }
+        types.push_back(PRE3_INVDEPTH); src.push_back(-1); n_out += 6;
+    }
+    return apply_map(c, desc, n_out, types, n_new, first_new_off, src, uvd, initial_rho, std_pxl);
 }
 
 }  // extern "C"

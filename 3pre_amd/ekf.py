@@ -158,6 +158,19 @@ class EkfFilter:
         self._refresh_map()
         return conv
 
+    def map_management(self, del_idx=(), new_uvd=None, std_pxl=1.0, initial_rho=0.5, linearity_index_threshold=None):
+        """map_management.m:27-79 as one call (delete_features, inversedepth_2_cartesian unless the threshold is None, the new features of
+        initialize_features): one pass over the covariance.  Returns the per-landmark converted flags of the map before the call."""
+        d = i32(sorted(int(v) for v in del_idx))
+        uvd = f64(new_uvd).reshape(-1, 2) if new_uvd is not None else np.zeros((0, 2))
+        rho = f64(np.broadcast_to(initial_rho, (uvd.shape[0],)))
+        conv = np.zeros(max(self.N, 1), np.int32)
+        n_before = self.N
+        check(lib.pre3_map_management(self._ctx, int(d.shape[0]), dptr(d), C.c_double(-1.0 if linearity_index_threshold is None else linearity_index_threshold),
+                                      dptr(conv), int(uvd.shape[0]), dptr(uvd), C.c_double(std_pxl), dptr(rho)))
+        self._refresh_map()
+        return conv[:n_before].copy()
+
     # ---- IC search on the device (search_IC_matches.m:31-44 + matching_sift_based.m:104-149)
     def set_descriptors(self, desc, first=0):
         """features_info(first+i).Descriptor; desc is (128, count) as MATLAB stores it (or (count, 128) C-order rows)."""

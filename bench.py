@@ -422,8 +422,7 @@ def frame_leg(pre3, synth, N=500, K2=600, frames=40, warm=4, n_hyp=200):
                     stage[name].append(t[-1] - t[-2])
             s = seq["steps"][k]
             # map_management.m:27-79: the landmark added last frame goes (frame 0: the last one of the map), a new one comes in
-            f.delete_features([f.N - 1])
-            f.add_features_inverse_depth(np.array([[rng.uniform(30, 140), rng.uniform(30, 110)]]), 1.0, 0.5)
+            f.map_management([f.N - 1], np.array([[rng.uniform(30, 140), rng.uniform(30, 110)]]), 1.0, 0.5)      # (pre3_map_management: one pass over P)
             f.set_descriptors(new_desc[:, k:k + 1], first=f.N - 1)
             mark("map_management")
             f.ekf_prediction(s["u"])

@@ -229,6 +229,13 @@ PRE3_API int pre3_map_add_inverse_depth(pre3_ctx *ctx, int n_new, const double *
 /* inversedepth_2_cartesian.m:27-76: convert every inverse-depth landmark whose linearity index is below the threshold
  * (0.1 in the reference) to a Cartesian point; converted_out[N] (may be NULL) receives the flags. */
 PRE3_API int pre3_map_inversedepth_2_cartesian(pre3_ctx *ctx, double linearity_threshold, int32_t *converted_out);
+/* map_management.m:27-79 as one call: delete_features (:33), inversedepth_2_cartesian (:48; convert_threshold < 0: skipped) and the
+ * addition of initialize_features (:58-66), in that order, with ONE pass over the covariance (their row maps compose: each only selects or
+ * recombines rows of the old state).  converted_out (may be null): per landmark of the map BEFORE the call, 1 = converted.
+ * The result is what the three calls in sequence give (bit for bit when nothing is converted; to rounding in the entries that pair
+ * a converted landmark with a new one). */
+PRE3_API int pre3_map_management(pre3_ctx *ctx, int n_del, const int32_t *del_idx, double convert_threshold, int32_t *converted_out,
+                                 int n_new, const double *uvd, double std_pxl, const double *initial_rho);
 /* current landmark table: returns N, writes lm_type_out[N] if not NULL */
 PRE3_API int pre3_get_map(pre3_ctx *ctx, int32_t *lm_type_out);
 

@@ -131,6 +131,16 @@ void mexFunction(int nout, mxArray *out[], int nin, const mxArray *in[])
         for (i = 0; i < N; ++i) mxGetPr(out[0])[i] = f[i];
         mxFree(f); check(rc);
     }
+    else if (!strcmp(cmd, "map_management")) {    /* converted = pre3_mex('map_management', del_idx (0-based, ascending), linearity_thr (< 0: no conversion), uvd (2xk), std_pxl, initial_rho (1xk))
+                                                     map_management.m:27-79 as one call: delete_features, inversedepth_2_cartesian, the new features -- one pass over P */
+        int k = (int)mxGetNumberOfElements(in[1]), N = pre3_get_map(g_ctx, NULL), i, rc;
+        int32_t *d = (int32_t *)mxMalloc(sizeof(int32_t) * (k ? k : 1)), *f = (int32_t *)mxCalloc(N ? N : 1, sizeof(int32_t));
+        for (i = 0; i < k; ++i) d[i] = (int32_t)mxGetPr(in[1])[i];
+        rc = pre3_map_management(g_ctx, k, d, mxGetScalar(in[2]), f, (int)mxGetN(in[3]), mxGetPr(in[3]), mxGetScalar(in[4]), mxGetPr(in[5]));
+        out[0] = mxCreateDoubleMatrix(1, N, mxREAL);
+        for (i = 0; i < N; ++i) mxGetPr(out[0])[i] = f[i];
+        mxFree(d); mxFree(f); check(rc);
+    }
     else if (!strcmp(cmd, "set_descriptors")) {   /* pre3_mex('set_descriptors', [features_info.Descriptor] (128xN), first (0-based)) */
         check(pre3_set_descriptors(g_ctx, nin > 2 ? (int)mxGetScalar(in[2]) : 0, (int)mxGetN(in[1]), mxGetPr(in[1])));
     }

@@ -183,3 +183,53 @@ def test_map_management_and_steps_over_several_frames(pre3, orc):
         assert np.abs(f.get_x_k_k() - x).max() < 1e-9 and np.abs(f.get_p_k_k() - P).max() < 1e-9 * np.abs(P).max(), "frame %d" % frame
     assert (types == 1).any() and len(types) == N0
     f.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_map_management_in_one_call_equals_the_three_calls(pre3, orc, dtype):
+    """pre3_map_management (map_management.m:27-79: delete, convert, add with ONE pass over P) against the three calls in sequence:
+    bit for bit when nothing is converted; with conversions, to rounding (only the entries pairing a converted landmark with a new one
+    associate differently) and against the oracle's sequence."""
+    N = 36
+    seq = synth.make_sequence(N, 2, 30, seed=17)
+    types, off, n = orc.landmark_table(np.zeros(N, int))
+    rng = np.random.default_rng(9)
+    uvd = np.stack([rng.uniform(5, 170, 3), rng.uniform(5, 140, 3)], 1)
+    rho = rng.uniform(0.1, 1.0, 3)
+    dele = [2, 11, 35]
+    # (a) no conversion: identical bits
+    fa = pre3.EkfFilter(seq["cam"], types, dtype=dtype, max_hyp=30, max_landmarks=N + 4)
+    fb = pre3.EkfFilter(seq["cam"], types, dtype=dtype, max_hyp=30, max_landmarks=N + 4)
+    for f in (fa, fb):
+        f.set_x_p_k_k(seq["x0"], seq["P0"])
+    conv = fa.map_management(dele, uvd, 1.0, rho)
+    fb.delete_features(dele); fb.add_features_inverse_depth(uvd, 1.0, rho)
+    assert conv.sum() == 0 and fa.N == fb.N == N and fa.n == fb.n and np.array_equal(fa.lm_type, fb.lm_type)
+    assert np.array_equal(fa.get_x_k_k(), fb.get_x_k_k()) and np.array_equal(fa.get_p_k_k(), fb.get_p_k_k())
+    fa.map_management()                                      # nothing to do
+    assert fa.N == N
+    fa.close(); fb.close()
+    # (b) with conversions
+    P0 = seq["P0"].copy()
+    for i in range(0, N, 3):
+        o = off[i] + 5
+        P0[o, :] *= 1e-3; P0[:, o] *= 1e-3
+    fa = pre3.EkfFilter(seq["cam"], types, dtype=dtype, max_hyp=30, max_landmarks=N + 4)
+    fb = pre3.EkfFilter(seq["cam"], types, dtype=dtype, max_hyp=30, max_landmarks=N + 4)
+    for f in (fa, fb):
+        f.set_x_p_k_k(seq["x0"], P0)
+    conv = fa.map_management(dele, uvd, 1.0, rho, linearity_index_threshold=0.1)
+    fb.delete_features(dele); conv_b = fb.inversedepth_2_cartesian(0.1); fb.add_features_inverse_depth(uvd, 1.0, rho)
+    kept = [i for i in range(N) if i not in dele]
+    assert conv[dele].sum() == 0 and np.array_equal(conv[kept], conv_b) and 0 < conv.sum() < N
+    assert fa.N == fb.N and fa.n == fb.n and np.array_equal(fa.lm_type, fb.lm_type)
+    xa, Pa, xb, Pb = fa.get_x_k_k(), fa.get_p_k_k(), fb.get_x_k_k(), fb.get_p_k_k()
+    assert np.array_equal(xa, xb)
+    assert np.abs(Pa - Pb).max() < TOL[dtype] * np.abs(Pb).max()
+    # ... and the oracle's own sequence
+    Pq = P0.astype(np.float32).astype(np.float64) if dtype == "f32" else P0
+    x1, P1, t1 = orc.map_delete(types, off, seq["x0"], Pq, dele)
+    x2, P2, t2, _ = orc.map_convert(t1, x1, P1, 0.1)
+    x3, P3 = orc.map_add(x2, P2, seq["cam"], uvd, 1.0, rho)
+    assert np.abs(xa - x3).max() < 1e-12 and np.abs(Pa - P3).max() < TOL[dtype] * np.abs(P3).max()
+    fa.close(); fb.close()
