@@ -23,7 +23,7 @@ void set_error(const char *fmt, ...)
 
 // launchers defined in the kernel files
 int launch_predict_impl(pre3_ctx *c, const double u[7], bool with_projection = false, size_t inbox_n16 = 0, int32_t inbox_seq = 0);
-int launch_inbox_pull(pre3_ctx *c, const void *src_host_mapped, void *dst_dev, size_t n16, int32_t seq);
+int launch_inbox_pull(pre3_ctx *c, const void *src_host_mapped, void *dst_dev, size_t n16, int32_t seq, int slot = 10);   // (either direction: 16-byte words between device memory and a mapped pinned block, then `seq` into mailbox word `slot`)
 int launch_window_gate(pre3_ctx *c, int M, const int32_t *pred_idx_dev, const int32_t *k1_dev, const double *zc_dev, int strict, int32_t *accept_dev);
 int launch_build_rows_impl(pre3_ctx *c, int nsel, const int32_t *sel_dev, int r_pad);
 int launch_ransac_score_impl(pre3_ctx *c, int k, double threshold, int hyp_begin, int hyp_end, int ldg, int32_t *support_dev, uint32_t *mask_dev, int mask_words,
@@ -341,6 +341,7 @@ int pre3_destroy(pre3_ctx *c)
     if (c->pinned_stats) (void)hipHostFree(c->pinned_stats);
     if (c->inbox_host) (void)hipHostFree(c->inbox_host);
     if (c->mail_host) (void)hipHostFree(c->mail_host);
+    if (c->ic_result_host) (void)hipHostFree(c->ic_result_host);
     for (hipEvent_t e : c->kt.ev) (void)hipEventDestroy(e);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
@@ -602,11 +603,14 @@ static int ensure_ic_buffers(pre3_ctx *c)
     const size_t N = (size_t)c->capN;
     PRE3_TRY(dmalloc(&c->bank, N * DESC_DIM)); PRE3_TRY(dmalloc(&c->bank_alt, N * DESC_DIM));
     // result block, fetched with ONE copy: [counts(4) | meas(capN) | pairs(3 capN) | z(2 capN doubles)]
-    PRE3_TRY(dmalloc(&c->ic_pred, N)); PRE3_TRY(dmalloc(&c->ic_counts, 4 + 4 * N + 4 * N)); PRE3_TRY(dmalloc(&c->ic_arg, N));
+    PRE3_TRY(dmalloc(&c->ic_pred, N)); PRE3_TRY(dmalloc(&c->ic_counts, 4 + 4 * N + 4 * N + 4)); PRE3_TRY(dmalloc(&c->ic_arg, N));
     c->ic_pairs = c->ic_counts + 4 + N;
     PRE3_HIP(hipMemset(c->ic_counts, 0, sizeof(int32_t) * (4 + 8 * N)));
     PRE3_TRY(dmalloc(&c->ic_newk2, N)); PRE3_TRY(dmalloc(&c->ic_best, N)); PRE3_TRY(dmalloc(&c->ic_second, N)); PRE3_TRY(dmalloc(&c->bank_src, N));
     PRE3_HIP(hipMemset(c->bank, 0, sizeof(double) * N * DESC_DIM));
+    const size_t blk_bytes = (sizeof(int32_t) * (4 + 4 * N) + sizeof(double) * 2 * N + 15) & ~(size_t)15;
+    PRE3_HIP(hipHostMalloc(&c->ic_result_host, blk_bytes, hipHostMallocMapped));
+    PRE3_HIP(hipHostGetDevicePointer(&c->ic_result_host_dev, c->ic_result_host, 0));
     return PRE3_OK;
 }
 
@@ -756,15 +760,16 @@ int pre3_ic_search(pre3_ctx *c, double thresh, int strict_reference, int32_t *n_
     }
     // search_IC_matches.m:31-44: h, H and S for every landmark at the prediction
     PRE3_CHECK(c->have_cam, PRE3_E_STATE, "pre3_ic_search: camera not set");
-    if (N) PRE3_TRY(launch_project_innovation(c, PRE3_X_K_KM1, 1, 0, 0.0));
+    if (N) PRE3_TRY(launch_project_innovation(c, PRE3_X_K_KM1, 1, 0, 0.0, true, true));      // (also clears individually_compatible of every landmark)
     c->projected = true; c->innovated = true;
-    PRE3_HIP(hipMemsetAsync(c->lm.ic, 0, sizeof(int32_t) * (N ? N : 1), c->stream));
     PRE3_TRY(launch_ic_search(c, thresh, strict_reference));
-    // one D2H copy of the result block [counts | meas | pairs | z]
+    // the result block [counts | meas | pairs | z] is written into mapped pinned memory by the device itself and announced through the mailbox:
+    // no DMA-engine copy, no stream synchronisation (the host polls one word)
     const size_t capN = (size_t)c->capN, blk_bytes = sizeof(int32_t) * (4 + 4 * capN) + sizeof(double) * 2 * capN;
-    std::vector<int32_t> blk(4 + 4 * capN + 4 * capN);
-    PRE3_HIP(hipMemcpyAsync(blk.data(), c->ic_counts, blk_bytes, hipMemcpyDeviceToHost, c->stream));
-    PRE3_HIP(hipStreamSynchronize(c->stream));
+    PRE3_TRY(launch_inbox_pull(c, c->ic_counts, c->ic_result_host_dev, (blk_bytes + 15) / 16, ++c->seq_ic, 12));
+    PRE3_TRY(wait_mail(c, 12, c->seq_ic));
+    const int32_t *blk_p = static_cast<const int32_t *>(c->ic_result_host);
+    std::vector<int32_t> blk(blk_p, blk_p + (4 + 4 * capN + 4 * capN));
     const int32_t *counts = blk.data();
     const int n_match = c->scan_K2 > 0 ? counts[1] : 0, m = c->scan_K2 > 0 ? counts[2] : 0;
     PRE3_CHECK(m >= 0 && m <= N && n_match >= 0 && n_match <= N, PRE3_E_STATE, "pre3_ic_search: inconsistent counts (%d matches, %d accepted)", n_match, m);

@@ -51,7 +51,7 @@ __device__ __forceinline__ double jn_row(const double *J, int i, const double v[
 }
 // The per-step inbox [meas | ic | hyp | z]: pinned host memory, read over PCIe by the device itself (16 bytes per lane).  ONE workgroup, so
 // that its last act can be to publish `seq` in the pinned mailbox: the host may overwrite the inbox once it reads that number back.
-struct InboxRide { const int4 *src; int4 *dst; int n16; int32_t *mail; int32_t seq; };        // n16 == 0: no pull in this launch
+struct InboxRide { const int4 *src; int4 *dst; int n16; int32_t *mail; int32_t seq; int slot = 10; };        // n16 == 0: no pull in this launch; slot: the mailbox word that takes seq
 __device__ __forceinline__ void inbox_pull_block(const InboxRide &ib)
 {
     // four PCIe reads in flight per lane (a read is ~1.5 us; one after the other they made this block the long pole of k_predict)
@@ -63,7 +63,7 @@ __device__ __forceinline__ void inbox_pull_block(const InboxRide &ib)
         for (int u = 0; u < 4; ++u) { const int i = i0 + u * blockDim.x; if (i < ib.n16) ib.dst[i] = v[u]; }
     }
     __syncthreads();
-    if (threadIdx.x == 0) { __threadfence_system(); __hip_atomic_store(ib.mail + 10, ib.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+    if (threadIdx.x == 0) { __threadfence_system(); __hip_atomic_store(ib.mail + ib.slot, ib.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }
 
 // k_predict_x and k_predict_P in ONE launch (a kernel boundary costs ~5 us on this platform, more than either kernel):
@@ -273,11 +273,14 @@ __global__ __launch_bounds__(256) void k_project_innovation(int N, const int32_t
                                                             double *Hc, double *Hl, int32_t *has_h, int mode, double chi2, double *h,
                                                             const double *__restrict__ z, const int32_t *__restrict__ ic,
                                                             const int32_t *__restrict__ li, int32_t *__restrict__ hi, double *__restrict__ S,
-                                                            int32_t *__restrict__ has_S, int32_t *__restrict__ clear, int n_clear, HiArgs ha)
+                                                            int32_t *__restrict__ has_S, int32_t *__restrict__ clear, int n_clear, HiArgs ha,
+                                                            int32_t *__restrict__ clear2, int n_clear2)
 {
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     // a step's IC search precedes its measurements: clear the inlier flags of the previous frame here (n_clear = 0 otherwise)
     for (int t = gt; t < n_clear; t += gridDim.x * blockDim.x) clear[t] = 0;
+    // (pre3_ic_search: individually_compatible of every landmark -- a hipMemsetAsync of 4 N bytes went out as three fill kernels, 15 us)
+    for (int t = gt; t < n_clear2; t += gridDim.x * blockDim.x) clear2[t] = 0;
     // the block's 16 landmarks are projected by the first 16 lanes of its first wave (one wave runs the long fp64 code, not four)
     if (threadIdx.x < 16 && (int)(blockIdx.x * 16 + threadIdx.x) < N) project_one(blockIdx.x * 16 + threadIdx.x, lm_type, lm_off, x, cam, clear_first, h, has_h, Hc, Hl);
     __threadfence_block();
@@ -1007,7 +1010,7 @@ int launch_project(pre3_ctx *c, int which, int clear_first)
 
 
 // project + innovation (+ the HI collection in mode 1) with one kernel boundary less
-int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode, double chi2, bool collect)
+int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode, double chi2, bool collect, bool clear_ic)
 {
     const double *x = which == PRE3_X_K_K ? c->x_kk : c->x_km1;
     int32_t *clr = (int32_t *)((unsigned char *)c->inbox_dev + c->off_flags);
@@ -1018,10 +1021,10 @@ int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode,
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_project_innovation<double>, g, b, 0, c->stream, c->N, c->lm.type, c->lm.off, x, to_camd(c->cam), clear_first,
                            (const double *)c->P, c->ld, c->lm.Hc, c->lm.Hl, c->lm.has_h, mode, chi2, c->lm.h, c->lm.z, c->lm.ic, c->lm.li,
-                           c->lm.hi, c->lm.S, c->lm.has_S, clr, n_clr, ha),
+                           c->lm.hi, c->lm.S, c->lm.has_S, clr, n_clr, ha, clear_ic ? c->lm.ic : nullptr, clear_ic ? c->N : 0),
         hipLaunchKernelGGL(k_project_innovation<float>, g, b, 0, c->stream, c->N, c->lm.type, c->lm.off, x, to_camd(c->cam), clear_first,
                            (const float *)c->P, c->ld, c->lm.Hc, c->lm.Hl, c->lm.has_h, mode, chi2, c->lm.h, c->lm.z, c->lm.ic, c->lm.li,
-                           c->lm.hi, c->lm.S, c->lm.has_S, clr, n_clr, ha));
+                           c->lm.hi, c->lm.S, c->lm.has_S, clr, n_clr, ha, clear_ic ? c->lm.ic : nullptr, clear_ic ? c->N : 0));
     PRE3_HIP(hipGetLastError());
     if (mode == 1 && collect && !ha.fuse) PRE3_TRY(launch_collect_hi(c, ha));
     return PRE3_OK;
@@ -1160,9 +1163,9 @@ int launch_update_x(pre3_ctx *c, int which_prior, int r)
 
 
 __global__ __launch_bounds__(1024) void k_inbox_pull(InboxRide ib) { inbox_pull_block(ib); }
-int launch_inbox_pull(pre3_ctx *c, const void *src_host_mapped, void *dst_dev, size_t n16, int32_t seq)
+int launch_inbox_pull(pre3_ctx *c, const void *src_host_mapped, void *dst_dev, size_t n16, int32_t seq, int slot)
 {
-    hipLaunchKernelGGL(k_inbox_pull, dim3(1), dim3(1024), 0, c->stream, InboxRide{ (const int4 *)src_host_mapped, (int4 *)dst_dev, (int)n16, c->mail_dev, seq });
+    hipLaunchKernelGGL(k_inbox_pull, dim3(1), dim3(1024), 0, c->stream, InboxRide{ (const int4 *)src_host_mapped, (int4 *)dst_dev, (int)n16, c->mail_dev, seq, slot });
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }

@@ -161,6 +161,7 @@ struct pre3_ctx {
     // no synchronisation, no read-back (pre3_api.hip: stage_acquire / stage_release)
     void *up_stage[2] = { nullptr, nullptr }; hipEvent_t up_stage_ev[2] = { nullptr, nullptr }; bool up_stage_used[2] = { false, false };
     int up_stage_next = 0; size_t up_stage_bytes = 0;
+    void *ic_result_host = nullptr, *ic_result_host_dev = nullptr; int32_t seq_ic = 0;    // the IC search's result block in mapped pinned memory: written by the device, announced through mailbox word 12
     int32_t *ic_pred = nullptr, *ic_counts = nullptr, *ic_arg = nullptr, *ic_pairs = nullptr, *ic_newk2 = nullptr; double *ic_best = nullptr, *ic_second = nullptr;
     int32_t *bank_src = nullptr;
     bool ic_last_ranked = false;                  // the last pre3_ic_search matched on the matrix cores (PRE3_OPT_IC_RANKED)
@@ -221,7 +222,7 @@ constexpr int DESC_DIM = 128;
 // ---- geometry / RANSAC kernels (pre3_geom.hip)
 int launch_project(pre3_ctx *c, int which, int clear_first);
 int launch_innovation(pre3_ctx *c, int mode /*0: S=HPH'+I for predicted; 1: rescue gate + HI list*/, double chi2, bool clear_flags = false, bool collect = true /* mode 1: the HI list follows (k_collect_hi) */);
-int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode, double chi2, bool collect = true);
+int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode, double chi2, bool collect = true, bool clear_ic = false);
 int launch_update_x(pre3_ctx *c, int which_prior, int r);
 int launch_jnorm(pre3_ctx *c, int which);
 
