@@ -23,7 +23,8 @@ void set_error(const char *fmt, ...)
 
 // launchers defined in the kernel files
 int launch_predict_impl(pre3_ctx *c, const double u[7], bool with_projection = false, size_t inbox_n16 = 0, int32_t inbox_seq = 0);
-int launch_inbox_pull(pre3_ctx *c, const void *src_host_mapped, void *dst_dev, size_t n16, int32_t seq, int slot = 10);   // (either direction: 16-byte words between device memory and a mapped pinned block, then `seq` into mailbox word `slot`)
+int launch_inbox_pull(pre3_ctx *c, const void *src_host_mapped, void *dst_dev, size_t n16, int32_t seq, int slot = 10);
+int launch_slice_prepare(pre3_ctx *c, const void *src_host_mapped, size_t n16, int32_t seq, int n_zero, int k, int lo, int hi, int tag);   // (either direction: 16-byte words between device memory and a mapped pinned block, then `seq` into mailbox word `slot`)
 int launch_window_gate(pre3_ctx *c, int M, const int32_t *pred_idx_dev, const int32_t *k1_dev, const double *zc_dev, int strict, int32_t *accept_dev);
 int launch_build_rows_impl(pre3_ctx *c, int nsel, const int32_t *sel_dev, int r_pad);
 int launch_ransac_score_impl(pre3_ctx *c, int k, double threshold, int hyp_begin, int hyp_end, int ldg, int32_t *support_dev, uint32_t *mask_dev, int mask_words,
@@ -783,14 +784,8 @@ int pre3_ic_search(pre3_ctx *c, double thresh, int strict_reference, int32_t *n_
 }
 
 // ---- RANSAC ---------------------------------------------------------------------------------------
-// need[s] = tag for every measurement position a hypothesis of [lo, hi) draws (a fresh tag per round: nothing to clear)
-__global__ void k_mark_needed(const int32_t *__restrict__ hyp, int k, int lo, int hi, int32_t *__restrict__ need, int tag)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < (hi - lo) * k) need[hyp[lo * k + t]] = tag;
-}
-
-static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, int lo = 0, int hi = -1, bool slice_form = false)
+// zero_words > 0 (the sliced forms): that many words of c->support (supports, masks [, the missing-slice word]) are cleared on the way
+static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, int lo = 0, int hi = -1, bool slice_form = false, size_t zero_words = 0)
 {
     PRE3_CHECK(c->measurements_set && c->projected, PRE3_E_STATE, "ransac: needs pre3_project and measurements");
     PRE3_CHECK(c->p_which == PRE3_X_K_KM1, PRE3_E_STATE, "ransac: needs the predicted estimate (call pre3_predict or set x_k_km1)");
@@ -799,24 +794,32 @@ static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, in
     PRE3_CHECK(hyp != nullptr, PRE3_E_ARG, "ransac: null hypothesis table");
     PRE3_CHECK(c->m >= k, PRE3_E_ARG, "ransac: %d measurements but k=%d", c->m, k);
     for (int i = 0; i < n_draw * k; ++i) PRE3_CHECK(hyp[i] >= 0 && hyp[i] < c->m, PRE3_E_ARG, "ransac: hyp[%d]=%d not a position in the IC list (m=%d)", i, hyp[i], c->m);
-    if (hyp != (const int32_t *)(c->inbox_host + c->off_hyp)) {       // not already shipped with the measurements
+    if (hi < 0) hi = n_draw;
+    const bool sliced = lo > 0 || hi < n_draw || slice_form;
+    const bool need_pull = hyp != (const int32_t *)(c->inbox_host + c->off_hyp);       // not already shipped with the measurements
+    if (need_pull) {
         if (c->inbox_pending) { PRE3_TRY(wait_mail(c, 10, c->seq_inbox)); c->inbox_pending = false; }
         memcpy(c->inbox_host + c->off_hyp, hyp, sizeof(int32_t) * n_draw * k);
-        PRE3_TRY(launch_inbox_pull(c, (const unsigned char *)c->inbox_host_dev + c->off_hyp, c->hyp, (sizeof(int32_t) * n_draw * k + 15) / 16, ++c->seq_inbox));
-        c->inbox_pending = true;
+    }
+    if (sliced) {
+        // one launch: the clear, the pull and the marks of the measurements this slice's hypotheses draw (k_slice_prepare)
+        ++c->need_tag;
+        PRE3_TRY(launch_slice_prepare(c, (const unsigned char *)c->inbox_host_dev + c->off_hyp, need_pull ? (sizeof(int32_t) * n_draw * k + 15) / 16 : 0,
+                                      need_pull ? ++c->seq_inbox : c->seq_inbox, (int)zero_words, k, lo, hi, c->need_tag));
+        if (need_pull) c->inbox_pending = true;
+    } else {
+        if (zero_words) PRE3_HIP(hipMemsetAsync(c->support, 0, sizeof(int32_t) * zero_words, c->stream));
+        if (need_pull) { PRE3_TRY(launch_inbox_pull(c, (const unsigned char *)c->inbox_host_dev + c->off_hyp, c->hyp, (sizeof(int32_t) * n_draw * k + 15) / 16, ++c->seq_inbox)); c->inbox_pending = true; }
     }
     c->masks = reinterpret_cast<uint32_t *>(c->support + round_up(n_draw, 4));
     c->scored_n_draw = n_draw; c->scored_k = k;         // the mask offset depends on n_draw: select / export / import must use the same
     int r = 2 * c->m, r_pad = round_up(r, NB);
     static const int inline_g_env = getenv("PRE3_INLINE_G") ? atoi(getenv("PRE3_INLINE_G")) : 1;
     const bool inline_g = inline_g_env != 0;
-    if (hi < 0) hi = n_draw;
-    if (lo > 0 || hi < n_draw || slice_form) {
+    if (sliced) {
         // a rank's slice of a sharded round: H*P and H*P*H' only for the measurements its hypotheses draw (the scorer of hypothesis h
         // reads the 2k rows of its own landmarks and the entries of G among them, nothing else) -- the part of the round that
         // shrinks with the number of ranks.  The LI update must not gather from these partial products: hp_all_valid stays false.
-        ++c->need_tag;
-        if (hi > lo) hipLaunchKernelGGL(k_mark_needed, dim3(ceil_div((hi - lo) * k, 256)), dim3(256), 0, c->stream, c->hyp, k, lo, hi, c->need, c->need_tag);
         PRE3_TRY(launch_ell_HP_build(c, c->HP, c->need, c->need_tag));
         if (!inline_g) PRE3_TRY(launch_ell_G_hyp(c, k, lo, hi, r_pad));
         c->g_valid = !inline_g;
@@ -839,8 +842,7 @@ int pre3_ransac_score(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, double
     PRE3_CHECK(hyp_begin >= 0 && hyp_begin <= hyp_end && hyp_end <= n_draw, PRE3_E_ARG, "ransac: bad hypothesis range [%d,%d) of %d", hyp_begin, hyp_end, n_draw);
     int words = ceil_div(c->m, 32);
     PRE3_CHECK(n_draw >= 1 && n_draw <= c->caph, PRE3_E_ARG, "ransac: n_draw=%d exceeds capacity %d", n_draw, c->caph);
-    PRE3_HIP(hipMemsetAsync(c->support, 0, sizeof(int32_t) * ((size_t)round_up(n_draw, 4) + (size_t)n_draw * words), c->stream));   // supports + masks
-    PRE3_TRY(ransac_prepare(c, n_draw, k, hyp, hyp_begin, hyp_end));
+    PRE3_TRY(ransac_prepare(c, n_draw, k, hyp, hyp_begin, hyp_end, false, (size_t)round_up(n_draw, 4) + (size_t)n_draw * words));   // (supports + masks cleared on the way)
     PRE3_TRY(launch_ransac_score_impl(c, k, threshold, hyp_begin, hyp_end, round_up(2 * c->m, NB), c->support, c->masks, words));
     if (support_dev) *support_dev = c->support;
     if (mask_dev) *mask_dev = c->masks;
@@ -939,10 +941,11 @@ int pre3_ransac_sharded(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, doub
     // one word more than supports + masks travels through the all-reduce: the number of ranks whose slice is MISSING.  A rank-local failure
     // between here and the collective (a bad table, a failed launch) must not leave the peers waiting in ncclAllReduce for a partner that has
     // returned: this rank still enters the collective -- with its slice zero and that word set -- and every rank then fails the round.
-    PRE3_HIP(hipMemsetAsync(c->support, 0, sizeof(int32_t) * (count + 1), c->stream));
+
     // (the slice form at any number of ranks, one included: H*P only of the measurements this rank's hypotheses draw, H*P*H' only among each
     // hypothesis' own rows -- the round's cost then falls with the number of ranks from the same code path)
-    int rc_local = ransac_prepare(c, n_draw, k, hyp, lo, hi, true);
+    int rc_local = ransac_prepare(c, n_draw, k, hyp, lo, hi, true, count + 1);
+    if (rc_local != PRE3_OK) (void)hipMemsetAsync(c->support, 0, sizeof(int32_t) * (count + 1), c->stream);      // (a failure in front of the prepare launch: the buffer must still be clear)
     if (rc_local == PRE3_OK && hi > lo) rc_local = launch_ransac_score_impl(c, k, threshold, lo, hi, round_up(2 * c->m, NB), c->support, c->masks, words);
     if (rc_local != PRE3_OK) {
         (void)hipMemsetAsync(c->support, 0, sizeof(int32_t) * count, c->stream);                      // whatever part of the slice got written does not count

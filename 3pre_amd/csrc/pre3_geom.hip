@@ -1163,6 +1163,30 @@ int launch_update_x(pre3_ctx *c, int which_prior, int r)
 
 
 __global__ __launch_bounds__(1024) void k_inbox_pull(InboxRide ib) { inbox_pull_block(ib); }
+
+// A rank's slice of a sharded RANSAC round starts with three small things -- the supports + masks zeroed (the slices are disjoint: the
+// all-reduce's integer sum is their union), the draw table pulled out of the pinned inbox, and the measurements its hypotheses draw marked
+// (need[s] = tag: a fresh tag per round, nothing to clear) -- which were a memset, k_inbox_pull and k_mark_needed: one launch (workgroup 0: pull + marks).
+__global__ __launch_bounds__(1024) void k_slice_prepare(InboxRide ib, int32_t *__restrict__ zero, int n_zero, const int32_t *hyp, int k, int lo, int hi,
+                                                        int32_t *__restrict__ need, int tag)
+{
+    if (blockIdx.x > 0) {                           // workgroups 1..: the clear, 16 bytes per lane
+        int4 *z4 = reinterpret_cast<int4 *>(zero);
+        for (int i = (blockIdx.x - 1) * 1024 + threadIdx.x; i < n_zero / 4; i += (gridDim.x - 1) * 1024) z4[i] = int4{ 0, 0, 0, 0 };
+        if (blockIdx.x == 1 && (int)threadIdx.x < (n_zero & 3)) zero[(n_zero & ~3) + threadIdx.x] = 0;
+        return;
+    }
+    if (ib.n16 > 0) inbox_pull_block(ib);          // (ends in a barrier: the table is in device memory, written by this workgroup)
+    else __syncthreads();
+    for (int t = threadIdx.x; t < (hi - lo) * k; t += 1024) need[hyp[lo * k + t]] = tag;
+}
+int launch_slice_prepare(pre3_ctx *c, const void *src_host_mapped, size_t n16, int32_t seq, int n_zero, int k, int lo, int hi, int tag)
+{
+    hipLaunchKernelGGL(k_slice_prepare, dim3(1 + (n_zero > 0 ? std::min(16, ceil_div(n_zero, 4096)) : 0)), dim3(1024), 0, c->stream, InboxRide{ (const int4 *)src_host_mapped, (int4 *)c->hyp, (int)n16, c->mail_dev, seq, 10 },
+                       c->support, n_zero, c->hyp, k, lo, hi, c->need, tag);
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
 int launch_inbox_pull(pre3_ctx *c, const void *src_host_mapped, void *dst_dev, size_t n16, int32_t seq, int slot)
 {
     hipLaunchKernelGGL(k_inbox_pull, dim3(1), dim3(1024), 0, c->stream, InboxRide{ (const int4 *)src_host_mapped, (int4 *)dst_dev, (int)n16, c->mail_dev, seq, slot });
