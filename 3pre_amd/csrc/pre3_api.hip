@@ -642,7 +642,7 @@ static int stage_acquire(pre3_ctx *c, size_t bytes, void **host, void **dev, int
         c->up_stage_bytes = 0;
         const size_t cap = (bytes + 65535) & ~(size_t)65535;
         for (int k = 0; k < 2; ++k) {
-            PRE3_HIP(hipHostMalloc(&c->up_stage[k], cap));
+            PRE3_HIP(hipHostMalloc(&c->up_stage[k], cap, hipHostMallocMapped));
             if (!c->up_stage_ev[k]) PRE3_HIP(hipEventCreateWithFlags(&c->up_stage_ev[k], hipEventDisableTiming));
         }
         c->up_stage_bytes = cap;

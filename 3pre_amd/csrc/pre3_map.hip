@@ -340,7 +340,7 @@ static int ensure_map_buffers(pre3_ctx *c)
     // after the call before last has been consumed (its event), so a call does not end in a stream synchronisation
     c->map_stage_bytes = (sizeof(int32_t) * (3 * (size_t)c->capn + 3 * (size_t)c->capN + 16) + sizeof(double) * 3 * (size_t)c->capN + 15) & ~(size_t)15;
     for (int k = 0; k < 2; ++k) {
-        if (hipHostMalloc(&c->map_stage[k], c->map_stage_bytes) != hipSuccess || hipEventCreateWithFlags(&c->map_stage_ev[k], hipEventDisableTiming) != hipSuccess) {
+        if (hipHostMalloc(&c->map_stage[k], c->map_stage_bytes, hipHostMallocMapped) != hipSuccess || hipEventCreateWithFlags(&c->map_stage_ev[k], hipEventDisableTiming) != hipSuccess) {
             set_error("map management: pinned staging allocation failed"); return PRE3_E_NOMEM;
         }
     }
