@@ -1124,7 +1124,7 @@ int launch_select_gather(pre3_ctx *c, int n_draw, int k, int early_exit, int mas
     const int seq = ++c->seq_select;
     static const int lds_env = getenv("PRE3_SELECT_GATHER_LDS") ? atoi(getenv("PRE3_SELECT_GATHER_LDS")) : 1;
     const size_t stage = (size_t)SGL_RB * c->ldw * (c->dtype == PRE3_F64 ? 8 : 4);
-    if (lds_env && stage <= 56 * 1024) {
+    if (lds_env && stage <= 55 * 1024) {          // (+ 8.8 KB of static LDS: inside the 64 KB a launch gets without opting in)
         const int ny = r_pad_max / SGL_RB;
         dim3 g(ny + 1), b(256);
         DISPATCH_T(c,
