@@ -195,6 +195,24 @@ __global__ __launch_bounds__(256) void k_map_cols(int n_new, const int32_t *__re
     dst[(size_t)a * ld + b] = s;
 }
 
+// Everything that follows the congruence as riders of the congruence's launch (k_map_one; round 4: it was one copy, two uploads, three fills and the bank gather with two
+// stream synchronisations): the new state, the new landmark table, the per-landmark fields cleared (update_features_info.m:30-44), the
+// inbox cleared, and the descriptor bank re-laid-out (src[i] = old index of new landmark i, -1: a new landmark, zero descriptor).
+struct MapFinish {
+    int n_new; const double *x_alt; double *x_kk; int N; const int32_t *types_src, *off_src; int32_t *lm_type, *lm_off; int capN;
+    int32_t *has_h, *has_S, *inbox; int inbox_words; const int32_t *src; const double *bank; double *bank_out;
+};
+__device__ __forceinline__ void map_finish_block(const MapFinish &f, int t, int nt)
+{
+    for (int i = t; i < f.n_new; i += nt) f.x_kk[i] = f.x_alt[i];
+    for (int i = t; i < f.N; i += nt) { f.lm_type[i] = f.types_src[i]; f.lm_off[i] = f.off_src[i]; }
+    for (int i = t; i < f.capN; i += nt) { f.has_h[i] = 0; f.has_S[i] = 0; }
+    for (int i = t; i < f.inbox_words; i += nt) f.inbox[i] = 0;
+    if (f.bank != nullptr)
+        for (int i = t; i < f.N * 128; i += nt) { const int sidx = f.src[i >> 7]; f.bank_out[i] = sidx >= 0 ? f.bank[(size_t)sidx * 128 + (i & 127)] : 0.0; }
+}
+__global__ __launch_bounds__(256) void k_map_finish(MapFinish f) { map_finish_block(f, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x); }
+
 // out = A P A' (+ D) in one pass: out[a][b] = sum_t val[b][t] * T[a][col[b][t]],  T[a][c] = sum_t val[a][t] * P[col[a][t]][c] -- the sums of
 // k_map_rows / k_map_cols term for term, T rounded to the storage type as the stored intermediate was.  A workgroup writes 8 rows x 1024
 // columns; where row and columns are plain copies (src0 >= 0: everything but the few new / converted rows) an entry is one load.
@@ -227,12 +245,15 @@ __device__ __attribute__((noinline)) T map_entry(int a, int b, const int32_t *__
 template <typename T>
 __global__ __launch_bounds__(256) void k_map_one(int n_new, const int32_t *__restrict__ desc, const int32_t *__restrict__ col, const T *__restrict__ val,
                                                  const int32_t *__restrict__ src0, const T *__restrict__ P, int ld, T *__restrict__ dst,
-                                                 const double *__restrict__ feat)
+                                                 const double *__restrict__ feat, int ny, MapFinish fin)
 {
     constexpr int RB = 8, CB = 4;                                                     // a workgroup writes RB rows x CB * 256 columns
+    // the block rows behind the congruence's own: what follows it (new state, landmark table, cleared fields, inbox, descriptor bank) -- it
+    // needs nothing of this launch, so it rides here instead of going out as k_map_finish
+    if ((int)blockIdx.y >= ny) { map_finish_block(fin, (((int)blockIdx.y - ny) * gridDim.x + blockIdx.x) * 256 + threadIdx.x, ((int)gridDim.y - ny) * gridDim.x * 256); return; }
     // (ld is a multiple of 128: all RB rows exist.)  Last rows first: the computed rows of an add sit at the end of the state and take a dozen
     // microseconds of dependent loads -- dispatched first they hide behind the copies, dispatched last they were the tail of the launch
-    const int a0 = ((int)gridDim.y - 1 - (int)blockIdx.y) * RB;
+    const int a0 = (ny - 1 - (int)blockIdx.y) * RB;
     int cb[CB], sb[CB];                                                               // lane-consecutive columns: every access of a wave is one contiguous run
 #pragma unroll
     for (int k = 0; k < CB; ++k) {
@@ -306,23 +327,6 @@ __global__ void k_map_add_noise(int n_feat, int first_off, const double *__restr
     P[o] = (T)((double)P[o] + feat[(size_t)f * FEATW + 14 + i * 6 + j]);
 }
 
-// Everything that follows the congruence in one launch (round 4; it was one copy, two uploads, three fills and the bank gather with two
-// stream synchronisations): the new state, the new landmark table, the per-landmark fields cleared (update_features_info.m:30-44), the
-// inbox cleared, and the descriptor bank re-laid-out (src[i] = old index of new landmark i, -1: a new landmark, zero descriptor).
-__global__ __launch_bounds__(256) void k_map_finish(int n_new, const double *__restrict__ x_alt, double *__restrict__ x_kk, int N, const int32_t *__restrict__ types_src,
-                                                   const int32_t *__restrict__ off_src, int32_t *__restrict__ lm_type, int32_t *__restrict__ lm_off, int capN,
-                                                   int32_t *__restrict__ has_h, int32_t *__restrict__ has_S, int32_t *__restrict__ inbox, int inbox_words,
-                                                   const int32_t *__restrict__ src, const double *__restrict__ bank, double *__restrict__ bank_out)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
-    for (int i = t; i < n_new; i += nt) x_kk[i] = x_alt[i];
-    for (int i = t; i < N; i += nt) { lm_type[i] = types_src[i]; lm_off[i] = off_src[i]; }
-    for (int i = t; i < capN; i += nt) { has_h[i] = 0; has_S[i] = 0; }
-    for (int i = t; i < inbox_words; i += nt) inbox[i] = 0;
-    if (bank != nullptr)
-        for (int i = t; i < N * 128; i += nt) { const int sidx = src[i >> 7]; bank_out[i] = sidx >= 0 ? bank[(size_t)sidx * 128 + (i & 127)] : 0.0; }
-}
-
 #define DISPATCH_T(c, expr_f64, expr_f32) do { if ((c)->dtype == PRE3_F64) { expr_f64; } else { expr_f32; } } while (0)
 
 static int ensure_map_buffers(pre3_ctx *c)
@@ -387,14 +391,20 @@ static int apply_map(pre3_ctx *c, const std::vector<int32_t> &desc, int n_new, c
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_map_fill<double>, dim3(ceil_div(n_new, 256)), dim3(256), 0, c->stream, n_new, c->map_desc, c->x_kk, feat, conv, c->lm.off, c->map_col, (double *)c->map_val, c->x_alt, c->map_src0),
         hipLaunchKernelGGL(k_map_fill<float>, dim3(ceil_div(n_new, 256)), dim3(256), 0, c->stream, n_new, c->map_desc, c->x_kk, feat, conv, c->lm.off, c->map_col, (float *)c->map_val, c->x_alt, c->map_src0));
+    // new state, landmark table, cleared per-landmark fields and inbox, re-laid-out descriptor bank: riders of the congruence's launch (or one launch behind the two-pass form); no synchronisation
+    const bool with_bank = c->bank != nullptr && c->bank_alt != nullptr && N > 0;
+    const int fin_work = std::max(std::max(n_new, (int)(c->inbox_bytes / 4)), with_bank ? N * 128 : 0);
+    const MapFinish fin{ n_new, c->x_alt, c->x_kk, N, d_types, d_off, c->lm.type, c->lm.off, c->capN, c->lm.has_h, c->lm.has_S, (int32_t *)c->inbox_dev, (int)(c->inbox_bytes / 4),
+                         d_src, with_bank ? c->bank : nullptr, c->bank_alt };
     static const int one_pass = getenv("PRE3_MAP_ONE_PASS") ? atoi(getenv("PRE3_MAP_ONE_PASS")) : 1;
     if (one_pass) {
         // one pass into the second buffer, which becomes P
-        dim3 g1(ceil_div(c->ld, 1024), c->ld / 8), b(256);
+        const int gx = ceil_div(c->ld, 1024), ny = c->ld / 8, fin_rows = std::min(64, ceil_div(ceil_div(fin_work, 256), gx));
+        dim3 g1(gx, ny + fin_rows), b(256);
         const double *noise = n_feat > 0 ? feat : nullptr;
         DISPATCH_T(c,
-            hipLaunchKernelGGL(k_map_one<double>, g1, b, 0, c->stream, n_new, c->map_desc, c->map_col, (const double *)c->map_val, c->map_src0, (const double *)c->P, c->ld, (double *)c->P_alt, noise),
-            hipLaunchKernelGGL(k_map_one<float>, g1, b, 0, c->stream, n_new, c->map_desc, c->map_col, (const float *)c->map_val, c->map_src0, (const float *)c->P, c->ld, (float *)c->P_alt, noise));
+            hipLaunchKernelGGL(k_map_one<double>, g1, b, 0, c->stream, n_new, c->map_desc, c->map_col, (const double *)c->map_val, c->map_src0, (const double *)c->P, c->ld, (double *)c->P_alt, noise, ny, fin),
+            hipLaunchKernelGGL(k_map_one<float>, g1, b, 0, c->stream, n_new, c->map_desc, c->map_col, (const float *)c->map_val, c->map_src0, (const float *)c->P, c->ld, (float *)c->P_alt, noise, ny, fin));
         std::swap(c->P, c->P_alt);
     } else {
         dim3 g(ceil_div(c->ld, 256), c->ld), b(256);
@@ -409,12 +419,8 @@ static int apply_map(pre3_ctx *c, const std::vector<int32_t> &desc, int n_new, c
                 hipLaunchKernelGGL(k_map_add_noise<double>, dim3(ceil_div(n_feat * 36, 256)), dim3(256), 0, c->stream, n_feat, first_new_off, feat, (double *)c->P, c->ld),
                 hipLaunchKernelGGL(k_map_add_noise<float>, dim3(ceil_div(n_feat * 36, 256)), dim3(256), 0, c->stream, n_feat, first_new_off, feat, (float *)c->P, c->ld));
         }
+        hipLaunchKernelGGL(k_map_finish, dim3(std::min(1024, ceil_div(fin_work, 256))), dim3(256), 0, c->stream, fin);
     }
-    // new state, landmark table, cleared per-landmark fields and inbox, re-laid-out descriptor bank: one launch, no synchronisation
-    const bool with_bank = c->bank != nullptr && c->bank_alt != nullptr && N > 0;
-    const int work = std::max(std::max(n_new, (int)(c->inbox_bytes / 4)), with_bank ? N * 128 : 0);
-    hipLaunchKernelGGL(k_map_finish, dim3(std::min(1024, ceil_div(work, 256))), dim3(256), 0, c->stream, n_new, c->x_alt, c->x_kk, N, d_types, d_off, c->lm.type, c->lm.off,
-                       c->capN, c->lm.has_h, c->lm.has_S, (int32_t *)c->inbox_dev, (int)(c->inbox_bytes / 4), d_src, with_bank ? c->bank : nullptr, c->bank_alt);
     PRE3_HIP(hipGetLastError());
     if (with_bank) std::swap(c->bank, c->bank_alt);
     c->N = N; c->n = n; c->lm_type_host = new_types;
