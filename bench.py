@@ -608,7 +608,7 @@ def main():
     ap.add_argument("--landmarks", type=int, default=500)
     ap.add_argument("--hyp", type=int, default=200)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--kt-every", type=int, default=4, help="bracket one K9 launch in N with HIP events (an event pair costs ~11 us of stream time); 1 = every launch")
+    ap.add_argument("--kt-every", type=int, default=8, help="bracket one K9 launch in N with HIP events (an event pair costs ~11 us of stream time); 1 = every launch")
     ap.add_argument("--sync-hi", action="store_true", help="complete every step's HI update inside the step call (default: deferred to the next call)")
     ap.add_argument("--k9-f32", action="store_true", help="fp32 path: K9 on the f32 MFMA instead of the three-way bf16 split (PRE3_OPT_K9_BF16X3 = 0)")
     ap.add_argument("--threshold", type=float, default=None, help="RANSAC threshold in pixels; default: the reference's own constant, 1.0 "
