@@ -151,7 +151,8 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
     c->device = device; c->dtype = dtype; c->esz = dtype == PRE3_F64 ? 8 : 4;
     c->capN = max_landmarks; c->capn = 13 + 6 * max_landmarks; c->capm = max_landmarks; c->caph = max_hyp;
     c->ld = round_up(c->capn, TILE); c->ldw = c->ld + NB;
-    c->rcap = round_up(2 * c->capm, NB);
+    { const char *e = getenv("PRE3_TAIL"); c->step_tail = e ? atoi(e) != 0 : false; }      // PRE3_OPT_STEP_TAIL: off by default (measured: DESIGN.md section 5d)
+    c->rcap = round_up(2 * c->capm, NB) + NB;       // (+ one panel: the rescued landmarks' rows follow the LI update's inside the persistent launch, pre3_cholp.hip)
     c->mask_words_cap = ceil_div(c->capm, 32);
     int rc = PRE3_OK;
     auto A = [&](int r) { if (rc == PRE3_OK) rc = r; };
@@ -265,6 +266,11 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
                                   hipMemcpy(c->dd_tiles, t64.data(), sizeof(int2) * t64.size(), hipMemcpyHostToDevice) != hipSuccess)) { set_error("consumer table upload failed"); rc = PRE3_E_HIP; }
         }
         A(dmalloc_bytes(&c->cholp_tp, (size_t)(c->rcap / NB) * 1536 * 16));
+        // the tail of the persistent launch (rescue stage + HI update, CpTail): per landmark y = H J W' as bf16 planes (+ one zero slot), the row H J, crit's list
+        A(dmalloc_bytes(&c->tail_yp, (size_t)(c->capN + 1) * 2 * 3 * c->rcap * 2));
+        { void *f = nullptr; A(dmalloc_bytes(&f, (size_t)c->capN * 2 * 16 * sizeof(float))); c->tail_hb = (float *)f; }
+        { void *f = nullptr; A(dmalloc_bytes(&f, sizeof(int32_t) * (64 + 64 * 16))); c->tail_hib = (int32_t *)f; }
+        { void *f = nullptr; A(dmalloc_bytes(&f, (size_t)c->ldw * c->rcap * sizeof(float))); c->tail_wt = (float *)f; }
         if (rc == PRE3_OK) { cholp_context_count(c->device, +1); c->cholp_counted = true; }
         const int nt = c->ld / 128, ns = ceil_div(nt, 4);
         std::vector<std::vector<int2>> lists(8);
@@ -335,7 +341,7 @@ int pre3_destroy(pre3_ctx *c)
     c->comm = nullptr;
     void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
                      c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
-                     c->sel_rows, c->support, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_src0, c->map_conv, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128, c->need, c->cholp_flags, c->cholp_tp, c->dd_groups, c->dd_tiles };
+                     c->sel_rows, c->support, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_src0, c->map_conv, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128, c->need, c->cholp_flags, c->cholp_tp, c->dd_groups, c->dd_tiles, c->tail_yp, c->tail_hb, c->tail_hib, c->tail_wt };
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (int k2 = 0; k2 < 2; ++k2) { if (c->map_stage[k2]) (void)hipHostFree(c->map_stage[k2]); if (c->map_stage_ev[k2]) (void)hipEventDestroy(c->map_stage_ev[k2]); }
     for (int k2 = 0; k2 < 2; ++k2) { if (c->up_stage[k2]) (void)hipHostFree(c->up_stage[k2]); if (c->up_stage_ev[k2]) (void)hipEventDestroy(c->up_stage_ev[k2]); }
@@ -359,6 +365,7 @@ int pre3_set_option(pre3_ctx *c, int option, int value)
     case PRE3_OPT_K9_BF16X3: c->k9_b3 = value != 0 && c->dtype == PRE3_F32 && c->Wp != nullptr; return PRE3_OK;
     case PRE3_OPT_CHOL_PERSIST: c->chol_persist = value != 0; return PRE3_OK;
     case PRE3_OPT_K9_OVERLAP: c->k9_overlap = value != 0; return PRE3_OK;
+    case PRE3_OPT_STEP_TAIL: c->step_tail = value != 0; return PRE3_OK;
     default: set_error("pre3_set_option: unknown option %d", option); return PRE3_E_ARG;
     }
 }
@@ -372,6 +379,7 @@ int pre3_get_option(pre3_ctx *c, int option, int *value_out)
     case PRE3_OPT_CHOL_PERSIST: *value_out = cholp_usable(c, 1) ? 1 : 0; return PRE3_OK;
     case PRE3_OPT_IC_RANKED: *value_out = c->ic_last_ranked ? 1 : 0; return PRE3_OK;
     case PRE3_OPT_K9_OVERLAP: *value_out = c->k9_overlap ? 1 : 0; return PRE3_OK;
+    case PRE3_OPT_STEP_TAIL: *value_out = (c->step_tail && c->tail_yp != nullptr) ? 1 : 0; return PRE3_OK;
     default: set_error("pre3_get_option: unknown option %d", option); return PRE3_E_ARG;
     }
 }
@@ -426,6 +434,19 @@ int pre3_state_size(pre3_ctx *c) { return c ? c->n : PRE3_E_ARG; }
 
 int pre3_set_state(pre3_ctx *c, int which, int n, const double *x, const double *P)
 {
+    {
+        // a fresh state also clears what an earlier state left in the device's error words (a factorisation that was not positive definite, a
+        // wait that gave up): the deferred work of the old state is dropped with them
+        const int rc0 = check_ctx(c);
+        if (c && rc0 != PRE3_OK && rc0 != PRE3_E_NUMERIC && rc0 != PRE3_E_HIP) return rc0;
+        if (c) {
+            PRE3_HIP(hipSetDevice(c->device));
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipMemsetAsync(c->stats + 6, 0, sizeof(int32_t) * 2, c->stream);
+            if (c->mail_host) { c->mail_host[6] = 0; c->mail_host[7] = 0; }
+            c->jn_pending = false; c->hi_pending = false; c->tail_done = false; c->hi_fused = false;
+        }
+    }
     PRE3_TRY(check_ctx(c));
     PRE3_CHECK(which == PRE3_X_K_K || which == PRE3_X_K_KM1, PRE3_E_ARG, "pre3_set_state: bad selector");
     PRE3_CHECK(n == c->n, PRE3_E_ARG, "pre3_set_state: n=%d but the map defines n=%d", n, c->n);
@@ -1027,7 +1048,14 @@ int pre3_update_li(pre3_ctx *c)
             static const int spec_env = getenv("PRE3_CHOL_SPEC0") ? atoi(getenv("PRE3_CHOL_SPEC0")) : 1;
             if (spec_env && round_up(2 * c->m, NB) <= c->rcap) {
                 // fp32: the whole factorisation + solve is ONE launch that reads the row count on the device (pre3_cholp.hip)
-                if (cholp_usable(c, round_up(2 * c->m, NB) / NB)) { PRE3_TRY(launch_cholp(c, -1, round_up(2 * c->m, NB) / NB, -1, PRE3_X_K_KM1)); c->cholp_done = true; }
+                if (cholp_usable(c, round_up(2 * c->m, NB) / NB)) {
+                    // pre3_step: the rescue stage and the HI update ride in the same launch (mono_slam.m:184-187 as panel nrb of this factorisation)
+                    CholpTailReq req{ c->tail_chi2, c->seq_collect + 1 };
+                    c->tail_launched = false;
+                    PRE3_TRY(launch_cholp(c, -1, round_up(2 * c->m, NB) / NB, -1, PRE3_X_K_KM1, c->tail_want ? &req : nullptr));
+                    if (c->tail_launched) ++c->seq_collect;
+                    c->cholp_done = true;
+                }
                 else PRE3_TRY(launch_chol_first_spec(c, c->m));
                 first_done = true;
             }
@@ -1035,6 +1063,9 @@ int pre3_update_li(pre3_ctx *c)
         PRE3_TRY(wait_mail(c, 8, c->seq_select)); n_li = c->mail_host[4];
         PRE3_CHECK(!c->shard_round || c->mail_host[11] == 0, PRE3_E_COMM, "sharded RANSAC: a rank failed before the collective of the round this update follows");
     }
+    // (a launch that found no rows on the device returned at once: the tail has not run either)
+    c->tail_done = first_done && c->cholp_done && c->tail_launched && n_li > 0;
+    c->tail_launched = false;
     return update_selected(c, PRE3_X_K_KM1, n_li, c->sel_rows, gathered, first_done);
 }
 
@@ -1059,17 +1090,37 @@ int pre3_update_hi(pre3_ctx *c)
 {
     PRE3_TRY(check_ctx(c));
     int n_hi = 0;
+    const bool tail_done = c->tail_done, was_fused = c->hi_fused;
+    c->tail_done = false; c->hi_fused = false;                      // (before anything can return)
     if (c->hi_from_host >= 0) n_hi = c->hi_from_host;
     else if (c->hi_kernel) {
         PRE3_TRY(wait_mail(c, 9, c->seq_collect)); n_hi = c->mail_host[5];
-        // the collection stage also brings the device's error words: what went wrong in this step's launches fails THIS call
-        PRE3_CHECK(c->mail_host[7] == 0, PRE3_E_HIP, "a device-side wait on another workgroup gave up (counter never arrived): results are invalid");
-        PRE3_CHECK(c->mail_host[6] == 0, PRE3_E_NUMERIC, "innovation covariance S is not positive definite");
+        // the collection stage also brings the device's error words: what went wrong in this step's launches fails THIS call -- once: the words
+        // are cleared with the report, so that a context that installs a fresh state (pre3_set_state) works again
+        const int e_wait = c->mail_host[7], e_npd = c->mail_host[6];
+        if (e_wait != 0 || e_npd != 0) {
+            c->mail_host[6] = 0; c->mail_host[7] = 0;
+            (void)hipMemsetAsync(c->stats + 6, 0, sizeof(int32_t) * 2, c->stream);
+        }
+        PRE3_CHECK(e_wait == 0, PRE3_E_HIP, "a device-side wait on another workgroup gave up (counter never arrived): results are invalid");
+        PRE3_CHECK(e_npd == 0, PRE3_E_NUMERIC, "innovation covariance S is not positive definite");
     }
-    if (c->hi_fused) {
+    if (tail_done) {
+        // The persistent launch of the LI update has run the rescue stage and (up to 32 landmarks) the HI update as well (pre3_cholp.hip, CpTail):
+        // P holds P - W'W - W~'W~ and update.m:42-46 of BOTH updates is one pending rows / columns 3..6 pass (params[16..] = params[96..] = J2 J1,
+        // or J1 alone when nothing was updated).  More than 32: that pass now (J1), then the general path.
+        c->hp_all_valid = false;
+        if (c->hi_from_host < 0 && n_hi <= 32) {
+            if (c->leave_jn_to_predict) c->jn_pending = true;
+            else PRE3_TRY(launch_jnorm(c, 0));
+            return PRE3_OK;
+        }
+        PRE3_TRY(launch_jnorm(c, 0));
+        return update_selected(c, PRE3_X_K_K, n_hi, c->sel_rows);
+    }
+    if (was_fused) {
         // pre3_step sent the collection and the update out as one device-driven pair of launches (k_hi_fused + its down-date): up to 32
         // landmarks are done, only the Jnorm pass of update.m:42-46 is left; more than that take the general path now
-        c->hi_fused = false;
         if (c->hi_from_host < 0 && n_hi <= 32) {
             if (n_hi > 0) {
                 c->hp_all_valid = false;
@@ -1141,12 +1192,18 @@ static int step_back(pre3_ctx *c, int m, int n_draw, int k, const int32_t *hyp, 
     static const int ride_rescue = getenv("PRE3_RIDE_RESCUE") ? atoi(getenv("PRE3_RIDE_RESCUE")) : 1;      // 0: projection + gate as one launch of their own (A/B)
     c->ride_rescue_projection = ride_rescue != 0;                   // the rescue's projection rides in the LI update's K9 launch
     {
+        c->tail_want = c->step_tail && hi_fused_usable(c); c->tail_chi2 = chi2;      // ... or, with the whole rescue stage and the HI update, in the persistent launch itself
         const int rc_li = pre3_update_li(c);                        // mono_slam.m:181
+        c->tail_want = false;
         c->ride_rescue_projection = false;                          // (also on failure: a later K9 launch must not carry the riders)
-        if (rc_li != PRE3_OK) { c->rescue_projected = false; return rc_li; }
+        if (rc_li != PRE3_OK) { c->rescue_projected = false; c->tail_done = false; return rc_li; }
     }
     if (ran) for (int i = 0; i < 4; ++i) st[i] = c->mail_host[i];
-    if (hi_fused_usable(c)) {
+    if (c->tail_done) {
+        // mono_slam.m:184 + :187 went out with the LI update's launch: the count arrives with mailbox word 9 (pre3_update_hi)
+        c->rescue_projected = false; c->proj_with_jnorm = false;
+        c->hi_from_host = -1; c->hi_kernel = true; c->hi_fused = false;
+    } else if (hi_fused_usable(c)) {
         // mono_slam.m:184 + :187 without the host in between: the chi2 gate, then the collection and the HI update of up to 32 landmarks as ONE
         // launch that reads the count on the device, and its down-date behind it (pre3_update.hip, k_hi_fused)
         PRE3_CHECK(c->p_which == PRE3_X_K_K && c->x_valid[PRE3_X_K_K], PRE3_E_STATE, "pre3_step: the LI update did not leave (x_k_k, p_k_k)");

@@ -21,6 +21,11 @@ void cholp_context_count(int device, int delta);      // a context with the pers
 // S (c->Smat, stride nrb * 64) and [HP | nu] (c->W) in place -> L and W = L^-1 [HP | nu], W's bf16 planes (c->Wp) included.
 // nrb < 0: the number of rows is read on the device (stats[4] measurements, as k_gather_li does); nrb_max bounds grid and LDS.
 void cholp_timing_rows(pre3_ctx *c, int r);             // pre3_kernel_timing: the rows of a bracketed speculative launch have reached the host
-int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows = -1, int which_prior = -1 /* >= 0: the launch may also compute x_k_k from that prior */);
+// tail_req (pre3_step's LI update, row count on the device): the launch also runs the rescue stage and the HI update of up to 32 landmarks
+// (mono_slam.m:184-187) when cholp_tail_usable and every tile group of P is in the launch; c->tail_launched says whether it does
+struct CholpTailReq { double chi2; int32_t seq; };
+bool cholp_tail_usable(const pre3_ctx *c, int nrb_max);
+int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows = -1, int which_prior = -1 /* >= 0: the launch may also compute x_k_k from that prior */,
+                 const CholpTailReq *tail_req = nullptr);
 
 }  // namespace pre3

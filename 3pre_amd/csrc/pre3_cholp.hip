@@ -55,6 +55,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t cp_rsrc(const void *p)
 // 16-byte sc1 load / store at a byte offset (aux 16 = sc1: bypasses this CU's L1 / writes through)
 __device__ __forceinline__ u32x4_t ld16_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16); }
 __device__ __forceinline__ void st16_sc1(u32x4_t v, __amdgpu_buffer_rsrc_t r, unsigned off) { __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16); }
+// four floats at a dword-aligned byte offset (the whole vector is re-typed: __builtin_bit_cast of ONE element of an ext-vector reads element 0)
+__device__ __forceinline__ f4v_t ld4f(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_bit_cast(f4v_t, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); }
+__device__ __forceinline__ f4v_t ld4f_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_bit_cast(f4v_t, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16)); }
+__device__ __forceinline__ int ld_i32_sc1(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_i32_sc1(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ unsigned cf_load(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -182,7 +187,33 @@ struct CpArgs {
     int stride;                          // crit and the rows are blocks 0, stride, 2 stride, ..
     int n; const double *x_prior; double *x_out; double *params; int xu;      // xu: the strips finish with x_out = x_prior + W'(L^-1 nu) (update.m:36,42,48)
     float *P; const int32_t *dd; int n_dd; int rows; int dd_mode;      // down-date consumers: group table (DG_WORDS each), groups in this launch, rows if host-known
+    int tail;                            // the rescue stage and the HI update follow inside this launch (CpTail): the HI rows are panel `nrb` of the same factorisation
+    float *Wt; int kcap;                 // tail: W once more, column-major (column j at Wt + j * kcap, k contiguous): what the gate's y = H J W' reads
 };
+// mono_slam.m:184-187 inside the launch (round 5).  Once the strips have x_k_k:  (B) every landmark is projected and linearised at x_k_k
+// (rescue_hi_inliers.m:32-33); for the candidates (individually compatible, not a low-innovation inlier) y_i = H_i J W' (2 x r), the gate
+// nu' inv(H_i J P+ J' H_i') nu < chi2 with H_i J P+ J' H_i' = (H_i J) P (H_i J)' - y_i y_i' (P+ = P - W'W is never formed; J = the normalisation
+// Jacobian of update.m:42-46), y_i as bf16 planes (Yp) and the row H_i J (Hb).  (C) crit collects the rescued landmarks (rescue_hi_inliers.m:44-46)
+// and publishes them (hib).  (D) their rows are panel nrb of the block factorisation the launch is running anyway: L(hi, K) = Y_hi(:, block K),
+// D_hi = (H J) P (H J)' + I - Y_hi Y_hi' on crit, chain -> M_hi; strips: W~ = M_hi ((H J) P - Y_hi W) -- i.e. L_hi^-1 H J P+ --, x += J W~' (L_hi^-1 nu);
+// consumers: one more panel, acc += W~' W~, and P - acc is written ONCE.  What is left of update.m:42-46 for BOTH updates -- rows / columns 3..6 <- (J2 J) . --
+// is one pending pass (params[96..]: the next prediction's launch applies it, or k_jnorm_P).
+struct CpTail {
+    int on, N, m, seq, ykcap, pad0;
+    double chi2;
+    const int32_t *lm_type, *lm_off, *lm_ic, *lm_li, *meas;
+    int32_t *lm_hi, *has_h, *hi_meas, *sel_rows, *stats, *mail;
+    double *h, *Hc, *Hl; const double *z;
+    CamD cam;
+    void *Yp;                            // [N + 1][2 rows][3 planes][ykcap] bf16: y_i = H_i J W' of candidate landmark i (slot N stays zero: padding rows)
+    float *Hb;                           // [N][2][16]: the row H_i J in ELL order (7 pose + 6 landmark entries), [13] = nu = z - h
+#ifdef PRE3_TAIL_DEBUG
+    double *dbgS;
+#endif
+    int32_t *hib;                        // what crit publishes: [0] count, [1] rows in this launch (0: none or more than HF_TAIL_MAXL), [4..35] landmark per entry, [64..] rows [64][16]
+};
+constexpr int HT_MAXL = 32;              // rescued landmarks the launch itself updates with (one panel); more: the host's general path
+constexpr int HT_HIB_WORDS = 64 + 64 * 16;
 // A call passes its arguments in VGPRs: the callee makes the (wave-uniform) launch arguments scalar again, word by word
 __device__ __forceinline__ CpArgs cp_uniform(const CpArgs &v)
 {
@@ -193,7 +224,33 @@ __device__ __forceinline__ CpArgs cp_uniform(const CpArgs &v)
     for (unsigned w = 0; w < sizeof(CpArgs) / 4; ++w) dst[w] = (unsigned)__builtin_amdgcn_readfirstlane((int)src[w]);
     return a;
 }
+__device__ __forceinline__ CpTail ct_uniform(const CpTail &v)
+{
+    CpTail a;
+    const unsigned *src = reinterpret_cast<const unsigned *>(&v);
+    unsigned *dst = reinterpret_cast<unsigned *>(&a);
+#pragma unroll
+    for (unsigned w = 0; w < sizeof(CpTail) / 4; ++w) dst[w] = (unsigned)__builtin_amdgcn_readfirstlane((int)src[w]);
+    return a;
+}
+// The tail's code reads the launch arguments from LDS (k_cholp puts them there): as by-value arguments of the out-of-line roles they would be a
+// hundred more registers live through the chain and the panel loop (measured: 300 scratch instructions inside the chain).
+constexpr size_t CP_T_OFF = 160 * 1024 - 1024, CP_TA_OFF = CP_T_OFF + 512;
+static_assert(sizeof(CpTail) <= 512 && sizeof(CpArgs) <= 512, "LDS slots of the launch arguments");
+template <typename S> __device__ __forceinline__ S args_from_lds(size_t off)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char cp_smem[];
+    S a;
+    const unsigned *src = reinterpret_cast<const unsigned *>(cp_smem + off);
+    unsigned *dst = reinterpret_cast<unsigned *>(&a);
+#pragma unroll
+    for (unsigned w = 0; w < sizeof(S) / 4; ++w) dst[w] = (unsigned)__builtin_amdgcn_readfirstlane((int)src[w]);
+    return a;
+}
 constexpr int CF_MP = 0, CF_ROWL = 32, CF_ROWA = 32 * 65, CF_STRIP = 32 * 130;     // one 128-byte line per flag; the strips' flags follow
+constexpr int CF_HI = CF_ROWL;           // (row 0 has no flag of its own) crit's word for the tail: the HI list is out; word [1] = its rows in this launch
+// values of a strip's flag behind the panels (base + J + 1, J < 16): x_k_k of its states is out / its landmarks are gated / its block of W~ is out
+constexpr unsigned CFV_X = 20, CFV_GATE = 21, CFV_HIL = 22, CFV_HIW = 23;
 __device__ __forceinline__ unsigned *cf_rowL(unsigned *cf, int i) { return cf + CF_ROWL + 32 * i; }
 __device__ __forceinline__ unsigned *cf_rowA(unsigned *cf, int i) { return cf + CF_ROWA + 32 * i; }
 __device__ __forceinline__ unsigned *cf_strip(unsigned *cf, int s) { return cf + CF_STRIP + 32 * s; }
@@ -231,6 +288,8 @@ __device__ __forceinline__ void crit_prologue(const CpArgs &a, int nrb, CritSmem
 }
 
 // waves 0-9: the chain and the two products.  Barriers per panel: the chain's ten, then b0..b3 (crit_side keeps the same count).
+__device__ __attribute__((noinline)) int crit_tail(int nrb_v);
+
 __device__ __forceinline__ void crit_main(const CpArgs &a, int nrb, CritSmem &sm)
 {
     auto &Ls = sm.ch.Ls; auto &Xs = sm.ch.Xs;
@@ -240,7 +299,7 @@ __device__ __forceinline__ void crit_main(const CpArgs &a, int nrb, CritSmem &sm
     if ((tid0 >> 6) == 8) __builtin_amdgcn_s_setprio(3);
     else if ((tid0 >> 6) == 9) __builtin_amdgcn_s_setprio(2);
     bool bad = false;
-    for (int J = 0; J < nrb; ++J) {
+    for (int J = 0; ; ++J) {                                     // J < nrb: the LI update's panels; J == nrb: the rescued landmarks' rows, if the tail brings any
         if (tid0 == 0) { CP_STAMP(0, J, 0); CP_CLK(19, J, 0); }
         {
             typename ChW<float>::acc_t acc[ChW<float>::NBLK][ChW<float>::NBLK];
@@ -252,7 +311,13 @@ __device__ __forceinline__ void crit_main(const CpArgs &a, int nrb, CritSmem &sm
         //  the chain, whose code already takes every register, and come back as scratch traffic inside the chain)
         int tid = tid0;
         asm volatile("" : "+v"(tid));
-        if (J + 1 >= nrb) break;
+        if (J >= nrb) break;
+        if (J + 1 == nrb) {
+            // the last panel of the LI update is factored: rescue stage (crit_tail: all twelve waves, crit_side calls it at the same barrier).  With
+            // rescued landmarks it leaves Ls = D_hi, Xs = I and the loop runs once more: the chain of panel nrb
+            if (!a.tail || crit_tail(nrb) == 0) break;
+            continue;
+        }
         __syncthreads();                                                            // b0: MPl complete, T1p / T2 landed
         if (tid0 == 0) CP_STAMP(0, J, 2);
         const int wave = tid >> 6, lane = tid & 63, fa = (wave >> 1) & 1, fb = wave & 1;
@@ -326,7 +391,7 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
     // per launch by this CU, so there is no older copy for its L1 to hold; the loads carry sc1 all the same.)
     int fst = 5, cool = 0;
     unsigned pv = 0;
-    for (int J = 0; J < nrb; ++J) {
+    for (int J = 0; ; ++J) {
         const bool more = J + 1 < nrb;
         const int fr = J + 1;                                     // the row whose tiles this panel's products need
         const unsigned *fflag = cf_rowA(a.cf, fr < 64 ? fr : 63);
@@ -382,6 +447,7 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
         // factor (k_gain; not read again in this launch): wave 11, lane = row
         auto publish_l_cols = [&](int sp) {
             const int i = lane, C = 8 * sp;
+            if (J >= nrb) return;                                                   // (the HI panel's factor is not part of S)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int c4 = C + 4 * u;
@@ -396,7 +462,7 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
             // wave, so this step's stores must come after it -- a store's write-through acknowledge takes about as long as a step)
             if (wave == 11) fetch_step(false);                    // (no LDS access of its own in this loop: nothing for the compiler to order behind the DMAs)
             if (wave == 10) {
-                if (k == -1 && J > 0) {      // L(J, J-1)'s planes (stored during the last products) have drained: publish
+                if (k == -1 && J > 0 && J < nrb) {      // L(J, J-1)'s planes (stored during the last products) have drained: publish
                     drain_stores();
                     if (lane == 0) cf_store(cf_rowL(a.cf, J), a.base + (unsigned)J);
                     CP_STAMP(1, J, 5);
@@ -413,7 +479,11 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
             publish_m_rows(7, !more);
             if (!more) { drain_stores(); if (lane == 0) cf_store(a.cf + CF_MP, a.base + (unsigned)J + 1); CP_STAMP(1, J, 4); }
         }
-        if (!more) break;
+        if (J >= nrb) break;                                                         // (as crit_main)
+        if (J + 1 == nrb) {
+            if (!a.tail || crit_tail(nrb) == 0) break;
+            continue;
+        }
         {   // the fetch must be complete before the products (normally it is: the tiles arrive mid-chain)
             int spin = 0;
             while (wave == 11 && fst < 5 && spin < SPIN_LIMIT) {
@@ -454,12 +524,220 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
     }
 }
 
+// what crit keeps behind CritSmem (and a strip behind its plane slots) of the rescue stage's outcome
+struct TailSmem {
+    int cnt, r_hi, pad[2];
+    int lm[HT_MAXL], off[HT_MAXL], d[HT_MAXL];
+    __attribute__((aligned(16))) float rv[NB][16];               // row a of (H J) for the listed landmarks: 7 pose + 6 landmark entries, [13] = nu
+    __attribute__((aligned(16))) float tpose[NB][8];             // crit: (H J P)(a, 0..6)
+};
+constexpr size_t CP_TAIL_OFF = (sizeof(CritSmem) + 127) / 128 * 128;
+constexpr size_t CP_PART_OFF = (CP_TAIL_OFF + sizeof(TailSmem) + 127) / 128 * 128;      // six [32][33] f32 tiles: shares of Y_hi Y_hi' (crit_tail)
+static_assert(CP_PART_OFF + 6 * 32 * 33 * sizeof(float) <= 160 * 1024 - 1024, "crit's LDS with the tail");
+static_assert(offsetof(CritSmem, T1p) == offsetof(CritSmem, MPl) + sizeof(frag_t) * B3_SGRAN, "crit_tail keeps (H J P) at the landmark columns in MPl | T1p");
+
 __device__ __forceinline__ void crit_body(const CpArgs &a, int nrb, unsigned char *smem_raw)
 {
     CritSmem &sm = *reinterpret_cast<CritSmem *>(smem_raw);
     crit_prologue(a, nrb, sm);
     if (threadIdx.x < 640) crit_main(a, nrb, sm);
     else crit_side(a, nrb, sm);
+    if (a.tail) {
+        const CpTail t = args_from_lds<CpTail>(CP_T_OFF);
+        // the rescue flags in measurement order (rescue_hi_inliers.m:44-46 as pre3_get_flags reports it): off the rescue stage's path
+        for (int j = threadIdx.x; j < t.m; j += CP_NTH) {
+            const int i = t.meas[j];
+            t.hi_meas[j] = (t.lm_ic[i] == 1 && t.lm_li[i] == 0) ? ld_i32_sc1(t.lm_hi + i) : 0;
+        }
+        // the rescue stage's count reaches the host with the device's error words, as k_collect_hi / k_hi_fused publish them -- behind the HI panel's
+        // chain, so that a factorisation that failed HERE fails the call that reads this count
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const TailSmem &ts = *reinterpret_cast<const TailSmem *>(smem_raw + CP_TAIL_OFF);
+            t.mail[5] = ts.cnt;
+            t.mail[6] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t.mail[7] = __hip_atomic_load(a.status + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(&t.mail[9], t.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// crit between the LI update's last panel and the HI panel (all twelve waves; same barrier count on every path)
+// ------------------------------------------------------------------------------------------------------------------------------
+// one 16-byte granule of y's planes: the lane's row (landmark, image row, k half) in the VGPR part, plane / block / k-step in the SGPR part
+__device__ __forceinline__ unsigned yp_voff(int lm, int c, int h, int ykcap) { return (unsigned)(((lm * 2 + c) * 3) * ykcap + 8 * h) * 2u; }
+__device__ __forceinline__ unsigned yp_soff(int pl, int K, int q, int ykcap) { return (unsigned)(pl * ykcap + 64 * K + 16 * q) * 2u; }
+
+// rescue_hi_inliers.m:44-46 from the strips' gate flags; D_hi = (H J) P (H J)' + I - Y_hi Y_hi' -> Ls, I -> Xs.  Returns the HI update's rows in
+// this launch (0: nothing rescued, or more than HT_MAXL landmarks: the host's general path takes that update).
+__device__ __attribute__((noinline)) int crit_tail(int nrb_v)
+{
+    const CpArgs a = args_from_lds<CpArgs>(CP_TA_OFF);
+    const CpTail t = args_from_lds<CpTail>(CP_T_OFF);
+    const int nrb = __builtin_amdgcn_readfirstlane(nrb_v);
+    extern __shared__ __attribute__((aligned(16))) unsigned char cp_smem[];
+    CritSmem &sm = *reinterpret_cast<CritSmem *>(cp_smem);
+    TailSmem &ts = *reinterpret_cast<TailSmem *>(cp_smem + CP_TAIL_OFF);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int32_t *guard = a.status + 1;
+    if (tid == 0) CP_STAMP(22, 0, 0);
+    // (C1) every strip has projected and gated its landmarks
+    if (wave < 2) {
+        bool gave_up = true;
+        for (int spin = 0; spin < SPIN_LIMIT; ++spin) {
+            bool ok = true;
+            for (int s0 = wave * 64; s0 < a.n_strips; s0 += 128) {
+                const int sx = s0 + lane;
+                if (sx < a.n_strips) ok = ok && cf_reached(cf_load(cf_strip(a.cf, sx)), a.base + CFV_GATE);
+            }
+            if (__all(ok)) { gave_up = false; break; }
+            if ((spin & 1023) == 1023 && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { gave_up = false; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (gave_up && lane == 0) atomicExch(guard, 1);
+    }
+    __syncthreads();
+    if (tid == 0) CP_STAMP(22, 0, 1);
+    // (C2) the HI list in measurement order (rescue_hi_inliers.m:44-46) from the candidates' flags: the selection stage listed the candidates in that
+    //      order (sel_rows[m ..]: measurement << 16 | landmark), so one load level separates the list from the flags
+    const int n_all = t.m - *a.n_dev;
+    unsigned char *flg = reinterpret_cast<unsigned char *>(&sm.ch.Bs[0][0]);       // [n_all] (m <= 16 K: the host checks)
+    for (int r = tid; r < n_all; r += CP_NTH) flg[r] = (unsigned char)(ld_i32_sc1(t.lm_hi + (t.sel_rows[t.m + r] & 0xffff)) != 0);
+    __syncthreads();
+    if (tid < 64) {
+        int cnt = 0;
+        for (int b0 = 0; b0 < n_all; b0 += 64) {
+            const int r = b0 + tid;
+            const int in = r < n_all ? flg[r] : 0;
+            const unsigned long long mask = __ballot(in);
+            const int pos = cnt + __popcll(mask & ((1ull << tid) - 1ull));
+            if (in) {
+                const int v = t.sel_rows[t.m + r];
+                if (pos < HT_MAXL) ts.lm[pos] = v & 0xffff;
+                t.sel_rows[pos] = v >> 16;                                          // (pos <= r < m: the candidates' own entries lie behind the first m)
+            }
+            cnt += __popcll(mask);
+        }
+        if (tid == 0) { ts.cnt = cnt; ts.r_hi = (cnt >= 1 && cnt <= HT_MAXL) ? 2 * cnt : 0; }
+    }
+    __syncthreads();
+    const int cnt = ts.cnt, r_hi = ts.r_hi;
+    if (tid == 0) { t.stats[5] = cnt; t.stats[8] = 0; CP_STAMP(22, 0, 2); }
+    // (C3) the listed landmarks' rows (H J, nu: written by the gate) -> LDS and, with the list, to the strips
+    const __amdgpu_buffer_rsrc_t rHb = cp_rsrc(t.Hb), rHib = cp_rsrc(t.hib);
+    if (tid < NB * 4) {
+        const int row = tid >> 2, g4 = tid & 3;
+        u32x4_t v = { 0u, 0u, 0u, 0u };
+        if (row < r_hi) v = ld16_sc1(rHb, (unsigned)((ts.lm[row >> 1] * 2 + (row & 1)) * 16 + 4 * g4) * 4u);
+        *reinterpret_cast<u32x4_t *>(&ts.rv[row][4 * g4]) = v;
+        st16_sc1(v, rHib, (unsigned)(64 + row * 16 + 4 * g4) * 4u);
+    } else if (tid < NB * 4 + HT_MAXL) {
+        const int l = tid - NB * 4;
+        int lm = 0, off = 0, d = 0;
+        if (2 * l < r_hi) { lm = ts.lm[l]; off = t.lm_off[lm]; d = t.lm_type[lm] == PRE3_INVDEPTH ? 6 : 3; }
+        ts.off[l] = off; ts.d[l] = d;
+        st_i32_sc1(t.hib + 4 + l, lm);
+    } else if (tid == NB * 4 + HT_MAXL) {
+        st_i32_sc1(t.hib + 0, cnt); st_i32_sc1(t.hib + 1, r_hi);
+        st_i32_sc1(reinterpret_cast<int32_t *>(a.cf + CF_HI + 1), r_hi);          // (the consumers read it from the flag's own line)
+    }
+    drain_stores();
+    __syncthreads();
+    if (tid == 0) { cf_store(a.cf + CF_HI, a.base + CFV_HIL); CP_STAMP(22, 0, 3); }
+    if (r_hi == 0) return 0;
+    // (D0) Y_hi Y_hi' on the matrix cores: wave -> (quadrant of the lower triangle, every n-th block of k); with at most 32 rows only the first
+    //      quadrant holds anything and all twelve waves share its blocks.  The first block's planes are requested before anything else: they
+    //      travel while (D1) gathers.  (One CU takes in ~70 GB/s of handed-off bytes: the planes, 72 KB per block over three quadrants, are what this costs.)
+    const bool one_quad = r_hi <= 32;
+    const int quad = one_quad ? 0 : wave % 3, kg = one_quad ? wave : wave / 3, kstep = one_quad ? 12 : 4, fa = quad >= 1 ? 1 : 0, fb = quad == 2 ? 1 : 0;
+    const __amdgpu_buffer_rsrc_t rY = cp_rsrc(t.Yp);
+    unsigned va, vb;
+    {
+        const int ra = 32 * fa + (lane & 31), rb2 = 32 * fb + (lane & 31), h = lane >> 5;
+        va = yp_voff(ra < r_hi ? ts.lm[ra >> 1] : t.N, ra & 1, h, t.ykcap); vb = yp_voff(rb2 < r_hi ? ts.lm[rb2 >> 1] : t.N, rb2 & 1, h, t.ykcap);
+    }
+    frag_t fA[4][3], fB[4][3];
+    auto load_y = [&](int K) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                fA[q][pl] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rY, va, yp_soff(pl, K, q, t.ykcap), 16));
+                fB[q][pl] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rY, vb, yp_soff(pl, K, q, t.ykcap), 16));
+            }
+    };
+    if (kg < nrb) load_y(kg);
+    // (D1) T = (H J P) at the columns the listed rows touch: pose columns -> ts.tpose, landmark l's six -> tlm[a][6 l ..].  P is symmetric to the bit,
+    //      so T[a][k] = sum_s rv[a][s] P[ucol k][col(a, s)]: one row of P per job, its 13 entries in four loads, both image rows of a landmark per job
+    float *tlm = reinterpret_cast<float *>(sm.MPl);                                // [64][192] = MPl | T1p (free until the chain publishes M)
+    {
+        const __amdgpu_buffer_rsrc_t rP = cp_rsrc(a.P);
+        const int nU = 7 + 6 * cnt, njobs = cnt * nU;
+        for (int job = tid; job < njobs; job += CP_NTH) {
+            const int la = job / nU, k = job - la * nU;
+            const int lk = k < 7 ? 0 : (k - 7) / 6, tk = k < 7 ? k : (k - 7) - 6 * lk;
+            const int ucol = k < 7 ? k : (tk < ts.d[lk] ? ts.off[lk] + tk : 0);
+            const unsigned rb = (unsigned)ucol * (unsigned)a.ld * 4u, ob = (unsigned)ts.off[la] * 4u;
+            const f4v_t p0 = ld4f(rP, rb), p1 = ld4f(rP, rb + 16u), p2 = ld4f(rP, rb + ob), p3 = ld4f(rP, rb + ob + 16u);
+            const float pv[13] = { p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, p2.w, p3.x, p3.y };
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float *rv = ts.rv[2 * la + c];
+                float sacc = 0.f;
+#pragma unroll
+                for (int u = 0; u < 13; ++u) sacc = fmaf(rv[u], pv[u], sacc);
+                if (k < 7) ts.tpose[2 * la + c][k] = sacc;
+                else tlm[(2 * la + c) * 192 + 6 * lk + tk] = sacc;
+            }
+        }
+    }
+    if (tid == 0) CP_STAMP(22, 0, 4);
+    // every wave's 32 x 32 share of Y_hi Y_hi' goes to an LDS tile of its own ([32][33]; three in As, three in Bs, six behind the tail's block):
+    // ONE barrier, then (D3) adds the shares of an entry in a fixed order
+    auto tile = [&](int w) -> float * {
+        return w < 3 ? &sm.ch.As[0][0] + w * (32 * 33) : w < 6 ? &sm.ch.Bs[0][0] + (w - 3) * (32 * 33) : reinterpret_cast<float *>(cp_smem + CP_PART_OFF) + (w - 6) * (32 * 33);
+    };
+    {
+        f32x16_t c2;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c2[e] = 0.f;
+        for (int K = kg; K < nrb; K += kstep) {
+            mma6(fA, fB, c2);
+            if (K + kstep < nrb) load_y(K + kstep);
+        }
+        float *mine = tile(wave);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mine[acc_row(e, lane) * 33 + (lane & 31)] = c2[e];
+        if (tid == 0) CP_STAMP(22, 0, 5);
+        __syncthreads();
+        // (D3) D_hi on and below the diagonal (k_hi_fused's S, minus Y Y'), identity padding; X side of the chain: the identity
+        for (int idx = tid; idx < NB * NB; idx += CP_NTH) {
+            const int r1 = idx >> 6, r2 = idx & 63;
+            float v = 0.f;
+            if (r2 <= r1) {
+                if (r1 < r_hi) {
+                    const float *rv = ts.rv[r2];
+                    const float *tl = tlm + r1 * 192 + 6 * (r2 >> 1);
+                    float g = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 13; ++u) g = fmaf(rv[u], u < 7 ? ts.tpose[r1][u] : tl[u - 7], g);
+                    const int o = (r1 & 31) * 33 + (r2 & 31);
+                    float yy = 0.f;
+                    if (one_quad) { for (int w = 0; w < 12; ++w) yy += tile(w)[o]; }
+                    else { const int q = (r1 >> 5) + (r2 >> 5); for (int w = q; w < 12; w += 3) yy += tile(w)[o]; }
+                    v = (g - yy) + (r1 == r2 ? 1.f : 0.f);
+                } else v = r1 == r2 ? 1.f : 0.f;
+            }
+            sm.ch.Ls[r1][r2] = v;
+            sm.ch.Xs[r1][r2] = r1 == r2 ? 1.f : 0.f;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) CP_STAMP(22, 0, 6);
+    return r_hi;
 }
 
 
@@ -697,11 +975,311 @@ __device__ __attribute__((noinline)) void row_body(CpArgs a_v, int nrb_v, int i_
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// strip s: 32 columns of [HP | nu]
+// the rescue stage's projection and chi2 gate (rescue_hi_inliers.m:32-43), on the strips' CUs behind their x-update: strip s takes the landmarks
+// i = s (mod n_strips), one wave per landmark
 // ------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rdlane_d(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double ld_f64_sc1(const double *p)
+{
+    return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_f64_sc1(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 constexpr int DG_SLOTS = 6, DG_KMAX = 12, DG_WORDS = 16, DG_SLOT_GRAN = 3 * 2 * 64;     // down-date consumers (dd_body)
 constexpr int CP_WS = 32 + 1;                        // row stride of the strip's f32 transposition buffer
 constexpr int CP_WGRAN = 4 * 3 * 64;                 // granules of one 64 x 32 block of W as B-operand planes: [q 4][plane 3][lane 64]
+// LDS of the gate (the strip's CP | Yw2 region, free behind the x-update): one slot per wave of a round, y of the two candidates in hand, the
+// waves' partial sums
+struct GateSmem {
+    struct Slot { float hjf[2][16]; double hj[2][14]; double q00, q01, q11; int lm, off, type, had; double h_old[2], z[2]; double hc[14], hl[12], zi[2]; } slot[8];      // hjf[c][0..12] = row c of H J (f32: the update's rows; hj: the same values as doubles), [13] = nu; hc / hl / zi: the projection's outputs
+    double part[8][3];
+};
+constexpr size_t CP_GATE_OFF = 9 * 1024;            // behind the x-update's scratch (c 4 KB | sums 4 KB | quaternion), inside the strip's CP | Yw2 region
+static_assert(CP_GATE_OFF + sizeof(GateSmem) <= 20 * 1024, "the gate's LDS is the strip's CP | Yw2 region");
+__device__ __forceinline__ GateSmem &gate_smem(int win)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char cp_smem[];
+    return *reinterpret_cast<GateSmem *>(cp_smem + (size_t)win * CP_WGRAN * 16 + CP_GATE_OFF);
+}
+
+// a strip's TailSmem lies behind its plane slots (crit's behind CritSmem); its tpose part, which only crit uses, holds the strip's prefetched records
+__device__ __forceinline__ unsigned char *strip_tail_smem(int win)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char cp_smem[];
+    return cp_smem + (((size_t)(win + 1) * CP_WGRAN * 16 + (size_t)NB * CP_WS * sizeof(float) + 127) / 128 * 128);
+}
+struct GatePre { int lm, off, type, had; double h_old[2], z[2]; };
+
+// What the first round's projections need from the tables (candidate list -> landmark -> type / offset / the kept prediction / the measured pixel:
+// three dependent load levels) is fetched when the strip starts -- it then waits for crit's first panel anyway: wave w, lane 0 -> record w
+__device__ __attribute__((noinline)) void gate_prefetch(int rows_v, int s_v)
+{
+    const CpArgs a = args_from_lds<CpArgs>(CP_TA_OFF);
+    const CpTail t = args_from_lds<CpTail>(CP_T_OFF);
+    const int s = __builtin_amdgcn_readfirstlane(s_v), wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int n_all = t.m - __builtin_amdgcn_readfirstlane(rows_v) / 2, r = s + a.n_strips * wave;
+    if ((threadIdx.x & 63) != 0 || r >= n_all) return;
+    GatePre &sl = reinterpret_cast<GatePre *>(&reinterpret_cast<TailSmem *>(strip_tail_smem(a.win))->tpose[0][0])[wave];
+    const int i = t.sel_rows[t.m + r] & 0xffff;
+    sl.lm = i; sl.off = t.lm_off[i]; sl.type = t.lm_type[i];
+    sl.had = t.has_h[i];
+    sl.h_old[0] = t.h[2 * i]; sl.h_old[1] = t.h[2 * i + 1];
+    sl.z[0] = t.z[2 * i]; sl.z[1] = t.z[2 * i + 1];
+}
+
+// projection + Jacobian of landmark i at x_k_k (lane 0 of the calling wave; predict_camera_measurements.m / calculate_derivatives.m through
+// project_core), once the strips that own the pose and the landmark's entries have x out (their flag also covers every panel of their W).
+// Out of line: its fp64 geometry takes most of the register file, and the gate calls it from three places.
+// (inlined at its ONE call site in the gate: an out-of-line function with this much fp64 geometry saves and restores sixty-four callee-saved
+//  registers per call -- about a microsecond on the rescue stage's path, and the gate sat three calls deep)
+__device__ __forceinline__ void gate_project(const CpArgs &a, const CpTail &t, const int i_in, const int wave)          // i_in < 0: the landmark and its table entries are in the wave's slot
+{
+    GateSmem::Slot &sl = gate_smem(a.win).slot[wave];
+    const int lane = threadIdx.x & 63;
+    int32_t *guard = a.status + 1;
+    const bool slot = i_in < 0;
+    const int i = slot ? sl.lm : i_in;
+    const int type = slot ? sl.type : t.lm_type[i], off = slot ? sl.off : t.lm_off[i], d = type == PRE3_INVDEPTH ? 6 : 3;
+    {
+        const int sw = lane == 0 ? 0 : lane == 1 ? (off >> 5) : ((off + d - 1) >> 5);
+        const unsigned *fp = cf_strip(a.cf, sw);
+        bool gave_up = true;
+        for (int spin = 0; spin < SPIN_LIMIT; ++spin) {
+            const bool ok = lane >= 3 || cf_reached(cf_load(fp), a.base + CFV_X);
+            if (__all(ok)) { gave_up = false; break; }
+            if ((spin & 1023) == 1023 && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { gave_up = false; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (gave_up && lane == 0) atomicExch(guard, 1);
+    }
+    if (lane != 0) return;
+    double Hc[14] = { 0 }, Hl[12] = { 0 }, zi[2] = { 0, 0 };
+    double xp[7], yl[6];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) xp[u] = ld_f64_sc1(a.x_out + u);
+#pragma unroll
+    for (int u = 0; u < 6; ++u) yl[u] = u < d ? ld_f64_sc1(a.x_out + off + u) : 0.0;
+    const int had = slot ? sl.had : t.has_h[i];
+    double h_old[2] = { 0, 0 };
+    if (had) { h_old[0] = slot ? sl.h_old[0] : t.h[2 * i]; h_old[1] = slot ? sl.h_old[1] : t.h[2 * i + 1]; }
+    bool fresh = false;
+    const bool now = project_core(type, xp, yl, t.cam, had, h_old, zi, fresh, Hc, Hl);
+    if (fresh) { t.h[2 * i] = zi[0]; t.h[2 * i + 1] = zi[1]; }
+    t.has_h[i] = now ? 1 : 0;
+    if (now) {
+#pragma unroll
+        for (int u = 0; u < 14; ++u) t.Hc[14 * i + u] = Hc[u];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) t.Hl[12 * i + u] = Hl[u];
+    } else {
+        // (never predicted: the table keeps what it held -- zeros since pre3_set_map -- and the gate reads those)
+#pragma unroll
+        for (int u = 0; u < 14; ++u) Hc[u] = t.Hc[14 * i + u];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) Hl[u] = t.Hl[12 * i + u];
+        zi[0] = t.h[2 * i]; zi[1] = t.h[2 * i + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 14; ++u) sl.hc[u] = Hc[u];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) sl.hl[u] = Hl[u];
+    sl.zi[0] = zi[0]; sl.zi[1] = zi[1];
+}
+
+// The strip's flag is stored INSIDE (behind its candidates): the projections of the other landmarks follow it, off the rescue stage's path.
+// Candidates (individually compatible, not a low-innovation inlier: rescue_hi_inliers.m:36) were listed by the selection stage (sel_rows[m ..], in
+// measurement order): the r-th goes to strip r mod n_strips, so that every strip has its share whatever the landmarks' order; of the other
+// landmarks strip s takes i = s (mod n_strips).
+__device__ __forceinline__ void tail_gate_body(const CpArgs &a, const CpTail &t, const int nrb, const int s, const int rows)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char cp_smem[];
+    GateSmem &gs = gate_smem(a.win);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const __amdgpu_buffer_rsrc_t rYp = cp_rsrc(t.Yp), rHb = cp_rsrc(t.Hb), rP = cp_rsrc(a.P);
+    const int n_all = t.m - rows / 2;                             // candidates of the frame: the measurements the selection stage did not take
+    const int n_cand = n_all > s ? (n_all - s + a.n_strips - 1) / a.n_strips : 0, n_rounds = (n_cand + 7) / 8;
+    const int32_t *cand = t.sel_rows + t.m;
+    auto gate_flag = [&]() {                                      // every candidate's planes, rows and flag have left: the strip's flag for crit
+        drain_stores();
+        __syncthreads();
+        if (tid == 0) cf_store(cf_strip(a.cf, s), a.base + CFV_GATE);
+        if (s == 1 && tid == 0) CP_STAMP(23, 1, 3);
+    };
+    if (n_rounds == 0) gate_flag();
+    // Iterations 0 .. n_rounds-1 are the candidates' rounds (wave w: candidate 8 it + w; the whole workgroup meets at their barriers); behind them
+    // every wave works through the other landmarks i = s (mod n_strips) on its own (rescue_hi_inliers.m:32-33 projects and linearises every
+    // landmark).  ONE projection site for both.
+    int j_other = wave;
+    for (int it = 0; ; ++it) {
+        const bool cround = it < n_rounds;
+        const int c0 = 8 * it, n_round = cround ? (n_cand - c0 < 8 ? n_cand - c0 : 8) : 0;
+        int item = -2;                                            // -2: nothing; -1: the wave's slot; >= 0: a landmark
+        if (cround) {
+            if (wave < n_round) {
+                GateSmem::Slot &sl = gs.slot[wave];
+                if (lane == 0) {
+                    if (c0 == 0) {                                 // (the first round's table entries came with gate_prefetch)
+                        const GatePre &pr = reinterpret_cast<const GatePre *>(&reinterpret_cast<const TailSmem *>(strip_tail_smem(a.win))->tpose[0][0])[wave];
+                        sl.lm = pr.lm; sl.off = pr.off; sl.type = pr.type; sl.had = pr.had;
+                        sl.h_old[0] = pr.h_old[0]; sl.h_old[1] = pr.h_old[1]; sl.z[0] = pr.z[0]; sl.z[1] = pr.z[1];
+                    } else {
+                        const int i = cand[s + a.n_strips * (c0 + wave)] & 0xffff;
+                        sl.lm = i; sl.off = t.lm_off[i]; sl.type = t.lm_type[i]; sl.had = t.has_h[i];
+                        sl.h_old[0] = t.h[2 * i]; sl.h_old[1] = t.h[2 * i + 1]; sl.z[0] = t.z[2 * i]; sl.z[1] = t.z[2 * i + 1];
+                    }
+                }
+                wave_lds_sync();
+                item = -1;
+            }
+        } else {
+            for (; s + a.n_strips * j_other < t.N && item == -2; j_other += 8) {
+                const int i = s + a.n_strips * j_other;
+                if (!(t.lm_ic[i] == 1 && t.lm_li[i] == 0)) item = i;      // (a candidate is some strip's round's)
+            }
+            if (item == -2) break;
+        }
+        if (s == 1 && it == 0 && wave == 0 && lane == 0) CP_STAMP(23, 1, 0);
+        if (item != -2) gate_project(a, t, item, wave);
+        if (s == 1 && it == 0 && wave == 0 && lane == 0) CP_STAMP(23, 1, 1);
+        if (!cround) continue;
+        // ---- the round's slots: H J (the normalisation Jacobian of the LI update folded into the quaternion columns), nu,
+        //      q = (H J) P (H J)' from the 13 x 13 block of P (innovation_body's sum)
+        if (wave < n_round) {
+            GateSmem::Slot &sl = gs.slot[wave];
+            const int off = sl.off, d = sl.type == PRE3_INVDEPTH ? 6 : 3;
+            if (lane == 0) {
+                const double *Hc = sl.hc, *Hl = sl.hl, *zi = sl.zi;
+                double Jn[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) Jn[u] = ld_f64_sc1(a.params + 16 + u);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) sl.hjf[c][u] = (float)Hc[7 * c + u];
+                    const double *hq = Hc + 7 * c + 3;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) sl.hjf[c][3 + b] = (float)fma(hq[3], Jn[12 + b], fma(hq[2], Jn[8 + b], fma(hq[1], Jn[4 + b], hq[0] * Jn[b])));
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) sl.hjf[c][7 + u] = (float)Hl[6 * c + u];
+                    sl.hjf[c][13] = (float)(sl.z[c] - zi[c]);
+                    sl.hjf[c][14] = 0.f; sl.hjf[c][15] = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 13; ++u) sl.hj[c][u] = (double)sl.hjf[c][u];
+                }
+            }
+            wave_lds_sync();
+            double q00 = 0, q01 = 0, q11 = 0;
+            if (lane < 7 + d) {
+                const int ib = lane < 7 ? lane : off + lane - 7;
+                const unsigned rb = (unsigned)ib * (unsigned)a.ld * 4u, ob = (unsigned)off * 4u;
+                const f4v_t p0 = ld4f(rP, rb), p1 = ld4f(rP, rb + 16u), p2 = ld4f(rP, rb + ob), p3 = ld4f(rP, rb + ob + 16u);
+                const float pv[13] = { p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, p2.w, p3.x, p3.y };
+                double hp0 = 0, hp1 = 0;
+#pragma unroll
+                for (int u = 0; u < 13; ++u) { hp0 = fma((double)sl.hjf[0][u], (double)pv[u], hp0); hp1 = fma((double)sl.hjf[1][u], (double)pv[u], hp1); }
+                const double h0b = (double)sl.hjf[0][lane], h1b = (double)sl.hjf[1][lane];
+                q00 = hp0 * h0b; q01 = hp0 * h1b; q11 = hp1 * h1b;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { q00 += __shfl_xor(q00, o); q01 += __shfl_xor(q01, o); q11 += __shfl_xor(q11, o); }
+            if (lane == 0) { sl.q00 = q00; sl.q01 = q01; sl.q11 = q11; }
+        }
+        __syncthreads();
+        // ---- y = (H J) W' of the round's candidates over the LI update's rows, from the column-major copy of W: one or two waves per candidate, a
+        //      thread takes eight consecutive k of the landmark's 13 columns (26 loads in flight, all lines fully used) -- a granule of each plane of y
+        //      straight from registers; then y y' and the gate nu' inv(q - y y') nu < chi2 (no R: rescue_hi_inliers.m:39)
+        const int wpc = (nrb * 8 + 63) / 64, cpp = 8 / wpc;       // waves per candidate (nrb <= 16: one or two), candidates per pass
+        const __amdgpu_buffer_rsrc_t rWt = cp_rsrc(a.Wt);
+        for (int w0 = 0; w0 < n_round; w0 += cpp) {
+            const int cnd = wave / wpc, g = (wave - cnd * wpc) * 64 + lane;
+            const bool on = w0 + cnd < n_round && cnd < cpp, live = on && g < nrb * 8;
+            double sm_[3] = { 0, 0, 0 };
+            if (on) {
+                const GateSmem::Slot &sl = gs.slot[w0 + cnd];
+                if (live) {
+                    const int off = sl.off, i = sl.lm;
+                    f4v_t wv[13][2];
+#pragma unroll
+                    for (int u = 0; u < 13; ++u) {
+                        const unsigned cb = (unsigned)((u < 7 ? u : off + u - 7) * a.kcap + 8 * g) * 4u;
+                        wv[u][0] = ld4f_sc1(rWt, cb); wv[u][1] = ld4f_sc1(rWt, cb + 16u);
+                    }
+                    double a0[8], a1[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { a0[j] = 0; a1[j] = 0; }
+#pragma unroll
+                    for (int u = 0; u < 13; ++u) {
+                        const double h0 = sl.hj[0][u], h1 = sl.hj[1][u];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const double w = (double)(j < 4 ? wv[u][0][j] : wv[u][1][j - 4]);
+                            a0[j] = fma(h0, w, a0[j]); a1[j] = fma(h1, w, a1[j]);
+                        }
+                    }
+                    float y0[8], y1[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        y0[j] = (float)a0[j]; y1[j] = (float)a1[j];
+                        sm_[0] = fma((double)y0[j], (double)y0[j], sm_[0]); sm_[1] = fma((double)y0[j], (double)y1[j], sm_[1]); sm_[2] = fma((double)y1[j], (double)y1[j], sm_[2]);
+                    }
+                    u32x4_t pa, pb, pc;
+                    const unsigned g0 = (unsigned)(((i * 2 + 0) * 3) * t.ykcap + 8 * g) * 2u, pst = (unsigned)t.ykcap * 2u;
+                    b3_split3(y0, pa, pb, pc);
+                    st16_sc1(pa, rYp, g0); st16_sc1(pb, rYp, g0 + pst); st16_sc1(pc, rYp, g0 + 2u * pst);
+                    b3_split3(y1, pa, pb, pc);
+                    st16_sc1(pa, rYp, g0 + 3u * pst); st16_sc1(pb, rYp, g0 + 4u * pst); st16_sc1(pc, rYp, g0 + 5u * pst);
+                }
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    double x = sm_[v];
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+                    if (lane == 0) gs.part[wave][v] = x;
+                }
+            }
+            __syncthreads();
+            if (on && g == 0) {                                   // the gate (first lane of the candidate's first wave)
+                const GateSmem::Slot &sl = gs.slot[w0 + cnd];
+                double y00 = 0, y01 = 0, y11 = 0;
+                for (int v = 0; v < wpc; ++v) { y00 += gs.part[wave + v][0]; y01 += gs.part[wave + v][1]; y11 += gs.part[wave + v][2]; }
+                const double g00 = sl.q00 - y00, g01 = sl.q01 - y01, g11 = sl.q11 - y11;
+                const double det = g00 * g11 - g01 * g01;
+                const double i00 = g11 / det, i01 = -g01 / det, i11 = g00 / det;
+                const double nu0 = (double)sl.hjf[0][13], nu1 = (double)sl.hjf[1][13];
+                const double t0 = nu0 * i00 + nu1 * i01, t1 = nu0 * i01 + nu1 * i11;
+                const double d2 = t0 * nu0 + t1 * nu1;
+                st_i32_sc1(t.lm_hi + sl.lm, d2 < t.chi2 ? 1 : 0);
+#ifdef PRE3_TAIL_DEBUG
+                t.dbgS[4 * sl.lm + 0] = sl.q00; t.dbgS[4 * sl.lm + 1] = y00; t.dbgS[4 * sl.lm + 2] = sl.q11; t.dbgS[4 * sl.lm + 3] = y11;
+#endif
+            }
+            if (on && g >= 8 && g < 16) {                         // the rows of H J for the update: [c][0..12], [13] = nu
+                const GateSmem::Slot &sl = gs.slot[w0 + cnd];
+                const int c = (g - 8) >> 2, g4 = (g - 8) & 3;
+                st16_sc1(*reinterpret_cast<const u32x4_t *>(&sl.hjf[c][4 * g4]), rHb, (unsigned)((sl.lm * 2 + c) * 16 + 4 * g4) * 4u);
+            }
+            __syncthreads();
+        }
+        if (s == 1 && it == 0 && tid == 0) CP_STAMP(23, 1, 2);
+        if (it == n_rounds - 1) gate_flag();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// strip s: 32 columns of [HP | nu]
+// ------------------------------------------------------------------------------------------------------------------------------
+
+// (the tail's arguments reach a strip through LDS: sixty more argument registers live through the panel loop cost it a kilobyte of scratch)
+
+__device__ __attribute__((noinline)) void strip_tail_body(int nrb_v, int s_v, int rows_v);
+__device__ __attribute__((noinline)) void gate_prefetch(int rows_v, int s_v);
 
 __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int rows_v, int s_v)
 {
@@ -786,6 +1364,7 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
     // acc of wave (fa, par): this wave's share of  sum_K L(J, K) W_K - HP_J  for the step about to be solved (-HP_J rides with par 0; blocks
     // K = par (mod 4); the newest block K = J-1 is split by k-steps instead).  It is accumulated AHEAD of need: the terms K <= J-2 of step J
     // while the strip waits for M_{J-1}, the last term as soon as W_{J-1} exists -- when M_J arrives only one product and the epilogue are left.
+    if (a.tail) gate_prefetch(rows_v, s);                             // (table entries of the rescue gate's first round: see gate_prefetch)
     f32x16_t acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = par == 0 ? -ld_f32(rW, wvoff, acc_soff(e, a.ldw)) : 0.f;
@@ -898,7 +1477,14 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
             }
         }
         __syncthreads();
-        tile_to_planes(J, more, c0 < a.ld + NB);
+        if (a.tail) {
+            // W_J of these columns once more, column-major (four k of one column per thread): the rescue gate reads whole columns of W (y = H J W'),
+            // which in the row-major image are one 128-byte line per entry.  Drained with everything else in front of the strip's x flag.
+            const int col = tid & 31, kq = tid >> 5;
+            const f4v_t v = { Yw[(4 * kq) * CP_WS + col], Yw[(4 * kq + 1) * CP_WS + col], Yw[(4 * kq + 2) * CP_WS + col], Yw[(4 * kq + 3) * CP_WS + col] };
+            st16_sc1(__builtin_bit_cast(u32x4_t, v), cp_rsrc(a.Wt), (unsigned)((c0 + col) * a.kcap + J * NB + 4 * kq) * 4u);
+        }
+        tile_to_planes(J, more || a.tail != 0, c0 < a.ld + NB);          // (tail: the HI panel's right-hand side needs every block of W)
         __syncthreads();
         // W_J's planes of these 32 columns are out (every storing thread has drained): the consumers' flag
         if (tid == 0 && publish) cf_store(cf_strip(a.cf, s), a.base + (unsigned)J + 1);
@@ -929,10 +1515,13 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
     //      -> params, the quaternion normalised.  Sixteen chains (chain g: rows a = g mod 16, in order), summed 0 .. 15, x_prior last -- term for
     //      term the sums of update_x_block / k_update_x, so x_k_k is the same bits whichever of them ran.  W is this strip's own (its stores have
     //      drained); c = L^-1 nu is the nu strip's column, written through and read here behind that strip's last flag.
+    // (scratch of the x-updates: the plane slots when they are dead; with the tail they still feed the HI panel, and CP | Yw2 take it)
+    unsigned char *xs_base = a.tail ? reinterpret_cast<unsigned char *>(CP) : cp_smem;
     if (a.xu && c0 < a.ld) {
+        if (s == 1 && tid == 0) CP_STAMP(23, 2, 0);
         const int rows = __builtin_amdgcn_readfirstlane(rows_v);
-        float *cs = reinterpret_cast<float *>(cp_smem);                              // [nrb * 64]
-        double *red = reinterpret_cast<double *>(cp_smem + 4096);                    // [16][32]
+        float *cs = reinterpret_cast<float *>(xs_base);                              // [nrb * 64]
+        double *red = reinterpret_cast<double *>(xs_base + 4096);                    // [16][32]
         double *qs = red + 16 * 32;
         __syncthreads();                                                             // (the plane slots are dead)
         wg_wait(cf_strip(a.cf, a.ld / 32), a.base + (unsigned)nrb, guard);
@@ -954,10 +1543,255 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
         if (s == 0) {                                                                // (strip-uniform: every thread reaches the barrier)
             if (rg == 0 && i >= 3 && i < 7) qs[i - 3] = sx;
             __syncthreads();
-            if (rg == 0 && i == 0) { double Jn[16]; d_normjac(qs, Jn); for (int t = 0; t < 16; ++t) { a.params[16 + t] = Jn[t]; a.params[96 + t] = Jn[t]; } }
+            if (rg == 0 && i == 0) { double Jn[16]; d_normjac(qs, Jn); for (int t = 0; t < 16; ++t) { st_f64_sc1(a.params + 16 + t, Jn[t]); st_f64_sc1(a.params + 96 + t, Jn[t]); } }
             if (rg == 0 && i >= 3 && i < 7) sx = sx / sqrt(qs[0] * qs[0] + qs[1] * qs[1] + qs[2] * qs[2] + qs[3] * qs[3]);
         }
-        if (rg == 0 && i < a.n) a.x_out[i] = sx;
+        if (rg == 0 && i < a.n) st_f64_sc1(a.x_out + i, sx);
+        if (a.tail) {
+            // x_k_k of these 32 states (and, from strip 0, the normalisation Jacobian) is out: the gate's waves wait for this value
+            drain_stores();
+            __syncthreads();
+            if (tid == 0) cf_store(cf_strip(a.cf, s), a.base + CFV_X);
+            if (s == 1 && tid == 0) CP_STAMP(23, 2, 1);
+        }
+    }
+    if (a.tail) strip_tail_body(nrb, s, rows_v);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// strip s behind its x-update, when the launch carries the tail (CpTail): (B) its landmarks are projected and gated; (C) crit's list; (D) the rescued
+// landmarks' rows as panel nrb: W~ = M_hi ((H J) P - Y_hi W) for its 32 columns, then the HI update's x.  Out of line and with the launch arguments
+// from LDS, so that nothing of it is live in the panel loop of strip_body.
+// ------------------------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((noinline)) void strip_tail_body(int nrb_v, int s_v, int rows_v)
+{
+    const CpArgs a = args_from_lds<CpArgs>(CP_TA_OFF);
+    const int nrb = __builtin_amdgcn_readfirstlane(nrb_v), s = __builtin_amdgcn_readfirstlane(s_v);
+    extern __shared__ __attribute__((aligned(16))) unsigned char cp_smem[];
+    const int win = a.win;
+    frag_t *WPl = reinterpret_cast<frag_t *>(cp_smem);
+    frag_t *CP = WPl + (size_t)win * CP_WGRAN;
+    float *Yw = reinterpret_cast<float *>(CP);
+    float *Yw2 = reinterpret_cast<float *>(CP + CP_WGRAN);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int fa = wave & 1, par = wave >> 1;
+    const int c0 = s * 32, lcol = lane & 31;
+    const bool nu_strip = c0 == a.ld;
+    int32_t *guard = a.status + 1;
+    const __amdgpu_buffer_rsrc_t rW = cp_rsrc(a.W), rSp = cp_rsrc(a.Sp), rWp = cp_rsrc(a.Wp);
+    const unsigned wvoff = acc_voff(lane, a.ldw) + (unsigned)((32 * fa) * a.ldw + c0) * 4u;
+    const unsigned plo = (unsigned)(fa * 64 + lane) * 16u;
+    float *yrow = Yw + (32 * fa) * CP_WS + lcol, *yrow2 = Yw2 + (32 * fa) * CP_WS + lcol;
+    unsigned char *xs_base = reinterpret_cast<unsigned char *>(CP);
+    f32x16_t acc;
+    // (reduce4 / tile_to_planes: as in strip_body)
+    auto reduce4 = [&](f32x16_t &v) {
+        if (par == 1) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) yrow[acc_row(e, lane) * CP_WS] = v[e];
+        } else if (par == 3) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) yrow2[acc_row(e, lane) * CP_WS] = v[e];
+        }
+        __syncthreads();
+        if (par == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] += yrow[acc_row(e, lane) * CP_WS];
+        } else if (par == 2) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] += yrow2[acc_row(e, lane) * CP_WS];
+        }
+        __syncthreads();
+        if (par == 2) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) yrow[acc_row(e, lane) * CP_WS] = v[e];
+        }
+        __syncthreads();
+        if (par == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] += yrow[acc_row(e, lane) * CP_WS];
+        }
+    };
+    auto tile_to_planes = [&](int J, bool, bool to_wp) {
+        const int q = (tid >> 6) & 3, l = tid & 63, col = l & 31, h = l >> 5;
+        u32x4_t p0, p1, p2;
+        if (tid < 256) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = Yw[(16 * q + 8 * h + j) * CP_WS + col];
+            b3_split3(x, p0, p1, p2);
+        }
+        __syncthreads();
+        if (tid < 256) {
+            if (!to_wp) {
+                CP[q * 192 + l] = __builtin_bit_cast(frag_t, p0); CP[q * 192 + 64 + l] = __builtin_bit_cast(frag_t, p1); CP[q * 192 + 128 + l] = __builtin_bit_cast(frag_t, p2);
+            } else {
+                const unsigned gb = (unsigned)((((size_t)(c0 >> 7) * a.nst_total + 4 * J + q) * B3_GRAN + ((c0 >> 5) & 3) * 64 + l) * 16u);
+                st16_sc1(p0, rWp, gb); st16_sc1(p1, rWp, gb + 256 * 16); st16_sc1(p2, rWp, gb + 512 * 16);
+                drain_stores();
+            }
+        }
+    };
+    const CpTail t = args_from_lds<CpTail>(CP_T_OFF);
+    if (s == 1 && tid == 0) CP_STAMP(23, 0, 0);
+    tail_gate_body(a, t, nrb, s, __builtin_amdgcn_readfirstlane(rows_v));      // (stores the strip's gate flag)
+    __syncthreads();
+    if (s == 1 && tid == 0) CP_STAMP(23, 0, 1);
+    wg_wait(a.cf + CF_HI, a.base + CFV_HIL, guard);
+    if (s == 1 && tid == 0) CP_STAMP(23, 0, 2);
+    const int r_hi = __builtin_amdgcn_readfirstlane(ld_i32_sc1(reinterpret_cast<const int32_t *>(a.cf + CF_HI + 1)));
+    if (r_hi == 0) return;                                       // (nothing rescued, or too much for one panel: params[96..] holds the LI update's Jacobian)
+    const int J = nrb;
+    TailSmem &ts = *reinterpret_cast<TailSmem *>(strip_tail_smem(win));
+    {
+        const __amdgpu_buffer_rsrc_t rHib = cp_rsrc(t.hib);
+        if (tid < NB * 4) *reinterpret_cast<u32x4_t *>(&ts.rv[tid >> 2][4 * (tid & 3)]) = ld16_sc1(rHib, (unsigned)(64 + (tid >> 2) * 16 + 4 * (tid & 3)) * 4u);
+        else if (tid < NB * 4 + HT_MAXL) {
+            const int l = tid - NB * 4;
+            int lm = t.N, off = 0, d = 0;
+            if (2 * l < r_hi) { lm = ld_i32_sc1(t.hib + 4 + l); off = t.lm_off[lm]; d = t.lm_type[lm] == PRE3_INVDEPTH ? 6 : 3; }
+            ts.lm[l] = lm; ts.off[l] = off; ts.d[l] = d;
+        }
+    }
+    __syncthreads();
+    // (D1) this wave's share of  sum_K Y_hi(:, K) W_K - (H J P)(:, these columns):  the 13 terms of the raw row are dealt over the four par groups,
+    //      the blocks of W as in the panels.  The nu column is the new innovation z - h(x_k_k) itself: nothing of the LI update's is subtracted.
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = 32 * fa + acc_row(e, lane);
+        float v = 0.f;
+        if (nu_strip) { if (par == 0 && lcol == 0) v = ts.rv[row][13]; }
+        else if (c0 + lcol < a.ld) {
+            const float *rv = ts.rv[row];
+            const int lo = ts.off[row >> 1];
+            for (int u = par; u < 13; u += 4) v = fmaf(rv[u], a.P[(size_t)(u < 7 ? u : lo + u - 7) * a.ld + c0 + lcol], v);
+        }
+        acc[e] = -v;
+    }
+#define ST_MMA(fa_, bb) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa_), __builtin_bit_cast(bf16x8_t, bb), acc, 0, 0, 0)
+    if (c0 < a.ld) {
+        const int ra = 32 * fa + (lane & 31);
+        const __amdgpu_buffer_rsrc_t rY = cp_rsrc(t.Yp);
+        const unsigned va = yp_voff(ra < r_hi ? ts.lm[ra >> 1] : t.N, ra & 1, lane >> 5, t.ykcap);
+        const unsigned wlane = (unsigned)lane * 16u;
+        const unsigned wbase = (unsigned)(((size_t)(c0 >> 7) * a.nst_total) * B3_GRAN + ((c0 >> 5) & 3) * 64);
+        for (int K = par; K < nrb; K += 4) {
+            frag_t f0[4][3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) f0[q][pl] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rY, va, yp_soff(pl, K, q, t.ykcap), 16));
+            if (K < nrb - win) {                                 // (left the ring: this strip's own write-through planes)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const frag_t b0 = ld_granule(rWp, wlane, wbase + (unsigned)(4 * K + q) * B3_GRAN, 1), b1 = ld_granule(rWp, wlane, wbase + (unsigned)(4 * K + q) * B3_GRAN + 256, 1),
+                                 b2 = ld_granule(rWp, wlane, wbase + (unsigned)(4 * K + q) * B3_GRAN + 512, 1);
+                    ST_MMA(f0[q][0], b0); ST_MMA(f0[q][0], b1); ST_MMA(f0[q][1], b0); ST_MMA(f0[q][1], b1); ST_MMA(f0[q][0], b2); ST_MMA(f0[q][2], b0);
+                }
+            } else {
+                const frag_t *wb = WPl + (size_t)(K % win) * CP_WGRAN + lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const frag_t b0 = wb[q * 192], b1 = wb[q * 192 + 64], b2 = wb[q * 192 + 128];
+                    ST_MMA(f0[q][0], b0); ST_MMA(f0[q][0], b1); ST_MMA(f0[q][1], b0); ST_MMA(f0[q][1], b1); ST_MMA(f0[q][0], b2); ST_MMA(f0[q][2], b0);
+                }
+            }
+        }
+    }
+#undef ST_MMA
+    // (D2) C_hi as planes, then W~ = M_hi C_hi once crit has published M_hi (the panel loop's (1) and (3))
+    if (s == 1 && tid == 0) CP_STAMP(23, 0, 3);
+    reduce4(acc);
+    __syncthreads();
+    if (par == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) yrow[acc_row(e, lane) * CP_WS] = -acc[e];
+    }
+    __syncthreads();
+    tile_to_planes(J, false, false);
+    wg_wait(a.cf + CF_MP, a.base + (unsigned)J + 1, guard);
+    if (s == 1 && tid == 0) CP_STAMP(23, 0, 4);
+    f32x16_t wacc;
+    {
+        frag_t fM[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) fM[pl] = ld_granule(rSp, plo, (unsigned)(J * a.sp_stride + J) * B3_SGRAN + par * 384 + pl * 128, 1);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) wacc[e] = 0.f;
+        const frag_t b0 = CP[par * 192 + lane], b1 = CP[par * 192 + 64 + lane], b2 = CP[par * 192 + 128 + lane];
+#define SM_MMA(px, bb) wacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fM[px]), __builtin_bit_cast(bf16x8_t, bb), wacc, 0, 0, 0)
+        SM_MMA(0, b0); SM_MMA(0, b1); SM_MMA(1, b0); SM_MMA(1, b1); SM_MMA(0, b2); SM_MMA(2, b0);
+#undef SM_MMA
+    }
+    __syncthreads();
+    reduce4(wacc);
+    __syncthreads();
+    if (par == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            yrow[acc_row(e, lane) * CP_WS] = wacc[e];
+            if (nu_strip) st_f32_sc1(wacc[e], rW, wvoff, (unsigned)(J * NB * a.ldw) * 4u + acc_soff(e, a.ldw));
+            else st_f32(wacc[e], rW, wvoff, (unsigned)(J * NB * a.ldw) * 4u + acc_soff(e, a.ldw));
+        }
+    }
+    __syncthreads();
+    tile_to_planes(J, false, c0 < a.ld + NB);
+    __syncthreads();
+    if (tid == 0) cf_store(cf_strip(a.cf, s), a.base + CFV_HIW);   // the consumers' panel nrb
+    if (s == 1 && tid == 0) CP_STAMP(23, 0, 5);
+    // (D3) update.m:36,42,48 of the HI update for these 32 states: x += J W~'(L_hi^-1 nu) (W~ lacks the J' of the LI update's normalisation on its
+    //      quaternion columns: the down-date carries it as a pending pass, the state takes it here); then this update's own Jacobian J2, and what is
+    //      left of update.m:42-46 for both updates is rows / columns 3..6 <- (J2 J) . : params[96..] (and [16..] for k_jnorm_P)
+    if (c0 < a.ld) {
+        float *cs = reinterpret_cast<float *>(xs_base);
+        double *red = reinterpret_cast<double *>(xs_base + 4096);
+        double *qs = red + 16 * 32;
+        __syncthreads();
+        wg_wait(cf_strip(a.cf, a.ld / 32), a.base + CFV_HIW, guard);
+        if (tid < NB) cs[tid] = ld_f32_sc1(rW, (unsigned)((J * NB + tid) * a.ldw + a.ld) * 4u, 0);
+        __syncthreads();
+        const int ci = tid & 31, rg = tid >> 5, i = c0 + ci;
+        const float *Wc = a.W + (size_t)(J * NB) * a.ldw + i;
+        double sx = 0;
+#pragma unroll
+        for (int k = 0; k < NB / 16; ++k) sx = fma((double)Wc[(size_t)(rg + 16 * k) * a.ldw], (double)cs[rg + 16 * k], sx);
+        red[rg * 32 + ci] = sx;
+        __syncthreads();
+        sx = 0;
+        if (rg == 0) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) sx += red[g * 32 + ci];
+        }
+        const bool quat = rg == 0 && i >= 3 && i < 7;
+        double J1[16];
+        if (s == 0) {
+            if (quat) qs[i - 3] = sx;
+            __syncthreads();
+            if (rg == 0 && (quat || i == 0)) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) J1[u] = ld_f64_sc1(a.params + 16 + u);
+            }
+            if (quat) sx = fma(J1[(i - 3) * 4 + 3], qs[3], fma(J1[(i - 3) * 4 + 2], qs[2], fma(J1[(i - 3) * 4 + 1], qs[1], J1[(i - 3) * 4] * qs[0])));
+            __syncthreads();
+        }
+        double xv = 0;
+        if (rg == 0 && i < a.n) xv = ld_f64_sc1(a.x_out + i) + sx;
+        if (s == 0) {
+            if (quat) qs[i - 3] = xv;
+            __syncthreads();
+            if (rg == 0 && i == 0) {
+                double J2[16];
+                d_normjac(qs, J2);
+                for (int r1 = 0; r1 < 4; ++r1)
+                    for (int c1 = 0; c1 < 4; ++c1) {
+                        const double v = fma(J2[r1 * 4 + 3], J1[12 + c1], fma(J2[r1 * 4 + 2], J1[8 + c1], fma(J2[r1 * 4 + 1], J1[4 + c1], J2[r1 * 4] * J1[c1])));
+                        a.params[96 + r1 * 4 + c1] = v; a.params[16 + r1 * 4 + c1] = v;
+                    }
+            }
+            if (quat) xv = xv / sqrt(qs[0] * qs[0] + qs[1] * qs[1] + qs[2] * qs[2] + qs[3] * qs[3]);
+        }
+        if (rg == 0 && i < a.n) a.x_out[i] = xv;
+        if (s == 1 && tid == 0) CP_STAMP(23, 0, 6);
     }
 }
 
@@ -1035,10 +1869,25 @@ __device__ __attribute__((noinline)) void dd_body(CpArgs a_v, int nrb_v, int row
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const frag_t *Wp = static_cast<const frag_t *>(a.Wp);
     const int j_last = (nst_real + 3) / 4 - 1;                  // the last panel that holds real rows
-    for (int J = 0; J < nrb; ++J) {
+    for (int J = 0; J <= nrb; ++J) {
         int ns = nst_real - 4 * J;
         ns = ns > 4 ? 4 : ns;
-        if (ns <= 0) break;
+        if (J < nrb) { if (ns <= 0) continue; }
+        else {
+            // panel nrb: the rescued landmarks' rows, if the tail brings any (crit's word says how many once the gate has run)
+            if (!a.tail) break;
+            int r_hi = 0;
+            if (wave == 0) {
+                if (lane == 0) cf_wait(a.cf + CF_HI, a.base + CFV_HIL, guard);
+                r_hi = ld_i32_sc1(reinterpret_cast<const int32_t *>(a.cf + CF_HI + 1));
+                if (lane == 0) *reinterpret_cast<volatile int *>(ops + 4 * DG_SLOTS * DG_SLOT_GRAN) = r_hi;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+            r_hi = U(*reinterpret_cast<volatile int *>(ops + 4 * DG_SLOTS * DG_SLOT_GRAN));
+            ns = (r_hi + B3_BK - 1) / B3_BK;
+            if (ns <= 0) break;
+        }
         if (J == j_last && (a.dd_mode & 4)) {
             // While the strips finish the last panel: this wave's tile of P is pulled towards the XCD's L2 (sixteen LDS-DMA requests into a 1 KB
             // scratch line behind the operand slots, contents ignored), so that the epilogue's read of P -- all consumers at once, behind the last
@@ -1054,7 +1903,7 @@ __device__ __attribute__((noinline)) void dd_body(CpArgs a_v, int nrb_v, int row
             const int nfl = 2 * nslots;
             bool gave_up = true;
             for (int spin = 0; spin < SPIN_LIMIT; ++spin) {
-                const bool ok = lane >= nfl || cf_reached(cf_load(fp), a.base + (unsigned)J + 1);
+                const bool ok = lane >= nfl || cf_reached(cf_load(fp), a.base + (J < nrb ? (unsigned)J + 1 : CFV_HIW));
                 if (__all(ok)) { gave_up = false; break; }
                 if ((spin & 1023) == 1023 && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { gave_up = false; break; }
                 __builtin_amdgcn_s_sleep(4);
@@ -1164,7 +2013,7 @@ __device__ __attribute__((noinline)) void dd_body(CpArgs a_v, int nrb_v, int row
     if (tid == 0 && (g == 0 || g == a.n_dd - 1)) CP_STAMP(g == 0 ? 20 : 21, 15, 1);
 }
 
-__global__ __launch_bounds__(CP_NTH) void k_cholp(CpArgs a)
+__global__ __launch_bounds__(CP_NTH) void k_cholp(CpArgs a, CpTail t)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char cp_smem[];
     int nrb = a.nrb, rows = a.rows;
@@ -1180,6 +2029,11 @@ __global__ __launch_bounds__(CP_NTH) void k_cholp(CpArgs a)
     // bulk operands (each L(k, J) is wanted by every row below k) and the hand-offs with crit are then served by that L2.  Placement is a
     // speed assumption only: every hand-off is valid for any placement.  Every other block is a strip.
     const int b = blockIdx.x, nH = a.nrb_max > 2 ? a.nrb_max - 2 : 0, stride = a.stride;
+    if (a.tail) {
+        // the tail's code (crit, strips) takes the launch arguments from LDS; it reads them behind many barriers of its own role
+        if (threadIdx.x < sizeof(CpTail) / 4) reinterpret_cast<unsigned *>(cp_smem + CP_T_OFF)[threadIdx.x] = reinterpret_cast<const unsigned *>(&t)[threadIdx.x];
+        if (threadIdx.x >= 128 && threadIdx.x < 128 + sizeof(CpArgs) / 4) reinterpret_cast<unsigned *>(cp_smem + CP_TA_OFF)[threadIdx.x - 128] = reinterpret_cast<const unsigned *>(&a)[threadIdx.x - 128];
+    }
 #ifndef CP_TEST_ROLE
 #define CP_TEST_ROLE 15
 #endif
@@ -1193,7 +2047,10 @@ __global__ __launch_bounds__(CP_NTH) void k_cholp(CpArgs a)
     const int sidx = b - (b / stride < nH ? b / stride + 1 : nH + 1);
     if (sidx < a.n_strips) {
         if (threadIdx.x >= 512) return;                         // strips are eight waves
-        if (CP_TEST_ROLE & 4) strip_body(a, nrb, rows, sidx);
+        // every strip's x-update waits for the strip that owns column ld (L^-1 nu): it takes the lowest block index of the strips, so that the one
+        // workgroup all the others wait for is dispatched in front of them
+        const int s_nu = a.ld / 32, s_col = sidx == 0 ? s_nu : sidx == s_nu ? 0 : sidx;
+        if (CP_TEST_ROLE & 4) strip_body(a, nrb, rows, s_col);
     } else if (sidx - a.n_strips < a.n_dd) {
         if (CP_TEST_ROLE & 8) dd_body(a, nrb, rows, sidx - a.n_strips);
     }
@@ -1337,7 +2194,17 @@ void cholp_timing_rows(pre3_ctx *c, int r)
 }
 
 // nrb < 0: the row count is read on the device (stats[4]); nrb_max bounds the grid and the LDS.  rows: the real row count when nrb >= 0.
-int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior)
+// Can the launch about to go out (LI update of a step, row count on the device) also carry the rescue stage and the HI update?  It needs the
+// consumers to hold every tile of P (P is then written once, behind the HI panel), the strips' x-update, one panel of room behind the LI
+// update's, and the tail's buffers.
+bool cholp_tail_usable(const pre3_ctx *c, int nrb_max)
+{
+    if ( !c->tail_yp || !c->tail_hb || !c->tail_hib || !c->tail_wt || c->N <= 0 || c->N > 65535 || c->m <= 0 || c->m > 16384) return false;
+    if (nrb_max + 1 > c->rcap / NB || nrb_max + 1 > CP_MAX_NRB + 1) return false;
+    return true;
+}
+
+int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior, const CholpTailReq *tail_req)
 {
     const int n_strips = c->ldw / 32;
     const int nH = nrb_max > 2 ? nrb_max - 2 : 0;
@@ -1362,6 +2229,15 @@ int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior)
         if (n_dd < 0 || std::max(1 + nH + n_strips + n_dd, stride * nH + 1) > c->num_cus) n_dd = 0;
     }
     if (n_dd > 0) lds = std::max(lds, (size_t)4 * DG_SLOTS * DG_SLOT_GRAN * 16 + 12 * 1024);      // operand slots + one scratch line per wave (P warm-up)
+    // the tail (rescue stage + HI update inside this launch): every group of P's tiles must be in the launch, the strips do the x-update, the row
+    // count is the device's (the speculative launch of a step)
+    static const int xu_env0 = getenv("PRE3_CHOLP_XU") ? atoi(getenv("PRE3_CHOLP_XU")) : 1;
+    const bool tail = tail_req != nullptr && nrb < 0 && n_dd > 0 && n_dd == c->dd_n_groups && xu_env0 && which_prior == PRE3_X_K_KM1 && cholp_tail_usable(c, nrb_max);
+    if (tail) {
+        const size_t strip_tail = ((size_t)(win + 1) * CP_WGRAN * 16 + (size_t)NB * CP_WS * sizeof(float) + 127) / 128 * 128 + sizeof(TailSmem);
+        PRE3_CHECK(strip_tail <= CP_T_OFF && CP_TAIL_OFF + sizeof(TailSmem) <= CP_T_OFF, PRE3_E_ARG, "launch_cholp: the tail's LDS does not fit");
+        lds = 160 * 1024;
+    }
     static std::atomic<unsigned long long> attr_set{ 0 };        // one bit per device
     if (c->device >= 0 && c->device < 64 && !((attr_set.load() >> c->device) & 1ull)) {
         PRE3_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cholp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1389,6 +2265,21 @@ int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior)
     a.xu = (xu_env && n_dd > 0 && which_prior >= 0) ? 1 : 0;
     a.n = c->n; a.x_prior = which_prior == PRE3_X_K_K ? c->x_kk : c->x_km1; a.x_out = c->x_kk; a.params = c->pred_params;
     a.P = (float *)c->P; a.dd = c->dd_groups; a.n_dd = n_dd; a.rows = nrb < 0 ? nrb_max * NB : (rows > 0 && rows <= nrb * NB ? rows : nrb * NB);
+    CpTail t{};
+    a.tail = tail ? 1 : 0;
+    if (tail) {
+        t.on = 1; t.N = c->N; t.m = c->m; t.seq = tail_req->seq; t.ykcap = c->rcap; t.chi2 = tail_req->chi2;
+        t.lm_type = c->lm.type; t.lm_off = c->lm.off; t.lm_ic = c->lm.ic; t.lm_li = c->lm.li; t.meas = c->meas;
+        t.lm_hi = c->lm.hi; t.has_h = c->lm.has_h; t.hi_meas = c->hi_meas; t.sel_rows = c->sel_rows; t.stats = c->stats; t.mail = c->mail_dev;
+        t.h = c->lm.h; t.Hc = c->lm.Hc; t.Hl = c->lm.Hl; t.z = c->lm.z;
+        t.cam = CamD{ c->cam.f, c->cam.Cx, c->cam.Cy, c->cam.k1, c->cam.k2, (double)c->cam.nRows, (double)c->cam.nCols };
+        t.Yp = c->tail_yp; t.Hb = c->tail_hb; t.hib = c->tail_hib;
+        a.Wt = c->tail_wt; a.kcap = c->rcap;
+#ifdef PRE3_TAIL_DEBUG
+        t.dbgS = c->lm.S;
+#endif
+    }
+    c->tail_launched = tail;
     // roofline bracket (pre3_kernel_timing): the launches that carry a matrix-bound down-date -- updates of the predicted state
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = c->kt.enabled && n_dd > 0 && which_prior == PRE3_X_K_KM1 && (nrb < 0 || nrb >= 2) && (c->kt.seen++ % c->kt.every) == 0;
@@ -1400,7 +2291,7 @@ int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior)
         c->kt.used += 2;
         PRE3_HIP(hipEventRecord(e0, c->stream));
     }
-    hipLaunchKernelGGL(k_cholp, dim3(std::max(1 + nH + n_strips + n_dd, stride * nH + 1)), dim3(CP_NTH), lds, c->stream, a);
+    hipLaunchKernelGGL(k_cholp, dim3(std::max(1 + nH + n_strips + n_dd, stride * nH + 1)), dim3(CP_NTH), lds, c->stream, a, t);
     if (timed) {
         PRE3_HIP(hipEventRecord(e1, c->stream));
         c->kt.fused += 1;

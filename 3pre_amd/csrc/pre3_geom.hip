@@ -674,6 +674,9 @@ __device__ __forceinline__ void select_body(int n_draw, int k, int early_exit, i
         int pre = s_base;
         for (int w2 = 0; w2 < wv && w2 < 4; ++w2) pre += s_wcnt[w2];
         if (in) sel_rows[pre + __popcll(bal & ((1ull << lane) - 1ull))] = j;
+        // the measurements that are NOT low-innovation inliers, as landmarks, in measurement order behind the list's first m entries: the rescue
+        // stage's candidates (rescue_hi_inliers.m:36) -- the persistent launch's strips deal them out by rank (pre3_cholp.hip, tail_gate_body)
+        else if (act && j < m) sel_rows[m + j - (pre + __popcll(bal & ((1ull << lane) - 1ull)))] = (j << 16) | (meas[j] & 0xffff);      // (measurement | landmark: the tail is off beyond 65535 landmarks)
         __syncthreads();
         if (tid == 0) s_base += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
         __syncthreads();

@@ -69,13 +69,11 @@ __device__ inline void d_ray(int type, const double *y, const double *t, double 
 // ------------------------------------------------------------------------------------------------
 // K2 project + Jacobian of one landmark (predict_camera_measurements.m:27-68, calculate_Hi_*_my_version.m)
 // ------------------------------------------------------------------------------------------------
-__device__ inline void project_one(const int i, const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
-                            const double *__restrict__ x, const CamD &cam, int clear_first,
-                            double *__restrict__ h, int32_t *__restrict__ has_h, double *__restrict__ Hc, double *__restrict__ Hl,
-                            const double *__restrict__ x_lm = nullptr /* the landmark part of the state, if it lives in another vector */)
+// project_core: the arithmetic, on a pose x[0..6] and the landmark's own entries y[0..5]; outputs in the caller's arrays (hc_out [14], hl_out [12]).
+// had / h_old: a prediction kept from before (quirk Q7).  Returns "has a prediction now"; zi = the prediction the Jacobian was taken at; fresh = it is new.
+__device__ inline bool project_core(const int type, const double *__restrict__ x, const double *__restrict__ y, const CamD &cam, const int had, const double *h_old,
+                                    double *zi, bool &fresh, double *__restrict__ hc_out, double *__restrict__ hl_out)
 {
-    int type = lm_type[i];
-    const double *y = (x_lm ? x_lm : x) + lm_off[i];
     double Rwc[9];
     d_q2r(x + 3, Rwc);
     double v[3], hrl[3];
@@ -90,13 +88,11 @@ __device__ inline void project_one(const int i, const int32_t *__restrict__ lm_t
         d_pinhole_distort(hrl, cam, uvd);
         ok = (uvd[0] > 0) && (uvd[0] < cam.nCols) && (uvd[1] > 0) && (uvd[1] < cam.nRows);
     }
-    int had = clear_first ? 0 : has_h[i];
-    double zi[2];
-    if (ok) { zi[0] = uvd[0]; zi[1] = uvd[1]; h[2 * i] = zi[0]; h[2 * i + 1] = zi[1]; }
-    else if (had) { zi[0] = h[2 * i]; zi[1] = h[2 * i + 1]; }      // stale h kept (quirk Q7)
-    int now = ok || had;
-    has_h[i] = now;
-    if (!now) return;
+    fresh = ok;
+    if (ok) { zi[0] = uvd[0]; zi[1] = uvd[1]; }
+    else if (had) { zi[0] = h_old[0]; zi[1] = h_old[1]; }          // stale h kept (quirk Q7)
+    const bool now = ok || had;
+    if (!now) return false;
     // ---- Jacobian (calculate_Hi_*_my_version.m); distortion Jacobian at the stored h (quirk Q8)
     double u_ = zi[0], v_ = zi[1];
     double xx = u_ - cam.Cx, yy = v_ - cam.Cy, f2 = cam.f * cam.f;
@@ -112,7 +108,6 @@ __device__ inline void project_one(const int i, const int32_t *__restrict__ lm_t
     double Rrw[9];
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rrw[r * 3 + c] = Rwc[c * 3 + r];
     double sc = (type == PRE3_INVDEPTH) ? y[5] : 1.0;
-    double *hc_out = Hc + 14 * i, *hl_out = Hl + 12 * i;
     // dh_drw = A * (-Rrw*rho)
     for (int r = 0; r < 2; ++r)
         for (int c = 0; c < 3; ++c)
@@ -148,6 +143,23 @@ __device__ inline void project_one(const int i, const int32_t *__restrict__ lm_t
     } else {
         for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) hl_out[r * 6 + c] = A[r * 3] * Rrw[c] + A[r * 3 + 1] * Rrw[3 + c] + A[r * 3 + 2] * Rrw[6 + c];
     }
+    return true;
+}
+
+__device__ inline void project_one(const int i, const int32_t *__restrict__ lm_type, const int32_t *__restrict__ lm_off,
+                            const double *__restrict__ x, const CamD &cam, int clear_first,
+                            double *__restrict__ h, int32_t *__restrict__ has_h, double *__restrict__ Hc, double *__restrict__ Hl,
+                            const double *__restrict__ x_lm = nullptr /* the landmark part of the state, if it lives in another vector */)
+{
+    const double *y = (x_lm ? x_lm : x) + lm_off[i];
+    const int had = clear_first ? 0 : has_h[i];
+    double h_old[2] = { 0, 0 };
+    if (had) { h_old[0] = h[2 * i]; h_old[1] = h[2 * i + 1]; }
+    double zi[2] = { 0, 0 };
+    bool fresh = false;
+    const bool now = project_core(lm_type[i], x, y, cam, had, h_old, zi, fresh, Hc + 14 * i, Hl + 12 * i);
+    if (fresh) { h[2 * i] = zi[0]; h[2 * i + 1] = zi[1]; }
+    has_h[i] = now ? 1 : 0;
 }
 
 

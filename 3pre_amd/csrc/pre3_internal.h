@@ -185,6 +185,13 @@ struct pre3_ctx {
     bool proj_with_jnorm = false;                 // the rescue's projection rides in the next k_jnorm_P launch (no K9 launch to carry it)
     int dd_done = 0;                              // groups the last k_cholp launch has down-dated (consumed by the next launch_downdate)
     bool hp_all_valid = false;                    // HP / G hold H*P, H*P*H' of ALL measured rows at the current prior (ransac_prepare)
+    // the rescue stage + HI update inside the persistent launch (pre3_cholp.hip, CpTail): per landmark the planes of y = H J W' and the row H J;
+    // crit's published list
+    void *tail_yp = nullptr; float *tail_hb = nullptr; int32_t *tail_hib = nullptr; float *tail_wt = nullptr;
+    bool step_tail = false;                       // PRE3_OPT_STEP_TAIL (default: the environment's PRE3_TAIL, else off)
+    bool tail_want = false; double tail_chi2 = 0;  // pre3_step asks the LI update's launch to carry the tail
+    bool tail_launched = false;                   // the last launch_cholp carried it
+    bool tail_done = false;                       // ... and it ran (the LI update had rows): P holds P - W'W - W~'W~ with ONE pending rows/cols 3..6 pass (params[96..])
 };
 
 namespace pre3 {

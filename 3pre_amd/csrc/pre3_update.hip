@@ -1832,6 +1832,13 @@ int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_d
     }
     // (a stateless update that wants K' back keeps the x-update where it was)
     PRE3_TRY(launch_chol_solve(c, r_pad, first_done, which_prior == PRE3_X_K_KM1, r, which_prior));
+    if (c->tail_done && first_done && which_prior == PRE3_X_K_KM1) {
+        // the speculative persistent launch has carried everything: factorisation, solve, x-update, rescue stage, the HI update of up to 32
+        // landmarks, and ONE down-date of P for both updates (pre3_cholp.hip, CpTail).  The rows / columns 3..6 pass that is left
+        // (update.m:42-46 of both updates, params[96..]) is pre3_update_hi's to schedule, once it knows how the rescue stage ended.
+        c->dd_done = 0; c->x_done = false; c->split_rows = 0; c->ride_rescue_projection = false; c->proj_with_jnorm = false;
+        return PRE3_OK;
+    }
     PRE3_TRY(launch_downdate(c, r, c->W, which_prior));
     // update.m:42-46.  leave_jn_to_predict (pre3_step completing the previous step's HI update): the prediction's launch that follows carries it
     if (c->leave_jn_to_predict && !Kt_out_dev && !c->proj_with_jnorm) c->jn_pending = true;

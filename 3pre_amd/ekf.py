@@ -128,6 +128,16 @@ class EkfFilter:
         check(lib.pre3_get_option(self._ctx, 5, C.byref(v)))
         return bool(v.value)
 
+    def step_tail(self, on=None):
+        """PRE3_OPT_STEP_TAIL (fp32 contexts): rescue_hi_inliers + ekf_update_hi_inliers (up to 32 landmarks) inside the LI update's persistent
+        launch, P swept once per step; off (default: measured no faster on MI355X): as launches of their own behind it.  Same inlier sets, x / P equal to fp32 rounding.
+        Returns the setting in force."""
+        if on is not None:
+            check(lib.pre3_set_option(self._ctx, 6, int(bool(on))))
+        v = C.c_int(0)
+        check(lib.pre3_get_option(self._ctx, 6, C.byref(v)))
+        return bool(v.value)
+
     # ---- map management between steps (map_management.m:27-79); the policy stays with the caller
     def _refresh_map(self):
         self.N = int(lib.pre3_get_map(self._ctx, None))

@@ -211,6 +211,15 @@ PRE3_API int pre3_update_ell(int device, int dtype, int n, int r, const double *
  * launch leaves idle (as many tile groups as there are CUs left; the rest, if any, in the launch that follows).  0: the down-date only
  * starts when the factorisation has finished.  Results are bit-identical either way. */
 #define PRE3_OPT_K9_OVERLAP 5
+/* PRE3_OPT_STEP_TAIL (fp32 contexts with PRE3_OPT_K9_OVERLAP; default 0, or the environment's PRE3_TAIL): inside pre3_step / pre3_step_predicted
+ * the rescue stage (rescue_hi_inliers.m:29-47) and the HI update of up to 32 rescued landmarks (ekf_update_hi_inliers.m:45-58, update.m:27-48) run
+ * INSIDE the LI update's persistent launch: the rescued landmarks' rows are one more panel of the same block factorisation, P is read and written
+ * once per step (P - W'W - W~'W~), and update.m:42-46 of both updates is one rows / columns 3..6 pass with the product of the two normalisation
+ * Jacobians, carried by the next prediction's launch.  Same inlier sets; x / P agree with the call-by-call sequence to fp32 rounding (the
+ * intermediate P_LI is never rounded to fp32).  0 (default): the rescue stage and the HI update as launches of their own -- on MI355X the
+ * in-launch form's hand-offs between workgroups cost what the second sweep of P saves (DESIGN.md section 5d has the measured timeline).
+ * pre3_get_option returns the setting; whether a step used it also depends on the launch carrying every tile of P (one live fp32 context). */
+#define PRE3_OPT_STEP_TAIL 6
 PRE3_API int pre3_set_option(pre3_ctx *ctx, int option, int value);
 PRE3_API int pre3_get_option(pre3_ctx *ctx, int option, int *value_out);
 

@@ -225,6 +225,7 @@ def test_downdate_consumers_inside_the_factorisation_are_bit_identical(pre3, N, 
     for on in (False, True):              # one filter at a time: with two fp32 contexts alive on the device the launches carry no consumers
         f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", max_hyp=n_hyp, std_z=1.0)
         f.k9_overlap(on)
+        f.step_tail(False)                # (the rescue stage + HI update as launches of their own in both runs: what is compared is WHERE the down-date runs)
         assert f.k9_overlap() == on and f.chol_persist()
         f.set_x_p_k_k(seq["x0"], seq["P0"])
         f.defer_hi_update(bool(N % 2 == 0))

@@ -241,6 +241,7 @@ def test_step_predicted_equals_the_call_by_call_sequence_and_the_whole_step(pre3
     outs = []
     for mode in ("predicted", "calls", "step"):
         f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype=dtype, max_hyp=n_hyp, std_z=1.0)
+        f.step_tail(True)
         f.set_x_p_k_k(seq["x0"], seq["P0"])
         st_all = []
         for s in seq["steps"]:
@@ -258,7 +259,13 @@ def test_step_predicted_equals_the_call_by_call_sequence_and_the_whole_step(pre3
             st_all.append((st["best"], st["max_support"], li.tobytes(), hi.tobytes()))
         outs.append((st_all, f.get_x_k_k(), f.get_p_k_k()))
         f.close()
-    for other in outs[1:]:
+    for k, other in enumerate(outs[1:]):
         assert outs[0][0] == other[0]
-        assert np.array_equal(outs[0][1], other[1]) and np.array_equal(outs[0][2], other[2])
+        if dtype == "f32" and k == 0:
+            # (round 5) inside pre3_step / pre3_step_predicted an fp32 context runs the rescue stage and the HI update in the LI update's persistent
+            # launch (PRE3_OPT_STEP_TAIL): P - W'W - W~'W~ in one sweep, P_LI never rounded to fp32.  The call-by-call sequence rounds it: same
+            # flags and statistics (asserted above), x / P to fp32 rounding over the four chained steps
+            assert np.abs(outs[0][1] - other[1]).max() < 2e-5 and np.abs(outs[0][2] - other[2]).max() < 3e-4 * np.abs(other[2]).max()
+        else:
+            assert np.array_equal(outs[0][1], other[1]) and np.array_equal(outs[0][2], other[2])
     assert any(np.frombuffer(h, np.int32).sum() > 0 for _, _, _, h in outs[0][0])          # the rescue stage found work somewhere

@@ -6,5 +6,5 @@ src=$1; tag=$2; shift; shift
 cd 3pre_amd/csrc
 make >/dev/null
 /opt/rocm/bin/hipcc "$@" -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fvisibility=hidden -Wall -Wno-unused-function -ffp-contract=on -mllvm -pragma-unroll-threshold=200000 -c $src.hip -o /tmp/${src}_$tag.o
-objs=""; for f in pre3_api pre3_geom pre3_update pre3_match pre3_map pre3_vo; do if [ $f = $src ]; then objs="$objs /tmp/${src}_$tag.o"; else objs="$objs $f.o"; fi; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-rpath,/opt/rocm/lib -o ../lib/libpre3_$tag.so $objs
+objs=""; for f in pre3_api pre3_geom pre3_update pre3_cholp pre3_match pre3_map pre3_vo pre3_comm; do if [ $f = $src ]; then objs="$objs /tmp/${src}_$tag.o"; else objs="$objs $f.o"; fi; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-rpath,/opt/rocm/lib -o ../lib/libpre3_$tag.so $objs -ldl
