@@ -52,6 +52,11 @@ class Comm:
         check(lib.pre3_comm_info(self._h, C.byref(r), C.byref(w), C.byref(v), path, 512))
         return dict(rank=r.value, world=w.value, rccl_version=v.value, library=path.value.decode(errors="replace"))
 
+    def set_timeout(self, milliseconds):
+        """deadline of the host waits behind this communicator's collectives (default 10 s): on expiry the communicator is aborted and the call
+        returns PRE3_E_COMM"""
+        check(lib.pre3_comm_set_timeout(self._h, int(milliseconds)))
+
     def close(self):
         if getattr(self, "_h", None) and lib is not None:          # (lib is None while the interpreter shuts down)
             lib.pre3_comm_destroy(self._h)

@@ -45,6 +45,7 @@ int match_shard_merge(void *h, int G, const void *gathered_dev, double thresh, d
 void match_shard_destroy(void *h);
 int match_shard_set_comm(void *h, void *comm);
 int match_shard_match(void *h, double thresh, double *pairs_out, double *score_out, int *M_out);
+int match_shard_test_stall(void *h, int release);
 
 template <typename T> static int dmalloc(T **p, size_t count)
 {
@@ -77,13 +78,23 @@ static int check_ctx(pre3_ctx *c)
 
 // Poll the pinned mailbox until the kernel that was launched with sequence number `seq` has published.
 // slot 8: k_ransac_select, slot 9: k_collect_hi.  Falls back to a stream sync if the word does not arrive.
+static double now_ms() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
 static int wait_mail(pre3_ctx *c, int slot, int32_t seq)
 {
     volatile int32_t *w = c->mail_host + slot;
-    for (long spin = 0; spin < 20000000L; ++spin) {
+    // With a communicator on the context the awaited kernel may sit behind a collective: a peer that stalls (or never entered) must not hang this
+    // host for ever -- the wait has a wall-clock deadline (pre3_comm_set_timeout), and never ends in a bare hipStreamSynchronize.
+    const bool coll = c->comm != nullptr;
+    const double t0 = coll ? now_ms() : 0;
+    for (long spin = 0; coll || spin < 20000000L; ++spin) {
         if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == seq) return PRE3_OK;
-        if ((spin & 1023) == 1023 && hipStreamQuery(c->stream) == hipSuccess) break;
-        if (c->comm && (spin & 0xfffff) == 0xfffff) PRE3_TRY(comm_poll_error(c->comm));     // a collective in front of the awaited kernel whose peer died
+        if ((spin & 1023) == 1023) {
+            if (hipStreamQuery(c->stream) == hipSuccess) break;
+            if (coll && (spin & 0x3ffff) == 0x3ffff) {
+                PRE3_TRY(comm_poll_error(c->comm));     // a collective in front of the awaited kernel whose peer died
+                if (now_ms() - t0 > comm_timeout_ms(c->comm)) return comm_give_up(c->comm, "a collective in front of the awaited kernel");
+            }
+        }
     }
     PRE3_HIP(hipStreamSynchronize(c->stream));
     PRE3_CHECK(__atomic_load_n(w, __ATOMIC_ACQUIRE) == seq, PRE3_E_STATE, "mailbox: the producing kernel has not been launched");
@@ -877,6 +888,8 @@ static int ransac_results(pre3_ctx *c, int n_draw, int32_t *support, int32_t *li
 {
     c->li_from_host = -1; c->li_kernel = true;
     if (support || li_mask) {
+        // (behind a collective the synchronisation comes second: the selection's mailbox word first, under the communicator's deadline)
+        if (c->shard_round) PRE3_TRY(wait_mail(c, 8, c->seq_select));
         PRE3_HIP(hipStreamSynchronize(c->stream));
         if (support) PRE3_HIP(hipMemcpy(support, c->support, sizeof(int32_t) * n_draw, hipMemcpyDeviceToHost));
         if (li_mask && c->m) PRE3_HIP(hipMemcpy(li_mask, c->li_meas, sizeof(int32_t) * c->m, hipMemcpyDeviceToHost));
@@ -947,25 +960,46 @@ int pre3_comm_init(pre3_ctx *c, const void *id, int rank, int world)
 // One sharded RANSAC round with everything on the context's stream: [H*P | H*P*H' of this rank's measurements] -> scoring of hypotheses
 // [lo, hi) -> ncclAllReduce(sum) of [supports | masks], in place (the slices are disjoint and the buffer is cleared first: the integer sum
 // is the union) -> selection.  The host waits once, on the selection's mailbox word.
+// ---- test hook: a kernel that keeps the stream busy until the host releases it (or ~30 s have passed) ----------------------------------
+__global__ void k_test_stall(volatile int32_t *flag)
+{
+    for (long spin = 0; spin < 6000000L; ++spin) {          // (~20 s: the kernel lets go by itself)
+        if (__hip_atomic_load(const_cast<int32_t *>(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
+        __builtin_amdgcn_s_sleep(100);
+    }
+}
+int pre3_test_stall(pre3_ctx *c, int release)
+{
+    PRE3_CHECK(c != nullptr, PRE3_E_ARG, "null context");
+    PRE3_HIP(hipSetDevice(c->device));
+    if (release) { __atomic_store_n(c->mail_host + 15, 1, __ATOMIC_RELEASE); return PRE3_OK; }
+    __atomic_store_n(c->mail_host + 15, 0, __ATOMIC_RELEASE);
+    hipLaunchKernelGGL(k_test_stall, dim3(1), dim3(1), 0, c->stream, (volatile int32_t *)(c->mail_dev + 15));
+    PRE3_HIP(hipGetLastError());
+    return PRE3_OK;
+}
+
 int pre3_ransac_sharded(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, double threshold, int early_exit, int32_t *support, int32_t *li_mask,
                         int32_t stats[4])
 {
-    PRE3_TRY(check_ctx(c));
+    // What may differ between the ranks must not decide whether a rank enters the collective: only the arguments every rank passes alike (the
+    // communicator, n_draw) return early.  Everything rank-local -- the deferred work of the previous step (check_ctx), the measurements, the
+    // table, a failed launch -- is folded into rc_local: the rank then still enters ncclAllReduce, with its slice zero and the missing-slice
+    // word set, and every rank fails the round with PRE3_E_COMM instead of waiting for a partner that has returned.
+    PRE3_CHECK(c != nullptr, PRE3_E_ARG, "null context");
+    PRE3_HIP(hipSetDevice(c->device));
     PRE3_CHECK(c->comm != nullptr, PRE3_E_STATE, "pre3_ransac_sharded: no communicator (pre3_comm_init / pre3_set_comm)");
     PRE3_CHECK(n_draw >= 1 && n_draw <= c->caph, PRE3_E_ARG, "ransac: n_draw=%d exceeds capacity %d", n_draw, c->caph);
+    int rc_local = check_ctx(c);
     int rank = 0, world = 1;
     comm_rank_world(c->comm, &rank, &world);
     const int base = n_draw / world, rem = n_draw % world;
     const int lo = rank * base + std::min(rank, rem), hi = lo + base + (rank < rem ? 1 : 0);
     const int words = ceil_div(c->m, 32);
-    const size_t count = (size_t)round_up(n_draw, 4) + (size_t)n_draw * words;
-    // one word more than supports + masks travels through the all-reduce: the number of ranks whose slice is MISSING.  A rank-local failure
-    // between here and the collective (a bad table, a failed launch) must not leave the peers waiting in ncclAllReduce for a partner that has
-    // returned: this rank still enters the collective -- with its slice zero and that word set -- and every rank then fails the round.
-
-    // (the slice form at any number of ranks, one included: H*P only of the measurements this rank's hypotheses draw, H*P*H' only among each
-    // hypothesis' own rows -- the round's cost then falls with the number of ranks from the same code path)
-    int rc_local = ransac_prepare(c, n_draw, k, hyp, lo, hi, true, count + 1);
+    // the element count of the all-reduce comes from the contexts' capacities, which the ranks share (replicas), not from this rank's
+    // measurement count: supports | masks laid out for the capacity's mask words | the missing-slice word
+    const size_t count = (size_t)round_up(n_draw, 4) + (size_t)n_draw * c->mask_words_cap;
+    if (rc_local == PRE3_OK) rc_local = ransac_prepare(c, n_draw, k, hyp, lo, hi, true, count + 1);
     if (rc_local != PRE3_OK) (void)hipMemsetAsync(c->support, 0, sizeof(int32_t) * (count + 1), c->stream);      // (a failure in front of the prepare launch: the buffer must still be clear)
     if (rc_local == PRE3_OK && hi > lo) rc_local = launch_ransac_score_impl(c, k, threshold, lo, hi, round_up(2 * c->m, NB), c->support, c->masks, words);
     if (rc_local != PRE3_OK) {
@@ -1604,6 +1638,7 @@ int pre3_match_shard_match(pre3_match_shard *s, double thresh, double *pairs_out
     return s ? match_shard_match(s, thresh, pairs_out, score_out, M_out) : PRE3_E_ARG;
 }
 int pre3_match_shard_destroy(pre3_match_shard *s) { if (s) match_shard_destroy(s); return PRE3_OK; }
+int pre3_match_shard_test_stall(pre3_match_shard *s, int release) { return s ? match_shard_test_stall(s, release) : PRE3_E_ARG; }
 
 // matcher roofline/bench probe (inputs resident in HBM); not part of the reference-shaped API
 PRE3_API void *pre3_match_bench_create(int device, int ND, int K1, const uint8_t *L1, int K2, const uint8_t *L2)

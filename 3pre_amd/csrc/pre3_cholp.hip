@@ -2213,6 +2213,11 @@ int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior, c
     PRE3_CHECK(stride >= 1, PRE3_E_ARG, "launch_cholp: %d panels need more CUs than the device has", nrb_max);
     const size_t lds_strip = (size_t)win * CP_WGRAN * 16 + (size_t)CP_WGRAN * 16 + (size_t)NB * CP_WS * sizeof(float);     // ring | CP (Yw) | Yw2
     size_t lds = std::max(lds_crit, std::max(lds_row, lds_strip));
+    static std::atomic<unsigned long long> attr_set{ 0 };        // one bit per device
+    if (c->device >= 0 && c->device < 64 && !((attr_set.load() >> c->device) & 1ull)) {
+        PRE3_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cholp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set.fetch_or(1ull << c->device);
+    }
     // Down-date consumers (P -= W_J' W_J behind the strips, update.m:37): as many groups as there are CUs left.  Every workgroup of the launch
     // declares the same LDS (more than half a CU's), so there is one per CU, and the grid never exceeds the CU count: all of them are resident
     // together whatever the dispatch order -- a consumer can never hold the CU a strip, a row or crit is waiting for.
@@ -2229,6 +2234,23 @@ int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior, c
         if (n_dd < 0 || std::max(1 + nH + n_strips + n_dd, stride * nH + 1) > c->num_cus) n_dd = 0;
     }
     if (n_dd > 0) lds = std::max(lds, (size_t)4 * DG_SLOTS * DG_SLOT_GRAN * 16 + 12 * 1024);      // operand slots + one scratch line per wave (P warm-up)
+    if (n_dd > 0) {
+        // With consumers in the launch every strip waits for the strip that owns column ld, and the consumers wait for the strips: whatever the
+        // dispatch order, nobody must wait for a workgroup that has no CU.  The grid never exceeds the CU count and every workgroup takes more than
+        // half a CU's LDS; what is still checked, once per device: that the runtime really places one such workgroup per CU on THIS device and
+        // configuration (occupancy query), and that the CU count the context holds is the device's.  If not: no consumers (round 3's form, whose
+        // strips only wait for crit and the rows, which are dispatched in front of them).
+        static std::atomic<int> resident_ok[64];                   // 0 unknown, 1 yes, -1 no
+        int ok = (c->device >= 0 && c->device < 64) ? resident_ok[c->device].load() : -1;
+        if (ok == 0) {
+            int per_cu = 0, cus = 0;
+            const hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_cholp), CP_NTH, 160 * 1024 - 1024);
+            const hipError_t e2 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+            ok = (e1 == hipSuccess && e2 == hipSuccess && per_cu >= 1 && cus >= c->num_cus) ? 1 : -1;
+            resident_ok[c->device].store(ok);
+        }
+        if (ok != 1) n_dd = 0;
+    }
     // the tail (rescue stage + HI update inside this launch): every group of P's tiles must be in the launch, the strips do the x-update, the row
     // count is the device's (the speculative launch of a step)
     static const int xu_env0 = getenv("PRE3_CHOLP_XU") ? atoi(getenv("PRE3_CHOLP_XU")) : 1;
@@ -2237,11 +2259,6 @@ int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior, c
         const size_t strip_tail = ((size_t)(win + 1) * CP_WGRAN * 16 + (size_t)NB * CP_WS * sizeof(float) + 127) / 128 * 128 + sizeof(TailSmem);
         PRE3_CHECK(strip_tail <= CP_T_OFF && CP_TAIL_OFF + sizeof(TailSmem) <= CP_T_OFF, PRE3_E_ARG, "launch_cholp: the tail's LDS does not fit");
         lds = 160 * 1024;
-    }
-    static std::atomic<unsigned long long> attr_set{ 0 };        // one bit per device
-    if (c->device >= 0 && c->device < 64 && !((attr_set.load() >> c->device) & 1ull)) {
-        PRE3_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cholp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set.fetch_or(1ull << c->device);
     }
     PRE3_CHECK(lds <= 160 * 1024, PRE3_E_ARG, "launch_cholp: %d panels do not fit the strips' LDS", nrb_max);
     // flag words are never cleared within an epoch range: values are epoch + step, compared as signed differences.  Long before a word that has

@@ -9,6 +9,7 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <mutex>
+#include <thread>
 
 namespace pre3 {
 
@@ -55,7 +56,7 @@ static const Rccl *rccl()
 
 #define PRE3_NCCL(R, expr) do { ncclResult_t nr_ = (expr); if (nr_ != ncclSuccess) { set_error("RCCL: %s failed: %s", #expr, (R)->GetErrorString(nr_)); return PRE3_E_COMM; } } while (0)
 
-struct Comm { ncclComm_t comm = nullptr; int device = 0, rank = 0, world = 1; bool broken = false; };
+struct Comm { ncclComm_t comm = nullptr; int device = 0, rank = 0, world = 1; bool broken = false; int timeout_ms = 10000; };
 
 int comm_all_reduce_i32(void *h, void *buf, size_t count, hipStream_t st)
 {
@@ -85,6 +86,29 @@ int comm_poll_error(void *h)
         return PRE3_E_COMM;
     }
     return PRE3_OK;
+}
+// the deadline of a host wait behind a collective (pre3_comm_set_timeout; default 10 s)
+int comm_timeout_ms(void *h) { Comm *cm = (Comm *)h; return cm ? cm->timeout_ms : 0; }
+// A host wait behind a collective has run out of time (a peer that stalls, or never entered): the communicator is aborted -- the collective the
+// stream is stuck in then returns -- and marked broken; the caller returns PRE3_E_COMM.  The context stays usable with a fresh communicator.
+int comm_give_up(void *h, const char *what)
+{
+    Comm *cm = (Comm *)h; const Rccl *R = rccl();
+    set_error("%s did not complete within %d ms: the communicator is aborted (pre3_comm_set_timeout sets the deadline)", what, cm ? cm->timeout_ms : 0);
+    if (cm && !cm->broken) {
+        cm->broken = true;
+        // ncclCommAbort makes a collective that is spinning on its peers return -- but it may itself wait for work that has not started yet (a
+        // collective queued behind other kernels of the stream): it runs on a thread of its own, so that the caller has its PRE3_E_COMM at the
+        // deadline whatever the abort has to wait for
+        if (R && cm->comm) {
+            ncclComm_t dead = cm->comm;
+            const int dev = cm->device;
+            auto abort_fn = R->CommAbort;
+            std::thread([dead, dev, abort_fn] { (void)hipSetDevice(dev); (void)abort_fn(dead); }).detach();
+        }
+        cm->comm = nullptr;
+    }
+    return PRE3_E_COMM;
 }
 void comm_rank_world(void *h, int *rank, int *world) { Comm *cm = (Comm *)h; *rank = cm ? cm->rank : 0; *world = cm ? cm->world : 1; }
 int comm_device(void *h) { return ((Comm *)h)->device; }
@@ -130,6 +154,14 @@ int pre3_comm_destroy(pre3_comm *h)
     const Rccl *R = rccl();
     if (R && cm->comm) { (void)hipSetDevice(cm->device); (void)(cm->broken ? R->CommAbort(cm->comm) : R->CommDestroy(cm->comm)); }
     delete cm;
+    return PRE3_OK;
+}
+
+int pre3_comm_set_timeout(pre3_comm *h, int milliseconds)
+{
+    Comm *cm = (Comm *)h;
+    PRE3_CHECK(cm != nullptr && milliseconds >= 1, PRE3_E_ARG, "pre3_comm_set_timeout: null communicator or a non-positive deadline");
+    cm->timeout_ms = milliseconds;
     return PRE3_OK;
 }
 

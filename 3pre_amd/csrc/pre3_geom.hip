@@ -659,6 +659,9 @@ __device__ __forceinline__ void select_body(int n_draw, int k, int early_exit, i
     if (tid == 0) { stats[0] = sb.best; stats[1] = sb.iters; stats[2] = sb.n_hyp; stats[3] = sb.max_support; }
     const int best = sb.best, iters = sb.iters;
     const bool act = tid < 256;                                            // the launch may have more waves (k_ransac_score: 8): they only keep the barriers
+    // (k_select_gather: the gather's workgroups replay select_find_best on this array while this store runs.  That is a benign race by an invariant
+    //  both sides keep: only entries BEHIND the exit index `iters` are overwritten, the replay's result depends on the entries up to it alone --
+    //  its exit test passes at the first index whose support suffices, and a -1 never passes it.  Trimming at or below `iters` would break it.)
     for (int it = iters + tid; act && it < n_draw; it += 256) support[it] = -1;   // never evaluated by the reference
     // winner's mask -> flags (set_as_most_supported_hypothesis.m:32-52) + ordered compaction of the LI rows
     for (int base = 0; base < m; base += 256) {

@@ -214,6 +214,8 @@ void scratch_release(int slot, void *p);
 // ---- RCCL communicator (pre3_comm.hip): collectives on the caller's stream
 int comm_all_reduce_i32(void *comm, void *buf, size_t count, hipStream_t st);                       /* in place, sum */
 int comm_all_gather_f64(void *comm, const void *src, void *dst, size_t count_per_rank, hipStream_t st);
+int comm_timeout_ms(void *comm);                                                                   /* deadline of a host wait behind a collective */
+int comm_give_up(void *comm, const char *what);                                                     /* deadline passed: abort, mark broken, PRE3_E_COMM */
 int comm_poll_error(void *comm);                                                                    /* PRE3_E_COMM once the communicator has failed (and is aborted) */
 void comm_rank_world(void *comm, int *rank, int *world);
 int comm_device(void *comm);

@@ -1481,7 +1481,8 @@ struct MatchShard {
     // pre3_match_shard_match: the whole match on one stream of the shard's own, result block written to pinned host memory by the merge kernel
     void *comm = nullptr;   // borrowed (pre3_match_shard_set_comm)
     hipStream_t st = nullptr;
-    DevBuf raw; int raw_stride = 0;                           // [best | second | arg] of the slice, the distance kernel's outputs live here
+    DevBuf raw; int raw_stride = 0;                           // [best | second | arg] of the slice, the distance kernel's outputs live here (+ the MISSING word behind arg)
+    bool missing_set = false, test_fail = false;                // (test_fail: pre3_match_shard_test_stall(s, 2) makes the next match's distance kernels "fail")
     DevBuf gathered; int gathered_world = 0;
     double *res_host = nullptr, *res_host_dev = nullptr;      // [1 + 3 K1] + one int32 sequence word behind it
     int32_t seq = 0;
@@ -1506,9 +1507,13 @@ __global__ __launch_bounds__(1024) void k_shard_merge(int G, int K1, const doubl
     __shared__ int s_cnt[4][16];
     __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) s_base = 0;
+    __shared__ int s_missing;
+    if (tid == 0) { s_base = 0; s_missing = 0; }
     __syncthreads();
     const int st = raw_stride ? raw_stride : K1;
+    // raw blocks (pre3_match_shard_match): the int32 word behind a rank's arg array says that the rank's slice is MISSING (its distance kernels
+    // failed before the all-gather, which it entered all the same so that nobody waits for it): every rank then fails this match
+    if (raw_stride && tid < G && reinterpret_cast<const int32_t *>(gathered + (size_t)tid * 3 * st + 2 * (size_t)st)[st] != 0) atomicAdd(&s_missing, 1);
     for (int k0 = 0; k0 < K1; k0 += 4096) {
         int ok[4], Kq[4]; double Bq[4];
         unsigned long long bal[4];
@@ -1561,7 +1566,7 @@ __global__ __launch_bounds__(1024) void k_shard_merge(int G, int K1, const doubl
     }
     if (tid == 0) {
         res[mail ? 3 * (size_t)K1 : 0] = (double)s_base;
-        if (mail) { __threadfence_system(); __hip_atomic_store(mail, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+        if (mail) { mail[1] = s_missing; __threadfence_system(); __hip_atomic_store(mail, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
     }
 }
 
@@ -1632,6 +1637,14 @@ int match_shard_set_comm(void *h, void *comm)
     MatchShard *sh = (MatchShard *)h;
     PRE3_CHECK(comm == nullptr || comm_device(comm) == sh->device, PRE3_E_ARG, "match shard: the communicator lives on device %d, the shard on %d", comm ? comm_device(comm) : -1, sh->device);
     sh->comm = comm;
+    if (comm) {
+        // the all-gather's destination is sized here, not inside a match: an allocation that fails must not be a reason for this rank to stay out
+        // of a collective its peers have entered
+        int rank = 0, world = 1;
+        comm_rank_world(comm, &rank, &world);
+        PRE3_HIP(hipSetDevice(sh->device));
+        if (sh->gathered_world != world) { sh->gathered_world = 0; PRE3_TRY(sh->gathered.alloc(sizeof(double) * 3 * (size_t)sh->raw_stride * world)); sh->gathered_world = world; }
+    }
     return PRE3_OK;
 }
 // run + all-gather + merge on the shard's stream; the host waits once, on the word the merge kernel writes behind its result block
@@ -1652,35 +1665,86 @@ int match_shard_match(void *h, double thresh, double *pairs_out, double *score_o
     int rank = 0, world = 1;
     if (sh->comm) comm_rank_world(sh->comm, &rank, &world);
     const size_t nraw = 3 * (size_t)sh->raw_stride;
-    if (sh->comm && sh->gathered_world != world) { PRE3_TRY(sh->gathered.alloc(sizeof(double) * nraw * world)); sh->gathered_world = world; }
-    if (o.K2 > 0) {
-        if (sh->cls == 2) PRE3_TRY(i8_run(sh->m, sh->k2_offset, sh->st));
-        else if (sh->cls == 0) PRE3_TRY(rank_run<double>(sh->r, sh->k2_offset, sh->st));
-        else PRE3_TRY(rank_run<float>(sh->r, sh->k2_offset, sh->st));
-    } else { PRE3_HIP(hipMemsetAsync(o.oa.p, 0xff, sizeof(int32_t) * K1, sh->st)); }
+    PRE3_CHECK(!sh->comm || sh->gathered_world == world, PRE3_E_STATE, "match shard: the gather buffer does not fit the communicator (pre3_match_shard_set_comm)");
+    // A rank-local failure of the distance kernels must not keep this rank out of the all-gather its peers are entering: it enters all the same,
+    // with its slice empty (arg = -1 everywhere) and the MISSING word behind the arg array set; the merge of every rank sees the word and every
+    // rank fails this match with PRE3_E_COMM (as pre3_ransac_sharded does with its missing-slice word).
+    int32_t *missing_dev = reinterpret_cast<int32_t *>((double *)sh->raw.p + 2 * (size_t)sh->raw_stride) + sh->raw_stride;
+    int rc_local = PRE3_OK;
+    if (sh->test_fail) { sh->test_fail = false; set_error("match shard: distance kernels failed (test hook)"); rc_local = PRE3_E_HIP; }
+    else if (o.K2 > 0) {
+        if (sh->cls == 2) rc_local = i8_run(sh->m, sh->k2_offset, sh->st);
+        else if (sh->cls == 0) rc_local = rank_run<double>(sh->r, sh->k2_offset, sh->st);
+        else rc_local = rank_run<float>(sh->r, sh->k2_offset, sh->st);
+    } else if (hipMemsetAsync(o.oa.p, 0xff, sizeof(int32_t) * K1, sh->st) != hipSuccess) { set_error("match shard: hipMemsetAsync failed"); rc_local = PRE3_E_HIP; }
+    if (rc_local != PRE3_OK) {
+        (void)hipMemsetAsync(o.oa.p, 0xff, sizeof(int32_t) * K1, sh->st);
+        (void)hipMemsetAsync(missing_dev, 1, sizeof(int32_t), sh->st);
+        sh->missing_set = true;
+    } else if (sh->missing_set) { (void)hipMemsetAsync(missing_dev, 0, sizeof(int32_t), sh->st); sh->missing_set = false; }
     const void *src = sh->raw.p;
-    if (sh->comm) { PRE3_TRY(comm_all_gather_f64(sh->comm, sh->raw.p, sh->gathered.p, nraw, sh->st)); src = sh->gathered.p; }
+    if (sh->comm) {
+        const int rc_coll = comm_all_gather_f64(sh->comm, sh->raw.p, sh->gathered.p, nraw, sh->st);
+        if (rc_local != PRE3_OK) return rc_local;
+        PRE3_TRY(rc_coll);
+        src = sh->gathered.p;
+    } else if (rc_local != PRE3_OK) return rc_local;
     int32_t *mail_host = reinterpret_cast<int32_t *>(sh->res_host + nres), *mail_dev = reinterpret_cast<int32_t *>(sh->res_host_dev + nres);
     const int32_t seq = ++sh->seq;
     hipLaunchKernelGGL(k_shard_merge, dim3(1), dim3(1024), 0, sh->st, world, K1, (const double *)src, (float)thresh, sh->res_host_dev, mail_dev, seq, sh->raw_stride);
     PRE3_HIP(hipGetLastError());
+    // the wait has a wall-clock deadline when a collective is in front of the merge (pre3_comm_set_timeout): a peer that stalls or never entered
+    // ends in PRE3_E_COMM with the communicator aborted, never in a bare hipStreamSynchronize
     bool arrived = false;
-    for (long spin = 0; spin < 2000000000L && !arrived; ++spin) {
+    timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
+    for (long spin = 0; (sh->comm || spin < 2000000000L) && !arrived; ++spin) {
         if (__atomic_load_n(mail_host, __ATOMIC_ACQUIRE) == seq) { arrived = true; break; }
-        if ((spin & 0xfffff) == 0xfffff) {
-            if (sh->comm) PRE3_TRY(comm_poll_error(sh->comm));
+        if ((spin & 0x3ffff) == 0x3ffff) {
+            if (sh->comm) {
+                PRE3_TRY(comm_poll_error(sh->comm));
+                timespec ts1; clock_gettime(CLOCK_MONOTONIC, &ts1);
+                if ((ts1.tv_sec - ts0.tv_sec) * 1e3 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-6 > comm_timeout_ms(sh->comm)) return comm_give_up(sh->comm, "the all-gather of a sharded match");
+            }
             const hipError_t q = hipStreamQuery(sh->st);
             if (q == hipSuccess) { arrived = __atomic_load_n(mail_host, __ATOMIC_ACQUIRE) == seq; break; }
             if (q != hipErrorNotReady) { set_error("match shard: stream failed: %s", hipGetErrorString(q)); return PRE3_E_HIP; }
         }
     }
     if (!arrived) { PRE3_HIP(hipStreamSynchronize(sh->st)); PRE3_CHECK(__atomic_load_n(mail_host, __ATOMIC_ACQUIRE) == seq, PRE3_E_HIP, "match shard: the merge kernel did not publish its result"); }
+    PRE3_CHECK(mail_host[1] == 0, PRE3_E_COMM, "sharded match: %d rank(s) failed before the all-gather (their slices are missing): the match is void on every rank", mail_host[1]);
     const int M = (int)sh->res_host[3 * (size_t)K1];
     if (M > 0) {
         memcpy(pairs_out, sh->res_host, sizeof(double) * 2 * M);
         if (score_out) memcpy(score_out, sh->res_host + 2 * (size_t)K1, sizeof(double) * M);
     }
     *M_out = M;
+    return PRE3_OK;
+}
+// test hook (pre3_match_shard_test_stall): a kernel on the shard's stream that spins on a word of the pinned result block until released
+__global__ void k_shard_stall(volatile int32_t *flag)
+{
+    for (long spin = 0; spin < 6000000L; ++spin) {          // (~20 s: the kernel lets go by itself)
+        if (__hip_atomic_load(const_cast<int32_t *>(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
+        __builtin_amdgcn_s_sleep(100);
+    }
+}
+int match_shard_test_stall(void *h, int release)
+{
+    MatchShard *sh = (MatchShard *)h;
+    if (release == 2) { sh->test_fail = true; return PRE3_OK; }
+    PRE3_HIP(hipSetDevice(sh->device));
+    const size_t nres = 1 + 3 * (size_t)sh->out().K1;
+    if (!sh->st) PRE3_HIP(hipStreamCreateWithFlags(&sh->st, hipStreamNonBlocking));
+    if (!sh->res_host) {
+        PRE3_HIP(hipHostMalloc((void **)&sh->res_host, sizeof(double) * nres + 64, hipHostMallocMapped));
+        memset(sh->res_host, 0, sizeof(double) * nres + 64);
+        PRE3_HIP(hipHostGetDevicePointer((void **)&sh->res_host_dev, sh->res_host, 0));
+    }
+    int32_t *mail_host = reinterpret_cast<int32_t *>(sh->res_host + nres), *mail_dev = reinterpret_cast<int32_t *>(sh->res_host_dev + nres);
+    if (release) { __atomic_store_n(mail_host + 3, 1, __ATOMIC_RELEASE); return PRE3_OK; }
+    __atomic_store_n(mail_host + 3, 0, __ATOMIC_RELEASE);
+    hipLaunchKernelGGL(k_shard_stall, dim3(1), dim3(1), 0, sh->st, (volatile int32_t *)(mail_dev + 3));
+    PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }
 void match_shard_destroy(void *h) { delete (MatchShard *)h; }

@@ -296,6 +296,10 @@ class EkfFilter:
         check(lib.pre3_ransac_sharded(self._ctx, n_draw, k, dptr(hyp), C.c_double(float(threshold)), int(bool(early_exit)), dptr(sup), dptr(li), dptr(st)))
         return dict(support=sup, li_mask=li[:self.m], best=int(st[0]), iters=int(st[1]), n_hyp=int(st[2]), max_support=int(st[3]))
 
+    def test_stall(self, release):
+        """test hook: 0 parks a kernel on the context's stream until test_stall(1) (a peer that stalls inside a collective)"""
+        check(lib.pre3_test_stall(self._ctx, int(release)))
+
     def ransac_export(self, n_draw, support_ptr, mask_ptr):
         check(lib.pre3_ransac_export(self._ctx, int(n_draw), C.c_void_p(support_ptr), C.c_void_p(mask_ptr)))
 

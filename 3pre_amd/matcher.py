@@ -132,6 +132,10 @@ class MatchShard:
         m = pairs[:M.value].T.copy()
         return (m, sc[:M.value].copy()) if return_scores else m
 
+    def test_stall(self, code):
+        """test hook: 0 parks a kernel on the shard's stream until test_stall(1); 2: the next match's distance kernels 'fail'"""
+        check(lib.pre3_match_shard_test_stall(self._h, int(code)))
+
     def close(self):
         if getattr(self, "_h", None) and lib is not None:          # (lib is None while the interpreter shuts down)
             lib.pre3_match_shard_destroy(self._h)

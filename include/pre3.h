@@ -354,13 +354,24 @@ PRE3_API int pre3_match_shard_destroy(pre3_match_shard *s);
  * RCCL is bound at run time: librccl.so.1 as already loaded in the process (e.g. PyTorch's copy), else from the loader path, else
  * /opt/rocm/lib; the environment's PRE3_RCCL_LIB overrides.  Without it these calls return PRE3_E_COMM; nothing else in libpre3 needs it.
  * A collective whose peer has died never completes: the wait of pre3_ransac_sharded / pre3_match_shard_match polls ncclCommGetAsyncError,
- * aborts the communicator when it reports one and returns PRE3_E_COMM; a peer that merely stalls is the host program's time-out to set. */
+ * aborts the communicator when it reports one and returns PRE3_E_COMM.  A peer that merely stalls -- or never entered the collective -- is
+ * caught by a wall-clock deadline on every host wait that has a collective in front of it (pre3_comm_set_timeout; default 10 s): on expiry
+ * the communicator is aborted (ncclCommAbort: the collective the stream is stuck in returns), marked broken, and the call returns
+ * PRE3_E_COMM; the context (or shard) stays usable once a fresh communicator is attached.  No wait of the library ends in an unbounded
+ * synchronisation behind a collective.  A rank whose own part of a round fails BEFORE the collective (a bad table, a failed launch) still
+ * enters it, with an empty slice and a "missing" word that travels with the data: every rank then returns PRE3_E_COMM for that round. */
 #define PRE3_COMM_ID_BYTES 128
 typedef struct pre3_comm pre3_comm;
 PRE3_API int pre3_comm_unique_id(void *id_out /* PRE3_COMM_ID_BYTES */);
 PRE3_API int pre3_comm_create(pre3_comm **out, int device, const void *id, int rank, int world);
 PRE3_API int pre3_comm_destroy(pre3_comm *comm);
 PRE3_API int pre3_comm_info(pre3_comm *comm, int *rank, int *world, int *rccl_version, char *lib_path, int lib_path_len);
+PRE3_API int pre3_comm_set_timeout(pre3_comm *comm, int milliseconds);      /* deadline of the host waits behind this communicator's collectives (default 10000) */
+/* Test hooks: park (release == 0) a kernel on the context's / the shard's stream that spins until released (release == 1; it also gives up by
+ * itself after some tens of seconds), so that a test can stand in for a peer that stalls inside a collective.  pre3_match_shard_test_stall(s, 2):
+ * the next match's distance kernels "fail" (a rank-local failure in front of the all-gather). */
+PRE3_API int pre3_test_stall(pre3_ctx *ctx, int release);
+PRE3_API int pre3_match_shard_test_stall(pre3_match_shard *s, int release);
 /* attach: the context / the shard borrows `comm` (must be on the same device; NULL detaches).  pre3_comm_init = create + attach, owned by the
  * context and destroyed with it. */
 PRE3_API int pre3_set_comm(pre3_ctx *ctx, pre3_comm *comm);

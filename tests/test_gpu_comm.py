@@ -97,3 +97,76 @@ def test_on_stream_shard_match_equals_the_oracle(pre3, orc, comm):
                 mr, dr = orc.siftmatch(A, B, thr)
                 assert np.array_equal(m, mr) and np.array_equal(d, dr), (A.dtype, with_comm, thr)
         sh.close()
+
+
+@pytest.mark.timeout(120)
+def test_a_stalled_collective_ends_in_the_deadline_not_in_a_hang(pre3):
+    """A peer that stalls inside (or never enters) a collective: the library's host wait has a wall-clock deadline (pre3_comm_set_timeout).  With one
+    rank the stall is a kernel parked in front of the round on the context's stream (test hook); the sharded round must return PRE3_E_COMM
+    within the deadline with the communicator aborted -- never sit in a stream synchronisation -- and the context must work again with a fresh
+    communicator once the stream has drained."""
+    import time
+    cm = importlib.import_module("3pre_amd.comm")
+    N, n_draw = 60, 24
+    seq = synth.make_sequence(N, 1, n_draw, seed=34)
+    s = seq["steps"][0]
+    f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", max_hyp=n_draw)
+    f.set_x_p_k_k(seq["x0"], seq["P0"])
+    c1 = cm.Comm(0, cm.unique_id(), 0, 1)
+    c1.set_timeout(300)
+    f.set_comm(c1)
+    f.ekf_prediction(s["u"]); f.search_IC_matches(); f.set_measurements(s["meas_idx"], s["z"])
+    ref = f.ransac_hypotheses(s["hyp"], threshold=1.0, early_exit=False)
+    f.test_stall(0)
+    t0 = time.time()
+    with pytest.raises(pre3.Pre3Error) as e:
+        f.ransac_sharded_stream(s["hyp"], 1.0, early_exit=False)
+    dt = time.time() - t0
+    assert e.value.code == -7 and 0.25 < dt < 5.0, (e.value.code, dt)          # PRE3_E_COMM, at the deadline
+    with pytest.raises(pre3.Pre3Error) as e2:                                  # the aborted communicator is unusable ...
+        f.ransac_sharded_stream(s["hyp"], 1.0, early_exit=False)
+    assert e2.value.code == -7
+    f.test_stall(1)                                                            # ... the "peer" comes back: the stream drains
+    f.sync()
+    c2 = cm.Comm(0, cm.unique_id(), 0, 1)
+    f.set_comm(c2)                                                             # a fresh communicator: the context works again
+    got = f.ransac_sharded_stream(s["hyp"], 1.0, early_exit=False)
+    assert got["best"] == ref["best"] and np.array_equal(got["support"], ref["support"]) and np.array_equal(got["li_mask"], ref["li_mask"])
+    f.set_comm(None)
+    f.close(); c1.close(); c2.close()
+
+
+@pytest.mark.timeout(120)
+def test_the_sharded_match_has_the_same_deadline_and_a_failing_rank_still_enters_the_all_gather(pre3, orc):
+    import time
+    cm = importlib.import_module("3pre_amd.comm")
+    mt = importlib.import_module("3pre_amd.matcher")
+    rng = np.random.default_rng(6)
+    L1 = rng.integers(0, 255, (128, 300)).astype(np.uint8)
+    L2 = rng.integers(0, 255, (128, 640)).astype(np.uint8)
+    L2[:, 40:200] = L1[:, :160]
+    sh = mt.MatchShard(L1, L2, 0)
+    c1 = cm.Comm(0, cm.unique_id(), 0, 1)
+    sh.set_comm(c1)
+    mr = orc.siftmatch(L1, L2, 1.5)[0]
+    assert np.array_equal(sh.match(1.5), mr)
+    # (i) this rank's distance kernels fail: it still enters the all-gather, its slice marked missing -> the match is void (PRE3_E_HIP here, the
+    #     rank-local error; its peers would see PRE3_E_COMM from the merge), and the NEXT match is correct again
+    sh.test_stall(2)
+    with pytest.raises(pre3.Pre3Error) as e:
+        sh.match(1.5)
+    assert e.value.code == -3
+    assert np.array_equal(sh.match(1.5), mr)
+    # (ii) a stall in front of the collective: PRE3_E_COMM at the deadline, communicator aborted, usable again with a fresh one
+    c1.set_timeout(300)
+    sh.test_stall(0)
+    t0 = time.time()
+    with pytest.raises(pre3.Pre3Error) as e:
+        sh.match(1.5)
+    assert e.value.code == -7 and 0.25 < time.time() - t0 < 5.0
+    sh.test_stall(1)
+    c2 = cm.Comm(0, cm.unique_id(), 0, 1)
+    sh.set_comm(c2)
+    assert np.array_equal(sh.match(1.5), mr)
+    sh.set_comm(None)
+    sh.close(); c1.close(); c2.close()
