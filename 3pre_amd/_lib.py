@@ -81,7 +81,7 @@ EXPORTS = [
     "pre3_set_map", "pre3_state_size", "pre3_set_state", "pre3_get_state", "pre3_predict", "pre3_predict_dense", "pre3_project", "pre3_innovation",
     "pre3_get_landmark_fields", "pre3_window_gate", "pre3_set_measurements", "pre3_ransac", "pre3_hypothesis_support", "pre3_ransac_score",
     "pre3_ransac_select", "pre3_ransac_export", "pre3_ransac_import", "pre3_update_li", "pre3_rescue", "pre3_update_hi", "pre3_update_all", "pre3_get_flags",
-    "pre3_set_flags", "pre3_step", "pre3_step_predicted", "pre3_set_option", "pre3_get_option", "pre3_map_delete", "pre3_map_add_inverse_depth", "pre3_map_inversedepth_2_cartesian", "pre3_map_management", "pre3_get_map", "pre3_set_descriptors", "pre3_get_descriptors", "pre3_set_scan", "pre3_ic_search", "pre3_vo_ransac", "pre3_vo_ransac_frames", "pre3_vo_bench", "pre3_update_ell", "pre3_siftmatch_f64", "pre3_siftmatch_f32", "pre3_siftmatch_u8",
+    "pre3_set_flags", "pre3_step", "pre3_step_all", "pre3_step_predicted", "pre3_set_option", "pre3_get_option", "pre3_map_delete", "pre3_map_add_inverse_depth", "pre3_map_inversedepth_2_cartesian", "pre3_map_management", "pre3_get_map", "pre3_set_descriptors", "pre3_get_descriptors", "pre3_set_scan", "pre3_ic_search", "pre3_vo_ransac", "pre3_vo_ransac_frames", "pre3_vo_bench", "pre3_update_ell", "pre3_siftmatch_f64", "pre3_siftmatch_f32", "pre3_siftmatch_u8",
     "pre3_siftmatch_i8", "pre3_siftmatch_partial", "pre3_siftmatch_merge", "pre3_match_shard_create", "pre3_match_shard_create_cls", "pre3_match_shard_run", "pre3_match_shard_merge",
     "pre3_match_shard_destroy", "pre3_release_scratch", "pre3_knn_f64", "pre3_timer_start",
     "pre3_timer_stop", "pre3_kernel_timing", "pre3_kernel_timing_read", "pre3_kernel_timing_info", "pre3_bench_downdate",

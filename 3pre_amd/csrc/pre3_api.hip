@@ -1316,6 +1316,37 @@ int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, co
     return rc_back;
 }
 
+/* mono_slam.m:153-162 + :199 -- the 'PURE_EKF' branch (config_file.m:21): prediction, projection + Jacobians + S_i of every landmark, then ONE
+ * update with every individually compatible measurement (ekf_update_all.m:46-62), as one call: the projection and the inbox ride in the
+ * prediction's launch, S_i and the flag clearing in the H*P launch -- four launches fewer than the call-by-call sequence
+ * (pre3_predict, pre3_project, pre3_innovation, pre3_set_measurements, pre3_update_all), the same arithmetic. */
+int pre3_step_all(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, const double *z)
+{
+    PRE3_TRY(check_ctx(c));
+    PRE3_CHECK(u != nullptr, PRE3_E_ARG, "pre3_step_all: null u");
+    PRE3_CHECK(c->have_cam, PRE3_E_STATE, "pre3_step_all: camera not set");
+    PRE3_CHECK(c->x_valid[PRE3_X_K_K] && c->p_which == PRE3_X_K_K, PRE3_E_STATE, "pre3_step_all: needs (x_k_k, p_k_k) on the device");
+    PRE3_CHECK(m == 0 || (meas_idx && z), PRE3_E_ARG, "pre3_step_all: null measurement pointers");
+    size_t inbox_bytes = 0;
+    PRE3_TRY(install_measurements(c, m, meas_idx, z, nullptr, 0, c->N > 0 && m > 0, false, &inbox_bytes));
+    {
+        const int rc_p = launch_predict_impl(c, u, true, (inbox_bytes + 15) / 16, ++c->seq_inbox);
+        c->inbox_pending = rc_p == PRE3_OK;
+        if (rc_p != PRE3_OK) { c->measurements_set = false; return rc_p; }
+    }
+    c->x_valid[PRE3_X_K_KM1] = true; c->p_which = PRE3_X_K_KM1; c->hp_all_valid = false;
+    c->projected = true;
+    c->ride_innovation = c->N > 0 && m > 0;          // S_i (and the clearing of last frame's flags) in the update's H*P launch
+    if (c->N && !c->ride_innovation) PRE3_TRY(launch_innovation(c, 0, 0.0, true));
+    c->innovated = true;
+    const int rc_u = update_selected(c, PRE3_X_K_KM1, c->m, nullptr);
+    if (c->ride_innovation) {                        // (the H*P launch did not go out: S_i on its own)
+        c->ride_innovation = false;
+        if (rc_u == PRE3_OK) PRE3_TRY(launch_innovation(c, 0, 0.0, true));
+    }
+    return rc_u;
+}
+
 /* The same behind a prediction and an IC search the caller has already run (mono_slam.m:153 ekf_prediction, :159 search_IC_matches +
  * matching_sift_based, e.g. pre3_predict + pre3_ic_search): the installed measurements are used. */
 int pre3_step_predicted(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, double threshold, int early_exit, double chi2, int32_t stats[8])

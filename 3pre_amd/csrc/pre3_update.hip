@@ -996,17 +996,18 @@ __global__ __launch_bounds__(256) void k_downdate(T *__restrict__ P, int ld, con
 // LDS-DMA of one [BK][64] operand stage (both operands): granule v = tid + l*256 covers row kr = v / ROWV, columns
 // (v % ROWV)*VEC ..; its LDS address is v*16 bytes into the stage image = wave-uniform base + lane*16, as the
 // instruction requires (global_load_lds_dwordx4).
-template <typename T, int BK>
+template <typename T, int BK, int NT = 256>
 __device__ __forceinline__ void lds_dma_stage(const T *__restrict__ W, int ldw, int k0, int I0, int J0, T *sA, T *sB, int tid, int wave)
 {
-    constexpr int VEC = 16 / sizeof(T), ROWV = 64 / VEC, NLD = (BK * ROWV) / 256;
+    constexpr int VEC = 16 / sizeof(T), ROWV = 64 / VEC, NLD = (BK * ROWV) / NT;
+    static_assert((BK * ROWV) % NT == 0 && NLD >= 1, "stage must divide over the workgroup");
 #pragma unroll
     for (int l = 0; l < NLD; ++l) {
-        const int v = tid + l * 256, kr = v / ROWV, cv = (v % ROWV) * VEC;
+        const int v = tid + l * NT, kr = v / ROWV, cv = (v % ROWV) * VEC;
         const T *ga = W + (size_t)(k0 + kr) * ldw + I0 + cv;
         const T *gb = W + (size_t)(k0 + kr) * ldw + J0 + cv;
-        T *la = sA + (size_t)(wave * 64 + l * 256) * VEC;            // lane 0's granule
-        T *lb = sB + (size_t)(wave * 64 + l * 256) * VEC;
+        T *la = sA + (size_t)(wave * 64 + l * NT) * VEC;            // lane 0's granule
+        T *lb = sB + (size_t)(wave * 64 + l * NT) * VEC;
         __builtin_amdgcn_global_load_lds(ga, (__attribute__((address_space(3))) void *)la, 16, 0, 0);
         __builtin_amdgcn_global_load_lds(gb, (__attribute__((address_space(3))) void *)lb, 16, 0, 0);
     }
@@ -1064,8 +1065,12 @@ struct XUpd { int n_tiles, n, r; const double *x_prior; double *x_out; double *p
 
 // waves_per_eu: the riders' fp64 geometry must not raise the register count of the tile path (5 workgroups per CU in fp32,
 // 4 in fp64 -- every tile resident at once); if anything spills, it is the riders.
-template <typename T, int BK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_downdate_1t(T *__restrict__ P, int ld, const T *__restrict__ W, int ldw, int r_pad,
+// NW = 8 (fp64 at small n, round 5): the tile's four 32 x 32 wave tiles are each held by TWO waves, one per half of every k-stage -- a CU that
+// holds one tile (n = 1213: 210 tiles on 256 CUs) then has two waves per SIMD, and one's LDS reads / DMA waits hide behind the other's MFMAs
+// (v_mfma_f64_16x16x4 takes 64 cycles: with one wave per SIMD the matrix pipe idled through every stage's LDS round trip and barrier).  The two
+// halves meet in LDS behind the last stage, (first half) + (second half): one fixed order.
+template <typename T, int BK, int NW = 4>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(5))) void k_downdate_1t(T *__restrict__ P, int ld, const T *__restrict__ W, int ldw, int r_pad,
                                                      const int2 *__restrict__ tiles, int gen_size, XUpd xu, ProjRide pr)
 {
     using M = Mfma<T>;
@@ -1073,9 +1078,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
     constexpr int NBLK = 32 / M::BLK;
     constexpr int VEC = 16 / sizeof(T);               // elements per 16-byte LDS-DMA granule
     constexpr int ROWV = TS / VEC;                    // granules per staged row
-    constexpr int NLD = (BK * ROWV) / 256;            // granules per lane per operand per stage
+    constexpr int NT = 64 * NW;
     constexpr int HS = BK / M::KS / 2;                // k-steps per half stage
-    static_assert((BK * ROWV) % 256 == 0 && NLD >= 1, "stage must divide over the workgroup");
+    static_assert(NW == 4 || NW == 8, "four wave tiles, one or two waves each");
     constexpr int STG = BK * TS;                      // elements of one operand stage
     // epilogue patches: fp32 [32][33] (padded); fp64 [32][32] with the column XOR-ed by the row -- conflict-free both ways without the
     // padding, so that the patches fit the 32 KB of staging and five workgroups still share a CU's 160 KB
@@ -1084,6 +1089,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
     __shared__ __attribute__((aligned(16))) T smem[SMEM];                   // [A0 | A1 | B0 | B1], each [BK][64]
     static_assert(sizeof(T) * SMEM >= sizeof(double) * (16 * 64 + 4), "the riders borrow the staging buffer");
     if ((int)blockIdx.x >= xu.n_tiles) {            // riders (launch_downdate adds these workgroups)
+        if (NW > 4 && threadIdx.x >= 256) return;   // (the riders are four-wave workgroups)
         __builtin_amdgcn_s_setprio(3);              // short dependent chains: must not starve behind the MFMA waves sharing their SIMD
         const int nx = xu.nx, rb = blockIdx.x - xu.n_tiles;
         if (rb < nx) {                              // the state update
@@ -1104,7 +1110,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
         else if (gen == 2) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
     }
-    T *patch = smem + (threadIdx.x >> 6) * (32 * PS);
+    T *patch = smem + ((threadIdx.x >> 6) & 3) * (32 * PS);
     auto pat = [&](int r, int c) -> T & { return patch[r * PS + (sizeof(T) == 4 ? c : (c ^ r))]; };
     const int2 ij = tiles[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1114,7 +1120,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
 #define RT_STAMP(k)
 #endif
     RT_STAMP(0);
-    const int wi = wave >> 1, wj = wave & 1;
+    const int wi = (wave & 3) >> 1, wj = wave & 1, kh = wave >> 2;      // kh: the half of every stage this wave multiplies (NW == 8)
     const int I0 = ij.x * TS, J0 = ij.y * TS;
     const int nstage = r_pad / BK;
     typename M::acc_t acc[NBLK][NBLK];
@@ -1124,26 +1130,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
         for (int q = 0; q < NBLK; ++q)
 #pragma unroll
             for (int e = 0; e < M::NREG; ++e) acc[p][q][e] = (T)0;
-    lds_dma_stage<T, BK>(W, ldw, 0, I0, J0, smem, smem + 2 * STG, tid, wave);
+    lds_dma_stage<T, BK, NT>(W, ldw, 0, I0, J0, smem, smem + 2 * STG, tid, wave);
     // this lane's 16 entries of the P tile: requested now, consumed in the epilogue (latency hidden by the k-loop)
     T pv[NBLK][NBLK][M::NREG];
+    if (kh == 0) {
 #pragma unroll
-    for (int p = 0; p < NBLK; ++p)
+        for (int p = 0; p < NBLK; ++p)
 #pragma unroll
-        for (int q = 0; q < NBLK; ++q)
+            for (int q = 0; q < NBLK; ++q)
 #pragma unroll
-            for (int e = 0; e < M::NREG; ++e)
-                pv[p][q][e] = P[(size_t)(I0 + wi * 32 + p * M::BLK + M::row(lane, e)) * ld + J0 + wj * 32 + q * M::BLK + M::col(lane)];
+                for (int e = 0; e < M::NREG; ++e)
+                    pv[p][q][e] = P[(size_t)(I0 + wi * 32 + p * M::BLK + M::row(lane, e)) * ld + J0 + wj * 32 + q * M::BLK + M::col(lane)];
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     RT_STAMP(1);
     for (int s = 0; s < nstage; ++s) {
         const int buf = s & 1;
         if (s + 1 < nstage)       // buf^1 was last read in stage s-1: every wave is past that barrier
-            lds_dma_stage<T, BK>(W, ldw, (s + 1) * BK, I0, J0, smem + (buf ^ 1) * STG, smem + (2 + (buf ^ 1)) * STG, tid, wave);
+            lds_dma_stage<T, BK, NT>(W, ldw, (s + 1) * BK, I0, J0, smem + (buf ^ 1) * STG, smem + (2 + (buf ^ 1)) * STG, tid, wave);
         const T *sA = smem + buf * STG, *sB = smem + (2 + buf) * STG;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
+            if (NW == 8 && hf != kh) continue;
             T av[HS][NBLK], bv[HS][NBLK];
 #pragma unroll
             for (int ks = 0; ks < HS; ++ks) {
@@ -1165,6 +1174,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
         __syncthreads();
     }
     RT_STAMP(2);
+    if (NW == 8) {
+        // the second half's share goes through the wave tile's patch (the staging buffers are dead behind the last barrier) and is added in one
+        // fixed order, (first half) + (second half); the epilogue is the first half's waves'
+        if (kh == 1) {
+#pragma unroll
+            for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+                for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+                    for (int e = 0; e < M::NREG; ++e) pat(p * M::BLK + M::row(lane, e), q * M::BLK + M::col(lane)) = acc[p][q][e];
+        }
+        __syncthreads();
+        if (kh == 1) return;
+#pragma unroll
+        for (int p = 0; p < NBLK; ++p)
+#pragma unroll
+            for (int q = 0; q < NBLK; ++q)
+#pragma unroll
+                for (int e = 0; e < M::NREG; ++e) acc[p][q][e] += pat(p * M::BLK + M::row(lane, e), q * M::BLK + M::col(lane));
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();           // (this wave's reads of its patch are done before the mirror image goes through it)
+    }
     const bool mirror = ij.x != ij.y;
 #pragma unroll
     for (int p = 0; p < NBLK; ++p)
@@ -1488,13 +1519,19 @@ int launch_ell_HP_build_sel(pre3_ctx *c, int nsel, const int32_t *sel_dev, void 
     if (r_pad == 0) return PRE3_OK;
     const int gx = ceil_div(c->ldw / 4, 256), ny = r_pad / 2;
     InnovRide ir{};
-    dim3 g(gx, ny), b(256);
+    if (c->ride_innovation && c->N > 0) {            // pre3_step_all: S_i of every predicted landmark (+ the clearing of last frame's inlier flags) in this launch
+        const int nb = ceil_div(c->N * 16, 256), rows = ceil_div(nb, gx);
+        ir = InnovRide{ rows * gx, c->N, c->ld, (int)(c->flags_bytes / sizeof(int32_t)), c->lm.type, c->lm.off, c->lm.has_h, c->P, c->lm.Hc, c->lm.Hl,
+                        c->lm.S, c->lm.has_S, (int32_t *)((unsigned char *)c->inbox_dev + c->off_flags) };
+    }
+    dim3 g(gx, ny + (ir.n_blocks ? ir.n_blocks / gx : 0)), b(256);
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_ell_HP_build<double>, g, b, 0, c->stream, nsel, r_pad, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl, c->lm.z, c->lm.h,
                            c->row_col, (double *)c->row_val, c->row_nu, (const double *)c->P, c->ld, (double *)dst, c->ldw, (const int32_t *)nullptr, 0, ny, ir, sel_dev),
         hipLaunchKernelGGL(k_ell_HP_build<float>, g, b, 0, c->stream, nsel, r_pad, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl, c->lm.z, c->lm.h,
                            c->row_col, (float *)c->row_val, c->row_nu, (const float *)c->P, c->ld, (float *)dst, c->ldw, (const int32_t *)nullptr, 0, ny, ir, sel_dev));
     PRE3_HIP(hipGetLastError());
+    if (ir.n_blocks) { c->ride_innovation = false; c->innovated = true; }
     return PRE3_OK;
 }
 
@@ -1684,6 +1721,15 @@ int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior)
             c->ride_rescue_projection = false; c->rescue_projected = true;
         }
         dim3 g1(c->n_tiles + nx + pr.n_blocks);
+        // fp64 with few tiles per CU (configs[1]: 210 tiles on 256 CUs): two waves per wave tile, so that every SIMD has two waves to overlap
+        static const int nw8_env = getenv("PRE3_K9_F64_NW8") ? atoi(getenv("PRE3_K9_F64_NW8")) : 3;      // (measured at n = 1213, r = 320: 0: 24.3 us; 1 (16-row stages, 8 waves): 30.5; 2 (32-row stages): 24.8; 3 (32-row stages, 8 waves): 22.5)
+        if (c->dtype == PRE3_F64 && nw8_env == 1 && c->n_tiles <= 2 * c->num_cus) {
+            hipLaunchKernelGGL((k_downdate_1t<double, 16, 8>), g1, dim3(512), 0, c->stream, (double *)c->P, c->ld, (const double *)W, c->ldw, r_pad, (const int2 *)c->tiles_flat, c->num_cus, xu, pr);
+        } else if (c->dtype == PRE3_F64 && nw8_env == 2 && c->n_tiles <= 2 * c->num_cus && r_pad % 32 == 0) {
+            hipLaunchKernelGGL((k_downdate_1t<double, 32, 4>), g1, dim3(256), 0, c->stream, (double *)c->P, c->ld, (const double *)W, c->ldw, r_pad, (const int2 *)c->tiles_flat, c->num_cus, xu, pr);
+        } else if (c->dtype == PRE3_F64 && nw8_env == 3 && c->n_tiles <= 2 * c->num_cus && r_pad % 32 == 0) {
+            hipLaunchKernelGGL((k_downdate_1t<double, 32, 8>), g1, dim3(512), 0, c->stream, (double *)c->P, c->ld, (const double *)W, c->ldw, r_pad, (const int2 *)c->tiles_flat, c->num_cus, xu, pr);
+        } else
         DISPATCH_T(c,
             hipLaunchKernelGGL((k_downdate_1t<double, 16>), g1, b, 0, c->stream, (double *)c->P, c->ld, (const double *)W, c->ldw, r_pad, (const int2 *)c->tiles_flat, c->num_cus, xu, pr),
             hipLaunchKernelGGL((k_downdate_1t<float, 32>), g1, b, 0, c->stream, (float *)c->P, c->ld, (const float *)W, c->ldw, r_pad, (const int2 *)c->tiles_flat, c->num_cus, xu, pr));

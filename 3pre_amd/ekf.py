@@ -343,6 +343,13 @@ class EkfFilter:
         s = st.tolist()
         return dict(best=s[0], iters=s[1], n_hyp=s[2], max_support=s[3], n_li=s[4], n_hi=s[5])
 
+    def step_all(self, u, meas_idx, z):
+        """pre3_step_all -- mono_slam.m's 'PURE_EKF' branch (:153-162, :199): ekf_prediction, search_IC_matches' projection / Jacobians / S_i, the
+        measurements, ekf_update_all, as one call (the same arithmetic as the four calls, fewer launches)"""
+        u, meas_idx, z = f64(u), i32(meas_idx), f64(z)
+        self.m = int(meas_idx.shape[0])
+        check(lib.pre3_step_all(self._ctx, dptr(u), self.m, dptr(meas_idx), dptr(z)))
+
     def step_predicted(self, hyp, threshold=None, early_exit=True, chi2=CHI2INV_2_95):
         """mono_slam.m:178-187 (RANSAC, LI update, rescue, HI update) behind ekf_prediction() and matching_sift_based() (or search_IC_matches()
         + set_measurements()): the installed measurements, pre3_step's device-driven launches."""

@@ -291,10 +291,7 @@ def fp64_n200_leg(pre3, synth, steps=40, warm=4):
         f.set_x_p_k_k(seq["x0"], seq["P0"])
 
         def one(s):
-            f.ekf_prediction(s["u"])
-            f.search_IC_matches()
-            f.set_measurements(s["meas_idx"], s["z"])
-            f.ekf_update_all()
+            f.step_all(s["u"], s["meas_idx"], s["z"])       # mono_slam.m's 'PURE_EKF' branch as one call (round 5; the four calls gave the same bits, 15 us slower)
         # timed first, checked afterwards: the C oracle's OpenMP pool keeps spinning on the host cores for a while after a call, and this
         # leg is host-driven (four calls per update): with the check in front the timed loop ran at 450 instead of 5700 updates/s
         for s in seq["steps"][:1 + warm]:

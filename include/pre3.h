@@ -177,6 +177,10 @@ PRE3_API int pre3_step(pre3_ctx *ctx, const double u[7], int m, const int32_t *m
  * context (pre3_predict, then pre3_ic_search or pre3_project + pre3_innovation + pre3_set_measurements): the measurements are the installed
  * ones, the launches are pre3_step's (the persistent factorisation with the down-date inside, the device-driven HI update), none of them
  * sized by a host poll.  stats as pre3_step.  This is what a frame loop that matches on the device calls instead of pre3_step. */
+/* mono_slam.m:153-162 + :199, the 'PURE_EKF' branch (config_file.m:21, EST_METHOD): prediction, projection / Jacobians / S_i of every landmark
+ * and ONE update with all individually compatible measurements (@ekf_filter/ekf_update_all.m:46-62) as one call -- the same arithmetic as
+ * pre3_predict + pre3_project + pre3_innovation + pre3_set_measurements + pre3_update_all, four launches fewer.  meas_idx strictly ascending. */
+PRE3_API int pre3_step_all(pre3_ctx *ctx, const double u[7], int m, const int32_t *meas_idx, const double *z /* [2 m] */);
 PRE3_API int pre3_step_predicted(pre3_ctx *ctx, int n_draw, int k, const int32_t *hyp, double threshold, int early_exit, double chi2,
                                  int32_t stats[8]);
 

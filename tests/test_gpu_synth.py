@@ -269,3 +269,27 @@ def test_step_predicted_equals_the_call_by_call_sequence_and_the_whole_step(pre3
         else:
             assert np.array_equal(outs[0][1], other[1]) and np.array_equal(outs[0][2], other[2])
     assert any(np.frombuffer(h, np.int32).sum() > 0 for _, _, _, h in outs[0][0])          # the rescue stage found work somewhere
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_step_all_equals_the_call_by_call_pure_ekf_branch(pre3, dtype):
+    """pre3_step_all (mono_slam.m:153-162 + :199, EST_METHOD 'PURE_EKF': prediction, search_IC_matches' projection / Jacobians / S_i, ekf_update_all as
+    one call with the projection and S_i riding in other launches) against ekf_prediction / search_IC_matches / set_measurements / ekf_update_all:
+    the same arithmetic, so x, P and the landmark table must agree bit for bit; an empty measurement set included."""
+    N = 90
+    seq = synth.make_sequence(N, 4, 8, seed=17, outlier_frac=0.0)
+    outs = []
+    for mode in ("one", "calls"):
+        f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype=dtype, max_hyp=8, std_z=1.0)
+        f.set_x_p_k_k(seq["x0"], seq["P0"])
+        for t, s in enumerate(seq["steps"]):
+            mi, z = (s["meas_idx"], s["z"]) if t != 2 else (s["meas_idx"][:0], s["z"][:0])
+            if mode == "one":
+                f.step_all(s["u"], mi, z)
+            else:
+                f.ekf_prediction(s["u"]); f.search_IC_matches(); f.set_measurements(mi, z); f.ekf_update_all()
+        fl = f.landmark_fields()
+        outs.append((f.get_x_k_k(), f.get_p_k_k(), fl["h"], fl["Hc"], fl["S"]))
+        f.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
