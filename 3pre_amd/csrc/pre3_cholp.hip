@@ -299,7 +299,12 @@ __device__ __forceinline__ void crit_main(const CpArgs &a, int nrb, CritSmem &sm
     if ((tid0 >> 6) == 8) __builtin_amdgcn_s_setprio(3);
     else if ((tid0 >> 6) == 9) __builtin_amdgcn_s_setprio(2);
     bool bad = false;
-    for (int J = 0; ; ++J) {                                     // J < nrb: the LI update's panels; J == nrb: the rescued landmarks' rows, if the tail brings any
+    // (two passes over ONE instance of the panel loop: the LI update's panels [0, nrb), then -- if the tail brings rescued landmarks -- their rows as
+    //  panel nrb.  The rescue stage's call sits BETWEEN the passes: inside the panel loop it cost the chain 4 % of its cycles and the products 0.5 us per
+    //  panel, although nothing of it was live there.)
+    for (int pass = 0; pass < 2; ++pass) {
+    const int j0 = pass == 0 ? 0 : nrb, j1 = pass == 0 ? nrb : nrb + 1;
+    for (int J = j0; J < j1; ++J) {
         if (tid0 == 0) { CP_STAMP(0, J, 0); CP_CLK(19, J, 0); }
         {
             typename ChW<float>::acc_t acc[ChW<float>::NBLK][ChW<float>::NBLK];
@@ -311,13 +316,7 @@ __device__ __forceinline__ void crit_main(const CpArgs &a, int nrb, CritSmem &sm
         //  the chain, whose code already takes every register, and come back as scratch traffic inside the chain)
         int tid = tid0;
         asm volatile("" : "+v"(tid));
-        if (J >= nrb) break;
-        if (J + 1 == nrb) {
-            // the last panel of the LI update is factored: rescue stage (crit_tail: all twelve waves, crit_side calls it at the same barrier).  With
-            // rescued landmarks it leaves Ls = D_hi, Xs = I and the loop runs once more: the chain of panel nrb
-            if (!a.tail || crit_tail(nrb) == 0) break;
-            continue;
-        }
+        if (J + 1 >= j1) break;
         __syncthreads();                                                            // b0: MPl complete, T1p / T2 landed
         if (tid0 == 0) CP_STAMP(0, J, 2);
         const int wave = tid >> 6, lane = tid & 63, fa = (wave >> 1) & 1, fb = wave & 1;
@@ -372,6 +371,10 @@ __device__ __forceinline__ void crit_main(const CpArgs &a, int nrb, CritSmem &sm
         __syncthreads();                                                            // b3: Ls = D_{J+1}, Xs = I
         if (tid0 == 0) CP_STAMP(0, J, 3);
     }
+    // the last panel of the LI update is factored: rescue stage (crit_tail: all twelve waves, crit_side calls it at the same barrier).  With rescued
+    // landmarks it leaves Ls = D_hi, Xs = I and the second pass runs the chain of panel nrb
+    if (pass == 1 || !a.tail || crit_tail(nrb) == 0) break;
+    }
     if (bad && tid0 == 512) atomicExch(a.status, 1);
 }
 
@@ -391,8 +394,10 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
     // per launch by this CU, so there is no older copy for its L1 to hold; the loads carry sc1 all the same.)
     int fst = 5, cool = 0;
     unsigned pv = 0;
-    for (int J = 0; ; ++J) {
-        const bool more = J + 1 < nrb;
+    for (int pass = 0; pass < 2; ++pass) {                         // (as crit_main)
+    const int j0 = pass == 0 ? 0 : nrb, j1 = pass == 0 ? nrb : nrb + 1;
+    for (int J = j0; J < j1; ++J) {
+        const bool more = J + 1 < j1;
         const int fr = J + 1;                                     // the row whose tiles this panel's products need
         const unsigned *fflag = cf_rowA(a.cf, fr < 64 ? fr : 63);
         fst = (more && J > 0) ? 0 : 5;                            // (panel 0's tiles came with the prologue)
@@ -479,11 +484,7 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
             publish_m_rows(7, !more);
             if (!more) { drain_stores(); if (lane == 0) cf_store(a.cf + CF_MP, a.base + (unsigned)J + 1); CP_STAMP(1, J, 4); }
         }
-        if (J >= nrb) break;                                                         // (as crit_main)
-        if (J + 1 == nrb) {
-            if (!a.tail || crit_tail(nrb) == 0) break;
-            continue;
-        }
+        if (!more) break;
         {   // the fetch must be complete before the products (normally it is: the tiles arrive mid-chain)
             int spin = 0;
             while (wave == 11 && fst < 5 && spin < SPIN_LIMIT) {
@@ -521,6 +522,8 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
             CP_STAMP(1, J, 6);
         }
         __syncthreads();                                                            // b3
+    }
+    if (pass == 1 || !a.tail || crit_tail(nrb) == 0) break;
     }
 }
 

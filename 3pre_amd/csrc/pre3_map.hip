@@ -254,18 +254,46 @@ __global__ __launch_bounds__(256) void k_map_one(int n_new, const int32_t *__res
     // (ld is a multiple of 128: all RB rows exist.)  Last rows first: the computed rows of an add sit at the end of the state and take a dozen
     // microseconds of dependent loads -- dispatched first they hide behind the copies, dispatched last they were the tail of the launch
     const int a0 = (ny - 1 - (int)blockIdx.y) * RB;
-    int cb[CB], sb[CB];                                                               // lane-consecutive columns: every access of a wave is one contiguous run
-#pragma unroll
-    for (int k = 0; k < CB; ++k) {
-        cb[k] = (blockIdx.x * CB + k) * 256 + threadIdx.x;
-        sb[k] = cb[k] < n_new ? src0[cb[k]] : -2;                                    // -1: a computed column, -2: beyond the new state (zero)
-    }
     int sa[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) sa[r] = a0 + r < n_new ? src0[a0 + r] : -2;
     bool rows_plain = true;
 #pragma unroll
     for (int r = 0; r < RB; ++r) rows_plain = rows_plain && sa[r] != -1;
+    {
+        // Round 5 -- the pure copy at HBM rate: a lane takes FOUR consecutive destination columns.  Behind a deleted landmark their sources are four
+        // consecutive columns too, shifted by a multiple of 3 entries: element-aligned only, which a 16-byte global load takes (the hardware
+        // needs dword alignment; tools/probe_unaligned.hip), so the whole run moves as 16-byte loads and aligned 16-byte stores instead of the
+        // dword accesses of round 4 (2.9 TB/s).  Any other pattern in the four (a computed column, the edge of the state) keeps the per-column path.
+        typedef T tv4_t __attribute__((ext_vector_type(4), aligned(sizeof(T))));
+        typedef T tv4a_t __attribute__((ext_vector_type(4)));
+        const int c4 = blockIdx.x * CB * 256 + threadIdx.x * 4;
+        bool run = rows_plain && c4 + 3 < n_new;
+        int s0 = 0;
+        if (run) {
+            const int4 sv = *reinterpret_cast<const int4 *>(src0 + c4);
+            s0 = sv.x;
+            run = sv.x >= 0 && sv.y == sv.x + 1 && sv.z == sv.x + 2 && sv.w == sv.x + 3;
+        }
+        if (__syncthreads_and(run ? 1 : 0)) {                                         // (workgroup-uniform: the whole 8 x 1024 block is a shifted copy)
+            tv4_t o[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) o[r] = *reinterpret_cast<const tv4_t *>(P + (size_t)(sa[r] >= 0 ? sa[r] : 0) * ld + s0);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                tv4a_t v = { o[r].x, o[r].y, o[r].z, o[r].w };
+                if (sa[r] < 0) v = tv4a_t{ (T)0, (T)0, (T)0, (T)0 };
+                *reinterpret_cast<tv4a_t *>(dst + (size_t)(a0 + r) * ld + c4) = v;
+            }
+            return;
+        }
+    }
+    int cb[CB], sb[CB];                                                               // lane-consecutive columns: every access of a wave is one contiguous run
+#pragma unroll
+    for (int k = 0; k < CB; ++k) {
+        cb[k] = (blockIdx.x * CB + k) * 256 + threadIdx.x;
+        sb[k] = cb[k] < n_new ? src0[cb[k]] : -2;                                    // -1: a computed column, -2: beyond the new state (zero)
+    }
     if (rows_plain) {
         // the common case (workgroup-uniform), free of branches between the loads of a column: copies P[src(a)][src(b)]; a computed column
         // (a new feature's, a converted landmark's: a handful of lanes per call) takes its <= 8 terms for all RB rows at once

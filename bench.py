@@ -84,12 +84,39 @@ def cpu_baseline(seq, threshold, budget_s=12.0):
         blas_threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
     except Exception:
         blas_threads = ncores
+    # where ONE CPU step spends its time (numpy twin, the fastest leg): dense algebra of the two updates against the interpreted per-landmark
+    # and per-hypothesis loops -- so that the GPU / CPU ratio can be read for what it is
+    split = {}
+    try:
+        s0 = seq["steps"][0]
+        cam = seq["cam"]
+        mi = np.asarray(s0["meas_idx"], np.int64)
+        tt = time.perf_counter(); x1, P1 = twin.predict(seq["x0"], seq["P0"], s0["u"]); split["predict"] = time.perf_counter() - tt
+        tt = time.perf_counter()
+        h_, has_ = twin.project(types, off, x1, cam); Hc_, Hl_ = twin.jacobian(types, off, x1, cam, h_, has_); twin.innovation(types, off, P1, Hc_, Hl_, has_)
+        split["project_jacobian_S_i (per-landmark loops)"] = time.perf_counter() - tt
+        zf = np.zeros((N, 2)); zf[mi] = s0["z"]
+        tt = time.perf_counter(); rr = twin.ransac(types, off, x1, P1, Hc_, Hl_, zf, h_, mi, mi, cam, s0["hyp"], threshold, False); split["ransac (per-hypothesis loop)"] = time.perf_counter() - tt
+        li_ = np.zeros(N, np.int32); li_[mi] = rr["li_mask"]
+        tt = time.perf_counter(); x2, P2 = twin.update_landmarks(types, off, np.nonzero(li_)[0], x1, P1, Hc_, Hl_, zf, h_); split["LI update (dense: S, inv, K S K')"] = time.perf_counter() - tt
+        tt = time.perf_counter()
+        h2, has2 = twin.project(types, off, x2, cam, h_, has_); Hc2, Hl2 = twin.jacobian(types, off, x2, cam, h2, has2)
+        ic_ = np.zeros(N, np.int32); ic_[mi] = 1
+        hi_ = twin.rescue(types, off, P2, Hc2, Hl2, h2, zf, ic_, li_)
+        split["rescue (per-landmark loops)"] = time.perf_counter() - tt
+        tt = time.perf_counter(); twin.update_landmarks(types, off, np.nonzero(hi_)[0], x2, P2, Hc2, Hl2, zf, h2); split["HI update (dense)"] = time.perf_counter() - tt
+        tot = sum(split.values())
+        split = {k: round(1e3 * v, 2) for k, v in split.items()}
+        split["dense_share"] = round((split["LI update (dense: S, inv, K S K')"] + split["HI update (dense)"]) / (1e3 * tot), 3)
+    except Exception as e:                                     # (a baseline detail must never take the line down)
+        split = {"error": repr(e)}
     legs = {"c_restatement_1_thread": {"value": c1, "steps": n1, "cores": 1},
             "c_restatement_all_cores": {"value": call, "steps": nall, "cores": threads_all},
             "numpy_twin_openblas": {"value": tw, "steps": ntw, "cores": int(blas_threads)}}
     best = max(legs, key=lambda k: legs[k]["value"])
     return {"value": legs[best]["value"], "unit": "steps/s", "cores": legs[best]["cores"], "kind": "port", "fastest_leg": best,
-            "cpu_model": _cpu_model(), "host_cores": ncores, "legs": legs,
+            "cpu_model": _cpu_model(), "host_cores": ncores, "legs": legs, "blas_threads": int(blas_threads),
+            "one_step_split_ms": split,
             "sample": "first steps of the same N=%d, %d-hypothesis sequence (all hypotheses evaluated, fp64), ~%d s per leg: C restatement of "
                       "the reference at 1 thread and at all cores (scalar loops, OpenMP over rows; no host BLAS in the image), and the numpy "
                       "twin (Python loops + OpenBLAS); MATLAB itself is unavailable" % (N, n_hyp, int(budget_s))}
