@@ -260,70 +260,60 @@ __global__ __launch_bounds__(256) void k_map_one(int n_new, const int32_t *__res
     bool rows_plain = true;
 #pragma unroll
     for (int r = 0; r < RB; ++r) rows_plain = rows_plain && sa[r] != -1;
-    {
-        // Round 5 -- the pure copy at HBM rate: a lane takes FOUR consecutive destination columns.  Behind a deleted landmark their sources are four
-        // consecutive columns too, shifted by a multiple of 3 entries: element-aligned only, which a 16-byte global load takes (the hardware
-        // needs dword alignment; tools/probe_unaligned.hip), so the whole run moves as 16-byte loads and aligned 16-byte stores instead of the
-        // dword accesses of round 4 (2.9 TB/s).  Any other pattern in the four (a computed column, the edge of the state) keeps the per-column path.
+    if (rows_plain) {
+        // Round 5 -- the common case (workgroup-uniform: no computed row among the RB) at HBM rate: a lane takes FOUR consecutive destination
+        // columns.  Behind a deleted landmark their sources are four consecutive columns too, shifted by a multiple of 3 entries: element-aligned
+        // only, which a 16-byte global load takes (the hardware needs dword alignment; tools/probe_unaligned.hip), so a run moves as 16-byte loads
+        // and aligned 16-byte stores instead of the dword accesses of round 4 (2.9 TB/s).  A lane whose four columns are not such a run (the edge
+        // of a deletion, a computed column of a new / converted landmark, the end of the state) takes them one by one, as before.
         typedef T tv4_t __attribute__((ext_vector_type(4), aligned(sizeof(T))));
         typedef T tv4a_t __attribute__((ext_vector_type(4)));
         const int c4 = blockIdx.x * CB * 256 + threadIdx.x * 4;
-        bool run = rows_plain && c4 + 3 < n_new;
-        int s0 = 0;
+        if (c4 >= ld) return;
+        int sb4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sb4[j] = c4 + j < n_new ? src0[c4 + j] : -2;     // -1: a computed column, -2: beyond the new state (zero)
+        const bool run = sb4[0] >= 0 && sb4[1] == sb4[0] + 1 && sb4[2] == sb4[0] + 2 && sb4[3] == sb4[0] + 3;
+        tv4a_t o[RB];
         if (run) {
-            const int4 sv = *reinterpret_cast<const int4 *>(src0 + c4);
-            s0 = sv.x;
-            run = sv.x >= 0 && sv.y == sv.x + 1 && sv.z == sv.x + 2 && sv.w == sv.x + 3;
-        }
-        if (__syncthreads_and(run ? 1 : 0)) {                                         // (workgroup-uniform: the whole 8 x 1024 block is a shifted copy)
-            tv4_t o[RB];
+            tv4_t t[RB];
 #pragma unroll
-            for (int r = 0; r < RB; ++r) o[r] = *reinterpret_cast<const tv4_t *>(P + (size_t)(sa[r] >= 0 ? sa[r] : 0) * ld + s0);
+            for (int r = 0; r < RB; ++r) t[r] = *reinterpret_cast<const tv4_t *>(P + (size_t)(sa[r] >= 0 ? sa[r] : 0) * ld + sb4[0]);
 #pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                tv4a_t v = { o[r].x, o[r].y, o[r].z, o[r].w };
-                if (sa[r] < 0) v = tv4a_t{ (T)0, (T)0, (T)0, (T)0 };
-                *reinterpret_cast<tv4a_t *>(dst + (size_t)(a0 + r) * ld + c4) = v;
+            for (int r = 0; r < RB; ++r) o[r] = sa[r] >= 0 ? tv4a_t{ t[r].x, t[r].y, t[r].z, t[r].w } : tv4a_t{ (T)0, (T)0, (T)0, (T)0 };
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (sb4[j] != -1) {
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) {
+                        const T v = P[(size_t)(sa[r] >= 0 ? sa[r] : 0) * ld + (sb4[j] >= 0 ? sb4[j] : 0)];
+                        o[r][j] = (sa[r] >= 0 && sb4[j] >= 0) ? v : (T)0;
+                    }
+                } else {
+                    // a computed column (a new feature's, a converted landmark's: a handful of lanes per call): its <= 8 terms for all RB rows at once
+                    T vv[MAPW]; int cc[MAPW];
+#pragma unroll
+                    for (int t = 0; t < MAPW; ++t) { vv[t] = val[(c4 + j) * MAPW + t]; cc[t] = col[(c4 + j) * MAPW + t]; }
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) {
+                        T e = (T)0;
+#pragma unroll
+                        for (int t = 0; t < MAPW; ++t) e = ell_fma(vv[t], P[(size_t)(sa[r] >= 0 ? sa[r] : 0) * ld + cc[t]], e);
+                        o[r][j] = sa[r] >= 0 ? e : (T)0;
+                    }
+                }
             }
-            return;
         }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) *reinterpret_cast<tv4a_t *>(dst + (size_t)(a0 + r) * ld + c4) = o[r];
+        return;
     }
     int cb[CB], sb[CB];                                                               // lane-consecutive columns: every access of a wave is one contiguous run
 #pragma unroll
     for (int k = 0; k < CB; ++k) {
         cb[k] = (blockIdx.x * CB + k) * 256 + threadIdx.x;
         sb[k] = cb[k] < n_new ? src0[cb[k]] : -2;                                    // -1: a computed column, -2: beyond the new state (zero)
-    }
-    if (rows_plain) {
-        // the common case (workgroup-uniform), free of branches between the loads of a column: copies P[src(a)][src(b)]; a computed column
-        // (a new feature's, a converted landmark's: a handful of lanes per call) takes its <= 8 terms for all RB rows at once
-        T o[RB][CB];
-#pragma unroll
-        for (int k = 0; k < CB; ++k) {
-            if (sb[k] != -1) {
-#pragma unroll
-                for (int r = 0; r < RB; ++r) {
-                    const T v = P[(size_t)(sa[r] >= 0 ? sa[r] : 0) * ld + (sb[k] >= 0 ? sb[k] : 0)];
-                    o[r][k] = (sa[r] >= 0 && sb[k] >= 0) ? v : (T)0;
-                }
-            } else {
-                T vv[MAPW]; int cc[MAPW];
-#pragma unroll
-                for (int t = 0; t < MAPW; ++t) { vv[t] = val[cb[k] * MAPW + t]; cc[t] = col[cb[k] * MAPW + t]; }
-#pragma unroll
-                for (int r = 0; r < RB; ++r) {
-                    T e = (T)0;
-#pragma unroll
-                    for (int t = 0; t < MAPW; ++t) e = ell_fma(vv[t], P[(size_t)(sa[r] >= 0 ? sa[r] : 0) * ld + cc[t]], e);
-                    o[r][k] = sa[r] >= 0 ? e : (T)0;
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int k = 0; k < CB; ++k) if (cb[k] < ld) dst[(size_t)(a0 + r) * ld + cb[k]] = o[r][k];
-        return;
     }
 #pragma unroll 1
     for (int r = 0; r < RB; ++r) {
