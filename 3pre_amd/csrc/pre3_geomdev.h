@@ -46,11 +46,14 @@ __device__ inline void d_pinhole_distort(const double *hrl, const CamD &cam, dou
 }
 
 // direction vector of a landmark in the world frame before rotation: (y-r)*rho + m(theta,phi)  or  y-r
-__device__ inline void d_ray(int type, const double *y, const double *t, double *v)
+// (sc: sin / cos of theta and phi, given by a caller that needs them again -- project_core's Jacobian: a double-precision sincos is ~1000 shader
+//  cycles, and the four of them were all but the whole cost of a projection, tools/probe_project.hip)
+__device__ inline void d_ray(int type, const double *y, const double *t, double *v, const double *sc = nullptr)
 {
     if (type == PRE3_INVDEPTH) {
         double sth, cth, sphi, cphi;                       // one shared range reduction per angle instead of four separate calls
-        sincos(y[3], &sth, &cth); sincos(y[4], &sphi, &cphi);
+        if (sc) { sth = sc[0]; cth = sc[1]; sphi = sc[2]; cphi = sc[3]; }
+        else { sincos(y[3], &sth, &cth); sincos(y[4], &sphi, &cphi); }
         double mi0 = cphi * sth, mi1 = -sphi, mi2 = cphi * cth;   // m.m:38-40
         v[0] = (y[0] - t[0]) * y[5] + mi0;
         v[1] = (y[1] - t[1]) * y[5] + mi1;
@@ -77,7 +80,9 @@ __device__ inline bool project_core(const int type, const double *__restrict__ x
     double Rwc[9];
     d_q2r(x + 3, Rwc);
     double v[3], hrl[3];
-    d_ray(type, y, x, v);
+    double tsc[4] = { 0, 1, 0, 1 };                        // sin / cos of theta, phi: once for the ray and the Jacobian (the same values either way)
+    if (type == PRE3_INVDEPTH) { sincos(y[3], &tsc[0], &tsc[1]); sincos(y[4], &tsc[2], &tsc[3]); }
+    d_ray(type, y, x, v, tsc);
     // r_cw = r_wc' (hi_inverse_depth.m:33); hi_cartesian.m:33 uses inv(r_wc) = r_wc' to rounding
     for (int c = 0; c < 3; ++c) hrl[c] = Rwc[0 * 3 + c] * v[0] + Rwc[1 * 3 + c] * v[1] + Rwc[2 * 3 + c] * v[2];
     const double PI = 3.141592653589793238462643383279502884;
@@ -126,9 +131,8 @@ __device__ inline bool project_core(const int type, const double *__restrict__ x
             hc_out[r * 7 + 3 + c] = A[r * 3] * dq[c] + A[r * 3 + 1] * dq[4 + c] + A[r * 3 + 2] * dq[8 + c];
     for (int t = 0; t < 12; ++t) hl_out[t] = 0;
     if (type == PRE3_INVDEPTH) {
-        double theta = y[3], phi = y[4], lambda = y[5];
-        double sth, cth, sph, cph;
-        sincos(theta, &sth, &cth); sincos(phi, &sph, &cph);
+        double lambda = y[5];
+        const double sth = tsc[0], cth = tsc[1], sph = tsc[2], cph = tsc[3];
         double dth[3] = { cph * cth, 0, -cph * sth };
         double dph[3] = { -sph * sth, -cph, -sph * cth };
         double d3[3] = { y[0] - x[0], y[1] - x[1], y[2] - x[2] };
