@@ -1153,9 +1153,9 @@ int pre3_update_hi(pre3_ctx *c)
         return update_selected(c, PRE3_X_K_K, n_hi, c->sel_rows);
     }
     if (was_fused) {
-        // pre3_step sent the collection and the update out as one device-driven pair of launches (k_hi_fused + its down-date): up to 32
-        // landmarks are done, only the Jnorm pass of update.m:42-46 is left; more than that take the general path now
-        if (c->hi_from_host < 0 && n_hi <= 32) {
+        // pre3_step sent the collection and the update out as one device-driven pair of launches (k_hi_fused + its down-date): up to 64
+        // landmarks (two panels) are done, only the Jnorm pass of update.m:42-46 is left; more than that take the general path now
+        if (c->hi_from_host < 0 && n_hi <= hi_fused_max(c)) {
             if (n_hi > 0) {
                 c->hp_all_valid = false;
                 if (c->leave_jn_to_predict) c->jn_pending = true;

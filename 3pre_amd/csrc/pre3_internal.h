@@ -254,6 +254,7 @@ int launch_ell_HP(pre3_ctx *c, int r, void *dst /*r_pad x ldw*/, bool with_nu);
 int launch_ell_G(pre3_ctx *c, int r, const void *HPsrc, void *dst, int ldg, int add_identity, const void *Rdense, bool lower_only = false);
 int launch_downdate(pre3_ctx *c, int r, const void *W, int which_prior = -1 /* >= 0: also x <- x_prior + W'y (update.m:36) */);
 bool hi_fused_usable(const pre3_ctx *c);
+int hi_fused_max(const pre3_ctx *c);                  /* landmarks k_hi_fused updates with on its own (64: two panels; 32) */
 int launch_hi_fused(pre3_ctx *c, int32_t seq);        /* the HI collection + update of up to 32 landmarks without the host (k_hi_fused + its down-date) */
 
 }  // namespace pre3

@@ -176,6 +176,32 @@ __global__ __launch_bounds__(256) void k_ell_G_hyp(const int32_t *__restrict__ h
 // W strip c holds M(i,a) = W[a][c*64+i] (transposed storage), so its loads/stores are coalesced in i.
 // ------------------------------------------------------------------------------------------------
 
+// A solved 64-row block of a W strip leaves LDS (X[a][i] = W[J*64 + a][c0 + i]): the f32 rows and, fp32 with k_downdate_b3 in use (Wp), this
+// strip's share of the bf16 planes of row block J, for the down-date and for the next launch's pending update.  Strip = half a 128-column
+// block: fragments 2*half, 2*half+1 of 4 stages; the nu strip lives in an extra column block.
+template <typename T, typename XT>
+__device__ __forceinline__ void chol_store_w_strip(const XT &X, T *__restrict__ W, int ldw, int J, int c0, void *__restrict__ Wp, int nst_total, int ld)
+{
+    const int tid = threadIdx.x;
+    typedef T st4_t __attribute__((ext_vector_type(4)));
+    for (int idx = tid; idx < NB * NB / 4; idx += CH_NTH) {
+        const int a2 = idx >> 4, i = (idx & 15) * 4;
+        *reinterpret_cast<st4_t *>(W + (size_t)(J * NB + a2) * ldw + c0 + i) = st4_t{ X[a2][i], X[a2][i + 1], X[a2][i + 2], X[a2][i + 3] };
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (Wp != nullptr && c0 < ld + NB) {
+            bf16x8_t *base = static_cast<bf16x8_t *>(Wp) + ((size_t)(c0 >> 7) * nst_total + 4 * J) * B3_GRAN + ((c0 >> 6) & 1) * 128;
+            for (int idx = tid; idx < 512; idx += CH_NTH) {
+                const int q = idx >> 7, fl = (idx >> 6) & 1, l = idx & 63, r = l & 31, h = l >> 5;
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = X[16 * q + 8 * h + j][fl * 32 + r];
+                b3_split_store(x, base + (size_t)q * B3_GRAN + fl * 64 + l);
+            }
+        }
+    }
+}
+
 // PRO: the workgroup first applies the update of panel J-1 to its own blocks (diagonal block and X), i.e. the K = J
 // column of the trailing update, so that the launch of panel J does not have to wait for a separate trail kernel.
 // PREBUILT: the raw diagonal block (Ls) and the workgroup's X block (Xs) are already in LDS (k_hi_fused computes them there): no global loads,
@@ -389,26 +415,7 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
             }
         }
     } else {
-        typedef T st4_t __attribute__((ext_vector_type(4)));
-        for (int idx = tid; idx < NB * NB / 4; idx += CH_NTH) {
-            const int a2 = idx >> 4, i = (idx & 15) * 4;
-            *reinterpret_cast<st4_t *>(W + (size_t)(J * NB + a2) * ldw + c0 + i) = st4_t{ Xs[a2][i], Xs[a2][i + 1], Xs[a2][i + 2], Xs[a2][i + 3] };
-        }
-        if constexpr (sizeof(T) == 4) {
-            // k_downdate_b3 in use: this strip's share of the bf16 planes of row block J straight from LDS, for the down-date and for the
-            // next launch's pending update (Sp set; without it only the last panel does this and riders split the earlier row blocks).
-            // Strip = half a 128-column block: fragments 2*half, 2*half+1 of 4 stages; the nu strip lives in an extra column block.
-            if (Wp != nullptr && (Sp != nullptr || J == nrb - 1) && c0 < ld + NB) {
-                bf16x8_t *base = static_cast<bf16x8_t *>(Wp) + ((size_t)(c0 >> 7) * nst_total + 4 * J) * B3_GRAN + ((c0 >> 6) & 1) * 128;
-                for (int idx = tid; idx < 512; idx += CH_NTH) {
-                    const int q = idx >> 7, fl = (idx >> 6) & 1, l = idx & 63, r = l & 31, h = l >> 5;
-                    float x[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] = Xs[16 * q + 8 * h + j][fl * 32 + r];
-                    b3_split_store(x, base + (size_t)q * B3_GRAN + fl * 64 + l);
-                }
-            }
-        }
+        chol_store_w_strip<T>(Xs, W, ldw, J, c0, (Sp != nullptr || J == nrb - 1) ? Wp : nullptr, nst_total, ld);
     }
     PROBE_STAMP(3);
 }
@@ -661,20 +668,92 @@ __global__ __launch_bounds__(CH_NTH) void k_chol_step(T *__restrict__ S, int lds
 // down-date behind this launch runs on that word; count == 0: nothing to do, the next prediction's Jnorm pass gets the identity;
 // count > 32: the host takes the general path once it has polled the count.
 // ------------------------------------------------------------------------------------------------
-constexpr int HF_MAXL = 32, HF_NU = 7 + 6 * HF_MAXL, HF_TS = HF_NU + 2;
+constexpr int HF_MAXL = 32, HF_MAXL2 = 2 * HF_MAXL, HF_NU = 7 + 6 * HF_MAXL, HF_TS = HF_NU + 2;
 struct HiFused {
     int m; const int32_t *meas, *lm_ic, *lm_li, *lm_hi, *lm_type, *lm_off; const double *Hc, *Hl, *z, *h;
     int32_t *hi_meas, *sel_rows, *stats, *mail; int seq;
     int32_t *row_col; float *row_val; double *row_nu;
     const float *P; int ld; float *S; float *W; int ldw; void *Wp; int nst_total; void *Sp; int sp_stride;
     double *params;
+    int max_l;                                    // landmarks this launch may update with: 64 (two panels) when the context's row capacity holds them, else 32
 };
 struct HfSmem {
-    int list[HF_MAXL]; int cnt;
-    int rc[NB][13]; float rv[NB][13]; float nu[NB];
-    int ucol[HF_NU];
-    float T[NB][HF_TS];                           // T[a][k] = (H*P)(a, ucol[k]): the columns S needs
+    int list[HF_MAXL2]; int cnt;
+    int rc[2 * NB][13]; float rv[2 * NB][13]; float nu[2 * NB];
+    int ucol[7 + 6 * HF_MAXL2];
+    union {
+        float T[NB][HF_TS];                       // T[a][k] = (H*P)(row0 + a, column k of the block's list): the columns S needs
+        struct { float S11[NB][NB + 1], H0[NB][NB + 1], H1[NB][NB + 1]; } two;       // two panels: the blocks that wait for the second chain
+    };
 };
+
+// T <- (H*P)(rows row0 .. row0+nrow-1, [pose columns 0..6 | the columns of landmarks lm0 .. lm0+nlm-1 of the list]).  The two image rows of a
+// landmark read the same 13 rows of P: one gather feeds both fma chains (each chain k_ell_HP_build's, term for term).
+// TRI (a diagonal block of S: rows row0.. are the landmarks lm0.. themselves): S is built on and below the diagonal only, which reads T(row, .) at the
+// pose columns and at the columns of landmarks up to the row's own -- the rest of T is neither computed nor read.
+template <bool TRI>
+__device__ __forceinline__ void hf_T_block(HfSmem &hf, const HiFused &a, const int row0, const int nrow, const int lm0, const int nlm)
+{
+    const int nU = 7 + 6 * nlm, np = nrow >> 1;
+    // TRI: row pair q has 13 + 6q columns; pairs q and np-1-q together have C = 20 + 6 np of them, so the items are dealt evenly.
+    // (What bounds this loop is the rate at which a CU takes scattered 4-byte reads -- every workgroup of the launch reads the same lines of P --,
+    //  not their latency: four items' reads in flight per lane measured 8 % slower, 28.6 against 26.5 us for the launch at 32 landmarks.)
+    const int C = TRI ? 20 + 6 * np : nU, nq = TRI ? (np + 1) >> 1 : np;
+    for (int idx = threadIdx.x; idx < nq * C; idx += CH_NTH) {
+        int p = idx / C, k = idx - p * C;
+        if (TRI && k >= 13 + 6 * p) {
+            k -= 13 + 6 * p; p = np - 1 - p;
+            if (2 * p + 1 == np) continue;               // (np odd: the middle pair has no partner)
+        }
+        const int row = row0 + 2 * p;
+        const float *pc = a.P + (k < 7 ? k : hf.ucol[7 + 6 * lm0 + k - 7]);
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 13; ++t) {
+            const float pv = pc[(size_t)hf.rc[row][t] * a.ld];
+            s0 = fmaf(hf.rv[row][t], pv, s0); s1 = fmaf(hf.rv[row + 1][t], pv, s1);
+        }
+        hf.T[2 * p][k] = s0; hf.T[2 * p + 1][k] = s1;
+    }
+}
+// (H*P*H')(ra, rb) out of T (k_ell_G: the sum over the non-zeros of row rb of H*P(ra, .) there); T holds rows row0.. and the landmarks of rows col0..
+__device__ __forceinline__ float hf_S_entry(const HfSmem &hf, const int ra, const int rb, const int row0, const int col0)
+{
+    const int kb = 7 + 6 * ((rb - col0) >> 1);
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 13; ++t) s = fmaf(hf.rv[rb][t], hf.T[ra - row0][t < 7 ? t : kb + t - 7], s);
+    return s;
+}
+// rows row0 .. row0+63 of this workgroup's 64 columns of [H*P | nu] (k_ell_HP_build's 13-term chain; rows >= r are zero)
+template <typename XT>
+__device__ __forceinline__ void hf_own_block(const HfSmem &hf, const HiFused &a, XT &X, const int row0, const int r, const int c0)
+{
+    for (int idx = threadIdx.x; idx < NB * NB / 2; idx += CH_NTH) {
+        const int p = idx >> 6, i = idx & 63, j = c0 + i, row = row0 + 2 * p;
+        float s0 = 0.f, s1 = 0.f;
+        if (row < r) {
+            if (j < a.ld) {
+                const float *pc = a.P + j;
+#pragma unroll
+                for (int t = 0; t < 13; ++t) {
+                    const float pv = pc[(size_t)hf.rc[row][t] * a.ld];
+                    s0 = fmaf(hf.rv[row][t], pv, s0); s1 = fmaf(hf.rv[row + 1][t], pv, s1);
+                }
+            } else if (j == a.ld) { s0 = hf.nu[row]; s1 = hf.nu[row + 1]; }
+        }
+        X[2 * p][i] = s0; X[2 * p + 1][i] = s1;
+    }
+}
+// one 32x32 tile of a 64-deep product on the f32 matrix cores (an exact fma chain over k): acc(r, c) += sum_k A(r, k) B(c, k); this lane feeds
+// row / column (lane & 31) and k = k0 + (lane >> 5); the accumulator layout is the chain's (Mfma<float>::row / col)
+template <typename FA, typename FB>
+__device__ __forceinline__ void hf_mma64(f32x16_t &acc, FA &&A, FB &&B, const int lane)
+{
+    const int cl = lane & 31, kh = lane >> 5;
+#pragma unroll 8
+    for (int k0 = 0; k0 < NB; k0 += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A(cl, k0 + kh), B(cl, k0 + kh), acc, 0, 0, 0);
+}
 
 __global__ __launch_bounds__(CH_NTH) void k_hi_fused(HiFused a)
 {
@@ -699,7 +778,7 @@ __global__ __launch_bounds__(CH_NTH) void k_hi_fused(HiFused a)
             const int in = j < a.m ? flg[j] : 0;
             const unsigned long long mask = __ballot(in);
             const int pos = cnt + __popcll(mask & ((1ull << tid) - 1ull));
-            if (in && pos < HF_MAXL) hf.list[pos] = j;
+            if (in && pos < HF_MAXL2) hf.list[pos] = j;
             if (in && b == 0) a.sel_rows[pos] = j;
             cnt += __popcll(mask);
         }
@@ -707,7 +786,7 @@ __global__ __launch_bounds__(CH_NTH) void k_hi_fused(HiFused a)
     }
     __syncthreads();
     const int cnt = hf.cnt, r = 2 * cnt;
-    const bool here = cnt >= 1 && cnt <= HF_MAXL;
+    const bool here = cnt >= 1 && cnt <= a.max_l;
     if (b == 0 && tid == 0) {
         a.stats[5] = cnt; a.stats[8] = here ? 1 : 0;
         if (cnt == 0) for (int t = 0; t < 16; ++t) a.params[96 + t] = (t % 5 == 0) ? 1.0 : 0.0;      // no update: the pending Jnorm pass is the identity
@@ -717,8 +796,10 @@ __global__ __launch_bounds__(CH_NTH) void k_hi_fused(HiFused a)
         __hip_atomic_store(&a.mail[9], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (!here) return;
+    const bool two = cnt > HF_MAXL;                    // 33 .. 64 landmarks: two panels
+    const int r_pad = two ? 2 * NB : NB;
     // ---- the rows (k_build_rows / k_ell_HP_build): row 2s+c of HI measurement s = [Hc(c,:) | Hl(c,:)] at columns [0..6 | off..off+d-1], nu = z - h
-    if (tid < NB) {
+    if (tid < r_pad) {
         const int row = tid;
         if (row < r) {
             const int i = a.meas[hf.list[row >> 1]], c = row & 1;
@@ -744,53 +825,130 @@ __global__ __launch_bounds__(CH_NTH) void k_hi_fused(HiFused a)
     }
     __syncthreads();
     if (b == 0) {                                  // the rows in their ELL form for whoever reads them after this launch
-        for (int idx = tid; idx < NB * ELLW; idx += CH_NTH) {
+        for (int idx = tid; idx < r_pad * ELLW; idx += CH_NTH) {
             const int row = idx >> 4, t = idx & 15;
             a.row_col[idx] = t < 13 ? hf.rc[row][t] : 0; a.row_val[idx] = t < 13 ? hf.rv[row][t] : 0.f;
         }
     }
-    const int nU = 7 + 6 * cnt;
-    // ---- T = (H*P) at the columns of the selected rows, and this workgroup's own block of [H*P | nu]
-    for (int idx = tid; idx < r * nU; idx += CH_NTH) {
-        const int row = idx / nU, k = idx - row * nU;
-        const float *pc = a.P + hf.ucol[k];
-        float s = 0.f;
-#pragma unroll
-        for (int t = 0; t < 13; ++t) s = fmaf(hf.rv[row][t], pc[(size_t)hf.rc[row][t] * a.ld], s);
-        hf.T[row][k] = s;
-    }
-    if (b >= 1) {
-        const int c0 = (b - 1) * NB;
+    if (!two) {
+        // ---- T = (H*P) at the columns of the selected rows, and this workgroup's own block of [H*P | nu]
+        hf_T_block<true>(hf, a, 0, r, 0, cnt);
+        if (b >= 1) hf_own_block(hf, a, sm.Xs, 0, r, (b - 1) * NB);
+        __syncthreads();
+        // ---- S = H*P*H' + I on and below the diagonal, identity padding
         for (int idx = tid; idx < NB * NB; idx += CH_NTH) {
-            const int row = idx >> 6, i = idx & 63, j = c0 + i;
+            const int ra = idx >> 6, rb = idx & 63;
             float s = 0.f;
-            if (row < r) {
-                if (j < a.ld) {
-                    const float *pc = a.P + j;
-#pragma unroll
-                    for (int t = 0; t < 13; ++t) s = fmaf(hf.rv[row][t], pc[(size_t)hf.rc[row][t] * a.ld], s);
-                } else if (j == a.ld) s = hf.nu[row];
+            if (rb <= ra) {
+                if (ra < r) { s = hf_S_entry(hf, ra, rb, 0, 0); if (ra == rb) s += 1.f; }
+                else s = ra == rb ? 1.f : 0.f;
             }
-            sm.Xs[row][i] = s;
+            sm.Ls[ra][rb] = s;
         }
+        __syncthreads();
+        chol_panel_body<float, false, true, true>(sm, a.S, NB, a.W, a.ldw, 0, 1, a.stats + 6, b, nullptr, 0u, a.Wp, a.nst_total, a.ld, a.Sp, a.sp_stride, r);
+        return;
     }
-    __syncthreads();
-    // ---- S = H*P*H' + I on and below the diagonal (k_ell_G: sum over the non-zeros of row b of H*P(a, .) there), identity padding
-    for (int idx = tid; idx < NB * NB; idx += CH_NTH) {
-        const int ra = idx >> 6, rb = idx & 63;
-        float s = 0.f;
-        if (rb <= ra) {
-            if (ra < r) {
-                const int kb = 7 + 6 * (rb >> 1);
+    // ---- two panels (33 .. 64 landmarks), every workgroup for itself as above.  S = [S00 . ; S10 S11], [H*P | nu] = [H0 ; H1] (this workgroup's
+    //      64 columns).  First chain: S00 = L00 L00' with the identity as right-hand side, which leaves M0 = L00^-1; then, on the f32 matrix cores,
+    //      L10 = S10 M0', W0 = M0 H0, S11 - L10 L10', H1 - L10 W0; second chain: L11 and W1 = L11^-1 (H1 - L10 W0).  Workgroup 0 owns no strip: it
+    //      keeps L in S (stride 128) and reports a non-positive pivot of either chain.
+    {
+        const int r1 = r - NB, c0 = (b - 1) * NB;
+        const bool hasX = b >= 1;
+        const int wave = tid >> 6, lane = tid & 63, wv = wave & 3, w0 = (wv >> 1) * 32, w1 = (wv & 1) * 32;
+        const int lrow = 4 * (lane >> 5), lcol = lane & 31;
+        auto &Ls = sm.Ls; auto &Xs = sm.Xs; auto &Bs = sm.Bs;
+        hf_T_block<true>(hf, a, 0, NB, 0, HF_MAXL);
+        __syncthreads();
+        for (int idx = tid; idx < NB * NB; idx += CH_NTH) {
+            const int ra = idx >> 6, rb = idx & 63;
+            float s = 0.f;
+            if (rb <= ra) { s = hf_S_entry(hf, ra, rb, 0, 0); if (ra == rb) s += 1.f; }
+            Ls[ra][rb] = s;
+        }
+        __syncthreads();
+        hf_T_block<false>(hf, a, NB, r1, 0, HF_MAXL);
+        __syncthreads();
+        for (int idx = tid; idx < NB * NB; idx += CH_NTH) {            // Bs[i][k] = S10(i, k); padding rows are zero
+            const int i = idx >> 6, rb = idx & 63;
+            Bs[i][rb] = NB + i < r ? hf_S_entry(hf, NB + i, rb, NB, 0) : 0.f;
+        }
+        __syncthreads();
+        hf_T_block<true>(hf, a, NB, r1, HF_MAXL, cnt - HF_MAXL);
+        __syncthreads();
+        float s11[(NB * NB + CH_NTH - 1) / CH_NTH];                    // (S11 takes T's place: through registers, across a barrier)
 #pragma unroll
-                for (int t = 0; t < 13; ++t) s = fmaf(hf.rv[rb][t], hf.T[ra][t < 7 ? t : kb + t - 7], s);
-                if (ra == rb) s += 1.f;
-            } else s = ra == rb ? 1.f : 0.f;
+        for (int q = 0; q < (NB * NB + CH_NTH - 1) / CH_NTH; ++q) {
+            const int idx = tid + q * CH_NTH, i = (idx >> 6) & 63, j = idx & 63;
+            float s = 0.f;
+            if (j <= i) {
+                if (NB + i < r) { s = hf_S_entry(hf, NB + i, NB + j, NB, NB); if (i == j) s += 1.f; }
+                else s = i == j ? 1.f : 0.f;
+            }
+            s11[q] = s;
         }
-        sm.Ls[ra][rb] = s;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < (NB * NB + CH_NTH - 1) / CH_NTH; ++q) {
+            const int idx = tid + q * CH_NTH;
+            if (idx < NB * NB) hf.two.S11[idx >> 6][idx & 63] = s11[q];
+        }
+        if (hasX) { hf_own_block(hf, a, hf.two.H0, 0, r, c0); hf_own_block(hf, a, hf.two.H1, NB, r, c0); }
+        for (int idx = tid; idx < NB * NB; idx += CH_NTH) Xs[idx >> 6][idx & 63] = (idx >> 6) == (idx & 63) ? 1.f : 0.f;
+        __syncthreads();
+        {
+            typename ChW<float>::acc_t acc[ChW<float>::NBLK][ChW<float>::NBLK];
+            bool bad = false;
+            chol_chain<float, false, false>(sm, acc, false, true, bad, [](int) {});
+            if (bad && wave == 8 && lane == 0 && b == 0) atomicExch(a.stats + 6, 1);
+        }
+        // (the chain ends behind a barrier)  Ls = L00 (lower triangle), Xs[a][k] = M0(a, k)
+        if (b == 0) {
+            for (int idx = tid; idx < NB * NB; idx += CH_NTH) {
+                const int i = idx >> 6, a2 = idx & 63;
+                a.S[(size_t)i * (2 * NB) + a2] = a2 <= i ? Ls[i][a2] : 0.f;
+                a.S[(size_t)i * (2 * NB) + NB + a2] = 0.f;
+            }
+        }
+        f32x16_t pa;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) pa[e] = 0.f;
+        if (wave < 4) hf_mma64(pa, [&](int c, int k) { return Bs[w0 + c][k]; }, [&](int c, int k) { return Xs[w1 + c][k]; }, lane);                       // L10(i, a) = sum_k S10(i, k) M0(a, k)
+        else if (wave < 8 && hasX) hf_mma64(pa, [&](int c, int k) { return Xs[w0 + c][k]; }, [&](int c, int k) { return hf.two.H0[k][w1 + c]; }, lane);      // W0(a, c) = sum_k M0(a, k) H0(k, c)
+        __syncthreads();
+        if (wave < 4) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Bs[w0 + (e & 3) + 8 * (e >> 2) + lrow][w1 + lcol] = pa[e];
+        } else if (wave < 8 && hasX) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) hf.two.H0[w0 + (e & 3) + 8 * (e >> 2) + lrow][w1 + lcol] = pa[e];
+        }
+        __syncthreads();
+        // the second chain's blocks: D = S11 - L10 L10' over L00 (the tile above the diagonal is dead), X = H1 - L10 W0 over M0
+        if (wave < 4) {
+            if (wv != 1) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) pa[e] = hf.two.S11[w0 + (e & 3) + 8 * (e >> 2) + lrow][w1 + lcol];
+                hf_mma64(pa, [&](int c, int k) { return -Bs[w0 + c][k]; }, [&](int c, int k) { return Bs[w1 + c][k]; }, lane);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) Ls[w0 + (e & 3) + 8 * (e >> 2) + lrow][w1 + lcol] = pa[e];
+            }
+        } else if (wave < 8 && hasX) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) pa[e] = hf.two.H1[w0 + (e & 3) + 8 * (e >> 2) + lrow][w1 + lcol];
+            hf_mma64(pa, [&](int c, int k) { return -Bs[w0 + c][k]; }, [&](int c, int k) { return hf.two.H0[k][w1 + c]; }, lane);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Xs[w0 + (e & 3) + 8 * (e >> 2) + lrow][w1 + lcol] = pa[e];
+        }
+        // row block 0 of W leaves (f32 rows + planes) while the second chain runs; workgroup 0: L10
+        if (hasX) chol_store_w_strip<float>(hf.two.H0, a.W, a.ldw, 0, c0, a.Wp, a.nst_total, a.ld);
+        else {
+            for (int idx = tid; idx < NB * NB; idx += CH_NTH) a.S[(size_t)(NB + (idx >> 6)) * (2 * NB) + (idx & 63)] = Bs[idx >> 6][idx & 63];
+        }
+        __syncthreads();
+        chol_panel_body<float, false, true, true>(sm, a.S, 2 * NB, a.W, a.ldw, 1, 2, a.stats + 6, b, nullptr, 0u, a.Wp, a.nst_total, a.ld, a.Sp, a.sp_stride, r1);
     }
-    __syncthreads();
-    chol_panel_body<float, false, true, true>(sm, a.S, NB, a.W, a.ldw, 0, 1, a.stats + 6, b, nullptr, 0u, a.Wp, a.nst_total, a.ld, a.Sp, a.sp_stride, r);
 }
 
 
@@ -1454,7 +1612,10 @@ __global__ __launch_bounds__(256) void k_downdate_b3(float *__restrict__ P, int 
 {
     __shared__ __attribute__((aligned(16))) bf16x8_t smem[B3_NBUF * 2 * B3_GRAN];       // 24 KB per ring slot: [slot][A | B][plane][fragment][lane]
     static_assert(sizeof(smem) >= 4 * 32 * 33 * sizeof(float) && sizeof(smem) >= sizeof(double) * (16 * 64 + 4), "patches and riders borrow the ring");
-    if (xu.gate != nullptr && xu.gate[8] != 1) return;          // the fused HI update in front found nothing to do (or too much: the host follows up)
+    if (xu.gate != nullptr) {
+        if (xu.gate[8] != 1) return;                            // the fused HI update in front found nothing to do (or too much: the host follows up)
+        nst = 2 * xu.gate[5] > NB ? 8 : 4;                      // one panel of rows (four k-stages) up to 32 landmarks, two up to 64
+    }
     if ((int)blockIdx.x >= xu.n_tiles) {            // riders, as in k_downdate_1t
         __builtin_amdgcn_s_setprio(3);
         const int nx = xu.nx, rb = blockIdx.x - xu.n_tiles;
@@ -1755,6 +1916,13 @@ bool hi_fused_usable(const pre3_ctx *c)
     return env != 0 && c->dtype == PRE3_F32 && c->k9_b3 && c->Wp != nullptr && c->Sp != nullptr && c->m > 0 && c->m <= 16384 && c->rcap >= NB && c->N > 0;
 }
 
+// landmarks k_hi_fused updates with on its own: 64 (two panels) when the row capacity holds them (PRE3_HI_FUSED_TWO=0: one panel, A/B)
+int hi_fused_max(const pre3_ctx *c)
+{
+    static const int two_env = getenv("PRE3_HI_FUSED_TWO") ? atoi(getenv("PRE3_HI_FUSED_TWO")) : 1;
+    return two_env != 0 && c->rcap >= 2 * NB ? HF_MAXL2 : HF_MAXL;
+}
+
 int launch_hi_fused(pre3_ctx *c, int32_t seq)
 {
     HiFused a{};
@@ -1764,8 +1932,9 @@ int launch_hi_fused(pre3_ctx *c, int32_t seq)
     a.row_col = c->row_col; a.row_val = (float *)c->row_val; a.row_nu = c->row_nu;
     a.P = (const float *)c->P; a.ld = c->ld; a.S = (float *)c->Smat; a.W = (float *)c->W; a.ldw = c->ldw;
     a.Wp = c->Wp; a.nst_total = c->rcap / B3_BK; a.Sp = c->Sp; a.sp_stride = c->rcap / NB; a.params = c->pred_params;
+    a.max_l = hi_fused_max(c);
     hipLaunchKernelGGL(k_hi_fused, dim3(1 + c->ldw / NB), dim3(CH_NTH), 0, c->stream, a);
-    // the down-date of that update (one panel: four k-stages), the x-update riding along; every workgroup leaves at once unless stats[8] == 1
+    // the down-date of that update (one or two panels: four or eight k-stages, read on the device), the x-update riding along; every workgroup leaves at once unless stats[8] == 1
     const int nx = ceil_div(c->n, 64);
     XUpd xu{ c->n_tiles128, c->n, 0, c->x_kk, c->x_kk, c->pred_params, c->stats, nx };
     xu.wt = k9_write_through();

@@ -30,7 +30,9 @@ VARIANTS = [
 
 
 def _run(env_extra, tail="0", dump=None):
-    env = dict(os.environ, PRE3_TAIL=tail, **env_extra)
+    # (PRE3_HI_FUSED_TWO=0: 33 .. 64 rescued landmarks take the host's general path in every variant -- k_hi_fused's two-panel path is another fp32
+    #  evaluation of the same update (explicit inverse of the first diagonal block), compared to rounding in tests/test_gpu_hi_fused.py)
+    env = dict(os.environ, PRE3_TAIL=tail, PRE3_HI_FUSED_TWO="0", **env_extra)
     if dump:
         env["VARIANT_DUMP"] = dump
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_worker.py")], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
