@@ -8,6 +8,7 @@
 
 #include <chrono>
 #include "pre3_internal.h"
+#include "pre3_geomdev.h"
 #include <mutex>
 #include "pre3_cholp.h"
 
@@ -23,6 +24,7 @@ void set_error(const char *fmt, ...)
 
 // launchers defined in the kernel files
 int launch_predict_impl(pre3_ctx *c, const double u[7], bool with_projection = false, size_t inbox_n16 = 0, int32_t inbox_seq = 0);
+IcMatchRide ic_match_ride(const pre3_ctx *c);
 int launch_inbox_pull(pre3_ctx *c, const void *src_host_mapped, void *dst_dev, size_t n16, int32_t seq, int slot = 10);
 int launch_slice_prepare(pre3_ctx *c, const void *src_host_mapped, size_t n16, int32_t seq, int n_zero, int k, int lo, int hi, int tag);   // (either direction: 16-byte words between device memory and a mapped pinned block, then `seq` into mailbox word `slot`)
 int launch_window_gate(pre3_ctx *c, int M, const int32_t *pred_idx_dev, const int32_t *k1_dev, const double *zc_dev, int strict, int32_t *accept_dev);
@@ -389,6 +391,7 @@ int pre3_get_option(pre3_ctx *c, int option, int *value_out)
     case PRE3_OPT_K9_BF16X3: *value_out = c->k9_b3 ? 1 : 0; return PRE3_OK;
     case PRE3_OPT_CHOL_PERSIST: *value_out = cholp_usable(c, 1) ? 1 : 0; return PRE3_OK;
     case PRE3_OPT_IC_RANKED: *value_out = c->ic_last_ranked ? 1 : 0; return PRE3_OK;
+    case PRE3_OPT_IC_ROUTE: *value_out = c->ic_route; return PRE3_OK;
     case PRE3_OPT_K9_OVERLAP: *value_out = c->k9_overlap ? 1 : 0; return PRE3_OK;
     case PRE3_OPT_STEP_TAIL: *value_out = (c->step_tail && c->tail_yp != nullptr) ? 1 : 0; return PRE3_OK;
     default: set_error("pre3_get_option: unknown option %d", option); return PRE3_E_ARG;
@@ -741,7 +744,7 @@ int pre3_set_scan(pre3_ctx *c, int K2, const double *descriptor_raw, const doubl
         c->scan_desc = c->scan_pos = nullptr; c->ic_pb = c->ic_ps = nullptr; c->ic_pa = nullptr; c->scan_cap = 0;
         const int cap = round_up(K2, 256);
         PRE3_TRY(dmalloc(&c->scan_desc, (size_t)cap * DESC_DIM)); PRE3_TRY(dmalloc(&c->scan_pos, (size_t)cap * 4));
-        const size_t np = (size_t)(cap / 64) * c->capN;
+        const size_t np = (size_t)(cap / 32) * c->capN;             // (column tiles of 32 keypoints: the fused route's; the 64-wide tiles use half)
         PRE3_TRY(dmalloc(&c->ic_pb, np)); PRE3_TRY(dmalloc(&c->ic_ps, np)); PRE3_TRY(dmalloc(&c->ic_pa, np));
         c->scan_cap = cap;
     }
@@ -793,13 +796,21 @@ int pre3_ic_search(pre3_ctx *c, double thresh, int strict_reference, int32_t *n_
     }
     // search_IC_matches.m:31-44: h, H and S for every landmark at the prediction
     PRE3_CHECK(c->have_cam, PRE3_E_STATE, "pre3_ic_search: camera not set");
-    if (N) PRE3_TRY(launch_project_innovation(c, PRE3_X_K_KM1, 1, 0, 0.0, true, true));      // (also clears individually_compatible of every landmark)
+    const bool fused = ic_search_fused_applies(c);
+    const IcMatchRide ride = fused ? ic_match_ride(c) : IcMatchRide{};          // the fused route's matcher tiles ride in the projection's launch
+    if (N) PRE3_TRY(launch_project_innovation(c, PRE3_X_K_KM1, 1, 0, 0.0, true, true, ride.n_blocks ? &ride : nullptr));      // (also clears individually_compatible of every landmark)
     c->projected = true; c->innovated = true;
-    PRE3_TRY(launch_ic_search(c, thresh, strict_reference));
     // the result block [counts | meas | pairs | z] is written into mapped pinned memory by the device itself and announced through the mailbox:
     // no DMA-engine copy, no stream synchronisation (the host polls one word)
     const size_t capN = (size_t)c->capN, blk_bytes = sizeof(int32_t) * (4 + 4 * capN) + sizeof(double) * 2 * capN;
-    PRE3_TRY(launch_inbox_pull(c, c->ic_counts, c->ic_result_host_dev, (blk_bytes + 15) / 16, ++c->seq_ic, 12));
+    if (fused) {
+        // the reference's real sizes: exact matcher + (stack, merge, gate, refresh, result block) as two launches (pre3_match.hip)
+        c->ic_last_ranked = false;
+        PRE3_TRY(launch_ic_search_fused(c, thresh, strict_reference, ++c->seq_ic, 12, ride.n_blocks > 0));
+    } else {
+        PRE3_TRY(launch_ic_search(c, thresh, strict_reference));
+        PRE3_TRY(launch_inbox_pull(c, c->ic_counts, c->ic_result_host_dev, (blk_bytes + 15) / 16, ++c->seq_ic, 12));
+    }
     PRE3_TRY(wait_mail(c, 12, c->seq_ic));
     const int32_t *blk_p = static_cast<const int32_t *>(c->ic_result_host);
     std::vector<int32_t> blk(blk_p, blk_p + (4 + 4 * capN + 4 * capN));

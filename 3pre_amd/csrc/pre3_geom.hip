@@ -274,13 +274,20 @@ __global__ __launch_bounds__(256) void k_project_innovation(int N, const int32_t
                                                             const double *__restrict__ z, const int32_t *__restrict__ ic,
                                                             const int32_t *__restrict__ li, int32_t *__restrict__ hi, double *__restrict__ S,
                                                             int32_t *__restrict__ has_S, int32_t *__restrict__ clear, int n_clear, HiArgs ha,
-                                                            int32_t *__restrict__ clear2, int n_clear2)
+                                                            int32_t *__restrict__ clear2, int n_clear2, IcMatchRide mr)
 {
+    // pre3_ic_search (round 5): the small-problem matcher's tiles are extra workgroups of this launch -- they read the descriptor bank and the scan,
+    // which nothing here touches
+    const int n_main = gridDim.x - mr.n_blocks;
+    if (mr.n_blocks > 0) {
+        __shared__ double Qs[ICS_T][ICS_LD], Bs[ICS_T][ICS_LD];
+        if ((int)blockIdx.x >= n_main) { ic_match_tile(mr, blockIdx.x - n_main, Qs, Bs); return; }
+    }
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     // a step's IC search precedes its measurements: clear the inlier flags of the previous frame here (n_clear = 0 otherwise)
-    for (int t = gt; t < n_clear; t += gridDim.x * blockDim.x) clear[t] = 0;
+    for (int t = gt; t < n_clear; t += n_main * blockDim.x) clear[t] = 0;
     // (pre3_ic_search: individually_compatible of every landmark -- a hipMemsetAsync of 4 N bytes went out as three fill kernels, 15 us)
-    for (int t = gt; t < n_clear2; t += gridDim.x * blockDim.x) clear2[t] = 0;
+    for (int t = gt; t < n_clear2; t += n_main * blockDim.x) clear2[t] = 0;
     // the block's 16 landmarks are projected by the first 16 lanes of its first wave (one wave runs the long fp64 code, not four)
     if (threadIdx.x < 16 && (int)(blockIdx.x * 16 + threadIdx.x) < N) project_one(blockIdx.x * 16 + threadIdx.x, lm_type, lm_off, x, cam, clear_first, h, has_h, Hc, Hl);
     __threadfence_block();
@@ -1016,21 +1023,22 @@ int launch_project(pre3_ctx *c, int which, int clear_first)
 
 
 // project + innovation (+ the HI collection in mode 1) with one kernel boundary less
-int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode, double chi2, bool collect, bool clear_ic)
+int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode, double chi2, bool collect, bool clear_ic, const IcMatchRide *ride)
 {
+    const IcMatchRide mr = ride ? *ride : IcMatchRide{};
     const double *x = which == PRE3_X_K_K ? c->x_kk : c->x_km1;
     int32_t *clr = (int32_t *)((unsigned char *)c->inbox_dev + c->off_flags);
     const int n_clr = mode == 0 ? (int)(c->flags_bytes / sizeof(int32_t)) : 0;
     HiArgs ha{};
     if (mode == 1 && collect) ha = HiArgs{ hi_fuse() ? 1 : 0, c->m, ++c->seq_collect, c->meas, c->hi_meas, c->sel_rows, c->stats, c->mail_dev, c->chol_arrive + 2 };
-    dim3 g(ceil_div(c->N * 16, 256)), b(256);
+    dim3 g(ceil_div(c->N * 16, 256) + mr.n_blocks), b(256);
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_project_innovation<double>, g, b, 0, c->stream, c->N, c->lm.type, c->lm.off, x, to_camd(c->cam), clear_first,
                            (const double *)c->P, c->ld, c->lm.Hc, c->lm.Hl, c->lm.has_h, mode, chi2, c->lm.h, c->lm.z, c->lm.ic, c->lm.li,
-                           c->lm.hi, c->lm.S, c->lm.has_S, clr, n_clr, ha, clear_ic ? c->lm.ic : nullptr, clear_ic ? c->N : 0),
+                           c->lm.hi, c->lm.S, c->lm.has_S, clr, n_clr, ha, clear_ic ? c->lm.ic : nullptr, clear_ic ? c->N : 0, mr),
         hipLaunchKernelGGL(k_project_innovation<float>, g, b, 0, c->stream, c->N, c->lm.type, c->lm.off, x, to_camd(c->cam), clear_first,
                            (const float *)c->P, c->ld, c->lm.Hc, c->lm.Hl, c->lm.has_h, mode, chi2, c->lm.h, c->lm.z, c->lm.ic, c->lm.li,
-                           c->lm.hi, c->lm.S, c->lm.has_S, clr, n_clr, ha, clear_ic ? c->lm.ic : nullptr, clear_ic ? c->N : 0));
+                           c->lm.hi, c->lm.S, c->lm.has_S, clr, n_clr, ha, clear_ic ? c->lm.ic : nullptr, clear_ic ? c->N : 0, mr));
     PRE3_HIP(hipGetLastError());
     if (mode == 1 && collect && !ha.fuse) PRE3_TRY(launch_collect_hi(c, ha));
     return PRE3_OK;

@@ -282,4 +282,107 @@ __device__ __forceinline__ void innov_ride_block(const InnovRide &ir, int blk)
 
 ProjRide make_proj_ride(pre3_ctx *c, int which, int clear_first, int slot, int n_producers);   // pre3_geom.hip
 
+
+// ---- (best, second, first arg) of siftmatch.c:110-116's scan, and the IC search's small-problem matcher tile (pre3_match.hip, k_ic_match_small; it
+// also rides in k_project_innovation's launch) --------------------------------------------------------------------------------------------
+template <typename ACC> struct Best3 { ACC best, second; int k; };
+
+template <typename ACC> __device__ inline ACC acc_max();
+template <> __device__ inline double acc_max<double>() { return INFINITY; }
+template <> __device__ inline float acc_max<float>() { return INFINITY; }
+template <> __device__ inline int acc_max<int>() { return 0x7fffffff; }
+
+// merge two scan states (order independent; ties -> lowest index)
+template <typename ACC>
+__device__ inline void merge3(ACC &best, ACC &second, int &k, ACC ob, ACC os, int ok)
+{
+    if (ok < 0) return;
+    if (k < 0) { best = ob; second = os; k = ok; return; }
+    if (ob < best || (ob == best && ok < k)) {
+        ACC ns = os < best ? os : best;
+        best = ob; k = ok; second = ns;
+    } else {
+        ACC ns = ob < second ? ob : second;
+        second = ns;
+    }
+}
+
+template <typename ACC>
+__device__ inline void push3(ACC &best, ACC &second, int &k, ACC v, int idx)
+{
+    // siftmatch.c:110-116 for increasing idx
+    if (v < best) { second = best; best = v; k = idx; }
+    else if (v < second) { second = v; }
+}
+
+
+constexpr int ICS_T = 32, ICS_LD = DESC_DIM + 1;          // tile edge; LDS row stride in doubles (odd: the 16 column pairs of a wave hit 16 different banks)
+struct IcMatchRide {
+    int n_blocks, ntn, N, K2;                     // n_blocks = ntn * ceil(N / 32) tiles, column tile fastest
+    const double *bank, *scan;
+    const int32_t *has_h;                         // not null: tiles without a predicted landmark leave at once (a launch of its own, behind the projection)
+    double *pb, *ps; int32_t *pa;                 // partials [column tile][landmark]
+};
+// siftmatch.c:97-116 exactly (every pair's bins in order, no contraction) for 32 landmarks x 32 keypoints; 256 threads, 2 x 2 pairs per thread
+__device__ __forceinline__ void ic_match_tile(const IcMatchRide &r, const int tile, double (*Qs)[ICS_LD], double (*Bs)[ICS_LD])
+{
+#pragma clang fp contract(off)
+    const int tid = threadIdx.x, q0 = (tile / r.ntn) * ICS_T, k0 = (tile % r.ntn) * ICS_T, N = r.N, K2 = r.K2;
+    if (r.has_h != nullptr) {
+        const int any = tid < ICS_T && q0 + tid < N ? r.has_h[q0 + tid] != 0 : 0;
+        if (!__syncthreads_or(any)) return;                // nothing predicted among these 32 landmarks: their partials are never read
+    }
+    {   // the tile's 32 + 32 descriptors, whole: 8 lanes per descriptor, 16 bytes per lane and load, every load in flight before the first LDS store
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        const int lq = tid >> 3, l8 = tid & 7;
+        const bool qok = q0 + lq < N, bok = k0 + lq < K2;
+        const d2_t *qs = reinterpret_cast<const d2_t *>(r.bank + (size_t)(qok ? q0 + lq : 0) * DESC_DIM), *bs = reinterpret_cast<const d2_t *>(r.scan + (size_t)(bok ? k0 + lq : 0) * DESC_DIM);
+        d2_t qv[8], bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qv[e] = qs[l8 + 8 * e]; bv[e] = bs[l8 + 8 * e]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int bin = 2 * (l8 + 8 * e);
+            Qs[lq][bin] = qok ? qv[e][0] : 0.0; Qs[lq][bin + 1] = qok ? qv[e][1] : 0.0;
+            Bs[lq][bin] = bok ? bv[e][0] : 0.0; Bs[lq][bin + 1] = bok ? bv[e][1] : 0.0;
+        }
+    }
+    __syncthreads();
+    const int tq = tid >> 4, tk = tid & 15;                // queries 2 tq, 2 tq + 1 against columns 2 tk, 2 tk + 1
+    double acc[2][2] = { { 0.0, 0.0 }, { 0.0, 0.0 } };
+#pragma unroll 8
+    for (int bin = 0; bin < DESC_DIM; ++bin) {
+        const double q[2] = { Qs[2 * tq][bin], Qs[2 * tq + 1][bin] }, b[2] = { Bs[2 * tk][bin], Bs[2 * tk + 1][bin] };
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const double delta = q[a] - b[j];
+                const double sq = delta * delta;
+                acc[a][j] = acc[a][j] + sq;
+            }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        double best = acc_max<double>(), second = acc_max<double>();
+        int bk = -1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k2 = k0 + 2 * tk + j;
+            if (k2 < K2) push3(best, second, bk, acc[a][j], k2);
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            const double ob = __shfl_xor(best, o, 16), os = __shfl_xor(second, o, 16);
+            const int ok = __shfl_xor(bk, o, 16);
+            merge3(best, second, bk, ob, os, ok);
+        }
+        const int q = q0 + 2 * tq + a;
+        if (tk == 0 && q < N) {
+            const size_t o = (size_t)(tile % r.ntn) * N + q;           // [column tile][landmark]
+            r.pb[o] = best; r.ps[o] = second; r.pa[o] = bk;
+        }
+    }
+}
+
 }  // namespace pre3

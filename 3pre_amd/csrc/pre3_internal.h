@@ -164,6 +164,7 @@ struct pre3_ctx {
     void *ic_result_host = nullptr, *ic_result_host_dev = nullptr; int32_t seq_ic = 0;    // the IC search's result block in mapped pinned memory: written by the device, announced through mailbox word 12
     int32_t *ic_pred = nullptr, *ic_counts = nullptr, *ic_arg = nullptr, *ic_pairs = nullptr, *ic_newk2 = nullptr; double *ic_best = nullptr, *ic_second = nullptr;
     int32_t *bank_src = nullptr;
+    int ic_route = 0;                             // the last pre3_ic_search's matcher: 0 exact tiled kernel, 1 ranked (matrix cores), 2 fused small-problem route
     bool ic_last_ranked = false;                  // the last pre3_ic_search matched on the matrix cores (PRE3_OPT_IC_RANKED)
     void *ic_rank = nullptr; bool bank_ok = false;   // the scan packed for the matrix-core matcher (pre3_match.hip: IcRank); every bank descriptor inside its bounds
     double *ic_pb = nullptr, *ic_ps = nullptr; int32_t *ic_pa = nullptr;     // per (column tile, landmark) partials of the tiled matcher [scan_cap/64][capN]
@@ -222,6 +223,8 @@ int comm_device(void *comm);
 
 // ---- IC search (pre3_match.hip)
 int launch_ic_search(pre3_ctx *c, double thresh, int strict);
+bool ic_search_fused_applies(const pre3_ctx *c);      /* N * K2 <= 2^20 pairs, N <= 4096, K2 <= 2048: the two-launch route */
+int launch_ic_search_fused(pre3_ctx *c, double thresh, int strict, int32_t seq, int slot, bool matched);      /* matched: the matcher rode in the projection's launch */
 int launch_bank_gather(pre3_ctx *c, int N_new, const int32_t *src_host);
 int ic_rank_set_scan(pre3_ctx *c, bool in_bounds);
 int launch_pull(pre3_ctx *c, const void *pinned_host, void *dst_dev, size_t bytes);      // pinned host block -> device, by a kernel (pre3_api.hip)
@@ -231,7 +234,8 @@ constexpr int DESC_DIM = 128;
 // ---- geometry / RANSAC kernels (pre3_geom.hip)
 int launch_project(pre3_ctx *c, int which, int clear_first);
 int launch_innovation(pre3_ctx *c, int mode /*0: S=HPH'+I for predicted; 1: rescue gate + HI list*/, double chi2, bool clear_flags = false, bool collect = true /* mode 1: the HI list follows (k_collect_hi) */);
-int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode, double chi2, bool collect = true, bool clear_ic = false);
+struct IcMatchRide;
+int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode, double chi2, bool collect = true, bool clear_ic = false, const IcMatchRide *ride = nullptr);
 int launch_update_x(pre3_ctx *c, int which_prior, int r);
 int launch_jnorm(pre3_ctx *c, int which);
 

@@ -15,38 +15,9 @@
 #include <vector>
 
 #include "pre3_internal.h"
+#include "pre3_geomdev.h"
 
 namespace pre3 {
-
-template <typename ACC> struct Best3 { ACC best, second; int k; };
-
-template <typename ACC> __device__ inline ACC acc_max();
-template <> __device__ inline double acc_max<double>() { return INFINITY; }
-template <> __device__ inline float acc_max<float>() { return INFINITY; }
-template <> __device__ inline int acc_max<int>() { return 0x7fffffff; }
-
-// merge two scan states (order independent; ties -> lowest index)
-template <typename ACC>
-__device__ inline void merge3(ACC &best, ACC &second, int &k, ACC ob, ACC os, int ok)
-{
-    if (ok < 0) return;
-    if (k < 0) { best = ob; second = os; k = ok; return; }
-    if (ob < best || (ob == best && ok < k)) {
-        ACC ns = os < best ? os : best;
-        best = ob; k = ok; second = ns;
-    } else {
-        ACC ns = ob < second ? ob : second;
-        second = ns;
-    }
-}
-
-template <typename ACC>
-__device__ inline void push3(ACC &best, ACC &second, int &k, ACC v, int idx)
-{
-    // siftmatch.c:110-116 for increasing idx
-    if (v < best) { second = best; best = v; k = idx; }
-    else if (v < second) { second = v; }
-}
 
 // generic exact kernel: block = one query column; lanes stride over database columns.
 // L1: ND x K1, L2: ND x K2 column-major.  Outputs per query: best, second (as double), arg (global index).
@@ -1333,7 +1304,7 @@ __global__ void k_bank_gather(const int32_t *__restrict__ src, const double *__r
 // descriptors in map order) is gathered from the bank through the device-side list and packed per call; k_rank_tiled<0/1> + k_rank_tail then
 // give (best, second, arg) bit-identical to the exact kernel's (tests/test_gpu_icsearch.py runs both).  Descriptors outside the ranked
 // route's bounds (NaN / Inf, |x| > 2^60, 0 < |x| < 2^-40), small problems and PRE3_IC_RANK=0 keep the exact VALU kernel.
-struct IcRank { RankMatch r; int K1cap = 0, K2 = -1; bool scan_ok = false; };
+struct IcRank { RankMatch r; int K1cap = 0, K2 = -1; bool scan_ok = false, packed = false; };       // scan_ok: inside the ranked route's bounds; packed: its planes exist
 
 // des1[q] = bank[pred[q]] (rows beyond the device-side count repeat older list entries: in range, never read back)
 __global__ __launch_bounds__(DESC_DIM) void k_ic_gather_q(const int32_t *__restrict__ pred, const double *__restrict__ bank, double *__restrict__ des1)
@@ -1341,6 +1312,7 @@ __global__ __launch_bounds__(DESC_DIM) void k_ic_gather_q(const int32_t *__restr
     des1[(size_t)blockIdx.x * DESC_DIM + threadIdx.x] = bank[(size_t)pred[blockIdx.x] * DESC_DIM + threadIdx.x];
 }
 
+static bool ic_fused_usable(const pre3_ctx *c);
 void ic_rank_free(pre3_ctx *c) { delete static_cast<IcRank *>(c->ic_rank); c->ic_rank = nullptr; }
 
 // the scan has just been uploaded: pack it for the ranked route (or note that it cannot take it)
@@ -1371,14 +1343,17 @@ int ic_rank_set_scan(pre3_ctx *c, bool in_bounds)
     }
     RankMatch &r = ic->r;
     const int K2p = round_up(K2, 128);
+    ic->K2 = K2;
+    ic->scan_ok = in_bounds;
+    ic->packed = false;
+    if (ic_fused_usable(c)) return PRE3_OK;             // the search will take the two-launch route: no planes needed (were a fill + k_rank_pack, 12 us per frame)
     // (on the context's stream, behind the upload; whether the scan is inside the ranked route's bounds is the caller's host-side check of
     // the same descriptors -- k_rank_pack's own flag word is not read back)
     PRE3_HIP(hipMemsetAsync(r.fl.p, 0, sizeof(int) * 4, c->stream));
     hipLaunchKernelGGL((k_rank_pack<double>), dim3(K2p * 8 / 256), dim3(256), 0, c->stream, DESC_DIM, K2, K2p, (const double *)c->scan_desc, (v4i *)r.dh.p, (v4i *)r.dl.p,
                        (float *)r.nU.p, (float *)r.nL.p, (float *)r.nd.p, (int8_t *)r.m.B.p, (int *)r.m.nb.p, (int *)r.fl.p);
     PRE3_HIP(hipGetLastError());
-    ic->K2 = K2;
-    ic->scan_ok = in_bounds;
+    ic->packed = true;
     return PRE3_OK;
 }
 
@@ -1387,8 +1362,188 @@ static bool ic_rank_usable(const pre3_ctx *c)
     const char *e = getenv("PRE3_IC_RANK");                    // 0: the exact VALU kernel (A/B, tests); read per call
     if (e && atoi(e) == 0) return false;
     const IcRank *ic = static_cast<const IcRank *>(c->ic_rank);
-    return ic && ic->scan_ok && ic->K2 == c->scan_K2 && c->bank_ok && c->N <= ic->K1cap && rank_applies<double>(DESC_DIM, c->N, c->scan_K2);
+    return ic && ic->scan_ok && ic->packed && ic->K2 == c->scan_K2 && c->bank_ok && c->N <= ic->K1cap && rank_applies<double>(DESC_DIM, c->N, c->scan_K2);
 }
+
+// ---- the fused route (round 5): at the reference's real sizes (N = 500 landmarks against a 600-keypoint scan: 3e5 pairs, 1.2e8 fp64 operations) the
+// rank / tail machinery and the bookkeeping launches around it were the cost -- ten launches, 62 us of kernels.  Two launches instead:
+//   k_ic_match_small  siftmatch.c:97-116 exactly (every pair's bins in order, no contraction), a 32 x 32 pair tile per workgroup so that the chip's
+//                     fp64 vector pipes all have work (the 64 x 64 tiles of k_match_exact_tiled are 80 workgroups here); every landmark of the map is a
+//                     query -- the stacking of matching_sift_based.m:108-114 needs a prefix over the map and is left to the gate, tiles without a
+//                     predicted landmark leave at once; partial (best, second, arg) per (column tile, landmark);
+//   k_ic_gate_fused   ONE workgroup: index_in_info by ballot compaction, the column tiles merged in scan order, Lowe's test, the window gate with its
+//                     rank quirk (k_ic_gate's logic), the accepted landmarks' descriptor refresh (matching_sift_based.m:135), and the result block
+//                     written straight into the host's mapped block and announced through the mailbox (was k_ic_stack, k_match_reduce_f / the five
+//                     launches of the ranked route, k_ic_gate, k_ic_refresh, k_inbox_pull).
+__global__ __launch_bounds__(256) void k_ic_match_small(IcMatchRide r)
+{
+    __shared__ double Qs[ICS_T][ICS_LD], Bs[ICS_T][ICS_LD];
+    ic_match_tile(r, blockIdx.x, Qs, Bs);
+}
+
+constexpr int ICG_NTH = 1024, ICG_MAXN = 4096, ICG_MAXT = 64;
+struct IcGateF {
+    int N, ntn, capN, strict; float thresh;
+    const int32_t *has_h; const double *pb, *ps; const int32_t *pa;
+    const double *pos, *h, *S; const int32_t *has_S;
+    double *z; int32_t *ic;
+    const double *scan_desc; double *bank;
+    int32_t *res;                                   // the host's mapped result block [counts 4 | meas capN | pairs 3 capN | z 2 capN doubles]
+    int32_t *counts_dev;                            // the device's copy of the counts (what k_ic_gate leaves)
+    int32_t *mail; int32_t seq; int slot;
+};
+__global__ __launch_bounds__(ICG_NTH) void k_ic_gate_fused(IcGateF a)
+{
+    __shared__ int s_pred[ICG_MAXN], s_lm[ICG_MAXN], s_k2[ICG_MAXN];
+    __shared__ int s_cnt[ICG_NTH / 64], s_cnt2[ICG_NTH / 64];
+    constexpr int NW = ICG_NTH / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int32_t *meas_out = a.res + 4, *pairs = a.res + 4 + a.capN;
+    double *z_out = reinterpret_cast<double *>(a.res + 4 + 4 * (size_t)a.capN);
+    // index_in_info (matching_sift_based.m:108-114): the predicted landmarks in map order
+    int npred = 0;
+    for (int i0 = 0; i0 < a.N; i0 += ICG_NTH) {
+        const int i = i0 + tid;
+        const int f = i < a.N && a.has_h[i] != 0;
+        const unsigned long long b = __ballot(f);
+        if (lane == 0) s_cnt[wv] = __popcll(b);
+        __syncthreads();
+        int off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const int cw = s_cnt[w]; if (w < wv) off += cw; tot += cw; }
+        if (f) s_pred[npred + off + __popcll(b & ((1ull << lane) - 1))] = i;
+        npred += tot;
+        __syncthreads();
+    }
+    // Lowe's test (siftmatch.c:122, in float) on the merged column tiles, then the window gate of matching_sift_based.m:119-133 on the i-th match
+    // (quirk Q5 needs the RANK of the match: S is read from index_in_info(i))
+    int base = 0, m = 0;
+    for (int p0 = 0; p0 < npred; p0 += ICG_NTH) {
+        const int k1 = p0 + tid;
+        int ok = 0, k2 = -1, lm = 0;
+        if (k1 < npred) {
+            lm = s_pred[k1];
+            double best = acc_max<double>(), second = acc_max<double>();
+            for (int t0 = 0; t0 < a.ntn; t0 += 8) {             // eight tiles' partials in flight, merged in scan order
+                double ob[8], os[8]; int oa[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const size_t o = (size_t)(t0 + u < a.ntn ? t0 + u : t0) * a.N + lm;
+                    ob[u] = a.pb[o]; os[u] = a.ps[o]; oa[u] = t0 + u < a.ntn ? a.pa[o] : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) merge3(best, second, k2, ob[u], os[u], oa[u]);
+            }
+            ok = k2 >= 0 && a.thresh * (float)best <= (float)second;
+        }
+        const unsigned long long b = __ballot(ok);
+        if (lane == 0) s_cnt[wv] = __popcll(b);
+        __syncthreads();
+        int off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const int cw = s_cnt[w]; if (w < wv) off += cw; tot += cw; }
+        int acc = 0;
+        double px = 0, py = 0;
+        if (ok) {
+            const int c = base + off + __popcll(b & ((1ull << lane) - 1));
+            const int slm = a.strict ? s_pred[c] : lm;
+            const double half = a.has_S[slm] ? ceil(3 * sqrt(a.S[4 * slm])) : 40.0;
+            px = a.pos[4 * (size_t)k2]; py = a.pos[4 * (size_t)k2 + 1];
+            const double dx = px - a.h[2 * lm], dy = py - a.h[2 * lm + 1];
+            acc = sqrt(dx * dx + dy * dy) <= half;
+            pairs[3 * c] = k1; pairs[3 * c + 1] = k2; pairs[3 * c + 2] = acc;
+            if (acc) { a.ic[lm] = 1; a.z[2 * lm] = px; a.z[2 * lm + 1] = py; }
+        }
+        base += tot;
+        // accepted matches arrive in increasing landmark order (the list is sorted): the measurement list for the host, and for the refresh below
+        const unsigned long long ab = __ballot(acc);
+        if (lane == 0) s_cnt2[wv] = __popcll(ab);
+        __syncthreads();
+        int off2 = 0, tot2 = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const int cw = s_cnt2[w]; if (w < wv) off2 += cw; tot2 += cw; }
+        if (acc) {
+            const int pm = m + off2 + __popcll(ab & ((1ull << lane) - 1));
+            meas_out[pm] = lm; z_out[2 * pm] = px; z_out[2 * pm + 1] = py;
+            s_lm[pm] = lm; s_k2[pm] = k2;
+        }
+        m += tot2;
+        __syncthreads();                          // (s_cnt / s_cnt2 are rewritten by the next pass; s_lm / s_k2 are read below)
+    }
+    if (tid == 0) {
+        a.res[0] = npred; a.res[1] = base; a.res[2] = m; a.res[3] = 0;
+        a.counts_dev[0] = npred; a.counts_dev[1] = base; a.counts_dev[2] = m;
+    }
+    // the result block is in the host's memory: every lane's stores first, then the sequence number -- before the refresh, which the host does not
+    // wait for (it draws its hypotheses meanwhile; the next launch on the stream is behind this one anyway)
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) { __threadfence_system(); __hip_atomic_store(a.mail + a.slot, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+    // matching_sift_based.m:135: the accepted landmark takes the scan's descriptor (16 descriptors per pass, 16 bytes per lane)
+    {
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        for (int j0 = 0; j0 < m; j0 += 4 * NW) {
+            d2_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * NW + wv;
+                if (j < m) v[u] = reinterpret_cast<const d2_t *>(a.scan_desc + (size_t)s_k2[j] * DESC_DIM)[lane];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * NW + wv;
+                if (j < m) reinterpret_cast<d2_t *>(a.bank + (size_t)s_lm[j] * DESC_DIM)[lane] = v[u];
+            }
+        }
+    }
+}
+
+static bool ic_fused_usable(const pre3_ctx *c)
+{
+    const char *e = getenv("PRE3_IC_FUSED");                   // 0: the ranked / exact routes (A/B, tests); read per call
+    if (e && atoi(e) == 0) return false;
+    const int ntn = ceil_div(c->scan_K2, ICS_T);
+    return c->scan_K2 > 0 && c->N <= ICG_MAXN && ntn <= ICG_MAXT && (size_t)ntn * c->capN <= (size_t)(c->scan_cap / ICS_T) * c->capN
+           && (size_t)c->N * c->scan_K2 <= ((size_t)1 << 20) && c->ic_pb != nullptr;
+}
+
+// the fused route's matcher as riders of another launch (pre3_ic_search: the projection + S_i launch in front of the gate -- nothing in it reads or
+// writes the descriptors, so the two run side by side and a kernel boundary goes; PRE3_IC_RIDE=0: a launch of its own, which can skip the tiles
+// without a predicted landmark)
+IcMatchRide ic_match_ride(const pre3_ctx *c)
+{
+    static const int ride_env = getenv("PRE3_IC_RIDE") ? atoi(getenv("PRE3_IC_RIDE")) : 1;
+    IcMatchRide r{};
+    if (!ride_env || !ic_fused_usable(c)) return r;
+    r.ntn = ceil_div(c->scan_K2, ICS_T); r.N = c->N; r.K2 = c->scan_K2; r.n_blocks = r.ntn * ceil_div(c->N, ICS_T);
+    r.bank = c->bank; r.scan = c->scan_desc; r.has_h = nullptr; r.pb = c->ic_pb; r.ps = c->ic_ps; r.pa = c->ic_pa;
+    return r;
+}
+
+// the fused route: the matcher (unless it rode in the projection's launch) and the gate; the gate publishes mailbox word `slot` = seq once the result
+// block is in c->ic_result_host
+int launch_ic_search_fused(pre3_ctx *c, double thresh, int strict, int32_t seq, int slot, bool matched)
+{
+    const int N = c->N, K2 = c->scan_K2, ntn = ceil_div(K2, ICS_T);
+    if (!matched) {
+        IcMatchRide r{ ntn * ceil_div(N, ICS_T), ntn, N, K2, c->bank, c->scan_desc, c->lm.has_h, c->ic_pb, c->ic_ps, c->ic_pa };
+        hipLaunchKernelGGL(k_ic_match_small, dim3(r.n_blocks), dim3(256), 0, c->stream, r);
+    }
+    IcGateF a{};
+    a.N = N; a.ntn = ntn; a.capN = c->capN; a.strict = strict; a.thresh = (float)thresh;
+    a.has_h = c->lm.has_h; a.pb = c->ic_pb; a.ps = c->ic_ps; a.pa = c->ic_pa;
+    a.pos = c->scan_pos; a.h = c->lm.h; a.S = c->lm.S; a.has_S = c->lm.has_S; a.z = c->lm.z; a.ic = c->lm.ic;
+    a.scan_desc = c->scan_desc; a.bank = c->bank;
+    a.res = static_cast<int32_t *>(c->ic_result_host_dev); a.counts_dev = c->ic_counts; a.mail = c->mail_dev; a.seq = seq; a.slot = slot;
+    hipLaunchKernelGGL(k_ic_gate_fused, dim3(1), dim3(ICG_NTH), 0, c->stream, a);
+    PRE3_HIP(hipGetLastError());
+    c->ic_route = 2;
+    // (accepted landmarks take the scan's descriptors: a scan outside the ranked route's bounds takes the bank with it)
+    const IcRank *ic = static_cast<const IcRank *>(c->ic_rank);
+    if (!(ic && ic->scan_ok && ic->K2 == c->scan_K2)) c->bank_ok = false;
+    return PRE3_OK;
+}
+bool ic_search_fused_applies(const pre3_ctx *c) { return ic_fused_usable(c); }
 
 int launch_ic_search(pre3_ctx *c, double thresh, int strict)
 {
@@ -1398,6 +1553,7 @@ int launch_ic_search(pre3_ctx *c, double thresh, int strict)
         const double *best = c->ic_best, *second = c->ic_second;
         const int32_t *arg = c->ic_arg;
         c->ic_last_ranked = ic_rank_usable(c);
+        c->ic_route = c->ic_last_ranked ? 1 : 0;
         if (c->ic_last_ranked) {
             RankMatch &r = static_cast<IcRank *>(c->ic_rank)->r;
             const int K2 = c->scan_K2;

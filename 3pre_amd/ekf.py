@@ -109,6 +109,12 @@ class EkfFilter:
         check(lib.pre3_get_option(self._ctx, 4, C.byref(v)))
         return bool(v.value)
 
+    def ic_search_route(self):
+        """PRE3_OPT_IC_ROUTE: 2 fused small-problem route, 1 ranked (matrix cores), 0 exact tiled kernel"""
+        v = C.c_int(0)
+        check(lib.pre3_get_option(self._ctx, 7, C.byref(v)))
+        return int(v.value)
+
     def chol_persist(self, on=None):
         """PRE3_OPT_CHOL_PERSIST (fp32 contexts): update.m:32-33 -- the factorisation of S and W = L^-1 [HP | nu] -- as one persistent launch
         (default) or, off, one launch per 64-column panel.  Returns whether the persistent form is in effect."""

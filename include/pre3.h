@@ -224,6 +224,12 @@ PRE3_API int pre3_update_ell(int device, int dtype, int n, int r, const double *
  * in-launch form's hand-offs between workgroups cost what the second sweep of P saves (DESIGN.md section 5d has the measured timeline).
  * pre3_get_option returns the setting; whether a step used it also depends on the launch carrying every tile of P (one live fp32 context). */
 #define PRE3_OPT_STEP_TAIL 6
+/* PRE3_OPT_IC_ROUTE (read only): how the last pre3_ic_search matched -- 2: the fused small-problem route (N * K2 <= 2^20 pairs, N <= 4096, K2 <= 2048:
+ * the sizes of the reference's own runs): siftmatch.c:97-116 exactly on 32 x 32 pair tiles over every landmark of the map, then ONE workgroup that
+ * stacks the predicted landmarks, merges the tiles, applies Lowe's test and the window gate, refreshes the accepted landmarks' descriptors and
+ * writes the result block into host memory -- two launches; 1: the ranked route of PRE3_OPT_IC_RANKED; 0: the exact 64 x 64 tiled kernel.
+ * The environment's PRE3_IC_FUSED=0 disables route 2.  Results are bit-identical on all three. */
+#define PRE3_OPT_IC_ROUTE 7
 PRE3_API int pre3_set_option(pre3_ctx *ctx, int option, int value);
 PRE3_API int pre3_get_option(pre3_ctx *ctx, int option, int *value_out);
 

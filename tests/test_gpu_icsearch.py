@@ -36,12 +36,15 @@ def _scan(rng, h, has_h, bank, n_clutter, frac_seen=0.8, px_sigma=1.5, n_far=4):
     return np.array(desc).T[:, perm].copy(), np.array(pos).T[:, perm].copy()
 
 
-@pytest.mark.parametrize("rank_env", ["1", "0"])
+@pytest.mark.parametrize("rank_env", ["1", "0", "fused"])
 def test_ic_search_on_the_matrix_cores_matches_oracle(pre3, orc, rank_env, monkeypatch):
     """N = 300 landmarks against ~300 keypoints (N * K2 >= 65536): matching_sift_based.m:118's siftmatch runs as the bf16 distance GEMM +
     exact re-evaluation inside pre3_ic_search (PRE3_IC_RANK=0: the exact VALU kernel); match list, scores-dependent ratio test, gate,
     measurement list, z and the refreshed bank are the oracle's bit for bit on both routes"""
-    monkeypatch.setenv("PRE3_IC_RANK", rank_env)
+    # ("fused": the default at these sizes since round 5 -- the exact matcher on 32 x 32 tiles + one gate workgroup, two launches; "1" / "0": the
+    #  ranked and the exact 64 x 64 tiled routes it stands in front of, PRE3_IC_FUSED=0)
+    monkeypatch.setenv("PRE3_IC_FUSED", "1" if rank_env == "fused" else "0")
+    monkeypatch.setenv("PRE3_IC_RANK", "1" if rank_env == "fused" else rank_env)
     N = 300
     rng, seq, bank = _scene(N, 31)
     s = seq["steps"][0]
@@ -59,6 +62,7 @@ def test_ic_search_on_the_matrix_cores_matches_oracle(pre3, orc, rank_env, monke
         bank_before = f.get_descriptors()
         out = f.matching_sift_based(1.5, strict_reference=True)
         assert f.ic_search_was_ranked() == (rank_env == "1") and N * sd.shape[1] >= 65536
+        assert f.ic_search_route() == {"fused": 2, "1": 1, "0": 0}[rank_env]
         ref = orc.ic_search(types, off, x1, P1, seq["cam"], bank_before, sd, sp, 1.5, True)
         assert ref["match_idx"].shape[1] > 100
         assert np.array_equal(out["match_idx"], ref["match_idx"]) and np.array_equal(out["accepted"], ref["accepted"])
@@ -69,8 +73,10 @@ def test_ic_search_on_the_matrix_cores_matches_oracle(pre3, orc, rank_env, monke
     f.close()
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("dtype,strict", [("f64", True), ("f64", False), ("f32", True)])
-def test_ic_search_matches_oracle(pre3, orc, dtype, strict):
+def test_ic_search_matches_oracle(pre3, orc, dtype, strict, fused, monkeypatch):
+    monkeypatch.setenv("PRE3_IC_FUSED", fused)
     N = 60
     rng, seq, bank = _scene(N, 23)
     s = seq["steps"][0]
@@ -84,6 +90,7 @@ def test_ic_search_matches_oracle(pre3, orc, dtype, strict):
     sd, sp = _scan(rng, h, has_h, bank, 60, px_sigma=5.0)      # wide enough that quirk Q5 changes the accepted set
     f.load_scan(sd, sp)
     out = f.matching_sift_based(1.5, strict_reference=strict)
+    assert f.ic_search_route() == (2 if fused == "1" else 0)
     ref = orc.ic_search(types, off, x1, P1, seq["cam"], bank, sd, sp, 1.5, strict)
     other = orc.ic_search(types, off, x1, P1, seq["cam"], bank, sd, sp, 1.5, not strict)
     assert not np.array_equal(ref["accepted"], other["accepted"])
