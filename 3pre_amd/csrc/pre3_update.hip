@@ -1227,6 +1227,17 @@ struct XUpd { int n_tiles, n, r; const double *x_prior; double *x_out; double *p
 // holds one tile (n = 1213: 210 tiles on 256 CUs) then has two waves per SIMD, and one's LDS reads / DMA waits hide behind the other's MFMAs
 // (v_mfma_f64_16x16x4 takes 64 cycles: with one wave per SIMD the matrix pipe idled through every stage's LDS round trip and barrier).  The two
 // halves meet in LDS behind the last stage, (first half) + (second half): one fixed order.
+// write-through (sc0 sc1) store of one down-dated entry of P (see store_wt below: the tiles drain while the launch runs, not in its end-of-kernel release)
+__device__ __forceinline__ void store1_wt(float *d, float v, bool wt)
+{
+    if (wt) asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(d), "v"(v) : "memory");
+    else *d = v;
+}
+__device__ __forceinline__ void store1_wt(double *d, double v, bool wt)
+{
+    if (wt) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(d), "v"(v) : "memory");
+    else *d = v;
+}
 template <typename T, int BK, int NW = 4>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(5))) void k_downdate_1t(T *__restrict__ P, int ld, const T *__restrict__ W, int ldw, int r_pad,
                                                      const int2 *__restrict__ tiles, int gen_size, XUpd xu, ProjRide pr)
@@ -1364,7 +1375,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(5))) vo
                 const int lr = p * M::BLK + M::row(lane, e), lc = q * M::BLK + M::col(lane);
                 const size_t o = (size_t)(I0 + wi * 32 + lr) * ld + J0 + wj * 32 + lc;
                 const T v = pv[p][q][e] - acc[p][q][e];
-                P[o] = v;
+                store1_wt(P + o, v, xu.wt != 0);
                 if (mirror) pat(lr, lc) = v;
             }
     if (mirror) {
@@ -1374,7 +1385,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(5))) vo
 #pragma unroll
         for (int cc = 0; cc < 32; cc += 2) {
             const int c = cc + half;
-            P[(size_t)(J0 + wj * 32 + c) * ld + I0 + wi * 32 + rr] = pat(rr, c);
+            store1_wt(P + (size_t)(J0 + wj * 32 + c) * ld + I0 + wi * 32 + rr, pat(rr, c), xu.wt != 0);
         }
     }
     RT_STAMP(3);
