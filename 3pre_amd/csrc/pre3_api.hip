@@ -741,10 +741,11 @@ int pre3_set_scan(pre3_ctx *c, int K2, const double *descriptor_raw, const doubl
         if (c->ic_pb) (void)hipFree(c->ic_pb);
         if (c->ic_ps) (void)hipFree(c->ic_ps);
         if (c->ic_pa) (void)hipFree(c->ic_pa);
-        c->scan_desc = c->scan_pos = nullptr; c->ic_pb = c->ic_ps = nullptr; c->ic_pa = nullptr; c->scan_cap = 0;
+        c->scan_desc = c->scan_pos = nullptr; c->ic_pb = c->ic_ps = nullptr; c->ic_pa = nullptr; c->scan_cap = 0; c->ic_pcap = 0;
         const int cap = round_up(K2, 256);
         PRE3_TRY(dmalloc(&c->scan_desc, (size_t)cap * DESC_DIM)); PRE3_TRY(dmalloc(&c->scan_pos, (size_t)cap * 4));
-        const size_t np = (size_t)(cap / 32) * c->capN;             // (column tiles of 32 keypoints: the fused route's; the 64-wide tiles use half)
+        const size_t np = std::max((size_t)(cap / 64) * c->capN, (size_t)64 * c->capN);     // [scan_cap/64][capN] for the 64-wide tiles; the fused route: [capN][64 column tiles of 32]
+        c->ic_pcap = np;
         PRE3_TRY(dmalloc(&c->ic_pb, np)); PRE3_TRY(dmalloc(&c->ic_ps, np)); PRE3_TRY(dmalloc(&c->ic_pa, np));
         c->scan_cap = cap;
     }

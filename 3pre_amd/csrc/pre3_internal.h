@@ -167,6 +167,7 @@ struct pre3_ctx {
     int ic_route = 0;                             // the last pre3_ic_search's matcher: 0 exact tiled kernel, 1 ranked (matrix cores), 2 fused small-problem route
     bool ic_last_ranked = false;                  // the last pre3_ic_search matched on the matrix cores (PRE3_OPT_IC_RANKED)
     void *ic_rank = nullptr; bool bank_ok = false;   // the scan packed for the matrix-core matcher (pre3_match.hip: IcRank); every bank descriptor inside its bounds
+    size_t ic_pcap = 0;                           // elements in each of ic_pb / ic_ps / ic_pa
     double *ic_pb = nullptr, *ic_ps = nullptr; int32_t *ic_pa = nullptr;     // per (column tile, landmark) partials of the tiled matcher [scan_cap/64][capN]
     // timing
     hipEvent_t t0 = nullptr, t1 = nullptr;

@@ -1381,7 +1381,7 @@ __global__ __launch_bounds__(256) void k_ic_match_small(IcMatchRide r)
     ic_match_tile(r, blockIdx.x, Qs, Bs);
 }
 
-constexpr int ICG_NTH = 1024, ICG_MAXN = 4096, ICG_MAXT = 64;
+constexpr int ICG_NTH = 1024, ICG_MAXN = 4096;
 struct IcGateF {
     int N, ntn, capN, strict; float thresh;
     const int32_t *has_h; const double *pb, *ps; const int32_t *pa;
@@ -1424,15 +1424,15 @@ __global__ __launch_bounds__(ICG_NTH) void k_ic_gate_fused(IcGateF a)
         if (k1 < npred) {
             lm = s_pred[k1];
             double best = acc_max<double>(), second = acc_max<double>();
-            for (int t0 = 0; t0 < a.ntn; t0 += 8) {             // eight tiles' partials in flight, merged in scan order
-                double ob[8], os[8]; int oa[8];
+            for (int t0 = 0; t0 < a.ntn; t0 += 16) {            // sixteen tiles' partials in flight (lanes = consecutive landmarks: whole lines), merged in scan order
+                double ob[16], os[16]; int oa[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     const size_t o = (size_t)(t0 + u < a.ntn ? t0 + u : t0) * a.N + lm;
                     ob[u] = a.pb[o]; os[u] = a.ps[o]; oa[u] = t0 + u < a.ntn ? a.pa[o] : -1;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) merge3(best, second, k2, ob[u], os[u], oa[u]);
+                for (int u = 0; u < 16; ++u) merge3(best, second, k2, ob[u], os[u], oa[u]);
             }
             ok = k2 >= 0 && a.thresh * (float)best <= (float)second;
         }
@@ -1479,18 +1479,18 @@ __global__ __launch_bounds__(ICG_NTH) void k_ic_gate_fused(IcGateF a)
     __threadfence_system();
     __syncthreads();
     if (tid == 0) { __threadfence_system(); __hip_atomic_store(a.mail + a.slot, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-    // matching_sift_based.m:135: the accepted landmark takes the scan's descriptor (16 descriptors per pass, 16 bytes per lane)
+    // matching_sift_based.m:135: the accepted landmark takes the scan's descriptor (a descriptor per wave, eight in flight, 16 bytes per lane)
     {
         typedef double d2_t __attribute__((ext_vector_type(2)));
-        for (int j0 = 0; j0 < m; j0 += 4 * NW) {
-            d2_t v[4];
+        for (int j0 = 0; j0 < m; j0 += 8 * NW) {
+            d2_t v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int j = j0 + u * NW + wv;
                 if (j < m) v[u] = reinterpret_cast<const d2_t *>(a.scan_desc + (size_t)s_k2[j] * DESC_DIM)[lane];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int j = j0 + u * NW + wv;
                 if (j < m) reinterpret_cast<d2_t *>(a.bank + (size_t)s_lm[j] * DESC_DIM)[lane] = v[u];
             }
@@ -1503,8 +1503,8 @@ static bool ic_fused_usable(const pre3_ctx *c)
     const char *e = getenv("PRE3_IC_FUSED");                   // 0: the ranked / exact routes (A/B, tests); read per call
     if (e && atoi(e) == 0) return false;
     const int ntn = ceil_div(c->scan_K2, ICS_T);
-    return c->scan_K2 > 0 && c->N <= ICG_MAXN && ntn <= ICG_MAXT && (size_t)ntn * c->capN <= (size_t)(c->scan_cap / ICS_T) * c->capN
-           && (size_t)c->N * c->scan_K2 <= ((size_t)1 << 20) && c->ic_pb != nullptr;
+    return c->scan_K2 > 0 && c->N <= ICG_MAXN && ntn <= ICS_MAXT && c->ic_pb != nullptr && c->ic_pcap >= (size_t)c->capN * ICS_MAXT
+           && (size_t)c->N * c->scan_K2 <= ((size_t)1 << 20);
 }
 
 // the fused route's matcher as riders of another launch (pre3_ic_search: the projection + S_i launch in front of the gate -- nothing in it reads or

@@ -470,11 +470,13 @@ def frame_leg(pre3, synth, N=500, K2=600, frames=40, warm=4, n_hyp=200):
         el = time.perf_counter() - t0
         for k in range(warm + frames // 2, warm + frames):
             frame(k, True)
+        ic_route = {2: "fused (exact 32 x 32 tiles riding in the projection launch + one gate workgroup: two launches)", 1: "ranked (bf16 matrix cores + exact tail)",
+                    0: "exact 64 x 64 tiled kernel"}.get(f.ic_search_route(), "?")
     finally:
         f.close()
     return {"workload": "one mono_slam.m frame at N=%d (n=%d): map_management (1 delete + 1 add), prediction, IC search on a %d-keypoint SIFT set (unit-norm doubles, "
                         "uploaded per frame), RANSAC (%d hypotheses), LI update, rescue, HI update; f32 covariance path; threshold / motion noise as the headline" % (N, seq["n"], K2, n_hyp),
-            "frames_per_s": len(ms) / el, "ms_per_frame": 1e3 * el / len(ms), "mean_ic_matches": float(np.mean(ms)),
+            "frames_per_s": len(ms) / el, "ms_per_frame": 1e3 * el / len(ms), "mean_ic_matches": float(np.mean(ms)), "ic_search_route": ic_route,
             "stage_us_synchronised": {k_: 1e6 * float(np.median(v)) for k_, v in stage.items()},
             "stage_us_max": {k_: 1e6 * float(np.max(v)) for k_, v in stage.items()},
             "note": "frames_per_s: no synchronisation inside a frame except what the calls themselves need (the IC search returns its match list, the RANSAC "
@@ -807,7 +809,7 @@ def main():
         fused = kt["launches"] > 0 and kt["fused"] == kt["launches"]                  # every bracketed launch was k_cholp with the down-date inside
         mean_r = (kt["flops"] / max(kt["launches"], 1)) / (n * (n + 1.0))
         traffic, traffic_src = None, None
-        for tag, key in (("r4", "pmc_cholp"), ("r3", "pmc_k9")) if fused else (("r3", "pmc_k9"), ("r2", "pmc_k9"), ("r1", "pmc_k9")):
+        for tag, key in (("r5", "pmc_cholp"), ("r4", "pmc_cholp"), ("r3", "pmc_k9")) if fused else (("r3", "pmc_k9"), ("r2", "pmc_k9"), ("r1", "pmc_k9")):
             try:     # HBM bytes per LI launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
                 with open(os.path.join(ROOT, "profiles", "%s_%s.json" % (tag, key))) as fh:
                     pj = json.load(fh)
@@ -839,7 +841,7 @@ def main():
                                            "executed_bf16_frac_of_peak": 6.0 * achieved / PEAK["bf16"],
                                            "note": "the SYRK count alone over the SAME duration (the launch also holds the factorisation's 60-us dependent chain): "
                                                    "what north_star's 'P-update >= 60 % of the fp32 MFMA roofline' would read if the whole launch were charged to K9; "
-                                                   "the consumers' own matrix-pipe occupancy is in profiles/r4_pmc_cholp.json"})
+                                                   "the consumers' own matrix-pipe occupancy is in profiles/r5_pmc_cholp.json"})
         else:
             algo = ("symmetric rank-r down-date (SYRK): n(n+1)r flop per launch, r = rows of that update, averaged over the K9 launches of "
                     "the timed region that were bracketed with HIP events: one in --kt-every of the launches with >= 128 rows, i.e. the LI "
