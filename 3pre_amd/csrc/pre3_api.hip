@@ -2,6 +2,7 @@
 // stage order of one filter step (mono_slam.m:153-187).  No compute happens on the host.
 #include <time.h>
 #include <algorithm>
+#include <immintrin.h>
 #include <cmath>
 #include <cstdarg>
 #include <new>
@@ -651,12 +652,39 @@ static int ensure_ic_buffers(pre3_ctx *c)
 }
 
 // k_rank_pack's test of its input, on the host: every value finite with |x| <= 2^60 and no non-zero |x| < 2^-40 (an or-reduction of two
-// compares per value; the block has just been written, so it is read from the cache)
-static bool desc_in_bounds_host(const double *__restrict__ d, size_t count)
+// compares per value), made on the way into the staging block: one pass over the caller's array instead of a copy and a second read
+// (AVX2 where the host has it: 36 us for copy + check of 600 keypoints -> see DESIGN.md section 11)
+__attribute__((target("avx2"))) static bool copy_desc_checked_avx2(double *__restrict__ dst, const double *__restrict__ src, size_t count)
 {
+    const __m256d absmask = _mm256_castsi256_pd(_mm256_set1_epi64x(0x7fffffffffffffffLL)), hi = _mm256_set1_pd(0x1p60), lo = _mm256_set1_pd(0x1p-40), zero = _mm256_setzero_pd();
+    __m256d bad = zero;
+    size_t i = 0;
+    for (; i + 8 <= count; i += 8) {
+        const __m256d v0 = _mm256_loadu_pd(src + i), v1 = _mm256_loadu_pd(src + i + 4);
+        _mm256_storeu_pd(dst + i, v0); _mm256_storeu_pd(dst + i + 4, v1);
+        const __m256d a0 = _mm256_and_pd(v0, absmask), a1 = _mm256_and_pd(v1, absmask);
+        // !(ax <= 2^60) (true for NaN too)  |  (ax != 0 && ax < 2^-40)
+        bad = _mm256_or_pd(bad, _mm256_cmp_pd(a0, hi, _CMP_NLE_UQ)); bad = _mm256_or_pd(bad, _mm256_cmp_pd(a1, hi, _CMP_NLE_UQ));
+        bad = _mm256_or_pd(bad, _mm256_and_pd(_mm256_cmp_pd(a0, zero, _CMP_NEQ_OQ), _mm256_cmp_pd(a0, lo, _CMP_LT_OQ)));
+        bad = _mm256_or_pd(bad, _mm256_and_pd(_mm256_cmp_pd(a1, zero, _CMP_NEQ_OQ), _mm256_cmp_pd(a1, lo, _CMP_LT_OQ)));
+    }
+    int b = _mm256_movemask_pd(bad);
+    for (; i < count; ++i) {
+        const double v = src[i], ax = fabs(v);
+        dst[i] = v;
+        b |= (int)!(ax <= 0x1p60);
+        b |= (int)(ax != 0.0) & (int)(ax < 0x1p-40);
+    }
+    return b == 0;
+}
+static bool copy_desc_checked(double *__restrict__ dst, const double *__restrict__ src, size_t count)
+{
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return copy_desc_checked_avx2(dst, src, count);
     int bad = 0;
     for (size_t i = 0; i < count; ++i) {
-        const double ax = fabs(d[i]);
+        const double v = src[i], ax = fabs(v);
+        dst[i] = v;
         bad |= (int)!(ax <= 0x1p60);
         bad |= (int)(ax != 0.0) & (int)(ax < 0x1p-40);
     }
@@ -707,8 +735,7 @@ int pre3_set_descriptors(pre3_ctx *c, int first, int count, const double *desc)
         const size_t nd = (size_t)count * DESC_DIM;
         void *st = nullptr, *st_dev = nullptr; int slot = 0;
         PRE3_TRY(stage_acquire(c, sizeof(double) * nd, &st, &st_dev, &slot));
-        memcpy(st, desc, sizeof(double) * nd);
-        ok = desc_in_bounds_host(static_cast<const double *>(st), nd);
+        ok = copy_desc_checked(static_cast<double *>(st), desc, nd);
         hipLaunchKernelGGL(k_scan_pull, dim3(ceil_div((int)(nd / 2), 256)), dim3(256), 0, c->stream, (const int4 *)st_dev, (int)(nd / 2),
                            (int4 *)(c->bank + (size_t)first * DESC_DIM), 0, (int4 *)nullptr);
         PRE3_HIP(hipGetLastError());
@@ -761,10 +788,9 @@ int pre3_set_scan(pre3_ctx *c, int K2, const double *descriptor_raw, const doubl
         const auto t1 = std::chrono::steady_clock::now();
         double *st = static_cast<double *>(st_v);
         const size_t nd = (size_t)K2 * DESC_DIM;
-        memcpy(st, descriptor_raw, sizeof(double) * nd);
-        memcpy(st + nd, scale_orient_pos_raw, sizeof(double) * (size_t)K2 * 4);
+        in_bounds = copy_desc_checked(st, descriptor_raw, nd);
         const auto t2 = std::chrono::steady_clock::now();
-        in_bounds = desc_in_bounds_host(st, nd);
+        memcpy(st + nd, scale_orient_pos_raw, sizeof(double) * (size_t)K2 * 4);
         const auto t3 = std::chrono::steady_clock::now();
         // the device reads the block over PCIe itself (16 bytes per lane, every request in flight at once: ~20 us for 600 keypoints) instead of
         // two DMA-engine copies with their start-up latencies
@@ -773,7 +799,7 @@ int pre3_set_scan(pre3_ctx *c, int K2, const double *descriptor_raw, const doubl
         PRE3_HIP(hipGetLastError());
         PRE3_TRY(stage_release(c, k));
         if (trace) { const auto t4 = std::chrono::steady_clock::now(); auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-            fprintf(stderr, "[pre3 set_scan, us] event wait %.1f | memcpy %.1f | check %.1f | enqueue %.1f\n", us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4)); }
+            fprintf(stderr, "[pre3 set_scan, us] event wait %.1f | descriptors copied + checked %.1f | positions %.1f | enqueue %.1f\n", us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4)); }
     }
     c->scan_K2 = K2;
     return ic_rank_set_scan(c, in_bounds);

@@ -73,6 +73,35 @@ def test_ic_search_on_the_matrix_cores_matches_oracle(pre3, orc, rank_env, monke
     f.close()
 
 
+@pytest.mark.parametrize("bad", [1e-20, 2.0 ** 61])
+def test_a_scan_outside_the_ranked_routes_bounds_takes_the_exact_kernel(pre3, orc, bad, monkeypatch):
+    """pre3_set_scan checks the descriptors on their way into the staging block (k_rank_pack's own test: finite, |x| <= 2^60, no non-zero
+    |x| < 2^-40; AVX2 on the host since round 5): one offending value and the search must leave the matrix-core route -- with the same results"""
+    monkeypatch.setenv("PRE3_IC_FUSED", "0")
+    N = 300
+    rng, seq, bank = _scene(N, 37)
+    s = seq["steps"][0]
+    types, off, n = orc.landmark_table(np.zeros(N, int))
+    f = pre3.EkfFilter(seq["cam"], types, dtype="f64", max_hyp=8)
+    f.set_x_p_k_k(seq["x0"], seq["P0"])
+    f.set_descriptors(bank)
+    f.ekf_prediction(s["u"])
+    x1, P1 = f.get_x_k_km1(), f.get_p_k_km1()
+    h, has_h = orc.project(types, off, x1, seq["cam"])
+    sd, sp = _scan(rng, h, has_h, bank, 90, px_sigma=4.0)
+    f.load_scan(sd, sp)
+    f.matching_sift_based(1.5, strict_reference=True)
+    assert f.ic_search_route() == 1                              # in bounds: the ranked route
+    f.set_x_p_k_k(seq["x0"], seq["P0"]); f.set_descriptors(bank); f.ekf_prediction(s["u"])
+    sd2 = sd.copy(); sd2[77, 41] = bad                            # (an odd position: the check's vector loop and its tail both see ordinary values around it)
+    f.load_scan(sd2, sp)
+    out = f.matching_sift_based(1.5, strict_reference=True)
+    assert f.ic_search_route() == 0
+    ref = orc.ic_search(types, off, x1, P1, seq["cam"], bank, sd2, sp, 1.5, True)
+    assert np.array_equal(out["match_idx"], ref["match_idx"]) and np.array_equal(out["meas_idx"], ref["meas_idx"])
+    f.close()
+
+
 @pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("dtype,strict", [("f64", True), ("f64", False), ("f32", True)])
 def test_ic_search_matches_oracle(pre3, orc, dtype, strict, fused, monkeypatch):
