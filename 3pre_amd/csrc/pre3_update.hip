@@ -697,7 +697,9 @@ __device__ __forceinline__ void hf_T_block(HfSmem &hf, const HiFused &a, const i
     const int nU = 7 + 6 * nlm, np = nrow >> 1;
     // TRI: row pair q has 13 + 6q columns; pairs q and np-1-q together have C = 20 + 6 np of them, so the items are dealt evenly.
     // (What bounds this loop is the rate at which a CU takes scattered 4-byte reads -- every workgroup of the launch reads the same lines of P --,
-    //  not their latency: four items' reads in flight per lane measured 8 % slower, 28.6 against 26.5 us for the launch at 32 landmarks.)
+    //  not their latency: four items' reads in flight per lane measured 8 % slower, 28.6 against 26.5 us for the launch at 32 landmarks; reading
+    //  P(col, rc[t]) instead -- P is symmetric to the bit here, and a row holds an item's thirteen entries in two runs -- 33.8 us: the lanes of a
+    //  wave then read 64 different rows, where consecutive columns of ONE row share lines.)
     const int C = TRI ? 20 + 6 * np : nU, nq = TRI ? (np + 1) >> 1 : np;
     for (int idx = threadIdx.x; idx < nq * C; idx += CH_NTH) {
         int p = idx / C, k = idx - p * C;
