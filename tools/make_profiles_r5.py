@@ -62,16 +62,25 @@ try:
 except Exception as e:
     print("no tail trace:", e)
 
-# ---- k_cholp launches: LI updates (the long class) and the general-path HI updates of more than 32 landmarks (two panels: the short class)
-cp = [dur(r) for r in rows(tr) if "k_cholp" in r["Kernel_Name"]]
-li = sorted(d for d in cp if d > 0.5 * max(cp)); hi2 = sorted(d for d in cp if d <= 0.5 * max(cp))
+# ---- k_cholp launches: LI updates (the long class) and the general-path HI updates of more than 64 landmarks (the short class: step 0 of a sequence)
+# (told apart by position: the first k_cholp behind a k_predict is that step's LI update, a second one the HI update's general path; the first
+#  five steps are the warm-up, whose LI updates are still growing -- 216 .. 584 rows -- and are listed apart)
+trs = sorted(rows(tr), key=lambda r: int(r["Start_Timestamp"]))
+li, li_warm, hi2, step_no, seen = [], [], [], -1, 0
+for r in trs:
+    if "k_predict" in r["Kernel_Name"]:
+        step_no += 1; seen = 0
+    elif "k_cholp" in r["Kernel_Name"]:
+        (hi2 if seen else (li_warm if step_no < 5 else li)).append(dur(r)); seen += 1
+li.sort(); li_warm.sort(); hi2.sort()
 out = ["# k_cholp in `%s --steps 40 --warmup 5` (%s), rocprofv3 --kernel-trace" % (CMD, WL),
-       "# LI updates (factorisation + solve + x-update + down-date in one launch): %d launches, median %.2f us, mean %.2f us, min %.2f us" % (len(li), med(li), sum(li) / len(li), li[0])]
+       "# LI updates (factorisation + solve + x-update + down-date in one launch), timed steps: %d launches, median %.2f us, mean %.2f us, min %.2f us" % (len(li), med(li), sum(li) / len(li), li[0]),
+       "# LI updates of the five warm-up steps (the map's first frames: fewer inliers): %s us" % ", ".join("%.1f" % d for d in li_warm)]
 if hi2:
-    out.append("# HI updates of more than 32 rescued landmarks (two panels, the host-polled general path): %d launches, median %.2f us" % (len(hi2), med(hi2)))
+    out.append("# HI updates of more than 64 rescued landmarks (the host-polled general path; step 0 of the sequence, inside the warm-up): %d launches, median %.2f us" % (len(hi2), med(hi2)))
 hf = sorted(dur(r) for r in rows(tr) if "k_hi_fused" in r["Kernel_Name"])
 hd = sorted(dur(r) for r in rows(tr) if "k_downdate_b3" in r["Kernel_Name"])
-out.append("# k_hi_fused (collection + HI update of <= 32 landmarks): %d launches, median %.2f us (min %.2f: nothing rescued, max %.2f)" % (len(hf), med(hf), hf[0], hf[-1]))
+out.append("# k_hi_fused (collection + HI update of <= 64 landmarks: one panel up to 32, two panels inside the launch up to 64): %d launches, median %.2f us (min %.2f: nothing rescued, max %.2f)" % (len(hf), med(hf), hf[0], hf[-1]))
 out.append("# k_downdate_b3 (the HI updates' down-date; device-gated, ~4 us when there is nothing to do): %d launches, median %.2f us, max %.2f us" % (len(hd), med(hd), hd[-1]))
 open(os.path.join(P, "%s_cholp_launches.txt" % tag), "w").write("\n".join(out) + "\n")
 print("\n".join(out))
