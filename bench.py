@@ -424,17 +424,19 @@ def frame_leg(pre3, synth, N=500, K2=600, frames=40, warm=4, n_hyp=200):
         f.defer_hi_update(True)
         new_desc = sift_like(rng.standard_normal((128, frames + warm + 1)))
 
-        def draws(m):                                        # select_random_match.m:47-51: 3 distinct measurements per hypothesis (vectorised; duplicates redrawn)
+        def draws(m, u):                                     # select_random_match.m:47-51: 3 distinct measurements per hypothesis (vectorised; duplicates redrawn)
+            # u: the frame's uniform variates, drawn while the device runs the IC search -- only their scaling by the match count waits for it
             if m <= 3:
                 return synth.draw_hypotheses(rng, m, n_hyp)
-            h = rng.integers(0, m, (n_hyp, 3))
+            h = (u * m).astype(np.int32)
             bad = (h[:, 0] == h[:, 1]) | (h[:, 0] == h[:, 2]) | (h[:, 1] == h[:, 2])
             while bad.any():
                 h[bad] = rng.integers(0, m, (int(bad.sum()), 3))
                 bad = (h[:, 0] == h[:, 1]) | (h[:, 0] == h[:, 2]) | (h[:, 1] == h[:, 2])
-            return h.astype(np.int32)
+            return h
 
         stage = {k: [] for k in ("map_management", "prediction", "scan_upload", "ic_search", "ransac_updates")}
+        hyp_u = [None]
 
         def frame(k, split):
             t = [time.perf_counter()]
@@ -453,12 +455,13 @@ def frame_leg(pre3, synth, N=500, K2=600, frames=40, warm=4, n_hyp=200):
             mark("prediction")
             f.load_scan(*scans[k])
             mark("scan_upload")
+            hyp_u[0] = rng.random((n_hyp, 3))                  # (while the device still pulls the scan)
             ic = f.matching_sift_based(1.5, strict_reference=True)
             mark("ic_search")
             if split and os.environ.get("PRE3_FRAME_DEBUG"):
                 print("frame %d: ic_search %.0f us, ranked %s, matches %d" % (k, 1e6 * (t[-1] - t[-2]), f.ic_search_was_ranked(), len(ic["meas_idx"])), file=sys.stderr, flush=True)
             m = len(ic["meas_idx"])
-            f.step_predicted(draws(m), threshold=thr, early_exit=False)      # RANSAC, LI update, rescue, HI update: pre3_step's launches on the installed measurements
+            f.step_predicted(draws(m, hyp_u[0]), threshold=thr, early_exit=False)      # RANSAC, LI update, rescue, HI update: pre3_step's launches on the installed measurements
             mark("ransac_updates")
             return m
         for k in range(warm):
