@@ -56,6 +56,64 @@ def test_whole_step_with_a_chosen_number_of_rescued_landmarks_matches_the_twin(p
     assert np.abs(xg - ref["x_kk"]).max() < tolx, np.abs(xg - ref["x_kk"]).max()
 
 
+def _convert(tw, x, P, types):
+    """inversedepth_2_cartesian.m:49-70 for the landmarks with types[i] == 1 (an all-inverse-depth map in): the point and its 3 x 6 Jacobian per landmark,
+    P <- A P A' with the sparse A those blocks make up"""
+    import scipy.sparse as sp
+    N = len(types)
+    xs, rows, cols, vals, o_new = [x[:13]], list(range(13)), list(range(13)), [1.0] * 13, 13
+    for i in range(N):
+        o = 13 + 6 * i
+        if types[i] == 0:
+            xs.append(x[o:o + 6])
+            rows += list(range(o_new, o_new + 6)); cols += list(range(o, o + 6)); vals += [1.0] * 6
+            o_new += 6
+            continue
+        rho, theta, phi = x[o + 5], x[o + 3], x[o + 4]
+        mi = tw.m_dir(theta, phi)
+        xs.append(x[o:o + 3] + mi / rho)
+        J = np.hstack([np.eye(3), (np.array([np.cos(phi) * np.cos(theta), 0, -np.cos(phi) * np.sin(theta)]) / rho)[:, None],
+                       (np.array([-np.sin(phi) * np.sin(theta), -np.cos(phi), -np.sin(phi) * np.cos(theta)]) / rho)[:, None], (-mi / rho ** 2)[:, None]])
+        for a in range(3):
+            for b in range(6):
+                rows.append(o_new + a); cols.append(o + b); vals.append(J[a, b])
+        o_new += 3
+    A = sp.csr_matrix((vals, (rows, cols)), shape=(o_new, len(x)))
+    Pn = (A @ (A @ P).T).T
+    return np.concatenate(xs), 0.5 * (Pn + Pn.T)
+
+
+@pytest.mark.parametrize("n_hi", [20, 40])
+def test_mixed_cartesian_and_inverse_depth_landmarks_through_the_fused_hi_update(pre3, orc, n_hi):
+    """a map in which part of the landmarks has been converted to Cartesian (inversedepth_2_cartesian.m:27-76 on the twin): their rows of H have three
+    landmark columns, the other three ELL slots are zero entries at column 0 -- one panel (20 rescued landmarks) and two panels (40) of k_hi_fused"""
+    from oracle import np_twin as tw
+    N, n_hyp = 500, 200
+    seq = synth.make_sequence(N, 1, n_hyp)
+    s = seq["steps"][0]
+    types = np.zeros(N, np.int32); types[::3] = 1                 # every third landmark Cartesian
+    x0, P0 = _convert(tw, seq["x0"], seq["P0"], types)
+    tt, off, n = orc.landmark_table(types)
+    z = np.array(s["z"], float)
+    ref = tw.step(tt, off, seq["cam"], x0, P0, s["u"], s["meas_idx"], z, s["hyp"], 1.0, early_exit=False)
+    hi_pos = np.nonzero(ref["hi"])[0]
+    if len(hi_pos) < n_hi:
+        pytest.skip("the sequence rescues only %d landmarks" % len(hi_pos))
+    z[hi_pos[n_hi:]] += 300.0
+    ref = tw.step(tt, off, seq["cam"], x0, P0, s["u"], s["meas_idx"], z, s["hyp"], 1.0, early_exit=False)
+    assert int(ref["hi"].sum()) == n_hi and np.any(types[np.asarray(s["meas_idx"])[ref["hi"] != 0]] != 0)       # (Cartesian landmarks among the rescued)
+    f = pre3.EkfFilter(seq["cam"], types, dtype="f32", max_hyp=n_hyp, std_z=1.0)
+    f.step_tail(False)
+    f.set_x_p_k_k(x0, P0)
+    st = f.step(s["u"], s["meas_idx"], z, s["hyp"], threshold=1.0, early_exit=False)
+    li, hi = f.get_flags()
+    xg, Pg = f.get_x_k_k(), f.get_p_k_k()
+    f.close()
+    assert np.array_equal(li, ref["li"]) and np.array_equal(hi, ref["hi"]) and st["n_hi"] == n_hi
+    assert np.abs(Pg - ref["P_kk"]).max() < 3e-4 * np.abs(ref["P_kk"]).max(), np.abs(Pg - ref["P_kk"]).max() / np.abs(ref["P_kk"]).max()
+    assert np.abs(xg - ref["x_kk"]).max() < 2e-5, np.abs(xg - ref["x_kk"]).max()
+
+
 _WORKER = r"""
 import importlib, json, sys
 import numpy as np
