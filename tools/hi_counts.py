@@ -1,6 +1,7 @@
+"""LI / HI landmark counts per step of the headline sequence (N = 500, threshold 1.0 px, motion noise 2.5): what the driver's 20-step window holds."""
 import importlib, sys, os
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pre3 = importlib.import_module("3pre_amd"); synth = importlib.import_module("3pre_amd.synth")
 N, H = 500, 200
 seq = synth.make_sequence(N, 40, H, **{"motion_noise": synth.HEADLINE["motion_noise"]})
