@@ -26,7 +26,7 @@ void set_error(const char *fmt, ...)
 // launchers defined in the kernel files
 int launch_predict_impl(pre3_ctx *c, const double u[7], bool with_projection = false, size_t inbox_n16 = 0, int32_t inbox_seq = 0);
 IcMatchRide ic_match_ride(const pre3_ctx *c);
-int launch_inbox_pull(pre3_ctx *c, const void *src_host_mapped, void *dst_dev, size_t n16, int32_t seq, int slot = 10);
+int launch_inbox_pull(pre3_ctx *c, const void *src_host_mapped, void *dst_dev, size_t n16, int32_t seq, int slot = 10, int32_t *clear = nullptr, int n_clear = 0);
 int launch_slice_prepare(pre3_ctx *c, const void *src_host_mapped, size_t n16, int32_t seq, int n_zero, int k, int lo, int hi, int tag);   // (either direction: 16-byte words between device memory and a mapped pinned block, then `seq` into mailbox word `slot`)
 int launch_window_gate(pre3_ctx *c, int M, const int32_t *pred_idx_dev, const int32_t *k1_dev, const double *zc_dev, int strict, int32_t *accept_dev);
 int launch_build_rows_impl(pre3_ctx *c, int nsel, const int32_t *sel_dev, int r_pad);
@@ -89,9 +89,20 @@ static int wait_mail(pre3_ctx *c, int slot, int32_t seq)
     // host for ever -- the wait has a wall-clock deadline (pre3_comm_set_timeout), and never ends in a bare hipStreamSynchronize.
     const bool coll = c->comm != nullptr;
     const double t0 = coll ? now_ms() : 0;
-    for (long spin = 0; coll || spin < 20000000L; ++spin) {
+    static const int query_env = getenv("PRE3_WAIT_QUERY") ? atoi(getenv("PRE3_WAIT_QUERY")) : 0;      // 1: hipStreamQuery from the first 1024 spins on (rounds 1-4)
+    double t_q = 0;
+    for (long spin = 0; coll || spin < 2000000000L; ++spin) {
         if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == seq) return PRE3_OK;
         if ((spin & 1023) == 1023) {
+            // Is the stream idle although the word has not come (the producing kernel was never launched)?  hipStreamQuery is not free of side effects:
+            // to learn the state of the last launch the runtime appends a marker (a barrier packet with a completion signal) behind it, and the next
+            // launch then starts ~6 us after its predecessor has ended -- the two "holes" of the step (behind k_cholp and behind the HI down-date: the
+            // two places where the host polls a count) were these markers, not store drains.  So: only after 2 ms without the word.
+            if (!query_env) {
+                const double t = now_ms();
+                if (t_q == 0) { t_q = t; continue; }
+                if (t - t_q < 2.0) continue;
+            }
             if (hipStreamQuery(c->stream) == hipSuccess) break;
             if (coll && (spin & 0x3ffff) == 0x3ffff) {
                 PRE3_TRY(comm_poll_error(c->comm));     // a collective in front of the awaited kernel whose peer died
@@ -114,22 +125,55 @@ static int fetch_stats(pre3_ctx *c)
 }
 
 // the staged scan [descriptors | positions] out of pinned host memory into the two device arrays (n16_pos == 0: one array)
-__global__ __launch_bounds__(256) void k_scan_pull(const int4 *__restrict__ src, int n16_desc, int4 *__restrict__ desc, int n16_pos, int4 *__restrict__ pos)
+// done.ctr != nullptr: the last workgroup to finish publishes done.seq in the pinned mailbox word done.mail -- the host may then overwrite the staging
+// block (stage_wait).  An event recorded behind the launch would tell the same, but its record puts a barrier packet with a completion signal into the
+// stream, and the NEXT launch then starts ~6 us after this one has ended (measured in the frame leg: three such holes per frame).
+struct StageDone { unsigned int *ctr; int32_t *mail; int32_t seq; };
+__global__ __launch_bounds__(256) void k_scan_pull(const int4 *__restrict__ src, int n16_desc, int4 *__restrict__ desc, int n16_pos, int4 *__restrict__ pos, StageDone done)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n16_desc) desc[i] = src[i];
     else if (i < n16_desc + n16_pos) pos[i - n16_desc] = src[i];
+    if (done.ctr != nullptr) {
+        __syncthreads();                                 // (this workgroup's reads of the block have returned: their values are on their way out)
+        if (threadIdx.x == 0 && atomicAdd(done.ctr, 1u) == gridDim.x - 1) {
+            atomicExch(done.ctr, 0u);
+            __threadfence_system();
+            __hip_atomic_store(done.mail, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
+// the staging block `k` (0, 1: uploads; 2, 3: map management) has been pulled: one read of host memory (after 2 ms: a stream synchronisation)
+int stage_wait(pre3_ctx *c, int k)
+{
+    volatile int32_t *w = c->mail_host + 16 + k;
+    const int32_t seq = c->stage_seq[k];
+    if (seq == 0) return PRE3_OK;
+    double t0 = 0;
+    for (long spin = 0; ; ++spin) {
+        if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == seq) return PRE3_OK;
+        if ((spin & 1023) == 1023) {
+            const double t = now_ms();
+            if (t0 == 0) t0 = t;
+            else if (t - t0 > 2.0) break;
+        }
+    }
+    PRE3_HIP(hipStreamSynchronize(c->stream));
+    PRE3_CHECK(__atomic_load_n(w, __ATOMIC_ACQUIRE) == seq, PRE3_E_STATE, "staging block %d: its pull has not run", k);
+    return PRE3_OK;
+}
+static StageDone stage_done(pre3_ctx *c, int k) { return StageDone{ c->chol_arrive + 8 + k, c->mail_dev + 16 + k, ++c->stage_seq[k] }; }
 
 // bytes of a pinned (device-mapped) host block -> device memory, read over PCIe by the device itself on the context's stream: no DMA engine,
 // whose copies start with ~10 us of latency each (and, once in a few hundred calls, with tens of milliseconds inside the runtime)
-int launch_pull(pre3_ctx *c, const void *pinned_host, void *dst_dev, size_t bytes)
+int launch_pull(pre3_ctx *c, const void *pinned_host, void *dst_dev, size_t bytes, int done_slot)
 {
     void *src_dev = nullptr;
     PRE3_HIP(hipHostGetDevicePointer(&src_dev, const_cast<void *>(pinned_host), 0));
     const int n16 = (int)((bytes + 15) / 16);
     if (n16 == 0) return PRE3_OK;
-    hipLaunchKernelGGL(k_scan_pull, dim3(ceil_div(n16, 256)), dim3(256), 0, c->stream, (const int4 *)src_dev, n16, (int4 *)dst_dev, 0, (int4 *)nullptr);
+    hipLaunchKernelGGL(k_scan_pull, dim3(ceil_div(n16, 256)), dim3(256), 0, c->stream, (const int4 *)src_dev, n16, (int4 *)dst_dev, 0, (int4 *)nullptr,
+                       done_slot >= 0 ? stage_done(c, done_slot) : StageDone{ nullptr, nullptr, 0 });
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }
@@ -255,8 +299,8 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
             A(dmalloc_bytes(&c->tiles_flat, sizeof(int2) * (inter.size() ? inter.size() : 1)));
             if (rc == PRE3_OK && hipMemcpy(c->tiles_flat, inter.data(), sizeof(int2) * inter.size(), hipMemcpyHostToDevice) != hipSuccess) { set_error("tile table upload failed"); rc = PRE3_E_HIP; }
         }
-        A(dmalloc(&c->tile_ctr, 8)); A(dmalloc(&c->tile_cnt, 8)); A(dmalloc(&c->chol_arrive, 8));
-        if (rc == PRE3_OK) (void)hipMemset(c->chol_arrive, 0, sizeof(unsigned int) * 8);
+        A(dmalloc(&c->tile_ctr, 8)); A(dmalloc(&c->tile_cnt, 8)); A(dmalloc(&c->chol_arrive, 16));      // ([8..11]: arrival counters of the staging pulls)
+        if (rc == PRE3_OK) (void)hipMemset(c->chol_arrive, 0, sizeof(unsigned int) * 16);
         if (rc == PRE3_OK) { (void)hipMemset(c->tile_ctr, 0, sizeof(unsigned int) * 8); (void)hipMemcpy(c->tile_cnt, cnts, sizeof(cnts), hipMemcpyHostToDevice); }
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) c->num_cus = pr.multiProcessorCount; }
         A(dmalloc_bytes(&c->tiles, sizeof(int2) * flat.size()));
@@ -330,9 +374,9 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
         if (rc == PRE3_OK && hipMemcpy(c->tiles128, inter.data(), sizeof(int2) * inter.size(), hipMemcpyHostToDevice) != hipSuccess) { set_error("tile table upload failed"); rc = PRE3_E_HIP; }
     }
     if (rc == PRE3_OK && hipHostMalloc((void **)&c->pinned_stats, sizeof(int32_t) * 16) != hipSuccess) { set_error("hipHostMalloc failed"); rc = PRE3_E_NOMEM; }
-    if (rc == PRE3_OK && hipHostMalloc((void **)&c->mail_host, sizeof(int32_t) * 16, hipHostMallocMapped) != hipSuccess) { set_error("hipHostMalloc failed"); rc = PRE3_E_NOMEM; }
+    if (rc == PRE3_OK && hipHostMalloc((void **)&c->mail_host, sizeof(int32_t) * 32, hipHostMallocMapped) != hipSuccess) { set_error("hipHostMalloc failed"); rc = PRE3_E_NOMEM; }
     if (rc == PRE3_OK) {
-        memset(c->mail_host, 0, sizeof(int32_t) * 16);
+        memset(c->mail_host, 0, sizeof(int32_t) * 32);      // (words 16..19: the staging blocks' "pulled" sequence numbers, stage_wait)
         if (hipHostGetDevicePointer((void **)&c->mail_dev, c->mail_host, 0) != hipSuccess) { set_error("hipHostGetDevicePointer failed"); rc = PRE3_E_HIP; }
     }
     if (rc == PRE3_OK && (hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess)) { set_error("hipEventCreate failed"); rc = PRE3_E_HIP; }
@@ -578,9 +622,11 @@ static int install_measurements(pre3_ctx *c, int m, const int32_t *meas_idx, con
     // The inbox crosses PCIe by a KERNEL that reads the pinned, device-mapped host buffer (14 KB at N=500): a hipMemcpyAsync between
     // kernels is a blit with barrier packets on both sides and opened two ~10 us holes in the stream around a 3 us copy.
     const size_t nbytes = z ? c->off_z + sizeof(double) * 2 * c->N : c->off_hyp + (hyp ? sizeof(int32_t) * n_hyp_ints : 0);
-    if (pull) { PRE3_TRY(launch_inbox_pull(c, c->inbox_host_dev, c->inbox_dev, (nbytes + 15) / 16, ++c->seq_inbox)); c->inbox_pending = true; }
+    // (the inlier flags behind the inbox are cleared by the pull's own workgroup: a hipMemsetAsync is a fill kernel between barrier packets)
+    int32_t *const flags = (int32_t *)((unsigned char *)c->inbox_dev + c->off_flags);
+    if (pull) { PRE3_TRY(launch_inbox_pull(c, c->inbox_host_dev, c->inbox_dev, (nbytes + 15) / 16, ++c->seq_inbox, 10, flags_clear ? nullptr : flags, flags_clear ? 0 : (int)(c->flags_bytes / 4))); c->inbox_pending = true; }
     if (nbytes_out) *nbytes_out = nbytes;
-    if (!flags_clear) PRE3_HIP(hipMemsetAsync((unsigned char *)c->inbox_dev + c->off_flags, 0, c->flags_bytes, c->stream));
+    if (!flags_clear && !pull) PRE3_HIP(hipMemsetAsync(flags, 0, c->flags_bytes, c->stream));
     c->li_from_host = c->hi_from_host = -1; c->li_kernel = c->hi_kernel = false;
     c->hp_all_valid = false;
     c->measurements_set = true;
@@ -692,13 +738,13 @@ static bool copy_desc_checked(double *__restrict__ dst, const double *__restrict
 }
 
 // A pinned block of the context for `bytes` of host data on their way to the device: two blocks, used alternately, grown on demand; a block is
-// written again only after the pull of its previous contents has run (its event).  The caller fills *host, enqueues the pull from *dev on the
+// written again only after the pull of its previous contents has run (its sequence number in the mailbox: stage_wait).  The caller fills *host, enqueues the pull from *dev on the
 // context's stream and calls stage_release.
 static int stage_acquire(pre3_ctx *c, size_t bytes, void **host, void **dev, int *slot)
 {
     if (c->up_stage_bytes < bytes) {
         for (int k = 0; k < 2; ++k) {
-            if (c->up_stage_used[k]) PRE3_HIP(hipEventSynchronize(c->up_stage_ev[k]));
+            if (c->up_stage_used[k]) PRE3_TRY(stage_wait(c, k));
             if (c->up_stage[k]) (void)hipHostFree(c->up_stage[k]);
             c->up_stage[k] = nullptr; c->up_stage_used[k] = false;
         }
@@ -706,19 +752,17 @@ static int stage_acquire(pre3_ctx *c, size_t bytes, void **host, void **dev, int
         const size_t cap = (bytes + 65535) & ~(size_t)65535;
         for (int k = 0; k < 2; ++k) {
             PRE3_HIP(hipHostMalloc(&c->up_stage[k], cap, hipHostMallocMapped));
-            if (!c->up_stage_ev[k]) PRE3_HIP(hipEventCreateWithFlags(&c->up_stage_ev[k], hipEventDisableTiming));
         }
         c->up_stage_bytes = cap;
     }
     const int k = c->up_stage_next; c->up_stage_next ^= 1;
-    if (c->up_stage_used[k]) PRE3_HIP(hipEventSynchronize(c->up_stage_ev[k]));
+    if (c->up_stage_used[k]) PRE3_TRY(stage_wait(c, k));
     *host = c->up_stage[k]; *slot = k;
     PRE3_HIP(hipHostGetDevicePointer(dev, c->up_stage[k], 0));
     return PRE3_OK;
 }
-static int stage_release(pre3_ctx *c, int slot)
+static int stage_release(pre3_ctx *c, int slot)        // (the pull launched with stage_done(c, slot) announces itself)
 {
-    PRE3_HIP(hipEventRecord(c->up_stage_ev[slot], c->stream));
     c->up_stage_used[slot] = true;
     return PRE3_OK;
 }
@@ -737,7 +781,7 @@ int pre3_set_descriptors(pre3_ctx *c, int first, int count, const double *desc)
         PRE3_TRY(stage_acquire(c, sizeof(double) * nd, &st, &st_dev, &slot));
         ok = copy_desc_checked(static_cast<double *>(st), desc, nd);
         hipLaunchKernelGGL(k_scan_pull, dim3(ceil_div((int)(nd / 2), 256)), dim3(256), 0, c->stream, (const int4 *)st_dev, (int)(nd / 2),
-                           (int4 *)(c->bank + (size_t)first * DESC_DIM), 0, (int4 *)nullptr);
+                           (int4 *)(c->bank + (size_t)first * DESC_DIM), 0, (int4 *)nullptr, stage_done(c, slot));
         PRE3_HIP(hipGetLastError());
         PRE3_TRY(stage_release(c, slot));
     }
@@ -795,7 +839,7 @@ int pre3_set_scan(pre3_ctx *c, int K2, const double *descriptor_raw, const doubl
         // the device reads the block over PCIe itself (16 bytes per lane, every request in flight at once: ~20 us for 600 keypoints) instead of
         // two DMA-engine copies with their start-up latencies
         const int n16_desc = (int)(nd / 2), n16_pos = K2 * 2;
-        hipLaunchKernelGGL(k_scan_pull, dim3(ceil_div(n16_desc + n16_pos, 256)), dim3(256), 0, c->stream, (const int4 *)st_dev, n16_desc, (int4 *)c->scan_desc, n16_pos, (int4 *)c->scan_pos);
+        hipLaunchKernelGGL(k_scan_pull, dim3(ceil_div(n16_desc + n16_pos, 256)), dim3(256), 0, c->stream, (const int4 *)st_dev, n16_desc, (int4 *)c->scan_desc, n16_pos, (int4 *)c->scan_pos, stage_done(c, k));
         PRE3_HIP(hipGetLastError());
         PRE3_TRY(stage_release(c, k));
         if (trace) { const auto t4 = std::chrono::steady_clock::now(); auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };

@@ -51,7 +51,7 @@ __device__ __forceinline__ double jn_row(const double *J, int i, const double v[
 }
 // The per-step inbox [meas | ic | hyp | z]: pinned host memory, read over PCIe by the device itself (16 bytes per lane).  ONE workgroup, so
 // that its last act can be to publish `seq` in the pinned mailbox: the host may overwrite the inbox once it reads that number back.
-struct InboxRide { const int4 *src; int4 *dst; int n16; int32_t *mail; int32_t seq; int slot = 10; };        // n16 == 0: no pull in this launch; slot: the mailbox word that takes seq
+struct InboxRide { const int4 *src; int4 *dst; int n16; int32_t *mail; int32_t seq; int slot = 10; int32_t *clear = nullptr; int n_clear = 0; };      // clear: n_clear ints zeroed on the way (the inlier flags behind the inbox: was a hipMemsetAsync, i.e. a fill kernel between barrier packets)        // n16 == 0: no pull in this launch; slot: the mailbox word that takes seq
 __device__ __forceinline__ void inbox_pull_block(const InboxRide &ib)
 {
     // four PCIe reads in flight per lane (a read is ~1.5 us; one after the other they made this block the long pole of k_predict)
@@ -62,6 +62,7 @@ __device__ __forceinline__ void inbox_pull_block(const InboxRide &ib)
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const int i = i0 + u * blockDim.x; if (i < ib.n16) ib.dst[i] = v[u]; }
     }
+    for (int i = threadIdx.x; i < ib.n_clear; i += blockDim.x) ib.clear[i] = 0;
     __syncthreads();
     if (threadIdx.x == 0) { __threadfence_system(); __hip_atomic_store(ib.mail + ib.slot, ib.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }
@@ -1201,9 +1202,9 @@ int launch_slice_prepare(pre3_ctx *c, const void *src_host_mapped, size_t n16, i
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }
-int launch_inbox_pull(pre3_ctx *c, const void *src_host_mapped, void *dst_dev, size_t n16, int32_t seq, int slot)
+int launch_inbox_pull(pre3_ctx *c, const void *src_host_mapped, void *dst_dev, size_t n16, int32_t seq, int slot, int32_t *clear, int n_clear)
 {
-    hipLaunchKernelGGL(k_inbox_pull, dim3(1), dim3(1024), 0, c->stream, InboxRide{ (const int4 *)src_host_mapped, (int4 *)dst_dev, (int)n16, c->mail_dev, seq, slot });
+    hipLaunchKernelGGL(k_inbox_pull, dim3(1), dim3(1024), 0, c->stream, InboxRide{ (const int4 *)src_host_mapped, (int4 *)dst_dev, (int)n16, c->mail_dev, seq, slot, clear, n_clear });
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }

@@ -161,6 +161,7 @@ struct pre3_ctx {
     // no synchronisation, no read-back (pre3_api.hip: stage_acquire / stage_release)
     void *up_stage[2] = { nullptr, nullptr }; hipEvent_t up_stage_ev[2] = { nullptr, nullptr }; bool up_stage_used[2] = { false, false };
     int up_stage_next = 0; size_t up_stage_bytes = 0;
+    int32_t stage_seq[4] = { 0, 0, 0, 0 };          // sequence number of the last pull of staging block k (0, 1: uploads; 2, 3: map management)
     void *ic_result_host = nullptr, *ic_result_host_dev = nullptr; int32_t seq_ic = 0;    // the IC search's result block in mapped pinned memory: written by the device, announced through mailbox word 12
     int32_t *ic_pred = nullptr, *ic_counts = nullptr, *ic_arg = nullptr, *ic_pairs = nullptr, *ic_newk2 = nullptr; double *ic_best = nullptr, *ic_second = nullptr;
     int32_t *bank_src = nullptr;
@@ -228,7 +229,8 @@ bool ic_search_fused_applies(const pre3_ctx *c);      /* N * K2 <= 2^20 pairs, N
 int launch_ic_search_fused(pre3_ctx *c, double thresh, int strict, int32_t seq, int slot, bool matched);      /* matched: the matcher rode in the projection's launch */
 int launch_bank_gather(pre3_ctx *c, int N_new, const int32_t *src_host);
 int ic_rank_set_scan(pre3_ctx *c, bool in_bounds);
-int launch_pull(pre3_ctx *c, const void *pinned_host, void *dst_dev, size_t bytes);      // pinned host block -> device, by a kernel (pre3_api.hip)
+int launch_pull(pre3_ctx *c, const void *pinned_host, void *dst_dev, size_t bytes, int done_slot = -1);      // done_slot >= 0: the pull announces itself in mailbox word 16 + slot (stage_wait)
+int stage_wait(pre3_ctx *c, int k);      // pinned host block -> device, by a kernel (pre3_api.hip)
 void ic_rank_free(pre3_ctx *c);
 constexpr int DESC_DIM = 128;
 

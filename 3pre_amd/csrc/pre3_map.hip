@@ -384,7 +384,7 @@ static int apply_map(pre3_ctx *c, const std::vector<int32_t> &desc, int n_new, c
     PRE3_CHECK(n == n_new, PRE3_E_STATE, "map management: internal size mismatch (%d vs %d)", n, n_new);
     // ---- stage: [desc 3 n_new | types N | off N | src N | pad to 8 bytes | uvd 2 n_feat, rho n_feat]
     const int k = c->map_stage_next; c->map_stage_next ^= 1;
-    if (c->map_stage_used[k]) PRE3_HIP(hipEventSynchronize(c->map_stage_ev[k]));
+    if (c->map_stage_used[k]) PRE3_TRY(stage_wait(c, 2 + k));
     int32_t *st = static_cast<int32_t *>(c->map_stage[k]);
     const size_t o_types = desc.size(), o_off = o_types + (size_t)N, o_src = o_off + (size_t)N, o_end = (o_src + (size_t)N + 1) & ~(size_t)1;
     memcpy(st, desc.data(), sizeof(int32_t) * desc.size());
@@ -396,8 +396,7 @@ static int apply_map(pre3_ctx *c, const std::vector<int32_t> &desc, int n_new, c
         bytes += sizeof(double) * 3 * (size_t)n_feat;
     }
     PRE3_CHECK(bytes <= c->map_stage_bytes, PRE3_E_ARG, "map management: staging block too small");
-    PRE3_TRY(launch_pull(c, st, c->map_desc, bytes));        // (read over PCIe by the device: no DMA-engine copy)
-    PRE3_HIP(hipEventRecord(c->map_stage_ev[k], c->stream));
+    PRE3_TRY(launch_pull(c, st, c->map_desc, bytes, 2 + k));        // (read over PCIe by the device: no DMA-engine copy; announces itself: no event)
     c->map_stage_used[k] = true;
     const int32_t *d_types = c->map_desc + o_types, *d_off = c->map_desc + o_off, *d_src = c->map_desc + o_src;
     if (n_feat > 0) {
