@@ -324,7 +324,7 @@ def fp64_n200_leg(pre3, synth, steps=40, warm=4):
         for s in seq["steps"][:1 + warm]:
             one(s)
         f.sync()
-        f.kernel_timing(1)
+        f.kernel_timing(8)      # one K9 launch in eight between HIP events, as the headline does: an event's record is a barrier packet with a completion signal, ~6 us of stream time each
         f.timer_start()
         for s in seq["steps"][1 + warm:1 + warm + steps]:
             one(s)
