@@ -404,7 +404,8 @@ PRE3_API int pre3_knn_f64(int device, int D, int N, const double *data, int M, c
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------------------- */
 /* HIP-event timing on the ctx stream: the timed region of bench.py and the per-launch duration of
- * the covariance down-date kernel (K9) are measured with these, not with torch events. */
+ * the covariance down-date kernel (K9) are measured with these, not with torch events.  An event's record is a barrier packet with a
+ * completion signal in the stream: the launch behind it starts ~6 us late, so a bracket costs ~12 us of stream time -- time one launch in N. */
 PRE3_API int pre3_timer_start(pre3_ctx *ctx);
 PRE3_API int pre3_timer_stop(pre3_ctx *ctx, double *ms_out);             /* synchronises */
 PRE3_API int pre3_kernel_timing(pre3_ctx *ctx, int enable);             /* 1: bracket every K9 launch of >= 128 rows (the matrix-bound ones) with events; N > 1: one such launch in N; 0: off */
