@@ -762,32 +762,63 @@ __global__ __launch_bounds__(CH_NTH) void k_hi_fused(HiFused a)
     __shared__ ChSmem<float> sm;
     __shared__ HfSmem hf;
     const int tid = threadIdx.x, b = blockIdx.x;
-    // ---- the HI list (rescue_hi_inliers.m:44-46: ic && !li && hi), in measurement order.  The flags of all measurements are fetched by the
-    //      whole workgroup at once (two dependent load levels, paid once: a single wave walking the list chunk by chunk took 9 us), then one
-    //      wave compacts them from LDS with ballots.
-    unsigned char *flg = reinterpret_cast<unsigned char *>(&sm.Bs[0][0]);          // [m] (Bs is free until the chain; m <= 16 K)
-    for (int j = tid; j < a.m; j += CH_NTH) {
-        const int i = a.meas[j];
-        const int in = (a.lm_ic[i] == 1 && a.lm_li[i] == 0) ? a.lm_hi[i] : 0;
-        flg[j] = (unsigned char)(in != 0);
-        if (b == 0) a.hi_meas[j] = in;
-    }
-    __syncthreads();
-    if (tid < 64) {
-        int cnt = 0;
-        for (int base = 0; base < a.m; base += 64) {
-            const int j = base + tid;
-            const int in = j < a.m ? flg[j] : 0;
-            const unsigned long long mask = __ballot(in);
-            const int pos = cnt + __popcll(mask & ((1ull << tid) - 1ull));
-            if (in && pos < HF_MAXL2) hf.list[pos] = j;
-            if (in && b == 0) a.sel_rows[pos] = j;
-            cnt += __popcll(mask);
+    // ---- the HI list (rescue_hi_inliers.m:44-46: ic && !li && hi), in measurement order, and the rows of its landmarks (k_build_rows / k_ell_HP_build:
+    //      row 2s+c of HI measurement s = [Hc(c,:) | Hl(c,:)] at columns [0..6 | off..off+d-1], nu = z - h).  A lane takes one measurement: its
+    //      landmark's flags are one load level behind meas[j], and a rescued landmark's Hc / Hl / z / h / type / off are fetched on the SAME level, before
+    //      the ballot prefix has told the lane its position in the list (round 5: the rows used to be two more dependent load levels behind the list)
+    __shared__ int s_wc[CH_NTH / 64];
+    const int lane = tid & 63, wv = tid >> 6;
+    int cnt = 0;
+    for (int j0 = 0; j0 < a.m; j0 += CH_NTH) {
+        const int j = j0 + tid;
+        int in = 0, i = 0;
+        if (j < a.m) {
+            i = a.meas[j];
+            const int f_ic = a.lm_ic[i], f_li = a.lm_li[i], f_hi = a.lm_hi[i];
+            in = (f_ic == 1 && f_li == 0) ? f_hi : 0;
+            if (b == 0) a.hi_meas[j] = in;
         }
-        if (tid == 0) hf.cnt = cnt;
+        double hc[14], hl[12], zz[2] = { 0, 0 }, hh[2] = { 0, 0 };
+        int ty = 0, of = 0;
+        if (in) {
+#pragma unroll
+            for (int t = 0; t < 14; ++t) hc[t] = a.Hc[14 * i + t];
+#pragma unroll
+            for (int t = 0; t < 12; ++t) hl[t] = a.Hl[12 * i + t];
+            zz[0] = a.z[2 * i]; zz[1] = a.z[2 * i + 1]; hh[0] = a.h[2 * i]; hh[1] = a.h[2 * i + 1];
+            ty = a.lm_type[i]; of = a.lm_off[i];
+        }
+        const unsigned long long mask = __ballot(in != 0);
+        if (lane == 0) s_wc[wv] = __popcll(mask);
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < CH_NTH / 64; ++w) { const int cw = s_wc[w]; if (w < wv) woff += cw; tot += cw; }
+        if (in) {
+            const int pos = cnt + woff + __popcll(mask & ((1ull << lane) - 1ull));
+            if (b == 0) a.sel_rows[pos] = j;
+            if (pos < HF_MAXL2) {
+                hf.list[pos] = j;
+                const int d = ty == PRE3_INVDEPTH ? 6 : 3;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int row = 2 * pos + c;
+#pragma unroll
+                    for (int t = 0; t < 7; ++t) { hf.rc[row][t] = t; hf.rv[row][t] = (float)hc[7 * c + t]; }
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) { hf.rc[row][7 + t] = t < d ? of + t : 0; hf.rv[row][7 + t] = t < d ? (float)hl[6 * c + t] : 0.f; }
+                    const double nu = zz[c] - hh[c];
+                    hf.nu[row] = (float)nu;
+                    if (b == 0) a.row_nu[row] = nu;         // (for whoever reads the rows behind this launch; the general path rebuilds them)
+                }
+#pragma unroll
+                for (int t = 0; t < 6; ++t) hf.ucol[7 + 6 * pos + t] = t < d ? of + t : 0;
+            }
+        }
+        cnt += tot;
+        __syncthreads();                                   // (s_wc is rewritten by the next pass)
     }
-    __syncthreads();
-    const int cnt = hf.cnt, r = 2 * cnt;
+    const int r = 2 * cnt;
     const bool here = cnt >= 1 && cnt <= a.max_l;
     if (b == 0 && tid == 0) {
         a.stats[5] = cnt; a.stats[8] = here ? 1 : 0;
@@ -800,24 +831,10 @@ __global__ __launch_bounds__(CH_NTH) void k_hi_fused(HiFused a)
     if (!here) return;
     const bool two = cnt > HF_MAXL;                    // 33 .. 64 landmarks: two panels
     const int r_pad = two ? 2 * NB : NB;
-    // ---- the rows (k_build_rows / k_ell_HP_build): row 2s+c of HI measurement s = [Hc(c,:) | Hl(c,:)] at columns [0..6 | off..off+d-1], nu = z - h
+    // the padding rows of the last panel: zero rows of H against identity rows of S
     if (tid < r_pad) {
         const int row = tid;
-        if (row < r) {
-            const int i = a.meas[hf.list[row >> 1]], c = row & 1;
-            const int d = a.lm_type[i] == PRE3_INVDEPTH ? 6 : 3, off = a.lm_off[i];
-#pragma unroll
-            for (int t = 0; t < 7; ++t) { hf.rc[row][t] = t; hf.rv[row][t] = (float)a.Hc[14 * i + 7 * c + t]; }
-#pragma unroll
-            for (int t = 0; t < 6; ++t) { hf.rc[row][7 + t] = t < d ? off + t : 0; hf.rv[row][7 + t] = t < d ? (float)a.Hl[12 * i + 6 * c + t] : 0.f; }
-            const double nu = a.z[2 * i + c] - a.h[2 * i + c];
-            hf.nu[row] = (float)nu;
-            if (c == 0) {
-#pragma unroll
-                for (int t = 0; t < 6; ++t) hf.ucol[7 + 6 * (row >> 1) + t] = t < d ? off + t : 0;
-            }
-            if (b == 0) a.row_nu[row] = nu;
-        } else {
+        if (row >= r) {
 #pragma unroll
             for (int t = 0; t < 13; ++t) { hf.rc[row][t] = 0; hf.rv[row][t] = 0.f; }
             hf.nu[row] = 0.f;
