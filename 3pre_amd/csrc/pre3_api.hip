@@ -159,7 +159,12 @@ int stage_wait(pre3_ctx *c, int k)
         }
     }
     PRE3_HIP(hipStreamSynchronize(c->stream));
-    PRE3_CHECK(__atomic_load_n(w, __ATOMIC_ACQUIRE) == seq, PRE3_E_STATE, "staging block %d: its pull has not run", k);
+    if (__atomic_load_n(w, __ATOMIC_ACQUIRE) != seq) {
+        c->stage_seq[k] = 0;                         // (the stream is idle: the block is free whatever became of that launch; the next pull starts a fresh count)
+        (void)hipMemsetAsync(c->chol_arrive + 8 + k, 0, sizeof(unsigned int), c->stream);
+        set_error("staging block %d: its pull has not run", k);
+        return PRE3_E_STATE;
+    }
     return PRE3_OK;
 }
 static StageDone stage_done(pre3_ctx *c, int k) { return StageDone{ c->chol_arrive + 8 + k, c->mail_dev + 16 + k, ++c->stage_seq[k] }; }
