@@ -159,6 +159,60 @@ def test_ic_search_edges(pre3, orc):
     f.close()
 
 
+@pytest.mark.parametrize("N,K2", [(37, 45), (65, 33), (96, 640)])
+def test_fused_route_on_ragged_sizes(pre3, orc, N, K2):
+    """the two-launch route's 32 x 32 pair tiles on sizes that are not multiples of 32 (ragged last tiles both ways; 96 x 640: twenty column tiles,
+    two batches of the gate's merge) against the oracle's composition, bit for bit"""
+    rng, seq, bank = _scene(N, 41 + N)
+    s = seq["steps"][0]
+    types, off, n = orc.landmark_table(np.zeros(N, int))
+    f = pre3.EkfFilter(seq["cam"], types, dtype="f64", max_hyp=8)
+    f.set_x_p_k_k(seq["x0"], seq["P0"]); f.set_descriptors(bank); f.ekf_prediction(s["u"])
+    x1, P1 = f.get_x_k_km1(), f.get_p_k_km1()
+    h, has_h = orc.project(types, off, x1, seq["cam"])
+    n_seen = int(has_h.sum())
+    sd, sp = _scan(rng, h, has_h, bank, max(0, K2 - n_seen), frac_seen=1.0, px_sigma=3.0)
+    sd, sp = sd[:, :K2].copy(), sp[:, :K2].copy()
+    f.load_scan(sd, sp)
+    out = f.matching_sift_based(1.5, strict_reference=True)
+    assert f.ic_search_route() == 2
+    ref = orc.ic_search(types, off, x1, P1, seq["cam"], bank, sd, sp, 1.5, True)
+    assert ref["match_idx"].shape[1] > 5
+    assert np.array_equal(out["match_idx"], ref["match_idx"]) and np.array_equal(out["accepted"], ref["accepted"])
+    assert np.array_equal(out["meas_idx"], ref["meas_idx"]) and np.array_equal(out["z"], ref["z"])
+    assert np.array_equal(f.get_descriptors(), ref["bank"])
+    f.close()
+
+
+def test_fused_route_with_no_predicted_landmark(pre3, orc):
+    """the camera looks away from the map (a half turn about the vertical axis): index_in_info is empty, no match, no measurement -- and the next
+    search, with the camera back, is unaffected"""
+    N = 40
+    rng, seq, bank = _scene(N, 43)
+    s = seq["steps"][0]
+    types, off, n = orc.landmark_table(np.zeros(N, int))
+    f = pre3.EkfFilter(seq["cam"], types, dtype="f64", max_hyp=8)
+    x_away = seq["x0"].copy(); x_away[3:7] = [0.0, 0.0, 1.0, 0.0]
+    f.set_x_p_k_k(x_away, seq["P0"]); f.set_descriptors(bank); f.ekf_prediction(np.array([0, 0, 0, 1.0, 0, 0, 0]))
+    h, has_h = orc.project(types, off, f.get_x_k_km1(), seq["cam"])
+    assert has_h.sum() == 0
+    sd = np.abs(rng.normal(0, 1, (128, 50))); sd /= np.linalg.norm(sd, axis=0)
+    sp = np.stack([rng.uniform(1, 176, 50), rng.uniform(1, 144, 50), np.full(50, 2.0), np.zeros(50)])
+    f.load_scan(sd, sp)
+    out = f.matching_sift_based(1.5)
+    assert f.ic_search_route() == 2 and out["match_idx"].shape == (2, 0) and len(out["meas_idx"]) == 0 and f.m == 0
+    assert np.array_equal(f.get_descriptors(), bank)
+    f.set_x_p_k_k(seq["x0"], seq["P0"]); f.ekf_prediction(s["u"])
+    x1, P1 = f.get_x_k_km1(), f.get_p_k_km1()
+    h, has_h = orc.project(types, off, x1, seq["cam"])
+    sd, sp = _scan(rng, h, has_h, bank, 20, px_sigma=3.0)
+    f.load_scan(sd, sp)
+    out = f.matching_sift_based(1.5)
+    ref = orc.ic_search(types, off, x1, P1, seq["cam"], bank, sd, sp, 1.5, True)
+    assert ref["match_idx"].shape[1] > 5 and np.array_equal(out["match_idx"], ref["match_idx"]) and np.array_equal(out["meas_idx"], ref["meas_idx"])
+    f.close()
+
+
 def test_descriptor_bank_follows_the_map(pre3, orc):
     N = 16
     rng, seq, bank = _scene(N, 31)
