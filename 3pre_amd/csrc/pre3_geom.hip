@@ -833,21 +833,56 @@ __global__ __launch_bounds__(256) void k_select_gather_lds(int n_draw, int k, in
     const T *src[SGL_RB];
 #pragma unroll
     for (int q = 0; q < SGL_RB; ++q) { const int a = a0 + q; src[q] = a < r ? HP + (size_t)(2 * s_sel[a >> 1] + (a & 1)) * ldw : nullptr; }
-    for (int j = tid * 4; j < ldw; j += 1024) {
-        v4_t v[SGL_RB];
+    // every load of the workgroup is in flight before its first store (round 5): the ELL row of this lane's first column of S, and the four rows of
+    // H*P in up to four 16-byte pieces per lane -- they used to be three to four dependent round trips to an L2 that another XCD wrote
+    const bool any0 = tid < r && tid <= a0 + SGL_RB - 1;
+    T vv0[ELLW]; int cc0[ELLW];
 #pragma unroll
-        for (int q = 0; q < SGL_RB; ++q) v[q] = src[q] ? *reinterpret_cast<const v4_t *>(src[q] + j) : v4_t{ (T)0, (T)0, (T)0, (T)0 };
+    for (int t = 0; t < ELLW; ++t) { vv0[t] = (T)0; cc0[t] = 0; }
+    if (any0) {
+        const int rb = 2 * s_sel[tid >> 1] + (tid & 1);
 #pragma unroll
-        for (int q = 0; q < SGL_RB; ++q) {
-            *reinterpret_cast<v4_t *>(W + (size_t)(a0 + q) * ldw + j) = v[q];
-            *reinterpret_cast<v4_t *>(rows + (size_t)q * ldw + j) = v[q];
+        for (int t = 0; t < ELLW; ++t) { vv0[t] = row_val[rb * ELLW + t]; cc0[t] = row_col[rb * ELLW + t]; }
+    }
+    {
+        constexpr int NIT = 4;                              // (the staged form holds four rows of at most ~3400 columns: four pieces of 1024)
+        v4_t v[NIT][SGL_RB];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int j = tid * 4 + it * 1024;
+#pragma unroll
+            for (int q = 0; q < SGL_RB; ++q) v[it][q] = (j < ldw && src[q]) ? *reinterpret_cast<const v4_t *>(src[q] + j) : v4_t{ (T)0, (T)0, (T)0, (T)0 };
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int j = tid * 4 + it * 1024;
+            if (j < ldw) {
+#pragma unroll
+                for (int q = 0; q < SGL_RB; ++q) {
+                    *reinterpret_cast<v4_t *>(W + (size_t)(a0 + q) * ldw + j) = v[it][q];
+                    *reinterpret_cast<v4_t *>(rows + (size_t)q * ldw + j) = v[it][q];
+                }
+            }
+        }
+        for (int j = tid * 4 + NIT * 1024; j < ldw; j += 1024) {
+            v4_t w[SGL_RB];
+#pragma unroll
+            for (int q = 0; q < SGL_RB; ++q) w[q] = src[q] ? *reinterpret_cast<const v4_t *>(src[q] + j) : v4_t{ (T)0, (T)0, (T)0, (T)0 };
+#pragma unroll
+            for (int q = 0; q < SGL_RB; ++q) {
+                *reinterpret_cast<v4_t *>(W + (size_t)(a0 + q) * ldw + j) = w[q];
+                *reinterpret_cast<v4_t *>(rows + (size_t)q * ldw + j) = w[q];
+            }
         }
     }
     __syncthreads();
     for (int b = tid; b < r_pad; b += 256) {
         const bool any = b < r && b <= a0 + SGL_RB - 1;
         T vv[ELLW]; int cc[ELLW];
-        if (any) {
+        if (b == tid) {
+#pragma unroll
+            for (int t = 0; t < ELLW; ++t) { vv[t] = vv0[t]; cc[t] = cc0[t]; }
+        } else if (any) {
             const int rb = 2 * s_sel[b >> 1] + (b & 1);
 #pragma unroll
             for (int t = 0; t < ELLW; ++t) { vv[t] = row_val[rb * ELLW + t]; cc[t] = row_col[rb * ELLW + t]; }
