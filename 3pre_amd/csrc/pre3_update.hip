@@ -210,7 +210,8 @@ template <typename T, bool PRO, bool EARLY = false, bool PREBUILT = false>
 __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb,
                                                 int32_t *__restrict__ status, const int b, unsigned int *__restrict__ arrive, unsigned int target,
                                                 void *__restrict__ Wp = nullptr, int nst_total = 0, int ld = 0, void *__restrict__ Sp = nullptr, int sp_stride = 0,
-                                                int rows_last = 0 /* > 0: real rows of the LAST panel (the rest of it is padding) */)
+                                                int rows_last = 0 /* > 0: real rows of the LAST panel (the rest of it is padding) */,
+                                                int pend2 = 0 /* 1 (planes form, J >= 2): the updates of panels J-2 AND J-1 are pending for this column -- the trailing launches sweep two panels at a time */)
 {
     PROBE_STAMP(0);
     auto &Ls = sm.Ls; auto &Xs = sm.Xs;
@@ -256,11 +257,12 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
             // operands as bf16 planes (written by the store epilogues of launch J-1), this wave's fragments straight into registers.
             // A operand: rows w0.. of B = M(J, J-1).  B operand: D tile -> rows w1.. of B;  X tile -> the own block's rows / columns w1..
             if (tile_live && J > 0) {                    // (panel 0 has no pending update: pacc stays 0)
-                const frag_t *Bp = static_cast<const frag_t *>(Sp) + ((size_t)J * sp_stride + (J - 1)) * B3_SGRAN + lane;
+                const int Jp = pend2 ? J - 2 : J - 1;    // (two pending panels: the older one first, as the sweep would have applied them)
+                const frag_t *Bp = static_cast<const frag_t *>(Sp) + ((size_t)J * sp_stride + Jp) * B3_SGRAN + lane;
                 const frag_t *Op; int ostage, oplane;
                 if (!xside) { Op = Bp + fb * 64; ostage = 384; oplane = 128; }
-                else if (!isW) { Op = static_cast<const frag_t *>(Sp) + ((size_t)(J + b) * sp_stride + (J - 1)) * B3_SGRAN + fb * 64 + lane; ostage = 384; oplane = 128; }
-                else { Op = static_cast<const frag_t *>(Wp) + ((size_t)(c0 >> 7) * nst_total + 4 * (J - 1)) * B3_GRAN + (2 * ((c0 >> 6) & 1) + fb) * 64 + lane; ostage = B3_GRAN; oplane = 256; }
+                else if (!isW) { Op = static_cast<const frag_t *>(Sp) + ((size_t)(J + b) * sp_stride + Jp) * B3_SGRAN + fb * 64 + lane; ostage = 384; oplane = 128; }
+                else { Op = static_cast<const frag_t *>(Wp) + ((size_t)(c0 >> 7) * nst_total + 4 * Jp) * B3_GRAN + (2 * ((c0 >> 6) & 1) + fb) * 64 + lane; ostage = B3_GRAN; oplane = 256; }
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -321,8 +323,15 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
                 for (int e = 0; e < 16; ++e) pacc[e] = 0.f;
 #define PRO_MMA(px, py) pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fA[q][px]), __builtin_bit_cast(bf16x8_t, fB[q][py]), pacc, 0, 0, 0)
                 if (J > 0) {
+                    // (two pending panels: the older one's update of an S block below the diagonal used to come from the trailing sweep, whose tile has
+                    //  the two factors in the other operand roles -- its six plane products in that sweep's order, so that the sum rounds as there)
+                    if (pend2 && xside && !isW) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { PRO_MMA(0, 0); PRO_MMA(0, 1); PRO_MMA(1, 0); PRO_MMA(1, 1); PRO_MMA(0, 2); PRO_MMA(2, 0); }
+                        for (int q = 0; q < 4; ++q) { PRO_MMA(0, 0); PRO_MMA(1, 0); PRO_MMA(0, 1); PRO_MMA(1, 1); PRO_MMA(2, 0); PRO_MMA(0, 2); }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { PRO_MMA(0, 0); PRO_MMA(0, 1); PRO_MMA(1, 0); PRO_MMA(1, 1); PRO_MMA(0, 2); PRO_MMA(2, 0); }
+                    }
                 }
 #undef PRO_MMA
                 const int lrow = 4 * (lane >> 5), lcol = lane & 31;
@@ -330,6 +339,26 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
                 for (int e = 0; e < 16; ++e) {
                     const int r = w0 + (e & 3) + 8 * (e >> 2) + lrow, c = w1 + lcol;
                     acc[0][0][e] = (xside ? Xs[r][c] : Ls[r][c]) - pacc[e];
+                }
+                if (pend2 && J > 1) {
+                    // ... then panel J-1's: its fragments now (the registers are free again), the same six products, subtracted from the rounded difference
+                    const frag_t *Bp = static_cast<const frag_t *>(Sp) + ((size_t)J * sp_stride + (J - 1)) * B3_SGRAN + lane;
+                    const frag_t *Op; int ostage, oplane;
+                    if (!xside) { Op = Bp + fb * 64; ostage = 384; oplane = 128; }
+                    else if (!isW) { Op = static_cast<const frag_t *>(Sp) + ((size_t)(J + b) * sp_stride + (J - 1)) * B3_SGRAN + fb * 64 + lane; ostage = 384; oplane = 128; }
+                    else { Op = static_cast<const frag_t *>(Wp) + ((size_t)(c0 >> 7) * nst_total + 4 * (J - 1)) * B3_GRAN + (2 * ((c0 >> 6) & 1) + fb) * 64 + lane; ostage = B3_GRAN; oplane = 256; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) { fA[q][pl] = Bp[q * 384 + pl * 128 + fa * 64]; fB[q][pl] = Op[q * ostage + pl * oplane]; }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) pacc[e] = 0.f;
+#define PRO_MMA(px, py) pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fA[q][px]), __builtin_bit_cast(bf16x8_t, fB[q][py]), pacc, 0, 0, 0)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { PRO_MMA(0, 0); PRO_MMA(0, 1); PRO_MMA(1, 0); PRO_MMA(1, 1); PRO_MMA(0, 2); PRO_MMA(2, 0); }
+#undef PRO_MMA
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[0][0][e] = acc[0][0][e] - pacc[e];
                 }
             }
             acc_loaded = true;
@@ -423,41 +452,50 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
 // One 64x64 tile of the trailing update with its operands as bf16 planes (written by the store epilogues of the launch that solved panel J):
 // fragments straight from global memory, six bf16 products per f32 product, no LDS and no barrier -- a third of the matrix-pipe time of
 // the f32 form.  256 threads.
+// J2 >= 0 (round 5): the updates of TWO panels, J then J2 = J + 1, in one pass over the tile -- (C - A_J B_J') - A_J2 B_J2', each product rounded and
+// subtracted as the one-panel-per-launch sweep does, so the bits are the same; the tile is read and written once instead of twice.
 __device__ __forceinline__ void chol_trail_b3_tile(float *__restrict__ S, int lds, float *__restrict__ W, int ldw, int J, bool isW, int rb, int K, int c0,
-                                       const void *__restrict__ Wp, int nst_total, const void *__restrict__ Sp, int sp_stride)
+                                       const void *__restrict__ Wp, int nst_total, const void *__restrict__ Sp, int sp_stride, int J2 = -1)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w0 = (wave >> 1) * 32, w1 = (wave & 1) * 32;
     typedef int frag_t __attribute__((ext_vector_type(4)));
     const int fa = wave >> 1, fb = wave & 1, lrow = 4 * (lane >> 5), lcol = lane & 31;
-    const frag_t *Ap, *Bp;
-    int bstage, bplane;
-    if (!isW) {
-        Ap = static_cast<const frag_t *>(Sp) + ((size_t)rb * sp_stride + J) * B3_SGRAN + fa * 64 + lane;
-        Bp = static_cast<const frag_t *>(Sp) + ((size_t)K * sp_stride + J) * B3_SGRAN + fb * 64 + lane; bstage = 384; bplane = 128;
-    } else {
-        Ap = static_cast<const frag_t *>(Sp) + ((size_t)K * sp_stride + J) * B3_SGRAN + fa * 64 + lane;
-        Bp = static_cast<const frag_t *>(Wp) + ((size_t)(c0 >> 7) * nst_total + 4 * J) * B3_GRAN + (2 * ((c0 >> 6) & 1) + fb) * 64 + lane; bstage = B3_GRAN; bplane = 256;
-    }
-    frag_t fA[4][3], fB[4][3];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) { fA[q][pl] = Ap[q * 384 + pl * 128]; fB[q][pl] = Bp[q * bstage + pl * bplane]; }
     float cvv[16];
     float *Cbase = !isW ? S + (size_t)(rb * NB + w0) * lds + K * NB + w1 + lcol : W + (size_t)(K * NB + w0) * ldw + c0 + w1 + lcol;
     const int cld = !isW ? lds : ldw;
+    for (int pass = 0; pass < (J2 >= 0 ? 2 : 1); ++pass) {
+        const int Jp = pass == 0 ? J : J2;
+        const frag_t *Ap, *Bp;
+        int bstage, bplane;
+        if (!isW) {
+            Ap = static_cast<const frag_t *>(Sp) + ((size_t)rb * sp_stride + Jp) * B3_SGRAN + fa * 64 + lane;
+            Bp = static_cast<const frag_t *>(Sp) + ((size_t)K * sp_stride + Jp) * B3_SGRAN + fb * 64 + lane; bstage = 384; bplane = 128;
+        } else {
+            Ap = static_cast<const frag_t *>(Sp) + ((size_t)K * sp_stride + Jp) * B3_SGRAN + fa * 64 + lane;
+            Bp = static_cast<const frag_t *>(Wp) + ((size_t)(c0 >> 7) * nst_total + 4 * Jp) * B3_GRAN + (2 * ((c0 >> 6) & 1) + fb) * 64 + lane; bstage = B3_GRAN; bplane = 256;
+        }
+        frag_t fA[4][3], fB[4][3];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) cvv[e] = Cbase[(size_t)((e & 3) + 8 * (e >> 2) + lrow) * cld];
-    f32x16_t acc;
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            for (int pl = 0; pl < 3; ++pl) { fA[q][pl] = Ap[q * 384 + pl * 128]; fB[q][pl] = Bp[q * bstage + pl * bplane]; }
+        if (pass == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) cvv[e] = Cbase[(size_t)((e & 3) + 8 * (e >> 2) + lrow) * cld];
+        }
+        f32x16_t acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #define TR_MMA(px, py) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fA[q][px]), __builtin_bit_cast(bf16x8_t, fB[q][py]), acc, 0, 0, 0)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { TR_MMA(0, 0); TR_MMA(0, 1); TR_MMA(1, 0); TR_MMA(1, 1); TR_MMA(0, 2); TR_MMA(2, 0); }
+        for (int q = 0; q < 4; ++q) { TR_MMA(0, 0); TR_MMA(0, 1); TR_MMA(1, 0); TR_MMA(1, 1); TR_MMA(0, 2); TR_MMA(2, 0); }
 #undef TR_MMA
 #pragma unroll
-    for (int e = 0; e < 16; ++e) Cbase[(size_t)((e & 3) + 8 * (e >> 2) + lrow) * cld] = cvv[e] - acc[e];
+        for (int e = 0; e < 16; ++e) cvv[e] = cvv[e] - acc[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Cbase[(size_t)((e & 3) + 8 * (e >> 2) + lrow) * cld] = cvv[e];
 }
 
 // tile number -> (S tile (rb, K) | W tile (K, c0)) of the update of panel J applied to column blocks >= K0
@@ -478,11 +516,11 @@ __device__ __forceinline__ void chol_trail_decode(int idx, int K0, int nrb, int 
 // The trailing update as a launch of its own (no LDS: 8 workgroups per CU instead of the 2 that k_chol_step's 75 KB allow): used when
 // the update has far more tiles than the chip has slots (large r and n), where it -- not the panel's chain -- sets the pace.
 __global__ __launch_bounds__(256) void k_chol_trail_b3(float *__restrict__ S, int lds, float *__restrict__ W, int ldw, int J, int K0, int nrb, int nW,
-                                                       const void *__restrict__ Wp, int nst_total, const void *__restrict__ Sp, int sp_stride)
+                                                       const void *__restrict__ Wp, int nst_total, const void *__restrict__ Sp, int sp_stride, int J2)
 {
     bool isW; int rb, K, c0;
     chol_trail_decode(blockIdx.x, K0, nrb, nW, isW, rb, K, c0);
-    chol_trail_b3_tile(S, lds, W, ldw, J, isW, rb, K, c0, Wp, nst_total, Sp, sp_stride);
+    chol_trail_b3_tile(S, lds, W, ldw, J, isW, rb, K, c0, Wp, nst_total, Sp, sp_stride, J2);
 }
 
 // Trailing update on the matrix cores: one 64 x 64 tile  C -= A B'  (K = 64) per workgroup, 4 waves, each a
@@ -614,7 +652,7 @@ template <typename T, bool EARLY = false>
 __global__ __launch_bounds__(CH_NTH) void k_chol_step(T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb, int nW,
                                                    int nP, int32_t *__restrict__ status, unsigned int *__restrict__ arrive, unsigned int target,
                                                    int nPT, void *__restrict__ Wp, int nst_total, int ncb, int ld_split, void *__restrict__ Sp, int sp_stride,
-                                                   const int32_t *__restrict__ n_dev, int nS_max, int rows_last = 0)
+                                                   const int32_t *__restrict__ n_dev, int nS_max, int rows_last = 0, int pend2 = 0)
 {
     __shared__ ChSmem<T> sm;
     int b = blockIdx.x;
@@ -650,7 +688,7 @@ __global__ __launch_bounds__(CH_NTH) void k_chol_step(T *__restrict__ S, int lds
         return;
     }
     if (b < nP) {
-        chol_panel_body<T, true, EARLY>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target, Wp, nst_total, ld_split, Sp, sp_stride, rows_last);     // (J == 0: no pending update, skipped at run time)
+        chol_panel_body<T, true, EARLY>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target, Wp, nst_total, ld_split, Sp, sp_stride, rows_last, pend2);     // (J == 0: no pending update, skipped at run time)
     } else {
         chol_trail_body<T>(sm.As, sm.Bs, S, lds, W, ldw, J - 1, J + 1, nrb, nW, b - nP, Wp, nst_total, Sp, sp_stride);
     }
@@ -1793,18 +1831,29 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad, bool first_done = false, bo
         const bool pro_planes = split && pro_env && c->Sp != nullptr;       // pending updates on the bf16 MFMA as well
         static const int early_env = getenv("PRE3_CHOL_EARLY") ? atoi(getenv("PRE3_CHOL_EARLY")) : 1;
         const int rows_last = (early_env && r > 0 && r <= r_pad && r > r_pad - NB) ? r - (r_pad - NB) : 0;      // real rows of the last panel (0: unknown / switched off)
+        // a trailing update with far more tiles than k_chol_step has slots (2 workgroups per CU: its 75 KB of LDS) goes out as a launch
+        // of its own (no LDS, 8 workgroups per CU)
+        static const int trail_split = getenv("PRE3_CHOL_TRAIL_SPLIT") ? atoi(getenv("PRE3_CHOL_TRAIL_SPLIT")) : 4;
+        auto n_trail = [&](int J) { const int nK = J >= 1 ? nrb - J - 1 : 0; return nK * (nK + 1) / 2 + nK * nW; };      // tiles of panel J-1's update of the column blocks >= J+1
+        auto own_trail_at = [&](int J) { return pro_planes && trail_split > 0 && n_trail(J) > trail_split * 2 * c->num_cus; };
+        // Round 5: where the trailing update is a launch of its own it is bound by the read-modify-write of W's remaining rows (N = 2000: 4.8 GB per
+        // update over 40 panels), so it sweeps TWO panels at a time -- behind every odd panel J: panels J-1 and J on the column blocks >= J+2, each tile
+        // read and written once -- and the panels apply what is still pending for their own column themselves (an even panel: J-2 and J-1; an odd
+        // one: J-1).  Every product is rounded and subtracted in the order of the one-panel sweep: the same bits (PRE3_CHOL_TRAIL2=0: that sweep).
+        // The pairing ends with the even panel Jt from which on the update is small enough to ride in the panels' launches.
+        static const int trail2_env = getenv("PRE3_CHOL_TRAIL2") ? atoi(getenv("PRE3_CHOL_TRAIL2")) : 1;
+        int Jt = 0;
+        if (trail2_env && own_trail_at(1)) { Jt = 2; while (Jt < nrb && own_trail_at(Jt)) Jt += 2; }
         for (int J = first_done ? 1 : 0; J < nrb; ++J) {
             const int nS = nrb - J - 1, nP = 1 + nS + nW;
-            const int nK = J >= 1 ? nrb - J - 1 : 0;                        // column blocks >= J+1 of panel J-1's update
-            const int nT = nK * (nK + 1) / 2 + nK * nW;
+            const bool paired = J >= 1 && J <= Jt;                          // this panel's column is brought up to date by the panel itself
+            const int pend2 = paired && (J & 1) == 0 ? 1 : 0;
+            const int nT = paired ? 0 : n_trail(J);
             const int ncb = (split && !pro_planes && J >= 1) ? c->ld / B3_T : 0;   // split riders: 4 stages x ncb column blocks of row block J-1
-            // a trailing update with far more tiles than k_chol_step has slots (2 workgroups per CU: its 75 KB of LDS) goes out as a launch
-            // of its own in front of the panel (no LDS, 8 workgroups per CU); both only depend on the previous launch
-            static const int trail_split = getenv("PRE3_CHOL_TRAIL_SPLIT") ? atoi(getenv("PRE3_CHOL_TRAIL_SPLIT")) : 4;
-            const bool own_trail = pro_planes && trail_split > 0 && nT > trail_split * 2 * c->num_cus;
+            const bool own_trail = !paired && own_trail_at(J);
             if (own_trail)
                 hipLaunchKernelGGL(k_chol_trail_b3, dim3(nT), dim3(256), 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J - 1, J + 1, nrb, nW,
-                                   c->Wp, c->rcap / B3_BK, c->Sp, c->rcap / NB);
+                                   c->Wp, c->rcap / B3_BK, c->Sp, c->rcap / NB, -1);
             const int nT_in = own_trail ? 0 : nT;
             dim3 g(nP + nT_in + 4 * ncb), bP(CH_NTH);
             c->chol_target += (unsigned)(nP - 1);                           // every non-diagonal workgroup of the panel arrives once
@@ -1812,15 +1861,21 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad, bool first_done = false, bo
             if (early) {
                 DISPATCH_T(c,
                     hipLaunchKernelGGL((k_chol_step<double, true>), g, bP, 0, c->stream, (double *)c->Smat, r_pad, (double *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
-                                       nP + nT_in, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, rows_last),
+                                       nP + nT_in, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, rows_last, 0),
                     hipLaunchKernelGGL((k_chol_step<float, true>), g, bP, 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
-                                       nP + nT_in, split ? c->Wp : nullptr, c->rcap / B3_BK, ncb, c->ld, pro_planes ? c->Sp : nullptr, c->rcap / NB, nullptr, 0, rows_last));
+                                       nP + nT_in, split ? c->Wp : nullptr, c->rcap / B3_BK, ncb, c->ld, pro_planes ? c->Sp : nullptr, c->rcap / NB, nullptr, 0, rows_last, pend2));
             } else {
             DISPATCH_T(c,
                 hipLaunchKernelGGL(k_chol_step<double>, g, bP, 0, c->stream, (double *)c->Smat, r_pad, (double *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
-                                   nP + nT_in, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, 0),
+                                   nP + nT_in, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, 0, 0),
                 hipLaunchKernelGGL(k_chol_step<float>, g, bP, 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
-                                   nP + nT_in, split ? c->Wp : nullptr, c->rcap / B3_BK, ncb, c->ld, pro_planes ? c->Sp : nullptr, c->rcap / NB, nullptr, 0, 0));
+                                   nP + nT_in, split ? c->Wp : nullptr, c->rcap / B3_BK, ncb, c->ld, pro_planes ? c->Sp : nullptr, c->rcap / NB, nullptr, 0, 0, pend2));
+            }
+            if (paired && (J & 1) == 1 && J + 2 <= nrb - 1) {
+                // panels J-1 and J on everything from column block J+2 on
+                const int nK2 = nrb - (J + 2), nT2 = nK2 * (nK2 + 1) / 2 + nK2 * nW;
+                hipLaunchKernelGGL(k_chol_trail_b3, dim3(nT2), dim3(256), 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J - 1, J + 2, nrb, nW,
+                                   c->Wp, c->rcap / B3_BK, c->Sp, c->rcap / NB, J);
             }
         }
         if (split) c->split_rows = nrb * NB;

@@ -239,3 +239,39 @@ def test_downdate_consumers_inside_the_factorisation_are_bit_identical(pre3, N, 
     assert np.array_equal(x0, x1)
     assert np.array_equal(P0, P1), np.abs(P0 - P1).max()
     assert np.isfinite(P1).all() and np.abs(P1).max() > 0
+
+
+_TRAIL2_WORKER = r"""
+import hashlib, importlib, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+pre3 = importlib.import_module("3pre_amd"); synth = importlib.import_module("3pre_amd.synth")
+N = 500
+seq = synth.make_sequence(N, 1, 8); s = seq["steps"][0]
+h = hashlib.sha256()
+for m in (450, 500, 330):
+    f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", max_hyp=8, std_z=1.0)
+    f.chol_persist(False)
+    f.set_x_p_k_k(seq["x0"], seq["P0"]); f.ekf_prediction(s["u"]); f.search_IC_matches()
+    meas = np.arange(m, dtype=np.int32)
+    f.set_measurements(meas, f.landmark_fields()["h"][:m] + 0.25)
+    f.set_flags(li=np.ones(m, np.int32)); f.ekf_update_li_inliers()
+    P = f.get_p_k_k(); assert np.isfinite(P).all()
+    h.update(f.get_x_k_k().tobytes()); h.update(P.tobytes()); f.close()
+print("DIGEST", h.hexdigest())
+"""
+
+
+def test_two_panel_trailing_sweep_is_bit_identical_to_the_one_panel_sweep():
+    """launch-per-panel form with the trailing update as launches of its own (PRE3_CHOL_TRAIL_SPLIT=1 forces that at N = 500; it is N = 2000's form):
+    the sweep over two panels at a time (round 5: each tile read and written once per pair, the panels applying what is pending for their own column)
+    rounds and subtracts every product in the one-panel sweep's order -- updates of 15, 16 and 11 panels must give the same bits"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for v in ("1", "0"):
+        env = dict(os.environ, PRE3_CHOL_TRAIL2=v, PRE3_CHOL_TRAIL_SPLIT="1")
+        r = subprocess.run([sys.executable, "-c", _TRAIL2_WORKER % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out[v] = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0]
+    assert out["1"] == out["0"]
