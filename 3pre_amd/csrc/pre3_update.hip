@@ -211,7 +211,7 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
                                                 int32_t *__restrict__ status, const int b, unsigned int *__restrict__ arrive, unsigned int target,
                                                 void *__restrict__ Wp = nullptr, int nst_total = 0, int ld = 0, void *__restrict__ Sp = nullptr, int sp_stride = 0,
                                                 int rows_last = 0 /* > 0: real rows of the LAST panel (the rest of it is padding) */,
-                                                int pend2 = 0 /* 1 (planes form, J >= 2): the updates of panels J-2 AND J-1 are pending for this column -- the trailing launches sweep two panels at a time */)
+                                                int npend = 1 /* planes form: the updates of panels J-npend .. J-1 are pending for this column (the trailing launches sweep several panels at a time) */)
 {
     PROBE_STAMP(0);
     auto &Ls = sm.Ls; auto &Xs = sm.Xs;
@@ -257,7 +257,7 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
             // operands as bf16 planes (written by the store epilogues of launch J-1), this wave's fragments straight into registers.
             // A operand: rows w0.. of B = M(J, J-1).  B operand: D tile -> rows w1.. of B;  X tile -> the own block's rows / columns w1..
             if (tile_live && J > 0) {                    // (panel 0 has no pending update: pacc stays 0)
-                const int Jp = pend2 ? J - 2 : J - 1;    // (two pending panels: the older one first, as the sweep would have applied them)
+                const int Jp = J - npend;                 // (several pending panels: the oldest first, as the sweep would have applied them)
                 const frag_t *Bp = static_cast<const frag_t *>(Sp) + ((size_t)J * sp_stride + Jp) * B3_SGRAN + lane;
                 const frag_t *Op; int ostage, oplane;
                 if (!xside) { Op = Bp + fb * 64; ostage = 384; oplane = 128; }
@@ -323,9 +323,9 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
                 for (int e = 0; e < 16; ++e) pacc[e] = 0.f;
 #define PRO_MMA(px, py) pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fA[q][px]), __builtin_bit_cast(bf16x8_t, fB[q][py]), pacc, 0, 0, 0)
                 if (J > 0) {
-                    // (two pending panels: the older one's update of an S block below the diagonal used to come from the trailing sweep, whose tile has
+                    // (several pending panels: the older ones' updates of an S block below the diagonal used to come from the trailing sweep, whose tile has
                     //  the two factors in the other operand roles -- its six plane products in that sweep's order, so that the sum rounds as there)
-                    if (pend2 && xside && !isW) {
+                    if (npend > 1 && xside && !isW) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) { PRO_MMA(0, 0); PRO_MMA(1, 0); PRO_MMA(0, 1); PRO_MMA(1, 1); PRO_MMA(2, 0); PRO_MMA(0, 2); }
                     } else {
@@ -340,13 +340,15 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
                     const int r = w0 + (e & 3) + 8 * (e >> 2) + lrow, c = w1 + lcol;
                     acc[0][0][e] = (xside ? Xs[r][c] : Ls[r][c]) - pacc[e];
                 }
-                if (pend2 && J > 1) {
-                    // ... then panel J-1's: its fragments now (the registers are free again), the same six products, subtracted from the rounded difference
-                    const frag_t *Bp = static_cast<const frag_t *>(Sp) + ((size_t)J * sp_stride + (J - 1)) * B3_SGRAN + lane;
+                for (int u = 1; u < npend; ++u) {
+                    // ... then the next pending panel's: its fragments now (the registers are free again), the same six products -- in the sweep's order for
+                    // all but the newest panel, whose update was always this launch's --, subtracted from the rounded difference
+                    const int Jp = J - npend + u;
+                    const frag_t *Bp = static_cast<const frag_t *>(Sp) + ((size_t)J * sp_stride + Jp) * B3_SGRAN + lane;
                     const frag_t *Op; int ostage, oplane;
                     if (!xside) { Op = Bp + fb * 64; ostage = 384; oplane = 128; }
-                    else if (!isW) { Op = static_cast<const frag_t *>(Sp) + ((size_t)(J + b) * sp_stride + (J - 1)) * B3_SGRAN + fb * 64 + lane; ostage = 384; oplane = 128; }
-                    else { Op = static_cast<const frag_t *>(Wp) + ((size_t)(c0 >> 7) * nst_total + 4 * (J - 1)) * B3_GRAN + (2 * ((c0 >> 6) & 1) + fb) * 64 + lane; ostage = B3_GRAN; oplane = 256; }
+                    else if (!isW) { Op = static_cast<const frag_t *>(Sp) + ((size_t)(J + b) * sp_stride + Jp) * B3_SGRAN + fb * 64 + lane; ostage = 384; oplane = 128; }
+                    else { Op = static_cast<const frag_t *>(Wp) + ((size_t)(c0 >> 7) * nst_total + 4 * Jp) * B3_GRAN + (2 * ((c0 >> 6) & 1) + fb) * 64 + lane; ostage = B3_GRAN; oplane = 256; }
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -354,8 +356,13 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
 #pragma unroll
                     for (int e = 0; e < 16; ++e) pacc[e] = 0.f;
 #define PRO_MMA(px, py) pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fA[q][px]), __builtin_bit_cast(bf16x8_t, fB[q][py]), pacc, 0, 0, 0)
+                    if (u < npend - 1 && xside && !isW) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { PRO_MMA(0, 0); PRO_MMA(0, 1); PRO_MMA(1, 0); PRO_MMA(1, 1); PRO_MMA(0, 2); PRO_MMA(2, 0); }
+                        for (int q = 0; q < 4; ++q) { PRO_MMA(0, 0); PRO_MMA(1, 0); PRO_MMA(0, 1); PRO_MMA(1, 1); PRO_MMA(2, 0); PRO_MMA(0, 2); }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { PRO_MMA(0, 0); PRO_MMA(0, 1); PRO_MMA(1, 0); PRO_MMA(1, 1); PRO_MMA(0, 2); PRO_MMA(2, 0); }
+                    }
 #undef PRO_MMA
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[0][0][e] = acc[0][0][e] - pacc[e];
@@ -452,8 +459,8 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
 // One 64x64 tile of the trailing update with its operands as bf16 planes (written by the store epilogues of the launch that solved panel J):
 // fragments straight from global memory, six bf16 products per f32 product, no LDS and no barrier -- a third of the matrix-pipe time of
 // the f32 form.  256 threads.
-// J2 >= 0 (round 5): the updates of TWO panels, J then J2 = J + 1, in one pass over the tile -- (C - A_J B_J') - A_J2 B_J2', each product rounded and
-// subtracted as the one-panel-per-launch sweep does, so the bits are the same; the tile is read and written once instead of twice.
+// J2 >= 0 (round 5): the updates of the panels J .. J2 in one pass over the tile -- ((C - A_J B_J') - A_J+1 B_J+1') - .., each product rounded and
+// subtracted as the one-panel-per-launch sweep does, so the bits are the same; the tile is read and written once instead of once per panel.
 __device__ __forceinline__ void chol_trail_b3_tile(float *__restrict__ S, int lds, float *__restrict__ W, int ldw, int J, bool isW, int rb, int K, int c0,
                                        const void *__restrict__ Wp, int nst_total, const void *__restrict__ Sp, int sp_stride, int J2 = -1)
 {
@@ -464,8 +471,8 @@ __device__ __forceinline__ void chol_trail_b3_tile(float *__restrict__ S, int ld
     float cvv[16];
     float *Cbase = !isW ? S + (size_t)(rb * NB + w0) * lds + K * NB + w1 + lcol : W + (size_t)(K * NB + w0) * ldw + c0 + w1 + lcol;
     const int cld = !isW ? lds : ldw;
-    for (int pass = 0; pass < (J2 >= 0 ? 2 : 1); ++pass) {
-        const int Jp = pass == 0 ? J : J2;
+    for (int Jp = J; Jp <= (J2 >= 0 ? J2 : J); ++Jp) {
+        const int pass = Jp - J;
         const frag_t *Ap, *Bp;
         int bstage, bplane;
         if (!isW) {
@@ -652,7 +659,7 @@ template <typename T, bool EARLY = false>
 __global__ __launch_bounds__(CH_NTH) void k_chol_step(T *__restrict__ S, int lds, T *__restrict__ W, int ldw, int J, int nrb, int nW,
                                                    int nP, int32_t *__restrict__ status, unsigned int *__restrict__ arrive, unsigned int target,
                                                    int nPT, void *__restrict__ Wp, int nst_total, int ncb, int ld_split, void *__restrict__ Sp, int sp_stride,
-                                                   const int32_t *__restrict__ n_dev, int nS_max, int rows_last = 0, int pend2 = 0)
+                                                   const int32_t *__restrict__ n_dev, int nS_max, int rows_last = 0, int npend = 1)
 {
     __shared__ ChSmem<T> sm;
     int b = blockIdx.x;
@@ -688,7 +695,7 @@ __global__ __launch_bounds__(CH_NTH) void k_chol_step(T *__restrict__ S, int lds
         return;
     }
     if (b < nP) {
-        chol_panel_body<T, true, EARLY>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target, Wp, nst_total, ld_split, Sp, sp_stride, rows_last, pend2);     // (J == 0: no pending update, skipped at run time)
+        chol_panel_body<T, true, EARLY>(sm, S, lds, W, ldw, J, nrb, status, b, arrive, target, Wp, nst_total, ld_split, Sp, sp_stride, rows_last, npend);     // (J == 0: no pending update, skipped at run time)
     } else {
         chol_trail_body<T>(sm.As, sm.Bs, S, lds, W, ldw, J - 1, J + 1, nrb, nW, b - nP, Wp, nst_total, Sp, sp_stride);
     }
@@ -1837,17 +1844,18 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad, bool first_done = false, bo
         auto n_trail = [&](int J) { const int nK = J >= 1 ? nrb - J - 1 : 0; return nK * (nK + 1) / 2 + nK * nW; };      // tiles of panel J-1's update of the column blocks >= J+1
         auto own_trail_at = [&](int J) { return pro_planes && trail_split > 0 && n_trail(J) > trail_split * 2 * c->num_cus; };
         // Round 5: where the trailing update is a launch of its own it is bound by the read-modify-write of W's remaining rows (N = 2000: 4.8 GB per
-        // update over 40 panels), so it sweeps TWO panels at a time -- behind every odd panel J: panels J-1 and J on the column blocks >= J+2, each tile
-        // read and written once -- and the panels apply what is still pending for their own column themselves (an even panel: J-2 and J-1; an odd
-        // one: J-1).  Every product is rounded and subtracted in the order of the one-panel sweep: the same bits (PRE3_CHOL_TRAIL2=0: that sweep).
-        // The pairing ends with the even panel Jt from which on the update is small enough to ride in the panels' launches.
-        static const int trail2_env = getenv("PRE3_CHOL_TRAIL2") ? atoi(getenv("PRE3_CHOL_TRAIL2")) : 1;
+        // update over 40 panels), so it sweeps a GROUP of p panels at a time -- behind the last panel J of a group: panels J-p+1 .. J on the column
+        // blocks >= J+2, each tile read and written once -- and a panel applies what is still pending for its own column itself (the first panel of
+        // a group: the whole group before it; the t-th: the t panels of its own group in front of it).  Every product is rounded and subtracted in
+        // the order of the one-panel sweep: the same bits (PRE3_CHOL_TRAIL_P=1: that sweep).  The grouping ends with the first panel Jt of a group
+        // from which on the update is small enough to ride in the panels' launches.
+        static const int trail_p = std::min(4, std::max(1, getenv("PRE3_CHOL_TRAIL_P") ? atoi(getenv("PRE3_CHOL_TRAIL_P")) : 4));
         int Jt = 0;
-        if (trail2_env && own_trail_at(1)) { Jt = 2; while (Jt < nrb && own_trail_at(Jt)) Jt += 2; }
+        if (trail_p > 1 && own_trail_at(1)) { Jt = trail_p; while (Jt < nrb && own_trail_at(Jt)) Jt += trail_p; }
         for (int J = first_done ? 1 : 0; J < nrb; ++J) {
             const int nS = nrb - J - 1, nP = 1 + nS + nW;
             const bool paired = J >= 1 && J <= Jt;                          // this panel's column is brought up to date by the panel itself
-            const int pend2 = paired && (J & 1) == 0 ? 1 : 0;
+            const int npend = !paired ? 1 : (J % trail_p == 0 ? trail_p : J % trail_p);
             const int nT = paired ? 0 : n_trail(J);
             const int ncb = (split && !pro_planes && J >= 1) ? c->ld / B3_T : 0;   // split riders: 4 stages x ncb column blocks of row block J-1
             const bool own_trail = !paired && own_trail_at(J);
@@ -1861,20 +1869,20 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad, bool first_done = false, bo
             if (early) {
                 DISPATCH_T(c,
                     hipLaunchKernelGGL((k_chol_step<double, true>), g, bP, 0, c->stream, (double *)c->Smat, r_pad, (double *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
-                                       nP + nT_in, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, rows_last, 0),
+                                       nP + nT_in, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, rows_last, 1),
                     hipLaunchKernelGGL((k_chol_step<float, true>), g, bP, 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
-                                       nP + nT_in, split ? c->Wp : nullptr, c->rcap / B3_BK, ncb, c->ld, pro_planes ? c->Sp : nullptr, c->rcap / NB, nullptr, 0, rows_last, pend2));
+                                       nP + nT_in, split ? c->Wp : nullptr, c->rcap / B3_BK, ncb, c->ld, pro_planes ? c->Sp : nullptr, c->rcap / NB, nullptr, 0, rows_last, npend));
             } else {
             DISPATCH_T(c,
                 hipLaunchKernelGGL(k_chol_step<double>, g, bP, 0, c->stream, (double *)c->Smat, r_pad, (double *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
-                                   nP + nT_in, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, 0, 0),
+                                   nP + nT_in, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, 0, 1),
                 hipLaunchKernelGGL(k_chol_step<float>, g, bP, 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J, nrb, nW, nP, c->stats + 6, c->chol_arrive, c->chol_target,
-                                   nP + nT_in, split ? c->Wp : nullptr, c->rcap / B3_BK, ncb, c->ld, pro_planes ? c->Sp : nullptr, c->rcap / NB, nullptr, 0, 0, pend2));
+                                   nP + nT_in, split ? c->Wp : nullptr, c->rcap / B3_BK, ncb, c->ld, pro_planes ? c->Sp : nullptr, c->rcap / NB, nullptr, 0, 0, npend));
             }
-            if (paired && (J & 1) == 1 && J + 2 <= nrb - 1) {
-                // panels J-1 and J on everything from column block J+2 on
+            if (paired && J % trail_p == trail_p - 1 && J + 2 <= nrb - 1) {
+                // the group J-p+1 .. J on everything from column block J+2 on
                 const int nK2 = nrb - (J + 2), nT2 = nK2 * (nK2 + 1) / 2 + nK2 * nW;
-                hipLaunchKernelGGL(k_chol_trail_b3, dim3(nT2), dim3(256), 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J - 1, J + 2, nrb, nW,
+                hipLaunchKernelGGL(k_chol_trail_b3, dim3(nT2), dim3(256), 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J - trail_p + 1, J + 2, nrb, nW,
                                    c->Wp, c->rcap / B3_BK, c->Sp, c->rcap / NB, J);
             }
         }

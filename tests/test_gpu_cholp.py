@@ -264,14 +264,14 @@ print("DIGEST", h.hexdigest())
 
 def test_two_panel_trailing_sweep_is_bit_identical_to_the_one_panel_sweep():
     """launch-per-panel form with the trailing update as launches of its own (PRE3_CHOL_TRAIL_SPLIT=1 forces that at N = 500; it is N = 2000's form):
-    the sweep over two panels at a time (round 5: each tile read and written once per pair, the panels applying what is pending for their own column)
+    the sweep over a group of 2 / 3 / 4 panels at a time (round 5: each tile read and written once per group, the panels applying what is pending for their own column)
     rounds and subtracts every product in the one-panel sweep's order -- updates of 15, 16 and 11 panels must give the same bits"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
-    for v in ("1", "0"):
-        env = dict(os.environ, PRE3_CHOL_TRAIL2=v, PRE3_CHOL_TRAIL_SPLIT="1")
+    for v in ("4", "3", "2", "1"):
+        env = dict(os.environ, PRE3_CHOL_TRAIL_P=v, PRE3_CHOL_TRAIL_SPLIT="1")
         r = subprocess.run([sys.executable, "-c", _TRAIL2_WORKER % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
         out[v] = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0]
-    assert out["1"] == out["0"]
+    assert out["4"] == out["1"] and out["3"] == out["1"] and out["2"] == out["1"]
