@@ -205,7 +205,14 @@ __device__ __forceinline__ void ch_worker_step(const int k, ChSmem<T> &sm, typen
 #pragma unroll
                 for (int p = 0; p < NBLK; ++p)
 #pragma unroll
-                    for (int q = 0; q < NBLK; ++q) M::mma(-a[p][j], bb[q][j], acc[p][q]);
+                    for (int q = 0; q < NBLK; ++q) {
+                        // fp64 (16 x 16 blocks, an MFMA every 64 cycles): a block whose columns are all factored, or that lies above the diagonal, is dead
+                        if constexpr (sizeof(T) == 8) {
+                            const int c_lo = w1 + q * M::BLK > MB * (k + 1) ? w1 + q * M::BLK : MB * (k + 1);
+                            if (w1 + (q + 1) * M::BLK <= MB * (k + 1) || w0 + (p + 1) * M::BLK - 1 < c_lo) continue;
+                        }
+                        M::mma(-a[p][j], bb[q][j], acc[p][q]);
+                    }
         }
         if (k + 1 <= NSP - 1) {
             // publish sub-panel k+1: columns Cn..Cn+7 of D (the tile's rows), from the accumulators
@@ -238,7 +245,10 @@ __device__ __forceinline__ void ch_worker_step(const int k, ChSmem<T> &sm, typen
 #pragma unroll
                 for (int p = 0; p < NBLK; ++p)
 #pragma unroll
-                    for (int q = 0; q < NBLK; ++q) M::mma(-a[p][j], bb[q][j], acc[p][q]);
+                    for (int q = 0; q < NBLK; ++q) {
+                        if constexpr (sizeof(T) == 8) { if (w0 + (p + 1) * M::BLK <= MB * k) continue; }      // (fp64: the block's rows are all solved)
+                        M::mma(-a[p][j], bb[q][j], acc[p][q]);
+                    }
         }
         if (CH_EXP_WX && k >= 0 && k <= NSP - 1) {
             // publish rows Cr..Cr+7 of X
@@ -267,9 +277,12 @@ __device__ __forceinline__ void ch_worker_step(const int k, ChSmem<T> &sm, typen
 // last panel of an update whose row count is not a multiple of 64).  Their steps change nothing -- L keeps its identity columns, the
 // right-hand side its rows -- so the steps behind the one in which sub-panel nsp_eff-1 passes the z wave (k = nsp_eff) are skipped: an update of 20 rows
 // runs 5 of the 10 steps.  nsp_eff is workgroup-uniform.
-template <typename T, bool RELAX = false, bool EARLY = false, typename SideStep>
+// z_tail: run by the z wave behind its last sub-panel (the whole of X is final in Xs for this wave: LDS operations of one wave are in order),
+// before the chain's last barrier -- crit turns M_J's last rows into planes there instead of behind the chain.
+struct ChNoTail { __device__ __forceinline__ void operator()() const {} };
+template <typename T, bool RELAX = false, bool EARLY = false, typename SideStep, typename ZTail = ChNoTail>
 __device__ __forceinline__ void chol_chain(ChSmem<T> &sm, typename ChW<T>::acc_t (&acc)[ChW<T>::NBLK][ChW<T>::NBLK], const bool acc_loaded,
-                                           const bool hasX, bool &bad, SideStep &&side_step, const int nsp_eff = CH_NSP)
+                                           const bool hasX, bool &bad, SideStep &&side_step, const int nsp_eff = CH_NSP, ZTail &&z_tail = ChNoTail{})
 {
     constexpr int MB = CH_MB, NSP = CH_NSP;
     typedef T v4_t __attribute__((ext_vector_type(4), aligned(16)));
@@ -440,6 +453,7 @@ __device__ __forceinline__ void chol_chain(ChSmem<T> &sm, typename ChW<T>::acc_t
             *reinterpret_cast<v4_t *>(&Zt[par][i][4]) = v4_t{ z[4], z[5], z[6], z[7] };
 #pragma unroll
             for (int t = 0; t < MB; ++t) { Xs[C + t][i] = z[t]; zprev[t] = z[t]; }
+            if (k == NSP) z_tail();
         }
         PROBE_STEP(k, 1);
         __syncthreads();

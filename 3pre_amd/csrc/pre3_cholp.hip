@@ -186,7 +186,7 @@ struct CpArgs {
     int win;                             // strips: blocks of W kept in LDS (a ring: block K in slot K % win); older blocks are re-read from Wp
     int stride;                          // crit and the rows are blocks 0, stride, 2 stride, ..
     int n; const double *x_prior; double *x_out; double *params; int xu;      // xu: the strips finish with x_out = x_prior + W'(L^-1 nu) (update.m:36,42,48)
-    float *P; const int32_t *dd; int n_dd; int rows; int dd_mode;      // down-date consumers: group table (DG_WORDS each), groups in this launch, rows if host-known
+    float *P; const int32_t *dd; int n_dd; int rows; int dd_mode; int poll_budget, poll_from;      // down-date consumers: group table (DG_WORDS each), groups in this launch, rows if host-known
     int tail;                            // the rescue stage and the HI update follow inside this launch (CpTail): the HI rows are panel `nrb` of the same factorisation
     float *Wt; int kcap;                 // tail: W once more, column-major (column j at Wt + j * kcap, k contiguous): what the gate's y = H J W' reads
 };
@@ -262,6 +262,12 @@ struct CritSmem {
     __attribute__((aligned(16))) unsigned fpoll[64];             // wave 11's view of row J+1's flag: filled by LDS-DMA, read without a memory wait
 };
 
+// planes of L(J+1, J), written by the first product straight from its accumulators (round 5), behind CritSmem: the region is the rescue stage's
+// between the LI update's last panel and the HI panel (TailSmem | parts), when no product is running
+constexpr size_t CP_LP_OFF = (sizeof(CritSmem) + 127) / 128 * 128;
+static_assert(CP_LP_OFF + sizeof(frag_t) * B3_SGRAN <= 160 * 1024 - 1024, "crit's LDS with the planes of L(J+1, J)");
+__device__ __forceinline__ frag_t *crit_lp(CritSmem &sm) { return reinterpret_cast<frag_t *>(reinterpret_cast<unsigned char *>(&sm) + CP_LP_OFF); }
+
 // panel 0: the raw blocks straight from S (written by the launch in front); all twelve waves
 __device__ __forceinline__ void crit_prologue(const CpArgs &a, int nrb, CritSmem &sm)
 {
@@ -287,7 +293,7 @@ __device__ __forceinline__ void crit_prologue(const CpArgs &a, int nrb, CritSmem
     __syncthreads();
 }
 
-// waves 0-9: the chain and the two products.  Barriers per panel: the chain's ten, then b0..b3 (crit_side keeps the same count).
+// waves 0-9: the chain and the two products.  Barriers per panel: the chain's ten, then b0, b2, b3 (crit_side keeps the same count).
 __device__ __attribute__((noinline)) int crit_tail(int nrb_v);
 
 __device__ __forceinline__ void crit_main(const CpArgs &a, int nrb, CritSmem &sm)
@@ -320,42 +326,57 @@ __device__ __forceinline__ void crit_main(const CpArgs &a, int nrb, CritSmem &sm
         __syncthreads();                                                            // b0: MPl complete, T1p / T2 landed
         if (tid0 == 0) CP_STAMP(0, J, 2);
         const int wave = tid >> 6, lane = tid & 63, fa = (wave >> 1) & 1, fb = wave & 1;
+        frag_t *LP = crit_lp(sm);
         if (wave < 4) {
-            // B1: L(J+1, J)(i, a) = sum_c A(J+1, J)(i, c) M_J(a, c)
+            // B1, transposed: L(J+1, J)'(a, i) = sum_c M_J(a, c) A(J+1, J)(i, c) -- rows a: the fb half of MPl (read k-step by k-step), columns i: the
+            // fa half of T1p
             frag_t fB[4][3];
-            frags_lds(sm.MPl, fb, lane, fB);
+            frags_lds(sm.T1p, fa, lane, fB);
             f32x16_t c1;
 #pragma unroll
             for (int e = 0; e < 16; ++e) c1[e] = 0.f;
-            mma6_alds(sm.T1p, fa, lane, fB, c1);
+            mma6_alds(sm.MPl, fb, lane, fB, c1);
+            // The accumulator holds column i = lane & 31 at rows a = (e & 3) + 8 (e >> 2) + 4 (lane >> 5): v_permlane32_swap of register groups (0, 1) and
+            // (2, 3) leaves every lane with eight consecutive a of its i -- exactly its granule of L(J+1, J)'s planes (k-steps 2 fb, 2 fb + 1; lanes >= 32:
+            // the upper eight k), with no trip through LDS (round 5: Y -> barrier -> 512 granule jobs -> barrier used to stand here)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) Y[(32 * fa + acc_row(e, lane)) * CP_YS + 32 * fb + (lane & 31)] = c1[e];
+            for (int g2 = 0; g2 < 2; ++g2) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // (__float_as_uint of a copy: __builtin_bit_cast of ONE element of an ext-vector reads element 0)
+                    const float lo = c1[8 * g2 + j], hi = c1[8 * g2 + 4 + j];
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+                    const unsigned s0 = sw[0], s1 = sw[1];
+                    x[j] = __uint_as_float(s0); x[4 + j] = __uint_as_float(s1);
+                }
+                u32x4_t p0, p1, p2;
+                b3_split3(x, p0, p1, p2);
+                const int gi = (2 * fb + g2) * 384 + fa * 64 + lane;
+                LP[gi] = __builtin_bit_cast(frag_t, p0); LP[gi + 128] = __builtin_bit_cast(frag_t, p1); LP[gi + 256] = __builtin_bit_cast(frag_t, p2);
+                float *yr = Y + (32 * fa + (lane & 31)) * CP_YS + 32 * fb + 16 * g2 + 8 * (lane >> 5);       // the f32 image (the final factor's block)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) yr[j] = x[j];
+            }
             if (tid0 == 0) CP_STAMP(0, J, 7);
         } else if (wave < 8) {
             // next chain's X block: the identity (M_J's f32 image is dead: its planes are complete)
             for (int idx = tid - 256; idx < NB * NB; idx += 256) Xs[idx >> 6][idx & 63] = (idx >> 6) == (idx & 63) ? 1.f : 0.f;
         }
-        __syncthreads();                                                            // b1: Y = L(J+1, J)
-        if (tid0 == 0) CP_STAMP(0, J, 4);
-        if (tid < 512) {
-            u32x4_t p0, p1, p2; int gi;
-            y_granule(Y, tid, p0, p1, p2, gi);
-            sm.T1p[gi] = __builtin_bit_cast(frag_t, p0); sm.T1p[gi + 128] = __builtin_bit_cast(frag_t, p1); sm.T1p[gi + 256] = __builtin_bit_cast(frag_t, p2);
-        }
-        __syncthreads();                                                            // b2: T1p = planes of L(J+1, J)
+        __syncthreads();                                                            // b2: LP = planes of L(J+1, J), Y = its f32 image
         if (tid0 == 0) CP_STAMP(0, J, 5);
         if (wave < 4) {
             if (wave != 1) {
                 // B2: D_{J+1} = A(J+1, J+1) - L(J+1, J) L(J+1, J)'   (the tile above the diagonal is never read)
                 frag_t fB[4][3];
-                frags_lds(sm.T1p, fb, lane, fB);
+                frags_lds(LP, fb, lane, fB);
                 float t2[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) t2[e] = T2[(32 * fa + acc_row(e, lane)) * NB + 32 * fb + (lane & 31)];
                 f32x16_t c2;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) c2[e] = 0.f;
-                mma6_alds(sm.T1p, fa, lane, fB, c2);
+                mma6_alds(LP, fa, lane, fB, c2);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) Ls[32 * fa + acc_row(e, lane)][32 * fb + (lane & 31)] = t2[e] - c2[e];
                 if (tid0 == 0) CP_STAMP(0, J, 6);
@@ -394,6 +415,7 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
     // per launch by this CU, so there is no older copy for its L1 to hold; the loads carry sc1 all the same.)
     int fst = 5, cool = 0;
     unsigned pv = 0;
+    const long long poll_budget = a.poll_budget;               // shader clocks per chain step spent polling row J+1's flag (0: one poll per step)
     for (int pass = 0; pass < 2; ++pass) {                         // (as crit_main)
     const int j0 = pass == 0 ? 0 : nrb, j1 = pass == 0 ? nrb : nrb + 1;
     for (int J = j0; J < j1; ++J) {
@@ -465,7 +487,18 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
         for (int k = -1; k <= CH_NSP; ++k) {                     // one barrier per pipeline step of the chain
             // the fetch first: it is the only thing here that waits on memory (the compiler's wait covers every older operation of the
             // wave, so this step's stores must come after it -- a store's write-through acknowledge takes about as long as a step)
-            if (wave == 11) fetch_step(false);                    // (no LDS access of its own in this loop: nothing for the compiler to order behind the DMAs)
+            // (round 5: while the flag is awaited the step's time is spent polling -- a poll every ~0.1 us instead of one per step: the word is seen
+            //  0.5 us earlier on average, and the tiles' DMAs leave mid-step.  The budget keeps the wave in front of the step's barrier.)
+            if (wave == 11) {
+                if (fst == 0 && poll_budget > 0 && k >= a.poll_from) {
+                    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                    do {
+                        fetch_step(false);
+                        if (fst != 0) break;
+                        __builtin_amdgcn_s_sleep(3);
+                    } while ((long long)(__builtin_amdgcn_s_memtime() - t0) < poll_budget);
+                } else fetch_step(false);
+            }
             if (wave == 10) {
                 if (k == -1 && J > 0 && J < nrb) {      // L(J, J-1)'s planes (stored during the last products) have drained: publish
                     drain_stores();
@@ -505,8 +538,7 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
             st16_sc1(mp0, rSp, mgb); st16_sc1(mp1, rSp, mgb + 128 * 16); st16_sc1(mp2, rSp, mgb + 256 * 16);
             drain_stores(); if (lane == 0) cf_store(a.cf + CF_MP, a.base + (unsigned)J + 1); CP_STAMP(1, J, 4);
         }
-        __syncthreads();                                                            // b1
-        __syncthreads();                                                            // b2: T1p = planes of L(J+1, J), Y = its f32 image
+        __syncthreads();                                                            // b2: LP = planes of L(J+1, J), Y = its f32 image
         if (wave == 10) {
             // L(J+1, J) leaves as planes: 24 granules per lane in three batches (the LDS reads of a batch first); the flag follows at the first
             // step of the next chain, once these stores have drained (the rows need it only after their own L(i, J))
@@ -514,7 +546,7 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
             for (int b8 = 0; b8 < 3; ++b8) {
                 frag_t g8[8];
 #pragma unroll
-                for (int t = 0; t < 8; ++t) g8[t] = sm.T1p[(b8 * 8 + t) * 64 + lane];
+                for (int t = 0; t < 8; ++t) g8[t] = crit_lp(sm)[(b8 * 8 + t) * 64 + lane];
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
                     st16_sc1(__builtin_bit_cast(u32x4_t, g8[t]), rSp, ((unsigned)((J + 1) * a.sp_stride + J) * B3_SGRAN + (b8 * 8 + t) * 64 + lane) * 16u);
@@ -858,6 +890,35 @@ __device__ __attribute__((noinline)) void row_body(CpArgs a_v, int nrb_v, int i_
         }
         __syncthreads();                                        // OL complete and drained; every tile store of the previous panel is ordered
         if (tid == 0) { cf_store(cf_rowL(a.cf, i), a.base + (unsigned)J + 1); if (i < 16) CP_STAMP(i, J, 1); }
+        if (last && wave >= 4 && wave < 8) {
+            // the diagonal tile A(i, i) -= L(i, J) L(i, J)' needs nothing from outside: waves 4-7 (idle in the row's last panel) send it to crit (in f32)
+            // while waves 0-3 wait for L(J+1, J) and build the other tile  (round 5: the two tiles used to follow each other on waves 0-3, and crit had
+            // them 1.1 us later -- at the very end of its chain)
+            const int fa = (wave >> 1) & 1, fb = wave & 1;
+            const unsigned tv = quad_voff(fa, fb);
+            frag_t fB[4][3];
+            float v[16];
+            f32x16_t c2;
+            frags_lds(sm.OL, fb, lane, fB);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = ld_f32(rS, tv, tile_soff(i) + acc_soff(e, lds));
+#pragma unroll
+            for (int e = 0; e < 16; ++e) c2[e] = 0.f;
+            mma6_alds(sm.OL, fa, lane, fB, c2);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) patch[acc_row(e, lane) * 33 + (lane & 31)] = v[e] - c2[e];
+            wave_lds_sync();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                    // 32 rows x 8 pieces of 16 bytes
+                const int g = lane + 64 * u, r = g >> 3, c4 = (g & 7) * 4;
+                const float *y = patch + r * 33 + c4;
+                st16_sc1(__builtin_bit_cast(u32x4_t, f4v_t{ y[0], y[1], y[2], y[3] }), rS, (unsigned)(((size_t)(i * NB + 32 * fa + r) * lds + i * NB + 32 * fb + c4) * 4));
+            }
+            wave_lds_sync();
+            drain_stores();
+            if (lane == 0 && wave == 4 && i < 16) CP_STAMP(i, J, 3);
+            if (lane == 0 && atomicAdd(&sm.cnt[0], 1u) == 7u) { cf_store(cf_rowA(a.cf, i), a.base + 2u); if (i < 16) CP_STAMP(i, J, 4); }
+        }
         if (wave < 4) {
             // ---- the tile the next panel starts from: A(i, J+1) -= L(i, J) L(J+1, J)'
             const int fa = (wave >> 1) & 1, fb = wave & 1;
@@ -865,26 +926,6 @@ __device__ __attribute__((noinline)) void row_body(CpArgs a_v, int nrb_v, int i_
             frag_t fB[4][3];
             float v[16];
             f32x16_t c2;
-            if (last) {
-                // the diagonal tile A(i, i) -= L(i, J) L(i, J)' needs nothing from outside: it goes to crit (in f32) while L(J+1, J) is on its way
-                frags_lds(sm.OL, fb, lane, fB);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = ld_f32(rS, tv, tile_soff(i) + acc_soff(e, lds));
-#pragma unroll
-                for (int e = 0; e < 16; ++e) c2[e] = 0.f;
-                mma6_alds(sm.OL, fa, lane, fB, c2);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) patch[acc_row(e, lane) * 33 + (lane & 31)] = v[e] - c2[e];
-                wave_lds_sync();
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {                    // 32 rows x 8 pieces of 16 bytes
-                    const int g = lane + 64 * u, r = g >> 3, c4 = (g & 7) * 4;
-                    const float *y = patch + r * 33 + c4;
-                    st16_sc1(__builtin_bit_cast(u32x4_t, f4v_t{ y[0], y[1], y[2], y[3] }), rS, (unsigned)(((size_t)(i * NB + 32 * fa + r) * lds + i * NB + 32 * fb + c4) * 4));
-                }
-                wave_lds_sync();
-                if (lane == 0 && wave == 0 && i < 16) CP_STAMP(i, J, 3);
-            }
             wave_wait(cf_rowL(a.cf, J + 1), a.base + (unsigned)J + 1, guard);
             if (lane == 0 && wave == 0 && i < 16) CP_STAMP(i, J, 2);
             frags_sc1(rSp, (unsigned)((J + 1) * a.sp_stride + J) * B3_SGRAN, fb, lane, fB);
@@ -906,7 +947,7 @@ __device__ __attribute__((noinline)) void row_body(CpArgs a_v, int nrb_v, int i_
                     st16_sc1(p0, rTp, gb); st16_sc1(p1, rTp, gb + 128 * 16); st16_sc1(p2, rTp, gb + 256 * 16);
                 });
                 drain_stores();
-                if (lane == 0 && atomicAdd(&sm.cnt[0], 1u) == 3u) { cf_store(cf_rowA(a.cf, i), a.base + 2u); if (i < 16) CP_STAMP(i, J, 4); }
+                if (lane == 0 && atomicAdd(&sm.cnt[0], 1u) == 7u) { cf_store(cf_rowA(a.cf, i), a.base + 2u); if (i < 16) CP_STAMP(i, J, 4); }
             }
         }
         if (!last) {
@@ -2211,7 +2252,7 @@ int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior, c
 {
     const int n_strips = c->ldw / 32;
     const int nH = nrb_max > 2 ? nrb_max - 2 : 0;
-    const size_t lds_crit = sizeof(CritSmem), lds_row = sizeof(RowSmem);
+    const size_t lds_crit = CP_LP_OFF + sizeof(frag_t) * B3_SGRAN, lds_row = sizeof(RowSmem);
     const int win = std::max(1, std::min(nrb_max - 1, CP_WIN_MAX)), stride = cholp_stride(c, nH);
     PRE3_CHECK(stride >= 1, PRE3_E_ARG, "launch_cholp: %d panels need more CUs than the device has", nrb_max);
     const size_t lds_strip = (size_t)win * CP_WGRAN * 16 + (size_t)CP_WGRAN * 16 + (size_t)NB * CP_WS * sizeof(float);     // ring | CP (Yw) | Yw2
@@ -2279,6 +2320,10 @@ int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior, c
     a.win = win; a.stride = stride;
     static const int dd_mode = getenv("PRE3_DD_MODE") ? atoi(getenv("PRE3_DD_MODE")) : 17;     // bit 0: sc1 LDS-DMA of the planes; bit 1: an acquire per panel (experiment); bit 2: P warm-up; bit 4: write-through stores of P
     a.dd_mode = dd_mode;
+    static const int poll_budget = getenv("PRE3_CHOLP_POLL") ? atoi(getenv("PRE3_CHOLP_POLL")) : 900;      // crit's wave 11: shader clocks per chain step spent polling (0: one poll per step, rounds 3-4)
+    a.poll_budget = poll_budget;
+    static const int poll_from = getenv("PRE3_CHOLP_POLL_FROM") ? atoi(getenv("PRE3_CHOLP_POLL_FROM")) : 3;
+    a.poll_from = poll_from;
     // with the consumers in the launch the strips also finish the state: x_k_k = x_prior + W'(L^-1 nu) (the K9 launch that used to carry the
     // x-update as riders has nothing left to do at N = 500)
     static const int xu_env = getenv("PRE3_CHOLP_XU") ? atoi(getenv("PRE3_CHOLP_XU")) : 1;

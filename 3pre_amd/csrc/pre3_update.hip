@@ -395,7 +395,10 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
 #pragma unroll
                 for (int p = 0; p < NBLK; ++p)
 #pragma unroll
-                    for (int q = 0; q < NBLK; ++q) M::mma(av[p], bv[q], pacc[p][q]);
+                    for (int q = 0; q < NBLK; ++q) {
+                        if (sizeof(T) == 8 && !xside && w0 == w1 && q > p) continue;      // (fp64: the 16 x 16 block above the diagonal is never read)
+                        M::mma(av[p], bv[q], pacc[p][q]);
+                    }
             }
 #pragma unroll
             for (int p = 0; p < NBLK; ++p)

@@ -1,0 +1,17 @@
+// v_permlane32_swap_b32 on gfx950: which halves are exchanged (run on the GPU box: hipcc --offload-arch=gfx950 permlane_probe.hip -o /tmp/pp && /tmp/pp)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+__global__ void k(unsigned *o) {
+    unsigned a = threadIdx.x, b = 100 + threadIdx.x;
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    o[threadIdx.x] = r[0]; o[64 + threadIdx.x] = r[1];
+}
+int main() {
+    unsigned *d, h[128];
+    hipMalloc(&d, sizeof(h));
+    hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d);
+    hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    printf("r0: lane0 %u lane31 %u lane32 %u lane63 %u\n", h[0], h[31], h[32], h[63]);
+    printf("r1: lane0 %u lane31 %u lane32 %u lane63 %u\n", h[64], h[95], h[96], h[127]);
+    return 0;
+}
