@@ -279,10 +279,15 @@ __device__ __forceinline__ void ch_worker_step(const int k, ChSmem<T> &sm, typen
 // runs 5 of the 10 steps.  nsp_eff is workgroup-uniform.
 // z_tail: run by the z wave behind its last sub-panel (the whole of X is final in Xs for this wave: LDS operations of one wave are in order),
 // before the chain's last barrier -- crit turns M_J's last rows into planes there instead of behind the chain.
+// worker_init(acc, xside, wv): run by a worker wave INSTEAD of the load from LDS when acc_loaded is set and the caller has no tiles in `acc` yet
+// (ChNoInit: the caller's `acc` is taken as it is).  The persistent kernel's crit computes D_{J+1} there -- a tile defined inside the worker branch
+// is dead on the factor and z waves' paths; defined outside the chain it would be sixteen live registers on every path through it.
 struct ChNoTail { __device__ __forceinline__ void operator()() const {} };
-template <typename T, bool RELAX = false, bool EARLY = false, typename SideStep, typename ZTail = ChNoTail>
+struct ChNoInit { static constexpr bool none = true; template <typename A> __device__ __forceinline__ void operator()(A &, bool, int) const {} };
+template <typename T, bool RELAX = false, bool EARLY = false, typename SideStep, typename ZTail = ChNoTail, typename WInit = ChNoInit>
 __device__ __forceinline__ void chol_chain(ChSmem<T> &sm, typename ChW<T>::acc_t (&acc)[ChW<T>::NBLK][ChW<T>::NBLK], const bool acc_loaded,
-                                           const bool hasX, bool &bad, SideStep &&side_step, const int nsp_eff = CH_NSP, ZTail &&z_tail = ChNoTail{})
+                                           const bool hasX, bool &bad, SideStep &&side_step, const int nsp_eff = CH_NSP, ZTail &&z_tail = ChNoTail{},
+                                           WInit &&worker_init = ChNoInit{})
 {
     constexpr int MB = CH_MB, NSP = CH_NSP;
     typedef T v4_t __attribute__((ext_vector_type(4), aligned(16)));
@@ -306,6 +311,8 @@ __device__ __forceinline__ void chol_chain(ChSmem<T> &sm, typename ChW<T>::acc_t
             else if (wv == 2) ch_worker_load<T, 2, false>(sm, acc, lane, tile_live);
             else ch_worker_load<T, 3, false>(sm, acc, lane, tile_live);
         }
+    } else if (worker) {
+        worker_init(acc, xside, wv);
     }
     T yprev[MB], zprev[MB];                          // factor wave: its row of Y(s-1); z wave: its column of Z(s-1)
 #pragma unroll

@@ -293,13 +293,11 @@ __device__ __forceinline__ void crit_prologue(const CpArgs &a, int nrb, CritSmem
     __syncthreads();
 }
 
-// waves 0-9: the chain and the two products.  Barriers per panel: the chain's ten, then b0, b2, b3 (crit_side keeps the same count).
+// waves 0-9: the chain and the two products.  Barriers per panel: the chain's ten, then b0, b2 (crit_side keeps the same count).
 __device__ __attribute__((noinline)) int crit_tail(int nrb_v);
 
 __device__ __forceinline__ void crit_main(const CpArgs &a, int nrb, CritSmem &sm)
 {
-    auto &Ls = sm.ch.Ls; auto &Xs = sm.ch.Xs;
-    float *Y = &sm.ch.As[0][0];                                  // B1's output (f32), alias of the chain's hand-off buffers
     const float *T2 = &sm.ch.Bs[0][0];                           // A(J+1, J+1), f32 [64][64]
     const int tid0 = threadIdx.x;
     if ((tid0 >> 6) == 8) __builtin_amdgcn_s_setprio(3);
@@ -310,11 +308,42 @@ __device__ __forceinline__ void crit_main(const CpArgs &a, int nrb, CritSmem &sm
     //  panel, although nothing of it was live there.)
     for (int pass = 0; pass < 2; ++pass) {
     const int j0 = pass == 0 ? 0 : nrb, j1 = pass == 0 ? nrb : nrb + 1;
+    // The workers' tiles: a pass's first panel loads them from LDS (Ls = the raw diagonal block, Xs = I); from then on the D workers -- the waves
+    // that used to compute D_{J+1} into Ls, with the same tiles and the same register layout -- compute it as the chain's first act, straight into
+    // the accumulators, and the X workers write their piece of the identity into registers  (round 5: Ls / Xs were written, a barrier passed and
+    // both read back)
+    bool loaded = false;
     for (int J = j0; J < j1; ++J) {
         if (tid0 == 0) { CP_STAMP(0, J, 0); CP_CLK(19, J, 0); }
         {
             typename ChW<float>::acc_t acc[ChW<float>::NBLK][ChW<float>::NBLK];
-            chol_chain<float, true>(sm.ch, acc, false, true, bad, [](int) {});
+            chol_chain<float, true>(sm.ch, acc, loaded, true, bad, [](int) {}, CH_NSP, ChNoTail{},
+                [&](typename ChW<float>::acc_t (&ac)[ChW<float>::NBLK][ChW<float>::NBLK], const bool xside, const int) {
+                    // (everything here hangs off a fenced copy of the thread index: shared with the chain's own address arithmetic it would stretch
+                    //  live ranges through the chain -- sixteen registers of scratch traffic per step in the z wave's branch)
+                    int tq = threadIdx.x;
+                    asm volatile("" : "+v"(tq));
+                    const int lane = tq & 63, wv = (tq >> 6) & 3, fa = (wv >> 1) & 1, fb = wv & 1;
+                    if (xside) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) ac[0][0][e] = (fa == fb && acc_row(e, lane) == (lane & 31)) ? 1.f : 0.f;
+                    } else if (wv != 1) {
+                        // B2: D_{J+1} = A(J+1, J+1) - L(J+1, J) L(J+1, J)'   (the tile above the diagonal is never read)
+                        const frag_t *LP = crit_lp(sm);
+                        frag_t fB[4][3];
+                        frags_lds(LP, fb, lane, fB);
+                        float t2[16];
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) t2[e] = T2[(32 * fa + acc_row(e, lane)) * NB + 32 * fb + (lane & 31)];
+                        f32x16_t c2;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) c2[e] = 0.f;
+                        mma6_alds(LP, fa, lane, fB, c2);
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) ac[0][0][e] = t2[e] - c2[e];
+                        if (threadIdx.x == 0) CP_STAMP(0, J - 1, 6);
+                    }
+                });
         }
         if (tid0 == 0) { CP_STAMP(0, J, 1); CP_CLK(19, J, 1); }
         // Ls = L_JJ, Xs = M_J
@@ -354,42 +383,18 @@ __device__ __forceinline__ void crit_main(const CpArgs &a, int nrb, CritSmem &sm
                 b3_split3(x, p0, p1, p2);
                 const int gi = (2 * fb + g2) * 384 + fa * 64 + lane;
                 LP[gi] = __builtin_bit_cast(frag_t, p0); LP[gi + 128] = __builtin_bit_cast(frag_t, p1); LP[gi + 256] = __builtin_bit_cast(frag_t, p2);
-                float *yr = Y + (32 * fa + (lane & 31)) * CP_YS + 32 * fb + 16 * g2 + 8 * (lane >> 5);       // the f32 image (the final factor's block)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) yr[j] = x[j];
+                // the f32 image is part of the final factor (k_gain; not read again in this launch): 32 bytes of row i
+                float *sr = a.S + (size_t)((J + 1) * NB + 32 * fa + (lane & 31)) * (nrb * NB) + J * NB + 32 * fb + 16 * g2 + 8 * (lane >> 5);
+                *reinterpret_cast<f4v_t *>(sr) = f4v_t{ x[0], x[1], x[2], x[3] };
+                *reinterpret_cast<f4v_t *>(sr + 4) = f4v_t{ x[4], x[5], x[6], x[7] };
             }
             if (tid0 == 0) CP_STAMP(0, J, 7);
-        } else if (wave < 8) {
-            // next chain's X block: the identity (M_J's f32 image is dead: its planes are complete)
-            for (int idx = tid - 256; idx < NB * NB; idx += 256) Xs[idx >> 6][idx & 63] = (idx >> 6) == (idx & 63) ? 1.f : 0.f;
         }
-        __syncthreads();                                                            // b2: LP = planes of L(J+1, J), Y = its f32 image
+        __syncthreads();                                                            // b2: LP = planes of L(J+1, J)
         if (tid0 == 0) CP_STAMP(0, J, 5);
-        if (wave < 4) {
-            if (wave != 1) {
-                // B2: D_{J+1} = A(J+1, J+1) - L(J+1, J) L(J+1, J)'   (the tile above the diagonal is never read)
-                frag_t fB[4][3];
-                frags_lds(LP, fb, lane, fB);
-                float t2[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) t2[e] = T2[(32 * fa + acc_row(e, lane)) * NB + 32 * fb + (lane & 31)];
-                f32x16_t c2;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) c2[e] = 0.f;
-                mma6_alds(LP, fa, lane, fB, c2);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) Ls[32 * fa + acc_row(e, lane)][32 * fb + (lane & 31)] = t2[e] - c2[e];
-                if (tid0 == 0) CP_STAMP(0, J, 6);
-            }
-        } else {
-            // L(J+1, J) in f32 as part of the final factor: waves 4-9
-#pragma unroll 3
-            for (int idx = tid - 256; idx < NB * NB / 4; idx += 384) {
-                const float *yp = Y + (idx >> 4) * CP_YS + (idx & 15) * 4;
-                *reinterpret_cast<f4v_t *>(a.S + (size_t)((J + 1) * NB + (idx >> 4)) * (nrb * NB) + J * NB + (idx & 15) * 4) = f4v_t{ yp[0], yp[1], yp[2], yp[3] };
-            }
-        }
-        __syncthreads();                                                            // b3: Ls = D_{J+1}, Xs = I
+        loaded = true;
+        // (the second product is the next chain's first act -- worker_init above; no barrier in between: the chain's first step ends in one, and until
+        //  then nothing another wave reads is written: crit_side's fetch starts behind that barrier)
         if (tid0 == 0) CP_STAMP(0, J, 3);
     }
     // the last panel of the LI update is factored: rescue stage (crit_tail: all twelve waves, crit_side calls it at the same barrier).  With rescued
@@ -489,7 +494,7 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
             // wave, so this step's stores must come after it -- a store's write-through acknowledge takes about as long as a step)
             // (round 5: while the flag is awaited the step's time is spent polling -- a poll every ~0.1 us instead of one per step: the word is seen
             //  0.5 us earlier on average, and the tiles' DMAs leave mid-step.  The budget keeps the wave in front of the step's barrier.)
-            if (wave == 11) {
+            if (wave == 11 && k >= 0) {                            // (k = -1: the second product of the panel before may still be reading T2)
                 if (fst == 0 && poll_budget > 0 && k >= a.poll_from) {
                     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
                     do {
@@ -553,7 +558,6 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
             }
             CP_STAMP(1, J, 6);
         }
-        __syncthreads();                                                            // b3
     }
     if (pass == 1 || !a.tail || crit_tail(nrb) == 0) break;
     }
@@ -1416,6 +1420,10 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
     float hp[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) hp[e] = (par == 0 && nrb > 1) ? ld_f32(rW, wvoff, (unsigned)(NB * a.ldw) * 4u + acc_soff(e, a.ldw)) : 0.f;
+    // fragments of the first block of the next step's bulk sum, L(J+2, par): requested in (4), as soon as row J+2 is known to have published, by
+    // write-through-coherent (sc1) loads -- no acquire, nothing to wait for when (2) comes  (round 5: they were plain loads behind an acquire, requested
+    // in (2): 1.7 us of every panel)
+    frag_t f0[4][3];
     for (int J = 0; J < nrb; ++J) {
         // (1) right-hand side C_J = HP_J - sum: the shares meet in the par == 0 waves, then C_J as B-operand planes (CP)
         reduce4(acc);
@@ -1437,24 +1445,17 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
                 for (int e = 0; e < 16; ++e) hp[e] = par == 0 ? ld_f32(rW, wvoff, (unsigned)((J + 2) * NB * a.ldw) * 4u + acc_soff(e, a.ldw)) : 0.f;
             }
             if (J >= 1) {
-                // L(J+1, K), K <= J-1, were published during panel J-1; plain loads (shared through the XCD's L2) behind the acquire thread 0
-                // issued in the previous step's (4) -- its invalidate has run in the shadow of that term and of (1)
-                if (tid == 448) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+                // L(J+1, K), K <= J-1, were published during panel J-1 (the previous step's (4) has seen row J+1's flag): sc1 loads
                 if (tid == 0 && (s == 0 || s == a.n_strips - 1)) CP_STAMP(s == 0 ? 16 : 17, J, 0);
                 // blocks K_u = par + 4 u: the fragments of the next block are requested, k-step by k-step, into the registers the current block
                 // has just multiplied from
                 const int nb = par <= J - 1 ? (J - 1 - par) / 4 + 1 : 0;
                 const unsigned row0 = (unsigned)((J + 1) * a.sp_stride + par) * B3_SGRAN;
-                frag_t f0[4][3];
                 auto loadq = [&](int u, int q) {
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) f0[q][pl] = ld_granule(rSp, plo, row0 + (unsigned)(4 * u) * B3_SGRAN + q * 384 + pl * 128, 0);
+                    for (int pl = 0; pl < 3; ++pl) f0[q][pl] = ld_granule(rSp, plo, row0 + (unsigned)(4 * u) * B3_SGRAN + q * 384 + pl * 128, 1);
                 };
-                if (nb > 0) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) loadq(0, q);
-                }
+                // (block 0 is on its way since the previous step's (4))
                 // blocks written so far: 0 .. J-1, the ring holds the last `win` of them; the older ones (K < J - win) come back from Wp (this
                 // strip's own write-through stores, drained steps ago), their fragments requested one block ahead like L's
                 const int n_old = J - win > par ? (J - win - par + 3) / 4 : 0;          // blocks K = par + 4 u < J - win
@@ -1535,15 +1536,20 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
         if (tid == 0 && (s == 0 || s == a.n_strips - 1)) CP_STAMP(s == 0 ? 16 : 17, J, 2);
         // (4) the newest term of step J+1: L(J+1, J) W_J, one k-step per wave; L(J+1, J) is published about now (sc1 loads)
         if (more) {
-            // the next step's (2) reads L(J+2, K), K <= J, by plain loads: once row J+2 has published them, thread 0 issues the acquire for those
-            // loads; its invalidate runs in the shadow of this term and of the next step's (1)
+            // the next step's (2) reads L(J+2, K), K <= J: once row J+2 has published them, the first block's fragments are requested (sc1 loads)
             if (wave == 7) {
                 // rows J+1 and (if it exists) J+2 have published their L(., J): one poll loop for both flags (lane 0 / lane 1)
                 wave_wait_rows(a.cf, J + 1, J + 2 < nrb ? 2 : 1, a.base + (unsigned)J + 1, lane, guard);
-                if (J + 2 < nrb) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
             if (tid == 0 && (s == 0 || s == a.n_strips - 1)) CP_STAMP(s == 0 ? 16 : 17, J, 6);
+            if (J + 2 < nrb && par <= J) {
+                const unsigned row0n = (unsigned)((J + 2) * a.sp_stride + par) * B3_SGRAN;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) f0[q][pl] = ld_granule(rSp, plo, row0n + q * 384 + pl * 128, 1);
+            }
             const frag_t *wb = WPl + (size_t)(J % win) * CP_WGRAN + lane;
             frag_t fL[3];
 #pragma unroll
@@ -2320,7 +2326,7 @@ int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior, c
     a.win = win; a.stride = stride;
     static const int dd_mode = getenv("PRE3_DD_MODE") ? atoi(getenv("PRE3_DD_MODE")) : 17;     // bit 0: sc1 LDS-DMA of the planes; bit 1: an acquire per panel (experiment); bit 2: P warm-up; bit 4: write-through stores of P
     a.dd_mode = dd_mode;
-    static const int poll_budget = getenv("PRE3_CHOLP_POLL") ? atoi(getenv("PRE3_CHOLP_POLL")) : 900;      // crit's wave 11: shader clocks per chain step spent polling (0: one poll per step, rounds 3-4)
+    static const int poll_budget = getenv("PRE3_CHOLP_POLL") ? atoi(getenv("PRE3_CHOLP_POLL")) : 0;      // crit's wave 11: shader clocks per chain step spent polling (0: one poll per step, rounds 3-4)
     a.poll_budget = poll_budget;
     static const int poll_from = getenv("PRE3_CHOLP_POLL_FROM") ? atoi(getenv("PRE3_CHOLP_POLL_FROM")) : 3;
     a.poll_from = poll_from;
