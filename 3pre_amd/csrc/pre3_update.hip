@@ -743,27 +743,37 @@ template <bool TRI>
 __device__ __forceinline__ void hf_T_block(HfSmem &hf, const HiFused &a, const int row0, const int nrow, const int lm0, const int nlm)
 {
     const int nU = 7 + 6 * nlm, np = nrow >> 1;
-    // TRI: row pair q has 13 + 6q columns; pairs q and np-1-q together have C = 20 + 6 np of them, so the items are dealt evenly.
+    // A thread keeps ONE column k of T and walks down the row pairs that read it (TRI: the pairs from the column's own landmark on): the seven pose
+    // rows of P at that column are the same for every pair and are read once, which leaves six scattered reads per item instead of thirteen.
     // (What bounds this loop is the rate at which a CU takes scattered 4-byte reads -- every workgroup of the launch reads the same lines of P --,
-    //  not their latency: four items' reads in flight per lane measured 8 % slower, 28.6 against 26.5 us for the launch at 32 landmarks; reading
-    //  P(col, rc[t]) instead -- P is symmetric to the bit here, and a row holds an item's thirteen entries in two runs -- 33.8 us: the lanes of a
-    //  wave then read 64 different rows, where consecutive columns of ONE row share lines.)
-    const int C = TRI ? 20 + 6 * np : nU, nq = TRI ? (np + 1) >> 1 : np;
-    for (int idx = threadIdx.x; idx < nq * C; idx += CH_NTH) {
-        int p = idx / C, k = idx - p * C;
-        if (TRI && k >= 13 + 6 * p) {
-            k -= 13 + 6 * p; p = np - 1 - p;
-            if (2 * p + 1 == np) continue;               // (np odd: the middle pair has no partner)
-        }
-        const int row = row0 + 2 * p;
+    //  not their latency: round 5's first form, one (pair, column) item per thread and iteration with all thirteen reads, 26.5 us for the launch at
+    //  32 landmarks; four items in flight per lane 28.6 us; reading P(col, rc[t]) instead -- P is symmetric to the bit here -- 33.8 us: the lanes
+    //  of a wave then read 64 different rows, where consecutive columns of ONE row share lines.)  The fma chains are k_ell_HP_build's, term for
+    //  term, whatever the order the values were fetched in.
+    const int G = nU >= CH_NTH ? 1 : CH_NTH / nU;             // row-pair classes: thread (k, g) takes the pairs p = g (mod G)
+    for (int idx = threadIdx.x; idx < nU * G; idx += CH_NTH) {
+        const int g = idx / nU, k = idx - g * nU;
+        const int jk = k < 7 ? 0 : (k - 7) / 6;                // TRI: the first pair that reads this column
         const float *pc = a.P + (k < 7 ? k : hf.ucol[7 + 6 * lm0 + k - 7]);
-        float s0 = 0.f, s1 = 0.f;
+        float pose[7];
+        if (g < np) {
 #pragma unroll
-        for (int t = 0; t < 13; ++t) {
-            const float pv = pc[(size_t)hf.rc[row][t] * a.ld];
-            s0 = fmaf(hf.rv[row][t], pv, s0); s1 = fmaf(hf.rv[row + 1][t], pv, s1);
+            for (int t = 0; t < 7; ++t) pose[t] = pc[(size_t)t * a.ld];      // (a row's first seven entries are the pose columns 0..6 themselves)
         }
-        hf.T[2 * p][k] = s0; hf.T[2 * p + 1][k] = s1;
+        for (int p = g; p < np; p += G) {
+            if (TRI && p < jk) continue;
+            const int row = row0 + 2 * p;
+            float lv[6];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) lv[t] = pc[(size_t)hf.rc[row][7 + t] * a.ld];
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 13; ++t) {
+                const float pv = t < 7 ? pose[t] : lv[t - 7];
+                s0 = fmaf(hf.rv[row][t], pv, s0); s1 = fmaf(hf.rv[row + 1][t], pv, s1);
+            }
+            hf.T[2 * p][k] = s0; hf.T[2 * p + 1][k] = s1;
+        }
     }
 }
 // (H*P*H')(ra, rb) out of T (k_ell_G: the sum over the non-zeros of row rb of H*P(ra, .) there); T holds rows row0.. and the landmarks of rows col0..
@@ -779,15 +789,26 @@ __device__ __forceinline__ float hf_S_entry(const HfSmem &hf, const int ra, cons
 template <typename XT>
 __device__ __forceinline__ void hf_own_block(const HfSmem &hf, const HiFused &a, XT &X, const int row0, const int r, const int c0)
 {
+    // (a thread's column is the same in every iteration -- CH_NTH is a multiple of 64 --: the pose rows of P at that column are read once)
+    static_assert(CH_NTH % 64 == 0, "hf_own_block: one column per thread");
+    const int i = threadIdx.x & 63, j = c0 + i;
+    const float *pc = a.P + j;
+    float pose[7];
+    if (j < a.ld && row0 + 2 * (int)(threadIdx.x >> 6) < r) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t) pose[t] = pc[(size_t)t * a.ld];
+    }
     for (int idx = threadIdx.x; idx < NB * NB / 2; idx += CH_NTH) {
-        const int p = idx >> 6, i = idx & 63, j = c0 + i, row = row0 + 2 * p;
+        const int p = idx >> 6, row = row0 + 2 * p;
         float s0 = 0.f, s1 = 0.f;
         if (row < r) {
             if (j < a.ld) {
-                const float *pc = a.P + j;
+                float lv[6];
+#pragma unroll
+                for (int t = 0; t < 6; ++t) lv[t] = pc[(size_t)hf.rc[row][7 + t] * a.ld];
 #pragma unroll
                 for (int t = 0; t < 13; ++t) {
-                    const float pv = pc[(size_t)hf.rc[row][t] * a.ld];
+                    const float pv = t < 7 ? pose[t] : lv[t - 7];
                     s0 = fmaf(hf.rv[row][t], pv, s0); s1 = fmaf(hf.rv[row + 1][t], pv, s1);
                 }
             } else if (j == a.ld) { s0 = hf.nu[row]; s1 = hf.nu[row + 1]; }
