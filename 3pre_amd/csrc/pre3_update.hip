@@ -15,6 +15,7 @@
 // Layout: P is ld x ld (ld multiple of 128, zero beyond n); W/HP are r_pad x ldw row-major, i.e. one
 // length-n vector per measurement row, so both MFMA operands of W'W are read k-major/contiguous.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include "pre3_internal.h"
@@ -531,6 +532,187 @@ __global__ __launch_bounds__(256) void k_chol_trail_b3(float *__restrict__ S, in
     bool isW; int rb, K, c0;
     chol_trail_decode(blockIdx.x, K0, nrb, nW, isW, rb, K, c0);
     chol_trail_b3_tile(S, lds, W, ldw, J, isW, rb, K, c0, Wp, nst_total, Sp, sp_stride, J2);
+}
+
+// The same sweep with the W part in 128 x 128 super-tiles (round 5): a wave owns a 64 x 64 tile -- four 32 x 32 accumulators that share two A and
+// two B fragment sets per k-step, i.e. half the operand bytes per MFMA of the 32 x 32-per-wave form, whose launches were bound by the rate at
+// which a CU takes operand fragments (twice the matrix-pipe time at N = 2000), not by the read-modify-write of W any more once four panels
+// share a pass.  Every 32 x 32 tile sees the products of the one-panel sweep in its order: the same bits.  S tiles (a tenth of the work) keep
+// the 64 x 64 form.  No LDS, no barrier.  (measured, N = 2000: the eight sweeps 759 -> 696 us; what is left is the fragments' latency at two waves
+// per SIMD -- requesting a k-step ahead by hand spilled (741 us), parking the tile's own values in LDS did not raise the occupancy: the compiler
+// hoists every load the register budget allows.  k_chol_trail_b3l below stages the operands through LDS instead: 635 us.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_chol_trail_b3w(float *__restrict__ S, int lds, float *__restrict__ W, int ldw, int J, int K0, int nrb, int nW,
+                                                        const void *__restrict__ Wp, int nst_total, const void *__restrict__ Sp, int sp_stride, int J2)
+{
+    const int nK = nrb - K0, nSt = nK * (nK + 1) / 2;
+    if ((int)blockIdx.x < nSt) {
+        bool isW; int rb, K, c0;
+        chol_trail_decode(blockIdx.x, K0, nrb, nW, isW, rb, K, c0);
+        chol_trail_b3_tile(S, lds, W, ldw, J, false, rb, K, 0, Wp, nst_total, Sp, sp_stride, J2);
+        return;
+    }
+    typedef int frag_t __attribute__((ext_vector_type(4)));
+    const int t = blockIdx.x - nSt, nWp = (nW + 1) >> 1;
+    const int kp = t / nWp, wp = t - kp * nWp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = K0 + 2 * kp + (wave >> 1), cb = 2 * wp + (wave & 1), c0 = cb * NB;
+    if (K >= nrb || cb >= nW) return;
+    const int lrow = 4 * (lane >> 5), lcol = lane & 31;
+    float *Cbase = W + (size_t)(K * NB) * ldw + c0 + lcol;
+    float cvv[2][2][16];
+#pragma unroll
+    for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) cvv[fa][fb][e] = Cbase[(size_t)(32 * fa + (e & 3) + 8 * (e >> 2) + lrow) * ldw + 32 * fb];
+    for (int Jp = J; Jp <= (J2 >= 0 ? J2 : J); ++Jp) {
+        const frag_t *Ap = static_cast<const frag_t *>(Sp) + ((size_t)K * sp_stride + Jp) * B3_SGRAN + lane;
+        const frag_t *Bp = static_cast<const frag_t *>(Wp) + ((size_t)(c0 >> 7) * nst_total + 4 * Jp) * B3_GRAN + (2 * ((c0 >> 6) & 1)) * 64 + lane;
+        f32x16_t acc[2][2];
+#pragma unroll
+        for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[fa][fb][e] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            frag_t fA[2][3], fB[2][3];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) { fA[h][pl] = Ap[q * 384 + pl * 128 + h * 64]; fB[h][pl] = Bp[q * B3_GRAN + pl * 256 + h * 64]; }
+            // (plane pairs outside, the four tiles inside: four independent accumulators between two products of the same tile)
+#define TW_MMA(px, py) \
+            _Pragma("unroll") for (int fa = 0; fa < 2; ++fa) \
+                _Pragma("unroll") for (int fb = 0; fb < 2; ++fb) \
+                    acc[fa][fb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fA[fa][px]), __builtin_bit_cast(bf16x8_t, fB[fb][py]), acc[fa][fb], 0, 0, 0)
+            TW_MMA(0, 0); TW_MMA(0, 1); TW_MMA(1, 0); TW_MMA(1, 1); TW_MMA(0, 2); TW_MMA(2, 0);
+#undef TW_MMA
+        }
+#pragma unroll
+        for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) cvv[fa][fb][e] = cvv[fa][fb][e] - acc[fa][fb][e];
+    }
+#pragma unroll
+    for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Cbase[(size_t)(32 * fa + (e & 3) + 8 * (e >> 2) + lrow) * ldw + 32 * fb] = cvv[fa][fb][e];
+}
+
+// The super-tile sweep with the operands staged through LDS (k_downdate_b3's form): per k-step the workgroup's four operand sub-blocks -- the
+// S planes of its two row blocks, the W planes of its 128 columns: 24 KB -- come in ONCE by LDS-DMA (six 1-KB requests per wave, no registers
+// held while they travel), three stages deep, and every wave takes its twelve fragments from LDS.  A quarter of the 32 x 32-per-wave form's
+// operand traffic, and the fragments' latency is the pipeline's, not the wave's.  Same products per 32 x 32 tile in the same order.
+// (measured, N = 2000: the eight sweeps of an update 759 us with 64 x 64 tiles -> 696 us (k_chol_trail_b3w) -> 635 us; step 3.99 -> 3.81 ms.  Two
+// workgroups per CU and two stages of lookahead still leave the start of a workgroup -- its tile of W from HBM -- and part of the DMA latency exposed.)
+constexpr int TL_STAGE = 1536, TL_NSLOT = 3;                // granules per stage: A0 384 | A1 384 | B 768
+__global__ __launch_bounds__(256) void k_chol_trail_b3l(float *__restrict__ S, int lds, float *__restrict__ W, int ldw, int J, int K0, int nrb, int nW,
+                                                        const void *__restrict__ Wp, int nst_total, const void *__restrict__ Sp, int sp_stride, int J2)
+{
+    const int nK = nrb - K0, nSt = nK * (nK + 1) / 2;
+    if ((int)blockIdx.x < nSt) {
+        bool isW; int rb, K, c0;
+        chol_trail_decode(blockIdx.x, K0, nrb, nW, isW, rb, K, c0);
+        chol_trail_b3_tile(S, lds, W, ldw, J, false, rb, K, 0, Wp, nst_total, Sp, sp_stride, J2);
+        return;
+    }
+    typedef int frag_t __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char tl_smem[];
+    frag_t *ops = reinterpret_cast<frag_t *>(tl_smem);
+    const int t = blockIdx.x - nSt, nWp = (nW + 1) >> 1;
+    const int kp = __builtin_amdgcn_readfirstlane(t / nWp), wp = __builtin_amdgcn_readfirstlane(t - kp * nWp);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wa = wave >> 1, wb = wave & 1;
+    const int Kb0 = K0 + 2 * kp, Kb1 = Kb0 + 1 < nrb ? Kb0 + 1 : Kb0;          // (a missing second row block / column block is fetched as a copy of the first: the
+    const bool vB1 = 2 * wp + 1 < nW;                                             //  DMA counts stay uniform; its waves skip the arithmetic)
+    const int K = Kb0 + wa, cb = 2 * wp + wb, c0 = cb * NB;
+    const bool mine = K < nrb && cb < nW;
+    const int lrow = 4 * (lane >> 5), lcol = lane & 31;
+    float *Cbase = W + (size_t)(K * NB) * ldw + c0 + lcol;
+    float cvv[2][2][16];
+    if (mine) {
+#pragma unroll
+        for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) cvv[fa][fb][e] = Cbase[(size_t)(32 * fa + (e & 3) + 8 * (e >> 2) + lrow) * ldw + 32 * fb];
+    }
+    // this wave's six DMA requests of a stage: request idx = wave + 4 u -> [0, 12): S planes (row block idx / 6, plane, half); [12, 24): W planes
+    // (plane, 32-column fragment).  Both sources are linear in the step it = 4 (panel - J) + k-step: + 384 granules (S), + B3_GRAN (W).
+    const frag_t *src[6]; int dst[6], stp[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int idx = wave + 4 * u;
+        if (idx < 12) {
+            const int a_ = idx / 6, r = idx - 6 * a_;
+            src[u] = static_cast<const frag_t *>(Sp) + ((size_t)(a_ ? Kb1 : Kb0) * sp_stride + J) * B3_SGRAN + (r >> 1) * 128 + (r & 1) * 64 + lane;
+            dst[u] = a_ * 384 + (r >> 1) * 128 + (r & 1) * 64; stp[u] = 384;
+        } else {
+            const int r = idx - 12, pl = r >> 2, f = r & 3, fs = (!vB1 && f >= 2) ? f - 2 : f;
+            src[u] = static_cast<const frag_t *>(Wp) + ((size_t)wp * nst_total + 4 * J) * B3_GRAN + pl * 256 + fs * 64 + lane;
+            dst[u] = 768 + pl * 256 + f * 64; stp[u] = B3_GRAN;
+        }
+    }
+    const int nIt = 4 * ((J2 >= 0 ? J2 : J) - J + 1);
+    auto issue = [&](int it) {
+        frag_t *slot = ops + (it % TL_NSLOT) * TL_STAGE;
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            __builtin_amdgcn_global_load_lds(src[u] + (size_t)it * stp[u], (__attribute__((address_space(3))) void *)(slot + dst[u]), 16, 0, 0);
+    };
+    issue(0);
+    issue(1);
+    f32x16_t acc[2][2];
+    for (int it = 0; it < nIt; ++it) {
+        if (it + 1 < nIt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // every wave's share of stage `it` has landed; the slot of stage it-1 is free
+        if (it + 2 < nIt) issue(it + 2);
+        if (!mine) continue;
+        const frag_t *sl = ops + (it % TL_NSLOT) * TL_STAGE + lane;
+        frag_t fA[2][3], fB[2][3];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) { fA[h][pl] = sl[wa * 384 + pl * 128 + h * 64]; fB[h][pl] = sl[768 + pl * 256 + (2 * wb + h) * 64]; }
+        if ((it & 3) == 0) {
+#pragma unroll
+            for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[fa][fb][e] = 0.f;
+        }
+#define TW_MMA(px, py) \
+        _Pragma("unroll") for (int fa = 0; fa < 2; ++fa) \
+            _Pragma("unroll") for (int fb = 0; fb < 2; ++fb) \
+                acc[fa][fb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fA[fa][px]), __builtin_bit_cast(bf16x8_t, fB[fb][py]), acc[fa][fb], 0, 0, 0)
+        TW_MMA(0, 0); TW_MMA(0, 1); TW_MMA(1, 0); TW_MMA(1, 1); TW_MMA(0, 2); TW_MMA(2, 0);
+#undef TW_MMA
+        if ((it & 3) == 3) {
+#pragma unroll
+            for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) cvv[fa][fb][e] = cvv[fa][fb][e] - acc[fa][fb][e];
+        }
+    }
+    if (mine) {
+#pragma unroll
+        for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) Cbase[(size_t)(32 * fa + (e & 3) + 8 * (e >> 2) + lrow) * ldw + 32 * fb] = cvv[fa][fb][e];
+    }
 }
 
 // Trailing update on the matrix cores: one 64 x 64 tile  C -= A B'  (K = 64) per workgroup, 4 waves, each a
@@ -1906,6 +2088,16 @@ static int launch_chol_solve(pre3_ctx *c, int r_pad, bool first_done = false, bo
             if (paired && J % trail_p == trail_p - 1 && J + 2 <= nrb - 1) {
                 // the group J-p+1 .. J on everything from column block J+2 on
                 const int nK2 = nrb - (J + 2), nT2 = nK2 * (nK2 + 1) / 2 + nK2 * nW;
+                static const int t128 = getenv("PRE3_CHOL_TRAIL_T128") ? atoi(getenv("PRE3_CHOL_TRAIL_T128")) : 2;      // W part in 128 x 128 super-tiles: 2 = operands staged through LDS, 1 = fragments straight from memory (0: 64 x 64 tiles)
+                if (t128 == 2) {
+                    static std::atomic<bool> attr{ false };
+                    if (!attr.exchange(true)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_trail_b3l), hipFuncAttributeMaxDynamicSharedMemorySize, TL_NSLOT * TL_STAGE * 16);
+                    hipLaunchKernelGGL(k_chol_trail_b3l, dim3(nK2 * (nK2 + 1) / 2 + ((nK2 + 1) / 2) * ((nW + 1) / 2)), dim3(256), TL_NSLOT * TL_STAGE * 16, c->stream, (float *)c->Smat, r_pad,
+                                       (float *)c->W, c->ldw, J - trail_p + 1, J + 2, nrb, nW, c->Wp, c->rcap / B3_BK, c->Sp, c->rcap / NB, J);
+                } else if (t128)
+                    hipLaunchKernelGGL(k_chol_trail_b3w, dim3(nK2 * (nK2 + 1) / 2 + ((nK2 + 1) / 2) * ((nW + 1) / 2)), dim3(256), 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W,
+                                       c->ldw, J - trail_p + 1, J + 2, nrb, nW, c->Wp, c->rcap / B3_BK, c->Sp, c->rcap / NB, J);
+                else
                 hipLaunchKernelGGL(k_chol_trail_b3, dim3(nT2), dim3(256), 0, c->stream, (float *)c->Smat, r_pad, (float *)c->W, c->ldw, J - trail_p + 1, J + 2, nrb, nW,
                                    c->Wp, c->rcap / B3_BK, c->Sp, c->rcap / NB, J);
             }

@@ -269,9 +269,10 @@ def test_two_panel_trailing_sweep_is_bit_identical_to_the_one_panel_sweep():
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
-    for v in ("4", "3", "2", "1"):
-        env = dict(os.environ, PRE3_CHOL_TRAIL_P=v, PRE3_CHOL_TRAIL_SPLIT="1")
+    # (group size, tile form of the W part: 2 = 128 x 128 super-tiles staged through LDS (default), 1 = super-tiles with fragments from memory, 0 = 64 x 64)
+    for v, t in (("4", "2"), ("3", "2"), ("2", "2"), ("1", "2"), ("4", "1"), ("4", "0"), ("3", "1")):
+        env = dict(os.environ, PRE3_CHOL_TRAIL_P=v, PRE3_CHOL_TRAIL_T128=t, PRE3_CHOL_TRAIL_SPLIT="1")
         r = subprocess.run([sys.executable, "-c", _TRAIL2_WORKER % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
-        out[v] = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0]
-    assert out["4"] == out["1"] and out["3"] == out["1"] and out["2"] == out["1"]
+        out[v, t] = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0]
+    assert all(d == out["1", "2"] for d in out.values()), out
