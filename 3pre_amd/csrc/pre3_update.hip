@@ -930,8 +930,10 @@ __device__ __forceinline__ void hf_T_block(HfSmem &hf, const HiFused &a, const i
     // (What bounds this loop is the rate at which a CU takes scattered 4-byte reads -- every workgroup of the launch reads the same lines of P --,
     //  not their latency: round 5's first form, one (pair, column) item per thread and iteration with all thirteen reads, 26.5 us for the launch at
     //  32 landmarks; four items in flight per lane 28.6 us; reading P(col, rc[t]) instead -- P is symmetric to the bit here -- 33.8 us: the lanes
-    //  of a wave then read 64 different rows, where consecutive columns of ONE row share lines.)  The fma chains are k_ell_HP_build's, term for
-    //  term, whatever the order the values were fetched in.
+    //  of a wave then read 64 different rows, where consecutive columns of ONE row share lines.  With a thread's pairs batched -- four, or all
+    //  eleven, pairs' reads in flight at once -- T took 5.4 / 6.2 us against 5.8: not latency either.  What it is: fifty workgroups ask for the
+    //  same ~8 k lines of P at the same time, ~3 k line requests per L2 channel.)  The fma chains are k_ell_HP_build's, term for term, whatever
+    //  the order the values were fetched in.
     const int G = nU >= CH_NTH ? 1 : CH_NTH / nU;             // row-pair classes: thread (k, g) takes the pairs p = g (mod G)
     for (int idx = threadIdx.x; idx < nU * G; idx += CH_NTH) {
         const int g = idx / nU, k = idx - g * nU;
@@ -1008,8 +1010,15 @@ __device__ __forceinline__ void hf_mma64(f32x16_t &acc, FA &&A, FB &&B, const in
     for (int k0 = 0; k0 < NB; k0 += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A(cl, k0 + kh), B(cl, k0 + kh), acc, 0, 0, 0);
 }
 
+#ifdef PRE3_PROBE
+static __device__ unsigned long long g_hf[16];                  // wall-clock stamps (100 MHz) of workgroup 5 of the last k_hi_fused launch (tools/probe_hi_fused.py)
+#define HF_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 5) g_hf[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define HF_STAMP(k)
+#endif
 __global__ __launch_bounds__(CH_NTH) void k_hi_fused(HiFused a)
 {
+    HF_STAMP(0);
     __shared__ ChSmem<float> sm;
     __shared__ HfSmem hf;
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -1069,6 +1078,7 @@ __global__ __launch_bounds__(CH_NTH) void k_hi_fused(HiFused a)
         cnt += tot;
         __syncthreads();                                   // (s_wc is rewritten by the next pass)
     }
+    HF_STAMP(1);
     const int r = 2 * cnt;
     const bool here = cnt >= 1 && cnt <= a.max_l;
     if (b == 0 && tid == 0) {
@@ -1102,9 +1112,12 @@ __global__ __launch_bounds__(CH_NTH) void k_hi_fused(HiFused a)
     }
     if (!two) {
         // ---- T = (H*P) at the columns of the selected rows, and this workgroup's own block of [H*P | nu]
+        HF_STAMP(2);
         hf_T_block<true>(hf, a, 0, r, 0, cnt);
+        HF_STAMP(3);
         if (b >= 1) hf_own_block(hf, a, sm.Xs, 0, r, (b - 1) * NB);
         __syncthreads();
+        HF_STAMP(4);
         // ---- S = H*P*H' + I on and below the diagonal, identity padding
         for (int idx = tid; idx < NB * NB; idx += CH_NTH) {
             const int ra = idx >> 6, rb = idx & 63;
@@ -1116,7 +1129,9 @@ __global__ __launch_bounds__(CH_NTH) void k_hi_fused(HiFused a)
             sm.Ls[ra][rb] = s;
         }
         __syncthreads();
+        HF_STAMP(5);
         chol_panel_body<float, false, true, true>(sm, a.S, NB, a.W, a.ldw, 0, 1, a.stats + 6, b, nullptr, 0u, a.Wp, a.nst_total, a.ld, a.Sp, a.sp_stride, r);
+        HF_STAMP(6);
         return;
     }
     // ---- two panels (33 .. 64 landmarks), every workgroup for itself as above.  S = [S00 . ; S10 S11], [H*P | nu] = [H0 ; H1] (this workgroup's
@@ -2395,6 +2410,10 @@ extern "C" __attribute__((visibility("default"))) int pre3_debug_rt(int on)
 extern "C" __attribute__((visibility("default"))) int pre3_debug_k9hw(unsigned int *out)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k9hw), sizeof(unsigned int) * 2048) == hipSuccess ? 0 : -3;
+}
+extern "C" __attribute__((visibility("default"))) int pre3_debug_hf(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hf), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -3;
 }
 extern "C" __attribute__((visibility("default"))) int pre3_debug_probe(unsigned long long *out)
 {
