@@ -329,6 +329,7 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
                                   hipMemcpy(c->dd_tiles, t64.data(), sizeof(int2) * t64.size(), hipMemcpyHostToDevice) != hipSuccess)) { set_error("consumer table upload failed"); rc = PRE3_E_HIP; }
         }
         A(dmalloc_bytes(&c->cholp_tp, (size_t)(c->rcap / NB) * 1536 * 16));
+        { void *f = nullptr; A(dmalloc_bytes(&f, sizeof(float) * 4 * (size_t)c->ld)); c->jn_q = (float *)f; }      // rows 3..6 of P before the Jnorm pass (GateRide, pre3_geom.hip)
         // the tail of the persistent launch (rescue stage + HI update, CpTail): per landmark y = H J W' as bf16 planes (+ one zero slot), the row H J, crit's list
         A(dmalloc_bytes(&c->tail_yp, (size_t)(c->capN + 1) * 2 * 3 * c->rcap * 2));
         { void *f = nullptr; A(dmalloc_bytes(&f, (size_t)c->capN * 2 * 16 * sizeof(float))); c->tail_hb = (float *)f; }
@@ -404,7 +405,7 @@ int pre3_destroy(pre3_ctx *c)
     c->comm = nullptr;
     void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
                      c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
-                     c->sel_rows, c->support, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_src0, c->map_conv, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128, c->need, c->cholp_flags, c->cholp_tp, c->dd_groups, c->dd_tiles, c->tail_yp, c->tail_hb, c->tail_hib, c->tail_wt };
+                     c->sel_rows, c->support, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_src0, c->map_conv, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128, c->need, c->cholp_flags, c->cholp_tp, c->dd_groups, c->dd_tiles, c->tail_yp, c->tail_hb, c->tail_hib, c->tail_wt, c->jn_q };
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (int k2 = 0; k2 < 2; ++k2) { if (c->map_stage[k2]) (void)hipHostFree(c->map_stage[k2]); if (c->map_stage_ev[k2]) (void)hipEventDestroy(c->map_stage_ev[k2]); }
     for (int k2 = 0; k2 < 2; ++k2) { if (c->up_stage[k2]) (void)hipHostFree(c->up_stage[k2]); if (c->up_stage_ev[k2]) (void)hipEventDestroy(c->up_stage_ev[k2]); }
@@ -1314,10 +1315,12 @@ static int step_back(pre3_ctx *c, int m, int n_draw, int k, const int32_t *hyp, 
     c->ride_rescue_projection = ride_rescue != 0;                   // the rescue's projection rides in the LI update's K9 launch
     {
         c->tail_want = c->step_tail && hi_fused_usable(c); c->tail_chi2 = chi2;      // ... or, with the whole rescue stage and the HI update, in the persistent launch itself
+        // ... or projection AND chi2 gate in the Jnorm pass's launch, when the persistent launch's consumers leave rows 3..6 of P behind (GateRide)
+        c->want_gate_ride = ride_rescue != 0 && !c->tail_want && hi_fused_usable(c); c->rescue_chi2 = chi2; c->rescue_gated = false;
         const int rc_li = pre3_update_li(c);                        // mono_slam.m:181
-        c->tail_want = false;
+        c->tail_want = false; c->want_gate_ride = false;
         c->ride_rescue_projection = false;                          // (also on failure: a later K9 launch must not carry the riders)
-        if (rc_li != PRE3_OK) { c->rescue_projected = false; c->tail_done = false; return rc_li; }
+        if (rc_li != PRE3_OK) { c->rescue_projected = false; c->rescue_gated = false; c->tail_done = false; return rc_li; }
     }
     if (ran) for (int i = 0; i < 4; ++i) st[i] = c->mail_host[i];
     if (c->tail_done) {
@@ -1328,9 +1331,10 @@ static int step_back(pre3_ctx *c, int m, int n_draw, int k, const int32_t *hyp, 
         // mono_slam.m:184 + :187 without the host in between: the chi2 gate, then the collection and the HI update of up to 32 landmarks as ONE
         // launch that reads the count on the device, and its down-date behind it (pre3_update.hip, k_hi_fused)
         PRE3_CHECK(c->p_which == PRE3_X_K_K && c->x_valid[PRE3_X_K_K], PRE3_E_STATE, "pre3_step: the LI update did not leave (x_k_k, p_k_k)");
-        if (c->rescue_projected) PRE3_TRY(launch_innovation(c, 1, chi2, false, false));
+        if (c->rescue_gated) { /* the gate rode with the Jnorm pass */ }
+        else if (c->rescue_projected) PRE3_TRY(launch_innovation(c, 1, chi2, false, false));
         else PRE3_TRY(launch_project_innovation(c, PRE3_X_K_K, 0, 1, chi2, false));
-        c->rescue_projected = false;
+        c->rescue_projected = false; c->rescue_gated = false;
         c->hi_from_host = -1; c->hi_kernel = true;
         PRE3_TRY(launch_hi_fused(c, ++c->seq_collect));
         c->hi_fused = true;

@@ -186,7 +186,7 @@ struct CpArgs {
     int win;                             // strips: blocks of W kept in LDS (a ring: block K in slot K % win); older blocks are re-read from Wp
     int stride;                          // crit and the rows are blocks 0, stride, 2 stride, ..
     int n; const double *x_prior; double *x_out; double *params; int xu;      // xu: the strips finish with x_out = x_prior + W'(L^-1 nu) (update.m:36,42,48)
-    float *P; const int32_t *dd; int n_dd; int rows; int dd_mode; int poll_budget, poll_from;      // down-date consumers: group table (DG_WORDS each), groups in this launch, rows if host-known
+    float *P; const int32_t *dd; int n_dd; int rows; int dd_mode; int poll_budget, poll_from; float *jn_q;      // (jn_q: rows 3..6 of the down-dated P, before update.m:42-46, for the gate that rides with that pass)      // down-date consumers: group table (DG_WORDS each), groups in this launch, rows if host-known
     int tail;                            // the rescue stage and the HI update follow inside this launch (CpTail): the HI rows are panel `nrb` of the same factorisation
     float *Wt; int kcap;                 // tail: W once more, column-major (column j at Wt + j * kcap, k contiguous): what the gate's y = H J W' reads
 };
@@ -2034,6 +2034,12 @@ __device__ __attribute__((noinline)) void dd_body(CpArgs a_v, int nrb_v, int row
                     patch[lr][lcol] = v;
                 }
                 wave_lds_sync();
+                if (a.jn_q != nullptr && r0 == 0) {
+                    // rows 3..6 as the Jnorm pass will read them from memory: below the diagonal that is the mirror image stored further down
+                    const int ra = 3 + (lane >> 5), rb = 5 + (lane >> 5);
+                    dd_store_wt(a.jn_q + (size_t)(ra - 3) * ld + c0 + lcol, lcol >= ra ? patch[ra][lcol] : patch[lcol][ra], wt);
+                    dd_store_wt(a.jn_q + (size_t)(rb - 3) * ld + c0 + lcol, lcol >= rb ? patch[rb][lcol] : patch[lcol][rb], wt);
+                }
                 const int rr = lane & 31, half = lane >> 5;
 #pragma unroll
                 for (int cc = 0; cc < 32; cc += 2) {
@@ -2049,6 +2055,7 @@ __device__ __attribute__((noinline)) void dd_body(CpArgs a_v, int nrb_v, int row
                     *reinterpret_cast<f4v_t *>(&patchT[lcol][8 * g4 + lrow]) = v;
                 }
                 wave_lds_sync();
+                if (a.jn_q != nullptr && r0 == 0) dd_store_wt(a.jn_q + (size_t)(lane >> 5) * ld + c0 + lcol, patch[3 + (lane >> 5)][lcol], wt), dd_store_wt(a.jn_q + (size_t)(2 + (lane >> 5)) * ld + c0 + lcol, patch[5 + (lane >> 5)][lcol], wt);
                 const int rr = lane >> 3, c4 = (lane & 7) * 4;
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
@@ -2330,6 +2337,9 @@ int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior, c
     a.poll_budget = poll_budget;
     static const int poll_from = getenv("PRE3_CHOLP_POLL_FROM") ? atoi(getenv("PRE3_CHOLP_POLL_FROM")) : 3;
     a.poll_from = poll_from;
+    // every group of P's tiles is in this launch and the strips finish x: the consumers also leave rows 3..6 behind for the gate (GateRide, pre3_geom.hip)
+    a.jn_q = (!tail && n_dd > 0 && n_dd == c->dd_n_groups && c->jn_q != nullptr) ? c->jn_q : nullptr;
+    c->jn_q_valid = a.jn_q != nullptr;
     // with the consumers in the launch the strips also finish the state: x_k_k = x_prior + W'(L^-1 nu) (the K9 launch that used to carry the
     // x-update as riders has nothing left to do at N = 500)
     static const int xu_env = getenv("PRE3_CHOLP_XU") ? atoi(getenv("PRE3_CHOLP_XU")) : 1;

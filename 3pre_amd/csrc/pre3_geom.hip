@@ -181,13 +181,90 @@ __global__ __launch_bounds__(256) void k_predict(const double *__restrict__ x_in
     }
 }
 
+// The rescue stage's chi2 gate (rescue_hi_inliers.m:35-46) in the SAME launch as the rows / columns 3..6 pass it depends on (round 5): the gate's
+// blocks never read what that pass writes.  The persistent launch's consumers leave the un-normalised rows 3..6 of P in a side buffer Q (4 x ld),
+// and an entry of the normalised P in those rows / columns is recomputed here from Q and Jn exactly as the pass computes and rounds it
+// (jn_row; the 4 x 4 corner through its double-precision intermediate) -- every other entry of the gathered 13 x 13 block is read from P, where
+// the pass leaves it alone.  Sixteen landmarks per block: the first sixteen lanes project them at x_k_k (as k_project_innovation), then sixteen
+// lanes per landmark gather H P H' as innovation_body does, term for term.
+template <typename T>
+struct GateRide {
+    int n_blocks, N; const T *Q; double chi2;
+    const int32_t *lm_type, *lm_off; const double *x; CamD cam;
+    double *h; int32_t *has_h; double *Hc, *Hl; const double *z; const int32_t *ic, *li; int32_t *hi;
+};
+template <typename T>
+__device__ __forceinline__ void gate_ride_block(const GateRide<T> &g, const T *__restrict__ P, int ld, const double *__restrict__ params, int blk)
+{
+    __shared__ double gJn[16];
+    if (threadIdx.x < 16) gJn[threadIdx.x] = params[16 + threadIdx.x];
+    if (threadIdx.x < 16 && blk * 16 + (int)threadIdx.x < g.N) project_one(blk * 16 + threadIdx.x, g.lm_type, g.lm_off, g.x, g.cam, 0, g.h, g.has_h, g.Hc, g.Hl);
+    __threadfence_block();
+    __syncthreads();
+    const int gt = blk * 256 + threadIdx.x, i = gt >> 4, b = gt & 15;
+    const bool valid = i < g.N;
+    const int ii = valid ? i : 0;
+    const bool active = valid && g.ic[ii] == 1 && g.li[ii] == 0;
+    const int d = g.lm_type[ii] == PRE3_INVDEPTH ? 6 : 3, off = g.lm_off[ii], nn = 7 + d;
+    const double *Hc = g.Hc, *Hl = g.Hl;
+    double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+    if (active && b < nn) {
+        const int ib = b < 7 ? b : off + b - 7;
+        // the un-normalised rows 3..6 of P at column c
+        auto qcol = [&](int c, double (&v)[4]) { for (int t = 0; t < 4; ++t) v[t] = (double)g.Q[(size_t)t * ld + c]; };
+        double p7[7], pl[6];
+        if (ib < 3 || ib >= 7) {
+            // a row the pass leaves alone, except at the columns 3..6: P(ib, 3+k) = P(3+k, ib) = (T) Jn(k, :) . Pold(3..6, ib)
+            const T *prow = P + (size_t)ib * ld;
+            double v[4]; qcol(ib, v);
+            for (int a = 0; a < 3; ++a) p7[a] = (double)prow[a];
+            for (int k = 0; k < 4; ++k) p7[3 + k] = (double)(T)jn_row(gJn, k, v);
+            for (int a = 0; a < 6; ++a) pl[a] = a < d ? (double)prow[off + a] : 0.0;
+        } else {
+            // row 3 + r of the normalised P: (T) Jn(r, :) . Pold(3..6, c) off the corner; the corner as k_jnorm_P's thread 0 computes it
+            const int r = ib - 3;
+            for (int a = 0; a < 3; ++a) { double v[4]; qcol(a, v); p7[a] = (double)(T)jn_row(gJn, r, v); }
+            double T1[4];
+            for (int k = 0; k < 4; ++k) { double w[4]; qcol(3 + k, w); T1[k] = jn_row(gJn, r, w); }
+            for (int k = 0; k < 4; ++k) p7[3 + k] = (double)(T)jn_row(gJn, k, T1);
+            for (int a = 0; a < 6; ++a) { pl[a] = 0.0; if (a < d) { double v[4]; qcol(off + a, v); pl[a] = (double)(T)jn_row(gJn, r, v); } }
+        }
+        double hp0 = 0, hp1 = 0;
+#pragma unroll
+        for (int a = 0; a < 7; ++a) { hp0 += Hc[14 * ii + a] * p7[a]; hp1 += Hc[14 * ii + 7 + a] * p7[a]; }
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+            if (a < d) { hp0 += Hl[12 * ii + a] * pl[a]; hp1 += Hl[12 * ii + 6 + a] * pl[a]; }
+        const double h0b = b < 7 ? Hc[14 * ii + b] : Hl[12 * ii + b - 7];
+        const double h1b = b < 7 ? Hc[14 * ii + 7 + b] : Hl[12 * ii + 6 + b - 7];
+        s00 = hp0 * h0b; s01 = hp0 * h1b; s10 = hp1 * h0b; s11 = hp1 * h1b;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        s00 += __shfl_xor(s00, o, 16); s01 += __shfl_xor(s01, o, 16);
+        s10 += __shfl_xor(s10, o, 16); s11 += __shfl_xor(s11, o, 16);
+    }
+    if (!valid || b != 0 || !active) return;
+    const double det = s00 * s11 - s01 * s10;
+    const double i00 = s11 / det, i01 = -s01 / det, i10 = -s10 / det, i11 = s00 / det;
+    const double n0 = g.z[2 * i] - g.h[2 * i], n1 = g.z[2 * i + 1] - g.h[2 * i + 1];
+    const double t0 = n0 * i00 + n1 * i10, t1 = n0 * i01 + n1 * i11;
+    const double d2 = t0 * n0 + t1 * n1;
+    g.hi[i] = d2 < g.chi2 ? 1 : 0;
+}
+
 // rows/cols 3..6 <- Jn (update.m:42-46).  params[16..31] = Jn.
 template <typename T>
-__global__ void k_jnorm_P(T *__restrict__ P, int n, int ld, const double *__restrict__ params, int n_jn_blocks, ProjRide pr)
+__global__ void k_jnorm_P(T *__restrict__ P, int n, int ld, const double *__restrict__ params, int n_jn_blocks, ProjRide pr, GateRide<T> gr)
 {
     // the rescue's projection at x_k_k (rescue_hi_inliers.m:31-32) rides along when the update's x came out of the launch in front
-    // (persistent factorisation with its own x-update): it needs nothing of this launch
-    if ((int)blockIdx.x >= n_jn_blocks) { proj_ride_block(pr, blockIdx.x - n_jn_blocks); return; }
+    // (persistent factorisation with its own x-update): it needs nothing of this launch -- and, when the launch in front also left the
+    // un-normalised rows 3..6 behind (GateRide), the whole gate does
+    if ((int)blockIdx.x >= n_jn_blocks) {
+        if (gr.n_blocks > 0) gate_ride_block<T>(gr, P, ld, params, blockIdx.x - n_jn_blocks);
+        else proj_ride_block(pr, blockIdx.x - n_jn_blocks);
+        return;
+    }
     __shared__ double sJn[16];
     __shared__ double corner[16];
     if (threadIdx.x < 16) sJn[threadIdx.x] = params[16 + threadIdx.x];
@@ -1036,14 +1113,25 @@ int launch_jnorm(pre3_ctx *c, int)
 {
     int blocks = ceil_div(c->n, 256);
     ProjRide pr{};
+    GateRide<float> gr{};
+    static const int gate_env = getenv("PRE3_GATE_RIDE") ? atoi(getenv("PRE3_GATE_RIDE")) : 1;      // 0: the gate as a launch of its own behind this one (rounds 3-4)
     if (c->proj_with_jnorm && c->N > 0) {        // (no producer to wait for: x_k_k is complete)
-        pr = make_proj_ride(c, PRE3_X_K_K, 0, 1, 0);
+        if (gate_env && c->want_gate_ride && c->jn_q_valid && c->dtype == PRE3_F32) {
+            // pre3_step behind a persistent launch whose consumers wrote all of P: projection AND chi2 gate ride here (GateRide)
+            gr.n_blocks = ceil_div(c->N, 16); gr.N = c->N; gr.Q = c->jn_q; gr.chi2 = c->rescue_chi2;
+            gr.lm_type = c->lm.type; gr.lm_off = c->lm.off; gr.x = c->x_kk; gr.cam = to_camd(c->cam);
+            gr.h = c->lm.h; gr.has_h = c->lm.has_h; gr.Hc = c->lm.Hc; gr.Hl = c->lm.Hl; gr.z = c->lm.z; gr.ic = c->lm.ic; gr.li = c->lm.li; gr.hi = c->lm.hi;
+            c->rescue_gated = true;
+        } else {
+            pr = make_proj_ride(c, PRE3_X_K_K, 0, 1, 0);
+        }
         c->rescue_projected = true;
     }
     c->proj_with_jnorm = false;
+    c->jn_q_valid = false;                        // (Q belongs to the update that has just been normalised)
     DISPATCH_T(c,
-        hipLaunchKernelGGL(k_jnorm_P<double>, dim3(blocks + pr.n_blocks), dim3(256), 0, c->stream, (double *)c->P, c->n, c->ld, c->pred_params, blocks, pr),
-        hipLaunchKernelGGL(k_jnorm_P<float>, dim3(blocks + pr.n_blocks), dim3(256), 0, c->stream, (float *)c->P, c->n, c->ld, c->pred_params, blocks, pr));
+        hipLaunchKernelGGL(k_jnorm_P<double>, dim3(blocks + pr.n_blocks), dim3(256), 0, c->stream, (double *)c->P, c->n, c->ld, c->pred_params, blocks, pr, GateRide<double>{}),
+        hipLaunchKernelGGL(k_jnorm_P<float>, dim3(blocks + pr.n_blocks + gr.n_blocks), dim3(256), 0, c->stream, (float *)c->P, c->n, c->ld, c->pred_params, blocks, pr, gr));
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }
