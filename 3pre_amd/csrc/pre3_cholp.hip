@@ -187,6 +187,7 @@ struct CpArgs {
     int stride;                          // crit and the rows are blocks 0, stride, 2 stride, ..
     int n; const double *x_prior; double *x_out; double *params; int xu;      // xu: the strips finish with x_out = x_prior + W'(L^-1 nu) (update.m:36,42,48)
     float *P; const int32_t *dd; int n_dd; int rows; int dd_mode; int poll_budget, poll_from; float *jn_q;      // (jn_q: rows 3..6 of the down-dated P, before update.m:42-46, for the gate that rides with that pass)      // down-date consumers: group table (DG_WORDS each), groups in this launch, rows if host-known
+    int proj;                            // the strips end with the rescue stage's projection of every landmark at x_k_k (strip_proj_body; tables in CpTail's LDS slot)
     int tail;                            // the rescue stage and the HI update follow inside this launch (CpTail): the HI rows are panel `nrb` of the same factorisation
     float *Wt; int kcap;                 // tail: W once more, column-major (column j at Wt + j * kcap, k contiguous): what the gate's y = H J W' reads
 };
@@ -1329,6 +1330,48 @@ __device__ __forceinline__ void tail_gate_body(const CpArgs &a, const CpTail &t,
 __device__ __attribute__((noinline)) void strip_tail_body(int nrb_v, int s_v, int rows_v);
 __device__ __attribute__((noinline)) void gate_prefetch(int rows_v, int s_v);
 
+// The rescue stage's projection (rescue_hi_inliers.m:31-32: every landmark at x_k_k) on the strips' CUs, idle behind their x-update while the
+// consumers finish P (round 5, without the in-launch tail): strip s takes the landmarks i = s (mod n_strips), one wave each, lane 0 runs the
+// fp64 geometry once the strips that own the pose and the landmark's entries have x out.  The gate that rides with the Jnorm pass behind this
+// launch then starts from h / H instead of waiting 4.5 us for them.  Same project_core as project_one: the same bits.
+__device__ __attribute__((noinline)) void strip_proj_body(int s_v)
+{
+    const CpArgs a = args_from_lds<CpArgs>(CP_TA_OFF);
+    const CpTail t = args_from_lds<CpTail>(CP_T_OFF);
+    const int s = __builtin_amdgcn_readfirstlane(s_v), wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int32_t *guard = a.status + 1;
+    for (int i = s + a.n_strips * wave; i < t.N; i += a.n_strips * 8) {
+        const int type = t.lm_type[i], off = t.lm_off[i], d = type == PRE3_INVDEPTH ? 6 : 3;
+        {
+            const int sw = lane == 0 ? 0 : lane == 1 ? (off >> 5) : ((off + d - 1) >> 5);
+            const unsigned *fp = cf_strip(a.cf, sw);
+            bool gave_up = true;
+            for (int spin = 0; spin < SPIN_LIMIT; ++spin) {
+                const bool ok = lane >= 3 || cf_reached(cf_load(fp), a.base + CFV_X);
+                if (__all(ok)) { gave_up = false; break; }
+                if ((spin & 1023) == 1023 && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { gave_up = false; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (gave_up && lane == 0) atomicExch(guard, 1);
+        }
+        if (lane != 0) continue;
+        // (as project_one, pre3_geomdev.h: the Jacobians go straight to the tables)
+        double zi[2] = { 0, 0 };
+        double xp[7], yl[6];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) xp[u] = ld_f64_sc1(a.x_out + u);
+#pragma unroll
+        for (int u = 0; u < 6; ++u) yl[u] = u < d ? ld_f64_sc1(a.x_out + off + u) : 0.0;
+        const int had = t.has_h[i];
+        double h_old[2] = { 0, 0 };
+        if (had) { h_old[0] = t.h[2 * i]; h_old[1] = t.h[2 * i + 1]; }
+        bool fresh = false;
+        const bool now = project_core(type, xp, yl, t.cam, had, h_old, zi, fresh, t.Hc + 14 * i, t.Hl + 12 * i);
+        if (fresh) { t.h[2 * i] = zi[0]; t.h[2 * i + 1] = zi[1]; }
+        t.has_h[i] = now ? 1 : 0;
+    }
+}
+
 __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int rows_v, int s_v)
 {
     const CpArgs a = cp_uniform(a_v);
@@ -1597,7 +1640,7 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
             if (rg == 0 && i >= 3 && i < 7) sx = sx / sqrt(qs[0] * qs[0] + qs[1] * qs[1] + qs[2] * qs[2] + qs[3] * qs[3]);
         }
         if (rg == 0 && i < a.n) st_f64_sc1(a.x_out + i, sx);
-        if (a.tail) {
+        if (a.tail || a.proj) {
             // x_k_k of these 32 states (and, from strip 0, the normalisation Jacobian) is out: the gate's waves wait for this value
             drain_stores();
             __syncthreads();
@@ -1606,6 +1649,7 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
         }
     }
     if (a.tail) strip_tail_body(nrb, s, rows_v);
+    else if (a.proj) strip_proj_body(s);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -2086,7 +2130,7 @@ __global__ __launch_bounds__(CP_NTH) void k_cholp(CpArgs a, CpTail t)
     // bulk operands (each L(k, J) is wanted by every row below k) and the hand-offs with crit are then served by that L2.  Placement is a
     // speed assumption only: every hand-off is valid for any placement.  Every other block is a strip.
     const int b = blockIdx.x, nH = a.nrb_max > 2 ? a.nrb_max - 2 : 0, stride = a.stride;
-    if (a.tail) {
+    if (a.tail || a.proj) {
         // the tail's code (crit, strips) takes the launch arguments from LDS; it reads them behind many barriers of its own role
         if (threadIdx.x < sizeof(CpTail) / 4) reinterpret_cast<unsigned *>(cp_smem + CP_T_OFF)[threadIdx.x] = reinterpret_cast<const unsigned *>(&t)[threadIdx.x];
         if (threadIdx.x >= 128 && threadIdx.x < 128 + sizeof(CpArgs) / 4) reinterpret_cast<unsigned *>(cp_smem + CP_TA_OFF)[threadIdx.x - 128] = reinterpret_cast<const unsigned *>(&a)[threadIdx.x - 128];
@@ -2348,6 +2392,15 @@ int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior, c
     a.P = (float *)c->P; a.dd = c->dd_groups; a.n_dd = n_dd; a.rows = nrb < 0 ? nrb_max * NB : (rows > 0 && rows <= nrb * NB ? rows : nrb * NB);
     CpTail t{};
     a.tail = tail ? 1 : 0;
+    // without the tail: the strips still end with the rescue stage's projection when the step wants the gate to ride with the Jnorm pass (GateRide)
+    static const int proj_env = getenv("PRE3_CHOLP_PROJ") ? atoi(getenv("PRE3_CHOLP_PROJ")) : 1;
+    a.proj = (proj_env && !tail && c->want_gate_ride && a.jn_q != nullptr && a.xu && c->N > 0 && lds_strip <= CP_T_OFF) ? 1 : 0;
+    if (a.proj) {
+        t.N = c->N; t.lm_type = c->lm.type; t.lm_off = c->lm.off; t.has_h = c->lm.has_h; t.h = c->lm.h; t.Hc = c->lm.Hc; t.Hl = c->lm.Hl;
+        t.cam = CamD{ c->cam.f, c->cam.Cx, c->cam.Cy, c->cam.k1, c->cam.k2, (double)c->cam.nRows, (double)c->cam.nCols };
+        lds = 160 * 1024;
+    }
+    c->proj_in_cholp = a.proj != 0;
     if (tail) {
         t.on = 1; t.N = c->N; t.m = c->m; t.seq = tail_req->seq; t.ykcap = c->rcap; t.chi2 = tail_req->chi2;
         t.lm_type = c->lm.type; t.lm_off = c->lm.off; t.lm_ic = c->lm.ic; t.lm_li = c->lm.li; t.meas = c->meas;

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_predict(const double *__restrict__ x_in
 // lanes per landmark gather H P H' as innovation_body does, term for term.
 template <typename T>
 struct GateRide {
-    int n_blocks, N; const T *Q; double chi2;
+    int n_blocks, N; const T *Q; double chi2; int project;        // project == 0: h / H at x_k_k are there already (the persistent launch's strips)
     const int32_t *lm_type, *lm_off; const double *x; CamD cam;
     double *h; int32_t *has_h; double *Hc, *Hl; const double *z; const int32_t *ic, *li; int32_t *hi;
 };
@@ -198,7 +198,7 @@ __device__ __forceinline__ void gate_ride_block(const GateRide<T> &g, const T *_
 {
     __shared__ double gJn[16];
     if (threadIdx.x < 16) gJn[threadIdx.x] = params[16 + threadIdx.x];
-    if (threadIdx.x < 16 && blk * 16 + (int)threadIdx.x < g.N) project_one(blk * 16 + threadIdx.x, g.lm_type, g.lm_off, g.x, g.cam, 0, g.h, g.has_h, g.Hc, g.Hl);
+    if (g.project && threadIdx.x < 16 && blk * 16 + (int)threadIdx.x < g.N) project_one(blk * 16 + threadIdx.x, g.lm_type, g.lm_off, g.x, g.cam, 0, g.h, g.has_h, g.Hc, g.Hl);
     __threadfence_block();
     __syncthreads();
     const int gt = blk * 256 + threadIdx.x, i = gt >> 4, b = gt & 15;
@@ -1118,7 +1118,7 @@ int launch_jnorm(pre3_ctx *c, int)
     if (c->proj_with_jnorm && c->N > 0) {        // (no producer to wait for: x_k_k is complete)
         if (gate_env && c->want_gate_ride && c->jn_q_valid && c->dtype == PRE3_F32) {
             // pre3_step behind a persistent launch whose consumers wrote all of P: projection AND chi2 gate ride here (GateRide)
-            gr.n_blocks = ceil_div(c->N, 16); gr.N = c->N; gr.Q = c->jn_q; gr.chi2 = c->rescue_chi2;
+            gr.n_blocks = ceil_div(c->N, 16); gr.N = c->N; gr.Q = c->jn_q; gr.chi2 = c->rescue_chi2; gr.project = c->proj_in_cholp ? 0 : 1;
             gr.lm_type = c->lm.type; gr.lm_off = c->lm.off; gr.x = c->x_kk; gr.cam = to_camd(c->cam);
             gr.h = c->lm.h; gr.has_h = c->lm.has_h; gr.Hc = c->lm.Hc; gr.Hl = c->lm.Hl; gr.z = c->lm.z; gr.ic = c->lm.ic; gr.li = c->lm.li; gr.hi = c->lm.hi;
             c->rescue_gated = true;
@@ -1127,7 +1127,7 @@ int launch_jnorm(pre3_ctx *c, int)
         }
         c->rescue_projected = true;
     }
-    c->proj_with_jnorm = false;
+    c->proj_with_jnorm = false; c->proj_in_cholp = false;
     c->jn_q_valid = false;                        // (Q belongs to the update that has just been normalised)
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_jnorm_P<double>, dim3(blocks + pr.n_blocks), dim3(256), 0, c->stream, (double *)c->P, c->n, c->ld, c->pred_params, blocks, pr, GateRide<double>{}),

@@ -187,6 +187,7 @@ struct pre3_ctx {
     bool x_done = false;                          // ... and its strips have computed x_k_k = x_prior + W'(L^-1 nu) as well (update.m:36,42,48)
     float *jn_q = nullptr; bool jn_q_valid = false;   // un-normalised rows 3..6 of P, left by the persistent launch's consumers for the gate that rides with the Jnorm pass (GateRide)
     bool want_gate_ride = false, rescue_gated = false; double rescue_chi2 = 0.0;
+    bool proj_in_cholp = false;                   // the persistent launch's strips have projected every landmark at x_k_k (strip_proj_body): the gate needs no projection
     bool proj_with_jnorm = false;                 // the rescue's projection rides in the next k_jnorm_P launch (no K9 launch to carry it)
     int dd_done = 0;                              // groups the last k_cholp launch has down-dated (consumed by the next launch_downdate)
     bool hp_all_valid = false;                    // HP / G hold H*P, H*P*H' of ALL measured rows at the current prior (ransac_prepare)
