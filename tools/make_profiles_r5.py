@@ -165,7 +165,10 @@ for leg, first, cap in (("frame", "k_map_", "one mono_slam.m frame at N=500, K2=
         shutil.copy(find("%s_%s" % (tag, leg), "t_kernel_stats.csv"), os.path.join(P, "%s_%s_kernel_stats.csv" % (tag, "frame" if leg == "frame" else "fp64_n200")))
         kt = sorted(rows(find("%s_%s" % (tag, leg), "t_kernel_trace.csv")), key=lambda r: int(r["Start_Timestamp"]))
         starts = [i for i, r in enumerate(kt) if first in r["Kernel_Name"] and (i == 0 or first not in kt[i - 1]["Kernel_Name"] or leg == "fp64")]
-        a, b = starts[len(starts) // 2], starts[len(starts) // 2 + 1]
+        # the iteration with the MEDIAN wall time (under the profiler some iterations of the frame leg wait for the host between launches)
+        walls = sorted((int(kt[starts[q + 1]]["Start_Timestamp"]) - int(kt[starts[q]]["Start_Timestamp"]), q) for q in range(2, len(starts) - 1))
+        qm = walls[len(walls) // 2][1]
+        a, b = starts[qm], starts[qm + 1]
         t0 = int(kt[a]["Start_Timestamp"]); prev = None
         lines = ["# %s -- one iteration from rocprofv3 --kernel-trace" % cap, "# kernel | start us | duration us | gap to previous us"]
         for r in kt[a:b]:
