@@ -89,26 +89,19 @@ __global__ __launch_bounds__(256) void k_predict(const double *__restrict__ x_in
     if (blockIdx.x == 0 && threadIdx.x < 49) corner[threadIdx.x] = (double)P[(threadIdx.x / 7) * ld + (threadIdx.x % 7)];
     if (threadIdx.x == 0) {
         const double *q = x_in + 3;
-        // qProd.m:16-33
         const double a = q[0], b = q[1], c = q[2], d = q[3];
         const double w = u.v[3], x = u.v[4], y = u.v[5], z = u.v[6];
-        double xo[7];
-        xo[3] = a * w - b * x - c * y - d * z;
-        xo[4] = a * x + b * w + c * z - d * y;
-        xo[5] = a * y - b * z + c * w + d * x;
-        xo[6] = a * z + b * y - c * x + d * w;
+        // the predicted pose (predict_pose, pre3_geomdev.h: the projection riders of this launch compute the same thing for themselves)
+        double xo[7], pose[7];
+        predict_pose(x_in, u, xo, pose);
         double R[9];
         if (blockIdx.x == 0) {
-            // the predicted pose first, and the riders' signal right behind it: they read nothing else of this launch, and the rest of this
-            // lane's serial work (normalisation Jacobian, G, process noise: a few hundred dependent fp64 operations) need not stand in front
-            // of the 500 projections
             d_q2R_sola(q, R);
-            for (int i = 0; i < 3; ++i) xo[i] = x_in[i] + (R[i * 3] * u.v[0] + R[i * 3 + 1] * u.v[1] + R[i * 3 + 2] * u.v[2]);
-            const double nq = sqrt(xo[3] * xo[3] + xo[4] * xo[4] + xo[5] * xo[5] + xo[6] * xo[6]);
-            for (int i = 0; i < 3; ++i) x_out[i] = xo[i];
-            for (int i = 0; i < 4; ++i) x_out[3 + i] = xo[3 + i] / nq;
+            for (int i = 0; i < 7; ++i) x_out[i] = pose[i];
             for (int i = 7; i < 13; ++i) x_out[i] = 0;
-            if (pr.n_blocks) { __threadfence(); __hip_atomic_fetch_add(pr.ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+            // (riders that wait for the pose -- PRE3_RIDE_POSE=0 -- get their signal right behind it: the rest of this lane's serial work, a few
+            //  hundred dependent fp64 operations, need not stand in front of the 500 projections)
+            if (pr.n_blocks && !pr.own_pose) { __threadfence(); __hip_atomic_fetch_add(pr.ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
         }
         const double Qq1[16] = { w, -x, -y, -z,  x, w, z, -y,  y, -z, w, x,  z, y, -x, w };
         double Jn[16];
@@ -1097,7 +1090,11 @@ int launch_predict_impl(pre3_ctx *c, const double u[7], bool with_projection, si
     U7 uu; for (int i = 0; i < 7; ++i) uu.v[i] = u[i];
     int blocks = ceil_div(c->n, 256);
     ProjRide pr{};
-    if (with_projection && c->N > 0) { pr = make_proj_ride(c, PRE3_X_K_KM1, 1, 0, 1); pr.x_lm = c->x_kk; }      // one producer: block 0 (the pose)
+    static const int own_pose = getenv("PRE3_RIDE_POSE") ? atoi(getenv("PRE3_RIDE_POSE")) : 1;      // 0: the riders wait for block 0's pose (rounds 2-4)
+    if (with_projection && c->N > 0) {
+        pr = make_proj_ride(c, PRE3_X_K_KM1, 1, 0, own_pose ? 0 : 1); pr.x_lm = c->x_kk;      // (one producer: block 0 -- or none: the riders compute the pose themselves)
+        pr.own_pose = own_pose ? 1 : 0; pr.x_prev = c->x_kk; pr.u = uu;
+    }
     InboxRide ib{ (const int4 *)c->inbox_host_dev, (int4 *)c->inbox_dev, (int)inbox_n16, c->mail_dev, inbox_seq };     // one more block when inbox_n16 > 0
     const int nb = blocks + pr.n_blocks + (inbox_n16 ? 1 : 0);
     const int fuse_jn = c->jn_pending ? 1 : 0;          // the pending update.m:42-46 pass of the update in front (run_update left it to this launch)

@@ -172,8 +172,31 @@ __device__ inline void project_one(const int i, const int32_t *__restrict__ lm_t
 // appended to the launch that produces the state they need (k_predict for the IC search, the K9 launch -- whose x-update
 // workgroups write x_k_k -- for the rescue).  Producers signal a device counter (monotonic, the host passes the target);
 // riders have higher block indices, so every producer has been dispatched before a rider can spin.
+// The predicted pose (predict_state_and_covariance.m:60-77: r + R(q) u_r, q x u_q, normalised), ONE function for the prediction's block 0 and for
+// the projection riders of the same launch, which compute it themselves instead of waiting for block 0 to publish it (round 5: fence + counter +
+// poll were ~1.5 us in front of every projection).  The same expressions, so the same bits as x_out.
+__device__ __forceinline__ void predict_pose(const double *__restrict__ x_in, const U7 &u, double (&xo)[7], double (&pose)[7])
+{
+    const double *q = x_in + 3;
+    // qProd.m:16-33
+    const double a = q[0], b = q[1], c = q[2], d = q[3];
+    const double w = u.v[3], x = u.v[4], y = u.v[5], z = u.v[6];
+    xo[3] = a * w - b * x - c * y - d * z;
+    xo[4] = a * x + b * w + c * z - d * y;
+    xo[5] = a * y - b * z + c * w + d * x;
+    xo[6] = a * z + b * y - c * x + d * w;
+    double R[9];
+    d_q2R_sola(q, R);
+    for (int i = 0; i < 3; ++i) xo[i] = x_in[i] + (R[i * 3] * u.v[0] + R[i * 3 + 1] * u.v[1] + R[i * 3 + 2] * u.v[2]);
+    const double nq = sqrt(xo[3] * xo[3] + xo[4] * xo[4] + xo[5] * xo[5] + xo[6] * xo[6]);
+    for (int i = 0; i < 3; ++i) pose[i] = xo[i];
+    for (int i = 0; i < 4; ++i) pose[3 + i] = xo[3 + i] / nq;
+}
+
 struct ProjRide {
     int n_blocks;                       // 0: no rider in this launch
+    int own_pose;                       // 1: the riders compute the predicted pose themselves from (x_prev, u) -- no producer to wait for
+    const double *x_prev; U7 u;
     int N, clear_first;
     const int32_t *lm_type, *lm_off; const double *x; const double *x_lm /* landmark entries (null: x) */; CamD cam;
     double *h; int32_t *has_h; double *Hc, *Hl;
@@ -202,10 +225,18 @@ __device__ __forceinline__ void ride_signal(unsigned int *ctr)      // call from
 
 __device__ __forceinline__ void proj_ride_block(const ProjRide &pr, int blk)
 {
+    const int i = blk * 64 + threadIdx.x;
+    if (pr.own_pose) {
+        if (threadIdx.x < 64 && i < pr.N) {
+            double xo[7], pose[7];
+            predict_pose(pr.x_prev, pr.u, xo, pose);
+            project_one(i, pr.lm_type, pr.lm_off, pose, pr.cam, pr.clear_first, pr.h, pr.has_h, pr.Hc, pr.Hl, pr.x_lm);
+        }
+        return;
+    }
     if (threadIdx.x == 0) bounded_wait(pr.ctr, pr.target, pr.guard);
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const int i = blk * 64 + threadIdx.x;
     if (threadIdx.x < 64 && i < pr.N) project_one(i, pr.lm_type, pr.lm_off, pr.x, pr.cam, pr.clear_first, pr.h, pr.has_h, pr.Hc, pr.Hl, pr.x_lm);
 }
 
