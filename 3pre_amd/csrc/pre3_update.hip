@@ -2359,6 +2359,7 @@ int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_d
 {
     if (r == 0) {   // update.m:50-55: x_k_k = x_km1_k, p_k_k = p_km1_k
         c->dd_done = 0; c->x_done = false; c->cholp_done = false;      // (a speculative persistent launch found no rows on the device either)
+        c->jn_q_valid = false; c->proj_in_cholp = false;               // (... so its consumers left no rows 3..6 behind and its strips projected nothing)
         if (c->kt.pending) cholp_timing_rows(c, 0);
         if (which_prior == PRE3_X_K_KM1) PRE3_HIP(hipMemcpyAsync(c->x_kk, c->x_km1, sizeof(double) * c->n, hipMemcpyDeviceToDevice, c->stream));
         return PRE3_OK;

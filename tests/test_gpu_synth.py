@@ -293,3 +293,34 @@ def test_step_all_equals_the_call_by_call_pure_ekf_branch(pre3, dtype):
         f.close()
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+def test_a_step_of_outliers_then_a_normal_one(pre3, orc):
+    """pre3_step at the headline's size (fp32, persistent launch + riders) when every measurement is an outlier: the only low-innovation inliers are the
+    winning hypothesis' own draws -- an LI update of a handful of rows (one panel, cut short), the projection on the strips and the gate riding with
+    the Jnorm pass as for any other update --, then a normal step.  Both against the oracle."""
+    N, n_hyp = 500, 40
+    seq = synth.make_sequence(N, 2, n_hyp, seed=77)
+    types, off, n = orc.landmark_table(np.zeros(N, int))
+    f = pre3.EkfFilter(seq["cam"], types, dtype="f32", max_hyp=n_hyp, std_z=1.0)
+    x, P = seq["x0"], seq["P0"]
+    f.set_x_p_k_k(x, P)
+    rng = np.random.default_rng(5)
+    for k, s in enumerate(seq["steps"]):
+        z = np.array(s["z"], float)
+        if k == 0:
+            z = z + rng.uniform(40.0, 90.0, z.shape) * rng.choice([-1.0, 1.0], z.shape)      # nothing agrees with anything
+        st = f.step(s["u"], s["meas_idx"], z, s["hyp"], threshold=1.0, early_exit=False)
+        ref = orc.step(types, off, seq["cam"], x, P, s["u"], s["meas_idx"], z, s["hyp"], 1.0, early_exit=False)
+        li, hi = f.get_flags()
+        assert np.array_equal(li, ref["li"]) and np.array_equal(hi, ref["hi"])
+        if k == 0:
+            assert st["n_li"] <= 3 and st["n_li"] == int(ref["li"].sum())
+        else:
+            assert st["n_li"] > 100
+        xg, Pg = f.get_x_k_k(), f.get_p_k_k()
+        assert np.abs(xg - ref["x_kk"]).max() < 2e-5
+        assert np.abs(Pg - ref["P_kk"]).max() < 5e-4 * np.abs(ref["P_kk"]).max()
+        x, P = ref["x_kk"], ref["P_kk"]
+        f.set_x_p_k_k(x, P)
+    f.close()
