@@ -880,7 +880,10 @@ __global__ __launch_bounds__(256) void k_select_gather(int n_draw, int k, int ea
 // The staged form (the SGL_RB rows of H*P fit in LDS: N = 500 in fp32): a workgroup reads its rows ONCE -- 16-byte loads, on their way to W
 // and into LDS -- and takes the entries of S out of LDS.  In the form above every row is read by the W copy and, entry by entry, by the S
 // workgroups, from an L2 that another XCD's k_ell_HP_build wrote (13.8 us against ~10).
-template <typename T>
+// RB rows per workgroup, NIT 1024-column pieces of a row held in registers at once: <4, 4> at N = 500 (the four rows fit the 64 KB a launch gets
+// without opting in); <1, 12> for long rows (N = 2000: one 48-KB row per workgroup -- round 5: that size used to take the unstaged form above, whose S
+// entries are 85 M scattered reads of H*P from memory: 147 us of the step)
+template <typename T, int RB = 4, int NIT_ = 4>
 __global__ __launch_bounds__(256) void k_select_gather_lds(int n_draw, int k, int early_exit, int m, const int32_t *__restrict__ meas,
                                                            int32_t *support, const uint32_t *masks, int mask_words,
                                                            int32_t *__restrict__ li_meas, int32_t *__restrict__ lm_li, int32_t *__restrict__ sel_rows,
@@ -896,16 +899,16 @@ __global__ __launch_bounds__(256) void k_select_gather_lds(int n_draw, int k, in
     __shared__ int s_sel[SG_MAXW * 32];
     const int tid = threadIdx.x;
     const int r = 2 * select_local_list(n_draw, k, early_exit, m, support, masks, mask_words, s_sel), r_pad = (r + NB - 1) / NB * NB;
-    const int a0 = blockIdx.x * SGL_RB;
+    const int a0 = blockIdx.x * RB;
     if (a0 >= r_pad) return;
     T *rows = reinterpret_cast<T *>(sg_smem);
     typedef T v4_t __attribute__((ext_vector_type(4)));
-    const T *src[SGL_RB];
+    const T *src[RB];
 #pragma unroll
-    for (int q = 0; q < SGL_RB; ++q) { const int a = a0 + q; src[q] = a < r ? HP + (size_t)(2 * s_sel[a >> 1] + (a & 1)) * ldw : nullptr; }
+    for (int q = 0; q < RB; ++q) { const int a = a0 + q; src[q] = a < r ? HP + (size_t)(2 * s_sel[a >> 1] + (a & 1)) * ldw : nullptr; }
     // every load of the workgroup is in flight before its first store (round 5): the ELL row of this lane's first column of S, and the four rows of
     // H*P in up to four 16-byte pieces per lane -- they used to be three to four dependent round trips to an L2 that another XCD wrote
-    const bool any0 = tid < r && tid <= a0 + SGL_RB - 1;
+    const bool any0 = tid < r && tid <= a0 + RB - 1;
     T vv0[ELLW]; int cc0[ELLW];
 #pragma unroll
     for (int t = 0; t < ELLW; ++t) { vv0[t] = (T)0; cc0[t] = 0; }
@@ -915,31 +918,31 @@ __global__ __launch_bounds__(256) void k_select_gather_lds(int n_draw, int k, in
         for (int t = 0; t < ELLW; ++t) { vv0[t] = row_val[rb * ELLW + t]; cc0[t] = row_col[rb * ELLW + t]; }
     }
     {
-        constexpr int NIT = 4;                              // (the staged form holds four rows of at most ~3400 columns: four pieces of 1024)
-        v4_t v[NIT][SGL_RB];
+        constexpr int NIT = NIT_;                           // (<4, 4>: four rows of at most ~3400 columns, four pieces of 1024; <1, 12>: one row of up to 12288)
+        v4_t v[NIT][RB];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int j = tid * 4 + it * 1024;
 #pragma unroll
-            for (int q = 0; q < SGL_RB; ++q) v[it][q] = (j < ldw && src[q]) ? *reinterpret_cast<const v4_t *>(src[q] + j) : v4_t{ (T)0, (T)0, (T)0, (T)0 };
+            for (int q = 0; q < RB; ++q) v[it][q] = (j < ldw && src[q]) ? *reinterpret_cast<const v4_t *>(src[q] + j) : v4_t{ (T)0, (T)0, (T)0, (T)0 };
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int j = tid * 4 + it * 1024;
             if (j < ldw) {
 #pragma unroll
-                for (int q = 0; q < SGL_RB; ++q) {
+                for (int q = 0; q < RB; ++q) {
                     *reinterpret_cast<v4_t *>(W + (size_t)(a0 + q) * ldw + j) = v[it][q];
                     *reinterpret_cast<v4_t *>(rows + (size_t)q * ldw + j) = v[it][q];
                 }
             }
         }
         for (int j = tid * 4 + NIT * 1024; j < ldw; j += 1024) {
-            v4_t w[SGL_RB];
+            v4_t w[RB];
 #pragma unroll
-            for (int q = 0; q < SGL_RB; ++q) w[q] = src[q] ? *reinterpret_cast<const v4_t *>(src[q] + j) : v4_t{ (T)0, (T)0, (T)0, (T)0 };
+            for (int q = 0; q < RB; ++q) w[q] = src[q] ? *reinterpret_cast<const v4_t *>(src[q] + j) : v4_t{ (T)0, (T)0, (T)0, (T)0 };
 #pragma unroll
-            for (int q = 0; q < SGL_RB; ++q) {
+            for (int q = 0; q < RB; ++q) {
                 *reinterpret_cast<v4_t *>(W + (size_t)(a0 + q) * ldw + j) = w[q];
                 *reinterpret_cast<v4_t *>(rows + (size_t)q * ldw + j) = w[q];
             }
@@ -947,7 +950,7 @@ __global__ __launch_bounds__(256) void k_select_gather_lds(int n_draw, int k, in
     }
     __syncthreads();
     for (int b = tid; b < r_pad; b += 256) {
-        const bool any = b < r && b <= a0 + SGL_RB - 1;
+        const bool any = b < r && b <= a0 + RB - 1;
         T vv[ELLW]; int cc[ELLW];
         if (b == tid) {
 #pragma unroll
@@ -958,7 +961,7 @@ __global__ __launch_bounds__(256) void k_select_gather_lds(int n_draw, int k, in
             for (int t = 0; t < ELLW; ++t) { vv[t] = row_val[rb * ELLW + t]; cc[t] = row_col[rb * ELLW + t]; }
         }
 #pragma unroll
-        for (int q = 0; q < SGL_RB; ++q) {
+        for (int q = 0; q < RB; ++q) {
             const int a = a0 + q;
             T out = (a == b) ? (T)1 : (T)0;
             if (any && a < r && b <= a) {
@@ -1259,13 +1262,23 @@ int launch_select_gather(pre3_ctx *c, int n_draw, int k, int early_exit, int mas
     const int seq = ++c->seq_select;
     static const int lds_env = getenv("PRE3_SELECT_GATHER_LDS") ? atoi(getenv("PRE3_SELECT_GATHER_LDS")) : 1;
     const size_t stage = (size_t)SGL_RB * c->ldw * (c->dtype == PRE3_F64 ? 8 : 4);
+    const size_t stage1 = stage / SGL_RB;
+    if (lds_env && stage > 55 * 1024 && stage1 <= 55 * 1024 && c->dtype == PRE3_F32) {
+        // long rows: one row per workgroup
+        const int ny = r_pad_max;
+        dim3 g(ny + 1), b(256);
+        hipLaunchKernelGGL((k_select_gather_lds<float, 1, 12>), g, b, stage1, c->stream, n_draw, k, early_exit, c->m, c->meas, c->support, c->masks, mask_words, c->li_meas, c->lm.li,
+                           c->sel_rows, c->stats, c->mail_dev, seq, ny, (const float *)c->HP, (float *)c->W, c->ldw, c->row_col, (const float *)c->row_val, (float *)c->Smat);
+        PRE3_HIP(hipGetLastError());
+        return PRE3_OK;
+    }
     if (lds_env && stage <= 55 * 1024) {          // (+ 8.8 KB of static LDS: inside the 64 KB a launch gets without opting in)
         const int ny = r_pad_max / SGL_RB;
         dim3 g(ny + 1), b(256);
         DISPATCH_T(c,
-            hipLaunchKernelGGL(k_select_gather_lds<double>, g, b, stage, c->stream, n_draw, k, early_exit, c->m, c->meas, c->support, c->masks, mask_words, c->li_meas, c->lm.li,
+            hipLaunchKernelGGL((k_select_gather_lds<double, SGL_RB, 4>), g, b, stage, c->stream, n_draw, k, early_exit, c->m, c->meas, c->support, c->masks, mask_words, c->li_meas, c->lm.li,
                                c->sel_rows, c->stats, c->mail_dev, seq, ny, (const double *)c->HP, (double *)c->W, c->ldw, c->row_col, (const double *)c->row_val, (double *)c->Smat),
-            hipLaunchKernelGGL(k_select_gather_lds<float>, g, b, stage, c->stream, n_draw, k, early_exit, c->m, c->meas, c->support, c->masks, mask_words, c->li_meas, c->lm.li,
+            hipLaunchKernelGGL((k_select_gather_lds<float, SGL_RB, 4>), g, b, stage, c->stream, n_draw, k, early_exit, c->m, c->meas, c->support, c->masks, mask_words, c->li_meas, c->lm.li,
                                c->sel_rows, c->stats, c->mail_dev, seq, ny, (const float *)c->HP, (float *)c->W, c->ldw, c->row_col, (const float *)c->row_val, (float *)c->Smat));
         PRE3_HIP(hipGetLastError());
         return PRE3_OK;
