@@ -929,7 +929,7 @@ static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, in
         if (need_pull) c->inbox_pending = true;
     } else {
         if (zero_words) PRE3_HIP(hipMemsetAsync(c->support, 0, sizeof(int32_t) * zero_words, c->stream));
-        if (need_pull) { PRE3_TRY(launch_inbox_pull(c, (const unsigned char *)c->inbox_host_dev + c->off_hyp, c->hyp, (sizeof(int32_t) * n_draw * k + 15) / 16, ++c->seq_inbox)); c->inbox_pending = true; }
+        // (need_pull: the caller's table crosses PCIe as a rider of the H*P launch below -- its first reader is the scorer behind that launch)
     }
     c->masks = reinterpret_cast<uint32_t *>(c->support + round_up(n_draw, 4));
     c->scored_n_draw = n_draw; c->scored_k = k;         // the mask offset depends on n_draw: select / export / import must use the same
@@ -946,6 +946,18 @@ static int ransac_prepare(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, in
         c->hp_all_valid = false;
         return PRE3_OK;
     }
+    if (need_pull) {
+        static const int ride_env = getenv("PRE3_HYP_RIDE") ? atoi(getenv("PRE3_HYP_RIDE")) : 1;      // 0: the pull as a launch of its own (rounds 2-4)
+        const size_t n16 = (sizeof(int32_t) * n_draw * k + 15) / 16;
+        if (ride_env) {
+            const InboxRide ib{ (const int4 *)((const unsigned char *)c->inbox_host_dev + c->off_hyp), (int4 *)c->hyp, (int)n16, c->mail_dev, ++c->seq_inbox, 10, nullptr, 0 };
+            c->inbox_pending = true;
+            PRE3_TRY(launch_ell_HP_build(c, c->HP, nullptr, 0, &ib));
+        } else {
+            PRE3_TRY(launch_inbox_pull(c, (const unsigned char *)c->inbox_host_dev + c->off_hyp, c->hyp, n16, ++c->seq_inbox)); c->inbox_pending = true;
+            PRE3_TRY(launch_ell_HP_build(c, c->HP));
+        }
+    } else
     PRE3_TRY(launch_ell_HP_build(c, c->HP));
     // H*P*H' of all measured rows is no longer built (6.6 us of launch in front of the scoring, PRE3_INLINE_G=0 brings it back): the scorer
     // computes the (2k)^2 entries among its hypothesis' rows and the LI gather the entries of S it needs, both with k_ell_G's sum

@@ -49,24 +49,6 @@ __device__ __forceinline__ double jn_row(const double *J, int i, const double v[
 {
     return fma(J[i * 4 + 3], v[3], fma(J[i * 4 + 2], v[2], fma(J[i * 4 + 1], v[1], J[i * 4] * v[0])));
 }
-// The per-step inbox [meas | ic | hyp | z]: pinned host memory, read over PCIe by the device itself (16 bytes per lane).  ONE workgroup, so
-// that its last act can be to publish `seq` in the pinned mailbox: the host may overwrite the inbox once it reads that number back.
-struct InboxRide { const int4 *src; int4 *dst; int n16; int32_t *mail; int32_t seq; int slot = 10; int32_t *clear = nullptr; int n_clear = 0; };      // clear: n_clear ints zeroed on the way (the inlier flags behind the inbox: was a hipMemsetAsync, i.e. a fill kernel between barrier packets)        // n16 == 0: no pull in this launch; slot: the mailbox word that takes seq
-__device__ __forceinline__ void inbox_pull_block(const InboxRide &ib)
-{
-    // four PCIe reads in flight per lane (a read is ~1.5 us; one after the other they made this block the long pole of k_predict)
-    for (int i0 = threadIdx.x; i0 < ib.n16; i0 += 4 * blockDim.x) {
-        int4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const int i = i0 + u * blockDim.x; v[u] = i < ib.n16 ? ib.src[i] : int4{ 0, 0, 0, 0 }; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const int i = i0 + u * blockDim.x; if (i < ib.n16) ib.dst[i] = v[u]; }
-    }
-    for (int i = threadIdx.x; i < ib.n_clear; i += blockDim.x) ib.clear[i] = 0;
-    __syncthreads();
-    if (threadIdx.x == 0) { __threadfence_system(); __hip_atomic_store(ib.mail + ib.slot, ib.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-}
-
 // k_predict_x and k_predict_P in ONE launch (a kernel boundary costs ~5 us on this platform, more than either kernel):
 // lane 0 of every block recomputes the quaternion product and its normalisation Jacobian (a few dozen flops) instead of
 // reading them from a previous kernel; block 0 additionally owns x_out[0:13], the process noise and the 7x7 pose block.

@@ -255,7 +255,9 @@ int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_d
                bool hp_built = false /* rows and W = H*P are in place (launch_ell_HP_build_sel), S is not */);
 int launch_ell_HP_build_sel(pre3_ctx *c, int nsel, const int32_t *sel_dev /* nullable: the first nsel measurements */, void *dst);
 int launch_chol_first_spec(pre3_ctx *c, int nsel_max);
-int launch_ell_HP_build(pre3_ctx *c, void *dst, const int32_t *need = nullptr, int need_tag = 0 /* sharded RANSAC: only the measurements with need[s] == need_tag */);
+struct InboxRide;
+int launch_ell_HP_build(pre3_ctx *c, void *dst, const int32_t *need = nullptr, int need_tag = 0 /* sharded RANSAC: only the measurements with need[s] == need_tag */,
+                        const InboxRide *ib = nullptr /* a pull from the pinned inbox that rides in the launch */);
 int launch_ell_G_hyp(pre3_ctx *c, int k, int lo, int hi, int ldg);                 /* H*P*H' entries among each hypothesis' own rows, hypotheses [lo, hi) */
 int launch_gather_li(pre3_ctx *c, int nsel /* < 0: count read on the device */, int nsel_max, const int32_t *sel_dev, int ldg);
 int launch_select_gather(pre3_ctx *c, int n_draw, int k, int early_exit, int mask_words);     // selection + LI gather in one launch (pre3_geom.hip)

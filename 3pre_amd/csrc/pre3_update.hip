@@ -64,8 +64,11 @@ __global__ __launch_bounds__(256) void k_ell_HP_build(int m, int r_pad, const in
                                                       const double *__restrict__ Hl, const double *__restrict__ z, const double *__restrict__ h,
                                                       int32_t *__restrict__ row_col, T *__restrict__ row_val, double *__restrict__ row_nu,
                                                       const T *__restrict__ P, int ld, T *__restrict__ dst, int ldw, const int32_t *__restrict__ need, int need_tag,
-                                                      int ny_build, InnovRide ir, const int32_t *__restrict__ sel = nullptr)
+                                                      int ny_build, InnovRide ir, const int32_t *__restrict__ sel = nullptr, InboxRide ib = InboxRide{})
 {
+    // the last block row (ib.n16 > 0): the hypothesis table's pull from the pinned inbox rides here -- the scorer behind this launch is its first reader
+    // (pre3_step_predicted / pre3_ransac with a caller's table: it was a 5-us launch of its own in front of this one)
+    if (ib.n16 > 0 && blockIdx.y == gridDim.y - 1) { if (blockIdx.x == 0) inbox_pull_block(ib); return; }
     // rows of blocks beyond the build's own: the S_i pass of search_IC_matches.m:33-44 rides here (pre3_step; it only needs what the
     // prediction's launch left behind, like this kernel)
     if ((int)blockIdx.y >= ny_build) { innov_ride_block<T>(ir, ((int)blockIdx.y - ny_build) * gridDim.x + blockIdx.x); return; }
@@ -1993,8 +1996,10 @@ int launch_ell_HP_build_sel(pre3_ctx *c, int nsel, const int32_t *sel_dev, void 
 }
 
 // rows of all m measurements built and multiplied in one launch (replaces launch_build_rows_impl + launch_ell_HP)
-int launch_ell_HP_build(pre3_ctx *c, void *dst, const int32_t *need, int need_tag)
+int launch_ell_HP_build(pre3_ctx *c, void *dst, const int32_t *need, int need_tag, const InboxRide *ib_in)
 {
+    const InboxRide ib = ib_in ? *ib_in : InboxRide{};
+    const int ib_rows = ib.n16 > 0 ? 1 : 0;
     const int r_pad = round_up(2 * c->m, NB);
     const int gx = ceil_div(c->ldw / 4, 256), ny = r_pad / 2;
     InnovRide ir{};
@@ -2003,12 +2008,12 @@ int launch_ell_HP_build(pre3_ctx *c, void *dst, const int32_t *need, int need_ta
         ir = InnovRide{ rows * gx, c->N, c->ld, (int)(c->flags_bytes / sizeof(int32_t)), c->lm.type, c->lm.off, c->lm.has_h, c->P, c->lm.Hc, c->lm.Hl,
                         c->lm.S, c->lm.has_S, (int32_t *)((unsigned char *)c->inbox_dev + c->off_flags) };
     }
-    dim3 g(gx, ny + (ir.n_blocks ? ir.n_blocks / gx : 0)), b(256);
+    dim3 g(gx, ny + (ir.n_blocks ? ir.n_blocks / gx : 0) + ib_rows), b(256);
     DISPATCH_T(c,
         hipLaunchKernelGGL(k_ell_HP_build<double>, g, b, 0, c->stream, c->m, r_pad, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl, c->lm.z, c->lm.h,
-                           c->row_col, (double *)c->row_val, c->row_nu, (const double *)c->P, c->ld, (double *)dst, c->ldw, need, need_tag, ny, ir),
+                           c->row_col, (double *)c->row_val, c->row_nu, (const double *)c->P, c->ld, (double *)dst, c->ldw, need, need_tag, ny, ir, (const int32_t *)nullptr, ib),
         hipLaunchKernelGGL(k_ell_HP_build<float>, g, b, 0, c->stream, c->m, r_pad, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl, c->lm.z, c->lm.h,
-                           c->row_col, (float *)c->row_val, c->row_nu, (const float *)c->P, c->ld, (float *)dst, c->ldw, need, need_tag, ny, ir));
+                           c->row_col, (float *)c->row_val, c->row_nu, (const float *)c->P, c->ld, (float *)dst, c->ldw, need, need_tag, ny, ir, (const int32_t *)nullptr, ib));
     PRE3_HIP(hipGetLastError());
     if (ir.n_blocks) { c->ride_innovation = false; c->innovated = true; }
     return PRE3_OK;
