@@ -8,20 +8,26 @@
 //          M_J = inv(L_JJ) falls out of the same lock-step solve;  then, on the bf16 matrix cores from planes in LDS,
 //          L(J+1,J) = A(J+1,J) M_J' and D_{J+1} = A(J+1,J+1) - L(J+1,J) L(J+1,J)'.  Nothing on this path waits for another workgroup:
 //          the two tiles of row J+1 it needs (updated through panel J-1) are fetched by its two side waves WHILE the chain of panel J
-//          runs, and M_J / L(J+1,J) leave as bf16 planes through the same side waves.
+//          runs, and M_J / L(J+1,J) leave as bf16 planes through the same side waves.  (Round 5: the first product is computed transposed and
+//          its accumulators become the result's plane granules by v_permlane32_swap, with no trip through LDS; the second product runs as the
+//          next chain's first act on the waves that are that chain's D workers, and D_{J+1} never leaves their accumulators.)
 //   row i  (blocks 1.., i >= 2, 4 waves)  for J = 0 .. i-2:  L(i,J) = A(i,J) M_J' once M_J is published, then A(i,k) -= L(i,J) L(k,J)'
 //          for k = J+1 .. i.  After panel i-2 the row's two leading tiles go to crit (A(i,i-1) as planes, A(i,i) as f32).
 //   strip s (32 columns of [HP | nu], 4 waves)  for J = 0 .. nrb-1:  W_J = M_J (HP_J - sum_{K<J} L(J,K) W_K), the W_K as bf16 planes in
-//          LDS; epilogue: W in f32 and as the bf16 planes k_downdate_b3 reads (sc1 stores, then the strip's flag for panel J).
+//          LDS; epilogue: W in f32 and as the bf16 planes k_downdate_b3 reads (sc1 stores, then the strip's flag for panel J).  Behind the last
+//          panel the strips finish the state (x-update) and -- inside pre3_step -- project every landmark at x_k_k for the rescue stage
+//          (strip_proj_body), in the shadow of the consumers' epilogue.
 //   down-date consumer g (the CUs the factorisation leaves idle; round 4)  up to twelve 64 x 64 tiles of P's upper triangle, one per wave,
 //          accumulators resident for the whole launch: for J = 0 .. nrb-1, as soon as the strips that own the group's column blocks have
 //          published W_J, the panel's planes come in by LDS-DMA and acc += W_J' W_J (update.m:37 is a sum over panels); P is read, down-dated
 //          and written (with its mirror image) once, behind the last panel.  Same products in the same order as k_downdate_b3: bit-identical.
+//          The tiles of block row 0 also leave rows 3..6 -- before update.m:42-46 -- in a side buffer for the chi2 gate that rides with that pass
+//          (jn_q; GateRide, pre3_geom.hip).
 //
 // Every hand-off is: payload by 16-byte sc1 (write-through) stores, each storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier,
 // ONE lane stores the flag (agent scope); consumer: one lane polls the flag (sc1), workgroup barrier, then every load of the payload
-// is an sc1 buffer load (crit, rows) or a plain load behind ONE agent-scope acquire (strips: they are not latency critical and
-// share the planes through their XCD's L2).  Flags are monotonic words tagged with a per-launch epoch; every wait is bounded
+// is an sc1 buffer load (crit, rows, and since round 5 the strips' fragments of L) or a plain load behind ONE agent-scope acquire (consumers:
+// they share the planes through their XCD's L2).  Flags are monotonic words tagged with a per-launch epoch; every wait is bounded
 // (guard word stats[7], as in pre3_geomdev.h) and no access depends on a value that a give-up would leave undefined.
 #include <algorithm>
 #include <atomic>
