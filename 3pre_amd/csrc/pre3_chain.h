@@ -132,10 +132,12 @@ constexpr int CH_MB = 8, CH_NSP = NB / CH_MB, CH_NTH = 640;
 template <typename T> struct ChLs { static constexpr int STRIDE = sizeof(T) == 4 ? NB + 4 : NB + 2; };   // rows 16-byte aligned
 template <typename T>
 struct ChPipe {
-    __attribute__((aligned(16))) T Pn[2][NB][CH_MB];   // published sub-panel columns: Pn[par][i][t] = A[i][C+t], updated through sub-panel s-2
+    __attribute__((aligned(16))) T Pn[3][NB][CH_MB];   // (the lock-step chain uses two slots, the flag-driven one up to three) published sub-panel columns: Pn[par][i][t] = A[i][C+t], updated through sub-panel s-2
     __attribute__((aligned(16))) T Zt[2][NB][CH_MB];   // final X[C+t][i], transposed for the workers
     __attribute__((aligned(16))) T Xr[2][CH_MB][NB];   // published rows of X: Xr[par][t][i] = X[C+t][i]
     __attribute__((aligned(16))) T Rs[2][CH_MB];       // 1/sqrt(pivot) of the sub-panel's columns
+    __attribute__((aligned(16))) T RsA[CH_NSP][CH_MB]; // the flag-driven chain (pre3_chain_async.h): the factor wave runs ahead of the z wave, every sub-panel keeps its slot
+    unsigned fl[16];                                   // its progress counters
 };
 template <typename T>
 struct ChSmem {
