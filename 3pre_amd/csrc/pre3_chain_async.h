@@ -18,7 +18,7 @@
 // The z wave's lookahead takes its A operand from LDS in the same layout (lane l: row C + 4h + (l & 3)): 4 reads instead of 16.
 //
 // Waves: 0-3 D workers, 4-7 X workers, 8 z wave, 9 factor wave (the factor wave shares its SIMD with the dead D tile above the diagonal),
-// any further wave runs side(flags) once and joins the barrier behind the chain.
+// wave 1 (the slot of the dead D tile) and any wave >= 10 run side(flags) once and join the barrier behind the chain.
 #pragma once
 #include "pre3_chain.h"
 
@@ -35,12 +35,22 @@ __device__ __forceinline__ void cha_store(unsigned *p, unsigned v, int lane)
 }
 constexpr int CHA_SPIN = 1 << 16;      // x (one LDS round trip + s_sleep 1): a few milliseconds; a hand-off inside one workgroup takes well under a microsecond
 // wait until *p >= need (wave-uniform); false if the bound ran out (a hand-off that never comes: the caller raises the status flag and goes on)
+// a blocking read of one counter, as ONE opaque instruction pair: around the builtin atomic load the compiler also waits for every vector-memory
+// operation of the wave (s_waitcnt vmcnt(0) at the poll loop's head) -- the persistent kernel's publisher wave then stood ~900 clocks per poll behind its
+// own write-through stores (tools/probe_cholp.py, round 6)
+__device__ __forceinline__ unsigned cha_load_wait(const unsigned *p)
+{
+    unsigned v;
+    const unsigned addr = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned *)p;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
 // BUSY: no s_sleep between polls (the D workers: the factor wave's next sub-panel waits for what they publish)
 template <bool BUSY = false>
 __device__ __forceinline__ bool cha_wait(const unsigned *p, unsigned need)
 {
     for (int spin = 0; spin < CHA_SPIN; ++spin) {
-        if (__builtin_amdgcn_readfirstlane((int)cha_load(p)) >= (int)need) { asm volatile("" ::: "memory"); return true; }
+        if (__builtin_amdgcn_readfirstlane((int)cha_load_wait(p)) >= (int)need) return true;
         if (!BUSY) __builtin_amdgcn_s_sleep(1);
     }
     return false;
@@ -224,7 +234,7 @@ __device__ __forceinline__ void cha_xworker(ChSmem<T> &sm, typename ChW<T>::acc_
 
 // On entry Ls holds the (fully updated) diagonal block and Xs the workgroup's X block (hasX), or the worker waves carry their tiles in `acc`
 // (acc_loaded) / build them in worker_init; on exit Ls holds L_JJ and Xs[a][i] the solved block L_JJ^-1 X.  Barriers: one on entry (the counters
-// are reset in front of it), one on exit.  side(fl): run once by every wave >= 10 (the persistent kernel's publisher / fetcher waves), with the
+// are reset in front of it), one on exit.  side(fl): run once by wave 1 and every wave >= 10 (the persistent kernel's publisher / fetcher waves), with the
 // counters to poll: fl[CHF_F] = columns 0 .. 8 fl - 1 of L are final in Ls, fl[CHF_Z] = rows 0 .. 8 fl - 1 of the solved block are final in Xs.
 // XTRI: the X block starts as the identity (the persistent kernel's crit: M = L^-1 is lower triangular): its tile above the diagonal stays zero, no wave works on it.
 template <typename T, bool RELAX = false, bool XTRI = false, typename Side = ChaNoSide, typename WInit = ChNoInit>
@@ -239,7 +249,7 @@ __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>:
     unsigned *fl = sm.pipe.fl;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int role = wave == 9 ? 0 : wave == CHA_ZWAVE ? 1 : wave < 8 ? 2 : 3;        // 0: factor wave, 1: z wave (the slot of the dead D tile: it shares the factor wave's SIMD, whose matrix core no 32 x 32 product occupies), 2: worker, 3: side wave (8, 10, 11)
+    const int role = wave == 9 ? 0 : wave == CHA_ZWAVE ? 1 : (wave < 8 && wave != 1) ? 2 : 3;        // 0: factor wave, 1: z wave (the slot of the dead D tile: it shares the factor wave's SIMD, whose matrix core no 32 x 32 product occupies), 2: worker, 3: side wave (8, 10, 11)
     const bool worker = role == 2, xside = wave >= 4 && wave < 8;
     const int wv = wave & 3;
     const bool tile_live = worker && (xside ? (hasX && !(XTRI && wv == 1)) : wv != 1);
@@ -254,12 +264,15 @@ __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>:
     } else if (worker && acc_loaded) {
         worker_init(acc, xside, wv);
     }
-    __syncthreads();                                  // counters reset; the raw tiles are in registers (the hand-off buffers alias the prologue's operand tiles)
+    // (raw barriers: only this wave's LDS operations are waited for.  __syncthreads() would also wait for every vector-memory operation in flight --
+    //  the persistent kernel's publisher wave arrives with write-through stores on their way, 1-1.4 us each way)
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();                     // counters reset; the raw tiles are in registers (the hand-off buffers alias the prologue's operand tiles)
 #ifdef CHA_F_ONLY
-    if (role != 0) { __syncthreads(); return; }
+    if (role != 0) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); return; }
 #endif
 #ifdef CHA_NO_X
-    if (role == 1 || xside) { __syncthreads(); return; }
+    if (role == 1 || xside) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); return; }
 #endif
     if (worker) {
         if (tile_live) {
@@ -524,7 +537,9 @@ __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>:
         side(fl);
     }
     if (role <= 1) __builtin_amdgcn_s_setprio(0);
-    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
 }  // namespace pre3

@@ -36,6 +36,7 @@
 #include "pre3_internal.h"
 #include "pre3_geomdev.h"
 #include "pre3_chain.h"
+#include "pre3_chain_async.h"
 #include "pre3_cholp.h"
 
 namespace pre3 {
@@ -570,6 +571,205 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
     }
 }
 
+#ifndef PRE3_CRIT_ASYNC
+#define PRE3_CRIT_ASYNC 1            // crit runs the flag-driven chain (pre3_chain_async.h); 0: the lock-step chain of rounds 2-5 (crit_main / crit_side)
+#endif
+// Round 6: crit on the flag-driven chain.  All twelve waves run ONE panel loop; per panel: [products of the previous panel: D_{J+1} into Ls, X := I]
+// -> barrier -> chain (waves 0-9) beside the publisher (wave 10: columns of L_JJ to S and rows of M_J to planes as the factor / z wave finish
+// them) and the fetcher (wave 11: row J+1's two tiles by LDS-DMA; it may now block on memory -- no barrier waits for it until the chain is over)
+// -> barrier (b0) -> first product L(J+1, J) = A M_J' (waves 0-3), M_J's flag (wave 10) -> barrier (b2) -> L(J+1, J)'s planes leave (wave 10).
+__device__ __forceinline__ void crit_loop_async(const CpArgs &a, int nrb, CritSmem &sm)
+{
+    auto &Ls = sm.ch.Ls; auto &Xs = sm.ch.Xs;
+    float *T2 = &sm.ch.Bs[0][0];                                 // A(J+1, J+1), f32 [64][64]
+    const int tid0 = threadIdx.x;
+    const int lds = nrb * NB;
+    const __amdgpu_buffer_rsrc_t rSp = cp_rsrc(a.Sp);
+    int32_t *guard = a.status + 1;
+    bool bad = false;
+    for (int pass = 0; pass < 2; ++pass) {
+    const int j0 = pass == 0 ? 0 : nrb, j1 = pass == 0 ? nrb : nrb + 1;
+    bool loaded = false;                                         // false: the pass's first panel, Ls / Xs hold the block and the identity
+    for (int J = j0; J < j1; ++J) {
+        const bool more = J + 1 < j1;
+        if (tid0 == 0) { CP_STAMP(0, J, 0); CP_CLK(19, J, 0); }
+        // rows 8 sp .. 8 sp + 7 of M_J (final once the z wave has passed them) -> planes in LDS (the first product's operand) and in Sp(J, J) (the rows'
+        // and strips'): one wave, 8 consecutive c of one row per lane
+        auto publish_m = [&](unsigned *fl, const int sp) {
+            int tq = threadIdx.x;
+            asm volatile("" : "+v"(tq));
+            const int lane = tq & 63;
+            if (!cha_wait(fl + CHF_Z, (unsigned)(sp + 1))) bad = true;
+            const int arow = 8 * sp + (lane >> 3), cg = lane & 7;
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = Xs[arow][8 * cg + j];
+            u32x4_t p0, p1, p2;
+            b3_split3(x, p0, p1, p2);
+            const int q = cg >> 1, h = cg & 1, half = arow >> 5, r = arow & 31;
+            const int gi = q * 384 + half * 64 + 32 * h + r;
+            sm.MPl[gi] = __builtin_bit_cast(frag_t, p0); sm.MPl[gi + 128] = __builtin_bit_cast(frag_t, p1); sm.MPl[gi + 256] = __builtin_bit_cast(frag_t, p2);
+            const unsigned gb = ((unsigned)(J * a.sp_stride + J) * B3_SGRAN + gi) * 16u;
+            st16_sc1(p0, rSp, gb); st16_sc1(p1, rSp, gb + 128 * 16); st16_sc1(p2, rSp, gb + 256 * 16);
+        };
+        {
+            typename ChW<float>::acc_t acc[ChW<float>::NBLK][ChW<float>::NBLK];
+            chol_chain_async<float, true, true>(sm.ch, acc, loaded, true, bad,
+                [&](unsigned *fl) {
+                    int tq = threadIdx.x;
+                    asm volatile("" : "+v"(tq));
+                    const int wave = __builtin_amdgcn_readfirstlane(tq >> 6), lane = tq & 63;
+                    if (wave == 1) {
+                        // columns 8 sp .. 8 sp + 7 of L_JJ (zero above the diagonal) to S as the factor wave finishes them: part of the final factor (k_gain;
+                        // not read again in this launch).  (The HI panel's factor is not part of S.)
+                        if (J < nrb) {
+                            __builtin_amdgcn_s_setprio(1);
+#pragma unroll 1
+                            for (int sp = 0; sp < CH_NSP; ++sp) {
+                                if (!cha_wait(fl + CHF_F, (unsigned)(sp + 1))) bad = true;
+                                const int i = lane, C = 8 * sp;
+#pragma unroll
+                                for (int u = 0; u < 2; ++u) {
+                                    const int c4 = C + 4 * u;
+                                    f4v_t w = *reinterpret_cast<const f4v_t *>(&Ls[i][c4]);
+                                    w.x = c4 <= i ? w.x : 0.f; w.y = c4 + 1 <= i ? w.y : 0.f; w.z = c4 + 2 <= i ? w.z : 0.f; w.w = c4 + 3 <= i ? w.w : 0.f;
+                                    *reinterpret_cast<f4v_t *>(a.S + (size_t)(J * NB + i) * lds + J * NB + c4) = w;
+                                }
+                                if ((sp & 1) && sp < CH_NSP - 1) publish_m(fl, sp);     // (rows of M_J: sub-panels 1, 3, 5 here, the others on wave 10)
+                            }
+                            __builtin_amdgcn_s_setprio(0);
+                        } else {
+                            for (int sp = 1; sp < CH_NSP - 1; sp += 2) publish_m(fl, sp);
+                        }
+                        // this wave's planes of M_J must be out before wave 10 raises M_J's flag (behind the chain's last barrier): they left at least
+                        // two sub-panels ago, the wait is normally over when it starts
+                        drain_stores();
+                    } else if (wave == 10) {
+                        // L(J, J-1)'s planes (stored behind the last products) have drained: row J's flag
+                        if (J > 0 && J < nrb) {
+                            drain_stores();
+                            if (lane == 0) cf_store(cf_rowL(a.cf, J), a.base + (unsigned)J);
+                            CP_STAMP(1, J, 5);
+                        }
+                        __builtin_amdgcn_s_setprio(1);
+#pragma unroll 1
+                        for (int sp = 0; sp < CH_NSP; sp += 2) publish_m(fl, sp);
+                        publish_m(fl, CH_NSP - 1);
+                        __builtin_amdgcn_s_setprio(0);
+                        // M_J is out once these stores have drained (the flag goes up behind the chain's last barrier, in the shadow of the first product)
+                    } else if (wave == 11 && more && J > 0) {
+                        // row J+1's two tiles (published by its row workgroup: flag = base + 2 once both are out).  (panel 0's came with the prologue)
+                        const int fr = J + 1;
+                        const unsigned *fflag = cf_rowA(a.cf, fr < 64 ? fr : 63);
+                        bool gave_up = true;
+                        for (int spin = 0; spin < SPIN_LIMIT; ++spin) {
+                            if (cf_reached(cf_load(fflag), a.base + 2)) { gave_up = false; break; }
+                            if ((spin & 1023) == 1023 && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { gave_up = false; break; }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        if (gave_up && lane == 0) atomicExch(guard, 1);
+                        CP_STAMP(1, J, 0);
+                        const frag_t *src1 = static_cast<const frag_t *>(a.Tp) + (size_t)fr * B3_SGRAN + lane;
+#pragma unroll
+                        for (int t = 0; t < 24; ++t)
+                            __builtin_amdgcn_global_load_lds(src1 + t * 64, (__attribute__((address_space(3))) void *)(sm.T1p + t * 64), 16, 0, 16);
+                        // A(fr, fr): 1024 granules of 4 floats; granule g = t * 64 + lane -> row g >> 4, columns 4 (g & 15); LDS image [64][64]
+                        const float *src2 = a.S + (size_t)(fr * NB + (lane >> 4)) * lds + fr * NB + (lane & 15) * 4;
+#pragma unroll
+                        for (int t = 0; t < 16; ++t)
+                            __builtin_amdgcn_global_load_lds(src2 + (size_t)(4 * t) * lds, (__attribute__((address_space(3))) void *)(T2 + (t * 64) * 4), 16, 0, 16);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        CP_STAMP(1, J, 3);
+                    }
+                },
+                [&](typename ChW<float>::acc_t (&ac)[ChW<float>::NBLK][ChW<float>::NBLK], const bool xside, const int) {
+                    int tq = threadIdx.x;
+                    asm volatile("" : "+v"(tq));
+                    const int lane = tq & 63, wv = (tq >> 6) & 3, fa = (wv >> 1) & 1, fb = wv & 1;
+                    if (xside) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) ac[0][0][e] = (fa == fb && acc_row(e, lane) == (lane & 31)) ? 1.f : 0.f;
+                    } else if (wv != 1 && (tq >> 6) < 4) {
+                        // B2: D_{J+1} = A(J+1, J+1) - L(J+1, J) L(J+1, J)' -> this wave's tile of Ls (the chain's D workers read their tiles from there)
+                        const frag_t *LP = crit_lp(sm);
+                        frag_t fB[4][3];
+                        frags_lds(LP, fb, lane, fB);
+                        float t2[16];
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) t2[e] = T2[(32 * fa + acc_row(e, lane)) * NB + 32 * fb + (lane & 31)];
+                        f32x16_t c2;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) c2[e] = 0.f;
+                        mma6_alds(LP, fa, lane, fB, c2);
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) Ls[32 * fa + acc_row(e, lane)][32 * fb + (lane & 31)] = t2[e] - c2[e];
+                        if (threadIdx.x == 0) CP_STAMP(0, J - 1, 6);
+                    }
+                });
+        }
+        // (the chain's last barrier = b0: Ls = L_JJ, Xs = M_J, MPl complete, T1p / T2 landed)
+        if (tid0 == 0) { CP_STAMP(0, J, 1); CP_CLK(19, J, 1); CP_STAMP(0, J, 2); }
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int wave = tid >> 6, lane = tid & 63, fa = (wave >> 1) & 1, fb = wave & 1;
+        if (wave == 10) {
+            // M_J's last planes have left with the publisher's loop: drained -> the flag, in the shadow of the first product
+            drain_stores();
+            if (lane == 0) cf_store(a.cf + CF_MP, a.base + (unsigned)J + 1);
+            CP_STAMP(1, J, 4);
+        }
+        if (!more) break;
+        frag_t *LP = crit_lp(sm);
+        if (wave < 4) {
+            // B1, transposed (as crit_main): L(J+1, J)'(a, i) = sum_c M_J(a, c) A(J+1, J)(i, c)
+            frag_t fB[4][3];
+            frags_lds(sm.T1p, fa, lane, fB);
+            f32x16_t c1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) c1[e] = 0.f;
+            mma6_alds(sm.MPl, fb, lane, fB, c1);
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float lo = c1[8 * g2 + j], hi = c1[8 * g2 + 4 + j];
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+                    const unsigned s0 = sw[0], s1 = sw[1];
+                    x[j] = __uint_as_float(s0); x[4 + j] = __uint_as_float(s1);
+                }
+                u32x4_t p0, p1, p2;
+                b3_split3(x, p0, p1, p2);
+                const int gi = (2 * fb + g2) * 384 + fa * 64 + lane;
+                LP[gi] = __builtin_bit_cast(frag_t, p0); LP[gi + 128] = __builtin_bit_cast(frag_t, p1); LP[gi + 256] = __builtin_bit_cast(frag_t, p2);
+                float *sr = a.S + (size_t)((J + 1) * NB + 32 * fa + (lane & 31)) * (nrb * NB) + J * NB + 32 * fb + 16 * g2 + 8 * (lane >> 5);
+                *reinterpret_cast<f4v_t *>(sr) = f4v_t{ x[0], x[1], x[2], x[3] };
+                *reinterpret_cast<f4v_t *>(sr + 4) = f4v_t{ x[4], x[5], x[6], x[7] };
+            }
+            if (tid0 == 0) CP_STAMP(0, J, 7);
+        }
+        __syncthreads();                                                            // b2: LP = planes of L(J+1, J)
+        if (tid0 == 0) { CP_STAMP(0, J, 5); CP_STAMP(0, J, 3); }
+        if (wave == 10) {
+            // L(J+1, J) leaves as planes; the flag follows at the start of the next chain, once these stores have drained
+#pragma unroll
+            for (int b8 = 0; b8 < 3; ++b8) {
+                frag_t g8[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) g8[t] = LP[(b8 * 8 + t) * 64 + lane];
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    st16_sc1(__builtin_bit_cast(u32x4_t, g8[t]), rSp, ((unsigned)((J + 1) * a.sp_stride + J) * B3_SGRAN + (b8 * 8 + t) * 64 + lane) * 16u);
+            }
+            CP_STAMP(1, J, 6);
+        }
+        loaded = true;
+    }
+    if (pass == 1 || !a.tail || crit_tail(nrb) == 0) break;
+    }
+    if (bad) atomicExch(a.status, 1);
+}
+
 // what crit keeps behind CritSmem (and a strip behind its plane slots) of the rescue stage's outcome
 struct TailSmem {
     int cnt, r_hi, pad[2];
@@ -586,8 +786,12 @@ __device__ __forceinline__ void crit_body(const CpArgs &a, int nrb, unsigned cha
 {
     CritSmem &sm = *reinterpret_cast<CritSmem *>(smem_raw);
     crit_prologue(a, nrb, sm);
+#if PRE3_CRIT_ASYNC
+    crit_loop_async(a, nrb, sm);
+#else
     if (threadIdx.x < 640) crit_main(a, nrb, sm);
     else crit_side(a, nrb, sm);
+#endif
     if (a.tail) {
         const CpTail t = args_from_lds<CpTail>(CP_T_OFF);
         // the rescue flags in measurement order (rescue_hi_inliers.m:44-46 as pre3_get_flags reports it): off the rescue stage's path
@@ -2450,6 +2654,13 @@ extern "C" __attribute__((visibility("default"))) int pre3_debug_cholp(unsigned 
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cp), sizeof(unsigned long long) * 24 * 16 * 8) == hipSuccess ? 0 : -3;
 }
+// the flag-driven chain's per-role stamps of crit's LAST chain (pre3_chain_async.h: [role 8][step 12][slot 4], shader clocks)
+#ifdef PRE3_PROBE_CHA
+extern "C" __attribute__((visibility("default"))) int pre3_debug_cha(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cha), sizeof(unsigned long long) * 8 * 12 * 4) == hipSuccess ? 0 : -3;
+}
+#endif
 #endif
 
 }  // namespace pre3

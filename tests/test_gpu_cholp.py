@@ -80,8 +80,10 @@ def test_update_sizes_from_one_row_pair_to_thirteen_panels(pre3, orc, n_rows_mea
     (xp, Pp, _, meas, z), (xl, Pl, _, _, _) = res
     scale = np.abs(Pl).max()
     assert np.isfinite(Pp).all()
-    # (the two forms differ by fp32 rounding of the update: 1e-4 of P's scale up to 13 panels, 2e-4 for the 16 panels of 500 measured landmarks, outliers included)
-    assert np.abs(Pp - Pl).max() < (1e-4 if n_rows_meas <= 416 else 2e-4) * scale, (n_rows_meas, np.abs(Pp - Pl).max() / scale)
+    # (the two forms differ by fp32 rounding of the update: 1.5e-4 of P's scale up to 13 panels, 2e-4 for the 16 panels of 500 measured landmarks, outliers included.
+    #  Round 6: the persistent form's chain also sums its lookahead in another order -- matrix-core fma chain instead of pair sums --, 1.12e-4 at 13 panels
+    #  where it was 0.9e-4; each form's distance from the fp64 twin, the parity claim, is the 3e-4 below and in profiles/r6_form_diff.txt)
+    assert np.abs(Pp - Pl).max() < (1.5e-4 if n_rows_meas <= 416 else 2e-4) * scale, (n_rows_meas, np.abs(Pp - Pl).max() / scale)
     assert np.abs(xp - xl).max() < 1e-5
     # ... and against update.m's restatement in fp64 (the numpy twin: explicit inv(S), K S K', 0.5 (P + P'), Jnorm rebuild)
     from oracle import np_twin as tw

@@ -56,3 +56,18 @@ print("down-date consumers (first / last group), per J: flags seen, panel's MFMA
 for J in range(min(nrb, 16)):
     print("  J=%2d  %s %s | %s %s" % (J, rel(t[20, J, 0]), rel(t[20, J, 1]), rel(t[21, J, 0]), rel(t[21, J, 1])))
 print("  epilogue start / end: %s %s | %s %s" % (rel(t[20, 15, 0]), rel(t[20, 15, 1]), rel(t[21, 15, 0]), rel(t[21, 15, 1])))
+
+# round 6: per-role stamps of crit's last chain (flag-driven form)
+if hasattr(lib, "pre3_debug_cha"):
+    g = (C.c_ulonglong * (8 * 12 * 4))()
+    lib.pre3_debug_cha(g)
+    a = np.array(g[:], dtype=np.int64).reshape(8, 12, 4)
+    t0 = a[0, 1, 0] if a[0, 1, 0] > 0 else a[a > 0].min()
+    Jl = nrb - 1
+    print("  last panel: chain start (all waves enter) -> factor wave's first stamp %d clocks; z wave's last stamp -> chain end (behind its last barrier) %d clocks" % (t0 - int(raw[19, Jl, 0]), int(raw[19, Jl, 1]) - int(a[1, 8, 3])))
+    print("flag-driven chain, crit's last panel (shader clocks after the factor wave's first stamp): per step k = -1 .. 8 the four slots")
+    for r, name in enumerate(["F", "z", "D0", "D2", "D3", "X0", "w10", "X2"]):
+        row = []
+        for k in range(10):
+            row.append(" ".join("%6d" % (v - t0) if v > 0 and abs(v - t0) < 200000 else "     -" for v in a[r, k]))
+        print("  %-3s | %s" % (name, " | ".join(row)))
