@@ -20,12 +20,13 @@
 // Waves: 0-3 D workers, 4-7 X workers, 8 z wave, 9 factor wave (the factor wave shares its SIMD with the dead D tile above the diagonal),
 // wave 1 (the slot of the dead D tile) and any wave >= 10 run side(flags) once and join the barrier behind the chain.
 #pragma once
+#include <type_traits>
 #include "pre3_chain.h"
 
 namespace pre3 {
 
 // progress counters (LDS words inside ChPipe): F / Z = sub-panels finished; D[w] / X[w] = pipeline steps finished by worker w (+2 / +1: see below)
-enum { CHF_F = 0, CHF_Z = 1, CHF_D0 = 2, CHF_X0 = 6, CHF_N = 10 };
+enum { CHF_F = 0, CHF_Z = 1, CHF_D0 = 2, CHF_X0 = 6, CHF_DI0 = 10 /* + WV: D worker WV has its whole tile in registers (DInit's sources may be overwritten) */, CHF_N = 14 };
 
 __device__ __forceinline__ unsigned cha_load(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void cha_store(unsigned *p, unsigned v, int lane)
@@ -58,7 +59,11 @@ __device__ __forceinline__ bool cha_wait(const unsigned *p, unsigned need)
 
 #ifdef PRE3_PROBE_CHA
 static __device__ unsigned long long g_cha[8 * 12 * 4];         // [role: 0 F, 1 z, 2 D0, 3 D2, 4 D3, 5 X0 .. 7 X2(sic: X2 = wave 6)][step + 1][slot]
+#if PRE3_PROBE_CHA == 2        // lite: the factor and z waves' first and last stamps only (every stamp waits for the wave's LDS operations: the full set stretches the chain by a quarter)
+#define CHA_STAMP(role, k, slot) do { if ((role) <= 1 && (((k) == 0 && (slot) == 0) || ((k) == 7 && (slot) == 3)) && (threadIdx.x & 63) == 0) g_cha[((role) * 12 + (k) + 1) * 4 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
 #define CHA_STAMP(role, k, slot) do { if ((threadIdx.x & 63) == 0) g_cha[((role) * 12 + (k) + 1) * 4 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #else
 #define CHA_STAMP(role, k, slot)
 #endif
@@ -99,8 +104,15 @@ template <> struct MfmaD<float> {
 
 // D worker wave WV (tile (WV >> 1, WV & 1) of the diagonal block, read from Ls on entry: the caller's raw / pre-updated block), pipeline step k
 // (-LA .. NSP-1-LA): D -= Y(k-1) Y(k-1)' where the tile still has columns >= 8(k+LA), sub-panel k+LA published as soon as its blocks are done
-template <typename T, int WV>
-__device__ __forceinline__ void cha_dworker(ChSmem<T> &sm, const int lane, bool &bad)
+// DInit: where a D worker's 16 x 16 blocks come from.  Default: the diagonal block in Ls.  The persistent kernel's crit computes them there and then
+// (D_{J+1} = A - L L' on the bf16 matrix cores, block column 0 first): sub-panels 0 and 1 are published -- and the factor wave starts -- while the
+// second block column is still being multiplied.
+struct ChaFromLs {
+    static constexpr bool from_ls = true;
+    template <typename ACC> __device__ __forceinline__ void operator()(ACC &, ACC &, bool, bool, int, int, int) const {}
+};
+template <typename T, int WV, typename DInit>
+__device__ __forceinline__ void cha_dworker(ChSmem<T> &sm, const int lane, bool &bad, DInit &&dinit)
 {
     using M = MfmaD<T>;
     constexpr int NBLK = 32 / M::BLK, NJ = CH_MB / M::KS, MB = CH_MB, NSP = CH_NSP, w0 = (WV >> 1) * 32, w1 = (WV & 1) * 32;
@@ -109,19 +121,27 @@ __device__ __forceinline__ void cha_dworker(ChSmem<T> &sm, const int lane, bool 
     const int cl = M::col(lane), kq = M::kk(lane) * NJ;
     unsigned *fl = sm.pipe.fl;
     acc_t acc[NBLK][NBLK];
+    constexpr bool from_ls = std::remove_reference<DInit>::type::from_ls;
+    auto load_q = [&](const int q) {
+        // (NBLK = 2: both row blocks of the block column at once -- DInit interleaves their matrix-core chains)
+        const bool live0 = !(w0 + M::BLK - 1 < w1 + q * M::BLK), live1 = !(w0 + 2 * M::BLK - 1 < w1 + q * M::BLK);
+        if constexpr (from_ls) {
 #pragma unroll
-    for (int p = 0; p < NBLK; ++p)
+            for (int p = 0; p < NBLK; ++p)
 #pragma unroll
-        for (int q = 0; q < NBLK; ++q)
-#pragma unroll
-            for (int e = 0; e < M::NREG; ++e)
-                acc[p][q][e] = (w0 + (p + 1) * M::BLK - 1 < w1 + q * M::BLK) ? (T)0 : sm.Ls[w0 + p * M::BLK + M::row(lane, e)][w1 + q * M::BLK + cl];     // (a block above the diagonal is never read)
+                for (int e = 0; e < M::NREG; ++e)
+                    acc[p][q][e] = (p == 0 ? live0 : live1) ? sm.Ls[w0 + p * M::BLK + M::row(lane, e)][w1 + q * M::BLK + cl] : (T)0;      // (a block above the diagonal is never read)
+        } else dinit(acc[0][q], acc[1][q], live0, live1, w0, w1 + q * M::BLK, lane);
+    };
+    load_q(0);
+    if constexpr (from_ls || w1 != 0) { load_q(1); cha_store(fl + CHF_DI0 + WV, 1u, lane); }      // (a tile whose first columns are sub-panel 0's publishes them before it takes up its second block column)
     // (the tile is in registers before this wave publishes anything, and the factor wave writes a column of Ls only after it has been published)
 #pragma unroll
     for (int k = -CHA_LA; k <= NSP - 1 - CHA_LA; ++k) {
         const int c_first = MB * (k + CHA_LA);                             // first column the workers still own at this step; also the sub-panel to publish
         const bool upd = k >= 1 && w1 + 32 > c_first;
         const bool pub = c_first >= w1 && c_first < w1 + 32;
+        if constexpr (!from_ls && w1 == 0) { if (k == 1 - CHA_LA + 1) { load_q(1); cha_store(fl + CHF_DI0 + WV, 1u, lane); } }      // (behind the publication of sub-panels 0 and 1 = the columns of block column 0)
         if (!upd && !pub) continue;
         const int qs = pub ? (c_first - w1) / M::BLK : 0, c8 = pub ? (c_first - w1) % M::BLK : 0, par = (k + CHA_LA) % (CHA_LA + 1);
         auto publish = [&]() {
@@ -237,9 +257,9 @@ __device__ __forceinline__ void cha_xworker(ChSmem<T> &sm, typename ChW<T>::acc_
 // are reset in front of it), one on exit.  side(fl): run once by wave 1 and every wave >= 10 (the persistent kernel's publisher / fetcher waves), with the
 // counters to poll: fl[CHF_F] = columns 0 .. 8 fl - 1 of L are final in Ls, fl[CHF_Z] = rows 0 .. 8 fl - 1 of the solved block are final in Xs.
 // XTRI: the X block starts as the identity (the persistent kernel's crit: M = L^-1 is lower triangular): its tile above the diagonal stays zero, no wave works on it.
-template <typename T, bool RELAX = false, bool XTRI = false, typename Side = ChaNoSide, typename WInit = ChNoInit>
+template <typename T, bool RELAX = false, bool XTRI = false, typename Side = ChaNoSide, typename WInit = ChNoInit, typename DInit = ChaFromLs>
 __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>::acc_t (&acc)[ChW<T>::NBLK][ChW<T>::NBLK], const bool acc_loaded,
-                                                 const bool hasX, bool &bad, Side &&side = ChaNoSide{}, WInit &&worker_init = ChNoInit{})
+                                                 const bool hasX, bool &bad, Side &&side = ChaNoSide{}, WInit &&worker_init = ChNoInit{}, DInit &&dinit = ChaFromLs{})
 {
     constexpr int MB = CH_MB, NSP = CH_NSP;
     typedef T v4_t __attribute__((ext_vector_type(4), aligned(16)));
@@ -282,9 +302,9 @@ __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>:
                 else if (wv == 2) cha_xworker<T, 2, RELAX>(sm, acc, lane, bad);
                 else cha_xworker<T, 3, RELAX>(sm, acc, lane, bad);
             } else {
-                if (wv == 0) cha_dworker<T, 0>(sm, lane, bad);
-                else if (wv == 2) cha_dworker<T, 2>(sm, lane, bad);
-                else cha_dworker<T, 3>(sm, lane, bad);
+                if (wv == 0) cha_dworker<T, 0>(sm, lane, bad, dinit);
+                else if (wv == 2) cha_dworker<T, 2>(sm, lane, bad, dinit);
+                else cha_dworker<T, 3>(sm, lane, bad, dinit);
             }
         }
     } else if (role == 0) {

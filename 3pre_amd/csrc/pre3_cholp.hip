@@ -571,6 +571,53 @@ __device__ __forceinline__ void crit_side(const CpArgs &a, int nrb, CritSmem &sm
     }
 }
 
+// The D workers' 16 x 16 blocks of the flag-driven chain in crit (pre3_chain_async.h, DInit).  First panel of a pass: the raw block is in Ls.  Otherwise
+// B2, D_{J+1} = A(J+1, J+1) - L(J+1, J) L(J+1, J)', block by block on v_mfma_f32_16x16x32_bf16 from the planes the first product left in LDS (LP: [k-step of
+// 16][plane][32-row half][lane] granules, lane = row & 31 + 32 (upper eight k)) and the f32 tile the fetcher brought (T2): six plane products per f32
+// product in k_downdate_b3's order, accumulated from zero and subtracted once.  The result lands in the layout the chain's D workers keep (row 4 (lane >> 4)
+// + reg, column lane & 15): no trip through LDS, and the block column that holds sub-panels 0 and 1 is done -- and published -- first.
+struct CritDInit {
+    static constexpr bool from_ls = false;
+    CritSmem *sm; bool loaded;
+    typedef float f4acc_t __attribute__((ext_vector_type(4)));
+    // the two 16 x 16 blocks (rows r0 .. r0+15 and r0+16 .. r0+31, columns c0 .. c0+15) of one block column; a block above the diagonal (live = false) is zero
+    __device__ __forceinline__ void operator()(f4acc_t &acc0, f4acc_t &acc1, const bool live0, const bool live1, const int r0, const int c0, const int lane) const
+    {
+        const int g = lane >> 4, cl = lane & 15;
+        if (!loaded) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc0[e] = live0 ? sm->ch.Ls[r0 + 4 * g + e][c0 + cl] : 0.f; acc1[e] = live1 ? sm->ch.Ls[r0 + 16 + 4 * g + e][c0 + cl] : 0.f; }
+            return;
+        }
+        const frag_t *LP = crit_lp(*sm);
+        const float *T2 = &sm->ch.Bs[0][0];
+        const int ra0 = r0 + cl, ra1 = r0 + 16 + cl, rb = c0 + cl;
+        float t20[4], t21[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { t20[e] = T2[(r0 + 4 * g + e) * NB + c0 + cl]; t21[e] = T2[(r0 + 16 + 4 * g + e) * NB + c0 + cl]; }
+        f4acc_t c0v = { 0.f, 0.f, 0.f, 0.f }, c1v = c0v;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int qq = 2 * kk + (g >> 1), kh = g & 1;
+            const frag_t *pa0 = LP + qq * 384 + (ra0 >> 5) * 64 + (ra0 & 31) + 32 * kh, *pa1 = LP + qq * 384 + (ra1 >> 5) * 64 + (ra1 & 31) + 32 * kh;
+            const frag_t *pb = LP + qq * 384 + (rb >> 5) * 64 + (rb & 31) + 32 * kh;
+            const frag_t b0 = pb[0], b1 = pb[128], b2 = pb[256];
+            const frag_t x0 = pa0[0], x1 = pa0[128], x2 = pa0[256], y0 = pa1[0], y1 = pa1[128], y2 = pa1[256];
+            // (two independent accumulate chains, interleaved: a dependent 16 x 16 x 32 product waits for its predecessor's result)
+#define CD_MMA(c, x, y) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, x), __builtin_bit_cast(bf16x8_t, y), c, 0, 0, 0)
+            if (live0) { CD_MMA(c0v, x0, b0); } CD_MMA(c1v, y0, b0);
+            if (live0) { CD_MMA(c0v, x0, b1); } CD_MMA(c1v, y0, b1);
+            if (live0) { CD_MMA(c0v, x1, b0); } CD_MMA(c1v, y1, b0);
+            if (live0) { CD_MMA(c0v, x1, b1); } CD_MMA(c1v, y1, b1);
+            if (live0) { CD_MMA(c0v, x0, b2); } CD_MMA(c1v, y0, b2);
+            if (live0) { CD_MMA(c0v, x2, b0); } CD_MMA(c1v, y2, b0);
+#undef CD_MMA
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc0[e] = live0 ? t20[e] - c0v[e] : 0.f; acc1[e] = t21[e] - c1v[e]; }
+    }
+};
+
 #ifndef PRE3_CRIT_ASYNC
 #define PRE3_CRIT_ASYNC 1            // crit runs the flag-driven chain (pre3_chain_async.h); 0: the lock-step chain of rounds 2-5 (crit_main / crit_side)
 #endif
@@ -645,19 +692,33 @@ __device__ __forceinline__ void crit_loop_async(const CpArgs &a, int nrb, CritSm
                         // two sub-panels ago, the wait is normally over when it starts
                         drain_stores();
                     } else if (wave == 10) {
-                        // L(J, J-1)'s planes (stored behind the last products) have drained: row J's flag
-                        if (J > 0 && J < nrb) {
-                            drain_stores();
-                            if (lane == 0) cf_store(cf_rowL(a.cf, J), a.base + (unsigned)J);
-                            CP_STAMP(1, J, 5);
-                        }
                         __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
                         for (int sp = 0; sp < CH_NSP; sp += 2) publish_m(fl, sp);
                         publish_m(fl, CH_NSP - 1);
                         __builtin_amdgcn_s_setprio(0);
                         // M_J is out once these stores have drained (the flag goes up behind the chain's last barrier, in the shadow of the first product)
-                    } else if (wave == 11 && more && J > 0) {
+                    } else if (wave == 11) {
+                        // L(J, J-1) leaves as planes (the first product of the panel before left them in LP: 24 granules per lane in three batches, the LDS
+                        // reads of a batch first) -- here, behind the chain's first barrier, which then does not wait for this wave's store instructions --;
+                        // once they have drained: row J's flag (the rows need it only after their own L(i, J-1))
+                        if (J > 0 && J < nrb) {
+                            const frag_t *LPs = crit_lp(sm);
+#pragma unroll
+                            for (int b8 = 0; b8 < 3; ++b8) {
+                                frag_t g8[8];
+#pragma unroll
+                                for (int t = 0; t < 8; ++t) g8[t] = LPs[(b8 * 8 + t) * 64 + lane];
+#pragma unroll
+                                for (int t = 0; t < 8; ++t)
+                                    st16_sc1(__builtin_bit_cast(u32x4_t, g8[t]), rSp, ((unsigned)(J * a.sp_stride + J - 1) * B3_SGRAN + (b8 * 8 + t) * 64 + lane) * 16u);
+                            }
+                            CP_STAMP(1, J - 1, 6);
+                            drain_stores();
+                            if (lane == 0) cf_store(cf_rowL(a.cf, J), a.base + (unsigned)J);
+                            CP_STAMP(1, J, 5);
+                        }
+                        if (more && J > 0) {
                         // row J+1's two tiles (published by its row workgroup: flag = base + 2 once both are out).  (panel 0's came with the prologue)
                         const int fr = J + 1;
                         const unsigned *fflag = cf_rowA(a.cf, fr < 64 ? fr : 63);
@@ -668,6 +729,8 @@ __device__ __forceinline__ void crit_loop_async(const CpArgs &a, int nrb, CritSm
                             __builtin_amdgcn_s_sleep(1);
                         }
                         if (gave_up && lane == 0) atomicExch(guard, 1);
+                        // (the D workers multiply D_{J+1} out of T2 behind the chain's first barrier: every one of them has its tile before T2 is overwritten)
+                        if (!cha_wait(fl + CHF_DI0 + 0, 1u) || !cha_wait(fl + CHF_DI0 + 2, 1u) || !cha_wait(fl + CHF_DI0 + 3, 1u)) bad = true;
                         CP_STAMP(1, J, 0);
                         const frag_t *src1 = static_cast<const frag_t *>(a.Tp) + (size_t)fr * B3_SGRAN + lane;
 #pragma unroll
@@ -680,6 +743,7 @@ __device__ __forceinline__ void crit_loop_async(const CpArgs &a, int nrb, CritSm
                             __builtin_amdgcn_global_load_lds(src2 + (size_t)(4 * t) * lds, (__attribute__((address_space(3))) void *)(T2 + (t * 64) * 4), 16, 0, 16);
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         CP_STAMP(1, J, 3);
+                        }
                     }
                 },
                 [&](typename ChW<float>::acc_t (&ac)[ChW<float>::NBLK][ChW<float>::NBLK], const bool xside, const int) {
@@ -689,23 +753,9 @@ __device__ __forceinline__ void crit_loop_async(const CpArgs &a, int nrb, CritSm
                     if (xside) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) ac[0][0][e] = (fa == fb && acc_row(e, lane) == (lane & 31)) ? 1.f : 0.f;
-                    } else if (wv != 1 && (tq >> 6) < 4) {
-                        // B2: D_{J+1} = A(J+1, J+1) - L(J+1, J) L(J+1, J)' -> this wave's tile of Ls (the chain's D workers read their tiles from there)
-                        const frag_t *LP = crit_lp(sm);
-                        frag_t fB[4][3];
-                        frags_lds(LP, fb, lane, fB);
-                        float t2[16];
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) t2[e] = T2[(32 * fa + acc_row(e, lane)) * NB + 32 * fb + (lane & 31)];
-                        f32x16_t c2;
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) c2[e] = 0.f;
-                        mma6_alds(LP, fa, lane, fB, c2);
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) Ls[32 * fa + acc_row(e, lane)][32 * fb + (lane & 31)] = t2[e] - c2[e];
-                        if (threadIdx.x == 0) CP_STAMP(0, J - 1, 6);
                     }
-                });
+                },
+                CritDInit{ &sm, loaded });
         }
         // (the chain's last barrier = b0: Ls = L_JJ, Xs = M_J, MPl complete, T1p / T2 landed)
         if (tid0 == 0) { CP_STAMP(0, J, 1); CP_CLK(19, J, 1); CP_STAMP(0, J, 2); }
@@ -748,21 +798,8 @@ __device__ __forceinline__ void crit_loop_async(const CpArgs &a, int nrb, CritSm
             }
             if (tid0 == 0) CP_STAMP(0, J, 7);
         }
-        __syncthreads();                                                            // b2: LP = planes of L(J+1, J)
+        // (no barrier of its own behind the first product: the next chain's first barrier orders LP for the D workers and the publisher)
         if (tid0 == 0) { CP_STAMP(0, J, 5); CP_STAMP(0, J, 3); }
-        if (wave == 10) {
-            // L(J+1, J) leaves as planes; the flag follows at the start of the next chain, once these stores have drained
-#pragma unroll
-            for (int b8 = 0; b8 < 3; ++b8) {
-                frag_t g8[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) g8[t] = LP[(b8 * 8 + t) * 64 + lane];
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-                    st16_sc1(__builtin_bit_cast(u32x4_t, g8[t]), rSp, ((unsigned)((J + 1) * a.sp_stride + J) * B3_SGRAN + (b8 * 8 + t) * 64 + lane) * 16u);
-            }
-            CP_STAMP(1, J, 6);
-        }
         loaded = true;
     }
     if (pass == 1 || !a.tail || crit_tail(nrb) == 0) break;

@@ -64,7 +64,7 @@ if hasattr(lib, "pre3_debug_cha"):
     a = np.array(g[:], dtype=np.int64).reshape(8, 12, 4)
     t0 = a[0, 1, 0] if a[0, 1, 0] > 0 else a[a > 0].min()
     Jl = nrb - 1
-    print("  last panel: chain start (all waves enter) -> factor wave's first stamp %d clocks; z wave's last stamp -> chain end (behind its last barrier) %d clocks" % (t0 - int(raw[19, Jl, 0]), int(raw[19, Jl, 1]) - int(a[1, 8, 3])))
+    print("  last panel: chain start (all waves enter) -> factor wave's first stamp %d clocks -> its last sub-panel written %d -> z wave's last sub-panel written %d -> chain end (behind its last barrier) %d clocks" % (t0 - int(raw[19, Jl, 0]), int(a[0, 8, 3]) - t0, int(a[1, 8, 3]) - int(a[0, 8, 3]), int(raw[19, Jl, 1]) - int(a[1, 8, 3])))
     print("flag-driven chain, crit's last panel (shader clocks after the factor wave's first stamp): per step k = -1 .. 8 the four slots")
     for r, name in enumerate(["F", "z", "D0", "D2", "D3", "X0", "w10", "X2"]):
         row = []
