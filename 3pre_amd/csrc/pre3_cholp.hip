@@ -581,8 +581,12 @@ struct CritDInit {
     CritSmem *sm; bool loaded;
     typedef float f4acc_t __attribute__((ext_vector_type(4)));
     // the two 16 x 16 blocks (rows r0 .. r0+15 and r0+16 .. r0+31, columns c0 .. c0+15) of one block column; a block above the diagonal (live = false) is zero
-    __device__ __forceinline__ void operator()(f4acc_t &acc0, f4acc_t &acc1, const bool live0, const bool live1, const int r0, const int c0, const int lane) const
+    __device__ __forceinline__ void operator()(f4acc_t &acc0, f4acc_t &acc1, const bool live0, const bool live1, const int r0, const int c0, const int lane_in) const
     {
+        // (the address arithmetic hangs off a fenced copy of the lane id: hoisted out of the panel loop it lives through the chain, whose code takes every
+        //  register, and comes back as scratch reloads -- with a vmcnt(0) each -- on the D workers' way to their first publication)
+        int lane = lane_in;
+        asm volatile("" : "+v"(lane));
         const int g = lane >> 4, cl = lane & 15;
         if (!loaded) {
 #pragma unroll

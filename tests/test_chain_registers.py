@@ -1,8 +1,9 @@
 """CPU (cross-compile only): the persistent factorisation kernel (3pre_amd/csrc/pre3_cholp.hip) must keep its dependent chain free of scratch
 traffic.  The chain's unrolled code takes every vector register a 768-thread workgroup may have; one more value living across it comes back
 as a scratch reload in every pipeline step of the worker waves (seen during development: +30 % chain time).  The check reads the compiler's
-own assembly: no scratch instruction between the first and the last v_mfma_f32_32x32x2_f32 of k_cholp (only the chain uses that
-instruction), and no vector-register spill in the kernel itself."""
+own assembly: no scratch instruction between the first and the last matrix instruction that only the chain uses (round 6, the flag-driven
+chain: v_mfma_f32_4x4x1 = the factor / z waves' lookahead, v_mfma_f32_16x16x4_f32 = the D workers, v_mfma_f32_32x32x2_f32 = the X workers), and
+a bounded number of vector-register spills in the kernel as a whole (those sit around the out-of-line rescue stage's call, outside that region)."""
 import os
 import re
 import shutil
@@ -31,7 +32,10 @@ def test_the_chain_of_k_cholp_has_no_scratch_traffic():
     start = [i for i, l in enumerate(asm) if l.startswith("_ZN4pre37k_cholp")]
     assert start, "k_cholp not found in the assembly"
     kern = asm[start[0]:]
-    mf = [i for i, l in enumerate(kern) if "v_mfma_f32_32x32x2_f32" in l]
+    chain_ops = ("v_mfma_f32_32x32x2_f32", "v_mfma_f32_4x4x1_16b_f32", "v_mfma_f32_16x16x4_f32")
+    for op in chain_ops:
+        assert sum(op in l for l in kern) >= 40, "the chain's %s are gone?" % op
+    mf = [i for i, l in enumerate(kern) if any(op in l for op in chain_ops)]
     assert len(mf) > 100, "the chain's f32 MFMAs are gone?"
     inside = [l.strip() for l in kern[mf[0]:mf[-1]] if "scratch_" in l]
     assert not inside, "scratch traffic inside the chain of k_cholp:\n" + "\n".join(inside[:8])
