@@ -112,7 +112,7 @@ struct ChaFromLs {
     template <typename ACC> __device__ __forceinline__ void operator()(ACC &, ACC &, bool, bool, int, int, int) const {}
 };
 template <typename T, int WV, typename DInit>
-__device__ __forceinline__ void cha_dworker(ChSmem<T> &sm, const int lane, bool &bad, DInit &&dinit)
+__device__ __forceinline__ void cha_dworker(ChSmem<T> &sm, const int lane, bool &bad, DInit &&dinit, const int nsp_eff)
 {
     using M = MfmaD<T>;
     constexpr int NBLK = 32 / M::BLK, NJ = CH_MB / M::KS, MB = CH_MB, NSP = CH_NSP, w0 = (WV >> 1) * 32, w1 = (WV & 1) * 32;
@@ -143,6 +143,7 @@ __device__ __forceinline__ void cha_dworker(ChSmem<T> &sm, const int lane, bool 
         const bool pub = c_first >= w1 && c_first < w1 + 32;
         if constexpr (!from_ls && w1 == 0) { if (k == 1 - CHA_LA + 1) { load_q(1); cha_store(fl + CHF_DI0 + WV, 1u, lane); } }      // (behind the publication of sub-panels 0 and 1 = the columns of block column 0)
         if (!upd && !pub) continue;
+        if (k + CHA_LA >= nsp_eff) continue;                                // (sub-panel k + LA is padding: nobody reads it)
         const int qs = pub ? (c_first - w1) / M::BLK : 0, c8 = pub ? (c_first - w1) % M::BLK : 0, par = (k + CHA_LA) % (CHA_LA + 1);
         auto publish = [&]() {
             if (CHA_ABL < 3 && cl >= c8 && cl < c8 + MB) {
@@ -187,7 +188,7 @@ __device__ __forceinline__ void cha_dworker(ChSmem<T> &sm, const int lane, bool 
 // X worker wave WV, pipeline step k (0 .. NSP-1): X -= Y(k-2) Z(k-2) where the tile still has rows >= 8k, then publish rows 8k .. 8k+7.
 // The counter goes up at EVERY live step: it also tells the z wave that Zt(k-2) has been consumed (its slot is rewritten two sub-panels later).
 template <typename T, int WV, bool RELAX>
-__device__ __forceinline__ void cha_xworker(ChSmem<T> &sm, typename ChW<T>::acc_t (&acc)[ChW<T>::NBLK][ChW<T>::NBLK], const int lane, bool &bad)
+__device__ __forceinline__ void cha_xworker(ChSmem<T> &sm, typename ChW<T>::acc_t (&acc)[ChW<T>::NBLK][ChW<T>::NBLK], const int lane, bool &bad, const int nsp_eff)
 {
     using M = Mfma<T>;
     typedef typename ChW<T>::vk_t vk_t;
@@ -196,6 +197,7 @@ __device__ __forceinline__ void cha_xworker(ChSmem<T> &sm, typename ChW<T>::acc_
     unsigned *fl = sm.pipe.fl;
 #pragma unroll
     for (int k = 0; k <= NSP - 1; ++k) {
+        if (k >= nsp_eff) continue;                                         // (rows 8k.. are padding: the right-hand side keeps them)
         if (!(w0 + 32 > MB * k)) {                                      // the tile's rows are all solved: nothing of Zt is read any more
             if (k == (w0 + 32) / MB) cha_store(fl + CHF_X0 + WV, 0x7fffffffu, lane);
             continue;
@@ -259,7 +261,8 @@ __device__ __forceinline__ void cha_xworker(ChSmem<T> &sm, typename ChW<T>::acc_
 // XTRI: the X block starts as the identity (the persistent kernel's crit: M = L^-1 is lower triangular): its tile above the diagonal stays zero, no wave works on it.
 template <typename T, bool RELAX = false, bool XTRI = false, typename Side = ChaNoSide, typename WInit = ChNoInit, typename DInit = ChaFromLs>
 __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>::acc_t (&acc)[ChW<T>::NBLK][ChW<T>::NBLK], const bool acc_loaded,
-                                                 const bool hasX, bool &bad, Side &&side = ChaNoSide{}, WInit &&worker_init = ChNoInit{}, DInit &&dinit = ChaFromLs{})
+                                                 const bool hasX, bool &bad, Side &&side = ChaNoSide{}, WInit &&worker_init = ChNoInit{}, DInit &&dinit = ChaFromLs{},
+                                                 const int nsp_eff = CH_NSP /* wave-uniform: sub-panels >= nsp_eff are padding (identity columns of the block against zero rows of the right-hand side) and are skipped; the counters end at NSP all the same */)
 {
     constexpr int MB = CH_MB, NSP = CH_NSP;
     typedef T v4_t __attribute__((ext_vector_type(4), aligned(16)));
@@ -297,14 +300,14 @@ __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>:
     if (worker) {
         if (tile_live) {
             if (xside) {
-                if (wv == 0) cha_xworker<T, 0, RELAX>(sm, acc, lane, bad);
-                else if (wv == 1) cha_xworker<T, 1, RELAX>(sm, acc, lane, bad);
-                else if (wv == 2) cha_xworker<T, 2, RELAX>(sm, acc, lane, bad);
-                else cha_xworker<T, 3, RELAX>(sm, acc, lane, bad);
+                if (wv == 0) cha_xworker<T, 0, RELAX>(sm, acc, lane, bad, nsp_eff);
+                else if (wv == 1) cha_xworker<T, 1, RELAX>(sm, acc, lane, bad, nsp_eff);
+                else if (wv == 2) cha_xworker<T, 2, RELAX>(sm, acc, lane, bad, nsp_eff);
+                else cha_xworker<T, 3, RELAX>(sm, acc, lane, bad, nsp_eff);
             } else {
-                if (wv == 0) cha_dworker<T, 0>(sm, lane, bad, dinit);
-                else if (wv == 2) cha_dworker<T, 2>(sm, lane, bad, dinit);
-                else cha_dworker<T, 3>(sm, lane, bad, dinit);
+                if (wv == 0) cha_dworker<T, 0>(sm, lane, bad, dinit, nsp_eff);
+                else if (wv == 2) cha_dworker<T, 2>(sm, lane, bad, dinit, nsp_eff);
+                else cha_dworker<T, 3>(sm, lane, bad, dinit, nsp_eff);
             }
         }
     } else if (role == 0) {
@@ -321,6 +324,7 @@ __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>:
         for (int t = 0; t < MB; ++t) yprev2[t] = (T)0;
 #pragma unroll
         for (int k = 0; k < NSP; ++k) {
+            if (k >= nsp_eff) continue;
             const int C = MB * k, par = k % (CHA_LA + 1), parn = (k + 1) % (CHA_LA + 1);
             T2 a2[MB / 2];
             T y[MB], rsv[MB];
@@ -415,7 +419,7 @@ __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>:
                 y[c] = ac * rsv[c];
             }
             CHA_STAMP(0, k, 2);
-            if (CHA_PREFETCH && k + 1 < NSP) {
+            if (CHA_PREFETCH && k + 1 < NSP && k + 1 < nsp_eff) {
                 const int Cn = C + MB;
                 pf0 = cha_load(fl + CHF_D0 + (Cn < 32 ? 0 : 3)); pf1 = cha_load(fl + CHF_D0 + (Cn < 32 ? 2 : 3));
                 asm volatile("" ::: "memory");
@@ -433,6 +437,7 @@ __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>:
 #pragma unroll
             for (int t = 0; t < MB; ++t) { yprev2[t] = yprev[t]; yprev[t] = y[t]; }
         }
+        if (nsp_eff < NSP) cha_store(fl + CHF_F, (unsigned)NSP, lane);     // (the padding's columns of L are the block's own identity columns)
     } else if (role == 1) {
         if (hasX) {
             // ---- z wave: lane = column i of the workgroup's X block; sub-panel s: z <- L8^-1 (x - lookahead).
@@ -469,6 +474,7 @@ __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>:
             issue_a(0);
 #pragma unroll
             for (int s2 = 0; s2 < NSP; ++s2) {
+                if (s2 >= nsp_eff) continue;
                 const int C = MB * s2, par = s2 & 1;
                 T x[MB], z[MB];
                 v4_t Ld[MB][2], r0, r1;
@@ -537,7 +543,7 @@ __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>:
                 }
                 CHA_STAMP(1, s2, 2);
                 // the next sub-panel's phase A travels while the solve runs (its operand of the lookahead, rows C+8 .. C+15 of Y(s2), is final: see phase B)
-                if (s2 + 1 < NSP) issue_a(s2 + 1);
+                if (s2 + 1 < NSP && s2 + 1 < nsp_eff) issue_a(s2 + 1);
                 // column-oriented: once z[u] is known every later row takes its term -- the dependent chain is one multiply and one fma per row
 #pragma unroll
                 for (int u = 0; u < MB; ++u) {
@@ -552,6 +558,7 @@ __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>:
                 cha_store(fl + CHF_Z, (unsigned)(s2 + 1), lane);
                 CHA_STAMP(1, s2, 3);
             }
+            if (nsp_eff < NSP) cha_store(fl + CHF_Z, (unsigned)NSP, lane);
         }
     } else {
         side(fl);

@@ -21,6 +21,10 @@
 #include "pre3_internal.h"
 #include "pre3_geomdev.h"
 #include "pre3_chain.h"
+#include "pre3_chain_async.h"
+#ifndef PRE3_CHAIN_ASYNC
+#define PRE3_CHAIN_ASYNC 1          // fp32 panel chains outside the persistent kernel (k_chol_step, k_hi_fused) on the flag-driven form; 0: the lock-step chain of rounds 2-5
+#endif
 #include "pre3_cholp.h"
 
 namespace pre3 {
@@ -371,6 +375,12 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[0][0][e] = acc[0][0][e] - pacc[e];
                 }
+                if (PRE3_CHAIN_ASYNC && !xside) {
+                    // the flag-driven chain's D workers read their tiles from Ls, in their own block layout (pre3_chain_async.h): the updated tile goes
+                    // back where the raw one came from (each wave its own tile: no barrier)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) Ls[w0 + (e & 3) + 8 * (e >> 2) + lrow][w1 + lcol] = acc[0][0][e];
+                }
             }
             acc_loaded = true;
         }
@@ -412,6 +422,7 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
                     for (int e = 0; e < M::NREG; ++e) {
                         const int r = w0 + p * M::BLK + M::row(lane, e), c = w1 + q * M::BLK + M::col(lane);
                         acc[p][q][e] = (xside ? Xs[r][c] : Ls[r][c]) - pacc[p][q][e];
+                        if (sizeof(T) == 4 && PRE3_CHAIN_ASYNC && !xside) Ls[r][c] = acc[p][q][e];      // (the flag-driven chain's D workers read Ls)
                     }
         }
         acc_loaded = true;
@@ -423,10 +434,18 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
     const int nsp_eff = (rows_last > 0 && J == nrb - 1) ? (rows_last + CH_MB - 1) / CH_MB : CH_NSP;
     // (EARLY is a KERNEL variant: the step-skipping form's uniform branches cost a full chain ~6 % -- measured in the persistent kernel, 14.35 k ->
     // 15.3 k cycles per panel -- and both forms in one kernel spill; the host launches it for a last panel that really has padding)
-    if constexpr (EARLY) chol_chain<T, false, true>(sm, acc, acc_loaded, hasX, bad, [](int) {}, __builtin_amdgcn_readfirstlane(nsp_eff));
-    else chol_chain<T, false, false>(sm, acc, acc_loaded, hasX, bad, [](int) {});
+    if constexpr (sizeof(T) == 4 && PRE3_CHAIN_ASYNC) {
+        // round 6: fp32 takes the flag-driven chain (no barrier per pipeline step; the step-skipping form costs it nothing, so EARLY or not is one code).
+        // worker_init: the X workers keep the tile the prologue left in `acc`; the D workers' went back to Ls above.
+        chol_chain_async<T, false, false>(sm, acc, acc_loaded, hasX, bad, ChaNoSide{},
+                                           [](typename ChW<T>::acc_t (&)[ChW<T>::NBLK][ChW<T>::NBLK], bool, int) {}, ChaFromLs{},
+                                           EARLY ? __builtin_amdgcn_readfirstlane(nsp_eff) : CH_NSP);
+    } else {
+        if constexpr (EARLY) chol_chain<T, false, true>(sm, acc, acc_loaded, hasX, bad, [](int) {}, __builtin_amdgcn_readfirstlane(nsp_eff));
+        else chol_chain<T, false, false>(sm, acc, acc_loaded, hasX, bad, [](int) {});
+    }
     PROBE_STAMP(2);
-    if (bad && role == 0 && (tid & 63) == 0 && b == 0) atomicExch(status, 1);
+    if (bad && (tid & 63) == 0 && b == 0) atomicExch(status, 1);
     if (b == 0) {
         if (!PREBUILT && tid == 0) {
             bounded_wait(arrive, target, status + 1);        // status + 1 = stats[7], the wait guard (a give-up is reported as PRE3_E_HIP)
@@ -1188,8 +1207,9 @@ __global__ __launch_bounds__(CH_NTH) void k_hi_fused(HiFused a)
         {
             typename ChW<float>::acc_t acc[ChW<float>::NBLK][ChW<float>::NBLK];
             bool bad = false;
-            chol_chain<float, false, false>(sm, acc, false, true, bad, [](int) {});
-            if (bad && wave == 8 && lane == 0 && b == 0) atomicExch(a.stats + 6, 1);
+            if constexpr (PRE3_CHAIN_ASYNC) chol_chain_async<float, false, true>(sm, acc, false, true, bad);       // (X = I: its tile above the diagonal stays zero)
+            else chol_chain<float, false, false>(sm, acc, false, true, bad, [](int) {});
+            if (bad && (wave == 8 || wave == 9) && lane == 0 && b == 0) atomicExch(a.stats + 6, 1);
         }
         // (the chain ends behind a barrier)  Ls = L00 (lower triangle), Xs[a][k] = M0(a, k)
         if (b == 0) {
