@@ -86,6 +86,6 @@ EXPORTS = [
     "pre3_match_shard_destroy", "pre3_release_scratch", "pre3_knn_f64", "pre3_timer_start",
     "pre3_timer_stop", "pre3_kernel_timing", "pre3_kernel_timing_read", "pre3_kernel_timing_info", "pre3_bench_downdate",
     "pre3_match_bench_create", "pre3_match_bench_create_cls", "pre3_match_bench_info", "pre3_match_bench_run", "pre3_match_bench_fetch", "pre3_match_bench_destroy",
-    "pre3_comm_unique_id", "pre3_comm_create", "pre3_comm_destroy", "pre3_comm_info", "pre3_comm_set_timeout", "pre3_test_stall", "pre3_match_shard_test_stall", "pre3_set_comm", "pre3_comm_init", "pre3_match_shard_set_comm",
+    "pre3_comm_unique_id", "pre3_comm_create", "pre3_comm_destroy", "pre3_comm_info", "pre3_comm_set_timeout", "pre3_set_comm", "pre3_comm_init", "pre3_match_shard_set_comm",
     "pre3_ransac_sharded", "pre3_match_shard_match",
 ]

@@ -9,6 +9,7 @@
 
 #include <chrono>
 #include "pre3_internal.h"
+#include "pre3_test_hooks.h"
 #include "pre3_geomdev.h"
 #include <mutex>
 #include "pre3_cholp.h"
@@ -82,6 +83,29 @@ static int check_ctx(pre3_ctx *c)
 // Poll the pinned mailbox until the kernel that was launched with sequence number `seq` has published.
 // slot 8: k_ransac_select, slot 9: k_collect_hi.  Falls back to a stream sync if the word does not arrive.
 static double now_ms() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
+// see pre3_internal.h
+int stream_drain_on(hipStream_t st, void *comm, const char *what)
+{
+    if (comm == nullptr) { PRE3_HIP(hipStreamSynchronize(st)); return PRE3_OK; }
+    const bool was_broken = comm_broken(comm);
+    const double t0 = now_ms();
+    for (long spin = 0; ; ++spin) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return PRE3_OK;
+        if (e != hipErrorNotReady) PRE3_HIP(e);
+        if ((spin & 15) == 15) {
+            if (!was_broken) PRE3_TRY(comm_poll_error(comm));
+            if (now_ms() - t0 > comm_timeout_ms(comm)) {
+                if (!was_broken) return comm_give_up(comm, what);
+                set_error("%s: the stream has not drained %d ms after its communicator was aborted", what, comm_timeout_ms(comm));
+                return PRE3_E_COMM;
+            }
+            timespec ts = { 0, 20000 };
+            nanosleep(&ts, nullptr);
+        }
+    }
+}
+int stream_drain(pre3_ctx *c, const char *what) { return stream_drain_on(c->stream, c->comm, what); }
 static int wait_mail(pre3_ctx *c, int slot, int32_t seq)
 {
     volatile int32_t *w = c->mail_host + slot;
@@ -110,7 +134,7 @@ static int wait_mail(pre3_ctx *c, int slot, int32_t seq)
             }
         }
     }
-    PRE3_HIP(hipStreamSynchronize(c->stream));
+    PRE3_TRY(stream_drain(c, __func__));
     PRE3_CHECK(__atomic_load_n(w, __ATOMIC_ACQUIRE) == seq, PRE3_E_STATE, "mailbox: the producing kernel has not been launched");
     return PRE3_OK;
 }
@@ -118,7 +142,7 @@ static int wait_mail(pre3_ctx *c, int slot, int32_t seq)
 static int fetch_stats(pre3_ctx *c)
 {
     PRE3_HIP(hipMemcpyAsync(c->pinned_stats, c->stats, sizeof(int32_t) * 16, hipMemcpyDeviceToHost, c->stream));
-    PRE3_HIP(hipStreamSynchronize(c->stream));
+    PRE3_TRY(stream_drain(c, __func__));
     PRE3_CHECK(c->pinned_stats[7] == 0, PRE3_E_HIP, "a device-side wait on another workgroup gave up (counter never arrived): results are invalid");
     PRE3_CHECK(c->pinned_stats[6] == 0, PRE3_E_NUMERIC, "innovation covariance S is not positive definite");
     return PRE3_OK;
@@ -158,7 +182,7 @@ int stage_wait(pre3_ctx *c, int k)
             else if (t - t0 > 2.0) break;
         }
     }
-    PRE3_HIP(hipStreamSynchronize(c->stream));
+    PRE3_TRY(stream_drain(c, __func__));
     if (__atomic_load_n(w, __ATOMIC_ACQUIRE) != seq) {
         c->stage_seq[k] = 0;                         // (the stream is idle: the block is free whatever became of that launch; the next pull starts a fresh count)
         (void)hipMemsetAsync(c->chol_arrive + 8 + k, 0, sizeof(unsigned int), c->stream);
@@ -197,6 +221,21 @@ int pre3_device_count(void)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+// The tail of the persistent launch (rescue stage + HI update inside k_cholp, CpTail; off by default): per landmark y = H J W' as bf16 planes (+ one zero
+// slot), the row H J, crit's list, and W once more column-major.  Allocated on demand (pre3_set_option(PRE3_OPT_STEP_TAIL, 1) or PRE3_TAIL=1 at creation).
+static int tail_alloc(pre3_ctx *c)
+{
+    if (c->tail_yp && c->tail_hb && c->tail_hib && c->tail_wt) return PRE3_OK;
+    PRE3_CHECK(c->dtype == PRE3_F32 && c->Wp != nullptr, PRE3_E_STATE, "PRE3_OPT_STEP_TAIL: fp32 contexts with the persistent factorisation only");
+    int rc = PRE3_OK;
+    auto A = [&](int r) { if (rc == PRE3_OK) rc = r; };
+    if (!c->tail_yp) A(dmalloc_bytes(&c->tail_yp, (size_t)(c->capN + 1) * 2 * 3 * c->rcap * 2));
+    if (!c->tail_hb) { void *f = nullptr; A(dmalloc_bytes(&f, (size_t)c->capN * 2 * 16 * sizeof(float))); c->tail_hb = (float *)f; }
+    if (!c->tail_hib) { void *f = nullptr; A(dmalloc_bytes(&f, sizeof(int32_t) * (64 + 64 * 16))); c->tail_hib = (int32_t *)f; }
+    if (!c->tail_wt) { void *f = nullptr; A(dmalloc_bytes(&f, (size_t)c->ldw * c->rcap * sizeof(float))); c->tail_wt = (float *)f; }
+    return rc;
 }
 
 int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int max_hyp)
@@ -330,11 +369,9 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
         }
         A(dmalloc_bytes(&c->cholp_tp, (size_t)(c->rcap / NB) * 1536 * 16));
         { void *f = nullptr; A(dmalloc_bytes(&f, sizeof(float) * 4 * (size_t)c->ld)); c->jn_q = (float *)f; }      // rows 3..6 of P before the Jnorm pass (GateRide, pre3_geom.hip)
-        // the tail of the persistent launch (rescue stage + HI update, CpTail): per landmark y = H J W' as bf16 planes (+ one zero slot), the row H J, crit's list
-        A(dmalloc_bytes(&c->tail_yp, (size_t)(c->capN + 1) * 2 * 3 * c->rcap * 2));
-        { void *f = nullptr; A(dmalloc_bytes(&f, (size_t)c->capN * 2 * 16 * sizeof(float))); c->tail_hb = (float *)f; }
-        { void *f = nullptr; A(dmalloc_bytes(&f, sizeof(int32_t) * (64 + 64 * 16))); c->tail_hib = (int32_t *)f; }
-        { void *f = nullptr; A(dmalloc_bytes(&f, (size_t)c->ldw * c->rcap * sizeof(float))); c->tail_wt = (float *)f; }
+        // (the buffers of the in-launch tail, PRE3_OPT_STEP_TAIL, are allocated when the option is switched on: tail_alloc -- at N = 2000 they are
+        //  ~300 MB that the default path never touches)
+        if (c->step_tail) A(tail_alloc(c));
         if (rc == PRE3_OK) { cholp_context_count(c->device, +1); c->cholp_counted = true; }
         const int nt = c->ld / 128, ns = ceil_div(nt, 4);
         std::vector<std::vector<int2>> lists(8);
@@ -389,7 +426,7 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
     if (rc != PRE3_OK) { pre3_destroy(c); return rc; }
     (void)hipMemsetAsync(c->stats, 0, sizeof(int32_t) * 16, c->stream);
     (void)hipMemsetAsync(c->P, 0, (size_t)c->ld * c->ld * c->esz, c->stream);
-    (void)hipStreamSynchronize(c->stream);
+    (void)stream_drain(c, __func__);
     *out = c;
     return PRE3_OK;
 }
@@ -398,7 +435,11 @@ int pre3_destroy(pre3_ctx *c)
 {
     if (!c) return PRE3_OK;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)stream_drain(c, __func__);
+    // an abort started by a deadline may still be inside RCCL, and the collective it unblocks may still touch this context's buffers: joined (within the
+    // deadline) and the stream drained again before anything is freed
+    if (c->comm && !comm_abort_wait(c->comm, comm_abort_ms(c->comm))) set_error("pre3_destroy: the communicator's abort has not returned: buffers are freed under it");
+    else if (c->comm && comm_broken(c->comm) && c->stream) (void)stream_drain(c, __func__);
     if (c->cholp_counted) { cholp_context_count(c->device, -1); c->cholp_counted = false; }
     ic_rank_free(c);
     if (c->comm && c->comm_owned) (void)pre3_comm_destroy((pre3_comm *)c->comm);
@@ -429,7 +470,11 @@ int pre3_set_option(pre3_ctx *c, int option, int value)
     case PRE3_OPT_K9_BF16X3: c->k9_b3 = value != 0 && c->dtype == PRE3_F32 && c->Wp != nullptr; return PRE3_OK;
     case PRE3_OPT_CHOL_PERSIST: c->chol_persist = value != 0; return PRE3_OK;
     case PRE3_OPT_K9_OVERLAP: c->k9_overlap = value != 0; return PRE3_OK;
-    case PRE3_OPT_STEP_TAIL: c->step_tail = value != 0; return PRE3_OK;
+    case PRE3_OPT_STEP_TAIL:
+        // (fp64 contexts have no persistent launch: the option is accepted and stays without effect, pre3_get_option reports 0)
+        if (value != 0 && c->dtype == PRE3_F32 && c->Wp != nullptr) { const int rc = tail_alloc(c); if (rc != PRE3_OK) { c->step_tail = false; return rc; } }
+        c->step_tail = value != 0;
+        return PRE3_OK;
     default: set_error("pre3_set_option: unknown option %d", option); return PRE3_E_ARG;
     }
 }
@@ -452,7 +497,7 @@ int pre3_get_option(pre3_ctx *c, int option, int *value_out)
 int pre3_sync(pre3_ctx *c)
 {
     PRE3_TRY(check_ctx(c));
-    PRE3_HIP(hipStreamSynchronize(c->stream));
+    PRE3_TRY(stream_drain(c, __func__));
     return PRE3_OK;
 }
 
@@ -476,7 +521,7 @@ int pre3_set_map(pre3_ctx *c, int N, const int32_t *lm_type)
         off[i] = n; n += lm_type[i] == PRE3_INVDEPTH ? 6 : 3;
     }
     PRE3_CHECK(n <= c->capn, PRE3_E_ARG, "pre3_set_map: state size %d exceeds capacity %d", n, c->capn);
-    PRE3_HIP(hipStreamSynchronize(c->stream));
+    PRE3_TRY(stream_drain(c, __func__));
     if (N) {
         PRE3_HIP(hipMemcpy(c->lm.type, lm_type, sizeof(int32_t) * N, hipMemcpyHostToDevice));
         PRE3_HIP(hipMemcpy(c->lm.off, off.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice));
@@ -506,7 +551,7 @@ int pre3_set_state(pre3_ctx *c, int which, int n, const double *x, const double 
         if (c && rc0 != PRE3_OK && rc0 != PRE3_E_NUMERIC && rc0 != PRE3_E_HIP) return rc0;
         if (c) {
             PRE3_HIP(hipSetDevice(c->device));
-            (void)hipStreamSynchronize(c->stream);
+            (void)stream_drain(c, __func__);
             (void)hipMemsetAsync(c->stats + 6, 0, sizeof(int32_t) * 2, c->stream);
             if (c->mail_host) { c->mail_host[6] = 0; c->mail_host[7] = 0; }
             c->jn_pending = false; c->hi_pending = false; c->tail_done = false; c->hi_fused = false;
@@ -516,7 +561,7 @@ int pre3_set_state(pre3_ctx *c, int which, int n, const double *x, const double 
     PRE3_CHECK(which == PRE3_X_K_K || which == PRE3_X_K_KM1, PRE3_E_ARG, "pre3_set_state: bad selector");
     PRE3_CHECK(n == c->n, PRE3_E_ARG, "pre3_set_state: n=%d but the map defines n=%d", n, c->n);
     PRE3_CHECK(x && P, PRE3_E_ARG, "pre3_set_state: null pointer");
-    PRE3_HIP(hipStreamSynchronize(c->stream));
+    PRE3_TRY(stream_drain(c, __func__));
     PRE3_HIP(hipMemcpy(which == PRE3_X_K_K ? c->x_kk : c->x_km1, x, sizeof(double) * n, hipMemcpyHostToDevice));
     const int ld = c->ld;
     PRE3_HIP(hipMemset(c->P, 0, (size_t)ld * ld * c->esz));
@@ -588,7 +633,7 @@ int pre3_innovation(pre3_ctx *c)
 int pre3_get_landmark_fields(pre3_ctx *c, double *h, int32_t *has_h, double *Hc, double *Hl, double *S)
 {
     PRE3_TRY(check_ctx(c));
-    PRE3_HIP(hipStreamSynchronize(c->stream));
+    PRE3_TRY(stream_drain(c, __func__));
     int N = c->N;
     if (N == 0) return PRE3_OK;
     if (h) PRE3_HIP(hipMemcpy(h, c->lm.h, sizeof(double) * 2 * N, hipMemcpyDeviceToHost));
@@ -653,7 +698,7 @@ int pre3_window_gate(pre3_ctx *c, int M, const int32_t *k1, const double *zc, in
     PRE3_CHECK(M >= 0 && (M == 0 || (k1 && zc)), PRE3_E_ARG, "pre3_window_gate: bad arguments");
     int N = c->N;
     std::vector<int32_t> has_h(N ? N : 1), pred;
-    PRE3_HIP(hipStreamSynchronize(c->stream));
+    PRE3_TRY(stream_drain(c, __func__));
     if (N) PRE3_HIP(hipMemcpy(has_h.data(), c->lm.has_h, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
     for (int i = 0; i < N; ++i) if (has_h[i]) pred.push_back(i);
     PRE3_CHECK(M <= (int)pred.size(), PRE3_E_ARG, "pre3_window_gate: %d candidates but only %zu predicted landmarks", M, pred.size());
@@ -672,7 +717,7 @@ int pre3_window_gate(pre3_ctx *c, int M, const int32_t *k1, const double *zc, in
         PRE3_HIP(hipMemcpy(d_zc, zc, sizeof(double) * 2 * M, hipMemcpyHostToDevice));
         PRE3_HIP(hipMemsetAsync(c->lm.ic, 0, sizeof(int32_t) * N, c->stream));
         PRE3_TRY(launch_window_gate(c, M, d_pred, d_k1, d_zc, strict_reference, d_acc));
-        PRE3_HIP(hipStreamSynchronize(c->stream));
+        PRE3_TRY(stream_drain(c, __func__));
         PRE3_HIP(hipMemcpy(acc.data(), d_acc, sizeof(int32_t) * M, hipMemcpyDeviceToHost));
     }
     // accepted candidates become the measurement list (ascending landmark order; one match per landmark)
@@ -802,7 +847,7 @@ int pre3_get_descriptors(pre3_ctx *c, int first, int count, double *desc)
     PRE3_TRY(check_ctx(c));
     PRE3_CHECK(first >= 0 && count >= 0 && first + count <= c->N && (count == 0 || desc), PRE3_E_ARG, "pre3_get_descriptors: range outside the map");
     PRE3_CHECK(c->bank_set, PRE3_E_STATE, "pre3_get_descriptors: no descriptors have been set");
-    PRE3_HIP(hipStreamSynchronize(c->stream));
+    PRE3_TRY(stream_drain(c, __func__));
     if (count) PRE3_HIP(hipMemcpy(desc, c->bank + (size_t)first * DESC_DIM, sizeof(double) * (size_t)count * DESC_DIM, hipMemcpyDeviceToHost));
     return PRE3_OK;
 }
@@ -812,7 +857,7 @@ int pre3_set_scan(pre3_ctx *c, int K2, const double *descriptor_raw, const doubl
     PRE3_TRY(check_ctx(c));
     PRE3_CHECK(K2 >= 0 && (K2 == 0 || (descriptor_raw && scale_orient_pos_raw)), PRE3_E_ARG, "pre3_set_scan: bad arguments");
     if (K2 > c->scan_cap) {
-        PRE3_HIP(hipStreamSynchronize(c->stream));             // (the buffers being replaced may still be read by queued kernels)
+        PRE3_TRY(stream_drain(c, __func__));             // (the buffers being replaced may still be read by queued kernels)
         if (c->scan_desc) (void)hipFree(c->scan_desc);
         if (c->scan_pos) (void)hipFree(c->scan_pos);
         if (c->ic_pb) (void)hipFree(c->ic_pb);
@@ -979,7 +1024,7 @@ int pre3_ransac_score(pre3_ctx *c, int n_draw, int k, const int32_t *hyp, double
     if (support_dev) *support_dev = c->support;
     if (mask_dev) *mask_dev = c->masks;
     if (mask_words) *mask_words = words;
-    PRE3_HIP(hipStreamSynchronize(c->stream));     // the caller's collective runs on another stream
+    PRE3_TRY(stream_drain(c, __func__));     // the caller's collective runs on another stream
     return PRE3_OK;
 }
 
@@ -990,7 +1035,7 @@ static int ransac_results(pre3_ctx *c, int n_draw, int32_t *support, int32_t *li
     if (support || li_mask) {
         // (behind a collective the synchronisation comes second: the selection's mailbox word first, under the communicator's deadline)
         if (c->shard_round) PRE3_TRY(wait_mail(c, 8, c->seq_select));
-        PRE3_HIP(hipStreamSynchronize(c->stream));
+        PRE3_TRY(stream_drain(c, __func__));
         if (support) PRE3_HIP(hipMemcpy(support, c->support, sizeof(int32_t) * n_draw, hipMemcpyDeviceToHost));
         if (li_mask && c->m) PRE3_HIP(hipMemcpy(li_mask, c->li_meas, sizeof(int32_t) * c->m, hipMemcpyDeviceToHost));
     }
@@ -1020,7 +1065,7 @@ int pre3_ransac_export(pre3_ctx *c, int n_draw, void *support_dst_dev, void *mas
     int words = ceil_div(c->m, 32);
     if (support_dst_dev) PRE3_HIP(hipMemcpyAsync(support_dst_dev, c->support, sizeof(int32_t) * n_draw, hipMemcpyDeviceToDevice, c->stream));
     if (mask_dst_dev) PRE3_HIP(hipMemcpyAsync(mask_dst_dev, c->masks, sizeof(uint32_t) * (size_t)n_draw * words, hipMemcpyDeviceToDevice, c->stream));
-    PRE3_HIP(hipStreamSynchronize(c->stream));
+    PRE3_TRY(stream_drain(c, __func__));
     return PRE3_OK;
 }
 
@@ -1032,7 +1077,7 @@ int pre3_ransac_import(pre3_ctx *c, int n_draw, const void *support_src_dev, con
     int words = ceil_div(c->m, 32);
     if (support_src_dev) PRE3_HIP(hipMemcpyAsync(c->support, support_src_dev, sizeof(int32_t) * n_draw, hipMemcpyDeviceToDevice, c->stream));
     if (mask_src_dev) PRE3_HIP(hipMemcpyAsync(c->masks, mask_src_dev, sizeof(uint32_t) * (size_t)n_draw * words, hipMemcpyDeviceToDevice, c->stream));
-    PRE3_HIP(hipStreamSynchronize(c->stream));
+    PRE3_TRY(stream_drain(c, __func__));
     return PRE3_OK;
 }
 
@@ -1041,7 +1086,12 @@ int pre3_set_comm(pre3_ctx *c, pre3_comm *comm)
 {
     PRE3_TRY(check_ctx(c));
     PRE3_CHECK(comm == nullptr || comm_device(comm) == c->device, PRE3_E_ARG, "pre3_set_comm: the communicator lives on device %d, the context on %d", comm ? comm_device(comm) : -1, c->device);
-    if (c->comm && c->comm_owned && c->comm != (void *)comm) { PRE3_HIP(hipStreamSynchronize(c->stream)); (void)pre3_comm_destroy((pre3_comm *)c->comm); }
+    if (c->comm && c->comm != (void *)comm) {
+        // nothing queued on the stream may still use the handle being replaced (the caller may destroy it next); after a deadline: its abort has come back
+        PRE3_TRY(stream_drain(c, __func__));
+        PRE3_CHECK(comm_abort_wait(c->comm, comm_abort_ms(c->comm)), PRE3_E_COMM, "pre3_set_comm: the abort of the previous communicator has not returned yet");
+        if (c->comm_owned) (void)pre3_comm_destroy((pre3_comm *)c->comm);
+    }
     c->comm = comm; c->comm_owned = false;
     return PRE3_OK;
 }
@@ -1060,7 +1110,8 @@ int pre3_comm_init(pre3_ctx *c, const void *id, int rank, int world)
 // One sharded RANSAC round with everything on the context's stream: [H*P | H*P*H' of this rank's measurements] -> scoring of hypotheses
 // [lo, hi) -> ncclAllReduce(sum) of [supports | masks], in place (the slices are disjoint and the buffer is cleared first: the integer sum
 // is the union) -> selection.  The host waits once, on the selection's mailbox word.
-// ---- test hook: a kernel that keeps the stream busy until the host releases it (or ~30 s have passed) ----------------------------------
+// ---- test hook (pre3_test_hooks.h; inert without PRE3_TEST_HOOKS=1): a kernel that keeps the stream busy until the host releases it (or ~20 s have passed)
+static bool test_hooks_on() { const char *e = getenv("PRE3_TEST_HOOKS"); return e && atoi(e) == 1; }
 __global__ void k_test_stall(volatile int32_t *flag)
 {
     for (long spin = 0; spin < 6000000L; ++spin) {          // (~20 s: the kernel lets go by itself)
@@ -1070,6 +1121,7 @@ __global__ void k_test_stall(volatile int32_t *flag)
 }
 int pre3_test_stall(pre3_ctx *c, int release)
 {
+    PRE3_CHECK(test_hooks_on(), PRE3_E_STATE, "pre3_test_stall: test hooks are off (PRE3_TEST_HOOKS=1 enables them)");
     PRE3_CHECK(c != nullptr, PRE3_E_ARG, "null context");
     PRE3_HIP(hipSetDevice(c->device));
     if (release) { __atomic_store_n(c->mail_host + 15, 1, __ATOMIC_RELEASE); return PRE3_OK; }
@@ -1214,7 +1266,7 @@ int pre3_rescue(pre3_ctx *c, double chi2, int32_t *hi_mask)
     c->rescue_projected = false;
     c->hi_from_host = -1; c->hi_kernel = true;
     if (hi_mask) {
-        PRE3_HIP(hipStreamSynchronize(c->stream));
+        PRE3_TRY(stream_drain(c, __func__));
         if (c->m) PRE3_HIP(hipMemcpy(hi_mask, c->hi_meas, sizeof(int32_t) * c->m, hipMemcpyDeviceToHost));
     }
     return PRE3_OK;
@@ -1277,7 +1329,7 @@ int pre3_update_all(pre3_ctx *c)
 int pre3_get_flags(pre3_ctx *c, int32_t *li, int32_t *hi)
 {
     PRE3_TRY(check_ctx(c));
-    PRE3_HIP(hipStreamSynchronize(c->stream));
+    PRE3_TRY(stream_drain(c, __func__));
     if (c->m == 0) return PRE3_OK;
     if (li) PRE3_HIP(hipMemcpy(li, c->li_meas, sizeof(int32_t) * c->m, hipMemcpyDeviceToHost));
     if (hi) PRE3_HIP(hipMemcpy(hi, c->hi_meas, sizeof(int32_t) * c->m, hipMemcpyDeviceToHost));
@@ -1288,7 +1340,7 @@ int pre3_set_flags(pre3_ctx *c, const int32_t *li, const int32_t *hi)
 {
     PRE3_TRY(check_ctx(c));
     PRE3_CHECK(c->measurements_set, PRE3_E_STATE, "pre3_set_flags: no measurements");
-    PRE3_HIP(hipStreamSynchronize(c->stream));
+    PRE3_TRY(stream_drain(c, __func__));
     int m = c->m, N = c->N;
     for (int pass = 0; pass < 2; ++pass) {
         const int32_t *src = pass == 0 ? li : hi;
@@ -1703,7 +1755,7 @@ int pre3_kernel_timing(pre3_ctx *c, int enable)
 int pre3_kernel_timing_read(pre3_ctx *c, int *launches_out, double *total_ms_out, double *flops_out, double *bytes_out)
 {
     PRE3_TRY(check_ctx(c));
-    PRE3_HIP(hipStreamSynchronize(c->stream));
+    PRE3_TRY(stream_drain(c, __func__));
     double tot = 0;
     for (int i = 0; i + 1 < c->kt.used; i += 2) { float ms = 0; PRE3_HIP(hipEventElapsedTime(&ms, c->kt.ev[i], c->kt.ev[i + 1])); tot += ms; }
     if (launches_out) *launches_out = c->kt.used / 2;
@@ -1772,7 +1824,11 @@ int pre3_match_shard_match(pre3_match_shard *s, double thresh, double *pairs_out
     return s ? match_shard_match(s, thresh, pairs_out, score_out, M_out) : PRE3_E_ARG;
 }
 int pre3_match_shard_destroy(pre3_match_shard *s) { if (s) match_shard_destroy(s); return PRE3_OK; }
-int pre3_match_shard_test_stall(pre3_match_shard *s, int release) { return s ? match_shard_test_stall(s, release) : PRE3_E_ARG; }
+int pre3_match_shard_test_stall(pre3_match_shard *s, int release)
+{
+    PRE3_CHECK(test_hooks_on(), PRE3_E_STATE, "pre3_match_shard_test_stall: test hooks are off (PRE3_TEST_HOOKS=1 enables them)");
+    return s ? match_shard_test_stall(s, release) : PRE3_E_ARG;
+}
 
 // matcher roofline/bench probe (inputs resident in HBM); not part of the reference-shaped API
 PRE3_API void *pre3_match_bench_create(int device, int ND, int K1, const uint8_t *L1, int K2, const uint8_t *L2)

@@ -9,6 +9,8 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <mutex>
+#include <atomic>
+#include <chrono>
 #include <thread>
 
 namespace pre3 {
@@ -56,7 +58,12 @@ static const Rccl *rccl()
 
 #define PRE3_NCCL(R, expr) do { ncclResult_t nr_ = (expr); if (nr_ != ncclSuccess) { set_error("RCCL: %s failed: %s", #expr, (R)->GetErrorString(nr_)); return PRE3_E_COMM; } } while (0)
 
-struct Comm { ncclComm_t comm = nullptr; int device = 0, rank = 0, world = 1; bool broken = false; int timeout_ms = 10000; };
+struct Comm {
+    ncclComm_t comm = nullptr; int device = 0, rank = 0, world = 1; bool broken = false; int timeout_ms = 10000;
+    // comm_give_up's abort runs on a thread of its own (it may wait for work that has not started).  The thread is kept: pre3_comm_destroy, pre3_destroy
+    // and the shard's destroy join it -- within the deadline -- before the library's buffers or code can go away under it.
+    std::thread aborter; std::atomic<bool> abort_done{ true };
+};
 
 int comm_all_reduce_i32(void *h, void *buf, size_t count, hipStream_t st)
 {
@@ -104,11 +111,31 @@ int comm_give_up(void *h, const char *what)
             ncclComm_t dead = cm->comm;
             const int dev = cm->device;
             auto abort_fn = R->CommAbort;
-            std::thread([dead, dev, abort_fn] { (void)hipSetDevice(dev); (void)abort_fn(dead); }).detach();
+            if (cm->aborter.joinable()) cm->aborter.join();          // (an earlier abort of this handle: it has long returned)
+            cm->abort_done.store(false);
+            std::atomic<bool> *done = &cm->abort_done;
+            cm->aborter = std::thread([dead, dev, abort_fn, done] { (void)hipSetDevice(dev); (void)abort_fn(dead); done->store(true); });
         }
         cm->comm = nullptr;
     }
     return PRE3_E_COMM;
+}
+// how long a join of the abort thread may take: ncclCommAbort tears the communicator down (proxy threads, IPC handles) once the collective has let go --
+// local work, but measured at up to a second; the hang-proofing deadline (timeout_ms, possibly a few hundred ms) is too short a bound for it
+int comm_abort_ms(void *h) { Comm *cm = (Comm *)h; return cm ? (cm->timeout_ms > 10000 ? cm->timeout_ms : 10000) : 0; }
+bool comm_broken(void *h) { Comm *cm = (Comm *)h; return cm && cm->broken; }
+// the abort thread, if one is running, has finished within `ms` (and is joined); false: it is still inside ncclCommAbort
+bool comm_abort_wait(void *h, int ms)
+{
+    Comm *cm = (Comm *)h;
+    if (!cm || !cm->aborter.joinable()) return true;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!cm->abort_done.load()) {
+        if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > ms) return false;
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    cm->aborter.join();
+    return true;
 }
 void comm_rank_world(void *h, int *rank, int *world) { Comm *cm = (Comm *)h; *rank = cm ? cm->rank : 0; *world = cm ? cm->world : 1; }
 int comm_device(void *h) { return ((Comm *)h)->device; }
@@ -153,6 +180,13 @@ int pre3_comm_destroy(pre3_comm *h)
     if (!cm) return PRE3_OK;
     const Rccl *R = rccl();
     if (R && cm->comm) { (void)hipSetDevice(cm->device); (void)(cm->broken ? R->CommAbort(cm->comm) : R->CommDestroy(cm->comm)); }
+    // an abort started by a deadline may still be inside RCCL: it is joined here, within the same deadline.  If it does not come back the handle is
+    // leaked on purpose (its thread keeps using it) and the call says so: the process must not unload librccl / libpre3 under that thread.
+    if (!comm_abort_wait(cm, comm_abort_ms(cm))) {
+        cm->aborter.detach();
+        set_error("pre3_comm_destroy: the abort of the communicator has not returned within %d ms: handle leaked", comm_abort_ms(cm));
+        return PRE3_E_COMM;
+    }
     delete cm;
     return PRE3_OK;
 }

@@ -222,7 +222,15 @@ int comm_all_reduce_i32(void *comm, void *buf, size_t count, hipStream_t st);   
 int comm_all_gather_f64(void *comm, const void *src, void *dst, size_t count_per_rank, hipStream_t st);
 int comm_timeout_ms(void *comm);                                                                   /* deadline of a host wait behind a collective */
 int comm_give_up(void *comm, const char *what);                                                     /* deadline passed: abort, mark broken, PRE3_E_COMM */
-int comm_poll_error(void *comm);                                                                    /* PRE3_E_COMM once the communicator has failed (and is aborted) */
+int comm_poll_error(void *comm);
+int comm_abort_ms(void *comm);                                                                       /* bound of a join of the abort thread (>= 10 s) */
+bool comm_broken(void *comm);                                                                       /* the communicator has been aborted (deadline or asynchronous error) */
+bool comm_abort_wait(void *comm, int ms);                                                           /* an abort started by comm_give_up has returned (joined) within ms; true also when none is running */
+/* Wait until everything queued on a stream has finished.  Without a communicator: hipStreamSynchronize.  With one (a collective may be queued on the
+   stream, and a peer may never enter it): hipStreamQuery polls with the communicator's wall-clock deadline; on expiry the communicator is aborted and the
+   call returns PRE3_E_COMM -- no host wait of the library ends in an unbounded synchronisation behind a collective. */
+int stream_drain_on(hipStream_t st, void *comm, const char *what);
+int stream_drain(pre3_ctx *c, const char *what);                                                                    /* PRE3_E_COMM once the communicator has failed (and is aborted) */
 void comm_rank_world(void *comm, int *rank, int *world);
 int comm_device(void *comm);
 

@@ -516,7 +516,7 @@ int pre3_map_inversedepth_2_cartesian(pre3_ctx *c, double thr, int32_t *converte
         hipLaunchKernelGGL(k_map_convert_flags<float>, dim3(ceil_div(N, 64)), dim3(64), 0, c->stream, N, c->lm.type, c->lm.off, c->x_kk, (const float *)c->P, c->ld, thr, c->map_flags, c->map_conv));
     PRE3_HIP(hipGetLastError());
     std::vector<int32_t> flags(N);
-    PRE3_HIP(hipStreamSynchronize(c->stream));
+    PRE3_TRY(stream_drain(c, __func__));
     PRE3_HIP(hipMemcpy(flags.data(), c->map_flags, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
     if (converted_out) for (int i = 0; i < N; ++i) converted_out[i] = flags[i];
     bool any = false;
@@ -561,7 +561,7 @@ int pre3_map_management(pre3_ctx *c, int n_del, const int32_t *del_idx, double c
             hipLaunchKernelGGL(k_map_convert_flags<double>, dim3(ceil_div(N, 64)), dim3(64), 0, c->stream, N, c->lm.type, c->lm.off, c->x_kk, (const double *)c->P, c->ld, convert_threshold, c->map_flags, c->map_conv),
             hipLaunchKernelGGL(k_map_convert_flags<float>, dim3(ceil_div(N, 64)), dim3(64), 0, c->stream, N, c->lm.type, c->lm.off, c->x_kk, (const float *)c->P, c->ld, convert_threshold, c->map_flags, c->map_conv));
         PRE3_HIP(hipGetLastError());
-        PRE3_HIP(hipStreamSynchronize(c->stream));
+        PRE3_TRY(stream_drain(c, __func__));
         PRE3_HIP(hipMemcpy(flags.data(), c->map_flags, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
     }
     std::vector<int32_t> desc, types, src;

@@ -1600,7 +1600,7 @@ int launch_bank_gather(pre3_ctx *c, int N_new, const int32_t *src_host)
     PRE3_HIP(hipMemcpyAsync(c->bank_src, src_host, sizeof(int32_t) * N_new, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_bank_gather, dim3(N_new), dim3(DESC_DIM), 0, c->stream, c->bank_src, c->bank, c->bank_alt);
     PRE3_HIP(hipGetLastError());
-    PRE3_HIP(hipStreamSynchronize(c->stream));       // src_host is the caller's stack vector
+    PRE3_TRY(stream_drain(c, __func__));       // src_host is the caller's stack vector
     std::swap(c->bank, c->bank_alt);
     return PRE3_OK;
 }
@@ -1866,7 +1866,7 @@ int match_shard_match(void *h, double thresh, double *pairs_out, double *score_o
             if (q != hipErrorNotReady) { set_error("match shard: stream failed: %s", hipGetErrorString(q)); return PRE3_E_HIP; }
         }
     }
-    if (!arrived) { PRE3_HIP(hipStreamSynchronize(sh->st)); PRE3_CHECK(__atomic_load_n(mail_host, __ATOMIC_ACQUIRE) == seq, PRE3_E_HIP, "match shard: the merge kernel did not publish its result"); }
+    if (!arrived) { PRE3_TRY(stream_drain_on(sh->st, sh->comm, "a sharded match")); PRE3_CHECK(__atomic_load_n(mail_host, __ATOMIC_ACQUIRE) == seq, PRE3_E_HIP, "match shard: the merge kernel did not publish its result"); }
     PRE3_CHECK(mail_host[1] == 0, PRE3_E_COMM, "sharded match: %d rank(s) failed before the all-gather (their slices are missing): the match is void on every rank", mail_host[1]);
     const int M = (int)sh->res_host[3 * (size_t)K1];
     if (M > 0) {
@@ -1903,7 +1903,16 @@ int match_shard_test_stall(void *h, int release)
     PRE3_HIP(hipGetLastError());
     return PRE3_OK;
 }
-void match_shard_destroy(void *h) { delete (MatchShard *)h; }
+void match_shard_destroy(void *h)
+{
+    MatchShard *sh = (MatchShard *)h;
+    if (!sh) return;
+    // a collective of this shard may still be queued, or -- after a deadline -- the communicator's abort may still be inside RCCL: the stream is drained
+    // (bounded) and the abort joined before the shard's buffers go
+    if (sh->st) (void)stream_drain_on(sh->st, sh->comm, "pre3_match_shard_destroy");
+    if (sh->comm && comm_abort_wait(sh->comm, comm_abort_ms(sh->comm)) && comm_broken(sh->comm) && sh->st) (void)stream_drain_on(sh->st, sh->comm, "pre3_match_shard_destroy");
+    delete sh;
+}
 
 // matcher bench handle (inputs resident in HBM): cls 2 = uint8 descriptors on the int8 MFMA path; cls 0 / 1 = double / float descriptors on
 // the route their data selects (info: [route, queries scanned in full, candidates re-evaluated] of the last run)

@@ -368,7 +368,11 @@ PRE3_API int pre3_match_shard_destroy(pre3_match_shard *s);
  * caught by a wall-clock deadline on every host wait that has a collective in front of it (pre3_comm_set_timeout; default 10 s): on expiry
  * the communicator is aborted (ncclCommAbort: the collective the stream is stuck in returns), marked broken, and the call returns
  * PRE3_E_COMM; the context (or shard) stays usable once a fresh communicator is attached.  No wait of the library ends in an unbounded
- * synchronisation behind a collective.  A rank whose own part of a round fails BEFORE the collective (a bad table, a failed launch) still
+ * synchronisation behind a collective: with a communicator attached EVERY drain of the context's stream -- pre3_sync, pre3_set_state, the
+ * staging blocks of pre3_set_scan / pre3_set_descriptors / map management, pre3_set_comm, pre3_destroy -- polls the stream against the same
+ * deadline (round 6).  The abort runs on a thread that pre3_set_comm, pre3_comm_destroy, pre3_destroy and pre3_match_shard_destroy join (bounded:
+ * 10 s or the deadline, whichever is longer) before the handle or any buffer the collective touches goes away; while the stream has not
+ * drained after an abort, calls that need it idle keep returning PRE3_E_COMM.  A rank whose own part of a round fails BEFORE the collective (a bad table, a failed launch) still
  * enters it, with an empty slice and a "missing" word that travels with the data: every rank then returns PRE3_E_COMM for that round. */
 #define PRE3_COMM_ID_BYTES 128
 typedef struct pre3_comm pre3_comm;
@@ -377,11 +381,6 @@ PRE3_API int pre3_comm_create(pre3_comm **out, int device, const void *id, int r
 PRE3_API int pre3_comm_destroy(pre3_comm *comm);
 PRE3_API int pre3_comm_info(pre3_comm *comm, int *rank, int *world, int *rccl_version, char *lib_path, int lib_path_len);
 PRE3_API int pre3_comm_set_timeout(pre3_comm *comm, int milliseconds);      /* deadline of the host waits behind this communicator's collectives (default 10000) */
-/* Test hooks: park (release == 0) a kernel on the context's / the shard's stream that spins until released (release == 1; it also gives up by
- * itself after some tens of seconds), so that a test can stand in for a peer that stalls inside a collective.  pre3_match_shard_test_stall(s, 2):
- * the next match's distance kernels "fail" (a rank-local failure in front of the all-gather). */
-PRE3_API int pre3_test_stall(pre3_ctx *ctx, int release);
-PRE3_API int pre3_match_shard_test_stall(pre3_match_shard *s, int release);
 /* attach: the context / the shard borrows `comm` (must be on the same device; NULL detaches).  pre3_comm_init = create + attach, owned by the
  * context and destroyed with it. */
 PRE3_API int pre3_set_comm(pre3_ctx *ctx, pre3_comm *comm);

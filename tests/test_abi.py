@@ -24,6 +24,15 @@ def test_library_exports_every_declared_symbol(pre3):
     assert sorted(pre3._lib.EXPORTS) == names
 
 
+def test_the_test_hooks_are_not_part_of_the_public_header(pre3):
+    """pre3_test_stall / pre3_match_shard_test_stall (3pre_amd/csrc/pre3_test_hooks.h) are exported for tests/test_gpu_comm.py, inert without
+    PRE3_TEST_HOOKS=1, and not declared in include/pre3.h"""
+    txt = open(os.path.join(ROOT, "include", "pre3.h")).read()
+    assert "test_stall" not in txt
+    lib = C.CDLL(pre3.LIB_PATH)
+    assert hasattr(lib, "pre3_test_stall") and hasattr(lib, "pre3_match_shard_test_stall")
+
+
 def test_no_torch_types_in_header():
     txt = open(os.path.join(ROOT, "include", "pre3.h")).read()
     code = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)          # strip comments

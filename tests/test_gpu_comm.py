@@ -99,6 +99,62 @@ def test_on_stream_shard_match_equals_the_oracle(pre3, orc, comm):
         sh.close()
 
 
+@pytest.fixture(autouse=True)
+def _test_hooks_on(monkeypatch):
+    """the stall hooks are inert unless the environment enables them (3pre_amd/csrc/pre3_test_hooks.h)"""
+    monkeypatch.setenv("PRE3_TEST_HOOKS", "1")
+
+
+def test_the_stall_hooks_are_inert_without_the_environment_switch(pre3, monkeypatch):
+    monkeypatch.delenv("PRE3_TEST_HOOKS", raising=False)
+    N = 20
+    seq = synth.make_sequence(N, 1, 8, seed=3)
+    f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", max_hyp=8)
+    with pytest.raises(pre3.Pre3Error) as e:
+        f.test_stall(0)
+    assert e.value.code == -4                                                  # PRE3_E_STATE: nothing was parked
+    f.sync()
+    f.close()
+
+
+@pytest.mark.timeout(120)
+def test_every_drain_behind_a_parked_stream_has_the_deadline(pre3):
+    """Round-5 advisor: stage_wait (pre3_set_scan, pre3_set_descriptors, map management), pre3_set_state and pre3_set_comm used to end in a bare
+    hipStreamSynchronize.  With a communicator on the context every drain of the stream is bounded by its deadline (stream_drain): behind a parked
+    kernel they return PRE3_E_COMM at the deadline, the communicator is aborted, and once the stream has drained the context works again."""
+    import time
+    cm = importlib.import_module("3pre_amd.comm")
+    N, n_draw = 60, 24
+    seq = synth.make_sequence(N, 1, n_draw, seed=35)
+    s = seq["steps"][0]
+    f = pre3.EkfFilter(seq["cam"], np.zeros(N, np.int32), dtype="f32", max_hyp=n_draw)
+    f.set_x_p_k_k(seq["x0"], seq["P0"])
+    c1 = cm.Comm(0, cm.unique_id(), 0, 1)
+    c1.set_timeout(300)
+    f.set_comm(c1)
+    f.test_stall(0)
+    t0 = time.time()
+    with pytest.raises(pre3.Pre3Error) as e:
+        f.set_x_p_k_k(seq["x0"], seq["P0"])                                    # pre3_set_state drains the stream first
+    dt = time.time() - t0
+    assert e.value.code == -7 and 0.25 < dt < 5.0, (e.value.code, dt)
+    t0 = time.time()
+    with pytest.raises(pre3.Pre3Error) as e2:                                  # ... and so does every later drain while the stream is still parked
+        f.sync()
+    assert e2.value.code == -7 and time.time() - t0 < 5.0
+    f.test_stall(1)
+    time.sleep(0.05)
+    c2 = cm.Comm(0, cm.unique_id(), 0, 1)
+    f.set_comm(c2)                                                             # drains (now possible), joins the abort, installs the fresh handle
+    f.set_x_p_k_k(seq["x0"], seq["P0"])
+    f.ekf_prediction(s["u"]); f.search_IC_matches(); f.set_measurements(s["meas_idx"], s["z"])
+    ref = f.ransac_hypotheses(s["hyp"], threshold=1.0, early_exit=False)
+    got = f.ransac_sharded_stream(s["hyp"], 1.0, early_exit=False)
+    assert got["best"] == ref["best"] and np.array_equal(got["support"], ref["support"])
+    f.set_comm(None)
+    f.close(); c1.close(); c2.close()
+
+
 @pytest.mark.timeout(120)
 def test_a_stalled_collective_ends_in_the_deadline_not_in_a_hang(pre3):
     """A peer that stalls inside (or never enters) a collective: the library's host wait has a wall-clock deadline (pre3_comm_set_timeout).  With one
