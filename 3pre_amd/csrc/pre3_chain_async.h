@@ -377,12 +377,7 @@ __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>:
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
-            if constexpr (sizeof(T) == 8) {
-                if (k > 0) {
-#pragma unroll
-                    for (int t = 0; t < MB; ++t) { Lh[t][0] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB]); Lh[t][1] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB + 4]); }
-                }
-            }
+            asm volatile("" ::: "memory");
             a2[0] = T2{ v0[0], v0[1] }; a2[1] = T2{ v0[2], v0[3] }; a2[2] = T2{ v1[0], v1[1] }; a2[3] = T2{ v1[2], v1[3] };
             CHA_STAMP(0, k, 1);
             if (k > 0) {
@@ -392,6 +387,10 @@ __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>:
                     const T2 yp[4] = { T2{ yprev[0], yprev[1] }, T2{ yprev[2], yprev[3] }, T2{ yprev[4], yprev[5] }, T2{ yprev[6], yprev[7] } };
 #pragma unroll
                     for (int t = 0; t < MB; ++t) {
+                        // (fp64: the lookahead's multipliers are read where they are used -- sixty-four doubles at once do not fit the register budget;
+                        //  the fences keep the reads from being hoisted as IR or gathered by the scheduler)
+                        if (t & 1) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+                        Lh[t][0] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB]); Lh[t][1] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB + 4]);
                         T2 s2 = yp[0] * T2{ Lh[t][0][0], Lh[t][0][1] };
                         s2 += yp[1] * T2{ Lh[t][0][2], Lh[t][0][3] };
                         s2 += yp[2] * T2{ Lh[t][1][0], Lh[t][1][1] };
@@ -464,17 +463,15 @@ __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>:
                         for (int h = 0; h < 2; ++h) {
                             La[h][0] = *reinterpret_cast<const v4_t *>(&Ls[C + 4 * h + (lane & 3)][C - MB]); La[h][1] = *reinterpret_cast<const v4_t *>(&Ls[C + 4 * h + (lane & 3)][C - MB + 4]);
                         }
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < MB; ++t) { Lh[t][0] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB]); Lh[t][1] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB + 4]); }
                     }
                 }
                 asm volatile("" ::: "memory");
             };
-            issue_a(0);
+            if constexpr (sizeof(T) == 4) issue_a(0);
 #pragma unroll
             for (int s2 = 0; s2 < NSP; ++s2) {
                 if (s2 >= nsp_eff) continue;
+                if constexpr (sizeof(T) == 8) issue_a(s2);          // (fp64: no prefetch across the solve -- the register budget)
                 const int C = MB * s2, par = s2 & 1;
                 T x[MB], z[MB];
                 v4_t Ld[MB][2], r0, r1;
@@ -489,6 +486,7 @@ __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>:
                     __builtin_amdgcn_s_sleep(1);
                     issue_a(s2);
                 }
+                asm volatile("" ::: "memory");          // (nothing that reads the producers' payload moves above the counters' check)
                 CHA_STAMP(1, s2, 1);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) { x[t] = xa[t]; x[4 + t] = xb[t]; }
@@ -503,10 +501,12 @@ __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>:
                 auto issue_b = [&]() {
                     bF = cha_load(fl + CHF_F);
                     asm volatile("" ::: "memory");
+                    if constexpr (sizeof(T) == 4) {
 #pragma unroll
-                    for (int t = 1; t < MB; ++t) {
-                        Ld[t][0] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C]);
-                        if (t > 4) Ld[t][1] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C + 4]);
+                        for (int t = 1; t < MB; ++t) {
+                            Ld[t][0] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C]);
+                            if (t > 4) Ld[t][1] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C + 4]);
+                        }
                     }
                     r0 = *reinterpret_cast<const v4_t *>(&Rs[s2][0]); r1 = *reinterpret_cast<const v4_t *>(&Rs[s2][4]);
                     asm volatile("" ::: "memory");
@@ -525,6 +525,8 @@ __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>:
                         const T2 zp[4] = { T2{ zprev[0], zprev[1] }, T2{ zprev[2], zprev[3] }, T2{ zprev[4], zprev[5] }, T2{ zprev[6], zprev[7] } };
 #pragma unroll
                         for (int t = 0; t < MB; ++t) {
+                            if (t & 1) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }      // (keeps the reads where they are used -- neither hoisted as IR nor sunk by the scheduler: batched up front they spill)
+                            Lh[t][0] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB]); Lh[t][1] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C - MB + 4]);
                             T2 s2v = zp[0] * T2{ Lh[t][0][0], Lh[t][0][1] };
                             s2v += zp[1] * T2{ Lh[t][0][2], Lh[t][0][3] };
                             s2v += zp[2] * T2{ Lh[t][1][0], Lh[t][1][1] };
@@ -541,15 +543,32 @@ __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>:
                     __builtin_amdgcn_s_sleep(1);
                     issue_b();
                 }
+                asm volatile("" ::: "memory");
                 CHA_STAMP(1, s2, 2);
                 // the next sub-panel's phase A travels while the solve runs (its operand of the lookahead, rows C+8 .. C+15 of Y(s2), is final: see phase B)
-                if (s2 + 1 < NSP && s2 + 1 < nsp_eff) issue_a(s2 + 1);
-                // column-oriented: once z[u] is known every later row takes its term -- the dependent chain is one multiply and one fma per row
+                if constexpr (sizeof(T) == 4) { if (s2 + 1 < NSP && s2 + 1 < nsp_eff) issue_a(s2 + 1); }
+                if constexpr (sizeof(T) == 4) {
+                    // column-oriented: once z[u] is known every later row takes its term -- the dependent chain is one multiply and one fma per row
 #pragma unroll
-                for (int u = 0; u < MB; ++u) {
-                    z[u] = x[u] * (u < 4 ? r0[u & 3] : r1[u & 3]);
+                    for (int u = 0; u < MB; ++u) {
+                        z[u] = x[u] * (u < 4 ? r0[u & 3] : r1[u & 3]);
 #pragma unroll
-                    for (int t = u + 1; t < MB; ++t) x[t] -= (u < 4 ? Ld[t][0][u] : Ld[t][1][u - 4]) * z[u];
+                        for (int t = u + 1; t < MB; ++t) x[t] -= (u < 4 ? Ld[t][0][u] : Ld[t][1][u - 4]) * z[u];
+                    }
+                } else {
+                    // fp64: row by row, a row's multipliers read where they are used (the same terms in the same order)
+#pragma unroll
+                    for (int t = 0; t < MB; ++t) {
+                        T accz = x[t];
+                        if (t & 1) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+                        if (t > 0) Ld[t][0] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C]);
+                        if (t > 4) Ld[t][1] = *reinterpret_cast<const v4_t *>(&Ls[C + t][C + 4]);
+#pragma unroll
+                        for (int u = 0; u < 4 && u < t; ++u) accz -= Ld[t][0][u] * z[u];
+#pragma unroll
+                        for (int u = 4; u < t; ++u) accz -= Ld[t][1][u - 4] * z[u];
+                        z[t] = accz * (t < 4 ? r0[t & 3] : r1[t & 3]);
+                    }
                 }
                 *reinterpret_cast<v4_t *>(&Zt[par][i][0]) = v4_t{ z[0], z[1], z[2], z[3] };
                 *reinterpret_cast<v4_t *>(&Zt[par][i][4]) = v4_t{ z[4], z[5], z[6], z[7] };

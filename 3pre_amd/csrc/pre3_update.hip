@@ -22,6 +22,9 @@
 #include "pre3_geomdev.h"
 #include "pre3_chain.h"
 #include "pre3_chain_async.h"
+#ifndef PRE3_CHAIN_ASYNC_F64
+#define PRE3_CHAIN_ASYNC_F64 0      // the same for fp64: works, but the compiler gathers the lookahead's 64 broadcast reads in front of the factor wave's arithmetic whatever fences sit between them (254 spilled registers) -- fp64 keeps the lock-step chain
+#endif
 #ifndef PRE3_CHAIN_ASYNC
 #define PRE3_CHAIN_ASYNC 1          // fp32 panel chains outside the persistent kernel (k_chol_step, k_hi_fused) on the flag-driven form; 0: the lock-step chain of rounds 2-5
 #endif
@@ -422,7 +425,7 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
                     for (int e = 0; e < M::NREG; ++e) {
                         const int r = w0 + p * M::BLK + M::row(lane, e), c = w1 + q * M::BLK + M::col(lane);
                         acc[p][q][e] = (xside ? Xs[r][c] : Ls[r][c]) - pacc[p][q][e];
-                        if (sizeof(T) == 4 && PRE3_CHAIN_ASYNC && !xside) Ls[r][c] = acc[p][q][e];      // (the flag-driven chain's D workers read Ls)
+                        if (((sizeof(T) == 4 && PRE3_CHAIN_ASYNC) || (sizeof(T) == 8 && PRE3_CHAIN_ASYNC_F64)) && !xside) Ls[r][c] = acc[p][q][e];      // (the flag-driven chain's D workers read Ls)
                     }
         }
         acc_loaded = true;
@@ -434,7 +437,7 @@ __device__ __forceinline__ void chol_panel_body(ChSmem<T> &sm, T *__restrict__ S
     const int nsp_eff = (rows_last > 0 && J == nrb - 1) ? (rows_last + CH_MB - 1) / CH_MB : CH_NSP;
     // (EARLY is a KERNEL variant: the step-skipping form's uniform branches cost a full chain ~6 % -- measured in the persistent kernel, 14.35 k ->
     // 15.3 k cycles per panel -- and both forms in one kernel spill; the host launches it for a last panel that really has padding)
-    if constexpr (sizeof(T) == 4 && PRE3_CHAIN_ASYNC) {
+    if constexpr ((sizeof(T) == 4 && PRE3_CHAIN_ASYNC) || (sizeof(T) == 8 && PRE3_CHAIN_ASYNC_F64)) {
         // round 6: fp32 takes the flag-driven chain (no barrier per pipeline step; the step-skipping form costs it nothing, so EARLY or not is one code).
         // worker_init: the X workers keep the tile the prologue left in `acc`; the D workers' went back to Ls above.
         chol_chain_async<T, false, false>(sm, acc, acc_loaded, hasX, bad, ChaNoSide{},
