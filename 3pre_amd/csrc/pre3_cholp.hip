@@ -194,6 +194,7 @@ struct CpArgs {
     int stride;                          // crit and the rows are blocks 0, stride, 2 stride, ..
     int n; const double *x_prior; double *x_out; double *params; int xu;      // xu: the strips finish with x_out = x_prior + W'(L^-1 nu) (update.m:36,42,48)
     float *P; const int32_t *dd; int n_dd; int rows; int dd_mode; int poll_budget, poll_from; float *jn_q;      // (jn_q: rows 3..6 of the down-dated P, before update.m:42-46, for the gate that rides with that pass)      // down-date consumers: group table (DG_WORDS each), groups in this launch, rows if host-known
+    int strip_rl;                        // strips: the right-looking, flag-driven panel loop (strip_rl_loop; round 6)
     int proj;                            // the strips end with the rescue stage's projection of every landmark at x_k_k (strip_proj_body; tables in CpTail's LDS slot)
     int tail;                            // the rescue stage and the HI update follow inside this launch (CpTail): the HI rows are panel `nrb` of the same factorisation
     float *Wt; int kcap;                 // tail: W once more, column-major (column j at Wt + j * kcap, k contiguous): what the gate's y = H J W' reads
@@ -1623,6 +1624,150 @@ __device__ __attribute__((noinline)) void strip_proj_body(int s_v)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Round 6: the strip's panel loop RIGHT-LOOKING and flag-driven (PRE3_STRIP_RL, default).  The left-looking loop below sums, in front of every M_J,
+// J blocks L(J+1, K) W_K whose L fragments (J x 24.6 KB per strip and panel, the same bytes for all 97 strips at the same moment) bound it at 2-2.7 us
+// per panel from J = 5 on -- after round 6's crit a strip's panel (8.5-8.7 us) was longer than crit's (8.0) and the strips finished ~3 us behind it --,
+// and its fifteen workgroup barriers per panel couple all eight waves to whichever is slowest.  Here every 32 x 32 tile of the right-hand side has ONE
+// owner wave (tile (j, fa) of C_j = HP_j - sum_K L(j, K) W_K: wave fa + 2 (j mod 4)) that holds it as an accumulator from start to finish and adds
+// L(j, J) W_J to it as soon as W_J exists -- the fragments of L(j, J) are then wanted by two waves at a time, spread over the whole panel, and only
+// the term j = J+1 is urgent.  The critical path of a panel is one owner pair's:  C_J -> planes (v_permlane32_swap: no transposition buffer) -> W_J[fa] =
+// M_J[fa rows] C_J (24 MFMAs, no reduction) -> planes -> the next pair's C_{J+1} += L(J+1, J) W_J (its fragments requested before W_J is there).
+// Hand-offs inside the workgroup are LDS counters (pre3_chain_async.h's recipe: payload, then counter; counter read first), no barrier in the loop.
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr int RL_MAXT = 4;                           // tiles per wave: row blocks j = par + 4 t < nrb <= 16
+enum { RLF_C0 = 0 /* + fa: C_J's planes of row half fa are in CPb (value J + 1) */, RLF_W0 = 2 /* + fa: W_J's */, RLF_DR0 = 4 /* + (J & 3): waves of panel J whose stores have drained */,
+       RLF_PUB = 8 /* panels whose consumer flag is up */, RLF_N = 12 };
+// a wave's 32 x 32 accumulator (rows = k of the next product) -> its granules of the B-operand planes: k-steps 2 fa + g2, this lane's eight consecutive k
+template <typename F>
+__device__ __forceinline__ void rl_acc_granules(const f32x16_t &v, const float sign, F &&fn)
+{
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = sign * v[8 * g2 + j], hi = sign * v[8 * g2 + 4 + j];
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+            const unsigned s0 = sw[0], s1 = sw[1];
+            x[j] = __uint_as_float(s0); x[4 + j] = __uint_as_float(s1);
+        }
+        u32x4_t p0, p1, p2;
+        b3_split3(x, p0, p1, p2);
+        fn(g2, x, p0, p1, p2);
+    }
+}
+__device__ __forceinline__ void strip_rl_loop(const CpArgs &a, const int nrb, const int s, frag_t *WPl, frag_t *CPb, unsigned *sf)
+{
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int fa = wave & 1, par = wave >> 1, win = a.win;
+    const int c0 = s * 32;
+    const bool nu_strip = c0 == a.ld, publish = a.n_dd > 0 || a.xu != 0, to_wp = c0 < a.ld + NB;
+    int32_t *guard = a.status + 1;
+    const __amdgpu_buffer_rsrc_t rW = cp_rsrc(a.W), rSp = cp_rsrc(a.Sp), rWp = cp_rsrc(a.Wp);
+    const unsigned wvoff = acc_voff(lane, a.ldw) + (unsigned)((32 * fa) * a.ldw + c0) * 4u;
+    const unsigned plo = (unsigned)(fa * 64 + lane) * 16u;
+    if (tid < RLF_N) sf[tid] = 0u;
+    // this wave's tiles: C[t] = sum_K L(j, K) W_K - HP_j, j = par + 4 t (the raw rows, cold in HBM, are all requested now)
+    f32x16_t C[RL_MAXT];
+#pragma unroll
+    for (int t = 0; t < RL_MAXT; ++t) {
+        const int j = par + 4 * t;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) C[t][e] = j < nrb ? -ld_f32(rW, wvoff, (unsigned)(j * NB * a.ldw) * 4u + acc_soff(e, a.ldw)) : 0.f;
+    }
+    __syncthreads();                                                     // (the counters are reset)
+    frag_t fA[4][3];
+    auto load_A = [&](const unsigned blk) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) fA[q][pl] = ld_granule(rSp, plo, blk + q * 384 + pl * 128, 1);
+    };
+    auto lds_wait2 = [&](const int k0, const unsigned need) {            // both halves' counters
+        if (!cha_wait(sf + k0, need) || !cha_wait(sf + k0 + 1, need)) { if (lane == 0) atomicExch(guard, 1); }
+    };
+#define RL_MMA(acc_, fa_, bb) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa_), __builtin_bit_cast(bf16x8_t, bb), acc_, 0, 0, 0)
+    for (int J = 0; J < nrb; ++J) {
+        if ((J & 3) == par) {
+            // ---- this wave owns C_J (row half fa): (1) its planes -> CPb
+            const int tJ = J >> 2;
+            f32x16_t cj;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) cj[e] = tJ == 0 ? C[0][e] : tJ == 1 ? C[1][e] : tJ == 2 ? C[2][e] : C[3][e];
+            rl_acc_granules(cj, -1.f, [&](int g2, const float (&)[8], u32x4_t p0, u32x4_t p1, u32x4_t p2) {
+                frag_t *d = CPb + (2 * fa + g2) * 192 + lane;
+                d[0] = __builtin_bit_cast(frag_t, p0); d[64] = __builtin_bit_cast(frag_t, p1); d[128] = __builtin_bit_cast(frag_t, p2);
+            });
+            cha_store(sf + RLF_C0 + fa, (unsigned)J + 1, lane);
+            if (fa == 0 && (s == 0 || s == a.n_strips - 1)) CP_STAMP(s == 0 ? 16 : 17, J, 3);
+            // (2) M_J's fragments (this row half, all four k-steps) as soon as its flag is up; (3) the other half's planes of C_J
+            wave_wait(a.cf + CF_MP, a.base + (unsigned)J + 1, guard);
+            if (fa == 0 && (s == 0 || s == a.n_strips - 1)) CP_STAMP(s == 0 ? 16 : 17, J, 1);
+            load_A((unsigned)(J * a.sp_stride + J) * B3_SGRAN);
+            lds_wait2(RLF_C0, (unsigned)J + 1);
+            f32x16_t wacc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) wacc[e] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const frag_t b0 = CPb[q * 192 + lane], b1 = CPb[q * 192 + 64 + lane], b2 = CPb[q * 192 + 128 + lane];
+                RL_MMA(wacc, fA[q][0], b0); RL_MMA(wacc, fA[q][0], b1); RL_MMA(wacc, fA[q][1], b0); RL_MMA(wacc, fA[q][1], b1); RL_MMA(wacc, fA[q][0], b2); RL_MMA(wacc, fA[q][2], b0);
+            }
+            if (fa == 0 && (s == 0 || s == a.n_strips - 1)) CP_STAMP(s == 0 ? 16 : 17, J, 5);
+            // (4) W_J[fa]: f32 to memory (the x-update and k_gain read it; the nu column written through: every strip reads it), planes to the ring slot
+            //     and -- write-through -- to k_downdate_b3's image
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                if (nu_strip) st_f32_sc1(wacc[e], rW, wvoff, (unsigned)(J * NB * a.ldw) * 4u + acc_soff(e, a.ldw));
+                else st_f32(wacc[e], rW, wvoff, (unsigned)(J * NB * a.ldw) * 4u + acc_soff(e, a.ldw));
+            }
+            rl_acc_granules(wacc, 1.f, [&](int g2, const float (&)[8], u32x4_t p0, u32x4_t p1, u32x4_t p2) {
+                const int q = 2 * fa + g2;
+                frag_t *d = WPl + (size_t)(J % win) * CP_WGRAN + q * 192 + lane;
+                d[0] = __builtin_bit_cast(frag_t, p0); d[64] = __builtin_bit_cast(frag_t, p1); d[128] = __builtin_bit_cast(frag_t, p2);
+                if (to_wp) {
+                    const unsigned gb = (unsigned)((((size_t)(c0 >> 7) * a.nst_total + 4 * J + q) * B3_GRAN + ((c0 >> 5) & 3) * 64 + lane) * 16u);
+                    st16_sc1(p0, rWp, gb); st16_sc1(p1, rWp, gb + 256 * 16); st16_sc1(p2, rWp, gb + 512 * 16);
+                }
+            });
+            cha_store(sf + RLF_W0 + fa, (unsigned)J + 1, lane);
+            if (fa == 0 && (s == 0 || s == a.n_strips - 1)) CP_STAMP(s == 0 ? 16 : 17, J, 2);
+            // (5) the consumers' flag: once both halves' stores have drained, in panel order.  This wave has nothing urgent now (the next panel's pair is
+            //     another one): it waits for its own stores here
+            if (publish) {
+                drain_stores();
+                unsigned old = 0;
+                if (lane == 0) old = atomicAdd(&sf[RLF_DR0 + (J & 3)], 1u);
+                if (__builtin_amdgcn_readfirstlane((int)old) == 1) {
+                    if (!cha_wait(sf + RLF_PUB, (unsigned)J)) { if (lane == 0) atomicExch(guard, 1); }
+                    if (lane == 0) { sf[RLF_DR0 + (J & 3)] = 0u; cf_store(cf_strip(a.cf, s), a.base + (unsigned)J + 1); }
+                    cha_store(sf + RLF_PUB, (unsigned)J + 1, lane);
+                }
+            }
+        }
+        // ---- W_J into this wave's tiles j > J (ascending: j = J + 1, the next panel's right-hand side, first)
+#pragma unroll
+        for (int t = 0; t < RL_MAXT; ++t) {
+            const int j = par + 4 * t;
+            if (j <= J || j >= nrb) continue;
+            wave_wait(cf_rowL(a.cf, j), a.base + (unsigned)J + 1, guard);     // L(j, J) is out (j = J + 1: crit's; else row j's)
+            if (j == J + 1 && fa == 0 && (s == 0 || s == a.n_strips - 1)) CP_STAMP(s == 0 ? 16 : 17, J, 6);
+            load_A((unsigned)(j * a.sp_stride + J) * B3_SGRAN);                // ... and on its way before W_J is waited for
+            lds_wait2(RLF_W0, (unsigned)J + 1);
+            const frag_t *wb = WPl + (size_t)(J % win) * CP_WGRAN + lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const frag_t b0 = wb[q * 192], b1 = wb[q * 192 + 64], b2 = wb[q * 192 + 128];
+                RL_MMA(C[t], fA[q][0], b0); RL_MMA(C[t], fA[q][0], b1); RL_MMA(C[t], fA[q][1], b0); RL_MMA(C[t], fA[q][1], b1); RL_MMA(C[t], fA[q][0], b2); RL_MMA(C[t], fA[q][2], b0);
+            }
+            if (j == J + 1 && fa == 0 && (s == 0 || s == a.n_strips - 1)) CP_STAMP(s == 0 ? 16 : 17, J, 7);
+        }
+    }
+#undef RL_MMA
+    __syncthreads();
+}
+
 __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int rows_v, int s_v)
 {
     const CpArgs a = cp_uniform(a_v);
@@ -1707,6 +1852,9 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
     // K = par (mod 4); the newest block K = J-1 is split by k-steps instead).  It is accumulated AHEAD of need: the terms K <= J-2 of step J
     // while the strip waits for M_{J-1}, the last term as soon as W_{J-1} exists -- when M_J arrives only one product and the epilogue are left.
     if (a.tail) gate_prefetch(rows_v, s);                             // (table entries of the rescue gate's first round: see gate_prefetch)
+    if (a.strip_rl && !a.tail && nrb <= 4 * RL_MAXT) {
+        strip_rl_loop(a, nrb, s, WPl, CP, reinterpret_cast<unsigned *>(Yw2));
+    } else {
     f32x16_t acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = par == 0 ? -ld_f32(rW, wvoff, acc_soff(e, a.ldw)) : 0.f;
@@ -1855,6 +2003,7 @@ __device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int 
     }
 #undef ST_MMA
 #undef SM_MMA
+    }
     // ---- update.m:36,42,48 for this strip's 32 states: x_out = x_prior + W'(L^-1 nu), the normalisation Jacobian at the un-normalised quaternion
     //      -> params, the quaternion normalised.  Sixteen chains (chain g: rows a = g mod 16, in order), summed 0 .. 15, x_prior last -- term for
     //      term the sums of update_x_block / k_update_x, so x_k_k is the same bits whichever of them ran.  W is this strip's own (its stores have
@@ -2632,6 +2781,8 @@ int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior, c
     a.poll_budget = poll_budget;
     static const int poll_from = getenv("PRE3_CHOLP_POLL_FROM") ? atoi(getenv("PRE3_CHOLP_POLL_FROM")) : 3;
     a.poll_from = poll_from;
+    static const int strip_rl = getenv("PRE3_STRIP_RL") ? atoi(getenv("PRE3_STRIP_RL")) : 1;
+    a.strip_rl = strip_rl;
     // every group of P's tiles is in this launch and the strips finish x: the consumers also leave rows 3..6 behind for the gate (GateRide, pre3_geom.hip)
     a.jn_q = (!tail && n_dd > 0 && n_dd == c->dd_n_groups && c->jn_q != nullptr) ? c->jn_q : nullptr;
     c->jn_q_valid = a.jn_q != nullptr;
