@@ -71,6 +71,9 @@ static __device__ unsigned long long g_cha[8 * 12 * 4];         // [role: 0 F, 1
 #ifndef CHA_DBUSY
 #define CHA_DBUSY true
 #endif
+#ifndef CHA_PREFETCH_POS
+#define CHA_PREFETCH_POS 0  // where the factor wave requests the next sub-panel's columns: 0 in front of its own LDS writes (end of the step), 1 in front of the column loop (CHA_LA = 2: they are out a step earlier)
+#endif
 #ifndef CHA_PREFETCH
 #define CHA_PREFETCH 1
 #endif
@@ -399,6 +402,16 @@ __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>:
                     }
                 }
             }
+            auto prefetch_next = [&]() {
+                if (CHA_PREFETCH && k + 1 < NSP && k + 1 < nsp_eff) {
+                    const int Cn = C + MB;
+                    pf0 = cha_load(fl + CHF_D0 + (Cn < 32 ? 0 : 3)); pf1 = cha_load(fl + CHF_D0 + (Cn < 32 ? 2 : 3));
+                    asm volatile("" ::: "memory");
+                    pv0 = *reinterpret_cast<const v4_t *>(&Pn[parn][i][0]); pv1 = *reinterpret_cast<const v4_t *>(&Pn[parn][i][4]);
+                    asm volatile("" ::: "memory");
+                }
+            };
+            if (CHA_PREFETCH_POS == 1) prefetch_next();
             // right-looking inside the sub-panel, division-free on the dependent chain (as chol_chain)
 #pragma unroll
             for (int c = 0; c < MB; ++c) {
@@ -418,13 +431,7 @@ __device__ __forceinline__ void chol_chain_async(ChSmem<T> &sm, typename ChW<T>:
                 y[c] = ac * rsv[c];
             }
             CHA_STAMP(0, k, 2);
-            if (CHA_PREFETCH && k + 1 < NSP && k + 1 < nsp_eff) {
-                const int Cn = C + MB;
-                pf0 = cha_load(fl + CHF_D0 + (Cn < 32 ? 0 : 3)); pf1 = cha_load(fl + CHF_D0 + (Cn < 32 ? 2 : 3));
-                asm volatile("" ::: "memory");
-                pv0 = *reinterpret_cast<const v4_t *>(&Pn[parn][i][0]); pv1 = *reinterpret_cast<const v4_t *>(&Pn[parn][i][4]);
-                asm volatile("" ::: "memory");
-            }
+            if (CHA_PREFETCH_POS == 0) prefetch_next();
             *reinterpret_cast<v4_t *>(&Ls[i][C]) = v4_t{ y[0], y[1], y[2], y[3] };
             *reinterpret_cast<v4_t *>(&Ls[i][C + 4]) = v4_t{ y[4], y[5], y[6], y[7] };
             if (i == 0) {

@@ -194,6 +194,8 @@ struct CpArgs {
     int stride;                          // crit and the rows are blocks 0, stride, 2 stride, ..
     int n; const double *x_prior; double *x_out; double *params; int xu;      // xu: the strips finish with x_out = x_prior + W'(L^-1 nu) (update.m:36,42,48)
     float *P; const int32_t *dd; int n_dd; int rows; int dd_mode; int poll_budget, poll_from; float *jn_q;      // (jn_q: rows 3..6 of the down-dated P, before update.m:42-46, for the gate that rides with that pass)      // down-date consumers: group table (DG_WORDS each), groups in this launch, rows if host-known
+    int row_late;                        // rows: in a row's last panel L(i, J)'s flag goes up with the tiles for crit (round 6)
+    int crit_early;                      // crit: the last panel's chain stops behind its last real sub-panel (round 6)
     int strip_rl;                        // strips: the right-looking, flag-driven panel loop (strip_rl_loop; round 6)
     int proj;                            // the strips end with the rescue stage's projection of every landmark at x_k_k (strip_proj_body; tables in CpTail's LDS slot)
     int tail;                            // the rescue stage and the HI update follow inside this launch (CpTail): the HI rows are panel `nrb` of the same factorisation
@@ -630,7 +632,7 @@ struct CritDInit {
 // -> barrier -> chain (waves 0-9) beside the publisher (wave 10: columns of L_JJ to S and rows of M_J to planes as the factor / z wave finish
 // them) and the fetcher (wave 11: row J+1's two tiles by LDS-DMA; it may now block on memory -- no barrier waits for it until the chain is over)
 // -> barrier (b0) -> first product L(J+1, J) = A M_J' (waves 0-3), M_J's flag (wave 10) -> barrier (b2) -> L(J+1, J)'s planes leave (wave 10).
-__device__ __forceinline__ void crit_loop_async(const CpArgs &a, int nrb, CritSmem &sm)
+__device__ __forceinline__ void crit_loop_async(const CpArgs &a, int nrb, int rows, CritSmem &sm)
 {
     auto &Ls = sm.ch.Ls; auto &Xs = sm.ch.Xs;
     float *T2 = &sm.ch.Bs[0][0];                                 // A(J+1, J+1), f32 [64][64]
@@ -644,6 +646,10 @@ __device__ __forceinline__ void crit_loop_async(const CpArgs &a, int nrb, CritSm
     bool loaded = false;                                         // false: the pass's first panel, Ls / Xs hold the block and the identity
     for (int J = j0; J < j1; ++J) {
         const bool more = J + 1 < j1;
+        // the update's last panel: the sub-panels behind its last real row are padding (identity columns of S against zero rows of [HP | nu]); the
+        // flag-driven chain skips them at no cost to the others (the lock-step chain's step-skipping form cost every panel 6 %: rounds 3-5 ran all ten
+        // steps here), and the publishers send the identity in their place
+        const int nsp_eff = (pass == 0 && J == nrb - 1 && a.crit_early) ? __builtin_amdgcn_readfirstlane((rows - J * NB + CH_MB - 1) / CH_MB) : CH_NSP;
         if (tid0 == 0) { CP_STAMP(0, J, 0); CP_CLK(19, J, 0); }
         // rows 8 sp .. 8 sp + 7 of M_J (final once the z wave has passed them) -> planes in LDS (the first product's operand) and in Sp(J, J) (the rows'
         // and strips'): one wave, 8 consecutive c of one row per lane
@@ -655,7 +661,7 @@ __device__ __forceinline__ void crit_loop_async(const CpArgs &a, int nrb, CritSm
             const int arow = 8 * sp + (lane >> 3), cg = lane & 7;
             float x[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = Xs[arow][8 * cg + j];
+            for (int j = 0; j < 8; ++j) x[j] = sp < nsp_eff ? Xs[arow][8 * cg + j] : (arow == 8 * cg + j ? 1.f : 0.f);
             u32x4_t p0, p1, p2;
             b3_split3(x, p0, p1, p2);
             const int q = cg >> 1, h = cg & 1, half = arow >> 5, r = arow & 31;
@@ -684,6 +690,7 @@ __device__ __forceinline__ void crit_loop_async(const CpArgs &a, int nrb, CritSm
                                 for (int u = 0; u < 2; ++u) {
                                     const int c4 = C + 4 * u;
                                     f4v_t w = *reinterpret_cast<const f4v_t *>(&Ls[i][c4]);
+                                    if (sp >= nsp_eff) w = f4v_t{ c4 == i ? 1.f : 0.f, c4 + 1 == i ? 1.f : 0.f, c4 + 2 == i ? 1.f : 0.f, c4 + 3 == i ? 1.f : 0.f };
                                     w.x = c4 <= i ? w.x : 0.f; w.y = c4 + 1 <= i ? w.y : 0.f; w.z = c4 + 2 <= i ? w.z : 0.f; w.w = c4 + 3 <= i ? w.w : 0.f;
                                     *reinterpret_cast<f4v_t *>(a.S + (size_t)(J * NB + i) * lds + J * NB + c4) = w;
                                 }
@@ -760,7 +767,7 @@ __device__ __forceinline__ void crit_loop_async(const CpArgs &a, int nrb, CritSm
                         for (int e = 0; e < 16; ++e) ac[0][0][e] = (fa == fb && acc_row(e, lane) == (lane & 31)) ? 1.f : 0.f;
                     }
                 },
-                CritDInit{ &sm, loaded });
+                CritDInit{ &sm, loaded }, nsp_eff);
         }
         // (the chain's last barrier = b0: Ls = L_JJ, Xs = M_J, MPl complete, T1p / T2 landed)
         if (tid0 == 0) { CP_STAMP(0, J, 1); CP_CLK(19, J, 1); CP_STAMP(0, J, 2); }
@@ -824,12 +831,12 @@ constexpr size_t CP_PART_OFF = (CP_TAIL_OFF + sizeof(TailSmem) + 127) / 128 * 12
 static_assert(CP_PART_OFF + 6 * 32 * 33 * sizeof(float) <= 160 * 1024 - 1024, "crit's LDS with the tail");
 static_assert(offsetof(CritSmem, T1p) == offsetof(CritSmem, MPl) + sizeof(frag_t) * B3_SGRAN, "crit_tail keeps (H J P) at the landmark columns in MPl | T1p");
 
-__device__ __forceinline__ void crit_body(const CpArgs &a, int nrb, unsigned char *smem_raw)
+__device__ __forceinline__ void crit_body(const CpArgs &a, int nrb, int rows, unsigned char *smem_raw)
 {
     CritSmem &sm = *reinterpret_cast<CritSmem *>(smem_raw);
     crit_prologue(a, nrb, sm);
 #if PRE3_CRIT_ASYNC
-    crit_loop_async(a, nrb, sm);
+    crit_loop_async(a, nrb, rows, sm);
 #else
     if (threadIdx.x < 640) crit_main(a, nrb, sm);
     else crit_side(a, nrb, sm);
@@ -1143,10 +1150,12 @@ __device__ __attribute__((noinline)) void row_body(CpArgs a_v, int nrb_v, int i_
                 const unsigned gb = ((unsigned)(i * a.sp_stride + J) * B3_SGRAN + gi) * 16u;
                 st16_sc1(p0, rSp, gb); st16_sc1(p1, rSp, gb + 128 * 16); st16_sc1(p2, rSp, gb + 256 * 16);
             });
-            drain_stores();
+            // (round 6: in the row's LAST panel these waves go straight on to the tile crit waits for; L(i, J)'s publication -- wanted by the rows below and
+            //  the strips, not by crit -- rides with that tile's drain and flag, ~2.5 us later, instead of standing 1 us in front of it: rl_last)
+            if (!(last && a.row_late)) drain_stores();
         }
         __syncthreads();                                        // OL complete and drained; every tile store of the previous panel is ordered
-        if (tid == 0) { cf_store(cf_rowL(a.cf, i), a.base + (unsigned)J + 1); if (i < 16) CP_STAMP(i, J, 1); }
+        if (tid == 0 && !(last && a.row_late)) { cf_store(cf_rowL(a.cf, i), a.base + (unsigned)J + 1); if (i < 16) CP_STAMP(i, J, 1); }
         if (last && wave >= 4 && wave < 8) {
             // the diagonal tile A(i, i) -= L(i, J) L(i, J)' needs nothing from outside: waves 4-7 (idle in the row's last panel) send it to crit (in f32)
             // while waves 0-3 wait for L(J+1, J) and build the other tile  (round 5: the two tiles used to follow each other on waves 0-3, and crit had
@@ -1174,7 +1183,7 @@ __device__ __attribute__((noinline)) void row_body(CpArgs a_v, int nrb_v, int i_
             wave_lds_sync();
             drain_stores();
             if (lane == 0 && wave == 4 && i < 16) CP_STAMP(i, J, 3);
-            if (lane == 0 && atomicAdd(&sm.cnt[0], 1u) == 7u) { cf_store(cf_rowA(a.cf, i), a.base + 2u); if (i < 16) CP_STAMP(i, J, 4); }
+            if (lane == 0 && atomicAdd(&sm.cnt[0], 1u) == 7u) { if (a.row_late) cf_store(cf_rowL(a.cf, i), a.base + (unsigned)J + 1); cf_store(cf_rowA(a.cf, i), a.base + 2u); if (i < 16) CP_STAMP(i, J, 4); }
         }
         if (wave < 4) {
             // ---- the tile the next panel starts from: A(i, J+1) -= L(i, J) L(J+1, J)'
@@ -1204,7 +1213,7 @@ __device__ __attribute__((noinline)) void row_body(CpArgs a_v, int nrb_v, int i_
                     st16_sc1(p0, rTp, gb); st16_sc1(p1, rTp, gb + 128 * 16); st16_sc1(p2, rTp, gb + 256 * 16);
                 });
                 drain_stores();
-                if (lane == 0 && atomicAdd(&sm.cnt[0], 1u) == 7u) { cf_store(cf_rowA(a.cf, i), a.base + 2u); if (i < 16) CP_STAMP(i, J, 4); }
+                if (lane == 0 && atomicAdd(&sm.cnt[0], 1u) == 7u) { if (a.row_late) cf_store(cf_rowL(a.cf, i), a.base + (unsigned)J + 1); cf_store(cf_rowA(a.cf, i), a.base + 2u); if (i < 16) CP_STAMP(i, J, 4); }
             }
         }
         if (!last) {
@@ -2540,7 +2549,7 @@ __global__ __launch_bounds__(CP_NTH) void k_cholp(CpArgs a, CpTail t)
 #endif
     if (b % stride == 0 && b / stride <= nH) {
         const int r = b / stride;
-        if (r == 0) { if (CP_TEST_ROLE & 1) crit_body(a, nrb, cp_smem); return; }
+        if (r == 0) { if (CP_TEST_ROLE & 1) crit_body(a, nrb, rows, cp_smem); return; }
         const int i = r + 1;
         if ((CP_TEST_ROLE & 2) && i < nrb) row_body(a, nrb, i);
         return;
@@ -2781,6 +2790,10 @@ int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior, c
     a.poll_budget = poll_budget;
     static const int poll_from = getenv("PRE3_CHOLP_POLL_FROM") ? atoi(getenv("PRE3_CHOLP_POLL_FROM")) : 3;
     a.poll_from = poll_from;
+    static const int row_late = getenv("PRE3_ROW_LATE") ? atoi(getenv("PRE3_ROW_LATE")) : 0;      // measured (round 6): 5625 vs 5644 steps/s -- crit does not wait for the rows at present
+    a.row_late = row_late;
+    static const int crit_early = getenv("PRE3_CRIT_EARLY") ? atoi(getenv("PRE3_CRIT_EARLY")) : 1;
+    a.crit_early = crit_early;
     static const int strip_rl = getenv("PRE3_STRIP_RL") ? atoi(getenv("PRE3_STRIP_RL")) : 1;
     a.strip_rl = strip_rl;
     // every group of P's tiles is in this launch and the strips finish x: the consumers also leave rows 3..6 behind for the gate (GateRide, pre3_geom.hip)
