@@ -1698,13 +1698,14 @@ __device__ __forceinline__ void strip_rl_loop(const CpArgs &a, const int nrb, co
     };
 #define RL_MMA(acc_, fa_, bb) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa_), __builtin_bit_cast(bf16x8_t, bb), acc_, 0, 0, 0)
     for (int J = 0; J < nrb; ++J) {
-        if ((J & 3) == par) {
-            // ---- this wave owns C_J (row half fa): (1) its planes -> CPb
-            const int tJ = J >> 2;
-            f32x16_t cj;
+        // (the owner's part is instantiated per tile slot: a run-time index into the register tiles would copy one -- sixteen more registers beside
+        //  four tiles and twelve fragments -- and the tiles came back as scratch traffic: +18 MB written per launch, measured)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) cj[e] = tJ == 0 ? C[0][e] : tJ == 1 ? C[1][e] : tJ == 2 ? C[2][e] : C[3][e];
-            rl_acc_granules(cj, -1.f, [&](int g2, const float (&)[8], u32x4_t p0, u32x4_t p1, u32x4_t p2) {
+        for (int tJ = 0; tJ < RL_MAXT; ++tJ) {
+        if (J == par + 4 * tJ) {
+            // ---- this wave owns C_J (row half fa): (1) its planes -> CPb
+            f32x16_t &wacc = C[tJ];                                       // (C_J is spent once its planes are out: the slot takes W_J)
+            rl_acc_granules(C[tJ], -1.f, [&](int g2, const float (&)[8], u32x4_t p0, u32x4_t p1, u32x4_t p2) {
                 frag_t *d = CPb + (2 * fa + g2) * 192 + lane;
                 d[0] = __builtin_bit_cast(frag_t, p0); d[64] = __builtin_bit_cast(frag_t, p1); d[128] = __builtin_bit_cast(frag_t, p2);
             });
@@ -1715,7 +1716,6 @@ __device__ __forceinline__ void strip_rl_loop(const CpArgs &a, const int nrb, co
             if (fa == 0 && (s == 0 || s == a.n_strips - 1)) CP_STAMP(s == 0 ? 16 : 17, J, 1);
             load_A((unsigned)(J * a.sp_stride + J) * B3_SGRAN);
             lds_wait2(RLF_C0, (unsigned)J + 1);
-            f32x16_t wacc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) wacc[e] = 0.f;
 #pragma unroll
@@ -1754,6 +1754,7 @@ __device__ __forceinline__ void strip_rl_loop(const CpArgs &a, const int nrb, co
                     cha_store(sf + RLF_PUB, (unsigned)J + 1, lane);
                 }
             }
+        }
         }
         // ---- W_J into this wave's tiles j > J (ascending: j = J + 1, the next panel's right-hand side, first)
 #pragma unroll

@@ -812,7 +812,7 @@ def main():
         fused = kt["launches"] > 0 and kt["fused"] == kt["launches"]                  # every bracketed launch was k_cholp with the down-date inside
         mean_r = (kt["flops"] / max(kt["launches"], 1)) / (n * (n + 1.0))
         traffic, traffic_src = None, None
-        for tag, key in (("r5", "pmc_cholp"), ("r4", "pmc_cholp"), ("r3", "pmc_k9")) if fused else (("r3", "pmc_k9"), ("r2", "pmc_k9"), ("r1", "pmc_k9")):
+        for tag, key in (("r6", "pmc_cholp"), ("r5", "pmc_cholp"), ("r4", "pmc_cholp"), ("r3", "pmc_k9")) if fused else (("r3", "pmc_k9"), ("r2", "pmc_k9"), ("r1", "pmc_k9")):
             try:     # HBM bytes per LI launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
                 with open(os.path.join(ROOT, "profiles", "%s_%s.json" % (tag, key))) as fh:
                     pj = json.load(fh)
@@ -844,7 +844,7 @@ def main():
                                            "executed_bf16_frac_of_peak": 6.0 * achieved / PEAK["bf16"],
                                            "note": "the SYRK count alone over the SAME duration (the launch also holds the factorisation's 60-us dependent chain): "
                                                    "what north_star's 'P-update >= 60 % of the fp32 MFMA roofline' would read if the whole launch were charged to K9; "
-                                                   "the consumers' own matrix-pipe occupancy is in profiles/r5_pmc_cholp.json"})
+                                                   "the consumers' own matrix-pipe occupancy is in profiles/r6_pmc_cholp.json"})
         else:
             algo = ("symmetric rank-r down-date (SYRK): n(n+1)r flop per launch, r = rows of that update, averaged over the K9 launches of "
                     "the timed region that were bracketed with HIP events: one in --kt-every of the launches with >= 128 rows, i.e. the LI "

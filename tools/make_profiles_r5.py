@@ -119,15 +119,20 @@ ALLW = lambda d, dmax: d > 8.0          # launches that did work (the device-gat
 cholp = pmc_summary("%s_pmc" % tag, "k_cholp", LONG)
 if cholp:
     o = {"command": "rocprofv3 --pmc <one set per pass> --kernel-trace --output-format csv -- %s --steps 10 --warmup 2" % CMD, "workload": WL,
-         "kernel": "k_cholp, the LI launches (the long duration class of each pass)", "counters_per_li_launch": cholp}
+         "kernel": "k_cholp, the LI launches (the long duration class of each pass)", "counters_per_li_launch": cholp,
+         "mean_rows": cfg.get("mean_li_rows")}
     if "FETCH_SIZE" in cholp and "WRITE_SIZE" in cholp:
         f_, w_ = cholp["FETCH_SIZE"]["mean"] * 1024, cholp["WRITE_SIZE"]["mean"] * 1024
         o["hbm_bytes_per_li_launch"] = {"raw": f_ + w_, "fetch_doubled": 2 * f_ + w_,
                                         "note": "FETCH_SIZE on gfx950 reports half the bytes of 16 B/lane streams (MI355X_MICROARCH.md): the read side lies between the raw figure and twice it"}
     if "SQ_VALU_MFMA_BUSY_CYCLES" in cholp and "GRBM_GUI_ACTIVE" in cholp:
-        cyc = cholp["GRBM_GUI_ACTIVE"]["mean"] / 8.0
+        # GRBM_GUI_ACTIVE arrives summed over its instances: 8 (one per XCD; rounds 4-5) or 128 (round 6's session): the divisor that gives a plausible clock
+        d_us = cholp["GRBM_GUI_ACTIVE"]["mean_duration_us_same_pass"]
+        div = min((8.0, 16.0, 64.0, 128.0), key=lambda dv: abs(cholp["GRBM_GUI_ACTIVE"]["mean"] / dv / (d_us * 1e3) - 2.4))
+        cyc = cholp["GRBM_GUI_ACTIVE"]["mean"] / div
         o["mfma_busy_fraction_of_chip"] = cholp["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (cyc * 1024.0)
-        o["clock_GHz_of_the_GRBM_pass"] = cyc / (cholp["GRBM_GUI_ACTIVE"]["mean_duration_us_same_pass"] * 1e3)
+        o["clock_GHz_of_the_GRBM_pass"] = cyc / (d_us * 1e3)
+        o["grbm_instances_assumed"] = div
     json.dump(o, open(os.path.join(P, "%s_pmc_cholp.json" % tag), "w"), indent=1)
     print("k_cholp LI:", {k: round(v["mean"], 1) for k, v in cholp.items() if k in ("FETCH_SIZE", "WRITE_SIZE")}, o.get("mfma_busy_fraction_of_chip"))
 hidd = pmc_summary("%s_pmc" % tag, "k_downdate_b3", ALLW)
@@ -153,7 +158,8 @@ if k9s:
         f_, w_ = k9s["FETCH_SIZE"]["mean"] * 1024, k9s["WRITE_SIZE"]["mean"] * 1024
         o["hbm_bytes_per_launch"] = {"raw": f_ + w_, "fetch_doubled": 2 * f_ + w_, "algorithmic": "P upper 18.2 MB read + P 36.3 MB written + planes 10 MB read = ~65 MB"}
     if "SQ_VALU_MFMA_BUSY_CYCLES" in k9s and "GRBM_GUI_ACTIVE" in k9s:
-        cyc = k9s["GRBM_GUI_ACTIVE"]["mean"] / 8.0
+        d_us = k9s["GRBM_GUI_ACTIVE"]["mean_duration_us_same_pass"]
+        cyc = k9s["GRBM_GUI_ACTIVE"]["mean"] / min((8.0, 16.0, 64.0, 128.0), key=lambda dv: abs(k9s["GRBM_GUI_ACTIVE"]["mean"] / dv / (d_us * 1e3) - 2.4))
         o["mfma_busy_fraction_of_chip"] = k9s["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (cyc * 1024.0)
     json.dump(o, open(os.path.join(P, "%s_pmc_k9_standalone.json" % tag), "w"), indent=1)
     print("K9 stand-alone:", {k: o[k] for k in o if k.startswith("of_") or k.startswith("mfma") or k.startswith("f32")})
