@@ -169,6 +169,10 @@ __device__ __forceinline__ void ch_worker_load(ChSmem<T> &sm, typename ChW<T>::a
     using M = Mfma<T>;
     constexpr int NBLK = ChW<T>::NBLK, w0 = (WV >> 1) * 32, w1 = (WV & 1) * 32;
     const int cl = M::col(lane);
+    // (the dead tile's zero is opaque: as a constant the compiler built ONE hoisted all-zero accumulator tuple for every such use in the kernel, took
+    //  its first register for "the zero register" of unrelated address arithmetic, and spilled and reloaded the whole tuple around the chain)
+    T zero = (T)0;
+    asm volatile("" : "+v"(zero));
 #pragma unroll
     for (int p = 0; p < NBLK; ++p)
 #pragma unroll
@@ -176,7 +180,7 @@ __device__ __forceinline__ void ch_worker_load(ChSmem<T> &sm, typename ChW<T>::a
 #pragma unroll
             for (int e = 0; e < M::NREG; ++e) {
                 const int r = p * M::BLK + M::row(lane, e), c = q * M::BLK + cl;
-                acc[p][q][e] = !live ? (T)0 : XSIDE ? sm.Xs[w0 + r][w1 + c] : sm.Ls[w0 + r][w1 + c];
+                acc[p][q][e] = !live ? zero : XSIDE ? sm.Xs[w0 + r][w1 + c] : sm.Ls[w0 + r][w1 + c];
             }
 }
 

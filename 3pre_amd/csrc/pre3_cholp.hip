@@ -248,6 +248,8 @@ __device__ __forceinline__ CpTail ct_uniform(const CpTail &v)
 // hundred more registers live through the chain and the panel loop (measured: 300 scratch instructions inside the chain).
 constexpr size_t CP_T_OFF = 160 * 1024 - 1024, CP_TA_OFF = CP_T_OFF + 512;
 static_assert(sizeof(CpTail) <= 512 && sizeof(CpArgs) <= 512, "LDS slots of the launch arguments");
+constexpr size_t CP_KA_TAIL = (sizeof(CpArgs) + alignof(CpTail) - 1) / alignof(CpTail) * alignof(CpTail);      // k_cholp(CpArgs, CpTail): the second argument's offset in the kernel-argument segment
+static_assert(sizeof(CpArgs) % 4 == 0 && sizeof(CpTail) % 4 == 0, "launch arguments are copied word by word");
 template <typename S> __device__ __forceinline__ S args_from_lds(size_t off)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char cp_smem[];
@@ -258,6 +260,29 @@ template <typename S> __device__ __forceinline__ S args_from_lds(size_t off)
     for (unsigned w = 0; w < sizeof(S) / 4; ++w) dst[w] = (unsigned)__builtin_amdgcn_readfirstlane((int)src[w]);
     return a;
 }
+// The strips and the consumers (241 of the launch's 256 workgroups) get the launch arguments as a POINTER to the kernel-argument segment and read them
+// by scalar loads.  As a by-value CpArgs they travel through scratch: 240 B stored per thread at the call, 47 MB of dirty lines per launch that the
+// consumers' epilogue then pushes out of the L2s -- 39 of the LI launch's 103 MB of HBM writes (round 6: tools/pmc_env_write.sh, tools/pmc_ab_write.sh).
+//  * __builtin_amdgcn_kernarg_segment_ptr() inside an out-of-line role returns null with this compiler: the kernel passes the pointer.
+//  * not_tail_called: a call that passes no pointer into the caller's frame gets the optimiser's `tail` mark (in tail position or not), and a local
+//    function with such a caller loses the "no callee-saved registers" treatment: ~75 registers stored per thread at the role's entry.
+//  * the rows (14 workgroups) keep the by-value form: with no by-value call left in k_cholp the register allocation of crit's chain (inlined in the
+//    kernel) falls apart -- 405 spilled registers against 51, the X workers' accumulators reloaded in every step (measured: LI launch 97 -> 182 us).
+typedef __attribute__((address_space(4))) const unsigned char *cp_ka_t;
+template <typename S> __device__ __forceinline__ S args_from_kernarg(cp_ka_t ka_v, size_t off)
+{
+    typedef __attribute__((address_space(4))) const unsigned char kb_t;
+    typedef __attribute__((address_space(4))) const unsigned kw_t;
+    const unsigned long long kav = (unsigned long long)ka_v;
+    const unsigned long long kau = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(kav >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)kav);
+    kw_t *src = (kw_t *)((kb_t *)kau + off);
+    S a;
+    unsigned *dst = reinterpret_cast<unsigned *>(&a);
+#pragma unroll
+    for (unsigned w = 0; w < sizeof(S) / 4; ++w) dst[w] = src[w];
+    return a;
+}
+#define CP_ROLE __attribute__((noinline, not_tail_called))
 constexpr int CF_MP = 0, CF_ROWL = 32, CF_ROWA = 32 * 65, CF_STRIP = 32 * 130;     // one 128-byte line per flag; the strips' flags follow
 constexpr int CF_HI = CF_ROWL;           // (row 0 has no flag of its own) crit's word for the tail: the HI list is out; word [1] = its rows in this launch
 // values of a strip's flag behind the panels (base + J + 1, J < 16): x_k_k of its states is out / its landmarks are gated / its block of W~ is out
@@ -1778,9 +1803,9 @@ __device__ __forceinline__ void strip_rl_loop(const CpArgs &a, const int nrb, co
     __syncthreads();
 }
 
-__device__ __attribute__((noinline)) void strip_body(CpArgs a_v, int nrb_v, int rows_v, int s_v)
+__device__ CP_ROLE void strip_body(cp_ka_t ka_v, int nrb_v, int rows_v, int s_v)
 {
-    const CpArgs a = cp_uniform(a_v);
+    const CpArgs a = args_from_kernarg<CpArgs>(ka_v, 0);
     const int nrb = __builtin_amdgcn_readfirstlane(nrb_v), s = __builtin_amdgcn_readfirstlane(s_v);
     extern __shared__ __attribute__((aligned(16))) unsigned char cp_smem[];
     // Eight waves: wave (fa, par) owns row half fa of the 64 x 32 block and every fourth operand block (or k-step) par; the four shares meet
@@ -2331,9 +2356,9 @@ __device__ __forceinline__ void dd_store_wt(f4v_t *d, f4v_t v, bool wt)
     else *d = v;
 }
 
-__device__ __attribute__((noinline)) void dd_body(CpArgs a_v, int nrb_v, int rows_v, int g_v)
+__device__ CP_ROLE void dd_body(cp_ka_t ka_v, int nrb_v, int rows_v, int g_v)
 {
-    const CpArgs a = cp_uniform(a_v);
+    const CpArgs a = args_from_kernarg<CpArgs>(ka_v, 0);
     const int nrb = __builtin_amdgcn_readfirstlane(nrb_v), rows = __builtin_amdgcn_readfirstlane(rows_v), g = __builtin_amdgcn_readfirstlane(g_v);
     extern __shared__ __attribute__((aligned(16))) unsigned char cp_smem[];
     frag_t *ops = reinterpret_cast<frag_t *>(cp_smem);
@@ -2541,9 +2566,14 @@ __global__ __launch_bounds__(CP_NTH) void k_cholp(CpArgs a, CpTail t)
     // speed assumption only: every hand-off is valid for any placement.  Every other block is a strip.
     const int b = blockIdx.x, nH = a.nrb_max > 2 ? a.nrb_max - 2 : 0, stride = a.stride;
     if (a.tail || a.proj) {
-        // the tail's code (crit, strips) takes the launch arguments from LDS; it reads them behind many barriers of its own role
-        if (threadIdx.x < sizeof(CpTail) / 4) reinterpret_cast<unsigned *>(cp_smem + CP_T_OFF)[threadIdx.x] = reinterpret_cast<const unsigned *>(&t)[threadIdx.x];
-        if (threadIdx.x >= 128 && threadIdx.x < 128 + sizeof(CpArgs) / 4) reinterpret_cast<unsigned *>(cp_smem + CP_TA_OFF)[threadIdx.x - 128] = reinterpret_cast<const unsigned *>(&a)[threadIdx.x - 128];
+        // the tail's code (crit, strips) takes the launch arguments from LDS; it reads them behind many barriers of its own role.  The copy is made
+        // from the kernel-argument segment, not from &a / &t: a dynamically indexed read of a by-value struct makes the compiler keep the struct in
+        // scratch, stored by EVERY thread at the kernel's entry -- 240 B x 768 threads x 256 workgroups = 47 MB of write-back per launch (round 6,
+        // tools/pmc_env_write.sh: the "unexplained" writes of the LI launch)
+        typedef __attribute__((address_space(4))) const unsigned kw_t;
+        kw_t *ka = (kw_t *)__builtin_amdgcn_kernarg_segment_ptr();
+        if (threadIdx.x < sizeof(CpTail) / 4) reinterpret_cast<unsigned *>(cp_smem + CP_T_OFF)[threadIdx.x] = ka[CP_KA_TAIL / 4 + threadIdx.x];
+        if (threadIdx.x >= 128 && threadIdx.x < 128 + sizeof(CpArgs) / 4) reinterpret_cast<unsigned *>(cp_smem + CP_TA_OFF)[threadIdx.x - 128] = ka[threadIdx.x - 128];
     }
 #ifndef CP_TEST_ROLE
 #define CP_TEST_ROLE 15
@@ -2561,9 +2591,9 @@ __global__ __launch_bounds__(CP_NTH) void k_cholp(CpArgs a, CpTail t)
         // every strip's x-update waits for the strip that owns column ld (L^-1 nu): it takes the lowest block index of the strips, so that the one
         // workgroup all the others wait for is dispatched in front of them
         const int s_nu = a.ld / 32, s_col = sidx == 0 ? s_nu : sidx == s_nu ? 0 : sidx;
-        if (CP_TEST_ROLE & 4) strip_body(a, nrb, rows, s_col);
+        if (CP_TEST_ROLE & 4) strip_body((cp_ka_t)__builtin_amdgcn_kernarg_segment_ptr(), nrb, rows, s_col);
     } else if (sidx - a.n_strips < a.n_dd) {
-        if (CP_TEST_ROLE & 8) dd_body(a, nrb, rows, sidx - a.n_strips);
+        if (CP_TEST_ROLE & 8) dd_body((cp_ka_t)__builtin_amdgcn_kernarg_segment_ptr(), nrb, rows, sidx - a.n_strips);
     }
 }
 

@@ -51,6 +51,18 @@ def test_the_chain_of_k_cholp_has_no_scratch_traffic():
     assert not inside, "scratch traffic inside the chain of k_cholp:\n" + "\n".join(inside[:8])
     between = [l for b in blocks for l in b if "scratch_" in l]
     assert len(between) <= 8, "scratch traffic between the chain's roles grew:\n" + "\n".join(between[:16])
+    # (round 6) the strips' and the consumers' roles take the launch arguments by pointer: as a by-value struct they were 240 B of scratch stores per
+    # thread at the call (39 MB of the LI launch's HBM writes, tools/pmc_ab_write.sh); and their calls must not carry the `tail` mark, or the roles
+    # save ~75 callee-saved registers per thread at their entry
+    for role in ("strip_body", "dd_body"):
+        lab = [i for i, l in enumerate(asm) if re.match(r"^_ZN4pre3\d+%sE\w*:" % role, l)]
+        assert lab, role
+        assert "6CpArgs" not in asm[lab[0]], "%s takes CpArgs by value again: %s" % (role, asm[lab[0]])
+        end = next(i for i in range(lab[0], len(asm)) if asm[i].startswith(".Lfunc_end"))
+        n_st = sum("scratch_store" in l for l in asm[lab[0]:end])
+        assert n_st <= 24, "%s stores %d registers to scratch (callee-saved convention back?)" % (role, n_st)
+    call_copies = [l for l in kern[:mf[0]] if "scratch_store" in l and "Spill" not in l]
+    assert len(call_copies) <= 32, "by-value argument copies in front of the roles' calls: %d stores" % len(call_copies)
     m = re.findall(r"Function Name: (\S+).*?VGPRs Spill: (\d+)", r.stderr, re.S)
     spills = {n: int(v) for n, v in m}
     k = [v for n, v in spills.items() if "k_cholp" in n]
