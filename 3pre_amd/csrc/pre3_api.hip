@@ -77,6 +77,8 @@ static int check_ctx(pre3_ctx *c)
         PRE3_TRY(pre3_update_hi(c));
         c->last_n_hi = c->hi_from_host >= 0 ? c->hi_from_host : (c->hi_kernel ? c->mail_host[5] : 0);
     }
+    // PRE3_OPT_PEND_HI: only pre3_step carries a pending HI down-date into its launches (pend_keep); for everybody else P is P before the call goes on
+    if (c->pend_rows > 0 && !c->pend_keep) PRE3_TRY(pend_flush(c));
     return PRE3_OK;
 }
 
@@ -225,6 +227,19 @@ int pre3_device_count(void)
 
 // The tail of the persistent launch (rescue stage + HI update inside k_cholp, CpTail; off by default): per landmark y = H J W' as bf16 planes (+ one zero
 // slot), the row H J, crit's list, and W once more column-major.  Allocated on demand (pre3_set_option(PRE3_OPT_STEP_TAIL, 1) or PRE3_TAIL=1 at creation).
+// PRE3_OPT_PEND_HI's buffers: W~ of up to two panels (f32 rows) and its planes in Wp's layout (same nst_total, so that the consumers' offsets hold for both)
+static int pend_alloc(pre3_ctx *c)
+{
+    if (c->W_pend && c->Wp_pend && c->hf_xy) return PRE3_OK;
+    PRE3_CHECK(c->dtype == PRE3_F32 && c->Wp != nullptr && c->rcap >= 2 * NB, PRE3_E_STATE, "PRE3_OPT_PEND_HI: fp32 contexts with the persistent factorisation only");
+    int rc = PRE3_OK;
+    auto A = [&](int r) { if (rc == PRE3_OK) rc = r; };
+    if (!c->W_pend) { void *f = nullptr; A(dmalloc_bytes(&f, (size_t)2 * NB * c->ldw * sizeof(float))); c->W_pend = (float *)f; }
+    if (!c->Wp_pend) A(dmalloc_bytes(&c->Wp_pend, (size_t)ceil_div(c->ldw, 128) * (c->rcap / 16) * (3 * 4 * 64) * 16));
+    if (!c->hf_xy) { void *f = nullptr; A(dmalloc_bytes(&f, sizeof(unsigned) * 256)); c->hf_xy = (unsigned *)f; }
+    return rc;
+}
+
 static int tail_alloc(pre3_ctx *c)
 {
     if (c->tail_yp && c->tail_hb && c->tail_hib && c->tail_wt) return PRE3_OK;
@@ -372,6 +387,7 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
         // (the buffers of the in-launch tail, PRE3_OPT_STEP_TAIL, are allocated when the option is switched on: tail_alloc -- at N = 2000 they are
         //  ~300 MB that the default path never touches)
         if (c->step_tail) A(tail_alloc(c));
+        { const char *e = getenv("PRE3_PEND_HI"); if (e && atoi(e) != 0 && c->rcap >= 2 * NB) { A(pend_alloc(c)); c->pend_opt = rc == PRE3_OK; } }      // PRE3_OPT_PEND_HI
         if (rc == PRE3_OK) { cholp_context_count(c->device, +1); c->cholp_counted = true; }
         const int nt = c->ld / 128, ns = ceil_div(nt, 4);
         std::vector<std::vector<int2>> lists(8);
@@ -446,7 +462,7 @@ int pre3_destroy(pre3_ctx *c)
     c->comm = nullptr;
     void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
                      c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
-                     c->sel_rows, c->support, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_src0, c->map_conv, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128, c->need, c->cholp_flags, c->cholp_tp, c->dd_groups, c->dd_tiles, c->tail_yp, c->tail_hb, c->tail_hib, c->tail_wt, c->jn_q };
+                     c->sel_rows, c->support, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_src0, c->map_conv, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128, c->need, c->cholp_flags, c->cholp_tp, c->dd_groups, c->dd_tiles, c->tail_yp, c->tail_hb, c->tail_hib, c->tail_wt, c->jn_q, c->W_pend, c->Wp_pend, c->hf_xy };
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (int k2 = 0; k2 < 2; ++k2) { if (c->map_stage[k2]) (void)hipHostFree(c->map_stage[k2]); if (c->map_stage_ev[k2]) (void)hipEventDestroy(c->map_stage_ev[k2]); }
     for (int k2 = 0; k2 < 2; ++k2) { if (c->up_stage[k2]) (void)hipHostFree(c->up_stage[k2]); if (c->up_stage_ev[k2]) (void)hipEventDestroy(c->up_stage_ev[k2]); }
@@ -475,6 +491,10 @@ int pre3_set_option(pre3_ctx *c, int option, int value)
         if (value != 0 && c->dtype == PRE3_F32 && c->Wp != nullptr) { const int rc = tail_alloc(c); if (rc != PRE3_OK) { c->step_tail = false; return rc; } }
         c->step_tail = value != 0;
         return PRE3_OK;
+    case PRE3_OPT_PEND_HI:
+        if (value != 0 && c->dtype == PRE3_F32 && c->Wp != nullptr) { const int rc = pend_alloc(c); if (rc != PRE3_OK) { c->pend_opt = false; return rc; } }
+        c->pend_opt = value != 0 && c->W_pend != nullptr;
+        return PRE3_OK;
     default: set_error("pre3_set_option: unknown option %d", option); return PRE3_E_ARG;
     }
 }
@@ -490,6 +510,7 @@ int pre3_get_option(pre3_ctx *c, int option, int *value_out)
     case PRE3_OPT_IC_ROUTE: *value_out = c->ic_route; return PRE3_OK;
     case PRE3_OPT_K9_OVERLAP: *value_out = c->k9_overlap ? 1 : 0; return PRE3_OK;
     case PRE3_OPT_STEP_TAIL: *value_out = (c->step_tail && c->tail_yp != nullptr) ? 1 : 0; return PRE3_OK;
+    case PRE3_OPT_PEND_HI: *value_out = c->pend_opt ? 1 : 0; return PRE3_OK;
     default: set_error("pre3_get_option: unknown option %d", option); return PRE3_E_ARG;
     }
 }
@@ -554,7 +575,7 @@ int pre3_set_state(pre3_ctx *c, int which, int n, const double *x, const double 
             (void)stream_drain(c, __func__);
             (void)hipMemsetAsync(c->stats + 6, 0, sizeof(int32_t) * 2, c->stream);
             if (c->mail_host) { c->mail_host[6] = 0; c->mail_host[7] = 0; }
-            c->jn_pending = false; c->hi_pending = false; c->tail_done = false; c->hi_fused = false;
+            c->jn_pending = false; c->hi_pending = false; c->tail_done = false; c->hi_fused = false; c->pend_rows = 0; c->hi_pend_launched = false;
         }
     }
     PRE3_TRY(check_ctx(c));
@@ -1307,14 +1328,19 @@ int pre3_update_hi(pre3_ctx *c)
     if (was_fused) {
         // pre3_step sent the collection and the update out as one device-driven pair of launches (k_hi_fused + its down-date): up to 64
         // landmarks (two panels) are done, only the Jnorm pass of update.m:42-46 is left; more than that take the general path now
+        const bool pend_launched = c->hi_pend_launched;
+        c->hi_pend_launched = false;
         if (c->hi_from_host < 0 && n_hi <= hi_fused_max(c)) {
             if (n_hi > 0) {
                 c->hp_all_valid = false;
+                // PRE3_OPT_PEND_HI: k_hi_fused's down-date was not launched -- from here on P stands for P - W~'W~ (2 n_hi rows) until somebody takes it
+                if (pend_launched) c->pend_rows = 2 * n_hi;
                 if (c->leave_jn_to_predict) c->jn_pending = true;
-                else PRE3_TRY(launch_jnorm(c, 0));
+                else PRE3_TRY(launch_jnorm(c, 0));              // (flushes the pending rows first: the pass reads P)
             }
             return PRE3_OK;
         }
+        // (more than k_hi_fused takes: it has written nothing -- no W~, no x-update --, the general path follows)
     }
     return update_selected(c, PRE3_X_K_K, n_hi, c->sel_rows);
 }
@@ -1420,6 +1446,10 @@ int pre3_step(pre3_ctx *c, const double u[7], int m, const int32_t *meas_idx, co
     // launch below (one launch less per step; PRE3_FUSE_JN=0: as its own launch).  Any return before that launch flushes it.
     static const int fuse_jn_env = getenv("PRE3_FUSE_JN") ? atoi(getenv("PRE3_FUSE_JN")) : 1;
     if (c) c->leave_jn_to_predict = fuse_jn_env && c->hi_pending;
+    // PRE3_OPT_PEND_HI: this call's own launches take a pending HI down-date along (prediction, H*P + S_i, the LI update's consumers); whatever of it
+    // cannot -- and every call made from in here that reads P some other way -- flushes it first (pend_flush in the launchers)
+    struct PendKeep { pre3_ctx *c; ~PendKeep() { if (c) c->pend_keep = false; } } pend_keep{ c };
+    if (c) c->pend_keep = c->pend_opt && c->dtype == PRE3_F32 && m >= k && m > 0 && c->N > 0;
     {
         const int rc0 = check_ctx(c);
         if (c) c->leave_jn_to_predict = false;

@@ -200,6 +200,8 @@ struct CpArgs {
     int proj;                            // the strips end with the rescue stage's projection of every landmark at x_k_k (strip_proj_body; tables in CpTail's LDS slot)
     int tail;                            // the rescue stage and the HI update follow inside this launch (CpTail): the HI rows are panel `nrb` of the same factorisation
     float *Wt; int kcap;                 // tail: W once more, column-major (column j at Wt + j * kcap, k contiguous): what the gate's y = H J W' reads
+    const void *Wp_pend; int pend_ns;    // PRE3_OPT_PEND_HI: planes of the HI update left pending by the step before (Wp's layout and nst_total) and their k-stages (0: none):
+                                         // the consumers take them as the panels in front of panel 0 -- they idle until W_0 is out anyway -- and P is written once for both
 };
 // mono_slam.m:184-187 inside the launch (round 5).  Once the strips have x_k_k:  (B) every landmark is projected and linearised at x_k_k
 // (rescue_hi_inliers.m:32-33); for the candidates (individually compatible, not a low-innovation inlier) y_i = H_i J W' (2 x r), the gate
@@ -2396,10 +2398,11 @@ __device__ CP_ROLE void dd_body(cp_ka_t ka_v, int nrb_v, int rows_v, int g_v)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    const frag_t *Wp = static_cast<const frag_t *>(a.Wp);
+    const frag_t *Wp = static_cast<const frag_t *>(a.Wp), *Wpp = static_cast<const frag_t *>(a.Wp_pend);
     const int j_last = (nst_real + 3) / 4 - 1;                  // the last panel that holds real rows
-    for (int J = 0; J <= nrb; ++J) {
-        int ns = nst_real - 4 * J;
+    const int npp = (a.pend_ns + 3) / 4;                        // panels of a pending HI update (J = -npp .. -1: complete in memory, no flag to wait for)
+    for (int J = -npp; J <= nrb; ++J) {
+        int ns = J < 0 ? a.pend_ns - 4 * (J + npp) : nst_real - 4 * J;
         ns = ns > 4 ? 4 : ns;
         if (J < nrb) { if (ns <= 0) continue; }
         else {
@@ -2428,7 +2431,7 @@ __device__ CP_ROLE void dd_body(cp_ka_t ka_v, int nrb_v, int rows_v, int g_v)
                 __builtin_amdgcn_global_load_lds(pt + (size_t)(4 * t) * a.ld, (__attribute__((address_space(3))) void *)sink, 16, 0, 0);
         }
         // the strips that own the group's column blocks (two per 64-column block) have published W_J
-        if (wave == 0) {
+        if (wave == 0 && J >= 0) {
             const int nfl = 2 * nslots;
             bool gave_up = true;
             for (int spin = 0; spin < SPIN_LIMIT; ++spin) {
@@ -2450,7 +2453,7 @@ __device__ CP_ROLE void dd_body(cp_ka_t ka_v, int nrb_v, int rows_v, int g_v)
         __builtin_amdgcn_s_barrier();
         if (tid == 0 && (g == 0 || g == a.n_dd - 1)) CP_STAMP(g == 0 ? 20 : 21, J, 0);
         for (int st = 0; st < ns; ++st) {
-            const frag_t *src = Wp + (size_t)(4 * J + st) * B3_GRAN + lane;
+            const frag_t *src = (J < 0 ? Wpp + (size_t)(4 * (J + npp) + st) * B3_GRAN : Wp + (size_t)(4 * J + st) * B3_GRAN) + lane;
             frag_t *dst = ops + st * (DG_SLOTS * DG_SLOT_GRAN);
 #pragma unroll
             for (int k = 0; k < DG_KMAX; ++k)
@@ -2560,7 +2563,8 @@ __global__ __launch_bounds__(CP_NTH) void k_cholp(CpArgs a, CpTail t)
         if (nrb > a.nrb_max) nrb = a.nrb_max;
     }
     if (rows > nrb * NB) rows = nrb * NB;
-    if (nrb <= 0) return;
+    if (nrb <= 0 && a.pend_ns == 0) return;
+    const bool only_pend = nrb <= 0;                             // no LI rows on the device: the consumers still owe P the pending HI down-date
     // Blocks 0, 8, 16, .. 8 nH are crit and the rows: blocks are dealt round-robin over the eight XCDs, so these share one XCD's L2 -- the rows'
     // bulk operands (each L(k, J) is wanted by every row below k) and the hand-offs with crit are then served by that L2.  Placement is a
     // speed assumption only: every hand-off is valid for any placement.  Every other block is a strip.
@@ -2579,6 +2583,7 @@ __global__ __launch_bounds__(CP_NTH) void k_cholp(CpArgs a, CpTail t)
 #define CP_TEST_ROLE 15
 #endif
     if (b % stride == 0 && b / stride <= nH) {
+        if (only_pend) return;
         const int r = b / stride;
         if (r == 0) { if (CP_TEST_ROLE & 1) crit_body(a, nrb, rows, cp_smem); return; }
         const int i = r + 1;
@@ -2587,7 +2592,7 @@ __global__ __launch_bounds__(CP_NTH) void k_cholp(CpArgs a, CpTail t)
     }
     const int sidx = b - (b / stride < nH ? b / stride + 1 : nH + 1);
     if (sidx < a.n_strips) {
-        if (threadIdx.x >= 512) return;                         // strips are eight waves
+        if (threadIdx.x >= 512 || only_pend) return;            // strips are eight waves
         // every strip's x-update waits for the strip that owns column ld (L^-1 nu): it takes the lowest block index of the strips, so that the one
         // workgroup all the others wait for is dispatched in front of them
         const int s_nu = a.ld / 32, s_col = sidx == 0 ? s_nu : sidx == s_nu ? 0 : sidx;
@@ -2860,6 +2865,12 @@ int launch_cholp(pre3_ctx *c, int nrb, int nrb_max, int rows, int which_prior, c
 #endif
     }
     c->tail_launched = tail;
+    // PRE3_OPT_PEND_HI: with every group of P's tiles in the launch the consumers take the pending HI down-date as the panels in front of panel 0
+    // (and run even when the device finds no LI rows); otherwise it goes out as its own launch now
+    if (c->pend_rows > 0) {
+        if (!tail && n_dd > 0 && n_dd == c->dd_n_groups && c->Wp_pend != nullptr) { a.Wp_pend = c->Wp_pend; a.pend_ns = (c->pend_rows + B3_BK - 1) / B3_BK; c->pend_rows = 0; }
+        else PRE3_TRY(pend_flush(c));
+    }
     // roofline bracket (pre3_kernel_timing): the launches that carry a matrix-bound down-date -- updates of the predicted state
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = c->kt.enabled && n_dd > 0 && which_prior == PRE3_X_K_KM1 && (nrb < 0 || nrb >= 2) && (c->kt.seen++ % c->kt.every) == 0;

@@ -14,6 +14,7 @@
 //   ransac         ransac_hypotheses.m:40-80, compute_hypothesis_support_fast.m:33-110
 #include "pre3_internal.h"
 #include "pre3_geomdev.h"
+#include "pre3_chain.h"
 
 namespace pre3 {
 
@@ -54,7 +55,7 @@ __device__ __forceinline__ double jn_row(const double *J, int i, const double v[
 // reading them from a previous kernel; block 0 additionally owns x_out[0:13], the process noise and the 7x7 pose block.
 template <typename T>
 __global__ __launch_bounds__(256) void k_predict(const double *__restrict__ x_in, double *x_out, T *__restrict__ P, int n, int ld, U7 u,
-                                                 double *__restrict__ params, int n_pred_blocks, ProjRide pr, InboxRide ib, int fuse_jn)
+                                                 double *__restrict__ params, int n_pred_blocks, ProjRide pr, InboxRide ib, int fuse_jn, PendW pw = PendW{})
 {
     if ((int)blockIdx.x >= n_pred_blocks + pr.n_blocks) { inbox_pull_block(ib); return; }               // the step's inbox crosses PCIe beside the prediction
     if ((int)blockIdx.x >= n_pred_blocks) { proj_ride_block(pr, blockIdx.x - n_pred_blocks); return; }   // IC-search projection rides along
@@ -153,6 +154,25 @@ __global__ __launch_bounds__(256) void k_predict(const double *__restrict__ x_in
         if (t < 49) { double s = 0; for (int q2 = 0; q2 < 7; ++q2) s += J7[i * 7 + q2] * C7[q2 * 7 + k]; T1[t] = s; }
         __syncthreads();
         if (t < 49) { double s = 0; for (int q2 = 0; q2 < 7; ++q2) s += T1[i * 7 + q2] * J7[k * 7 + q2]; P[i * ld + k] = (T)s; }
+    }
+    if constexpr (sizeof(T) == 4) {
+        // PRE3_OPT_PEND_HI: P stands for P - W~'W~, so W~ takes the same congruence -- columns 3..6 of every row, through the same chain (the pending
+        // update.m:42-46 pass first, rounded as it is for P, then Qq1 and Jn) --, and the planes of the one column block that holds them are split
+        // again.  The last prediction block does it (it has the fewest columns of P).
+        if (pw.rows > 0 && (int)blockIdx.x == n_pred_blocks - 1) {
+            for (int k = threadIdx.x; k < pw.rows; k += blockDim.x) {
+                float *wr = pw.W + (size_t)k * pw.ldw + 3;
+                double wv[4] = { (double)wr[0], (double)wr[1], (double)wr[2], (double)wr[3] };
+                if (fuse_jn) { double w[4]; for (int i = 0; i < 4; ++i) w[i] = (double)(T)jn_row(sJu, i, wv); for (int i = 0; i < 4; ++i) wv[i] = w[i]; }
+                double a[4], b[4];
+                for (int i = 0; i < 4; ++i) a[i] = sQq1[i * 4] * wv[0] + sQq1[i * 4 + 1] * wv[1] + sQq1[i * 4 + 2] * wv[2] + sQq1[i * 4 + 3] * wv[3];
+                for (int i = 0; i < 4; ++i) b[i] = sJn[i * 4] * a[0] + sJn[i * 4 + 1] * a[1] + sJn[i * 4 + 2] * a[2] + sJn[i * 4 + 3] * a[3];
+                for (int i = 0; i < 4; ++i) wr[i] = (float)b[i];
+            }
+            __syncthreads();
+            const int nst = (pw.rows + B3_BK - 1) / B3_BK;
+            for (int st = 0; st < nst; ++st) b3_split_block(pw.W, pw.ldw, static_cast<bf16x8_t *>(pw.Wp), pw.nst_total, 0, st, threadIdx.x);
+        }
     }
 }
 
@@ -1084,8 +1104,8 @@ int launch_predict_impl(pre3_ctx *c, const double u[7], bool with_projection, si
     const int nb = blocks + pr.n_blocks + (inbox_n16 ? 1 : 0);
     const int fuse_jn = c->jn_pending ? 1 : 0;          // the pending update.m:42-46 pass of the update in front (run_update left it to this launch)
     DISPATCH_T(c,
-        hipLaunchKernelGGL(k_predict<double>, dim3(nb), dim3(256), 0, c->stream, c->x_kk, c->x_km1, (double *)c->P, c->n, c->ld, uu, c->pred_params, blocks, pr, ib, fuse_jn),
-        hipLaunchKernelGGL(k_predict<float>, dim3(nb), dim3(256), 0, c->stream, c->x_kk, c->x_km1, (float *)c->P, c->n, c->ld, uu, c->pred_params, blocks, pr, ib, fuse_jn));
+        hipLaunchKernelGGL(k_predict<double>, dim3(nb), dim3(256), 0, c->stream, c->x_kk, c->x_km1, (double *)c->P, c->n, c->ld, uu, c->pred_params, blocks, pr, ib, fuse_jn, PendW{}),
+        hipLaunchKernelGGL(k_predict<float>, dim3(nb), dim3(256), 0, c->stream, c->x_kk, c->x_km1, (float *)c->P, c->n, c->ld, uu, c->pred_params, blocks, pr, ib, fuse_jn, pend_args(c)));
     PRE3_HIP(hipGetLastError());
     c->jn_pending = false;
     return PRE3_OK;
@@ -1093,6 +1113,7 @@ int launch_predict_impl(pre3_ctx *c, const double u[7], bool with_projection, si
 
 int launch_jnorm(pre3_ctx *c, int)
 {
+    PRE3_TRY(pend_flush(c));                    // (reads P: a pending HI down-date goes first)
     int blocks = ceil_div(c->n, 256);
     ProjRide pr{};
     GateRide<float> gr{};
@@ -1131,6 +1152,7 @@ int launch_project(pre3_ctx *c, int which, int clear_first)
 // project + innovation (+ the HI collection in mode 1) with one kernel boundary less
 int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode, double chi2, bool collect, bool clear_ic, const IcMatchRide *ride)
 {
+    PRE3_TRY(pend_flush(c));                    // (reads P: a pending HI down-date goes first)
     const IcMatchRide mr = ride ? *ride : IcMatchRide{};
     const double *x = which == PRE3_X_K_K ? c->x_kk : c->x_km1;
     int32_t *clr = (int32_t *)((unsigned char *)c->inbox_dev + c->off_flags);
@@ -1152,6 +1174,7 @@ int launch_project_innovation(pre3_ctx *c, int which, int clear_first, int mode,
 
 int launch_innovation(pre3_ctx *c, int mode, double chi2, bool clear_flags, bool collect)
 {
+    PRE3_TRY(pend_flush(c));                    // (reads P: a pending HI down-date goes first)
     int32_t *clr = (int32_t *)((unsigned char *)c->inbox_dev + c->off_flags);
     const int n_clr = clear_flags ? (int)(c->flags_bytes / sizeof(int32_t)) : 0;
     HiArgs ha{};

@@ -248,7 +248,8 @@ __device__ __forceinline__ void innovation_body(int N, const int32_t *__restrict
                                                 const int32_t *has_h, int mode, double chi2,
                                                 const double *h, const double *__restrict__ z,
                                                 const int32_t *__restrict__ ic, const int32_t *__restrict__ li, int32_t *__restrict__ hi,
-                                                double *__restrict__ S, int32_t *__restrict__ has_S, const int gt /* global lane: 16 per landmark */)
+                                                double *__restrict__ S, int32_t *__restrict__ has_S, const int gt /* global lane: 16 per landmark */,
+                                                const float *__restrict__ pend_W = nullptr, const int pend_ldw = 0, const int pend_rows = 0)
 {
     // 16 lanes per landmark: lane b < 13 owns column b of the gathered 13x13 block of P (7 pose + 6 landmark
     // entries; P is symmetric, so the column is read as a row: two contiguous runs), then a 16-lane shuffle sum.
@@ -274,6 +275,19 @@ __device__ __forceinline__ void innovation_body(int N, const int32_t *__restrict
         const double h0b = b < 7 ? Hc[14 * ii + b] : Hl[12 * ii + b - 7];
         const double h1b = b < 7 ? Hc[14 * ii + 7 + b] : Hl[12 * ii + 6 + b - 7];
         s00 = hp0 * h0b; s01 = hp0 * h1b; s10 = hp1 * h0b; s11 = hp1 * h1b;
+    }
+    if (pend_rows > 0 && active) {
+        // P is P - W~'W~ (PendW): S_i -= g g', g(c, k) = H_i(c, :) W~(k, :)'; lane b takes the rows k = b (mod 16), its share leaves with the sums below
+        for (int k = b; k < pend_rows; k += 16) {
+            const float *wr = pend_W + (size_t)k * pend_ldw;
+            double g0 = 0, g1 = 0;
+#pragma unroll
+            for (int a = 0; a < 7; ++a) { const double w = (double)wr[a]; g0 += Hc[14 * ii + a] * w; g1 += Hc[14 * ii + 7 + a] * w; }
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+                if (a < d) { const double w = (double)wr[off + a]; g0 += Hl[12 * ii + a] * w; g1 += Hl[12 * ii + 6 + a] * w; }
+            s00 -= g0 * g0; s01 -= g0 * g1; s10 -= g1 * g0; s11 -= g1 * g1;
+        }
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) {
@@ -314,11 +328,19 @@ __device__ __forceinline__ void inbox_pull_block(const InboxRide &ib)
     if (threadIdx.x == 0) { __threadfence_system(); __hip_atomic_store(ib.mail + ib.slot, ib.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }
 
+// PRE3_OPT_PEND_HI: the HI update's down-date P - W~'W~ (update.m:37-38 of ekf_update_hi_inliers.m) left pending across the step boundary -- W~ (rows x ldw,
+// f32; column ld = L^-1 nu) and its bf16 planes in k_downdate_b3's layout.  rows == 0: nothing pending.  Whoever reads P while it is pending reads
+// P - W~'W~ (k_predict transforms W~ with P; k_ell_HP_build_mb and the S_i pass subtract the rank-`rows` term; k_cholp's consumers take W~ as the
+// panels in front of panel 0) or runs behind pend_flush().
+struct PendW { float *W; int ldw, rows; void *Wp; int nst_total; };
+PendW pend_args(const pre3_ctx *c);           // what is pending on this context (rows == 0: nothing)              (pre3_update.hip)
+int pend_flush(pre3_ctx *c);                  // k_downdate_b3 on the pending rows, if any: P is P again           (pre3_update.hip)
 struct InnovRide {                       // mode-0 innovation riding in another launch; n_blocks == 0: none
     int n_blocks, N, ld, n_clear;
     const int32_t *lm_type, *lm_off, *has_h;
     const void *P; const double *Hc, *Hl;
     double *S; int32_t *has_S, *clear;
+    const float *pend_W = nullptr; int pend_ldw = 0, pend_rows = 0;        // PendW (fp32 contexts)
 };
 template <typename T>
 __device__ __forceinline__ void innov_ride_block(const InnovRide &ir, int blk)
@@ -326,7 +348,7 @@ __device__ __forceinline__ void innov_ride_block(const InnovRide &ir, int blk)
     const int gt = blk * blockDim.x + threadIdx.x;
     for (int t = gt; t < ir.n_clear; t += ir.n_blocks * blockDim.x) ir.clear[t] = 0;
     innovation_body<T>(ir.N, ir.lm_type, ir.lm_off, static_cast<const T *>(ir.P), ir.ld, ir.Hc, ir.Hl, ir.has_h, 0, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr,
-                       ir.S, ir.has_S, gt);
+                       ir.S, ir.has_S, gt, ir.pend_W, ir.pend_ldw, ir.pend_rows);
 }
 
 ProjRide make_proj_ride(pre3_ctx *c, int which, int clear_first, int slot, int n_producers);   // pre3_geom.hip

@@ -129,6 +129,140 @@ __global__ __launch_bounds__(256) void k_ell_HP_build(int m, int r_pad, const in
     }
 }
 
+// The same with MB measurements per workgroup (round 6): the seven pose rows of P -- 7 of the 13 rows every measurement gathers -- are read once per
+// workgroup and column quad instead of once per measurement (35 instead of 64 MB through the L2s at N = 500), the measurements' coefficient rows
+// come from an LDS table built once per workgroup, and all MB x 6 landmark-row loads of a thread are in flight together.  Same 13-term chain in the
+// same order per entry: bit-identical to k_ell_HP_build (tests/test_gpu_variants.py, PRE3_HP_MB=0 restores that kernel).
+template <typename T, int MB, bool PEND = false>
+__global__ __launch_bounds__(256) void k_ell_HP_build_mb(int m, int r_pad, const int32_t *__restrict__ meas, const int32_t *__restrict__ lm_type,
+                                                         const int32_t *__restrict__ lm_off, const double *__restrict__ Hc,
+                                                         const double *__restrict__ Hl, const double *__restrict__ z, const double *__restrict__ h,
+                                                         int32_t *__restrict__ row_col, T *__restrict__ row_val, double *__restrict__ row_nu,
+                                                         const T *__restrict__ P, int ld, T *__restrict__ dst, int ldw, const int32_t *__restrict__ need, int need_tag,
+                                                         int ny_build, InnovRide ir, const int32_t *__restrict__ sel = nullptr, InboxRide ib = InboxRide{}, PendW pw = PendW{})
+{
+    if (ib.n16 > 0 && blockIdx.y == gridDim.y - 1) { if (blockIdx.x == 0) inbox_pull_block(ib); return; }
+    if ((int)blockIdx.y >= ny_build) { innov_ride_block<T>(ir, ((int)blockIdx.y - ny_build) * gridDim.x + blockIdx.x); return; }
+    typedef T v4_t __attribute__((ext_vector_type(4)));
+    constexpr int PEND_MAX = 2 * NB;               // rows of a pending HI update (two panels)
+    __shared__ __attribute__((aligned(16))) float gp[PEND ? MB * 2 * PEND_MAX : 1];     // PendW: gp[k][2 mi + c] = row c of measurement mi times row k of W~
+    __shared__ T cv[MB][2][16];                    // coefficient rows of measurement s0 + mi: [c][t], t = 0..6 pose, 7..12 landmark
+    __shared__ int ccs[MB][16];                    // their columns (= rows of P)
+    __shared__ int state[MB];                      // 0: nothing to do (beyond r_pad, or not needed by this slice), 1: zero rows (padding), 2: a measurement
+    __shared__ double nus[MB][2];
+    const int s0 = blockIdx.y * MB, tid = threadIdx.x;
+    if (tid < MB * 16) {
+        const int mi = tid >> 4, t = tid & 15, sIdx = s0 + mi;
+        int st = 0, cvv = 0; T a0 = (T)0, a1 = (T)0;
+        if (2 * sIdx < r_pad && !(need != nullptr && sIdx < m && need[sIdx] != need_tag)) {
+            st = 1;
+            if (sIdx < m) {
+                st = 2;
+                const int i = meas[sel ? sel[sIdx] : sIdx];
+                const int d = lm_type[i] == PRE3_INVDEPTH ? 6 : 3, off = lm_off[i];
+                if (t < 7) { cvv = t; a0 = (T)Hc[14 * i + t]; a1 = (T)Hc[14 * i + 7 + t]; }
+                else if (t < 13) { const int u = t - 7; cvv = u < d ? off + u : 0; a0 = u < d ? (T)Hl[12 * i + u] : (T)0; a1 = u < d ? (T)Hl[12 * i + 6 + u] : (T)0; }
+                if (t == 13) { nus[mi][0] = z[2 * i] - h[2 * i]; nus[mi][1] = z[2 * i + 1] - h[2 * i + 1]; }
+            } else if (t == 13) { nus[mi][0] = 0; nus[mi][1] = 0; }
+        }
+        cv[mi][0][t] = a0; cv[mi][1][t] = a1; ccs[mi][t] = cvv;
+        if (t == 0) state[mi] = st;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < MB * 2 * ELLW) {
+        // the rows for the kernels that follow (H*P*H', scoring, the update), as k_ell_HP_build's block column 0 leaves them
+        const int mi = tid / (2 * ELLW), c = (tid / ELLW) & 1, t = tid & (ELLW - 1), sIdx = s0 + mi;
+        if (state[mi] != 0) {
+            row_col[(2 * sIdx + c) * ELLW + t] = t < 13 ? ccs[mi][t] : 0;
+            row_val[(2 * sIdx + c) * ELLW + t] = t < 13 ? cv[mi][c][t] : (T)0;
+            if (t == 0) row_nu[2 * sIdx + c] = nus[mi][c];
+        }
+    }
+    const int j = (blockIdx.x * blockDim.x + tid) * 4;
+    const int prow = PEND ? (pw.rows < PEND_MAX ? pw.rows : PEND_MAX) : 0;
+    int any = 0;
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi) any |= state[mi] == 2;
+    v4_t pp[7], lp[MB][6];
+    const bool inside = j < ld;                     // ld is a multiple of 128: the whole quad is inside
+    if (inside && any) {                            // (the gathers of P are on their way while the pending rows' coefficients are worked out)
+#pragma unroll
+        for (int t = 0; t < 7; ++t) pp[t] = *reinterpret_cast<const v4_t *>(P + (size_t)t * ld + j);
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi)
+            if (state[mi] == 2) {
+#pragma unroll
+                for (int t = 0; t < 6; ++t) lp[mi][t] = *reinterpret_cast<const v4_t *>(P + (size_t)ccs[mi][7 + t] * ld + j);
+            }
+    }
+    // P stands for P - W~'W~ (PRE3_OPT_PEND_HI): H*P loses (H W~') W~.  Eight rows of W~ per round trip, the next eight on their way while the last
+    // are used (a workgroup has few neighbours on its CU to hide an L2 latency behind), the first eight already while the coefficients are worked out.
+    constexpr int KB = 8;
+    const bool corr = PEND && prow > 0 && (int)(blockIdx.x * blockDim.x * 4) < ld;      // (block-uniform; the block column behind ld holds nu only)
+    const bool corr_t = corr && inside && any;
+    v4_t wa[KB], wb[KB];
+    auto loadw = [&](v4_t (&w)[KB], const int k0) {
+#pragma unroll
+        for (int u = 0; u < KB; ++u) { const int k = k0 + u < prow ? k0 + u : prow - 1; w[u] = *reinterpret_cast<const v4_t *>(reinterpret_cast<const T *>(pw.W) + (size_t)k * pw.ldw + j); }
+    };
+    v4_t out[MB][2];
+    auto applyw = [&](const v4_t (&w)[KB], const int k0) {
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            if (k0 + u < prow) {
+#pragma unroll
+                for (int mi = 0; mi < MB; ++mi) { out[mi][0] -= (T)gp[(k0 + u) * (2 * MB) + 2 * mi] * w[u]; out[mi][1] -= (T)gp[(k0 + u) * (2 * MB) + 2 * mi + 1] * w[u]; }
+            }
+        }
+    };
+    if (corr_t) loadw(wa, 0);
+    if (corr) {
+        // the MB x 2 x rows coefficients gp[k][2 mi + c] (the whole workgroup, before anybody leaves): thirteen scattered reads of W~ feed both rows of a measurement
+        for (int e = tid; e < MB * prow; e += 256) {
+            const int mi = e % MB, k = e / MB;
+            float g0 = 0.f, g1 = 0.f;
+            if (state[mi] == 2) {
+                const float *wr = pw.W + (size_t)k * pw.ldw;
+#pragma unroll
+                for (int t = 0; t < 13; ++t) { const float wv = wr[ccs[mi][t]]; g0 += (float)cv[mi][0][t] * wv; g1 += (float)cv[mi][1][t] * wv; }
+            }
+            gp[k * (2 * MB) + 2 * mi] = g0; gp[k * (2 * MB) + 2 * mi + 1] = g1;
+        }
+        __syncthreads();
+    }
+    if (j >= ldw) return;
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi) {
+        v4_t out0 = { (T)0, (T)0, (T)0, (T)0 }, out1 = out0;
+        if (state[mi] == 2) {
+            if (inside) {
+#pragma unroll
+                for (int t = 0; t < 7; ++t) { out0 += cv[mi][0][t] * pp[t]; out1 += cv[mi][1][t] * pp[t]; }
+#pragma unroll
+                for (int t = 0; t < 6; ++t) { out0 += cv[mi][0][7 + t] * lp[mi][t]; out1 += cv[mi][1][7 + t] * lp[mi][t]; }
+            } else if (j == ld) {
+                out0[0] = (T)nus[mi][0]; out1[0] = (T)nus[mi][1];
+            }
+        }
+        out[mi][0] = out0; out[mi][1] = out1;
+    }
+    if (corr_t) {
+        for (int k0 = 0; k0 < prow; k0 += 2 * KB) {
+            if (k0 + KB < prow) loadw(wb, k0 + KB);
+            applyw(wa, k0);
+            if (k0 + 2 * KB < prow) loadw(wa, k0 + 2 * KB);
+            if (k0 + KB < prow) applyw(wb, k0 + KB);
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi) {
+        const int sIdx = s0 + mi;
+        if (state[mi] == 0) continue;
+        *reinterpret_cast<v4_t *>(dst + (size_t)(2 * sIdx) * ldw + j) = out[mi][0];
+        *reinterpret_cast<v4_t *>(dst + (size_t)(2 * sIdx + 1) * ldw + j) = out[mi][1];
+    }
+}
+
 // dst[a][b] = sum_t val[b][t] * HP[a][col[b][t]] + (R ? R[a][b] : add_identity*delta_ab); padding = identity
 template <typename T>
 __global__ __launch_bounds__(64) void k_ell_G(int r, int r_pad, const int32_t *__restrict__ row_col, const T *__restrict__ row_val,
@@ -931,6 +1065,7 @@ struct HiFused {
     const float *P; int ld; float *S; float *W; int ldw; void *Wp; int nst_total; void *Sp; int sp_stride;
     double *params;
     int max_l;                                    // landmarks this launch may update with: 64 (two panels) when the context's row capacity holds them, else 32
+    int n = 0; double *x = nullptr; unsigned *xflag = nullptr;      // PRE3_OPT_PEND_HI (xflag != nullptr): no launch follows this one -- the strips finish the state themselves (hf_x_update)
 };
 struct HfSmem {
     int list[HF_MAXL2]; int cnt;
@@ -1041,6 +1176,70 @@ static __device__ unsigned long long g_hf[16];                  // wall-clock st
 #else
 #define HF_STAMP(k)
 #endif
+// PRE3_OPT_PEND_HI: x_k_k <- x_k_k + W~'(L^-1 nu) and update.m:42-46's normalisation (params[16..], [96..]) at the end of k_hi_fused itself -- the down-date
+// launch that used to carry this as its riders (update_x_block) is not sent.  Strip b owns the columns 64 (b - 1) ..: the entries of x it updates; L^-1 nu is
+// column ld, the last strip's, which raises a flag behind its stores (all workgroups of the launch are resident: 50 of them, one per CU).  The sums are
+// update_x_block's, term for term (sixteen chains over the rows a = g mod 16, then the chains in order, the prior last).
+__device__ __forceinline__ void hf_x_update(const HiFused &a, const int b, const int r, const bool two, ChSmem<float> &sm, HfSmem &hf)
+{
+    // No release / acquire fences (an agent-scope release writes the whole L2 back: 18 us per launch when every workgroup did one) and one hop only: the
+    // last strip sends L^-1 nu as write-through (sequence number, value) pairs, one 8-byte store per row; a reader polls the pair it needs with sc1
+    // loads until the number is this launch's.  A workgroup's own rows of W~ are still in LDS (what chol_store_w_strip has just read: Xs, and H0 for
+    // the first of two panels).
+    const int tid = threadIdx.x, b_nu = 1 + a.ld / NB;
+    auto wrow = [&](const int k, const int ci) -> float { return two ? (k < NB ? hf.two.H0[k][ci] : sm.Xs[k - NB][ci]) : sm.Xs[k][ci]; };
+    unsigned long long *ybuf = reinterpret_cast<unsigned long long *>(a.xflag);          // [128] pairs
+    if (b == b_nu) {
+        for (int k = tid; k < r; k += CH_NTH) {
+            const unsigned long long pr = ((unsigned long long)(unsigned)a.seq << 32) | (unsigned long long)__float_as_uint(wrow(k, 0));
+            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(ybuf + k), "v"(pr) : "memory");
+        }
+        return;                                                // (column block ld / 64 holds no entry of the state)
+    }
+    const int blk = b - 1;
+    if (b < 1 || blk * NB >= a.n) return;                      // workgroup 0 (no strip) and the strips behind the state's last entry
+    double *scratch = reinterpret_cast<double *>(&sm.Ls[0][0]);                         // (the factor is out; >= 16 * 64 + 4 + 128 doubles)
+    double (*red)[64] = reinterpret_cast<double (*)[64]>(scratch);
+    double *q = scratch + 16 * 64, *ys = scratch + 16 * 64 + 4;
+    __syncthreads();                                           // (everybody is done with Ls)
+    for (int k = tid; k < r; k += CH_NTH) {
+        unsigned long long pr = 0;
+        bool gave_up = true;
+        for (int spin = 0; spin < (1 << 20); ++spin) {
+            asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(pr) : "v"(ybuf + k) : "memory");
+            if ((unsigned)(pr >> 32) == (unsigned)a.seq) { gave_up = false; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (gave_up) atomicExch(a.stats + 7, 1);
+        ys[k] = (double)__uint_as_float((unsigned)pr);
+    }
+    __syncthreads();
+    const int ci = tid & 63, rg = tid >> 6;
+    const int i = blk * 64 + ci;
+    if (rg < 4) {
+#pragma unroll 1
+        for (int u = 0; u < 4; ++u) {
+            double sc = 0;
+            for (int k = rg + 4 * u; k < r; k += 16) sc = fma((double)wrow(k, ci), ys[k], sc);
+            red[rg + 4 * u][ci] = sc;
+        }
+    }
+    __syncthreads();
+    double sx = 0;
+    if (rg == 0) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) sx += red[g][ci];
+        if (i < a.n) sx += a.x[i];
+    }
+    if (blk == 0) {
+        if (rg == 0 && i >= 3 && i < 7) q[i - 3] = sx;
+        __syncthreads();
+        if (rg == 0 && i == 0) { double Jn[16]; d_normjac(q, Jn); for (int t = 0; t < 16; ++t) { a.params[16 + t] = Jn[t]; a.params[96 + t] = Jn[t]; } }
+        if (rg == 0 && i >= 3 && i < 7) sx = sx / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    }
+    if (rg == 0 && i < a.n) a.x[i] = sx;
+}
+
 __global__ __launch_bounds__(CH_NTH) void k_hi_fused(HiFused a)
 {
     HF_STAMP(0);
@@ -1157,6 +1356,7 @@ __global__ __launch_bounds__(CH_NTH) void k_hi_fused(HiFused a)
         HF_STAMP(5);
         chol_panel_body<float, false, true, true>(sm, a.S, NB, a.W, a.ldw, 0, 1, a.stats + 6, b, nullptr, 0u, a.Wp, a.nst_total, a.ld, a.Sp, a.sp_stride, r);
         HF_STAMP(6);
+        if (a.xflag != nullptr) hf_x_update(a, b, r, false, sm, hf);
         return;
     }
     // ---- two panels (33 .. 64 landmarks), every workgroup for itself as above.  S = [S00 . ; S10 S11], [H*P | nu] = [H0 ; H1] (this workgroup's
@@ -1259,6 +1459,7 @@ __global__ __launch_bounds__(CH_NTH) void k_hi_fused(HiFused a)
         }
         __syncthreads();
         chol_panel_body<float, false, true, true>(sm, a.S, 2 * NB, a.W, a.ldw, 1, 2, a.stats + 6, b, nullptr, 0u, a.Wp, a.nst_total, a.ld, a.Sp, a.sp_stride, r1);
+        if (a.xflag != nullptr) hf_x_update(a, b, r, true, sm, hf);
     }
 }
 
@@ -1984,6 +2185,7 @@ __global__ void k_fill_w(T *W, size_t count, float scale)
 
 int launch_ell_HP(pre3_ctx *c, int r, void *dst, bool with_nu)
 {
+    PRE3_TRY(pend_flush(c));
     int r_pad = round_up(r, NB);
     dim3 g(ceil_div(c->ldw, 256), r_pad), b(256);
     DISPATCH_T(c,
@@ -1995,9 +2197,12 @@ int launch_ell_HP(pre3_ctx *c, int r, void *dst, bool with_nu)
     return PRE3_OK;
 }
 
+static inline int hp_build_mb() { static const int v = getenv("PRE3_HP_MB") ? atoi(getenv("PRE3_HP_MB")) : 1; return v; }      // 0: one measurement per workgroup (k_ell_HP_build)
+
 // the same for a subset: row pair a = measurement sel[a] (sel == nullptr: a), a < nsel; the padding up to r_pad is zero rows
 int launch_ell_HP_build_sel(pre3_ctx *c, int nsel, const int32_t *sel_dev, void *dst)
 {
+    PRE3_TRY(pend_flush(c));
     const int r_pad = round_up(2 * nsel, NB);
     if (r_pad == 0) return PRE3_OK;
     const int gx = ceil_div(c->ldw / 4, 256), ny = r_pad / 2;
@@ -2006,6 +2211,20 @@ int launch_ell_HP_build_sel(pre3_ctx *c, int nsel, const int32_t *sel_dev, void 
         const int nb = ceil_div(c->N * 16, 256), rows = ceil_div(nb, gx);
         ir = InnovRide{ rows * gx, c->N, c->ld, (int)(c->flags_bytes / sizeof(int32_t)), c->lm.type, c->lm.off, c->lm.has_h, c->P, c->lm.Hc, c->lm.Hl,
                         c->lm.S, c->lm.has_S, (int32_t *)((unsigned char *)c->inbox_dev + c->off_flags) };
+    }
+    if (hp_build_mb() > 0) {
+        constexpr int MBF = 4, MBD = 2;
+        auto kd = k_ell_HP_build_mb<double, MBD>; auto kf = k_ell_HP_build_mb<float, MBF>;
+        const int nyg = c->dtype == PRE3_F32 ? ceil_div(ny, MBF) : ceil_div(ny, MBD);
+        dim3 g(gx, nyg + (ir.n_blocks ? ir.n_blocks / gx : 0)), b(256);
+        DISPATCH_T(c,
+            hipLaunchKernelGGL(kd, g, b, 0, c->stream, nsel, r_pad, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl, c->lm.z, c->lm.h,
+                               c->row_col, (double *)c->row_val, c->row_nu, (const double *)c->P, c->ld, (double *)dst, c->ldw, (const int32_t *)nullptr, 0, nyg, ir, sel_dev, InboxRide{}, PendW{}),
+            hipLaunchKernelGGL(kf, g, b, 0, c->stream, nsel, r_pad, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl, c->lm.z, c->lm.h,
+                               c->row_col, (float *)c->row_val, c->row_nu, (const float *)c->P, c->ld, (float *)dst, c->ldw, (const int32_t *)nullptr, 0, nyg, ir, sel_dev, InboxRide{}, PendW{}));
+        PRE3_HIP(hipGetLastError());
+        if (ir.n_blocks) { c->ride_innovation = false; c->innovated = true; }
+        return PRE3_OK;
     }
     dim3 g(gx, ny + (ir.n_blocks ? ir.n_blocks / gx : 0)), b(256);
     DISPATCH_T(c,
@@ -2030,6 +2249,24 @@ int launch_ell_HP_build(pre3_ctx *c, void *dst, const int32_t *need, int need_ta
         const int nb = ceil_div(c->N * 16, 256), rows = ceil_div(nb, gx);
         ir = InnovRide{ rows * gx, c->N, c->ld, (int)(c->flags_bytes / sizeof(int32_t)), c->lm.type, c->lm.off, c->lm.has_h, c->P, c->lm.Hc, c->lm.Hl,
                         c->lm.S, c->lm.has_S, (int32_t *)((unsigned char *)c->inbox_dev + c->off_flags) };
+    }
+    // PRE3_OPT_PEND_HI: this launch (rows of ALL measurements at the predicted state, S_i riding) reads P - W~'W~; every other form runs behind the flush
+    PendW pw = pend_args(c);
+    if (pw.rows > 0 && !(hp_build_mb() > 0 && c->dtype == PRE3_F32 && need == nullptr)) { PRE3_TRY(pend_flush(c)); pw = PendW{}; }
+    if (pw.rows > 0) { ir.pend_W = pw.W; ir.pend_ldw = pw.ldw; ir.pend_rows = pw.rows; }
+    if (hp_build_mb() > 0) {
+        constexpr int MBF = 4, MBD = 2;
+        auto kd = k_ell_HP_build_mb<double, MBD>; auto kf = pw.rows > 0 ? k_ell_HP_build_mb<float, MBF, true> : k_ell_HP_build_mb<float, MBF, false>;
+        const int nyg = c->dtype == PRE3_F32 ? ceil_div(ny, MBF) : ceil_div(ny, MBD);
+        dim3 g(gx, nyg + (ir.n_blocks ? ir.n_blocks / gx : 0) + ib_rows), b(256);
+        DISPATCH_T(c,
+            hipLaunchKernelGGL(kd, g, b, 0, c->stream, c->m, r_pad, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl, c->lm.z, c->lm.h,
+                               c->row_col, (double *)c->row_val, c->row_nu, (const double *)c->P, c->ld, (double *)dst, c->ldw, need, need_tag, nyg, ir, (const int32_t *)nullptr, ib, PendW{}),
+            hipLaunchKernelGGL(kf, g, b, 0, c->stream, c->m, r_pad, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl, c->lm.z, c->lm.h,
+                               c->row_col, (float *)c->row_val, c->row_nu, (const float *)c->P, c->ld, (float *)dst, c->ldw, need, need_tag, nyg, ir, (const int32_t *)nullptr, ib, pw));
+        PRE3_HIP(hipGetLastError());
+        if (ir.n_blocks) { c->ride_innovation = false; c->innovated = true; }
+        return PRE3_OK;
     }
     dim3 g(gx, ny + (ir.n_blocks ? ir.n_blocks / gx : 0) + ib_rows), b(256);
     DISPATCH_T(c,
@@ -2275,8 +2512,31 @@ int hi_fused_max(const pre3_ctx *c)
     return two_env != 0 && c->rcap >= 2 * NB ? HF_MAXL2 : HF_MAXL;
 }
 
+PendW pend_args(const pre3_ctx *c)
+{
+    if (c->pend_rows <= 0 || c->W_pend == nullptr) return PendW{};
+    return PendW{ c->W_pend, c->ldw, c->pend_rows, c->Wp_pend, c->rcap / B3_BK };
+}
+
+// the pending HI down-date as the launch it would have been (tiles only: the x-update went out with k_hi_fused's launch pair)
+int pend_flush(pre3_ctx *c)
+{
+    if (c->pend_rows <= 0) return PRE3_OK;
+    const int rows = c->pend_rows;
+    c->pend_rows = 0;
+    XUpd xu{ c->n_tiles128, c->n, 0, c->x_kk, c->x_kk, c->pred_params, nullptr, 0 };
+    xu.wt = k9_write_through();
+    ProjRide pr{};
+    hipLaunchKernelGGL(k_downdate_b3, dim3(c->n_tiles128), dim3(256), 0, c->stream, (float *)c->P, c->ld, (const bf16x8_t *)c->Wp_pend, c->rcap / B3_BK, rows > NB ? 8 : 4,
+                       (const float *)c->W_pend, c->ldw, (const int2 *)c->tiles128, xu, pr);
+    PRE3_HIP(hipGetLastError());
+    c->hp_all_valid = false;
+    return PRE3_OK;
+}
+
 int launch_hi_fused(pre3_ctx *c, int32_t seq)
 {
+    PRE3_TRY(pend_flush(c));                       // (k_hi_fused reads P)
     HiFused a{};
     a.m = c->m; a.meas = c->meas; a.lm_ic = c->lm.ic; a.lm_li = c->lm.li; a.lm_hi = c->lm.hi; a.lm_type = c->lm.type; a.lm_off = c->lm.off;
     a.Hc = c->lm.Hc; a.Hl = c->lm.Hl; a.z = c->lm.z; a.h = c->lm.h;
@@ -2285,7 +2545,17 @@ int launch_hi_fused(pre3_ctx *c, int32_t seq)
     a.P = (const float *)c->P; a.ld = c->ld; a.S = (float *)c->Smat; a.W = (float *)c->W; a.ldw = c->ldw;
     a.Wp = c->Wp; a.nst_total = c->rcap / B3_BK; a.Sp = c->Sp; a.sp_stride = c->rcap / NB; a.params = c->pred_params;
     a.max_l = hi_fused_max(c);
+    // PRE3_OPT_PEND_HI: W~ and its planes go to buffers of their own (the next LI update's strips overwrite W / Wp), the launch behind this one carries
+    // the x-update only, and P - W~'W~ stays pending (pre3_update_hi learns the row count; pend_flush / launch_cholp end it)
+    const bool pend = c->pend_opt && c->W_pend != nullptr && c->Wp_pend != nullptr && c->hf_xy != nullptr;
+    if (pend) { a.W = c->W_pend; a.Wp = c->Wp_pend; a.n = c->n; a.x = c->x_kk; a.xflag = c->hf_xy; }
+    c->hi_pend_launched = pend;
     hipLaunchKernelGGL(k_hi_fused, dim3(1 + c->ldw / NB), dim3(CH_NTH), 0, c->stream, a);
+    if (pend) {                                    // (the strips finish the state themselves: hf_x_update)
+        PRE3_HIP(hipGetLastError());
+        c->split_rows = 0; c->dd_done = 0; c->x_done = false; c->cholp_done = false;
+        return PRE3_OK;
+    }
     // the down-date of that update (one or two panels: four or eight k-stages, read on the device), the x-update riding along; every workgroup leaves at once unless stats[8] == 1
     const int nx = ceil_div(c->n, 64);
     XUpd xu{ c->n_tiles128, c->n, 0, c->x_kk, c->x_kk, c->pred_params, c->stats, nx };
@@ -2394,6 +2664,7 @@ int run_update(pre3_ctx *c, int which_prior, int r, bool dense_R, void *Kt_out_d
     }
     int r_pad = round_up(r, NB);
     PRE3_CHECK(r_pad <= c->rcap, PRE3_E_ARG, "update with %d rows exceeds the context capacity %d", r, c->rcap);
+    PRE3_TRY(pend_flush(c));                       // (PRE3_OPT_PEND_HI: unless the speculative persistent launch's consumers have taken the pending rows already)
     if (!prebuilt) {
         if (!hp_built) PRE3_TRY(launch_ell_HP(c, r, c->W, true));           // (hp_built: launch_ell_HP_build_sel made the rows and W = H*P in one launch)
         PRE3_TRY(launch_ell_G(c, r, c->W, c->Smat, r_pad, 1, dense_R ? c->Rdense : nullptr));

@@ -134,6 +134,16 @@ class EkfFilter:
         check(lib.pre3_get_option(self._ctx, 5, C.byref(v)))
         return bool(v.value)
 
+    def pend_hi(self, on=None):
+        """PRE3_OPT_PEND_HI (fp32 contexts with the persistent factorisation, together with defer_hi_update): the HI update's down-date of P is not
+        launched behind the update but taken along by the next step's launches (prediction, H*P, the LI update's consumers): P is swept once per
+        step.  Results agree with the default form to fp32 rounding.  Returns the setting in force."""
+        if on is not None:
+            check(lib.pre3_set_option(self._ctx, 8, int(bool(on))))
+        v = C.c_int(0)
+        check(lib.pre3_get_option(self._ctx, 8, C.byref(v)))
+        return bool(v.value)
+
     def step_tail(self, on=None):
         """PRE3_OPT_STEP_TAIL (fp32 contexts): rescue_hi_inliers + ekf_update_hi_inliers (up to 32 landmarks) inside the LI update's persistent
         launch, P swept once per step; off (default: measured no faster on MI355X): as launches of their own behind it.  Same inlier sets, x / P equal to fp32 rounding.

@@ -230,6 +230,13 @@ PRE3_API int pre3_update_ell(int device, int dtype, int n, int r, const double *
  * writes the result block into host memory -- two launches; 1: the ranked route of PRE3_OPT_IC_RANKED; 0: the exact 64 x 64 tiled kernel.
  * The environment's PRE3_IC_FUSED=0 disables route 2.  Results are bit-identical on all three. */
 #define PRE3_OPT_IC_ROUTE 7
+/* PRE3_OPT_PEND_HI (fp32 contexts with PRE3_OPT_K9_OVERLAP; default: the environment's PRE3_PEND_HI, else 0): inside pre3_step the covariance down-date of
+ * the HI update (update.m:37-38 as ekf_update_hi_inliers.m:58 calls it) is not launched behind the update; P - W~'W~ stays PENDING across the step
+ * boundary: the next pre3_step's prediction transforms W~ with P, its H*P / S_i launch subtracts (H W~')W~, and the consumers of its LI update's
+ * persistent launch take W~ as the panels in front of panel 0 -- P is read and written ONCE per step instead of twice.  Every other call on the
+ * context (and every path of pre3_step that cannot take the pending rows) first runs the down-date as the launch it would have been.  The same
+ * arithmetic except that P between the two updates is never rounded to fp32: results agree with the default form to fp32 rounding, not to the bit. */
+#define PRE3_OPT_PEND_HI 8
 PRE3_API int pre3_set_option(pre3_ctx *ctx, int option, int value);
 PRE3_API int pre3_get_option(pre3_ctx *ctx, int option, int *value_out);
 
