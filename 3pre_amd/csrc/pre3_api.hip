@@ -1334,7 +1334,13 @@ int pre3_update_hi(pre3_ctx *c)
             if (n_hi > 0) {
                 c->hp_all_valid = false;
                 // PRE3_OPT_PEND_HI: k_hi_fused's down-date was not launched -- from here on P stands for P - W~'W~ (2 n_hi rows) until somebody takes it
-                if (pend_launched) c->pend_rows = 2 * n_hi;
+                if (pend_launched) {
+                    c->pend_rows = 2 * n_hi;
+                    // (two panels of pending rows cost the next H*P launch ~19 us more, one panel ~5: sending the two-panel ones out at once -- PRE3_PEND_MAX_ROWS=64 --
+                    //  measured 5922 against 5954 steps/s: the launch they then need costs as much)
+                    static const int pend_max = getenv("PRE3_PEND_MAX_ROWS") ? atoi(getenv("PRE3_PEND_MAX_ROWS")) : 2 * NB;
+                    if (c->pend_rows > pend_max) PRE3_TRY(pend_flush(c));
+                }
                 if (c->leave_jn_to_predict) c->jn_pending = true;
                 else PRE3_TRY(launch_jnorm(c, 0));              // (flushes the pending rows first: the pass reads P)
             }

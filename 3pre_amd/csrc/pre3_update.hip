@@ -133,6 +133,9 @@ __global__ __launch_bounds__(256) void k_ell_HP_build(int m, int r_pad, const in
 // workgroup and column quad instead of once per measurement (35 instead of 64 MB through the L2s at N = 500), the measurements' coefficient rows
 // come from an LDS table built once per workgroup, and all MB x 6 landmark-row loads of a thread are in flight together.  Same 13-term chain in the
 // same order per entry: bit-identical to k_ell_HP_build (tests/test_gpu_variants.py, PRE3_HP_MB=0 restores that kernel).
+#ifndef PRE3_PEND_KB
+#define PRE3_PEND_KB 8
+#endif
 template <typename T, int MB, bool PEND = false>
 __global__ __launch_bounds__(256) void k_ell_HP_build_mb(int m, int r_pad, const int32_t *__restrict__ meas, const int32_t *__restrict__ lm_type,
                                                          const int32_t *__restrict__ lm_off, const double *__restrict__ Hc,
@@ -183,21 +186,25 @@ __global__ __launch_bounds__(256) void k_ell_HP_build_mb(int m, int r_pad, const
     int any = 0;
 #pragma unroll
     for (int mi = 0; mi < MB; ++mi) any |= state[mi] == 2;
-    v4_t pp[7], lp[MB][6];
+    constexpr int GB = PEND ? 2 : (MB < 4 ? MB : 4);      // measurements whose landmark rows are in flight together (the pending form keeps 2 MB quads of results)
+    v4_t pp[7], lp[GB][6];
     const bool inside = j < ld;                     // ld is a multiple of 128: the whole quad is inside
+    auto load_lp = [&](const int h) {
+#pragma unroll
+        for (int u = 0; u < GB; ++u)
+            if (state[h + u] == 2) {
+#pragma unroll
+                for (int t = 0; t < 6; ++t) lp[u][t] = *reinterpret_cast<const v4_t *>(P + (size_t)ccs[h + u][7 + t] * ld + j);
+            }
+    };
     if (inside && any) {                            // (the gathers of P are on their way while the pending rows' coefficients are worked out)
 #pragma unroll
         for (int t = 0; t < 7; ++t) pp[t] = *reinterpret_cast<const v4_t *>(P + (size_t)t * ld + j);
-#pragma unroll
-        for (int mi = 0; mi < MB; ++mi)
-            if (state[mi] == 2) {
-#pragma unroll
-                for (int t = 0; t < 6; ++t) lp[mi][t] = *reinterpret_cast<const v4_t *>(P + (size_t)ccs[mi][7 + t] * ld + j);
-            }
+        load_lp(0);
     }
     // P stands for P - W~'W~ (PRE3_OPT_PEND_HI): H*P loses (H W~') W~.  Eight rows of W~ per round trip, the next eight on their way while the last
     // are used (a workgroup has few neighbours on its CU to hide an L2 latency behind), the first eight already while the coefficients are worked out.
-    constexpr int KB = 8;
+    constexpr int KB = PRE3_PEND_KB;
     const bool corr = PEND && prow > 0 && (int)(blockIdx.x * blockDim.x * 4) < ld;      // (block-uniform; the block column behind ld holds nu only)
     const bool corr_t = corr && inside && any;
     v4_t wa[KB], wb[KB];
@@ -215,7 +222,6 @@ __global__ __launch_bounds__(256) void k_ell_HP_build_mb(int m, int r_pad, const
             }
         }
     };
-    if (corr_t) loadw(wa, 0);
     if (corr) {
         // the MB x 2 x rows coefficients gp[k][2 mi + c] (the whole workgroup, before anybody leaves): thirteen scattered reads of W~ feed both rows of a measurement
         for (int e = tid; e < MB * prow; e += 256) {
@@ -232,21 +238,28 @@ __global__ __launch_bounds__(256) void k_ell_HP_build_mb(int m, int r_pad, const
     }
     if (j >= ldw) return;
 #pragma unroll
-    for (int mi = 0; mi < MB; ++mi) {
-        v4_t out0 = { (T)0, (T)0, (T)0, (T)0 }, out1 = out0;
-        if (state[mi] == 2) {
-            if (inside) {
+    for (int h = 0; h < MB; h += GB) {
+        if (h > 0 && inside && any) load_lp(h);
 #pragma unroll
-                for (int t = 0; t < 7; ++t) { out0 += cv[mi][0][t] * pp[t]; out1 += cv[mi][1][t] * pp[t]; }
+        for (int u = 0; u < GB; ++u) {
+            const int mi = h + u;
+            v4_t out0 = { (T)0, (T)0, (T)0, (T)0 }, out1 = out0;
+            if (state[mi] == 2) {
+                if (inside) {
 #pragma unroll
-                for (int t = 0; t < 6; ++t) { out0 += cv[mi][0][7 + t] * lp[mi][t]; out1 += cv[mi][1][7 + t] * lp[mi][t]; }
-            } else if (j == ld) {
-                out0[0] = (T)nus[mi][0]; out1[0] = (T)nus[mi][1];
+                    for (int t = 0; t < 7; ++t) { out0 += cv[mi][0][t] * pp[t]; out1 += cv[mi][1][t] * pp[t]; }
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) { out0 += cv[mi][0][7 + t] * lp[u][t]; out1 += cv[mi][1][7 + t] * lp[u][t]; }
+                } else if (j == ld) {
+                    out0[0] = (T)nus[mi][0]; out1[0] = (T)nus[mi][1];
+                }
             }
+            out[mi][0] = out0; out[mi][1] = out1;
         }
-        out[mi][0] = out0; out[mi][1] = out1;
     }
     if (corr_t) {
+        asm volatile("" ::: "memory");                       // (the rows of W~ are not fetched while the gathers of P hold the registers: 222 against 160)
+        loadw(wa, 0);
         for (int k0 = 0; k0 < prow; k0 += 2 * KB) {
             if (k0 + KB < prow) loadw(wb, k0 + KB);
             applyw(wa, k0);
@@ -2256,8 +2269,10 @@ int launch_ell_HP_build(pre3_ctx *c, void *dst, const int32_t *need, int need_ta
     if (pw.rows > 0) { ir.pend_W = pw.W; ir.pend_ldw = pw.ldw; ir.pend_rows = pw.rows; }
     if (hp_build_mb() > 0) {
         constexpr int MBF = 4, MBD = 2;
-        auto kd = k_ell_HP_build_mb<double, MBD>; auto kf = pw.rows > 0 ? k_ell_HP_build_mb<float, MBF, true> : k_ell_HP_build_mb<float, MBF, false>;
-        const int nyg = c->dtype == PRE3_F32 ? ceil_div(ny, MBF) : ceil_div(ny, MBD);
+        static const int mbp = getenv("PRE3_PEND_MB") ? atoi(getenv("PRE3_PEND_MB")) : 4;      // measurements per workgroup of the pending form: 4 (17.1 -> 16.5 us with their landmark rows gathered two at a time); 8 halves the loads of W~ but leaves 156 workgroups for 256 CUs (18.7 us), 2 doubles them (21.5 us)
+        const int mbf = pw.rows > 0 ? (mbp == 8 ? 8 : 4) : MBF;
+        auto kd = k_ell_HP_build_mb<double, MBD>; auto kf = pw.rows > 0 ? (mbf == 8 ? k_ell_HP_build_mb<float, 8, true> : k_ell_HP_build_mb<float, 4, true>) : k_ell_HP_build_mb<float, MBF, false>;
+        const int nyg = c->dtype == PRE3_F32 ? ceil_div(ny, mbf) : ceil_div(ny, MBD);
         dim3 g(gx, nyg + (ir.n_blocks ? ir.n_blocks / gx : 0) + ib_rows), b(256);
         DISPATCH_T(c,
             hipLaunchKernelGGL(kd, g, b, 0, c->stream, c->m, r_pad, c->meas, c->lm.type, c->lm.off, c->lm.Hc, c->lm.Hl, c->lm.z, c->lm.h,

@@ -638,6 +638,7 @@ def main():
     ap.add_argument("--hyp", type=int, default=200)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--kt-every", type=int, default=8, help="bracket one K9 launch in N with HIP events (an event pair costs ~11 us of stream time); 1 = every launch")
+    ap.add_argument("--no-pend-hi", action="store_true", help="headline leg: the HI update's down-date as its own launch behind the update (PRE3_OPT_PEND_HI = 0, the library's default)")
     ap.add_argument("--sync-hi", action="store_true", help="complete every step's HI update inside the step call (default: deferred to the next call)")
     ap.add_argument("--k9-f32", action="store_true", help="fp32 path: K9 on the f32 MFMA instead of the three-way bf16 split (PRE3_OPT_K9_BF16X3 = 0)")
     ap.add_argument("--threshold", type=float, default=None, help="RANSAC threshold in pixels; default: the reference's own constant, 1.0 "
@@ -732,6 +733,10 @@ def main():
     f.set_x_p_k_k(seq["x0"], seq["P0"])
     for s in seq["steps"][:W]:
         f.step(s["u"], s["meas_idx"], s["z"], s["hyp"], threshold=thr, early_exit=False)
+    pend_hi = False
+    if not args.sync_hi and not args.no_pend_hi and args.dtype == "f32":
+        pend_hi = f.pend_hi(True)                  # PRE3_OPT_PEND_HI: the HI update's down-date of P is taken along by the next step's launches (P swept once per
+                                                   # step; the same arithmetic to fp32 rounding -- check_step below compares what was timed with the twin)
     if not args.sync_hi:
         f.defer_hi_update(True)                    # PRE3_OPT_DEFER_HI: the HI update of step k is completed by the call of step k+1 (same results;
                                                    # the caller's time between steps overlaps the rescue stage); the final timer_stop() flushes the last one
@@ -886,6 +891,7 @@ def main():
                        "sequence": "3pre_amd/synth.py HEADLINE: SURVEY 8(d)'s measurement spec (0.8 N measured, 20 % gross outliers, threshold 1.0 px); the truth "
                                    "leaves the odometry by motion_noise x the filter's process noise, which is what gives rescue_hi_inliers.m work in every step",
                        "parallelism": "replicas x%d" % world,
+                       "options": {"PRE3_OPT_DEFER_HI": 0 if args.sync_hi else 1, "PRE3_OPT_PEND_HI": 1 if pend_hi else 0},
                        "hip_event_ms_per_step": ev_ms / K},
             "roofline": roofline,
             "k9_standalone": k9_alone,
