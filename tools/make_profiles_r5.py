@@ -87,7 +87,8 @@ if hi2:
 hf = sorted(dur(r) for r in rows(tr) if "k_hi_fused" in r["Kernel_Name"])
 hd = sorted(dur(r) for r in rows(tr) if "k_downdate_b3" in r["Kernel_Name"])
 out.append("# k_hi_fused (collection + HI update of <= 64 landmarks: one panel up to 32, two panels inside the launch up to 64): %d launches, median %.2f us (min %.2f: nothing rescued, max %.2f)" % (len(hf), med(hf), hf[0], hf[-1]))
-out.append("# k_downdate_b3 (the HI updates' down-date; device-gated, ~4 us when there is nothing to do): %d launches, median %.2f us, max %.2f us" % (len(hd), med(hd), hd[-1]))
+out.append("# k_downdate_b3 (the HI updates' down-date; device-gated, ~4 us when there is nothing to do; with PRE3_OPT_PEND_HI -- bench.py's headline from round 6 on -- only where "
+           "pending rows are flushed: the warm-up's steps, which complete their HI update inside the call): %d launches, median %.2f us, max %.2f us" % (len(hd), med(hd) if hd else 0.0, hd[-1] if hd else 0.0))
 open(os.path.join(P, "%s_cholp_launches.txt" % tag), "w").write("\n".join(out) + "\n")
 print("\n".join(out))
 
