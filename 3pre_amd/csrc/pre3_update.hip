@@ -2267,7 +2267,7 @@ int launch_ell_HP_build(pre3_ctx *c, void *dst, const int32_t *need, int need_ta
     PendW pw = pend_args(c);
     if (pw.rows > 0 && !(hp_build_mb() > 0 && c->dtype == PRE3_F32 && need == nullptr)) { PRE3_TRY(pend_flush(c)); pw = PendW{}; }
     if (pw.rows > 0) { ir.pend_W = pw.W; ir.pend_ldw = pw.ldw; ir.pend_rows = pw.rows; }
-    if (hp_build_mb() > 0) {
+    if (hp_build_mb() > 0 && need == nullptr) {      // (a sharded round's slice -- need != nullptr -- skips most measurements: one per workgroup, k_ell_HP_build, returns at once for those)
         constexpr int MBF = 4, MBD = 2;
         static const int mbp = getenv("PRE3_PEND_MB") ? atoi(getenv("PRE3_PEND_MB")) : 4;      // measurements per workgroup of the pending form: 4 (17.1 -> 16.5 us with their landmark rows gathered two at a time); 8 halves the loads of W~ but leaves 156 workgroups for 256 CUs (18.7 us), 2 doubles them (21.5 us)
         const int mbf = pw.rows > 0 ? (mbp == 8 ? 8 : 4) : MBF;
