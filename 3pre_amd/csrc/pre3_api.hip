@@ -383,7 +383,8 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
                                   hipMemcpy(c->dd_tiles, t64.data(), sizeof(int2) * t64.size(), hipMemcpyHostToDevice) != hipSuccess)) { set_error("consumer table upload failed"); rc = PRE3_E_HIP; }
         }
         A(dmalloc_bytes(&c->cholp_tp, (size_t)(c->rcap / NB) * 1536 * 16));
-        { void *f = nullptr; A(dmalloc_bytes(&f, sizeof(float) * 4 * (size_t)c->ld)); c->jn_q = (float *)f; }      // rows 3..6 of P before the Jnorm pass (GateRide, pre3_geom.hip)
+        { void *f = nullptr; A(dmalloc_bytes(&f, sizeof(float) * 4 * (size_t)c->ld)); c->jn_q = (float *)f; }
+        { void *f = nullptr; A(dmalloc_bytes(&f, sizeof(unsigned long long) * (2 * NB) * (2 * NB))); c->hf_sx = (unsigned long long *)f; }      // rows 3..6 of P before the Jnorm pass (GateRide, pre3_geom.hip)
         // (the buffers of the in-launch tail, PRE3_OPT_STEP_TAIL, are allocated when the option is switched on: tail_alloc -- at N = 2000 they are
         //  ~300 MB that the default path never touches)
         if (c->step_tail) A(tail_alloc(c));
@@ -462,7 +463,7 @@ int pre3_destroy(pre3_ctx *c)
     c->comm = nullptr;
     void *bufs[] = { c->x_kk, c->x_km1, c->P, c->lm.type, c->lm.off, c->lm.h, c->lm.has_h, c->lm.Hc, c->lm.Hl, c->lm.S, c->lm.has_S,
                      c->inbox_dev, c->row_col, c->row_val, c->row_nu, c->HP, c->W, c->G, c->Smat, c->Rdense,
-                     c->sel_rows, c->support, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_src0, c->map_conv, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128, c->need, c->cholp_flags, c->cholp_tp, c->dd_groups, c->dd_tiles, c->tail_yp, c->tail_hb, c->tail_hib, c->tail_wt, c->jn_q, c->W_pend, c->Wp_pend, c->hf_xy };
+                     c->sel_rows, c->support, c->stats, c->pred_params, c->tiles, c->tile_ctr, c->tile_cnt, c->tiles_flat, c->P_alt, c->x_alt, c->map_col, c->map_val, c->map_desc, c->map_src0, c->map_conv, c->map_feat, c->map_flags, c->bank, c->bank_alt, c->scan_desc, c->scan_pos, c->ic_pred, c->ic_counts, c->ic_arg, c->ic_newk2, c->ic_best, c->ic_second, c->bank_src, c->chol_arrive, c->ic_pb, c->ic_ps, c->ic_pa, c->Wp, c->Sp, c->tiles128, c->need, c->cholp_flags, c->cholp_tp, c->dd_groups, c->dd_tiles, c->tail_yp, c->tail_hb, c->tail_hib, c->tail_wt, c->jn_q, c->W_pend, c->Wp_pend, c->hf_xy, c->hf_sx };
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (int k2 = 0; k2 < 2; ++k2) { if (c->map_stage[k2]) (void)hipHostFree(c->map_stage[k2]); if (c->map_stage_ev[k2]) (void)hipEventDestroy(c->map_stage_ev[k2]); }
     for (int k2 = 0; k2 < 2; ++k2) { if (c->up_stage[k2]) (void)hipHostFree(c->up_stage[k2]); if (c->up_stage_ev[k2]) (void)hipEventDestroy(c->up_stage_ev[k2]); }

@@ -197,6 +197,7 @@ struct pre3_ctx {
     // PRE3_OPT_PEND_HI (PendW, pre3_geomdev.h): k_hi_fused's W~ goes to its own buffers and the down-date is not launched; pend_rows > 0 from the moment the host
     // has the HI count (pre3_update_hi) until k_cholp's consumers have taken the panels (launch_cholp) or pend_flush() has run k_downdate_b3 on them
     bool pend_opt = false; bool hi_pend_launched = false; bool pend_keep = false; int pend_rows = 0;
+    unsigned long long *hf_sx = nullptr;          // k_hi_fused, two panels: S as [128][128] (sequence number, value) pairs, dealt over the workgroups (hf_S_dealt)
     float *W_pend = nullptr; void *Wp_pend = nullptr; unsigned *hf_xy = nullptr;      // hf_xy: [0] k_hi_fused's "L^-1 nu is out" word, [64 .. 191] L^-1 nu (hf_x_update)
     bool step_tail = false;                       // PRE3_OPT_STEP_TAIL (default: the environment's PRE3_TAIL, else off)
     bool tail_want = false; double tail_chi2 = 0;  // pre3_step asks the LI update's launch to carry the tail

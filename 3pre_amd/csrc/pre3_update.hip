@@ -1078,6 +1078,7 @@ struct HiFused {
     const float *P; int ld; float *S; float *W; int ldw; void *Wp; int nst_total; void *Sp; int sp_stride;
     double *params;
     int max_l;                                    // landmarks this launch may update with: 64 (two panels) when the context's row capacity holds them, else 32
+    unsigned long long *sx = nullptr;             // two panels: S dealt over the workgroups -- [128][128] (sequence number, value) pairs (hf_S_dealt); nullptr: every workgroup builds all of S
     int n = 0; double *x = nullptr; unsigned *xflag = nullptr;      // PRE3_OPT_PEND_HI (xflag != nullptr): no launch follows this one -- the strips finish the state themselves (hf_x_update)
 };
 struct HfSmem {
@@ -1189,6 +1190,91 @@ static __device__ unsigned long long g_hf[16];                  // wall-clock st
 #else
 #define HF_STAMP(k)
 #endif
+// Two panels (33 .. 64 rescued landmarks): S = H*P*H' + I dealt over the launch's workgroups instead of built by every one of them (three blocks of T,
+// 24 us at 64 landmarks: fifty workgroups asking for the same lines of P).  Workgroup b takes the row pairs p = b, b + G, .. of the list: T(rows of p,
+// [pose | landmarks 0 .. p]) -- one column per thread, thirteen reads --, then S(ra, rb) for rb <= ra by hf_S_entry's chain, out as write-through
+// (sequence number, value) pairs; then everybody collects the lower triangle with sc1 loads, re-reading what is not there yet (no fences, no counters:
+// round 5's form of this, with a release / acquire per workgroup, cost 10-11 us).  A small map has fewer workgroups than pairs: they take several, one after the other.  The same fma chains as hf_T_block / hf_S_entry: the same bits.
+// Leaves Ls = S00, Bs = S10 (padding rows zero), hf.two.S11 = S11 (identity padding), as the redundant form does.
+__device__ __forceinline__ void hf_S_dealt(HfSmem &hf, ChSmem<float> &sm, const HiFused &a, const int b, const int cnt, int32_t *status_wait)
+{
+    const int tid = threadIdx.x, r = 2 * cnt, G = gridDim.x;
+    constexpr int TW = 7 + 6 * HF_MAXL2 + 1;                  // 392
+    float (*T2)[TW] = reinterpret_cast<float (*)[TW]>(&hf.T[0][0]);      // [2][392] inside T's 64 x 202 floats
+    static_assert(2 * TW <= NB * HF_TS, "hf_S_dealt: T2 fits T");
+    for (int p = b; p < cnt; p += G) {                        // (block-uniform: the barriers inside are reached by the whole workgroup)
+        const int nU = 7 + 6 * (p + 1), row = 2 * p;
+        for (int k = tid; k < nU; k += CH_NTH) {
+            const float *pc = a.P + (k < 7 ? k : hf.ucol[k]);
+            float pv[13];
+#pragma unroll
+            for (int t = 0; t < 7; ++t) pv[t] = pc[(size_t)t * a.ld];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) pv[7 + t] = pc[(size_t)hf.rc[row][7 + t] * a.ld];
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 13; ++t) { s0 = fmaf(hf.rv[row][t], pv[t], s0); s1 = fmaf(hf.rv[row + 1][t], pv[t], s1); }
+            T2[0][k] = s0; T2[1][k] = s1;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * (2 * p + 2); idx += CH_NTH) {
+            const int rr = idx / (2 * p + 2), rb = idx - rr * (2 * p + 2), ra = 2 * p + rr;
+            if (rb > ra) continue;
+            const int kb = 7 + 6 * (rb >> 1);
+            float sv = 0.f;
+#pragma unroll
+            for (int t = 0; t < 13; ++t) sv = fmaf(hf.rv[rb][t], T2[rr][t < 7 ? t : kb + t - 7], sv);
+            if (ra == rb) sv += 1.f;
+            const unsigned long long pr = ((unsigned long long)(unsigned)a.seq << 32) | (unsigned long long)__float_as_uint(sv);
+            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(a.sx + (size_t)ra * (2 * NB) + rb), "v"(pr) : "memory");
+        }
+        __syncthreads();                                       // (T2 is rewritten by the next pair)
+    }
+    __syncthreads();                                           // (T2 is dead: S11 takes its place)
+    // collect: the lower triangle of the r real rows; four pairs in flight per thread and pass
+    const int ntri = r * (r + 1) / 2;
+    bool gave_up = false;
+    for (int e0 = tid * 4; e0 < ntri; e0 += CH_NTH * 4) {
+        int ra[4], rb[4]; unsigned long long pr[4]; bool have[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u < ntri ? e0 + u : ntri - 1;
+            int row_ = (int)((sqrtf(8.f * (float)e + 1.f) - 1.f) * 0.5f);
+            while (row_ * (row_ + 1) / 2 > e) --row_;
+            while ((row_ + 1) * (row_ + 2) / 2 <= e) ++row_;
+            ra[u] = row_; rb[u] = e - row_ * (row_ + 1) / 2; have[u] = false; pr[u] = 0;
+        }
+        for (int spin = 0; spin < (1 << 20); ++spin) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (!have[u]) asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1" : "=v"(pr[u]) : "v"(a.sx + (size_t)ra[u] * (2 * NB) + rb[u]) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bool all = true;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { have[u] = have[u] || (unsigned)(pr[u] >> 32) == (unsigned)a.seq; all = all && have[u]; }
+            if (all) break;
+            if (spin == (1 << 20) - 1) gave_up = true;
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (e0 + u >= ntri) continue;
+            const float v = __uint_as_float((unsigned)pr[u]);
+            if (ra[u] < NB) sm.Ls[ra[u]][rb[u]] = v;
+            else if (rb[u] < NB) sm.Bs[ra[u] - NB][rb[u]] = v;
+            else hf.two.S11[ra[u] - NB][rb[u] - NB] = v;
+        }
+    }
+    if (gave_up) atomicExch(status_wait, 1);
+    // what the triangle does not hold: zeros above the diagonals, S10's padding rows, S11's identity padding
+    for (int idx = tid; idx < NB * NB; idx += CH_NTH) {
+        const int i = idx >> 6, j = idx & 63;
+        if (j > i) { sm.Ls[i][j] = 0.f; hf.two.S11[i][j] = 0.f; }
+        if (NB + i >= r) { sm.Bs[i][j] = 0.f; if (j <= i) hf.two.S11[i][j] = i == j ? 1.f : 0.f; }
+    }
+    __syncthreads();
+}
+
 // PRE3_OPT_PEND_HI: x_k_k <- x_k_k + W~'(L^-1 nu) and update.m:42-46's normalisation (params[16..], [96..]) at the end of k_hi_fused itself -- the down-date
 // launch that used to carry this as its riders (update_x_block) is not sent.  Strip b owns the columns 64 (b - 1) ..: the entries of x it updates; L^-1 nu is
 // column ld, the last strip's, which raises a flag behind its stores (all workgroups of the launch are resident: 50 of them, one per CU).  The sums are
@@ -1382,40 +1468,43 @@ __global__ __launch_bounds__(CH_NTH) void k_hi_fused(HiFused a)
         const int wave = tid >> 6, lane = tid & 63, wv = wave & 3, w0 = (wv >> 1) * 32, w1 = (wv & 1) * 32;
         const int lrow = 4 * (lane >> 5), lcol = lane & 31;
         auto &Ls = sm.Ls; auto &Xs = sm.Xs; auto &Bs = sm.Bs;
-        hf_T_block<true>(hf, a, 0, NB, 0, HF_MAXL);
-        __syncthreads();
-        for (int idx = tid; idx < NB * NB; idx += CH_NTH) {
-            const int ra = idx >> 6, rb = idx & 63;
-            float s = 0.f;
-            if (rb <= ra) { s = hf_S_entry(hf, ra, rb, 0, 0); if (ra == rb) s += 1.f; }
-            Ls[ra][rb] = s;
-        }
-        __syncthreads();
-        hf_T_block<false>(hf, a, NB, r1, 0, HF_MAXL);
-        __syncthreads();
-        for (int idx = tid; idx < NB * NB; idx += CH_NTH) {            // Bs[i][k] = S10(i, k); padding rows are zero
-            const int i = idx >> 6, rb = idx & 63;
-            Bs[i][rb] = NB + i < r ? hf_S_entry(hf, NB + i, rb, NB, 0) : 0.f;
-        }
-        __syncthreads();
-        hf_T_block<true>(hf, a, NB, r1, HF_MAXL, cnt - HF_MAXL);
-        __syncthreads();
-        float s11[(NB * NB + CH_NTH - 1) / CH_NTH];                    // (S11 takes T's place: through registers, across a barrier)
-#pragma unroll
-        for (int q = 0; q < (NB * NB + CH_NTH - 1) / CH_NTH; ++q) {
-            const int idx = tid + q * CH_NTH, i = (idx >> 6) & 63, j = idx & 63;
-            float s = 0.f;
-            if (j <= i) {
-                if (NB + i < r) { s = hf_S_entry(hf, NB + i, NB + j, NB, NB); if (i == j) s += 1.f; }
-                else s = i == j ? 1.f : 0.f;
+        if (a.sx != nullptr) hf_S_dealt(hf, sm, a, b, cnt, a.stats + 7);
+        else {
+            hf_T_block<true>(hf, a, 0, NB, 0, HF_MAXL);
+            __syncthreads();
+            for (int idx = tid; idx < NB * NB; idx += CH_NTH) {
+                const int ra = idx >> 6, rb = idx & 63;
+                float s = 0.f;
+                if (rb <= ra) { s = hf_S_entry(hf, ra, rb, 0, 0); if (ra == rb) s += 1.f; }
+                Ls[ra][rb] = s;
             }
-            s11[q] = s;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < (NB * NB + CH_NTH - 1) / CH_NTH; ++q) {
-            const int idx = tid + q * CH_NTH;
-            if (idx < NB * NB) hf.two.S11[idx >> 6][idx & 63] = s11[q];
+            __syncthreads();
+            hf_T_block<false>(hf, a, NB, r1, 0, HF_MAXL);
+            __syncthreads();
+            for (int idx = tid; idx < NB * NB; idx += CH_NTH) {            // Bs[i][k] = S10(i, k); padding rows are zero
+                const int i = idx >> 6, rb = idx & 63;
+                Bs[i][rb] = NB + i < r ? hf_S_entry(hf, NB + i, rb, NB, 0) : 0.f;
+            }
+            __syncthreads();
+            hf_T_block<true>(hf, a, NB, r1, HF_MAXL, cnt - HF_MAXL);
+            __syncthreads();
+            float s11[(NB * NB + CH_NTH - 1) / CH_NTH];                    // (S11 takes T's place: through registers, across a barrier)
+    #pragma unroll
+            for (int q = 0; q < (NB * NB + CH_NTH - 1) / CH_NTH; ++q) {
+                const int idx = tid + q * CH_NTH, i = (idx >> 6) & 63, j = idx & 63;
+                float s = 0.f;
+                if (j <= i) {
+                    if (NB + i < r) { s = hf_S_entry(hf, NB + i, NB + j, NB, NB); if (i == j) s += 1.f; }
+                    else s = i == j ? 1.f : 0.f;
+                }
+                s11[q] = s;
+            }
+            __syncthreads();
+    #pragma unroll
+            for (int q = 0; q < (NB * NB + CH_NTH - 1) / CH_NTH; ++q) {
+                const int idx = tid + q * CH_NTH;
+                if (idx < NB * NB) hf.two.S11[idx >> 6][idx & 63] = s11[q];
+            }
         }
         if (hasX) { hf_own_block(hf, a, hf.two.H0, 0, r, c0); hf_own_block(hf, a, hf.two.H1, NB, r, c0); }
         for (int idx = tid; idx < NB * NB; idx += CH_NTH) Xs[idx >> 6][idx & 63] = (idx >> 6) == (idx & 63) ? 1.f : 0.f;
@@ -2560,6 +2649,8 @@ int launch_hi_fused(pre3_ctx *c, int32_t seq)
     a.P = (const float *)c->P; a.ld = c->ld; a.S = (float *)c->Smat; a.W = (float *)c->W; a.ldw = c->ldw;
     a.Wp = c->Wp; a.nst_total = c->rcap / B3_BK; a.Sp = c->Sp; a.sp_stride = c->rcap / NB; a.params = c->pred_params;
     a.max_l = hi_fused_max(c);
+    static const int deal_env = getenv("PRE3_HF_DEAL") ? atoi(getenv("PRE3_HF_DEAL")) : 1;      // 0: every workgroup builds all of S in the two-panel case too (round 5)
+    a.sx = deal_env ? c->hf_sx : nullptr;
     // PRE3_OPT_PEND_HI: W~ and its planes go to buffers of their own (the next LI update's strips overwrite W / Wp), the launch behind this one carries
     // the x-update only, and P - W~'W~ stays pending (pre3_update_hi learns the row count; pend_flush / launch_cholp end it)
     const bool pend = c->pend_opt && c->W_pend != nullptr && c->Wp_pend != nullptr && c->hf_xy != nullptr;

@@ -163,6 +163,22 @@ def test_two_panels_inside_the_launch_agree_with_the_general_path(pre3, tmp_path
         assert not np.array_equal(P1, P0)                            # (the two runs did take different paths)
 
 
+def test_s_dealt_over_the_workgroups_is_bit_identical_to_s_built_by_every_one(pre3, tmp_path):
+    """round 6, two panels: S = H P H' + I dealt over the launch's workgroups (hf_S_dealt: write-through (sequence, value) pairs) against every workgroup
+    building all of it (PRE3_HF_DEAL=0): the same fma chains entry by entry -- the same bits of x and P"""
+    if len(seq_rescued()) < 64:
+        pytest.skip("the sequence rescues fewer than 64 landmarks")
+    res = {}
+    for deal in ("1", "0"):
+        env = dict(os.environ, PRE3_HF_DEAL=deal)
+        base = str(tmp_path / ("deal" + deal))
+        r = subprocess.run([sys.executable, "-c", _WORKER % {"root": ROOT}, base], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[deal] = {k: (np.load(base + "_%d.npy" % k), np.load(base + "_x%d.npy" % k)) for k in (33, 48, 64)}
+    for k in (33, 48, 64):
+        assert np.array_equal(res["1"][k][0], res["0"][k][0]) and np.array_equal(res["1"][k][1], res["0"][k][1]), k
+
+
 def seq_rescued():
     import oracle as orc
     from oracle import np_twin as tw
