@@ -1078,6 +1078,7 @@ struct HiFused {
     const float *P; int ld; float *S; float *W; int ldw; void *Wp; int nst_total; void *Sp; int sp_stride;
     double *params;
     int max_l;                                    // landmarks this launch may update with: 64 (two panels) when the context's row capacity holds them, else 32
+    int deal_min = 1 << 30;                       // one panel: S dealt from this many landmarks on
     unsigned long long *sx = nullptr;             // two panels: S dealt over the workgroups -- [128][128] (sequence number, value) pairs (hf_S_dealt); nullptr: every workgroup builds all of S
     int n = 0; double *x = nullptr; unsigned *xflag = nullptr;      // PRE3_OPT_PEND_HI (xflag != nullptr): no launch follows this one -- the strips finish the state themselves (hf_x_update)
 };
@@ -1196,7 +1197,7 @@ static __device__ unsigned long long g_hf[16];                  // wall-clock st
 // (sequence number, value) pairs; then everybody collects the lower triangle with sc1 loads, re-reading what is not there yet (no fences, no counters:
 // round 5's form of this, with a release / acquire per workgroup, cost 10-11 us).  A small map has fewer workgroups than pairs: they take several, one after the other.  The same fma chains as hf_T_block / hf_S_entry: the same bits.
 // Leaves Ls = S00, Bs = S10 (padding rows zero), hf.two.S11 = S11 (identity padding), as the redundant form does.
-__device__ __forceinline__ void hf_S_dealt(HfSmem &hf, ChSmem<float> &sm, const HiFused &a, const int b, const int cnt, int32_t *status_wait)
+__device__ __forceinline__ void hf_S_dealt(HfSmem &hf, ChSmem<float> &sm, const HiFused &a, const int b, const int cnt, int32_t *status_wait, const bool two = true)
 {
     const int tid = threadIdx.x, r = 2 * cnt, G = gridDim.x;
     constexpr int TW = 7 + 6 * HF_MAXL2 + 1;                  // 392
@@ -1266,11 +1267,16 @@ __device__ __forceinline__ void hf_S_dealt(HfSmem &hf, ChSmem<float> &sm, const 
         }
     }
     if (gave_up) atomicExch(status_wait, 1);
-    // what the triangle does not hold: zeros above the diagonals, S10's padding rows, S11's identity padding
+    // what the triangle does not hold: zeros above the diagonals, S10's padding rows, S11's (one panel: S00's) identity padding
     for (int idx = tid; idx < NB * NB; idx += CH_NTH) {
         const int i = idx >> 6, j = idx & 63;
-        if (j > i) { sm.Ls[i][j] = 0.f; hf.two.S11[i][j] = 0.f; }
-        if (NB + i >= r) { sm.Bs[i][j] = 0.f; if (j <= i) hf.two.S11[i][j] = i == j ? 1.f : 0.f; }
+        if (two) {
+            if (j > i) { sm.Ls[i][j] = 0.f; hf.two.S11[i][j] = 0.f; }
+            if (NB + i >= r) { sm.Bs[i][j] = 0.f; if (j <= i) hf.two.S11[i][j] = i == j ? 1.f : 0.f; }
+        } else {
+            if (j > i) sm.Ls[i][j] = 0.f;
+            else if (i >= r) sm.Ls[i][j] = i == j ? 1.f : 0.f;
+        }
     }
     __syncthreads();
 }
@@ -1436,6 +1442,12 @@ __global__ __launch_bounds__(CH_NTH) void k_hi_fused(HiFused a)
     if (!two) {
         // ---- T = (H*P) at the columns of the selected rows, and this workgroup's own block of [H*P | nu]
         HF_STAMP(2);
+        if (a.sx != nullptr && cnt >= a.deal_min) {
+            // (round 6) S dealt over the workgroups, as in the two-panel case: from ~20 landmarks on it is cheaper than fifty copies of T
+            if (b >= 1) hf_own_block(hf, a, sm.Xs, 0, r, (b - 1) * NB);
+            hf_S_dealt(hf, sm, a, b, cnt, a.stats + 7, false);
+            HF_STAMP(3); HF_STAMP(4);
+        } else {
         hf_T_block<true>(hf, a, 0, r, 0, cnt);
         HF_STAMP(3);
         if (b >= 1) hf_own_block(hf, a, sm.Xs, 0, r, (b - 1) * NB);
@@ -1452,6 +1464,7 @@ __global__ __launch_bounds__(CH_NTH) void k_hi_fused(HiFused a)
             sm.Ls[ra][rb] = s;
         }
         __syncthreads();
+        }
         HF_STAMP(5);
         chol_panel_body<float, false, true, true>(sm, a.S, NB, a.W, a.ldw, 0, 1, a.stats + 6, b, nullptr, 0u, a.Wp, a.nst_total, a.ld, a.Sp, a.sp_stride, r);
         HF_STAMP(6);
@@ -2651,6 +2664,8 @@ int launch_hi_fused(pre3_ctx *c, int32_t seq)
     a.max_l = hi_fused_max(c);
     static const int deal_env = getenv("PRE3_HF_DEAL") ? atoi(getenv("PRE3_HF_DEAL")) : 1;      // 0: every workgroup builds all of S in the two-panel case too (round 5)
     a.sx = deal_env ? c->hf_sx : nullptr;
+    static const int deal_min = getenv("PRE3_HF_DEAL_MIN") ? atoi(getenv("PRE3_HF_DEAL_MIN")) : 18;      // measured, k_hi_fused at 4 .. 32 landmarks: dealt 14.4 14.7 15.7 16.3 17.0 17.5 19.1 us, every workgroup for itself 12.3 13.4 14.7 16.4 17.4 18.6 22.8
+    a.deal_min = deal_min;
     // PRE3_OPT_PEND_HI: W~ and its planes go to buffers of their own (the next LI update's strips overwrite W / Wp), the launch behind this one carries
     // the x-update only, and P - W~'W~ stays pending (pre3_update_hi learns the row count; pend_flush / launch_cholp end it)
     const bool pend = c->pend_opt && c->W_pend != nullptr && c->Wp_pend != nullptr && c->hf_xy != nullptr;
