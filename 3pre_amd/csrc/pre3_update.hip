@@ -2663,12 +2663,15 @@ int launch_hi_fused(pre3_ctx *c, int32_t seq)
     a.Wp = c->Wp; a.nst_total = c->rcap / B3_BK; a.Sp = c->Sp; a.sp_stride = c->rcap / NB; a.params = c->pred_params;
     a.max_l = hi_fused_max(c);
     static const int deal_env = getenv("PRE3_HF_DEAL") ? atoi(getenv("PRE3_HF_DEAL")) : 1;      // 0: every workgroup builds all of S in the two-panel case too (round 5)
-    a.sx = deal_env ? c->hf_sx : nullptr;
+    // (the dealt S and the pending form's state update make workgroups of this launch wait for one another: only when all of them are resident together --
+    //  one per CU: each declares more than half a CU's LDS)
+    const bool co_resident = 1 + c->ldw / NB <= c->num_cus;
+    a.sx = deal_env && co_resident ? c->hf_sx : nullptr;
     static const int deal_min = getenv("PRE3_HF_DEAL_MIN") ? atoi(getenv("PRE3_HF_DEAL_MIN")) : 18;      // measured, k_hi_fused at 4 .. 32 landmarks: dealt 14.4 14.7 15.7 16.3 17.0 17.5 19.1 us, every workgroup for itself 12.3 13.4 14.7 16.4 17.4 18.6 22.8
     a.deal_min = deal_min;
     // PRE3_OPT_PEND_HI: W~ and its planes go to buffers of their own (the next LI update's strips overwrite W / Wp), the launch behind this one carries
     // the x-update only, and P - W~'W~ stays pending (pre3_update_hi learns the row count; pend_flush / launch_cholp end it)
-    const bool pend = c->pend_opt && c->W_pend != nullptr && c->Wp_pend != nullptr && c->hf_xy != nullptr;
+    const bool pend = c->pend_opt && c->W_pend != nullptr && c->Wp_pend != nullptr && c->hf_xy != nullptr && co_resident;
     if (pend) { a.W = c->W_pend; a.Wp = c->Wp_pend; a.n = c->n; a.x = c->x_kk; a.xflag = c->hf_xy; }
     c->hi_pend_launched = pend;
     hipLaunchKernelGGL(k_hi_fused, dim3(1 + c->ldw / NB), dim3(CH_NTH), 0, c->stream, a);

@@ -28,6 +28,7 @@ VARIANTS = [
     {"PRE3_CHOL_EARLY": "0"},                               # the padded last panel runs all ten chain steps (the skipped ones change nothing)
     {"PRE3_CHOLP_PROJ": "0"},                               # the rescue stage's projection in the gate's blocks instead of on the persistent launch's strips behind their x-update
     {"PRE3_RIDE_POSE": "0"},                                # the prediction's projection riders wait for block 0 to publish the predicted pose instead of computing it themselves
+    {"PRE3_HF_DEAL": "0"},                                  # k_hi_fused: every workgroup builds all of S = H P H' + I instead of dealing its rows out from 18 rescued landmarks on (round 6)
     {"PRE3_HP_MB": "0"},                                    # H*P of the measured rows one measurement per workgroup (k_ell_HP_build) instead of four sharing the pose rows' loads (round 6)
     {"PRE3_GATE_RIDE": "0"},                                # the rescue stage's chi2 gate as a launch of its own behind the Jnorm pass instead of riding in it (round 5: GateRide recomputes the
                                                             # normalised rows / columns 3..6 it needs from the un-normalised rows the consumers leave behind -- the same bits)
