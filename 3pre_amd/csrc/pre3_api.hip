@@ -388,7 +388,7 @@ int pre3_create(pre3_ctx **out, int device, int dtype, int max_landmarks, int ma
         // (the buffers of the in-launch tail, PRE3_OPT_STEP_TAIL, are allocated when the option is switched on: tail_alloc -- at N = 2000 they are
         //  ~300 MB that the default path never touches)
         if (c->step_tail) A(tail_alloc(c));
-        { const char *e = getenv("PRE3_PEND_HI"); if (e && atoi(e) != 0 && c->rcap >= 2 * NB) { A(pend_alloc(c)); c->pend_opt = rc == PRE3_OK; } }      // PRE3_OPT_PEND_HI
+        { const char *e = getenv("PRE3_PEND_HI"); if (e && atoi(e) != 0 && c->rcap >= 2 * NB && c->rcap / NB <= CP_MAX_NRB + 1) { A(pend_alloc(c)); c->pend_opt = rc == PRE3_OK; } }      // PRE3_OPT_PEND_HI
         if (rc == PRE3_OK) { cholp_context_count(c->device, +1); c->cholp_counted = true; }
         const int nt = c->ld / 128, ns = ceil_div(nt, 4);
         std::vector<std::vector<int2>> lists(8);
@@ -493,7 +493,9 @@ int pre3_set_option(pre3_ctx *c, int option, int value)
         c->step_tail = value != 0;
         return PRE3_OK;
     case PRE3_OPT_PEND_HI:
-        if (value != 0 && c->dtype == PRE3_F32 && c->Wp != nullptr) { const int rc = pend_alloc(c); if (rc != PRE3_OK) { c->pend_opt = false; return rc; } }
+        // (contexts that cannot take the persistent launch at their capacity -- fp64, more than 16 panels of rows -- accept the option and stay without it: the
+        //  pending rows would only ever be flushed, and their planes mirror Wp's size)
+        if (value != 0 && c->dtype == PRE3_F32 && c->Wp != nullptr && c->rcap / NB <= CP_MAX_NRB + 1) { const int rc = pend_alloc(c); if (rc != PRE3_OK) { c->pend_opt = false; return rc; } }
         c->pend_opt = value != 0 && c->W_pend != nullptr;
         return PRE3_OK;
     default: set_error("pre3_set_option: unknown option %d", option); return PRE3_E_ARG;
