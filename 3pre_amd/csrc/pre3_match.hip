@@ -10,6 +10,7 @@
 //   * uint8 / int8 classes: distances are integers; d2 = |a|^2 + |b|^2 - 2 a.b is evaluated exactly in
 //     int32 on the matrix cores (v_mfma_i32_32x32x32_i8; uint8 is re-centred by -128, which leaves a-b
 //     unchanged) with the best/second-best scan fused into the epilogue.
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -868,6 +869,166 @@ __global__ __launch_bounds__(64 * RT_WAVES) void k_rank_tiled(int K1, int K2, in
     }
 }
 
+// ---- round 6: the same two phases with 128 queries per workgroup and the database slice staged through LDS --------------------------------------------
+// k_rank_tiled moves 2 MB of database planes into every one of its K1p / 64 query groups and 2 MB of query planes into every slice: 136 MB through the
+// L2 -> CU paths per phase at 4096 x 4096 (64 groups x 4 slices), which is what sets its time.  Here a workgroup owns TWO sets of four query blocks -- waves
+// 0-3 hold the fragments of queries 0..63 of the group, waves 4-7 those of 64..127 -- and every block of the slice is fetched ONCE (LDS-DMA, three-slot ring
+// of four blocks) and read from LDS by one wave of each half: 32 groups x 8 slices, 80 MB per phase.  Same MFMA chains per (query block, database block)
+// as k_rank_tiled: the same bounds, the same candidate sets.
+// *(measured, round 6)* 52.2 us per match against k_rank_tiled's 43.5 (unit-norm doubles), 47.3 against 40.0 (floats), with a three- or a four-slot ring alike:
+// the phases are NOT bound by operand delivery at this size -- both forms sit at three times their MFMA time, and the lock-step of eight waves per step
+// costs more than the halved traffic saves.  Kept as PRE3_MATCH_RANK_FORM=2 (bit-identical: tests/test_gpu_match_rank.py), not the default.
+constexpr int R2_Q = 128, R2_STEP = 4;                // queries per workgroup; database blocks per step (one per wave of a half)
+template <int PHASE>
+__global__ __launch_bounds__(64 * RT_WAVES) void k_rank_tiled2(int K1, int K2, int K2p, int nsl, const v4i *__restrict__ Qh, const v4i *__restrict__ Ql,
+                                                                 const v4i *__restrict__ Dh, const v4i *__restrict__ Dl, const float *__restrict__ nq,
+                                                                 const float *__restrict__ norms, float *__restrict__ pb, float *__restrict__ ps, int K1p,
+                                                                 int *__restrict__ gcnt, int *__restrict__ gcand)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char r2_smem[];
+    v4i *ring = reinterpret_cast<v4i *>(r2_smem);                            // [4 slots][plane 2][R2_STEP blocks][256] v4i = 4 x 32 KB
+    __shared__ float mb[RT_WAVES][RT_Q], ms[RT_WAVES][RT_Q];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, qi = lane & 15;
+    const int half = wave >> 2, wq = wave & 3;
+    const int qg = blockIdx.x, sl = blockIdx.y;
+    const int nblk = K2p / 16;
+    const int b0 = (int)((long long)nblk * sl / nsl), b1 = (int)((long long)nblk * (sl + 1) / nsl);
+    const int nstep = (b1 - b0 + R2_STEP - 1) / R2_STEP;
+    constexpr int SLOT = 2 * R2_STEP * 256;                                  // v4i per slot
+    // this thread's share of a step's 2048 granules: granule i = tid + 512 u (u < 4): plane i >> 10, the rest linear in the step's blocks
+    auto issue = [&](const int step, const int slot) {
+        const int blk0 = b0 + step * R2_STEP;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + 512 * u, pl = i >> 10, w = i & 1023;
+            int blk = blk0 + (w >> 8);
+            blk = blk < b1 ? blk : b1 - 1;                                   // (a short last step re-reads the slice's last block: never used)
+            const v4i *src = (pl ? Dl : Dh) + (size_t)blk * 256 + (w & 255);
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(ring + slot * SLOT + (i & ~63)), 16, 0, 0);
+        }
+    };
+    // the 128 queries' fragments (64 KB) go through slots 2 and 3 into registers; slots 0 and 1 take the first two steps meanwhile
+    if (nstep > 0) issue(0, 0);
+    if (nstep > 1) issue(1, 1);
+    {
+        v4i *qst = ring + 2 * SLOT;
+        for (int i = tid; i < 2 * RT_NQB * 256; i += 64 * RT_WAVES) {
+            qst[i] = Qh[(size_t)qg * 2 * RT_NQB * 256 + i]; qst[2 * RT_NQB * 256 + i] = Ql[(size_t)qg * 2 * RT_NQB * 256 + i];
+        }
+    }
+    __syncthreads();
+    v4i fqh[RT_NQB][4], fql[RT_NQB][4];
+    {
+        const v4i *qst = ring + 2 * SLOT;
+#pragma unroll
+        for (int t = 0; t < RT_NQB; ++t)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                fqh[t][s2] = qst[(half * RT_NQB + t) * 256 + 64 * s2 + lane];
+                fql[t][s2] = qst[2 * RT_NQB * 256 + (half * RT_NQB + t) * 256 + 64 * s2 + lane];
+            }
+    }
+    __syncthreads();                                                         // (slots 2 and 3 are free)
+    if (nstep > 2) issue(2, 2);
+    float thr[RT_NQB];
+    if (PHASE == 1) {
+#pragma unroll
+        for (int t = 0; t < RT_NQB; ++t) {
+            const int q = qg * R2_Q + half * RT_Q + 16 * t + qi;
+            float b = INFINITY, s2 = INFINITY;
+            for (int x = 0; x < nsl; ++x) {
+                const float ob = pb[(size_t)x * K1p + q], os = ps[(size_t)x * K1p + q];
+                s2 = fminf(fmaxf(b, ob), fminf(s2, os));
+                b = fminf(b, ob);
+            }
+            thr[t] = s2 + (float)(2.0 * RK_E) * (q < K1 ? nq[q] : 0.f);
+        }
+    } else if (sl == 0 && tid < R2_Q) gcnt[qg * R2_Q + tid] = 0;
+    float best[RT_NQB], second[RT_NQB];
+#pragma unroll
+    for (int t = 0; t < RT_NQB; ++t) best[t] = second[t] = INFINITY;
+    for (int step = 0; step < nstep; ++step) {
+        const int slot = step & 3;
+        // this step's granules have landed (the next two steps' four per thread each may still fly), everybody's: the slot of step - 1 is free for step + 3
+        if (step + 2 < nstep) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (step + 1 < nstep) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                  // (raw barrier: __syncthreads() would wait for the next steps' granules too)
+        __builtin_amdgcn_s_barrier();
+        if (step + 3 < nstep) issue(step + 3, (step + 3) & 3);
+        const int blk = b0 + step * R2_STEP + wq;
+        if (blk < b1) {
+            RtSet S;
+            const v4i *sh = ring + slot * SLOT + wq * 256 + lane, *sl2 = sh + R2_STEP * 256;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) { S.h[s2] = sh[64 * s2]; S.l[s2] = sl2[64 * s2]; }
+            S.n = *reinterpret_cast<const v4f *>(norms + blk * 16 + 4 * g);
+            v4f acc[RT_NQB];
+#pragma unroll
+            for (int t = 0; t < RT_NQB; ++t) acc[t] = v4f{ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+#pragma unroll
+                for (int t = 0; t < RT_NQB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, S.h[s2]), __builtin_bit_cast(bf16x8, fqh[t][s2]), acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < RT_NQB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, S.h[s2]), __builtin_bit_cast(bf16x8, fql[t][s2]), acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < RT_NQB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, S.l[s2]), __builtin_bit_cast(bf16x8, fqh[t][s2]), acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < RT_NQB; ++t) {
+                if (PHASE == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float u = fmaf(-2.f, acc[t][e], S.n[e]);
+                        second[t] = __builtin_amdgcn_fmed3f(best[t], u, second[t]);
+                        best[t] = fminf(best[t], u);
+                    }
+                } else {
+                    float lw[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) lw[e] = fmaf(-2.f, acc[t][e], S.n[e]);
+                    if (fminf(fminf(lw[0], lw[1]), fminf(lw[2], lw[3])) <= thr[t]) {
+                        const int q = qg * R2_Q + half * RT_Q + 16 * t + qi;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int idx = blk * 16 + 4 * g + e;
+                            if (lw[e] <= thr[t] && idx < K2 && q < K1) {
+                                const int p2 = atomicAdd(&gcnt[q], 1);
+                                if (p2 < RK_CAP) gcand[(size_t)q * RK_CAP + p2] = idx;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (PHASE == 0) {
+#pragma unroll
+        for (int t = 0; t < RT_NQB; ++t) {
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float ob = __shfl_xor(best[t], o, 64), os = __shfl_xor(second[t], o, 64);
+                second[t] = fminf(fmaxf(best[t], ob), fminf(second[t], os));
+                best[t] = fminf(best[t], ob);
+            }
+            if (g == 0) { mb[wave][16 * t + lane] = best[t]; ms[wave][16 * t + lane] = second[t]; }
+        }
+        __syncthreads();
+        if (tid < R2_Q) {
+            const int hf = tid >> 6, qq = tid & 63;
+            float b = mb[4 * hf][qq], s2 = ms[4 * hf][qq];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float ob = mb[4 * hf + w][qq], os = ms[4 * hf + w][qq];
+                s2 = fminf(fmaxf(b, ob), fminf(s2, os));
+                b = fminf(b, ob);
+            }
+            pb[(size_t)sl * K1p + qg * R2_Q + tid] = b; ps[(size_t)sl * K1p + qg * R2_Q + tid] = s2;
+        }
+    }
+}
+
 // one wave per query: the candidates of k_rank_tiled<1>, re-evaluated as the tail of k_match_rank does
 template <typename T>
 __global__ __launch_bounds__(256) void k_rank_tail(int ND, int K1, int K2, const T *__restrict__ L1, const T *__restrict__ L2, const int *__restrict__ gcnt,
@@ -1098,6 +1259,7 @@ struct RankMatch {
     int cls = 0, ND = 0, K1 = 0, K2 = 0, K1p = 0, K2p = 0, route = 0;     // route 0: exact kernels (data outside the bounds), 1: int8 MFMA, 2: bf16 rank + re-evaluation
     DevBuf L1, L2, qh, ql, dh, dl, nq, nqU, nqL, nU, nL, nd, fl, pb, ps, gcnt, gcand;
     int nsl = 1;                                                          // database slices of the tiled form (k_rank_tiled)
+    int nsl2 = 0;                                                         // ... of the LDS-staged form with 128 queries per workgroup (k_rank_tiled2); 0: that form does not apply
     I8Match m;                                                            // int8 operands + the outputs (ob, os, oa) of every route
 };
 static int float_form()
@@ -1131,8 +1293,10 @@ static int rank_prepare(RankMatch &r, int ND, int K1, const T *L1, int K2, const
         }
         const int groups = r.K1p / RT_Q, nblk = r.K2p / 16;
         r.nsl = std::max(1, std::min(std::min(ceil_div(ncu, groups), nblk / RT_WAVES), 64));
+        // (k_rank_tiled2: K1p / 128 groups, at least four steps of four blocks per slice)
+        r.nsl2 = (r.K1p % R2_Q == 0 && nblk >= 4 * R2_STEP) ? std::max(1, std::min(std::min(ceil_div(ncu, r.K1p / R2_Q), nblk / (4 * R2_STEP)), 64)) : 0;
     }
-    PRE3_TRY(r.pb.alloc(sizeof(float) * (size_t)r.nsl * r.K1p)); PRE3_TRY(r.ps.alloc(sizeof(float) * (size_t)r.nsl * r.K1p));
+    PRE3_TRY(r.pb.alloc(sizeof(float) * (size_t)std::max(r.nsl, r.nsl2) * r.K1p)); PRE3_TRY(r.ps.alloc(sizeof(float) * (size_t)std::max(r.nsl, r.nsl2) * r.K1p));
     PRE3_TRY(r.gcnt.alloc(sizeof(int) * r.K1p)); PRE3_TRY(r.gcand.alloc(sizeof(int) * (size_t)r.K1p * RK_CAP));
     PRE3_TRY(m.A.alloc((size_t)m.K1p * 128)); PRE3_TRY(m.B.alloc((size_t)m.K2p * 128));
     PRE3_TRY(m.na.alloc(sizeof(int) * m.K1p)); PRE3_TRY(m.nb.alloc(sizeof(int) * m.K2p));
@@ -1155,7 +1319,28 @@ static int rank_run(RankMatch &r, int k2_offset, hipStream_t st, bool count = fa
     if (r.route == 1) return i8_run(r.m, k2_offset, st);
     PRE3_CHECK(r.route == 2, PRE3_E_STATE, "float-class matcher: the data is outside the ranked path's bounds");
     const char *fe = getenv("PRE3_MATCH_RANK_FORM");                      // 1 (default): tiled both ways, three launches; 0: one launch, database streamed per 16 queries
-    if (!fe || atoi(fe) != 0) {
+    static const int form2_default = 0;                                      // (measured, 4096 x 4096 unit-norm doubles: form 2 52.2 us per match, form 1 43.5)
+    const int form = fe ? atoi(fe) : (form2_default ? 2 : 1);               // 2: 128 queries per workgroup, database staged through LDS (round 6); 1: k_rank_tiled; 0: k_match_rank
+    if (form == 2 && r.nsl2 > 0) {
+        static std::atomic<int> attr_ok{ 0 };
+        if (attr_ok.load() == 0) {
+            const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_rank_tiled2<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_rank_tiled2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            attr_ok.store(e0 == hipSuccess && e1 == hipSuccess ? 1 : -1);
+        }
+        if (attr_ok.load() == 1) {
+            dim3 g(r.K1p / R2_Q, r.nsl2), b(64 * RT_WAVES);
+            hipLaunchKernelGGL((k_rank_tiled2<0>), g, b, 128 * 1024, st, r.K1, r.K2, r.K2p, r.nsl2, (const v4i *)r.qh.p, (const v4i *)r.ql.p, (const v4i *)r.dh.p, (const v4i *)r.dl.p,
+                               (const float *)r.nq.p, (const float *)r.nU.p, (float *)r.pb.p, (float *)r.ps.p, r.K1p, (int *)r.gcnt.p, (int *)r.gcand.p);
+            hipLaunchKernelGGL((k_rank_tiled2<1>), g, b, 128 * 1024, st, r.K1, r.K2, r.K2p, r.nsl2, (const v4i *)r.qh.p, (const v4i *)r.ql.p, (const v4i *)r.dh.p, (const v4i *)r.dl.p,
+                               (const float *)r.nq.p, (const float *)r.nL.p, (float *)r.pb.p, (float *)r.ps.p, r.K1p, (int *)r.gcnt.p, (int *)r.gcand.p);
+            hipLaunchKernelGGL((k_rank_tail<T>), dim3(ceil_div(r.K1, 4)), dim3(256), 0, st, r.ND, r.K1, r.K2, (const T *)r.L1.p, (const T *)r.L2.p, (const int *)r.gcnt.p,
+                               (const int *)r.gcand.p, k2_offset, (double *)r.m.ob.p, (double *)r.m.os.p, (int32_t *)r.m.oa.p, count ? (int *)r.fl.p + 2 : nullptr);
+            PRE3_HIP(hipGetLastError());
+            return PRE3_OK;
+        }
+    }
+    if (form != 0) {
         dim3 g(r.K1p / RT_Q, r.nsl), b(64 * RT_WAVES);
         hipLaunchKernelGGL((k_rank_tiled<0>), g, b, 0, st, r.K1, r.K2, r.K2p, r.nsl, (const v4i *)r.qh.p, (const v4i *)r.ql.p, (const v4i *)r.dh.p, (const v4i *)r.dl.p,
                            (const float *)r.nq.p, (const float *)r.nU.p, (float *)r.pb.p, (float *)r.ps.p, r.K1p, (int *)r.gcnt.p, (int *)r.gcand.p);

@@ -186,7 +186,20 @@ def test_one_launch_and_tiled_forms_agree(pre3, orc, dt):
     L2[:, 100:300] = L1[:, :200] + (0.05 * rng.standard_normal((128, 200))).astype(dt)
     L2[:, 900] = L2[:, 100]
     mr, dr = orc.siftmatch(L1, L2, 1.4)
-    for form in (1, 0):
+    for form in (1, 0, 2):                     # (2, round 6: 128 queries per workgroup, the database slice staged through LDS -- measured slower, kept as an option)
         with _Form(form, "PRE3_MATCH_RANK_FORM"):
             m, d = pre3.siftmatch(L1, L2, 1.4, return_scores=True)
         assert np.array_equal(m, mr) and np.array_equal(d, dr), form
+
+
+def test_lds_staged_rank_form_at_full_size_is_bit_identical(pre3):
+    """4096 x 4096 x 128 unit-norm doubles (BASELINE configs[3]'s float class): PRE3_MATCH_RANK_FORM=2 against the default form"""
+    rng = np.random.default_rng(11)
+    L1 = rng.random((128, 4096)); L1 /= np.linalg.norm(L1, axis=0)
+    L2 = rng.random((128, 4096)); L2 /= np.linalg.norm(L2, axis=0)
+    L2[:, 7] = L1[:, 1234]
+    res = []
+    for form in (1, 2):
+        with _Form(form, "PRE3_MATCH_RANK_FORM"):
+            res.append(pre3.siftmatch(L1, L2, 1.5, return_scores=True))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
