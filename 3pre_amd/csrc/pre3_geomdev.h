@@ -278,14 +278,24 @@ __device__ __forceinline__ void innovation_body(int N, const int32_t *__restrict
     }
     if (pend_rows > 0 && active) {
         // P is P - W~'W~ (PendW): S_i -= g g', g(c, k) = H_i(c, :) W~(k, :)'; lane b takes the rows k = b (mod 16), its share leaves with the sums below
+        double hc0[7], hc1[7], hl0[6], hl1[6];                        // (the landmark's rows once, not per pending row)
+#pragma unroll
+        for (int a = 0; a < 7; ++a) { hc0[a] = Hc[14 * ii + a]; hc1[a] = Hc[14 * ii + 7 + a]; }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { hl0[a] = a < d ? Hl[12 * ii + a] : 0.0; hl1[a] = a < d ? Hl[12 * ii + 6 + a] : 0.0; }
         for (int k = b; k < pend_rows; k += 16) {
             const float *wr = pend_W + (size_t)k * pend_ldw;
+            float wp[7], wl[6];
+#pragma unroll
+            for (int a = 0; a < 7; ++a) wp[a] = wr[a];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) wl[a] = a < d ? wr[off + a] : 0.f;
             double g0 = 0, g1 = 0;
 #pragma unroll
-            for (int a = 0; a < 7; ++a) { const double w = (double)wr[a]; g0 += Hc[14 * ii + a] * w; g1 += Hc[14 * ii + 7 + a] * w; }
+            for (int a = 0; a < 7; ++a) { const double w = (double)wp[a]; g0 += hc0[a] * w; g1 += hc1[a] * w; }
 #pragma unroll
             for (int a = 0; a < 6; ++a)
-                if (a < d) { const double w = (double)wr[off + a]; g0 += Hl[12 * ii + a] * w; g1 += Hl[12 * ii + 6 + a] * w; }
+                if (a < d) { const double w = (double)wl[a]; g0 += hl0[a] * w; g1 += hl1[a] * w; }
             s00 -= g0 * g0; s01 -= g0 * g1; s10 -= g1 * g0; s11 -= g1 * g1;
         }
     }
