@@ -2647,7 +2647,7 @@ int pend_flush(pre3_ctx *c)
     hipLaunchKernelGGL(k_downdate_b3, dim3(c->n_tiles128), dim3(256), 0, c->stream, (float *)c->P, c->ld, (const bf16x8_t *)c->Wp_pend, c->rcap / B3_BK, rows > NB ? 8 : 4,
                        (const float *)c->W_pend, c->ldw, (const int2 *)c->tiles128, xu, pr);
     PRE3_HIP(hipGetLastError());
-    c->hp_all_valid = false;
+    // (H*P / S_i built while the rows were pending were built for P - W~'W~: they stay valid)
     return PRE3_OK;
 }
 

@@ -80,3 +80,27 @@ def test_small_maps_and_steps_without_li_rows(pre3):
     a = _run(pre3, seq, N, n_hyp, True)
     b = _run(pre3, seq, N, n_hyp, False)
     _close(a, b, "no-li")
+
+
+@pytest.mark.parametrize("variant", [{}, {"PRE3_K9_OVERLAP": "0"}, {"PRE3_DD_MAX": "3"}, {"PRE3_HI_FUSED": "0"}, {"PRE3_GATE_RIDE": "0"}, {"PRE3_RIDE_INNOV": "0"},
+                                     {"PRE3_HP_MB": "0"}, {"PRE3_CHOL_FORM": "0"}, {"PRE3_FUSE_JN": "0"}, {"TAIL": "1"}])
+def test_launch_structures_that_cannot_take_the_pending_rows_flush_them(tmp_path, variant):
+    """PRE3_PEND_HI=1 under the launch-structure switches of tests/test_gpu_variants.py: wherever a launch cannot take the pending rows along (the down-date as its own
+    launch, too few consumer groups in the persistent launch, the launch-per-panel form, the stand-alone S_i pass, the one-measurement H*P kernel, the in-launch tail, the
+    Jnorm pass as its own launch, the general HI path) the flush must run first.  The worker's sequences (a frame without LI rows, map management behind the steps) against
+    the default form: statistics and flags identical, fp64 states equal to the bit (no pending form there), fp32 states to rounding."""
+    import numpy as np
+    from test_gpu_variants import _run
+    v = dict(variant)
+    tail = v.pop("TAIL", "0")
+    a, b = str(tmp_path / "pend.npz"), str(tmp_path / "ref.npz")
+    ra = _run(dict(v, PRE3_PEND_HI="1"), tail=tail, dump=a)
+    rb = _run({}, tail="0", dump=b)
+    assert ra["FLAGS"] == rb["FLAGS"], variant
+    da, db = np.load(a), np.load(b)
+    for k in da.files:
+        if k.endswith("f64"):
+            assert np.array_equal(da[k], db[k]), (variant, k)
+        else:
+            tol = 3e-4 * np.abs(db[k]).max() if k.startswith("P") else 2e-5
+            assert np.abs(da[k] - db[k]).max() < tol, (variant, k, np.abs(da[k] - db[k]).max())
